@@ -1,0 +1,96 @@
+"""Pin the CPU oracle against every golden vector captured from the reference (CPU-only test).
+
+Tolerances: the oracle runs the same fp32 arithmetic through torch-CPU, but deduplicates redundant
+reference work (matmul instead of the [B,B,F] broadcast, single encoder pass, O(BF) spectral form), so
+results agree to fp32 rounding, not bitwise: metrics rel 2e-5, gradients / parameters rel-L2 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fixture_io import Case, cases, summary, rel_l2
+from oracle import make_oracle
+from oracle.agents import gather_batch
+
+OPT_TAG = {'critic_optimizer': 'critic', 'actor_optimizer': 'actor', 'log_alpha_optimizer': 'alpha',
+           'feature_optimizer': 'feature', 'phi_optimizer': 'phi', 'nablamu_net_optimizer': 'nablamu'}
+
+
+def run_oracle(c, dtype=torch.float32, check_grads=True):
+    torch.set_num_threads(1)
+    o = make_oracle(c.alg, c.S, c.A, c.init, dtype=dtype, **c.kw)
+    worst = dict(info=0.0, grad=0.0)
+    for t, tr in enumerate(c.trains):
+        batches = [gather_batch(c.replay, i, dtype) for i in tr['idx']]
+        noise = [torch.as_tensor(e) if e.dtype.kind == 'i' else torch.as_tensor(e).to(dtype) for e in tr['eps']]
+        info = o.train(batches, noise)
+        for k, v in tr['info'].items():
+            err = abs(info[k] - v) / max(abs(v), 1e-3)
+            worst['info'] = max(worst['info'], err)
+            assert err < 5e-5, (c.name, t, k, info[k], v)
+        if check_grads:
+            # only the LAST step of each optimizer within a train() is still held by the oracle
+            for optkey, gd in tr['grads'].items():
+                opt, j = optkey.split('#')
+                nsteps = 1 + max(int(k.split('#')[1]) for k in tr['grads'] if k.startswith(opt + '#'))
+                if int(j) != nsteps - 1 or OPT_TAG[opt] not in o.last_grads:
+                    continue
+                for pname, g in gd.items():
+                    mine = o.last_grads[OPT_TAG[opt]].get(pname)
+                    assert mine is not None, (c.name, optkey, pname)
+                    if c.full:
+                        err = rel_l2(mine.numpy(), g)
+                    else:
+                        s = summary(mine.numpy())
+                        err = abs(s[0] - g[0]) / max(g[0], 1e-12)
+                        err = max(err, rel_l2(s[2:], g[2:]))
+                    worst['grad'] = max(worst['grad'], err)
+                    assert err < 1e-4, (c.name, t, optkey, pname, err)
+    return o, worst
+
+
+@pytest.mark.parametrize('name', cases())
+def test_oracle_matches_reference(name):
+    c = Case(name)
+    o, worst = run_oracle(c)
+    P = o.state()
+    werr = 0.0
+    for k, v in c.final.items():
+        if k not in P:
+            continue
+        mine = P[k].numpy()
+        if c.full:
+            err = rel_l2(mine, v)
+        else:
+            s = summary(mine)
+            err = max(abs(s[0] - v[0]) / max(v[0], 1e-12), rel_l2(s[2:], v[2:]))
+        werr = max(werr, err)
+        assert err < 2e-5, (name, k, err)
+    print(f'{name}: worst info {worst["info"]:.2e} grad {worst["grad"]:.2e} final-param {werr:.2e}')
+
+
+def test_oracle_quirks():
+    """Reference quirks the oracle must reproduce."""
+    c = Case('vlsac_tiny')
+    o, _ = run_oracle(c, check_grads=False)
+    P = o.state()
+    # Q2: l6 never receives a gradient -> unchanged, and no Adam state
+    assert np.array_equal(P['critic.l6.weight'].numpy(), c.init['critic.l6.weight'])
+    assert 'critic.l6.weight' not in o.opt_critic.state
+    # Q1: log_alpha stays float64
+    assert P['log_alpha'].dtype == torch.float64
+    c = Case('diffsrsac_tiny')
+    o, _ = run_oracle(c, check_grads=False)
+    P = o.state()
+    # Q11: diffsrsac critic never trains
+    for k in P:
+        if k.startswith('critic.'):
+            assert np.array_equal(P[k].numpy(), c.init[k]), k
+    c = Case('ctrlsac_tiny')
+    o, _ = run_oracle(c, check_grads=False)
+    P = o.state()
+    # Q8: both frozen copies equal the live phi after train()
+    for k in P:
+        if k.startswith('phi.'):
+            assert np.array_equal(P[k].numpy(), P['frozen_phi' + k[3:]].numpy())
+            assert np.array_equal(P[k].numpy(), P['frozen_phi_target' + k[3:]].numpy())
