@@ -1,0 +1,230 @@
+/*
+ * rlrep.h -- C ABI of librlrep_hip.so: the MI355X-native (gfx950) update hot path of rl-rep.
+ *
+ * The reference (haotiansun14/rl-rep) has NO FFI/operator layer: its boundary for this path is the
+ * Python class API of the agents.  Each entry point below therefore names the reference method it
+ * replaces (paths relative to the reference repository root):
+ *
+ *   rlrep_agent_create        <- SACAgent.__init__        agent/sac/sac_agent.py:19-81
+ *                                VLSACAgent.__init__      agent/vlsac/vlsac_agent.py:71-123
+ *                                CTRLSACAgent.__init__    agent/ctrlsac/ctrlsac_agent.py:127-210
+ *                                SPEDERSACAgent.__init__  agent/spedersac/spedersac_agent.py:102-179
+ *                                DIFFSRSACAgent.__init__  agent/diffsrsac/diffsrsac_agent.py:95-176
+ *   rlrep_feature_step        <- feature_step             vlsac_agent.py:126-162, ctrlsac_agent.py:213-251,
+ *                                                         spedersac_agent.py:181-219;
+ *                                critic_feeder_feature_step  diffsrsac_agent.py:271-318
+ *                                (+ update_feature_target: vlsac :240-242, ctrlsac :253-255, speder :221-223)
+ *   rlrep_critic_step         <- critic_step              sac_agent.py:105-135 and per-agent overrides
+ *   rlrep_actor_alpha_step    <- update_actor_and_alpha   sac_agent.py:138-166 and per-agent overrides
+ *   rlrep_update_target       <- update_target            sac_agent.py:99-102
+ *   rlrep_train               <- train                    sac_agent.py:169-188, vlsac_agent.py:245-273, ...
+ *   rlrep_set_batch           <- Batch / unpack_batch     utils/buffer.py:7-10, utils/util.py:10-11
+ *   rlrep_replay_add/_sample  <- ReplayBuffer.add/.sample utils/buffer.py:28-48
+ *   rlrep_actor_forward       <- SACAgent.select_action   sac_agent.py:89-96
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is a DEVICE pointer owned by the caller (e.g. a torch
+ *     tensor's data_ptr()); the library never allocates or frees device memory on the hot path
+ *     (it uploads small task tables into the caller-provided workspace at create time);
+ *   - all tensors are contiguous row-major fp32 unless stated; nn.Linear weights are [out,in];
+ *   - every call is ASYNCHRONOUS and stream-ordered on `stream` (a hipStream_t passed as void*);
+ *     no call synchronises the device; calls on one agent are not thread-safe;
+ *   - return value: 0 on success, negative rlrep_status otherwise; rlrep_last_error() gives text.
+ */
+#ifndef RLREP_H
+#define RLREP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLREP_ABI_VERSION 1
+
+typedef enum {
+    RLREP_OK = 0,
+    RLREP_ERR_ARG = -1,        /* bad argument / unsupported dimension */
+    RLREP_ERR_HIP = -2,        /* a HIP runtime call failed */
+    RLREP_ERR_STATE = -3,      /* call order violated (e.g. step before set_batch) */
+    RLREP_ERR_NOMEM = -4       /* caller-provided workspace too small */
+} rlrep_status;
+
+typedef enum {
+    RLREP_ALG_SAC = 0,
+    RLREP_ALG_VLSAC = 1,
+    RLREP_ALG_CTRLSAC = 2,
+    RLREP_ALG_SPEDERSAC = 3,
+    RLREP_ALG_DIFFSRSAC = 4
+} rlrep_alg;
+
+/* Network dimensions (mirrors the reference constructors' dimension kwargs). */
+typedef struct {
+    int32_t alg;               /* rlrep_alg */
+    int32_t state_dim;         /* S */
+    int32_t action_dim;        /* A */
+    int32_t hidden_dim;        /* critic hidden (sac/vlsac/ctrlsac `hidden_dim`, speder `critic_and_actor_hidden_dim`) */
+    int32_t actor_hidden_dim;  /* actor trunk hidden (sac/vlsac: hidden_dim; ctrlsac: 256; speder: critic_and_actor_hidden_dim) */
+    int32_t feature_dim;       /* F */
+    int32_t vae_hidden_dim;    /* vlsac Encoder/Decoder/GaussianFeature hidden (reference default 256) */
+    int32_t phi_hidden_dim;    /* ctrlsac hidden_dim / speder phi_hidden_dim / diffsr phi_hidden_dim */
+    int32_t phi_hidden_depth;  /* speder, diffsr (ctrlsac: 2 fixed) */
+    int32_t mu_hidden_dim;     /* ctrlsac hidden_dim / speder mu_hidden_dim / diffsr nabla_mu_hidden_dim */
+    int32_t mu_hidden_depth;   /* speder, diffsr (ctrlsac: 2 fixed) */
+    int32_t num_noise;         /* vlsac critic noise rows (20) / diffsr num_noises (1000) */
+    int32_t max_batch;         /* largest batch size this agent will be stepped with */
+    int32_t reserved[3];
+} rlrep_dims;
+
+/* Hyper-parameters (mirrors the reference constructors' scalar kwargs). */
+typedef struct {
+    float lr_feature;          /* feature optimizer(s) */
+    float lr_critic;
+    float lr_actor;            /* actor and log_alpha optimizers */
+    float discount;
+    float tau;                 /* critic target Polyak rate */
+    float feature_tau;         /* feature target Polyak rate */
+    float target_entropy;      /* -action_dim */
+    float sigma_scale;         /* diffsr sigma_scale_factor */
+    int32_t target_update_period;
+    int32_t extra_feature_steps;
+    int32_t learn_alpha;       /* auto_entropy_tuning */
+    int32_t world_size;        /* data-parallel replicas: local losses are scaled by 1/(B*world_size) */
+    float beta1, beta2, adam_eps;
+    float reserved[1];
+} rlrep_hyper;
+
+/* One named tensor inside an arena (what nn.Parameter views / state_dict() are built from). */
+typedef struct {
+    char name[72];             /* reference state_dict key, e.g. "encoder.mean_linear.weight" */
+    int32_t arena;             /* rlrep_arena */
+    int32_t group;             /* optimizer group: 0 feature, 1 critic, 2 actor, 3 feature2 (diffsr nabla-mu), -1 none */
+    int64_t offset;            /* in floats from the arena base */
+    int32_t rows, cols;        /* bias: rows=n, cols=1 */
+} rlrep_tensor_desc;
+
+typedef enum {
+    RLREP_ARENA_PARAM = 0,     /* trainable parameters            (fp32) */
+    RLREP_ARENA_TARGET = 1,    /* target / frozen copies + vlsac noise + diffsr alphabars (fp32) */
+    RLREP_ARENA_COUNT = 2
+} rlrep_arena;
+
+/* Sizes the caller must allocate (floats unless stated). grad/exp_avg/exp_avg_sq arenas have the
+ * PARAM arena's size and layout (+ RLREP_GRAD_TAIL floats of cross-rank-reducible partial sums at the
+ * end of the grad arena). */
+typedef struct {
+    int64_t param_floats;
+    int64_t target_floats;
+    int64_t grad_floats;       /* = param_floats + RLREP_GRAD_TAIL */
+    int64_t workspace_bytes;   /* activations, batch slots, task tables, metric partials */
+    int64_t group_offset[4];   /* start of each optimizer group inside the PARAM arena (floats) */
+    int64_t group_floats[4];
+    int32_t n_tensors;
+    int32_t n_metrics;
+} rlrep_layout_info;
+
+#define RLREP_GRAD_TAIL 256
+
+/* Device pointers handed over at create time; they must outlive the agent. */
+typedef struct {
+    float* param_dev;
+    float* target_dev;
+    float* grad_dev;
+    float* exp_avg_dev;
+    float* exp_avg_sq_dev;
+    void* workspace_dev;
+    double* alpha_state_dev;   /* 4 doubles: log_alpha, exp_avg, exp_avg_sq, step   (quirk Q1: float64) */
+} rlrep_arenas;
+
+/* A minibatch as five separate device arrays (utils/buffer.py:7-10 field order). */
+typedef struct {
+    const float* state_dev;       /* [B,S] */
+    const float* action_dev;      /* [B,A] */
+    const float* reward_dev;      /* [B,1] */
+    const float* next_state_dev;  /* [B,S] */
+    const float* done_dev;        /* [B,1] */
+    int32_t batch;
+} rlrep_batch;
+
+typedef struct rlrep_agent rlrep_agent;
+
+/* ---- introspection ------------------------------------------------------------------------ */
+int32_t rlrep_abi_version(void);
+const char* rlrep_last_error(void);
+
+/* Layout of every tensor of algorithm dims->alg.  `descs` may be NULL to query counts only. */
+int32_t rlrep_layout(const rlrep_dims* dims, rlrep_layout_info* info, rlrep_tensor_desc* descs, int32_t cap);
+
+/* Names of the metrics slots written by the step programs (reference dict keys). */
+int32_t rlrep_metric_names(int32_t alg, char (*names)[32], int32_t cap);
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, const rlrep_arenas* arenas,
+                           void* stream, rlrep_agent** out);
+void rlrep_agent_destroy(rlrep_agent* agent);
+
+/* ---- data: minibatch slots ---------------------------------------------------------------- */
+/* slot 0 = the batch used by feature/critic/actor steps; slot 1 = spedersac's second ("random") batch. */
+int32_t rlrep_set_batch(rlrep_agent* agent, int32_t slot, const rlrep_batch* batch, void* stream);
+
+/* Device-resident replay ring: rows of [s | a | s' | r | d] (row length 2S+A+2 floats). */
+int32_t rlrep_replay_row_floats(const rlrep_dims* dims);
+int32_t rlrep_replay_add(rlrep_agent* agent, float* ring_dev, int64_t capacity, int64_t ptr,
+                         const float* row_host, void* stream);
+/* gather rows idx_dev[0..batch) of the ring into a batch slot */
+int32_t rlrep_replay_sample(rlrep_agent* agent, int32_t slot, const float* ring_dev, const int32_t* idx_dev,
+                            int32_t batch, void* stream);
+/* Philox4x32-10 fills: uniform indices in [0,hi) and N(0,1) noise (counter-based, replayable). */
+int32_t rlrep_fill_indices(int32_t* dst_dev, int64_t n, int32_t hi, uint64_t seed, uint64_t offset, void* stream);
+int32_t rlrep_fill_normal(float* dst_dev, int64_t n, float std, uint64_t seed, uint64_t offset, void* stream);
+
+/* Graph-replay-safe variants: the Philox offset is `offset + *counter_dev` and the index range is `*hi_dev`,
+ * both read on the device at execution time (rlrep_steps_dev() is the agent's train() counter). */
+int32_t rlrep_fill_indices_dev(int32_t* dst_dev, int64_t n, const int32_t* hi_dev, uint64_t seed, uint64_t offset,
+                               const int32_t* counter_dev, void* stream);
+int32_t rlrep_fill_normal_dev(float* dst_dev, int64_t n, float std, uint64_t seed, uint64_t offset,
+                              const int32_t* counter_dev, void* stream);
+const int32_t* rlrep_steps_dev(rlrep_agent* agent);
+
+/* ---- step programs ------------------------------------------------------------------------ */
+/* eps pointers: caller-provided standard-normal noise (parity runs inject the oracle's tensors).
+ *   vlsac feature: eps[B,F];  diffsr feature: noise_idx int32[B] + eps[B,S] (already scaled by sigma);
+ *   critic/actor: eps[B,A].                                                                        */
+int32_t rlrep_feature_step(rlrep_agent* agent, const float* eps_dev, const int32_t* noise_idx_dev, void* stream);
+int32_t rlrep_critic_step(rlrep_agent* agent, const float* eps_dev, void* stream);
+int32_t rlrep_actor_alpha_step(rlrep_agent* agent, const float* eps_dev, void* stream);
+/* Polyak critic -> critic_target iff (steps % target_update_period == 0), steps kept on the device. */
+int32_t rlrep_update_target(rlrep_agent* agent, void* stream);
+/* steps += 1 (device counter; graph-replay safe) */
+int32_t rlrep_begin_train(rlrep_agent* agent, void* stream);
+
+/* Split entry points for data-parallel training: backward part writes the group's gradient arena
+ * (caller all-reduces grad_dev[group_offset .. +group_floats (+tail)] over RCCL), apply part runs
+ * Adam / Polyak / temperature update.  rlrep_*_step == backward immediately followed by apply. */
+int32_t rlrep_feature_backward(rlrep_agent* agent, const float* eps_dev, const int32_t* noise_idx_dev, void* stream);
+int32_t rlrep_feature_apply(rlrep_agent* agent, void* stream);
+int32_t rlrep_critic_backward(rlrep_agent* agent, const float* eps_dev, void* stream);
+int32_t rlrep_critic_apply(rlrep_agent* agent, void* stream);
+int32_t rlrep_actor_backward(rlrep_agent* agent, const float* eps_dev, void* stream);
+int32_t rlrep_actor_apply(rlrep_agent* agent, void* stream);
+
+/* ctrlsac: frozen_phi, frozen_phi_target <- phi (ctrlsac_agent.py:344-346). No-op for other agents. */
+int32_t rlrep_sync_frozen(rlrep_agent* agent, void* stream);
+
+/* ---- inference ---------------------------------------------------------------------------- */
+/* action[n,A] = tanh(mu + eps*std) (eps_dev != NULL) or tanh(mu) (NULL), clamped to [lo,hi]. */
+int32_t rlrep_actor_forward(rlrep_agent* agent, const float* obs_dev, int32_t n, const float* eps_dev,
+                            float lo, float hi, float* action_dev, void* stream);
+
+/* ---- metrics ------------------------------------------------------------------------------ */
+/* device float array of n_metrics slots, valid after the stream has passed the producing step */
+const float* rlrep_metrics_dev(rlrep_agent* agent);
+
+/* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
+int32_t rlrep_last_launch_count(rlrep_agent* agent);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLREP_H */

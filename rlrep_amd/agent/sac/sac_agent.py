@@ -1,0 +1,309 @@
+"""SACAgent with the reference's call surface (agent/sac/sac_agent.py:15-188) on the HIP step programs.
+
+`train(buffer, batch_size)`, `critic_step(batch)`, `update_actor_and_alpha(batch)`, `update_target()`,
+`select_action(state, explore)` and the constructor kwargs are the reference's; the arithmetic runs in
+librlrep_hip.so (rlrep_amd/csrc).  Subclasses (vlsac, ctrlsac, spedersac, diffsrsac) only describe their
+dimensions, hyper-parameters, feature-step noise and parameter initialisation.
+"""
+import os
+import zlib
+import numpy as np
+import torch
+from torch import nn
+
+from rlrep_amd.core import HipCore
+from rlrep_amd.utils import util
+
+device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+class ArenaModule(nn.Module):
+    """nn.Module shell whose parameters are views into the agent's flat device arenas, registered under
+    the reference's names, so `state_dict()` / `load_state_dict()` / `parameters()` keep working."""
+
+    def __init__(self, core, prefix):
+        super().__init__()
+        self._core_ref = [core]
+        for name in core.order:
+            if not name.startswith(prefix + '.') or name.endswith('.noise'):
+                continue
+            parts = name[len(prefix) + 1:].split('.')
+            mod = self
+            for p in parts[:-1]:
+                if not hasattr(mod, p):
+                    mod.add_module(p, nn.Module())
+                mod = getattr(mod, p)
+            mod.register_parameter(parts[-1], nn.Parameter(core.view(name), requires_grad=False))
+
+
+def _world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+    except Exception:
+        pass
+    return 1, 0
+
+
+class SACAgent(object):
+    ALG = 'sac'
+    MODULES = ('critic', 'critic_target', 'actor')
+    FEATURE_KEYS = ()
+    CRITIC_KEYS = ('q_loss', 'q1', 'q2')
+    ACTOR_KEYS = ('actor_loss', 'alpha_loss', 'alpha')
+
+    def __init__(self, state_dim, action_dim, action_space, lr=3e-4, discount=0.99, target_update_period=2,
+                 tau=0.005, alpha=0.1, auto_entropy_tuning=True, hidden_dim=1024, **_hip):
+        self._init_common(state_dim, action_dim, action_space, discount, target_update_period, tau, alpha,
+                          auto_entropy_tuning)
+        self._dims = dict(state_dim=state_dim, action_dim=action_dim, hidden_dim=hidden_dim,
+                          actor_hidden_dim=hidden_dim)
+        self._hyper = dict(lr_feature=lr, lr_critic=lr, lr_actor=lr)
+        self._finish_init(_hip)
+
+    # ---- construction -------------------------------------------------------------------------
+    def _init_common(self, state_dim, action_dim, action_space, discount, target_update_period, tau, alpha,
+                     auto_entropy_tuning):
+        self.steps = 0
+        self.device = device
+        self.state_dim, self.action_dim = int(state_dim), int(action_dim)
+        self.action_range = [float(action_space.low.min()), float(action_space.high.max())]
+        self.discount, self.tau = float(discount), float(tau)
+        self.target_update_period = int(target_update_period)
+        self.learnable_temperature = bool(auto_entropy_tuning)
+        self.target_entropy = -action_dim
+        self._alpha0 = float(alpha)
+        self.extra_feature_steps = 0
+        self.feature_tau = 0.0
+
+    def _finish_init(self, hip_kwargs):
+        self.max_batch = int(hip_kwargs.get('max_batch', os.environ.get('RLREP_MAX_BATCH', 256)))
+        self.world_size, self.rank = _world()
+        dims = dict(feature_dim=0, vae_hidden_dim=0, phi_hidden_dim=0, phi_hidden_depth=0, mu_hidden_dim=0,
+                    mu_hidden_depth=0, num_noise=0, max_batch=self.max_batch)
+        dims.update(self._dims)
+        hyper = dict(discount=self.discount, tau=self.tau, feature_tau=float(self.feature_tau),
+                     target_entropy=float(self.target_entropy), sigma_scale=0.0,
+                     target_update_period=self.target_update_period,
+                     extra_feature_steps=int(self.extra_feature_steps), learn_alpha=int(self.learnable_temperature))
+        hyper.update({k: float(v) for k, v in self._hyper.items()})
+        self.core = HipCore(self.ALG, dims, hyper, world_size=self.world_size)
+        self.core.alpha_state[0] = float(np.log(self._alpha0))      # quirk Q1: float64 log_alpha
+        self._init_parameters()
+        if self.world_size > 1:
+            import torch.distributed as dist
+            for t in (self.core.params, self.core.targets, self.core.alpha_state):
+                dist.broadcast(t, src=0)
+        for m in self.MODULES:
+            setattr(self, m, ArenaModule(self.core, m))
+        self._seed = int(hip_kwargs.get('seed', torch.initial_seed() & 0x7fffffff)) + 7919 * self.rank
+        self._ctr = 0
+        self._bufs = {}
+        self._graph = None
+        self._inject = None
+        self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
+
+    # parameter initialisation (values only; layout is the library's)
+    def _orth(self, name, gain=1.0):
+        w = self.core.view(name)
+        cpu = torch.empty(w.shape)
+        nn.init.orthogonal_(cpu, gain)
+        w.copy_(cpu)
+
+    def _default_linear(self, wname, bname):
+        """nn.Linear default init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias."""
+        w = self.core.view(wname)
+        bound = 1.0 / np.sqrt(w.shape[1])
+        w.copy_(torch.empty(w.shape).uniform_(-bound, bound))
+        b = self.core.view(bname)
+        b.copy_(torch.empty(b.shape).uniform_(-bound, bound))
+
+    def _init_prefix(self, prefix, orthogonal):
+        for n in self.core.order:
+            if n.startswith(prefix + '.') and n.endswith('.weight'):
+                if orthogonal:
+                    self._orth(n)
+                    self.core.view(n[:-6] + 'bias').zero_()
+                else:
+                    self._default_linear(n, n[:-6] + 'bias')
+
+    def _copy_prefix(self, src, dst):
+        for n in self.core.order:
+            if n.startswith(src + '.') and not n.endswith('noise'):
+                self.core.view(dst + n[len(src):]).copy_(self.core.view(n))
+
+    def _init_parameters(self):
+        # utils/util.py:61-66 via .apply(weight_init) in DoubleQCritic / DiagGaussianActor
+        self._init_prefix('critic', True)
+        self._copy_prefix('critic', 'critic_target')            # sac_agent.py:58
+        self._init_prefix('actor', True)
+
+    # ---- reference surface --------------------------------------------------------------------
+    @property
+    def alpha(self):
+        return self.core.alpha_state[0].exp()
+
+    @property
+    def log_alpha(self):
+        return self.core.alpha_state[0]
+
+    def select_action(self, state, explore=False):
+        obs = torch.as_tensor(np.asarray(state, dtype=np.float32)).reshape(1, -1).to(self.core.device)
+        eps = self._noise('sel', (1, self.action_dim)) if explore else None
+        action = self.core.actor_forward(obs, eps, *self.action_range)
+        assert action.ndim == 2 and action.shape[0] == 1
+        return util.to_np(action[0])
+
+    def update_target(self):
+        self.core.update_target()
+
+    def critic_step(self, batch, eps=None):
+        self._set_batch(batch)
+        self.core.critic_step(self._noise('crit', (self._B, self.action_dim)) if eps is None else eps)
+        return self.core.info(self.CRITIC_KEYS)
+
+    def update_actor_and_alpha(self, batch, eps=None):
+        self._set_batch(batch)
+        self.core.actor_step(self._noise('act', (self._B, self.action_dim)) if eps is None else eps)
+        return self.core.info(self.ACTOR_KEYS)
+
+    def train(self, buffer, batch_size):
+        """One train step (sac_agent.py:169-188)."""
+        self.steps += 1
+        if self.use_graph and self.world_size == 1:
+            return self._train_graph(buffer, batch_size)
+        return self._train_eager(buffer, batch_size)
+
+    update = train      # BASELINE.json's north_star calls it agent.update()
+
+    # ---- internals ----------------------------------------------------------------------------
+    def _set_batch(self, batch, slot=0):
+        self._B = int(batch.state.shape[0])
+        self.core.set_batch(slot, batch.state, batch.action, batch.reward, batch.next_state, batch.done)
+
+    def _buf(self, key, shape, dtype=torch.float32):
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.core.device)
+        return t
+
+    def _noise(self, key, shape, std=1.0):
+        t = self._buf('eps_' + key, shape)
+        self._ctr += 1
+        self.core.fill_normal(t, std, self._seed, self._ctr << 20)
+        return t
+
+    def _indices(self, key, n, hi):
+        t = self._buf('idx_' + key, (n,), torch.int32)
+        self._ctr += 1
+        self.core.fill_indices(t, hi, self._seed, self._ctr << 20)
+        return t
+
+    def _feature_iters(self):
+        return 0
+
+    def _feature_once(self, buffer, B, i, g):
+        raise NotImplementedError
+
+    def _allreduce(self, group, with_tail=False):
+        import torch.distributed as dist
+        lay = self.core.layout
+        o, n = lay.group_offset[group], lay.group_floats[group]
+        end = lay.grad_floats if with_tail else o + n
+        dist.all_reduce(self.core.grads[o:end])
+
+    def _sample_into(self, buffer, B, key, slot=0, g=False):
+        if self._inject is not None:
+            idx = torch.as_tensor(np.asarray(self._inject['idx'].pop(0)), dtype=torch.int32).to(self.core.device)
+            self._bufs['idx_' + key] = idx
+        elif g:
+            idx = self._buf('idx_' + key, (B,), torch.int32)
+            self.core.fill_indices_dev(idx, buffer.size_dev(), self._seed, self._graph_off(key))
+        else:
+            idx = self._indices(key, B, buffer.size)
+        self.core.sample(slot, buffer.ring, idx, B)
+
+    def _graph_off(self, key):
+        # distinct Philox streams per noise tensor inside one train(): offset = (hash << 32) + device step counter
+        return (zlib.crc32(key.encode()) % 65521 + 1) << 32
+
+    def _eps(self, key, shape, g=False, std=1.0):
+        if self._inject is not None:
+            e = self._inject['eps'].pop(0)
+            t = torch.as_tensor(np.asarray(e)).to(self.core.device)
+            t = t.to(torch.int32) if t.dtype in (torch.int64, torch.int32) else t.to(torch.float32)
+            assert tuple(t.shape) == tuple(shape), (key, t.shape, shape)
+            self._bufs['eps_' + key] = t.contiguous()
+            return self._bufs['eps_' + key]
+        if g:
+            t = self._buf('eps_' + key, shape)
+            self.core.fill_normal_dev(t, std, self._seed, self._graph_off(key))
+            return t
+        return self._noise(key, shape, std)
+
+    def _body(self, buffer, B, g):
+        """The whole train() as a sequence of stream-ordered library calls (captured into a hipGraph when g)."""
+        c, W = self.core, self.world_size
+        c.begin_train()
+        nf = self._feature_iters()
+        for i in range(nf):
+            self._feature_once(buffer, B, i, g)
+        if nf == 0:
+            self._sample_into(buffer, B, 's0', 0, g)
+        self._between_feature_and_critic()
+        e1 = self._eps('crit', (B, self.action_dim), g)
+        if W > 1:
+            if self._critic_trains():
+                c.critic_backward(e1); self._allreduce(1); c.critic_apply()
+            else:
+                c.critic_step(e1)
+        else:
+            c.critic_step(e1)
+        e2 = self._eps('act', (B, self.action_dim), g)
+        if W > 1:
+            c.actor_backward(e2); self._allreduce(2, True); c.actor_apply()
+        else:
+            c.actor_step(e2)
+        c.update_target()
+
+    def _critic_trains(self):
+        return True
+
+    def _between_feature_and_critic(self):
+        pass
+
+    def train_injected(self, buffer, batch_size, idx, eps):
+        """train() with caller-supplied sample indices and noise tensors, consumed in the reference's draw
+        order.  Used by the parity tests and smoke(): 'fixed seeds' parity is
+        injected-noise parity, the torch/NumPy generators cannot be reproduced on the device."""
+        self.steps += 1
+        buffer.flush()
+        self._inject = dict(idx=list(idx), eps=list(eps))
+        try:
+            self._body(buffer, batch_size, False)
+        finally:
+            self._inject = None
+        return self.core.info()
+
+    def _train_eager(self, buffer, B):
+        buffer.flush()
+        self._body(buffer, B, False)
+        return self.core.info()
+
+    def _train_graph(self, buffer, B):
+        buffer.flush()
+        buffer.size_dev()
+        key = (id(buffer), B)
+        if self._graph is None or self._graph_key != key:
+            # size the library's tables for B outside the capture (it re-uploads them with blocking copies
+            # when the batch size changes), then capture the whole train() into one hipGraph
+            self._sample_into(buffer, B, 'warm', 0, False)
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._body(buffer, B, True)
+            self._graph, self._graph_key = g, key
+        self._graph.replay()
+        return self.core.info()

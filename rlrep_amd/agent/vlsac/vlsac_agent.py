@@ -1,0 +1,68 @@
+"""VLSACAgent (reference agent/vlsac/vlsac_agent.py:67-273) on the HIP step programs.
+
+feature_step = VAE ELBO (encoder/decoder/f) + Adam + Polyak f->f_target in one step program
+(csrc/engine.hip build_vlsac); critic = noise-averaged RFF critic (csrc/noisecritic.hip).
+"""
+import torch
+
+from rlrep_amd.agent.sac.sac_agent import SACAgent, device  # noqa: F401
+
+NUM_NOISE = 20            # vlsac_agent.py:24 (Critic num_noise default)
+VAE_HIDDEN = 256          # networks/vae.py:24,70,101 (ctor defaults; the agent never overrides them)
+
+
+class VLSACAgent(SACAgent):
+    ALG = 'vlsac'
+    MODULES = ('critic', 'critic_target', 'actor', 'encoder', 'decoder', 'f', 'f_target')
+    FEATURE_KEYS = ('vae_loss', 'ml_loss', 'kl_loss', 's_loss', 'r_loss')
+    CRITIC_KEYS = ('q1_loss', 'q2_loss', 'q1', 'q2')
+
+    def __init__(self, state_dim, action_dim, action_space, lr=1e-4, discount=0.99, target_update_period=2,
+                 tau=0.005, alpha=0.1, auto_entropy_tuning=True, hidden_dim=256, feature_tau=0.001,
+                 feature_dim=256, use_feature_target=True, extra_feature_steps=1, **_hip):
+        if not use_feature_target:
+            raise NotImplementedError('use_feature_target=False is not built (main.py never sets it)')
+        self._init_common(state_dim, action_dim, action_space, discount, target_update_period, tau, alpha,
+                          auto_entropy_tuning)
+        self.feature_dim = int(feature_dim)
+        self.feature_tau = float(feature_tau)
+        self.use_feature_target = True
+        self.extra_feature_steps = int(extra_feature_steps)
+        self._dims = dict(state_dim=state_dim, action_dim=action_dim, hidden_dim=hidden_dim, actor_hidden_dim=hidden_dim,
+                          feature_dim=feature_dim, vae_hidden_dim=int(_hip.pop('vae_hidden_dim', VAE_HIDDEN)),
+                          num_noise=NUM_NOISE)
+        self._hyper = dict(lr_feature=lr, lr_critic=lr, lr_actor=lr)
+        self._finish_init(_hip)
+
+    def _init_parameters(self):
+        self._init_prefix('actor', True)                         # DiagGaussianActor.apply(weight_init)
+        for m in ('encoder', 'decoder', 'f', 'critic'):          # plain nn.Linear defaults
+            self._init_prefix(m, False)
+        self._copy_prefix('f', 'f_target')                       # vlsac_agent.py:113-114 deepcopy
+        self._copy_prefix('critic', 'critic_target')             # vlsac_agent.py:121 deepcopy (noise shared, Q3)
+        self.core.view('critic.noise').copy_(torch.randn(NUM_NOISE, self.feature_dim))
+
+    # ---- reference surface --------------------------------------------------------------------
+    def feature_step(self, batch, eps=None):
+        """vlsac_agent.py:126-162 (+ update_feature_target :240-242, fused into the optimizer launch)."""
+        self._set_batch(batch)
+        self.core.feature_step(self._noise('feat', (self._B, self.feature_dim)) if eps is None else eps)
+        return self.core.info(self.FEATURE_KEYS)
+
+    def update_feature_target(self):
+        """Polyak f -> f_target happens inside feature_step's optimizer launch (same values as calling it
+        right after, which is the only way the reference uses it: vlsac_agent.py:252-258)."""
+        return None
+
+    # ---- train() body ---------------------------------------------------------------------------
+    def _feature_iters(self):
+        return self.extra_feature_steps + 1
+
+    def _feature_once(self, buffer, B, i, g):
+        c = self.core
+        self._sample_into(buffer, B, f'f{i}', 0, g)
+        eps = self._eps(f'feat{i}', (B, self.feature_dim), g)
+        if self.world_size > 1:
+            c.feature_backward(eps); self._allreduce(0); c.feature_apply()
+        else:
+            c.feature_step(eps)

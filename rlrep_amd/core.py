@@ -1,0 +1,236 @@
+"""HipCore: owns the device arenas of one agent and drives the step programs of librlrep_hip.so.
+
+torch is used for what the C ABI asks the caller to provide -- device memory (arenas, workspace, noise
+and index buffers), the current HIP stream -- and nothing else: no torch op runs on the update path.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+METRIC_SLOTS = 16
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class LazyInfo(dict):
+    """The dict `train()` returns.  The reference calls `.item()` 4-25 times per train() (SURVEY quirk
+    Q14), each a device sync; here the metric slots are snapshotted on the device and only fetched when a
+    value is actually read (main.py reads `info` once per 5000 steps)."""
+
+    def __init__(self, names, snapshot):
+        super().__init__()
+        self._names, self._snap, self._done = names, snapshot, False
+        for n in names:
+            if n:
+                dict.__setitem__(self, n, None)
+
+    def _fetch(self):
+        if not self._done:
+            vals = self._snap.cpu().numpy()
+            for i, n in enumerate(self._names):
+                if n:
+                    dict.__setitem__(self, n, float(vals[i]))
+            self._done = True
+
+    def __getitem__(self, k):
+        self._fetch()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._fetch()
+        return dict.get(self, k, d)
+
+    def items(self):
+        self._fetch()
+        return dict.items(self)
+
+    def values(self):
+        self._fetch()
+        return dict.values(self)
+
+    def __repr__(self):
+        self._fetch()
+        return dict.__repr__(self)
+
+
+class HipCore:
+    def __init__(self, alg, dims, hyper, device=None, world_size=1):
+        if not torch.cuda.is_available():
+            raise RuntimeError('rlrep_amd needs an MI355X (no CPU fallback): torch.cuda.is_available() is False')
+        self.alg = alg
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.dims = _lib.Dims()
+        self.dims.alg = _lib.ALG[alg]
+        for k, v in dims.items():
+            setattr(self.dims, k, int(v))
+        self.hyper = _lib.Hyper()
+        for k, v in hyper.items():
+            setattr(self.hyper, k, v)
+        self.hyper.world_size = int(world_size)
+        self.hyper.beta1, self.hyper.beta2, self.hyper.adam_eps = 0.9, 0.999, 1e-8
+        info = _lib.LayoutInfo()
+        check(lib.rlrep_layout(C.byref(self.dims), C.byref(info), None, 0), 'layout')
+        descs = (_lib.TensorDesc * info.n_tensors)()
+        check(lib.rlrep_layout(C.byref(self.dims), C.byref(info), descs, info.n_tensors), 'layout')
+        self.layout = info
+        self.descs = {d.name.decode(): (d.arena, d.group, d.offset, d.rows, d.cols) for d in descs}
+        self.order = [d.name.decode() for d in descs]
+        dev = self.device
+        self.params = torch.zeros(info.param_floats, dtype=torch.float32, device=dev)
+        self.targets = torch.zeros(info.target_floats, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(info.grad_floats, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(info.param_floats, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(info.param_floats, dtype=torch.float32, device=dev)
+        self.workspace = torch.zeros(info.workspace_bytes, dtype=torch.uint8, device=dev)
+        self.alpha_state = torch.zeros(4, dtype=torch.float64, device=dev)     # log_alpha, m, v, step
+        self.alpha_state[0] = float(np.log(0.1))
+        ar = _lib.Arenas(self.params.data_ptr(), self.targets.data_ptr(), self.grads.data_ptr(),
+                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.workspace.data_ptr(),
+                         self.alpha_state.data_ptr())
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(lib.rlrep_agent_create(C.byref(self.dims), C.byref(self.hyper), C.byref(ar), _stream(), C.byref(h)), 'agent_create')
+        self.h = h
+        names = (C.c_char * 32 * METRIC_SLOTS)()
+        lib.rlrep_metric_names(self.dims.alg, C.cast(names, C.c_void_p), METRIC_SLOTS)
+        self.metric_names = [bytes(n).split(b'\0', 1)[0].decode() for n in names]
+        mp = lib.rlrep_metrics_dev(self.h)
+        self._metrics_ptr = mp
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                torch.cuda.synchronize()
+                lib.rlrep_agent_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- named tensors -----------------------------------------------------------------------
+    def view(self, name, which='param'):
+        arena, group, off, rows, cols = self.descs[name]
+        base = {'param': self.params if arena == _lib.ARENA_PARAM else self.targets,
+                'grad': self.grads, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}[which]
+        if which != 'param' and arena != _lib.ARENA_PARAM:
+            raise KeyError(f'{name} is not trainable')
+        t = base[off:off + rows * cols]
+        return t.view(rows, cols) if (cols > 1 or name.endswith('weight') or name.endswith('noise')) else t.view(rows)
+
+    def group_slice(self, group, with_tail=False):
+        o, n = self.layout.group_offset[group], self.layout.group_floats[group]
+        return self.grads[o:o + n]
+
+    def grad_tail(self):
+        return self.grads[self.layout.param_floats:self.layout.param_floats + _lib.GRAD_TAIL]
+
+    def load_state(self, sd):
+        """sd: name -> array/tensor with the reference's state_dict keys (+ 'log_alpha', 'critic.noise')."""
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k == 'log_alpha':
+                    self.alpha_state[0] = float(np.asarray(v))
+                    continue
+                if k not in self.descs:
+                    continue
+                dst = self.view(k)
+                dst.copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(dst.shape))
+
+    def state(self):
+        out = {k: self.view(k).detach().cpu().clone() for k in self.order}
+        out['log_alpha'] = self.alpha_state[0].detach().cpu().clone()
+        return out
+
+    # ---- data ---------------------------------------------------------------------------------
+    def set_batch(self, slot, state, action, reward, next_state, done):
+        B = int(state.shape[0])
+        ts = [t.to(self.device, torch.float32).contiguous() for t in (state, action, reward, next_state, done)]
+        self._keep = ts
+        b = _lib.Batch(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), ts[4].data_ptr(), B)
+        check(lib.rlrep_set_batch(self.h, slot, C.byref(b), _stream()), 'set_batch')
+
+    def sample(self, slot, ring, idx, batch):
+        check(lib.rlrep_replay_sample(self.h, slot, _ptr(ring), _ptr(idx), int(batch), _stream()), 'replay_sample')
+
+    # ---- steps --------------------------------------------------------------------------------
+    def begin_train(self):
+        check(lib.rlrep_begin_train(self.h, _stream()), 'begin_train')
+
+    def feature_step(self, eps=None, noise_idx=None):
+        check(lib.rlrep_feature_step(self.h, _ptr(eps), _ptr(noise_idx), _stream()), 'feature_step')
+
+    def feature_backward(self, eps=None, noise_idx=None):
+        check(lib.rlrep_feature_backward(self.h, _ptr(eps), _ptr(noise_idx), _stream()), 'feature_backward')
+
+    def feature_apply(self):
+        check(lib.rlrep_feature_apply(self.h, _stream()), 'feature_apply')
+
+    def critic_step(self, eps):
+        check(lib.rlrep_critic_step(self.h, _ptr(eps), _stream()), 'critic_step')
+
+    def critic_backward(self, eps):
+        check(lib.rlrep_critic_backward(self.h, _ptr(eps), _stream()), 'critic_backward')
+
+    def critic_apply(self):
+        check(lib.rlrep_critic_apply(self.h, _stream()), 'critic_apply')
+
+    def actor_step(self, eps):
+        check(lib.rlrep_actor_alpha_step(self.h, _ptr(eps), _stream()), 'actor_alpha_step')
+
+    def actor_backward(self, eps):
+        check(lib.rlrep_actor_backward(self.h, _ptr(eps), _stream()), 'actor_backward')
+
+    def actor_apply(self):
+        check(lib.rlrep_actor_apply(self.h, _stream()), 'actor_apply')
+
+    def update_target(self):
+        check(lib.rlrep_update_target(self.h, _stream()), 'update_target')
+
+    def sync_frozen(self):
+        check(lib.rlrep_sync_frozen(self.h, _stream()), 'sync_frozen')
+
+    def actor_forward(self, obs, eps, lo, hi):
+        n = int(obs.shape[0])
+        out = torch.empty(n, self.dims.action_dim, dtype=torch.float32, device=self.device)
+        check(lib.rlrep_actor_forward(self.h, _ptr(obs), n, _ptr(eps), float(lo), float(hi), _ptr(out), _stream()), 'actor_forward')
+        return out
+
+    # ---- noise --------------------------------------------------------------------------------
+    def fill_normal(self, t, std, seed, offset):
+        check(lib.rlrep_fill_normal(_ptr(t), t.numel(), float(std), int(seed), int(offset), _stream()), 'fill_normal')
+
+    def fill_indices(self, t, hi, seed, offset):
+        check(lib.rlrep_fill_indices(_ptr(t), t.numel(), int(hi), int(seed), int(offset), _stream()), 'fill_indices')
+
+    def fill_normal_dev(self, t, std, seed, offset):
+        check(lib.rlrep_fill_normal_dev(_ptr(t), t.numel(), float(std), int(seed), int(offset),
+                                        C.c_void_p(lib.rlrep_steps_dev(self.h)), _stream()), 'fill_normal_dev')
+
+    def fill_indices_dev(self, t, hi_dev, seed, offset):
+        check(lib.rlrep_fill_indices_dev(_ptr(t), t.numel(), _ptr(hi_dev), int(seed), int(offset),
+                                         C.c_void_p(lib.rlrep_steps_dev(self.h)), _stream()), 'fill_indices_dev')
+
+    # ---- metrics ------------------------------------------------------------------------------
+    def metrics_tensor(self):
+        """A float32[16] torch view of the library's metric slots (no copy)."""
+        if not hasattr(self, '_mt'):
+            off = self._metrics_ptr - self.workspace.data_ptr()
+            self._mt = self.workspace[off:off + 4 * METRIC_SLOTS].view(torch.float32)
+        return self._mt
+
+    def info(self, keys=None):
+        snap = self.metrics_tensor().clone()
+        names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]
+        return LazyInfo(names, snap)
+
+    def launch_count(self):
+        return lib.rlrep_last_launch_count(self.h)

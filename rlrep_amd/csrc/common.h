@@ -1,0 +1,100 @@
+// Shared device/host definitions for librlrep_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RL_WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// activation / epilogue codes
+// ------------------------------------------------------------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIN = 3, ACT_TANH = 4 };
+
+// operand loaders of the tile GEMM (see gemm16.hip)
+enum Load : int {
+    LD_ROW = 0,     // element(i, kk) = P[(base+i)*ld + kk]           (inner index contiguous)
+    LD_COL = 1,     // element(i, kk) = P[kk*ld + base+i]              (inner index is the row)
+    LD_NCG = 2,     // vlsac noise critic, virtual dPre: GH[b, base+i]/N * elu'(U[kk, base+i]),  b = kk / N
+    LD_NCX = 3      // vlsac noise critic, virtual input: mean[b,c] + exp(clamp(lstd[b,c])) * noise[kk % N, c]
+};
+
+// epilogues
+enum Epi : int {
+    EPI_FWD = 0,        // C = act(acc + bias[c]); ACT_SIN also stores the pre-activation to out2
+    EPI_DX = 1,         // C (=|+=) acc * act'(aux[r,c])
+    EPI_DX_REPARAM = 2, // vlsac: C[r,c] += acc ; C[r,c+F] += acc * aux3[r,c]  (aux3 = eps*exp(l)*clamp-mask)
+    EPI_DW = 3,         // C = acc (weight gradient), bias gradient = column sums of operand A
+    EPI_DX_TANHOUT = 4  // reserved
+};
+
+#define FLAG_ACCUM 1       // C += value instead of C = value
+#define FLAG_BIASGRAD 2    // EPI_DW: also emit the bias gradient (only by column-tile 0)
+
+struct GemmTask {
+    const float* A;      // operand A (output rows)
+    const float* B;      // operand B (output cols)
+    float* C;
+    const float* bias;   // EPI_FWD: bias[Cn];  EPI_DW: unused
+    const float* aux;    // EPI_DX: saved activation (or pre-activation for sin);  LD_NCG: GH
+    const float* aux2;   // LD_NCX: log-std
+    const float* aux3;   // EPI_DX_REPARAM: eps*exp(l)*mask;  LD_NCX: mean
+    float* out2;         // EPI_FWD+ACT_SIN: pre-activation; EPI_DW: bias gradient
+    int lda, ldb, ldc, ldaux, ldaux2, ldaux3, ldout2;
+    int R, Cn, K;        // output R x Cn, inner length K
+    int tiles_c, tile_base, ntiles;
+    int epi, act, flags;
+    int ncN;             // noise rows (20) for LD_NCG/LD_NCX
+    int F;               // EPI_DX_REPARAM: column offset of the log-std half
+    float scale;         // multiplies acc before the epilogue (1.0 default)
+};
+
+// ------------------------------------------------------------------------------------------------
+// elementwise task (Adam / Polyak)
+// ------------------------------------------------------------------------------------------------
+struct AdamTask {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    float lr, beta1, beta2, eps;
+    const int* step;            // device step counter (already incremented for this step)
+    // optional Polyak of a sub-range [pol_off, pol_off+pol_n) of p into target
+    float* target; long long pol_off, pol_n; float tau;
+};
+
+struct PolyakTask {
+    const float* src; float* dst; long long n; float tau;
+    const int* steps; int period;     // if steps != nullptr: only when *steps % period == 0
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float clamp_lstd(float x) { return fminf(fmaxf(x, -20.f), 2.f); }
+__device__ __forceinline__ float lstd_mask(float x) { return (x >= -20.f && x <= 2.f) ? 1.f : 0.f; }
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+// derivative of ELU expressed through its OUTPUT y (in-place ELU in the reference, utils/util.py:89-91)
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ float softplus_f(float u) {   // torch F.softplus, beta=1, threshold=20
+    return u > 20.f ? u : log1pf(expf(u));
+}
+
+// block-wide sum for 256-thread blocks; result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* sh /* >= 4 floats */) {
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}

@@ -1,0 +1,424 @@
+// Elementwise, reduction and optimizer kernels of the update path (gfx950).
+// All of them are HBM/L2-latency bound at batch 256: one pass, coalesced, wave-shuffle reductions,
+// deterministic per-block partial sums (no float atomics) that the optimizer launch finalises.
+#include "common.h"
+#include "kparams.h"
+
+// ------------------------------------------------------------------------------------------------
+// minibatch slot fill: replay-ring gather (idx) or five separate arrays (reference Batch fields)
+// reference: utils/buffer.py:39-48 (sample), utils/util.py:10-11 (unpack_batch)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_slot_kernel(SlotFill p) {
+    const int row_w = 2 * p.S + p.A + 2;
+    const long long total = (long long)p.B * row_w;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / row_w), c = (int)(e - (long long)b * row_w);
+        float v;
+        if (p.ring) {
+            v = p.ring[(size_t)p.idx[b] * row_w + c];
+        } else {
+            if (c < p.S) v = p.s[(size_t)b * p.S + c];
+            else if (c < p.S + p.A) v = p.a[(size_t)b * p.A + (c - p.S)];
+            else if (c < 2 * p.S + p.A) v = p.s2[(size_t)b * p.S + (c - p.S - p.A)];
+            else if (c == 2 * p.S + p.A) v = p.r[b];
+            else v = p.d[b];
+        }
+        const int SA = p.S + p.A;
+        if (c < p.S) {
+            p.XE[(size_t)b * (SA + p.S) + c] = v;
+            p.XF[(size_t)b * SA + c] = v;
+            p.XFpi[(size_t)b * SA + c] = v;
+        } else if (c < SA) {
+            p.XE[(size_t)b * (SA + p.S) + c] = v;
+            p.XF[(size_t)b * SA + c] = v;
+        } else if (c < SA + p.S) {
+            p.XE[(size_t)b * (SA + p.S) + c] = v;
+            p.XF2[(size_t)b * SA + (c - SA)] = v;
+        } else if (c == SA + p.S) {
+            p.R[b] = v;
+        } else {
+            p.D[b] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011): counter-based, replayable under hipGraph (counter from device)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void philox_fill_kernel(PhiloxFill p) {
+    const unsigned long long step = p.step_dev ? (unsigned long long)(*p.step_dev) : 0ull;
+    const unsigned long long off = p.offset + step;
+    const int hi = p.hi_dev ? *p.hi_dev : p.hi;
+    const long long nq = (p.n + 3) / 4;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)off, (uint32_t)(off >> 32) ^ p.stream_id};
+        philox4x32_10(c, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+        float out[4];
+        if (p.kind == 0) {          // standard normal * std, Box-Muller on two pairs
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                const float rad = sqrtf(-2.0f * logf(u1));
+                float sn, cs;
+                sincosf(6.283185307179586f * u2, &sn, &cs);
+                out[2 * h] = rad * cs * p.std;
+                out[2 * h + 1] = rad * sn * p.std;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long e = q * 4 + s;
+            if (e >= p.n) break;
+            if (p.kind == 0) p.dst_f[e] = out[s];
+            else p.dst_i[e] = (int)(((unsigned long long)c[s] * (unsigned long long)hi) >> 32);   // uniform in [0,hi)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tanh-squashed Gaussian policy head  (agent/sac/actor.py:76-91, 16-60)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void policy_fwd_kernel(PolicyFwd p) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= p.B) return;
+    const float* o = p.O + (size_t)b * 2 * p.A;
+    float lp = 0.f;
+    for (int j = 0; j < p.A; ++j) {
+        const float mu = o[j];
+        const float t = tanhf(o[p.A + j]);
+        const float l = -5.f + 3.5f * (t + 1.f);
+        const float sg = expf(l);
+        const float e = p.eps ? p.eps[(size_t)b * p.A + j] : 0.f;
+        const float x = mu + e * sg;
+        const float y = tanhf(x);
+        p.act[(size_t)b * p.ld_act + j] = p.clamp ? fminf(fmaxf(y, p.lo), p.hi) : y;
+        lp += -0.5f * e * e - l - 0.91893853320467274f - 2.f * (0.69314718055994531f - x - softplus_f(-2.f * x));
+    }
+    if (p.logp) p.logp[b] = lp;
+}
+
+// gradient of the actor loss w.r.t. the trunk output [mu | rho]; h = dL/d(action) from the critic path
+__global__ __launch_bounds__(256) void policy_bwd_kernel(PolicyBwd p) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= p.B) return;
+    const float g = (float)exp(p.alpha_state[0]) * p.inv_batch;      // dL/dlogpi = alpha / B
+    const float* o = p.O + (size_t)b * 2 * p.A;
+    for (int j = 0; j < p.A; ++j) {
+        const float t = tanhf(o[p.A + j]);
+        const float l = -5.f + 3.5f * (t + 1.f);
+        const float sg = expf(l);
+        const float e = p.eps[(size_t)b * p.A + j];
+        const float y = p.act[(size_t)b * p.ld_act + j];
+        const float h = p.dA[(size_t)b * p.ld_dA + j] * (1.f - y * y);
+        const float dmu = g * 2.f * y + h;
+        const float dl = g * (-1.f + 2.f * y * e * sg) + h * e * sg;
+        p.G[(size_t)b * 2 * p.A + j] = dmu;
+        p.G[(size_t)b * 2 * p.A + p.A + j] = dl * 3.5f * (1.f - t * t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vlsac ELBO pieces (agent/vlsac/vlsac_agent.py:135-150)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_mid_kernel(VaeMid p) {
+    __shared__ float sh[4];
+    const int F = p.F;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    float k = 0.f;
+    if (e < (long long)p.B * F) {
+        const int b = (int)(e / F), j = (int)(e - (long long)b * F);
+        const float m1 = p.EH[(size_t)b * 2 * F + j], l1r = p.EH[(size_t)b * 2 * F + F + j];
+        const float m2 = p.FH[(size_t)b * 2 * F + j], l2r = p.FH[(size_t)b * 2 * F + F + j];
+        const float l1 = clamp_lstd(l1r), l2 = clamp_lstd(l2r);
+        const float es = p.eps[(size_t)b * F + j] * expf(l1);
+        p.Z[(size_t)b * F + j] = m1 + es;
+        p.EZ[(size_t)b * F + j] = es * lstd_mask(l1r);        // dz/dlog_std (clamp gradient folded in)
+        const float v1 = expf(2.f * l1), iv2 = expf(-2.f * l2), d = m1 - m2;
+        k = l2 - l1 + 0.5f * (v1 + d * d) * iv2 - 0.5f;
+        const float sc = p.scale;                       // 1 / (B_global * F)
+        const float dm1 = d * iv2 * sc;
+        p.GEH[(size_t)b * 2 * F + j] = dm1;
+        p.GEH[(size_t)b * 2 * F + F + j] = (v1 * iv2 - 1.f) * sc * lstd_mask(l1r);
+        p.GFH[(size_t)b * 2 * F + j] = -dm1;
+        p.GFH[(size_t)b * 2 * F + F + j] = (1.f - (v1 + d * d) * iv2) * sc * lstd_mask(l2r);
+    }
+    const float s = block_sum_256(k, sh);
+    if (threadIdx.x == 0) {
+        p.partial[blockIdx.x] = s;
+        if (blockIdx.x == 0 && p.step) *p.step += 1;    // Adam step counter of the feature group
+    }
+}
+
+__global__ __launch_bounds__(256) void vae_mse_kernel(VaeMse p) {
+    __shared__ float sh[4];
+    const int W = p.S + 1;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    float es = 0.f, er = 0.f;
+    if (e < (long long)p.B * W) {
+        const int b = (int)(e / W), c = (int)(e - (long long)b * W);
+        const float pred = p.DH[(size_t)b * W + c];
+        if (c < p.S) {
+            const float d = pred - p.s2[(size_t)b * p.ld_s2 + c];
+            es = d * d;
+            p.GDH[(size_t)b * W + c] = d * p.scale_s;   // 1/(B_global*S)
+        } else {
+            const float d = pred - p.r[b];
+            er = d * d;
+            p.GDH[(size_t)b * W + c] = d * p.scale_r;   // 1/B_global
+        }
+    }
+    const float a = block_sum_256(es, sh);
+    const float c2 = block_sum_256(er, sh);
+    if (threadIdx.x == 0) { p.partial[2 * blockIdx.x] = a; p.partial[2 * blockIdx.x + 1] = c2; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q heads: last H->1 linear on an ELU activation, TD target, critic / actor losses
+// (sac_agent.py:112-123,141-159; vlsac_agent.py:207-226,169-180)
+// one wave per batch row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_dot(const float* __restrict__ e, const float* __restrict__ w, int H, int lane) {
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s = fmaf(e[k], w[k], s);
+    return wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void qhead_critic_kernel(QHeadCritic p) {
+    __shared__ float shp[4][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float alpha = (float)exp(p.alpha_state[0]);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = blockIdx.x * 4 + w; b < p.B; b += gridDim.x * 4) {
+        const size_t ro = (size_t)b * p.H;
+        const float tq1 = row_dot(p.Et[0] + ro, p.wt[0], p.H, lane) + p.bt[0][0];
+        const float tq2 = row_dot(p.Et[1] + ro, p.wt[1], p.H, lane) + p.bt[1][0];
+        const float q1 = row_dot(p.Ec[0] + ro, p.wc[0], p.H, lane) + p.bc[0][0];
+        const float q2 = row_dot(p.Ec[1] + ro, p.wc[1], p.H, lane) + p.bc[1][0];
+        const float tv = fminf(tq1, tq2) - alpha * p.logp[b];
+        const float y = p.R[b] + (1.f - p.D[b]) * p.gamma * tv;
+        const float d1 = q1 - y, d2 = q2 - y;
+        const float g1 = 2.f * d1 * p.inv_batch, g2 = 2.f * d2 * p.inv_batch;
+        if (p.train) {
+            for (int k = lane; k < p.H; k += 64) {
+                p.GE[0][ro + k] = g1 * p.wc[0][k] * elu_grad_from_out(p.Ec[0][ro + k]);
+                p.GE[1][ro + k] = g2 * p.wc[1][k] * elu_grad_from_out(p.Ec[1][ro + k]);
+            }
+            if (lane == 0) { p.dq[b] = g1; p.dq[p.B + b] = g2; }
+        }
+        acc[0] += d1 * d1; acc[1] += d2 * d2; acc[2] += q1; acc[3] += q2;
+    }
+    if (lane == 0) { for (int i = 0; i < 4; ++i) shp[w][i] = acc[i]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int i = threadIdx.x;
+        p.partial[4 * blockIdx.x + i] = ((shp[0][i] + shp[1][i]) + shp[2][i]) + shp[3][i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.step) *p.step += 1;
+}
+
+__global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
+    __shared__ float shp[4][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float alpha = (float)exp(p.alpha_state[0]);
+    float accl = 0.f, accc = 0.f;
+    for (int b = blockIdx.x * 4 + w; b < p.B; b += gridDim.x * 4) {
+        const size_t ro = (size_t)b * p.H;
+        const float q1 = row_dot(p.Ec[0] + ro, p.wc[0], p.H, lane) + p.bc[0][0];
+        const float q2 = row_dot(p.Ec[1] + ro, p.wc[1], p.H, lane) + p.bc[1][0];
+        // d(-min(q1,q2))/dq_i : -1 to the arg-min head, ties split 1/2 (torch.min backward)
+        float s1, s2;
+        if (q1 < q2) { s1 = 1.f; s2 = 0.f; } else if (q2 < q1) { s1 = 0.f; s2 = 1.f; } else { s1 = s2 = 0.5f; }
+        const float g1 = -s1 * p.inv_batch, g2 = -s2 * p.inv_batch;
+        for (int k = lane; k < p.H; k += 64) {
+            p.GE[0][ro + k] = g1 * p.wc[0][k] * elu_grad_from_out(p.Ec[0][ro + k]);
+            p.GE[1][ro + k] = g2 * p.wc[1][k] * elu_grad_from_out(p.Ec[1][ro + k]);
+        }
+        const float lp = p.logp[b];
+        accl += alpha * lp - fminf(q1, q2);
+        accc += -lp - p.target_entropy;
+    }
+    if (lane == 0) { shp[w][0] = accl; shp[w][1] = accc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.partial_loss[blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
+        p.partial_c[blockIdx.x] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
+        if (blockIdx.x == 0 && p.step) *p.step += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-tensor Adam (+ Polyak of a sub-range) + metric finalisation + temperature update
+// torch/optim/adam.py::_single_tensor_adam operation order; SURVEY Appendix A.11/A.12
+// ------------------------------------------------------------------------------------------------
+__device__ void finalize_tasks(const FinTask* __restrict__ fin, int nfin, int lane) {
+    for (int q = 0; q < nfin; ++q) {
+        const FinTask f = fin[q];
+        if (f.kind == FIN_SUM) {
+            float s = 0.f;
+            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
+            s = wave_sum(s);
+            if (lane == 0) *f.out = s * f.scale;
+        } else if (f.kind == FIN_COMBINE) {
+            if (lane == 0) *f.out = f.scale * (*f.in_a) + f.scale_b * (*f.in_b);
+        } else if (f.kind == FIN_COPY) {
+            if (lane == 0) *f.out = *f.in_a;
+        } else if (f.kind == FIN_ALPHA) {
+            // L_alpha = mean(exp(log_alpha) * c), c detached; d/dlog_alpha = alpha * mean(c); fp64 Adam (quirk Q1)
+            float s = 0.f;
+            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
+            s = wave_sum(s);
+            if (lane == 0) {
+                double* st = f.alpha_state;           // log_alpha, m, v, step
+                const float mean_c = s * f.scale;
+                const double alpha = exp(st[0]);
+                *f.out = (float)alpha * mean_c;       // alpha_loss (fp32 product as in the reference)
+                if (f.learn) {
+                    const double g = (double)mean_c * alpha;
+                    const double b1 = (double)f.beta1, b2 = (double)f.beta2;
+                    st[3] += 1.0;
+                    st[1] = st[1] + (1.0 - b1) * (g - st[1]);
+                    st[2] = st[2] * b2 + (1.0 - b2) * g * g;
+                    const double bc1 = 1.0 - pow(b1, st[3]), bc2 = 1.0 - pow(b2, st[3]);
+                    const double denom = sqrt(st[2]) / sqrt(bc2) + (double)f.eps;
+                    st[0] = st[0] - ((double)f.lr / bc1) * (st[1] / denom);
+                }
+                *f.out2 = (float)exp(st[0]);          // info['alpha'] is read after the optimizer step
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
+                                                   const PolyakTask* __restrict__ pol, int npol,
+                                                   const FinTask* __restrict__ fin, int nfin) {
+    __shared__ float sc[3];
+    const int bid = blockIdx.x;
+    if (bid >= adam_blocks) {
+        // trailing block: standalone Polyak tasks are handled by their own blocks below; this one finalises
+        if (threadIdx.x < 64) finalize_tasks(fin, nfin, threadIdx.x);
+        return;
+    }
+    // locate task
+    int ti = 0; long long base_blk = 0;
+    for (int q = 0; q < ntasks; ++q) {
+        const long long nb = (tasks[q].n + 1023) / 1024;
+        if (bid < base_blk + nb) { ti = q; break; }
+        base_blk += nb;
+    }
+    const AdamTask& t = tasks[ti];
+    if (threadIdx.x == 0) {
+        const double step = (double)(*t.step);
+        const double bc1 = 1.0 - pow((double)t.beta1, step);
+        const double bc2 = 1.0 - pow((double)t.beta2, step);
+        sc[0] = (float)(-((double)t.lr / bc1));     // value = -step_size
+        sc[1] = (float)sqrt(bc2);                    // bias_correction2_sqrt
+    }
+    __syncthreads();
+    const float nss = sc[0], bc2s = sc[1];
+    const float w1 = (float)(1.0 - (double)t.beta1), w2 = (float)(1.0 - (double)t.beta2);
+    const float omt = (float)(1.0 - (double)t.tau);
+    const long long i0 = (long long)(bid - base_blk) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const long long i = i0 + s * 256;
+        if (i >= t.n) break;
+        const float g = t.g[i];
+        float m = t.m[i], v = t.v[i], pv = t.p[i];
+        m = m + w1 * (g - m);
+        v = v * t.beta2;
+        v = v + (w2 * g) * g;
+        const float denom = sqrtf(v) / bc2s + t.eps;
+        pv = pv + nss * (m / denom);
+        t.m[i] = m; t.v[i] = v; t.p[i] = pv;
+        if (t.target && i >= t.pol_off && i < t.pol_off + t.pol_n) {
+            float* tp = t.target + (i - t.pol_off);
+            *tp = t.tau * pv + omt * (*tp);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void polyak_kernel(PolyakTask t) {
+    if (t.steps && ((*t.steps) % t.period) != 0) return;
+    const float omt = (float)(1.0 - (double)t.tau);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (long long)gridDim.x * 256)
+        t.dst[i] = t.tau * t.src[i] + omt * t.dst[i];
+}
+
+__global__ void counter_inc_kernel(int* c) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1; }
+
+__global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(long long n, int per_block, int cap) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+extern "C" int rl_launch_fill_slot(const SlotFill* p, hipStream_t st) {
+    const long long total = (long long)p->B * (2 * p->S + p->A + 2);
+    hipLaunchKernelGGL(fill_slot_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_philox(const PhiloxFill* p, hipStream_t st) {
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(grid_for((p->n + 3) / 4, 256, 2048)), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st) {
+    hipLaunchKernelGGL(policy_fwd_kernel, dim3((p->B + 255) / 256), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_policy_bwd(const PolicyBwd* p, hipStream_t st) {
+    hipLaunchKernelGGL(policy_bwd_kernel, dim3((p->B + 255) / 256), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_vae_mid(const VaeMid* p, hipStream_t st) {
+    hipLaunchKernelGGL(vae_mid_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_vae_mse(const VaeMse* p, hipStream_t st) {
+    hipLaunchKernelGGL(vae_mse_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_qhead_critic(const QHeadCritic* p, hipStream_t st) {
+    hipLaunchKernelGGL(qhead_critic_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st) {
+    hipLaunchKernelGGL(qhead_actor_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1), dim3(256), 0, st, tasks, ntasks, adam_blocks,
+                       (const PolyakTask*)nullptr, 0, fin, nfin);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {
+    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(t->n, 256, 1024)), dim3(256), 0, st, *t);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_counter_inc(int* c, hipStream_t st) {
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, c);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_copy(const float* src, float* dst, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, src, dst, n);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,122 @@
+// Host-side engine: tensor layout, workspace, step-program builder (librlrep_hip.so internals).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <functional>
+#include <cstring>
+#include <cstdio>
+#include "../../include/rlrep.h"
+#include "common.h"
+#include "kparams.h"
+
+// kernel launchers (defined next to the kernels)
+extern "C" {
+int rl_launch_gemm16(int la, int lb, const GemmTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st);
+int rl_launch_nc_fwd(const NcFwdTask* tasks_dev, int ntasks, int total_tiles, int F, int N, hipStream_t st);
+int rl_launch_nc_dx(const NcDxTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st);
+int rl_launch_fill_slot(const SlotFill* p, hipStream_t st);
+int rl_launch_philox(const PhiloxFill* p, hipStream_t st);
+int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st);
+int rl_launch_policy_bwd(const PolicyBwd* p, hipStream_t st);
+int rl_launch_vae_mid(const VaeMid* p, hipStream_t st);
+int rl_launch_vae_mse(const VaeMse* p, hipStream_t st);
+int rl_launch_qhead_critic(const QHeadCritic* p, hipStream_t st);
+int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st);
+int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, hipStream_t st);
+int rl_launch_polyak(const PolyakTask* t, hipStream_t st);
+int rl_launch_counter_inc(int* c, hipStream_t st);
+int rl_launch_copy(const float* src, float* dst, long long n, hipStream_t st);
+}
+
+void rl_set_error(const char* fmt, ...);
+
+// metric slots (union over the agents; names per agent in rlrep_metric_names)
+enum Metric : int {
+    M_FEAT_TOTAL = 0,   // vae_loss / total_loss / score_loss
+    M_FEAT_A = 1,       // ml_loss / model_loss
+    M_KL = 2, M_S_LOSS = 3, M_R_LOSS = 4,
+    M_Q1_LOSS = 5,      // q1_loss (sac: q_loss; diffsr: q_loss_reg)
+    M_Q2_LOSS = 6,      // q2_loss (diffsr: q_loss_noreg)
+    M_Q1 = 7, M_Q2 = 8, M_ACTOR_LOSS = 9, M_ALPHA_LOSS = 10, M_ALPHA = 11,
+    M_TMP0 = 12, M_TMP1 = 13, M_TMP2 = 14, M_TMP3 = 15,
+    M_COUNT = 16
+};
+
+// ------------------------------------------------------------------------------------------------
+// layout
+// ------------------------------------------------------------------------------------------------
+struct LT {
+    std::string name; int rows, cols; int arena; int group; int64_t off;
+};
+
+struct Layout {
+    std::vector<LT> t;
+    std::map<std::string, int> index;
+    int64_t cur[RLREP_ARENA_COUNT] = {0, 0};
+    int64_t group_off[4] = {0, 0, 0, 0}, group_n[4] = {0, 0, 0, 0};
+
+    void align(int arena) { cur[arena] = (cur[arena] + 3) & ~int64_t(3); }
+    int64_t add(const std::string& name, int rows, int cols, int arena, int group, bool glue = false) {
+        if (!glue) align(arena);
+        LT e{name, rows, cols, arena, group, cur[arena]};
+        index[name] = (int)t.size();
+        t.push_back(e);
+        cur[arena] += (int64_t)rows * cols;
+        return e.off;
+    }
+    void lin(const std::string& p, int out_f, int in_f, int arena, int group) {
+        add(p + ".weight", out_f, in_f, arena, group);
+        add(p + ".bias", out_f, 1, arena, group);
+    }
+    // two Linear layers sharing the input, stored as one [o1+o2, in] matrix (+ one [o1+o2] bias)
+    void lin_pair(const std::string& p1, int o1, const std::string& p2, int o2, int in_f, int arena, int group) {
+        add(p1 + ".weight", o1, in_f, arena, group);
+        add(p2 + ".weight", o2, in_f, arena, group, true);
+        add(p1 + ".bias", o1, 1, arena, group);
+        add(p2 + ".bias", o2, 1, arena, group, true);
+    }
+    void begin_group(int g) { align(RLREP_ARENA_PARAM); group_off[g] = cur[RLREP_ARENA_PARAM]; }
+    void end_group(int g) { align(RLREP_ARENA_PARAM); group_n[g] = cur[RLREP_ARENA_PARAM] - group_off[g]; }
+    const LT& get(const std::string& n) const {
+        auto it = index.find(n);
+        if (it == index.end()) { fprintf(stderr, "rlrep: unknown tensor %s\n", n.c_str()); abort(); }
+        return t[it->second];
+    }
+};
+
+bool build_layout(const rlrep_dims& d, Layout& L);
+
+// ------------------------------------------------------------------------------------------------
+// workspace bump allocator over caller memory
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+    char* base = nullptr; size_t cap = 0, used = 0; bool dry = false;
+    void* alloc(size_t bytes) {
+        used = (used + 255) & ~size_t(255);
+        void* p = dry ? nullptr : (void*)(base + used);
+        used += bytes;
+        return p;
+    }
+    float* f(size_t n) { return (float*)alloc(n * sizeof(float)); }
+    bool ok() const { return dry || used <= cap; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// programs
+// ------------------------------------------------------------------------------------------------
+struct Stage { std::function<int(hipStream_t)> run; const char* what; };
+
+struct Program {
+    std::vector<Stage> stages;
+    int run(hipStream_t st) const {
+        for (auto& s : stages) {
+            int rc = s.run(st);
+            if (rc != 0) { rl_set_error("stage '%s' failed: hip error %d", s.what, rc); return RLREP_ERR_HIP; }
+        }
+        return 0;
+    }
+};
+
+struct Mat { float* p; int rows, cols, ld; };

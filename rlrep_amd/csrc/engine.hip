@@ -1,0 +1,869 @@
+// librlrep_hip.so host side: layout, step-program construction for each agent, C ABI (include/rlrep.h).
+//
+// A step program is a short, fixed list of kernel launches (stages).  Each stage executes a TABLE of
+// independent tasks (grouped GEMMs, see gemm16.hip), so the number of dependent launches equals the depth
+// of the agent's computation graph.  Tables live in the caller-provided workspace and are uploaded when
+// the batch size changes; the hot path performs no allocation, no host<->device copy and no sync.
+#include "engine.h"
+#include <cstdarg>
+#include <memory>
+
+static thread_local char g_err[512] = "";
+void rl_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+
+// ================================================================================================
+// layout (names = reference state_dict keys; see oracle/shapes.py for the reference order)
+// ================================================================================================
+static void lay_actor(Layout& L, int S, int A, int Ha, int arena, int group) {
+    L.lin("actor.trunk.0", Ha, S, arena, group);          // agent/sac/actor.py:63-74
+    L.lin("actor.trunk.2", Ha, Ha, arena, group);
+    L.lin("actor.trunk.4", 2 * A, Ha, arena, group);
+}
+static void lay_doubleq(Layout& L, const std::string& m, int SA, int H, int arena, int group) {
+    // agent/sac/critic.py:15-36; the two heads' first layers are stored as one [2H, S+A] matrix
+    L.lin_pair(m + ".Q1.0", H, m + ".Q2.0", H, SA, arena, group);
+    L.lin(m + ".Q1.2", H, H, arena, group);
+    L.lin(m + ".Q2.2", H, H, arena, group);
+    L.lin(m + ".Q1.4", 1, H, arena, group);
+    L.lin(m + ".Q2.4", 1, H, arena, group);
+}
+static void lay_six(Layout& L, const std::string& m, int in_f, int H, int arena, int group) {
+    // l1..l6 critics (vlsac_agent.py:33-41, spedersac_agent.py:26-34, diffsrsac_agent.py:51-59); l1|l4 glued
+    L.lin_pair(m + ".l1", H, m + ".l4", H, in_f, arena, group);
+    L.lin(m + ".l2", H, H, arena, group);
+    L.lin(m + ".l5", H, H, arena, group);
+    L.lin(m + ".l3", 1, H, arena, group);
+    L.lin(m + ".l6", 1, H, arena, group);
+}
+static void lay_gauss(Layout& L, const std::string& m, int in_f, int Hv, int F, int arena, int group) {
+    // networks/vae.py:28-35 / 104-109; mean|log_std heads glued into one [2F, Hv] matrix
+    L.lin(m + ".l1", Hv, in_f, arena, group);
+    L.lin(m + ".l2", Hv, Hv, arena, group);
+    L.lin_pair(m + ".mean_linear", F, m + ".log_std_linear", F, Hv, arena, group);
+}
+
+bool build_layout(const rlrep_dims& d, Layout& L) {
+    const int S = d.state_dim, A = d.action_dim, H = d.hidden_dim, Ha = d.actor_hidden_dim, F = d.feature_dim;
+    const int P = RLREP_ARENA_PARAM, T = RLREP_ARENA_TARGET;
+    switch (d.alg) {
+    case RLREP_ALG_SAC:
+        L.begin_group(1); lay_doubleq(L, "critic", S + A, H, P, 1); L.end_group(1);
+        L.begin_group(2); lay_actor(L, S, A, Ha, P, 2); L.end_group(2);
+        lay_doubleq(L, "critic_target", S + A, H, T, -1);
+        return true;
+    case RLREP_ALG_VLSAC: {
+        const int Hv = d.vae_hidden_dim;
+        L.begin_group(0);
+        lay_gauss(L, "encoder", 2 * S + A, Hv, F, P, 0);
+        L.lin("decoder.l1", Hv, F, P, 0);                                   // networks/vae.py:74-77
+        L.lin_pair("decoder.state_linear", S, "decoder.reward_linear", 1, Hv, P, 0);
+        lay_gauss(L, "f", S + A, Hv, F, P, 0);
+        L.end_group(0);
+        L.begin_group(1); lay_six(L, "critic", F, H, P, 1); L.end_group(1);
+        L.begin_group(2); lay_actor(L, S, A, Ha, P, 2); L.end_group(2);
+        lay_gauss(L, "f_target", S + A, Hv, F, T, -1);
+        lay_six(L, "critic_target", F, H, T, -1);
+        L.add("critic.noise", d.num_noise, F, T, -1);                      // quirk Q3: plain attribute
+        return true;
+    }
+    default:
+        rl_set_error("algorithm %d not built yet", d.alg);
+        return false;
+    }
+}
+
+// ================================================================================================
+// agent
+// ================================================================================================
+struct Slot { float *XE, *XF, *XF2, *XFpi, *R, *D; bool filled = false; };
+
+struct rlrep_agent {
+    rlrep_dims d; rlrep_hyper h; rlrep_arenas a; Layout L; Workspace ws;
+    int B = 0;
+    int* steps = nullptr; int* adam_step = nullptr; float* metrics = nullptr; float* obs_in = nullptr; float* act_out = nullptr;
+    Slot slot[2];
+    // per-call dynamic inputs, read by the by-value parameter blocks at launch time
+    const float* cur_eps = nullptr; const int* cur_idx = nullptr;
+    Program feat_bwd, feat_apply, critic_bwd, critic_apply, actor_bwd, actor_apply, upd_target, infer;
+    int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
+    int last_launches = 0;
+    size_t ws_static = 0;     // workspace bytes used by batch-independent state
+
+    float* P(const std::string& n) const { return a.param_dev ? a.param_dev + L.get(n).off : nullptr; }
+    float* T(const std::string& n) const { return a.target_dev ? a.target_dev + L.get(n).off : nullptr; }
+    float* G(const std::string& n) const { return a.grad_dev ? a.grad_dev + L.get(n).off : nullptr; }
+    float* Gtail() const { return a.grad_dev ? a.grad_dev + L.cur[RLREP_ARENA_PARAM] : nullptr; }
+    float inv_batch() const { return 1.0f / ((float)B * (float)(h.world_size > 0 ? h.world_size : 1)); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// builder helpers
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    rlrep_agent* ag; Workspace& ws; bool dry;
+    Builder(rlrep_agent* a) : ag(a), ws(a->ws), dry(a->ws.dry) {}
+
+    template <class Tt> const Tt* upload(const std::vector<Tt>& v) {
+        Tt* dev = (Tt*)ws.alloc(v.size() * sizeof(Tt));
+        if (!dry && ws.ok()) {
+            hipError_t e = hipMemcpy(dev, v.data(), v.size() * sizeof(Tt), hipMemcpyHostToDevice);
+            if (e != hipSuccess) rl_set_error("table upload failed: %s", hipGetErrorString(e));
+        }
+        return dev;
+    }
+    Mat mat(int rows, int cols) { return Mat{ws.f((size_t)rows * cols), rows, cols, cols}; }
+
+    // ---- GEMM task constructors -------------------------------------------------------------
+    static GemmTask base() { GemmTask t; memset(&t, 0, sizeof(t)); t.scale = 1.f; return t; }
+    // Y[B,N] = act(X[B,K] W[N,K]^T + b)
+    static GemmTask fwd(const float* X, int ldx, int Bn, int K, const float* W, int ldw, const float* bias, int N,
+                        float* Y, int ldy, int act, float* pre = nullptr, int ldpre = 0) {
+        GemmTask t = base();
+        t.A = X; t.lda = ldx; t.B = W; t.ldb = ldw; t.C = Y; t.ldc = ldy; t.bias = bias;
+        t.R = Bn; t.Cn = N; t.K = K; t.epi = EPI_FWD; t.act = act; t.out2 = pre; t.ldout2 = ldpre;
+        return t;
+    }
+    // dX[B,Kout] (=|+=) (G[B,N] W[N, Kout(+off)]) * act'(aux)
+    static GemmTask dx(const float* Gm, int ldg, int Bn, int N, const float* W, int ldw, float* dX, int lddx, int Kout,
+                       int act, const float* aux, int ldaux, int flags = 0) {
+        GemmTask t = base();
+        t.A = Gm; t.lda = ldg; t.B = W; t.ldb = ldw; t.C = dX; t.ldc = lddx; t.aux = aux; t.ldaux = ldaux;
+        t.R = Bn; t.Cn = Kout; t.K = N; t.epi = EPI_DX; t.act = act; t.flags = flags;
+        return t;
+    }
+    // gW[N,K] = G[M,N]^T X[M,K];  gb[N] = colsum G
+    static GemmTask dw(const float* Gm, int ldg, int N, const float* X, int ldx, int K, int M, float* gW, int ldgw, float* gb) {
+        GemmTask t = base();
+        t.A = Gm; t.lda = ldg; t.B = X; t.ldb = ldx; t.C = gW; t.ldc = ldgw; t.out2 = gb;
+        t.R = N; t.Cn = K; t.K = M; t.epi = EPI_DW; t.flags = gb ? FLAG_BIASGRAD : 0;
+        return t;
+    }
+
+    void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
+        int base_tile = 0;
+        for (auto& t : tasks) {
+            t.tiles_c = (t.Cn + 15) / 16;
+            const int tr = (t.R + 15) / 16;
+            t.ntiles = tr * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles;
+        }
+        const GemmTask* dev = upload(tasks);
+        const int nt = (int)tasks.size(), total = base_tile;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, dev, nt, total, st); }, what});
+    }
+    void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
+    void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
+    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_COL, LD_COL, t, w); }
+
+    void adam(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau,
+              std::vector<FinTask> fin, const char* what) {
+        const auto& L = ag->L;
+        AdamTask t; memset(&t, 0, sizeof(t));
+        const int64_t off = L.group_off[group];
+        t.p = ag->a.param_dev ? ag->a.param_dev + off : nullptr;
+        t.g = ag->a.grad_dev ? ag->a.grad_dev + off : nullptr;
+        t.m = ag->a.exp_avg_dev ? ag->a.exp_avg_dev + off : nullptr;
+        t.v = ag->a.exp_avg_sq_dev ? ag->a.exp_avg_sq_dev + off : nullptr;
+        t.n = L.group_n[group];
+        t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
+        t.step = ag->adam_step + group;
+        t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau;
+        std::vector<AdamTask> tv{t};
+        const AdamTask* dev = upload(tv);
+        const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
+        const int nfin = (int)fin.size();
+        const int blocks = (int)((t.n + 1023) / 1024);
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(dev, 1, blocks, fdev, nfin, st); }, what});
+    }
+    void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
+        const FinTask* fdev = upload(fin);
+        const int nfin = (int)fin.size();
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, st); }, what});
+    }
+
+    static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {
+        FinTask f; memset(&f, 0, sizeof(f));
+        f.kind = FIN_SUM; f.partials = partials; f.count = count; f.stride = stride; f.scale = scale; f.out = out;
+        return f;
+    }
+    static FinTask fin_combine(const float* a, float sa, const float* b, float sb, float* out) {
+        FinTask f; memset(&f, 0, sizeof(f));
+        f.kind = FIN_COMBINE; f.in_a = a; f.in_b = b; f.scale = sa; f.scale_b = sb; f.out = out;
+        return f;
+    }
+    static FinTask fin_copy(const float* a, float* out) {
+        FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_COPY; f.in_a = a; f.out = out; return f;
+    }
+};
+
+// rows processed per qhead block loop: grid <= 128 blocks of 4 waves
+static int qhead_blocks(int B) { int g = (B + 3) / 4; return g > 128 ? 128 : g; }
+
+// ------------------------------------------------------------------------------------------------
+// shared fragments: actor forward / backward, actor+alpha apply
+// ------------------------------------------------------------------------------------------------
+struct ActorBufs { float *A1, *A2, *AO, *logp, *dA, *Ghead, *GA2, *GA1; };
+
+static ActorBufs alloc_actor(Builder& b, int B, int A, int Ha) {
+    ActorBufs r;
+    r.A1 = b.ws.f((size_t)B * Ha); r.A2 = b.ws.f((size_t)B * Ha); r.AO = b.ws.f((size_t)B * 2 * A);
+    r.logp = b.ws.f(B); r.dA = b.ws.f((size_t)B * A); r.Ghead = b.ws.f((size_t)B * 2 * A);
+    r.GA2 = b.ws.f((size_t)B * Ha); r.GA1 = b.ws.f((size_t)B * Ha);
+    return r;
+}
+
+// GEMM tasks of the three actor trunk layers on input X[B, S] (row stride ldx)
+static GemmTask actor_l(rlrep_agent* ag, int layer, const float* X, int ldx, const ActorBufs& ab) {
+    const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
+    if (layer == 0) return Builder::fwd(X, ldx, B, S, ag->P("actor.trunk.0.weight"), S, ag->P("actor.trunk.0.bias"), Ha, ab.A1, Ha, ACT_ELU);
+    if (layer == 1) return Builder::fwd(ab.A1, Ha, B, Ha, ag->P("actor.trunk.2.weight"), Ha, ag->P("actor.trunk.2.bias"), Ha, ab.A2, Ha, ACT_ELU);
+    return Builder::fwd(ab.A2, Ha, B, Ha, ag->P("actor.trunk.4.weight"), Ha, ag->P("actor.trunk.4.bias"), 2 * A, ab.AO, 2 * A, ACT_NONE);
+}
+
+static void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, const char* what) {
+    PolicyFwd pf; memset(&pf, 0, sizeof(pf));
+    pf.O = ab.AO; pf.B = ag->B; pf.A = ag->d.action_dim; pf.act = act; pf.ld_act = ld_act; pf.logp = ab.logp;
+    p.stages.push_back({[=](hipStream_t st) { PolicyFwd q = pf; q.eps = ag->cur_eps; return rl_launch_policy_fwd(&q, st); }, what});
+}
+
+// policy head backward + trunk backward + weight gradients (X = actor input with row stride ldx)
+static void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx,
+                           const float* act, int ld_act) {
+    const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
+    PolicyBwd pb; memset(&pb, 0, sizeof(pb));
+    pb.O = ab.AO; pb.act = act; pb.ld_act = ld_act; pb.dA = ab.dA; pb.ld_dA = A;
+    pb.alpha_state = ag->a.alpha_state_dev; pb.inv_batch = ag->inv_batch(); pb.G = ab.Ghead; pb.B = B; pb.A = A;
+    p.stages.push_back({[=](hipStream_t st) { PolicyBwd q = pb; q.eps = ag->cur_eps; return rl_launch_policy_bwd(&q, st); }, "policy_bwd"});
+    b.dx_stage(p, {Builder::dx(ab.Ghead, 2 * A, B, 2 * A, ag->P("actor.trunk.4.weight"), Ha, ab.GA2, Ha, Ha, ACT_ELU, ab.A2, Ha)}, "actor.head dx");
+    b.dx_stage(p, {Builder::dx(ab.GA2, Ha, B, Ha, ag->P("actor.trunk.2.weight"), Ha, ab.GA1, Ha, Ha, ACT_ELU, ab.A1, Ha)}, "actor.l2 dx");
+    b.dw_stage(p, {Builder::dw(ab.Ghead, 2 * A, 2 * A, ab.A2, Ha, Ha, B, ag->G("actor.trunk.4.weight"), Ha, ag->G("actor.trunk.4.bias")),
+                   Builder::dw(ab.GA2, Ha, Ha, ab.A1, Ha, Ha, B, ag->G("actor.trunk.2.weight"), Ha, ag->G("actor.trunk.2.bias")),
+                   Builder::dw(ab.GA1, Ha, Ha, X, ldx, S, B, ag->G("actor.trunk.0.weight"), S, ag->G("actor.trunk.0.bias"))},
+               "actor dW");
+}
+
+static void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk) {
+    Program& p = ag->actor_apply;
+    FinTask fa; memset(&fa, 0, sizeof(fa));
+    fa.kind = FIN_ALPHA; fa.partials = ag->Gtail(); fa.count = nblk; fa.stride = 1; fa.scale = ag->inv_batch();
+    fa.out = ag->metrics + M_ALPHA_LOSS; fa.out2 = ag->metrics + M_ALPHA; fa.alpha_state = ag->a.alpha_state_dev;
+    fa.lr = ag->h.lr_actor; fa.beta1 = ag->h.beta1; fa.beta2 = ag->h.beta2; fa.eps = ag->h.adam_eps; fa.learn = ag->h.learn_alpha;
+    b.adam(p, 2, ag->h.lr_actor, nullptr, 0, 0, 0.f,
+           {Builder::fin_sum(partial_loss, nblk, 1, 1.0f / (float)ag->B, ag->metrics + M_ACTOR_LOSS), fa}, "adam actor + alpha");
+}
+
+static void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst) {
+    // critic -> critic_target over the whole critic group (identical internal layouts)
+    PolyakTask t; memset(&t, 0, sizeof(t));
+    t.src = ag->a.param_dev ? ag->a.param_dev + ag->L.group_off[1] : nullptr;
+    t.dst = ag->a.target_dev ? ag->a.target_dev + ag->L.get(first_dst).off : nullptr;
+    (void)first_src;
+    t.n = ag->L.group_n[1]; t.tau = ag->h.tau; t.steps = ag->steps; t.period = ag->h.target_update_period;
+    ag->upd_target.stages.push_back({[=](hipStream_t st) { return rl_launch_polyak(&t, st); }, "polyak critic"});
+}
+
+// ================================================================================================
+// SAC   (agent/sac/sac_agent.py:105-166)
+// ================================================================================================
+static void build_sac(Builder& b, rlrep_agent* ag) {
+    const int S = ag->d.state_dim, A = ag->d.action_dim, H = ag->d.hidden_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
+    const int SA = S + A;
+    Slot& s0 = ag->slot[0];
+    ActorBufs ab = alloc_actor(b, B, A, Ha);
+    float* E1t = b.ws.f((size_t)B * 2 * H);       // target first-layer activations [B, 2H] (Q1|Q2)
+    float* E1c = b.ws.f((size_t)B * 2 * H);
+    float* Et = b.ws.f((size_t)2 * B * H);        // second-layer activations, heads stacked [2][B,H]
+    float* Ec = b.ws.f((size_t)2 * B * H);
+    float* GE = b.ws.f((size_t)2 * B * H);
+    float* G1 = b.ws.f((size_t)B * 2 * H);
+    float* dq = b.ws.f((size_t)2 * B);
+    const int nblk = qhead_blocks(B);
+    float* part_q = b.ws.f((size_t)4 * nblk);
+    float* part_l = b.ws.f(nblk);
+    auto Pw = [&](const char* n) { return ag->P(n); };
+    auto Tw = [&](const char* n) { return ag->T(n); };
+
+    // ---- critic step ----
+    {
+        Program& p = ag->critic_bwd;
+        b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab)}, "actor.l1(s')");
+        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
+        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
+        policy_fwd_stage(p, ag, ab, s0.XF2 + S, SA, "policy(s')");
+        b.fwd_stage(p, {Builder::fwd(s0.XF2, SA, B, SA, Tw("critic_target.Q1.0.weight"), SA, Tw("critic_target.Q1.0.bias"), 2 * H, E1t, 2 * H, ACT_ELU),
+                        Builder::fwd(s0.XF, SA, B, SA, Pw("critic.Q1.0.weight"), SA, Pw("critic.Q1.0.bias"), 2 * H, E1c, 2 * H, ACT_ELU)}, "Q l1");
+        b.fwd_stage(p, {Builder::fwd(E1t, 2 * H, B, H, Tw("critic_target.Q1.2.weight"), H, Tw("critic_target.Q1.2.bias"), H, Et, H, ACT_ELU),
+                        Builder::fwd(E1t + H, 2 * H, B, H, Tw("critic_target.Q2.2.weight"), H, Tw("critic_target.Q2.2.bias"), H, Et + (size_t)B * H, H, ACT_ELU),
+                        Builder::fwd(E1c, 2 * H, B, H, Pw("critic.Q1.2.weight"), H, Pw("critic.Q1.2.bias"), H, Ec, H, ACT_ELU),
+                        Builder::fwd(E1c + H, 2 * H, B, H, Pw("critic.Q2.2.weight"), H, Pw("critic.Q2.2.bias"), H, Ec + (size_t)B * H, H, ACT_ELU)}, "Q l2");
+        QHeadCritic q; memset(&q, 0, sizeof(q));
+        q.Et[0] = Et; q.Et[1] = Et + (size_t)B * H; q.Ec[0] = Ec; q.Ec[1] = Ec + (size_t)B * H;
+        q.wt[0] = Tw("critic_target.Q1.4.weight"); q.wt[1] = Tw("critic_target.Q2.4.weight");
+        q.bt[0] = Tw("critic_target.Q1.4.bias"); q.bt[1] = Tw("critic_target.Q2.4.bias");
+        q.wc[0] = Pw("critic.Q1.4.weight"); q.wc[1] = Pw("critic.Q2.4.weight");
+        q.bc[0] = Pw("critic.Q1.4.bias"); q.bc[1] = Pw("critic.Q2.4.bias");
+        q.logp = ab.logp; q.R = s0.R; q.D = s0.D; q.alpha_state = ag->a.alpha_state_dev; q.gamma = ag->h.discount;
+        q.inv_batch = ag->inv_batch(); q.dq = dq; q.GE[0] = GE; q.GE[1] = GE + (size_t)B * H; q.partial = part_q;
+        q.B = B; q.H = H; q.nblk = nblk; q.train = 1; q.step = ag->adam_step + 1;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_critic(&q, st); }, "qhead critic"});
+        b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.Q1.2.weight"), H, G1, 2 * H, H, ACT_ELU, E1c, 2 * H),
+                       Builder::dx(GE + (size_t)B * H, H, B, H, Pw("critic.Q2.2.weight"), H, G1 + H, 2 * H, H, ACT_ELU, E1c + H, 2 * H)}, "Q l2 dx");
+        b.dw_stage(p, {Builder::dw(dq, 1, 1, Ec, H, H, B, ag->G("critic.Q1.4.weight"), H, ag->G("critic.Q1.4.bias")),
+                       Builder::dw(dq + B, 1, 1, Ec + (size_t)B * H, H, H, B, ag->G("critic.Q2.4.weight"), H, ag->G("critic.Q2.4.bias")),
+                       Builder::dw(GE, H, H, E1c, 2 * H, H, B, ag->G("critic.Q1.2.weight"), H, ag->G("critic.Q1.2.bias")),
+                       Builder::dw(GE + (size_t)B * H, H, H, E1c + H, 2 * H, H, B, ag->G("critic.Q2.2.weight"), H, ag->G("critic.Q2.2.bias")),
+                       Builder::dw(G1, 2 * H, 2 * H, s0.XF, SA, SA, B, ag->G("critic.Q1.0.weight"), SA, ag->G("critic.Q1.0.bias"))}, "Q dW");
+        // sac reports q_loss = mse1+mse2 and q2 := q1 (quirk Q13)
+        const float ib = 1.0f / (float)B;
+        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f,
+               {Builder::fin_sum(part_q + 0, nblk, 4, ib, ag->metrics + M_TMP0),
+                Builder::fin_sum(part_q + 1, nblk, 4, ib, ag->metrics + M_TMP1),
+                Builder::fin_combine(ag->metrics + M_TMP0, 1.f, ag->metrics + M_TMP1, 1.f, ag->metrics + M_Q1_LOSS),
+                Builder::fin_sum(part_q + 2, nblk, 4, ib, ag->metrics + M_Q1),
+                Builder::fin_copy(ag->metrics + M_Q1, ag->metrics + M_Q2)}, "adam critic");
+    }
+    // ---- actor step ----
+    {
+        Program& p = ag->actor_bwd;
+        b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
+        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
+        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
+        policy_fwd_stage(p, ag, ab, s0.XFpi + S, SA, "policy(s)");
+        b.fwd_stage(p, {Builder::fwd(s0.XFpi, SA, B, SA, Pw("critic.Q1.0.weight"), SA, Pw("critic.Q1.0.bias"), 2 * H, E1c, 2 * H, ACT_ELU)}, "Q l1");
+        b.fwd_stage(p, {Builder::fwd(E1c, 2 * H, B, H, Pw("critic.Q1.2.weight"), H, Pw("critic.Q1.2.bias"), H, Ec, H, ACT_ELU),
+                        Builder::fwd(E1c + H, 2 * H, B, H, Pw("critic.Q2.2.weight"), H, Pw("critic.Q2.2.bias"), H, Ec + (size_t)B * H, H, ACT_ELU)}, "Q l2");
+        QHeadActor q; memset(&q, 0, sizeof(q));
+        q.Ec[0] = Ec; q.Ec[1] = Ec + (size_t)B * H;
+        q.wc[0] = Pw("critic.Q1.4.weight"); q.wc[1] = Pw("critic.Q2.4.weight");
+        q.bc[0] = Pw("critic.Q1.4.bias"); q.bc[1] = Pw("critic.Q2.4.bias");
+        q.logp = ab.logp; q.alpha_state = ag->a.alpha_state_dev; q.inv_batch = ag->inv_batch(); q.target_entropy = ag->h.target_entropy;
+        q.GE[0] = GE; q.GE[1] = GE + (size_t)B * H; q.partial_loss = part_l; q.partial_c = ag->Gtail();
+        q.B = B; q.H = H; q.nblk = nblk; q.step = ag->adam_step + 2;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_actor(&q, st); }, "qhead actor"});
+        b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.Q1.2.weight"), H, G1, 2 * H, H, ACT_ELU, E1c, 2 * H),
+                       Builder::dx(GE + (size_t)B * H, H, B, H, Pw("critic.Q2.2.weight"), H, G1 + H, 2 * H, H, ACT_ELU, E1c + H, 2 * H)}, "Q l2 dx");
+        // both heads at once: [G1_1 | G1_2] [B,2H] x [W_Q1.0 ; W_Q2.0][:, S:S+A]
+        b.dx_stage(p, {Builder::dx(G1, 2 * H, B, 2 * H, Pw("critic.Q1.0.weight") ? Pw("critic.Q1.0.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0)}, "Q l1 dx(action)");
+        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA);
+        actor_apply_program(b, ag, part_l, nblk);
+    }
+    update_target_program(ag, "critic.Q1.0.weight", "critic_target.Q1.0.weight");
+}
+
+// ================================================================================================
+// VLSAC   (agent/vlsac/vlsac_agent.py:126-273)
+// ================================================================================================
+struct GaussBufs { float *H1, *H2, *HH; };
+
+static void gauss_tasks(rlrep_agent* ag, bool target, const std::string& m, const float* X, int ldx, int K, const GaussBufs& g,
+                        GemmTask (&out)[3]) {
+    const int Hv = ag->d.vae_hidden_dim, F = ag->d.feature_dim, B = ag->B;
+    auto W = [&](const std::string& n) { return target ? ag->T(m + n) : ag->P(m + n); };
+    out[0] = Builder::fwd(X, ldx, B, K, W(".l1.weight"), K, W(".l1.bias"), Hv, g.H1, Hv, ACT_RELU);
+    out[1] = Builder::fwd(g.H1, Hv, B, Hv, W(".l2.weight"), Hv, W(".l2.bias"), Hv, g.H2, Hv, ACT_RELU);
+    out[2] = Builder::fwd(g.H2, Hv, B, Hv, W(".mean_linear.weight"), Hv, W(".mean_linear.bias"), 2 * F, g.HH, 2 * F, ACT_NONE);
+}
+
+static void build_vlsac(Builder& b, rlrep_agent* ag) {
+    const int S = ag->d.state_dim, A = ag->d.action_dim, H = ag->d.hidden_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
+    const int F = ag->d.feature_dim, Hv = ag->d.vae_hidden_dim, N = ag->d.num_noise;
+    const int SA = S + A, KE = 2 * S + A;
+    Slot& s0 = ag->slot[0];
+    Workspace& ws = b.ws;
+    auto Pw = [&](const char* n) { return ag->P(n); };
+    auto Tw = [&](const char* n) { return ag->T(n); };
+    auto Gw = [&](const char* n) { return ag->G(n); };
+
+    // ---- feature step buffers ----
+    GaussBufs ge{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};
+    GaussBufs gf{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};
+    float* Z = ws.f((size_t)B * F); float* EZ = ws.f((size_t)B * F);
+    float* D1 = ws.f((size_t)B * Hv); float* DH = ws.f((size_t)B * (S + 1));
+    float* GDH = ws.f((size_t)B * (S + 1)); float* GD1 = ws.f((size_t)B * Hv);
+    float* GEH = ws.f((size_t)B * 2 * F); float* GFH = ws.f((size_t)B * 2 * F);
+    float* GH2e = ws.f((size_t)B * Hv); float* GH1e = ws.f((size_t)B * Hv);
+    float* GH2f = ws.f((size_t)B * Hv); float* GH1f = ws.f((size_t)B * Hv);
+    const int nblk_kl = (int)(((long long)B * F + 255) / 256), nblk_mse = (int)(((long long)B * (S + 1) + 255) / 256);
+    float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse);
+    {
+        Program& p = ag->feat_bwd;
+        GemmTask te[3], tf[3];
+        gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
+        gauss_tasks(ag, false, "f", s0.XF, SA, SA, gf, tf);
+        b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
+        b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
+        b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
+        VaeMid vm; memset(&vm, 0, sizeof(vm));
+        vm.EH = ge.HH; vm.FH = gf.HH; vm.Z = Z; vm.GEH = GEH; vm.GFH = GFH; vm.partial = part_kl;
+        vm.B = B; vm.F = F; vm.nblk = nblk_kl; vm.scale = ag->inv_batch() / (float)F; vm.step = ag->adam_step + 0;
+        vm.EZ = EZ;
+        p.stages.push_back({[=](hipStream_t st) { VaeMid q = vm; q.eps = ag->cur_eps; return rl_launch_vae_mid(&q, st); }, "vae_mid"});
+        b.fwd_stage(p, {Builder::fwd(Z, F, B, F, Pw("decoder.l1.weight"), F, Pw("decoder.l1.bias"), Hv, D1, Hv, ACT_RELU)}, "dec.l1");
+        b.fwd_stage(p, {Builder::fwd(D1, Hv, B, Hv, Pw("decoder.state_linear.weight"), Hv, Pw("decoder.state_linear.bias"), S + 1, DH, S + 1, ACT_NONE)}, "dec.heads");
+        VaeMse ms; memset(&ms, 0, sizeof(ms));
+        ms.DH = DH; ms.s2 = s0.XE ? s0.XE + SA : nullptr; ms.ld_s2 = KE; ms.r = s0.R; ms.GDH = GDH; ms.partial = part_mse;
+        ms.B = B; ms.S = S; ms.nblk = nblk_mse; ms.scale_s = ag->inv_batch() / (float)S; ms.scale_r = ag->inv_batch();
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_vae_mse(&ms, st); }, "vae_mse"});
+        b.dx_stage(p, {Builder::dx(GDH, S + 1, B, S + 1, Pw("decoder.state_linear.weight"), Hv, GD1, Hv, Hv, ACT_RELU, D1, Hv)}, "dec.heads dx");
+        {
+            GemmTask t = Builder::dx(GD1, Hv, B, Hv, Pw("decoder.l1.weight"), F, GEH, 2 * F, F, ACT_NONE, nullptr, 0);
+            t.epi = EPI_DX_REPARAM; t.aux3 = EZ; t.ldaux3 = F; t.F = F;
+            b.dx_stage(p, {t}, "dec.l1 dx -> (dmean, dlog_std)");
+        }
+        b.dx_stage(p, {Builder::dx(GEH, 2 * F, B, 2 * F, Pw("encoder.mean_linear.weight"), Hv, GH2e, Hv, Hv, ACT_RELU, ge.H2, Hv),
+                       Builder::dx(GFH, 2 * F, B, 2 * F, Pw("f.mean_linear.weight"), Hv, GH2f, Hv, Hv, ACT_RELU, gf.H2, Hv)}, "heads dx");
+        b.dx_stage(p, {Builder::dx(GH2e, Hv, B, Hv, Pw("encoder.l2.weight"), Hv, GH1e, Hv, Hv, ACT_RELU, ge.H1, Hv),
+                       Builder::dx(GH2f, Hv, B, Hv, Pw("f.l2.weight"), Hv, GH1f, Hv, Hv, ACT_RELU, gf.H1, Hv)}, "l2 dx");
+        b.dw_stage(p, {Builder::dw(GDH, S + 1, S + 1, D1, Hv, Hv, B, Gw("decoder.state_linear.weight"), Hv, Gw("decoder.state_linear.bias")),
+                       Builder::dw(GD1, Hv, Hv, Z, F, F, B, Gw("decoder.l1.weight"), F, Gw("decoder.l1.bias")),
+                       Builder::dw(GEH, 2 * F, 2 * F, ge.H2, Hv, Hv, B, Gw("encoder.mean_linear.weight"), Hv, Gw("encoder.mean_linear.bias")),
+                       Builder::dw(GFH, 2 * F, 2 * F, gf.H2, Hv, Hv, B, Gw("f.mean_linear.weight"), Hv, Gw("f.mean_linear.bias")),
+                       Builder::dw(GH2e, Hv, Hv, ge.H1, Hv, Hv, B, Gw("encoder.l2.weight"), Hv, Gw("encoder.l2.bias")),
+                       Builder::dw(GH2f, Hv, Hv, gf.H1, Hv, Hv, B, Gw("f.l2.weight"), Hv, Gw("f.l2.bias")),
+                       Builder::dw(GH1e, Hv, Hv, s0.XE, KE, KE, B, Gw("encoder.l1.weight"), KE, Gw("encoder.l1.bias")),
+                       Builder::dw(GH1f, Hv, Hv, s0.XF, SA, SA, B, Gw("f.l1.weight"), SA, Gw("f.l1.bias"))}, "feature dW");
+        // apply: Adam over (encoder, decoder, f) + Polyak f -> f_target (vlsac_agent.py:152-154, 240-242)
+        const LT& f0 = ag->L.get("f.l1.weight");
+        const LT& flast = ag->L.get("f.log_std_linear.bias");
+        const int64_t fn = flast.off + flast.rows - f0.off;
+        float* m = ag->metrics;
+        b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau,
+               {Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), m + M_KL),
+                Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), m + M_S_LOSS),
+                Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, m + M_R_LOSS),
+                Builder::fin_combine(m + M_R_LOSS, 1.f, m + M_S_LOSS, 1.f, m + M_FEAT_A),
+                Builder::fin_combine(m + M_FEAT_A, 1.f, m + M_KL, 1.f, m + M_FEAT_TOTAL)}, "adam feature + polyak f");
+    }
+
+    // ---- critic / actor shared buffers ----
+    ActorBufs ab = alloc_actor(b, B, A, Ha);
+    GaussBufs gt{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s, a)
+    GaussBufs gn{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s', a')
+    float* HmT = ws.f((size_t)2 * B * H); float* HmC = ws.f((size_t)2 * B * H);
+    float* U = ws.f((size_t)2 * B * N * H);
+    float* Et = ws.f((size_t)2 * B * H); float* Ec = ws.f((size_t)2 * B * H);
+    float* GE = ws.f((size_t)2 * B * H); float* GHm = ws.f((size_t)2 * B * H);
+    float* dq = ws.f((size_t)2 * B);
+    float* GTH = ws.f((size_t)B * 2 * F); float* GT2 = ws.f((size_t)B * Hv); float* GT1 = ws.f((size_t)B * Hv);
+    const int nblk = qhead_blocks(B);
+    float* part_q = ws.f((size_t)4 * nblk); float* part_l = ws.f(nblk);
+    const size_t BH = (size_t)B * H, BNH = (size_t)B * N * H;
+    const float* noise = Tw("critic.noise");
+
+    auto nc_task = [&](const float* HH, const float* W, const float* bias, float* Hm, float* Ubuf) {
+        NcFwdTask t; memset(&t, 0, sizeof(t));
+        t.mean = HH; t.lstd = HH ? HH + F : nullptr; t.ld_ml = 2 * F; t.noise = noise; t.W = W; t.bias = bias; t.Hm = Hm; t.U = Ubuf;
+        t.B = B; t.F = F; t.H = H; t.N = N;
+        return t;
+    };
+    auto nc_stage = [&](Program& p, std::vector<NcFwdTask> tasks, const char* what) {
+        int base_tile = 0;
+        for (auto& t : tasks) { t.tiles_h = (H + 63) / 64; t.ntiles = ((B + 7) / 8) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles; }
+        const NcFwdTask* dev = b.upload(tasks);
+        const int nt = (int)tasks.size(), total = base_tile;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_fwd(dev, nt, total, F, N, st); }, what});
+    };
+
+    // ---- critic step (vlsac_agent.py:201-237) ----
+    {
+        Program& p = ag->critic_bwd;
+        GemmTask tt[3], tn[3];
+        gauss_tasks(ag, true, "f_target", s0.XF, SA, SA, gt, tt);
+        gauss_tasks(ag, true, "f_target", s0.XF2, SA, SA, gn, tn);
+        b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), tt[0]}, "actor.l1(s') ft.l1(s,a)");
+        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), tt[1]}, "actor.l2 ft.l2");
+        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab), tt[2]}, "actor.head ft.heads");
+        policy_fwd_stage(p, ag, ab, s0.XF2 + S, SA, "policy(s')");
+        b.fwd_stage(p, {tn[0]}, "ft.l1(s',a')");
+        b.fwd_stage(p, {tn[1]}, "ft.l2");
+        b.fwd_stage(p, {tn[2]}, "ft.heads");
+        nc_stage(p, {nc_task(gn.HH, Tw("critic_target.l1.weight"), Tw("critic_target.l1.bias"), HmT, nullptr),
+                     nc_task(gn.HH, Tw("critic_target.l4.weight"), Tw("critic_target.l4.bias"), HmT + BH, nullptr),
+                     nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
+                     nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4 (target+live)");
+        b.fwd_stage(p, {Builder::fwd(HmT, H, B, H, Tw("critic_target.l2.weight"), H, Tw("critic_target.l2.bias"), H, Et, H, ACT_ELU),
+                        Builder::fwd(HmT + BH, H, B, H, Tw("critic_target.l5.weight"), H, Tw("critic_target.l5.bias"), H, Et + BH, H, ACT_ELU),
+                        Builder::fwd(HmC, H, B, H, Pw("critic.l2.weight"), H, Pw("critic.l2.bias"), H, Ec, H, ACT_ELU),
+                        Builder::fwd(HmC + BH, H, B, H, Pw("critic.l5.weight"), H, Pw("critic.l5.bias"), H, Ec + BH, H, ACT_ELU)}, "critic l2/l5");
+        QHeadCritic q; memset(&q, 0, sizeof(q));
+        q.Et[0] = Et; q.Et[1] = Et + BH; q.Ec[0] = Ec; q.Ec[1] = Ec + BH;
+        // quirk Q2: BOTH heads end in l3 (l6 is dead)
+        q.wt[0] = q.wt[1] = Tw("critic_target.l3.weight"); q.bt[0] = q.bt[1] = Tw("critic_target.l3.bias");
+        q.wc[0] = q.wc[1] = Pw("critic.l3.weight"); q.bc[0] = q.bc[1] = Pw("critic.l3.bias");
+        q.logp = ab.logp; q.R = s0.R; q.D = s0.D; q.alpha_state = ag->a.alpha_state_dev; q.gamma = ag->h.discount;
+        q.inv_batch = ag->inv_batch(); q.dq = dq; q.GE[0] = GE; q.GE[1] = GE + BH; q.partial = part_q;
+        q.B = B; q.H = H; q.nblk = nblk; q.train = 1; q.step = ag->adam_step + 1;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_critic(&q, st); }, "qhead critic"});
+        b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.l2.weight"), H, GHm, H, H, ACT_NONE, nullptr, 0),
+                       Builder::dx(GE + BH, H, B, H, Pw("critic.l5.weight"), H, GHm + BH, H, H, ACT_NONE, nullptr, 0)}, "critic l2/l5 dx");
+        b.dw_stage(p, {Builder::dw(dq, 1, 1, Ec, H, H, 2 * B, Gw("critic.l3.weight"), H, Gw("critic.l3.bias")),     // shared l3: heads stacked
+                       Builder::dw(GE, H, H, HmC, H, H, B, Gw("critic.l2.weight"), H, Gw("critic.l2.bias")),
+                       Builder::dw(GE + BH, H, H, HmC + BH, H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias"))}, "critic dW l3 l2 l5");
+        {
+            auto ncdw = [&](float* Ubuf, float* GH, float* gW, float* gb) {
+                GemmTask t = Builder::base();
+                t.A = Ubuf; t.lda = H; t.aux = GH; t.ldaux = H;
+                t.B = noise; t.ldb = F; t.aux3 = gt.HH; t.ldaux3 = 2 * F; t.aux2 = gt.HH ? gt.HH + F : nullptr; t.ldaux2 = 2 * F;
+                t.C = gW; t.ldc = F; t.out2 = gb; t.R = H; t.Cn = F; t.K = N * B; t.ncN = N; t.epi = EPI_DW; t.flags = FLAG_BIASGRAD;
+                return t;
+            };
+            b.gemm(p, LD_NCG, LD_NCX, {ncdw(U, GHm, Gw("critic.l1.weight"), Gw("critic.l1.bias")),
+                                       ncdw(U + BNH, GHm + BH, Gw("critic.l4.weight"), Gw("critic.l4.bias"))}, "noise critic dW l1/l4");
+        }
+        const float ib = 1.0f / (float)B;
+        float* m = ag->metrics;
+        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f,
+               {Builder::fin_sum(part_q + 0, nblk, 4, ib, m + M_Q1_LOSS), Builder::fin_sum(part_q + 1, nblk, 4, ib, m + M_Q2_LOSS),
+                Builder::fin_sum(part_q + 2, nblk, 4, ib, m + M_Q1), Builder::fin_sum(part_q + 3, nblk, 4, ib, m + M_Q2)}, "adam critic");
+    }
+
+    // ---- actor + temperature step (vlsac_agent.py:165-198) ----
+    {
+        Program& p = ag->actor_bwd;
+        GemmTask tt[3];
+        gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gt, tt);
+        b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
+        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
+        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
+        policy_fwd_stage(p, ag, ab, s0.XFpi + S, SA, "policy(s)");
+        b.fwd_stage(p, {tt[0]}, "ft.l1(s,a_pi)");
+        b.fwd_stage(p, {tt[1]}, "ft.l2");
+        b.fwd_stage(p, {tt[2]}, "ft.heads");
+        nc_stage(p, {nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
+                     nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4");
+        b.fwd_stage(p, {Builder::fwd(HmC, H, B, H, Pw("critic.l2.weight"), H, Pw("critic.l2.bias"), H, Ec, H, ACT_ELU),
+                        Builder::fwd(HmC + BH, H, B, H, Pw("critic.l5.weight"), H, Pw("critic.l5.bias"), H, Ec + BH, H, ACT_ELU)}, "critic l2/l5");
+        QHeadActor q; memset(&q, 0, sizeof(q));
+        q.Ec[0] = Ec; q.Ec[1] = Ec + BH; q.wc[0] = q.wc[1] = Pw("critic.l3.weight"); q.bc[0] = q.bc[1] = Pw("critic.l3.bias");
+        q.logp = ab.logp; q.alpha_state = ag->a.alpha_state_dev; q.inv_batch = ag->inv_batch(); q.target_entropy = ag->h.target_entropy;
+        q.GE[0] = GE; q.GE[1] = GE + BH; q.partial_loss = part_l; q.partial_c = ag->Gtail();
+        q.B = B; q.H = H; q.nblk = nblk; q.step = ag->adam_step + 2;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_actor(&q, st); }, "qhead actor"});
+        b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.l2.weight"), H, GHm, H, H, ACT_NONE, nullptr, 0),
+                       Builder::dx(GE + BH, H, B, H, Pw("critic.l5.weight"), H, GHm + BH, H, H, ACT_NONE, nullptr, 0)}, "critic l2/l5 dx");
+        {
+            NcDxTask t; memset(&t, 0, sizeof(t));
+            t.GH[0] = GHm; t.GH[1] = GHm + BH; t.ldgh = H; t.U[0] = U; t.U[1] = U + BNH;
+            t.W[0] = Pw("critic.l1.weight"); t.W[1] = Pw("critic.l4.weight"); t.noise = noise;
+            t.lstd = gt.HH ? gt.HH + F : nullptr; t.ld_l = 2 * F; t.G = GTH; t.ldg = 2 * F;
+            t.B = B; t.F = F; t.H = H; t.N = N; t.nheads = 2;
+            t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 7) / 8) * t.tiles_k; t.tile_base = 0;
+            std::vector<NcDxTask> tv{t};
+            const NcDxTask* dev = b.upload(tv);
+            const int total = t.ntiles;
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(dev, 1, total, st); }, "noise critic dX -> (dmean, dlog_std)"});
+        }
+        b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gt.H2, Hv)}, "ft.heads dx");
+        b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gt.H1, Hv)}, "ft.l2 dx");
+        b.dx_stage(p, {Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0)}, "ft.l1 dx(action)");
+        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA);
+        actor_apply_program(b, ag, part_l, nblk);
+    }
+    update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
+}
+
+// ================================================================================================
+// (re)build for a batch size
+// ================================================================================================
+static int build_programs(rlrep_agent* ag, int B) {
+    ag->B = B;
+    ag->ws.used = ag->ws_static;
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer})
+        p->stages.clear();
+    ag->infer_n = 0;
+    Builder b(ag);
+    const int S = ag->d.state_dim, A = ag->d.action_dim;
+    for (int i = 0; i < 2; ++i) {
+        Slot& s = ag->slot[i];
+        s.XE = b.ws.f((size_t)B * (2 * S + A)); s.XF = b.ws.f((size_t)B * (S + A)); s.XF2 = b.ws.f((size_t)B * (S + A));
+        s.XFpi = b.ws.f((size_t)B * (S + A)); s.R = b.ws.f(B); s.D = b.ws.f(B); s.filled = false;
+        if (ag->d.alg != RLREP_ALG_SPEDERSAC) break;
+    }
+    switch (ag->d.alg) {
+    case RLREP_ALG_SAC: build_sac(b, ag); break;
+    case RLREP_ALG_VLSAC: build_vlsac(b, ag); break;
+    default: rl_set_error("algorithm %d not built yet", ag->d.alg); return RLREP_ERR_ARG;
+    }
+    ag->prog_end = ag->ws.used;
+    // room for the B<=max_batch inference program (rlrep_actor_forward)
+    const size_t infer_bytes = (size_t)ag->d.max_batch * (2 * ag->d.actor_hidden_dim + 2 * ag->d.action_dim) * sizeof(float) + 8192;
+    if (!ag->ws.dry && ag->ws.used + infer_bytes > ag->ws.cap) { rl_set_error("workspace too small: need %zu bytes, have %zu", ag->ws.used + infer_bytes, ag->ws.cap); return RLREP_ERR_NOMEM; }
+    if (ag->ws.dry) ag->ws.used += infer_bytes;
+    return 0;
+}
+
+static bool check_dims(const rlrep_dims* d) {
+    if (!d || d->state_dim <= 0 || d->action_dim <= 0 || d->hidden_dim <= 0 || d->actor_hidden_dim <= 0 || d->max_batch <= 0) {
+        rl_set_error("bad dimensions"); return false;
+    }
+    if (d->alg == RLREP_ALG_VLSAC) {
+        if (d->num_noise != 4 * NC_NF_HOST) { rl_set_error("vlsac: num_noise must be %d", 4 * NC_NF_HOST); return false; }
+        if (d->feature_dim <= 0 || d->vae_hidden_dim <= 0 || (d->feature_dim & 3)) { rl_set_error("vlsac: feature_dim must be a positive multiple of 4"); return false; }
+        if ((size_t)(16 + d->num_noise) * (((d->feature_dim + 15) & ~15) + 16) * 4 > 64 * 1024) { rl_set_error("vlsac: feature_dim too large for the LDS-resident noise tables"); return false; }
+    }
+    return true;
+}
+
+static void static_state(rlrep_agent* ag) {
+    Workspace& ws = ag->ws;
+    ws.used = 0;
+    ag->steps = (int*)ws.alloc(sizeof(int) * 8);
+    ag->adam_step = ag->steps + 1;     // [4] groups
+    ag->metrics = ws.f(M_COUNT);
+    const int S = ag->d.state_dim, A = ag->d.action_dim;
+    ag->obs_in = ws.f((size_t)ag->d.max_batch * S);
+    ag->act_out = ws.f((size_t)ag->d.max_batch * A);
+    ag->ws_static = ws.used;
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int32_t rlrep_abi_version(void) { return RLREP_ABI_VERSION; }
+const char* rlrep_last_error(void) { return g_err; }
+
+int32_t rlrep_layout(const rlrep_dims* dims, rlrep_layout_info* info, rlrep_tensor_desc* descs, int32_t cap) {
+    if (!check_dims(dims) || !info) return RLREP_ERR_ARG;
+    rlrep_agent tmp;
+    tmp.d = *dims; memset(&tmp.h, 0, sizeof(tmp.h)); memset(&tmp.a, 0, sizeof(tmp.a));
+    tmp.h.world_size = 1;
+    if (!build_layout(*dims, tmp.L)) return RLREP_ERR_ARG;
+    tmp.L.align(RLREP_ARENA_PARAM); tmp.L.align(RLREP_ARENA_TARGET);
+    tmp.ws.dry = true;
+    static_state(&tmp);
+    if (build_programs(&tmp, dims->max_batch) != 0) return RLREP_ERR_ARG;
+    memset(info, 0, sizeof(*info));
+    info->param_floats = tmp.L.cur[RLREP_ARENA_PARAM];
+    info->target_floats = tmp.L.cur[RLREP_ARENA_TARGET] > 0 ? tmp.L.cur[RLREP_ARENA_TARGET] : 4;
+    info->grad_floats = info->param_floats + RLREP_GRAD_TAIL;
+    info->workspace_bytes = (int64_t)tmp.ws.used + 4096;
+    for (int g = 0; g < 4; ++g) { info->group_offset[g] = tmp.L.group_off[g]; info->group_floats[g] = tmp.L.group_n[g]; }
+    info->n_tensors = (int32_t)tmp.L.t.size();
+    info->n_metrics = M_COUNT;
+    if (descs) {
+        for (int i = 0; i < (int)tmp.L.t.size() && i < cap; ++i) {
+            const LT& e = tmp.L.t[i];
+            memset(&descs[i], 0, sizeof(descs[i]));
+            snprintf(descs[i].name, sizeof(descs[i].name), "%s", e.name.c_str());
+            descs[i].arena = e.arena; descs[i].group = e.group; descs[i].offset = e.off; descs[i].rows = e.rows; descs[i].cols = e.cols;
+        }
+    }
+    return 0;
+}
+
+int32_t rlrep_metric_names(int32_t alg, char (*names)[32], int32_t cap) {
+    const char* n[M_COUNT];
+    for (int i = 0; i < M_COUNT; ++i) n[i] = "";
+    n[M_ACTOR_LOSS] = "actor_loss"; n[M_ALPHA_LOSS] = "alpha_loss"; n[M_ALPHA] = "alpha"; n[M_Q1] = "q1"; n[M_Q2] = "q2";
+    switch (alg) {
+    case RLREP_ALG_SAC: n[M_Q1_LOSS] = "q_loss"; break;
+    case RLREP_ALG_VLSAC:
+        n[M_FEAT_TOTAL] = "vae_loss"; n[M_FEAT_A] = "ml_loss"; n[M_KL] = "kl_loss"; n[M_S_LOSS] = "s_loss"; n[M_R_LOSS] = "r_loss";
+        n[M_Q1_LOSS] = "q1_loss"; n[M_Q2_LOSS] = "q2_loss"; break;
+    case RLREP_ALG_CTRLSAC: case RLREP_ALG_SPEDERSAC:
+        n[M_FEAT_TOTAL] = "total_loss"; n[M_FEAT_A] = "model_loss"; n[M_R_LOSS] = "r_loss"; n[M_Q1_LOSS] = "q1_loss"; n[M_Q2_LOSS] = "q2_loss"; break;
+    case RLREP_ALG_DIFFSRSAC:
+        n[M_FEAT_TOTAL] = "score_loss"; n[M_Q1_LOSS] = "q_loss_reg"; n[M_Q2_LOSS] = "q_loss_noreg"; break;
+    default: return RLREP_ERR_ARG;
+    }
+    for (int i = 0; i < M_COUNT && i < cap; ++i) snprintf(names[i], 32, "%s", n[i]);
+    return M_COUNT;
+}
+
+int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, const rlrep_arenas* arenas, void* stream, rlrep_agent** out) {
+    if (!check_dims(dims) || !hyper || !arenas || !out) return RLREP_ERR_ARG;
+    if (!arenas->param_dev || !arenas->grad_dev || !arenas->exp_avg_dev || !arenas->exp_avg_sq_dev || !arenas->workspace_dev ||
+        !arenas->alpha_state_dev || !arenas->target_dev) { rl_set_error("null arena pointer"); return RLREP_ERR_ARG; }
+    rlrep_layout_info info;
+    if (rlrep_layout(dims, &info, nullptr, 0) != 0) return RLREP_ERR_ARG;
+    std::unique_ptr<rlrep_agent> ag(new rlrep_agent());
+    ag->d = *dims; ag->h = *hyper; ag->a = *arenas;
+    if (ag->h.world_size <= 0) ag->h.world_size = 1;
+    if (!build_layout(*dims, ag->L)) return RLREP_ERR_ARG;
+    ag->L.align(RLREP_ARENA_PARAM); ag->L.align(RLREP_ARENA_TARGET);
+    ag->ws.base = (char*)arenas->workspace_dev; ag->ws.cap = (size_t)info.workspace_bytes; ag->ws.dry = false;
+    static_state(ag.get());
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ag->steps, 0, sizeof(int) * 8 + 0, st);
+    if (e == hipSuccess) e = hipMemsetAsync(ag->metrics, 0, sizeof(float) * M_COUNT, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rl_set_error("create: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    int rc = build_programs(ag.get(), dims->max_batch);
+    if (rc != 0) return rc;
+    *out = ag.release();
+    return 0;
+}
+
+void rlrep_agent_destroy(rlrep_agent* agent) { delete agent; }
+
+static int ensure_batch(rlrep_agent* ag, int B) {
+    if (B <= 0 || B > ag->d.max_batch) { rl_set_error("batch %d outside (0, max_batch=%d]", B, ag->d.max_batch); return RLREP_ERR_ARG; }
+    if (B != ag->B) {
+        // table re-upload uses blocking copies: quiesce the device first (rare path: batch size changed)
+        (void)hipDeviceSynchronize();
+        return build_programs(ag, B);
+    }
+    return 0;
+}
+
+int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, void* stream) {
+    if (!ag || !bt || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("set_batch: bad argument"); return RLREP_ERR_ARG; }
+    int rc = ensure_batch(ag, bt->batch);
+    if (rc) return rc;
+    Slot& s = ag->slot[slot];
+    SlotFill p; memset(&p, 0, sizeof(p));
+    p.s = bt->state_dev; p.a = bt->action_dev; p.r = bt->reward_dev; p.s2 = bt->next_state_dev; p.d = bt->done_dev;
+    p.B = ag->B; p.S = ag->d.state_dim; p.A = ag->d.action_dim;
+    p.XE = s.XE; p.XF = s.XF; p.XF2 = s.XF2; p.XFpi = s.XFpi; p.R = s.R; p.D = s.D;
+    s.filled = true;
+    rc = rl_launch_fill_slot(&p, (hipStream_t)stream);
+    if (rc) { rl_set_error("fill_slot: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+int32_t rlrep_replay_row_floats(const rlrep_dims* d) { return d ? 2 * d->state_dim + d->action_dim + 2 : RLREP_ERR_ARG; }
+
+int32_t rlrep_replay_add(rlrep_agent* ag, float* ring_dev, int64_t capacity, int64_t ptr, const float* row_host, void* stream) {
+    if (!ag || !ring_dev || !row_host || ptr < 0 || ptr >= capacity) { rl_set_error("replay_add: bad argument"); return RLREP_ERR_ARG; }
+    const int w = 2 * ag->d.state_dim + ag->d.action_dim + 2;
+    hipError_t e = hipMemcpyAsync(ring_dev + ptr * w, row_host, sizeof(float) * w, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { rl_set_error("replay_add: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev, const int32_t* idx_dev, int32_t batch, void* stream) {
+    if (!ag || !ring_dev || !idx_dev || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("replay_sample: bad argument"); return RLREP_ERR_ARG; }
+    int rc = ensure_batch(ag, batch);
+    if (rc) return rc;
+    Slot& s = ag->slot[slot];
+    SlotFill p; memset(&p, 0, sizeof(p));
+    p.ring = ring_dev; p.idx = idx_dev; p.B = ag->B; p.S = ag->d.state_dim; p.A = ag->d.action_dim;
+    p.XE = s.XE; p.XF = s.XF; p.XF2 = s.XF2; p.XFpi = s.XFpi; p.R = s.R; p.D = s.D;
+    s.filled = true;
+    rc = rl_launch_fill_slot(&p, (hipStream_t)stream);
+    if (rc) { rl_set_error("fill_slot: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+static int philox(float* df, int32_t* di, int64_t n, int kind, float std, int hi, const int* hi_dev, uint64_t seed, uint64_t off,
+                  const int* step_dev, void* stream) {
+    if (n <= 0) return 0;
+    PhiloxFill p; memset(&p, 0, sizeof(p));
+    p.dst_f = df; p.dst_i = di; p.n = n; p.kind = kind; p.std = std; p.hi = hi; p.hi_dev = hi_dev; p.seed = seed; p.offset = off;
+    p.step_dev = step_dev; p.stream_id = 0;
+    int rc = rl_launch_philox(&p, (hipStream_t)stream);
+    if (rc) { rl_set_error("philox: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+int32_t rlrep_fill_indices(int32_t* dst, int64_t n, int32_t hi, uint64_t seed, uint64_t offset, void* stream) {
+    if (!dst || hi <= 0) { rl_set_error("fill_indices: bad argument"); return RLREP_ERR_ARG; }
+    return philox(nullptr, dst, n, 1, 0.f, hi, nullptr, seed, offset, nullptr, stream);
+}
+int32_t rlrep_fill_normal(float* dst, int64_t n, float std, uint64_t seed, uint64_t offset, void* stream) {
+    if (!dst) { rl_set_error("fill_normal: bad argument"); return RLREP_ERR_ARG; }
+    return philox(dst, nullptr, n, 0, std, 0, nullptr, seed, offset, nullptr, stream);
+}
+int32_t rlrep_fill_indices_dev(int32_t* dst, int64_t n, const int32_t* hi_dev, uint64_t seed, uint64_t offset, const int32_t* counter_dev, void* stream) {
+    if (!dst || !hi_dev) { rl_set_error("fill_indices_dev: bad argument"); return RLREP_ERR_ARG; }
+    return philox(nullptr, dst, n, 1, 0.f, 1, hi_dev, seed, offset, counter_dev, stream);
+}
+int32_t rlrep_fill_normal_dev(float* dst, int64_t n, float std, uint64_t seed, uint64_t offset, const int32_t* counter_dev, void* stream) {
+    if (!dst) { rl_set_error("fill_normal_dev: bad argument"); return RLREP_ERR_ARG; }
+    return philox(dst, nullptr, n, 0, std, 0, nullptr, seed, offset, counter_dev, stream);
+}
+const int32_t* rlrep_steps_dev(rlrep_agent* ag) { return ag ? ag->steps : nullptr; }
+
+static int run(rlrep_agent* ag, const Program& p, void* stream) {
+    if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    ag->last_launches += (int)p.stages.size();
+    return p.run((hipStream_t)stream);
+}
+#define STEP_PROLOGUE(needs_feature) \
+    if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; } \
+    if ((needs_feature) && ag->d.alg == RLREP_ALG_SAC) { rl_set_error("sac has no feature step"); return RLREP_ERR_ARG; }
+
+int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t* idx, void* stream) {
+    STEP_PROLOGUE(true)
+    if (ag->d.alg == RLREP_ALG_VLSAC && !eps) { rl_set_error("vlsac feature step needs eps[B,F]"); return RLREP_ERR_ARG; }
+    ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
+    return run(ag, ag->feat_bwd, stream);
+}
+int32_t rlrep_feature_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(true) return run(ag, ag->feat_apply, stream); }
+int32_t rlrep_critic_backward(rlrep_agent* ag, const float* eps, void* stream) {
+    STEP_PROLOGUE(false)
+    if (!eps) { rl_set_error("critic step needs eps[B,A]"); return RLREP_ERR_ARG; }
+    ag->cur_eps = eps; ag->last_launches = 0;
+    return run(ag, ag->critic_bwd, stream);
+}
+int32_t rlrep_critic_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(false) return run(ag, ag->critic_apply, stream); }
+int32_t rlrep_actor_backward(rlrep_agent* ag, const float* eps, void* stream) {
+    STEP_PROLOGUE(false)
+    if (!eps) { rl_set_error("actor step needs eps[B,A]"); return RLREP_ERR_ARG; }
+    ag->cur_eps = eps; ag->last_launches = 0;
+    return run(ag, ag->actor_bwd, stream);
+}
+int32_t rlrep_actor_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(false) return run(ag, ag->actor_apply, stream); }
+
+int32_t rlrep_feature_step(rlrep_agent* ag, const float* eps, const int32_t* idx, void* stream) {
+    int rc = rlrep_feature_backward(ag, eps, idx, stream);
+    return rc ? rc : rlrep_feature_apply(ag, stream);
+}
+int32_t rlrep_critic_step(rlrep_agent* ag, const float* eps, void* stream) {
+    int rc = rlrep_critic_backward(ag, eps, stream);
+    return rc ? rc : rlrep_critic_apply(ag, stream);
+}
+int32_t rlrep_actor_alpha_step(rlrep_agent* ag, const float* eps, void* stream) {
+    int rc = rlrep_actor_backward(ag, eps, stream);
+    return rc ? rc : rlrep_actor_apply(ag, stream);
+}
+int32_t rlrep_update_target(rlrep_agent* ag, void* stream) {
+    if (!ag) return RLREP_ERR_ARG;
+    ag->last_launches += (int)ag->upd_target.stages.size();
+    return ag->upd_target.run((hipStream_t)stream);
+}
+int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
+    if (!ag) return RLREP_ERR_ARG;
+    int rc = rl_launch_counter_inc(ag->steps, (hipStream_t)stream);
+    if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+int32_t rlrep_sync_frozen(rlrep_agent* ag, void* stream) { (void)stream; return ag ? 0 : RLREP_ERR_ARG; }
+
+int32_t rlrep_actor_forward(rlrep_agent* ag, const float* obs, int32_t n, const float* eps, float lo, float hi, float* action, void* stream) {
+    if (!ag || !obs || !action || n <= 0 || n > ag->d.max_batch) { rl_set_error("actor_forward: bad argument"); return RLREP_ERR_ARG; }
+    const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim;
+    hipStream_t st = (hipStream_t)stream;
+    if (ag->infer_n != n) {
+        (void)hipDeviceSynchronize();
+        ag->infer.stages.clear();
+        // inference scratch lives behind the step programs' buffers
+        ag->ws.used = ag->prog_end;
+        Builder b(ag);
+        float* A1 = b.ws.f((size_t)n * Ha); float* A2 = b.ws.f((size_t)n * Ha); float* AO = b.ws.f((size_t)n * 2 * A);
+        b.fwd_stage(ag->infer, {Builder::fwd(ag->obs_in, S, n, S, ag->P("actor.trunk.0.weight"), S, ag->P("actor.trunk.0.bias"), Ha, A1, Ha, ACT_ELU)}, "infer l1");
+        b.fwd_stage(ag->infer, {Builder::fwd(A1, Ha, n, Ha, ag->P("actor.trunk.2.weight"), Ha, ag->P("actor.trunk.2.bias"), Ha, A2, Ha, ACT_ELU)}, "infer l2");
+        b.fwd_stage(ag->infer, {Builder::fwd(A2, Ha, n, Ha, ag->P("actor.trunk.4.weight"), Ha, ag->P("actor.trunk.4.bias"), 2 * A, AO, 2 * A, ACT_NONE)}, "infer head");
+        PolicyFwd pf; memset(&pf, 0, sizeof(pf));
+        pf.O = AO; pf.B = n; pf.A = A; pf.act = ag->act_out; pf.ld_act = A; pf.logp = nullptr; pf.clamp = 1;
+        rlrep_agent* a2 = ag;
+        ag->infer.stages.push_back({[=](hipStream_t s2) { PolicyFwd q = pf; q.eps = a2->cur_eps; q.lo = a2->infer_lo; q.hi = a2->infer_hi; return rl_launch_policy_fwd(&q, s2); }, "infer policy"});
+        if (!ag->ws.ok()) { ag->ws.used = ag->prog_end; ag->infer.stages.clear(); rl_set_error("workspace too small for inference"); return RLREP_ERR_NOMEM; }
+        ag->infer_n = n;
+    }
+    int rc = rl_launch_copy(obs, ag->obs_in, (long long)n * S, st);
+    if (rc) { rl_set_error("actor_forward copy-in: hip error %d", rc); return RLREP_ERR_HIP; }
+    ag->cur_eps = eps; ag->infer_lo = lo; ag->infer_hi = hi;
+    rc = ag->infer.run(st);
+    if (rc) return rc;
+    rc = rl_launch_copy(ag->act_out, action, (long long)n * A, st);
+    if (rc) { rl_set_error("actor_forward copy-out: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
+int32_t rlrep_last_launch_count(rlrep_agent* ag) { return ag ? ag->last_launches : 0; }
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// gemm16: the small-matrix fp32 tile engine of the update path (gfx950).
+//
+// Every MLP layer of the hot path at batch 256 is a GEMM whose output is 256 x {1..512}: too small to
+// fill 256 CUs with large tiles, and bounded by dependent-launch latency rather than FLOPs.  The engine
+// therefore gives every workgroup ONE 16x16 output tile and splits the inner dimension over its four
+// waves (one wave per SIMD), each wave streaming its operand fragments straight from L2 into VGPRs
+// (no LDS round trip, no barrier in the main loop) and issuing v_mfma_f32_16x16x4_f32 -- exact fp32,
+// k-ordered fma chain, same peak as the VALU but one VGPR per operand.  The four partial tiles are
+// summed through 4 KB of LDS in fixed wave order (bitwise reproducible), after which each of the 256
+// threads owns exactly one output element and applies the fused epilogue (bias+activation, activation
+// derivative, reparameterisation backward, weight/bias gradient).
+//
+// One launch executes a TABLE of independent GEMMs (GemmTask[]): independent layers of one stage of a
+// step program (e.g. encoder.l1 and f.l1) share a launch, so the number of dependent launches is the
+// depth of the network graph, not its size.
+//
+// Operand fragment maps (MI355X guide, section 3): A: lane l holds A[i=l&15][k=l>>4];
+// B: lane l holds B[k=l>>4][j=l&15]; C/D: col=l&15, row=4*(l>>4)+reg.  The inner index may be permuted
+// freely as long as A and B agree, so each lane takes FOUR CONSECUTIVE inner indices (one 16-byte load in
+// the row-contiguous case) and feeds them to four successive MFMAs.
+#include "common.h"
+
+template <int LOADER>
+__device__ __forceinline__ void load_frag(const GemmTask& t, const float* __restrict__ P, int ld, int base, int lim,
+                                          int i, int k0, int K, bool vec, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    const int idx = base + i;
+    if (idx >= lim || k0 >= K) return;
+    if (LOADER == LD_ROW) {
+        const float* p = P + (size_t)idx * ld + k0;
+        if (vec) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(p);
+            v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[s];
+        }
+    } else if (LOADER == LD_COL) {
+        const float* p = P + (size_t)k0 * ld + idx;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[(size_t)s * ld];
+    } else if (LOADER == LD_NCG) {
+        // virtual dPre[(b,n), j] = GH[b,j]/N * elu'(U[(b,n), j]);  k0 is a multiple of 4 and 4 | N
+        const int b = k0 / t.ncN;
+        const float gh = t.aux[(size_t)b * t.ldaux + idx] / (float)t.ncN;
+        const float* p = P + (size_t)k0 * ld + idx;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = gh * elu_grad_from_out(p[(size_t)s * ld]);
+    } else {  // LD_NCX
+        const int b = k0 / t.ncN;
+        const int n0 = k0 - b * t.ncN;
+        const float mu = t.aux3[(size_t)b * t.ldaux3 + idx];
+        const float sg = expf(clamp_lstd(t.aux2[(size_t)b * t.ldaux2 + idx]));
+        const float* p = P + (size_t)n0 * ld + idx;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = mu + sg * p[(size_t)s * ld];
+    }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+    __shared__ float red[4][4][64];
+    __shared__ float bsum[4][16];
+
+    const int bid = blockIdx.x;
+    int ti = 0;
+    for (int q = 1; q < ntasks; ++q) if (bid >= tasks[q].tile_base) ti = q;
+    const GemmTask& t = tasks[ti];
+    const int local = bid - t.tile_base;
+    const int tr = local / t.tiles_c, tc = local - tr * t.tiles_c;
+    const int r0 = tr * 16, c0 = tc * 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int K = t.K;
+
+    const bool vecA = (LA == LD_ROW) && ((t.lda & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)t.A) & 15) == 0);
+    const bool vecB = (LB == LD_ROW) && ((t.ldb & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)t.B) & 15) == 0);
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float asum = 0.f;
+    const bool want_bias = (t.epi == EPI_DW) && (t.flags & FLAG_BIASGRAD) && (tc == 0);
+
+    float a[4], b[4], an[4], bn[4];
+    int kb = w * 16;
+    if (kb < K) {
+        load_frag<LA>(t, t.A, t.lda, r0, t.R, i, kb + 4 * kq, K, vecA, a);
+        load_frag<LB>(t, t.B, t.ldb, c0, t.Cn, i, kb + 4 * kq, K, vecB, b);
+    }
+    for (; kb < K; kb += 64) {
+        const int kn = kb + 64;
+        if (kn < K) {
+            load_frag<LA>(t, t.A, t.lda, r0, t.R, i, kn + 4 * kq, K, vecA, an);
+            load_frag<LB>(t, t.B, t.ldb, c0, t.Cn, i, kn + 4 * kq, K, vecB, bn);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+        if (want_bias) asum += (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { a[s] = an[s]; b[s] = bn[s]; }
+    }
+
+    // cross-wave reduction in fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][r][lane] = acc[r];
+    if (want_bias) {
+        asum += __shfl_xor(asum, 16, 64);
+        asum += __shfl_xor(asum, 32, 64);
+        if (lane < 16) bsum[w][lane] = asum;
+    }
+    __syncthreads();
+
+    const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
+    float v = ((red[0][oreg][ol] + red[1][oreg][ol]) + red[2][oreg][ol]) + red[3][oreg][ol];
+    v *= t.scale;
+    const int r = r0 + (ol >> 4) * 4 + oreg;
+    const int c = c0 + (ol & 15);
+
+    if (want_bias && threadIdx.x < 16 && r0 + (int)threadIdx.x < t.R) {
+        const int q = threadIdx.x;
+        t.out2[r0 + q] = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
+    }
+    if (r >= t.R || c >= t.Cn) return;
+
+    float* cp = t.C + (size_t)r * t.ldc + c;
+    switch (t.epi) {
+    case EPI_FWD: {
+        float x = v + (t.bias ? t.bias[c] : 0.f);
+        float y;
+        switch (t.act) {
+        case ACT_RELU: y = fmaxf(x, 0.f); break;
+        case ACT_ELU: y = elu_f(x); break;
+        case ACT_SIN: y = sinf(x); t.out2[(size_t)r * t.ldout2 + c] = x; break;
+        case ACT_TANH: y = tanhf(x); break;
+        default: y = x;
+        }
+        *cp = y;
+    } break;
+    case EPI_DX: {
+        float g = v;
+        if (t.act != ACT_NONE) {
+            const float s = t.aux[(size_t)r * t.ldaux + c];
+            switch (t.act) {
+            case ACT_RELU: g = s > 0.f ? g : 0.f; break;
+            case ACT_ELU: g *= elu_grad_from_out(s); break;
+            case ACT_SIN: g *= cosf(s); break;
+            case ACT_TANH: g *= (1.f - s * s); break;
+            default: break;
+            }
+        }
+        if (t.flags & FLAG_ACCUM) *cp += g; else *cp = g;
+    } break;
+    case EPI_DX_REPARAM: {
+        // aux3 = eps * exp(log_std) * clamp-mask, written by vae_mid_kernel
+        *cp += v;
+        cp[t.F] += v * t.aux3[(size_t)r * t.ldaux3 + c];
+    } break;
+    case EPI_DW:
+    default:
+        if (t.flags & FLAG_ACCUM) *cp += v; else *cp = v;
+        break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------
+extern "C" int rl_launch_gemm16(int la, int lb, const GemmTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st) {
+    if (total_tiles <= 0) return 0;
+    dim3 g(total_tiles), b(256);
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW>), g, b, 0, st, tasks_dev, ntasks);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL>), g, b, 0, st, tasks_dev, ntasks);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL>), g, b, 0, st, tasks_dev, ntasks);
+    else if (la == LD_NCG && lb == LD_NCX) hipLaunchKernelGGL((gemm16_kernel<LD_NCG, LD_NCX>), g, b, 0, st, tasks_dev, ntasks);
+    else return -1;
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,92 @@
+// Kernel parameter blocks shared by the device code and the host-side program builder.
+#pragma once
+#include <stdint.h>
+
+struct SlotFill {
+    const float* ring; const int* idx;                       // ring gather (ring != nullptr) ...
+    const float *s, *a, *r, *s2, *d;                         // ... or five separate arrays
+    int B, S, A;
+    float *XE, *XF, *XF2, *XFpi, *R, *D;                    // slot buffers
+};
+
+struct PhiloxFill {
+    float* dst_f; int* dst_i; long long n;
+    int kind;                  // 0: normal*std -> dst_f ; 1: uniform int in [0,hi) -> dst_i
+    float std; int hi; const int* hi_dev;
+    unsigned long long seed, offset; const int* step_dev; uint32_t stream_id;
+};
+
+struct PolicyFwd {
+    const float* O; const float* eps; int B, A;
+    float* act; int ld_act; float* logp;
+    int clamp; float lo, hi;
+};
+
+struct PolicyBwd {
+    const float* O; const float* eps; const float* act; int ld_act;
+    const float* dA; int ld_dA;
+    const double* alpha_state; float inv_batch;
+    float* G; int B, A;
+};
+
+struct VaeMid {
+    const float* EH; const float* FH; const float* eps;
+    float* Z; float* EZ; float* GEH; float* GFH; float* partial;
+    int B, F, nblk; float scale; int* step;
+};
+
+struct VaeMse {
+    const float* DH; const float* s2; int ld_s2; const float* r;
+    float* GDH; float* partial; int B, S, nblk; float scale_s, scale_r;
+};
+
+struct QHeadCritic {
+    const float* Et[2]; const float* Ec[2];
+    const float* wt[2]; const float* bt[2]; const float* wc[2]; const float* bc[2];
+    const float* logp; const float* R; const float* D;
+    const double* alpha_state; float gamma, inv_batch;
+    float* dq; float* GE[2]; float* partial;
+    int B, H, nblk, train; int* step;
+};
+
+struct QHeadActor {
+    const float* Ec[2]; const float* wc[2]; const float* bc[2];
+    const float* logp; const double* alpha_state; float inv_batch, target_entropy;
+    float* GE[2]; float* partial_loss; float* partial_c;
+    int B, H, nblk; int* step;
+};
+
+enum FinKind : int { FIN_SUM = 0, FIN_COMBINE = 1, FIN_ALPHA = 2, FIN_COPY = 3 };
+
+struct FinTask {
+    int kind;
+    const float* partials; int count, stride; float scale;
+    float* out; float* out2;
+    const float* in_a; const float* in_b; float scale_b;
+    double* alpha_state; float lr, beta1, beta2, eps; int learn;
+};
+
+// vlsac noise critic (noisecritic.hip)
+struct NcFwdTask {
+    const float* mean; const float* lstd; int ld_ml;
+    const float* noise;              // [N, F]
+    const float* W; const float* bias;   // [H, F], [H]
+    float* Hm;                       // [B, H]
+    float* U;                        // [B*N, H] elu outputs (nullptr: not stored)
+    int B, F, H, N;
+    int tiles_h, tile_base, ntiles;
+};
+
+struct NcDxTask {
+    const float* GH[2]; int ldgh;    // dL/dHm per head [B, H]
+    const float* U[2];               // elu outputs per head [B*N, H]
+    const float* W[2];               // [H, F]
+    const float* noise;              // [N, F]
+    const float* lstd; int ld_l;     // raw log-std [B, F]
+    float* G; int ldg;               // out [B, 2F]: (dmean | dlog_std)
+    int B, F, H, N, nheads;
+    int tiles_k, tile_base, ntiles;
+};
+
+
+#define NC_NF_HOST 5   /* vlsac noise rows / 4 (noisecritic.hip NC_NF) */

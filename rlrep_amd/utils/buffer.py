@@ -1,0 +1,122 @@
+"""Device-resident replay ring behind the reference's `ReplayBuffer` API (utils/buffer.py:13-48).
+
+The reference keeps five float64 NumPy rings on the host and, on every `sample`, fancy-indexes them,
+casts to float32 and issues five host->device copies.  Here the transitions live on the MI355X as ONE
+fp32 array-of-structs ring, row = [state | action | next_state | reward | done] (2S+A+2 floats), so that
+a minibatch is gathered by a single kernel (`rlrep_replay_sample`) and the concatenated network inputs
+[s,a,s'] / [s,a] are prefixes of a row.  `add` stages rows in pinned host memory and flushes them with
+one asynchronous copy per `sample`/`flush`.
+"""
+import collections
+import numpy as np
+import torch
+
+Batch = collections.namedtuple('Batch', ['state', 'action', 'reward', 'next_state', 'done'])
+
+
+class ReplayBuffer(object):
+    def __init__(self, state_dim, action_dim, max_size=int(1e6), device=None, stage_rows=4096):
+        self.max_size = int(max_size)
+        self.ptr = 0
+        self.size = 0
+        self.state_dim, self.action_dim = int(state_dim), int(action_dim)
+        self.row = 2 * self.state_dim + self.action_dim + 2
+        self.device = torch.device(device if device is not None else
+                                   ('cuda' if torch.cuda.is_available() else 'cpu'))
+        self.ring = torch.zeros(self.max_size, self.row, dtype=torch.float32, device=self.device)
+        pin = self.device.type == 'cuda'
+        self._stage = torch.zeros(min(stage_rows, self.max_size), self.row, dtype=torch.float32, pin_memory=pin)
+        self._stage_np = self._stage.numpy()
+        self._staged = 0            # rows waiting in the staging buffer
+        self._stage_start = 0       # ring position of the first staged row
+        self._copy_done = None
+        self._size_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._size_pushed = -1
+
+    # ---- reference API ------------------------------------------------------------------------
+    def add(self, state, action, next_state, reward, done):
+        if self._staged == self._stage.shape[0]:
+            self.flush()
+        if self._copy_done is not None:
+            self._copy_done.synchronize()
+            self._copy_done = None
+        if self._staged == 0:
+            self._stage_start = self.ptr
+        S, A = self.state_dim, self.action_dim
+        r = self._stage_np[self._staged]
+        r[:S] = state
+        r[S:S + A] = action
+        r[S + A:2 * S + A] = next_state
+        r[2 * S + A] = reward
+        r[2 * S + A + 1] = done
+        self._staged += 1
+        self.ptr = (self.ptr + 1) % self.max_size
+        self.size = min(self.size + 1, self.max_size)
+
+    def flush(self):
+        n = self._staged
+        if n == 0:
+            return
+        a = self._stage_start
+        first = min(n, self.max_size - a)
+        self.ring[a:a + first].copy_(self._stage[:first], non_blocking=True)
+        if first < n:
+            self.ring[:n - first].copy_(self._stage[first:n], non_blocking=True)
+        if self.device.type == 'cuda':
+            self._copy_done = torch.cuda.Event()
+            self._copy_done.record()
+        self._staged = 0
+
+    def load(self, state, action, next_state, reward, done):
+        """Bulk-fill the ring (synthetic benchmarks / tests)."""
+        n = int(len(state))
+        rows = np.concatenate([np.asarray(state, np.float32).reshape(n, -1), np.asarray(action, np.float32).reshape(n, -1),
+                               np.asarray(next_state, np.float32).reshape(n, -1), np.asarray(reward, np.float32).reshape(n, 1),
+                               np.asarray(done, np.float32).reshape(n, 1)], axis=1)
+        self.ring[:n].copy_(torch.from_numpy(rows))
+        self.size, self.ptr, self._staged = n, n % self.max_size, 0
+
+    def size_dev(self):
+        """int32[1] device scalar holding `size` (read by the graph-replayed index generator)."""
+        if self._size_pushed != self.size:
+            self._size_dev.fill_(self.size)
+            self._size_pushed = self.size
+        return self._size_dev
+
+    def sample(self, batch_size):
+        self.flush()
+        ind = torch.from_numpy(np.random.randint(0, self.size, size=batch_size)).to(self.device)
+        return self.gather(ind)
+
+    def gather(self, ind):
+        S, A = self.state_dim, self.action_dim
+        rows = self.ring[ind.long()]
+        return Batch(state=rows[:, :S].contiguous(), action=rows[:, S:S + A].contiguous(),
+                     reward=rows[:, 2 * S + A:2 * S + A + 1].contiguous(),
+                     next_state=rows[:, S + A:2 * S + A].contiguous(),
+                     done=rows[:, 2 * S + A + 1:2 * S + A + 2].contiguous())
+
+    # public array attributes of the reference, materialised on demand (read-only copies)
+    def _col(self, a, b):
+        self.flush()
+        return self.ring[:, a:b].cpu().numpy().astype(np.float64)
+
+    @property
+    def state(self):
+        return self._col(0, self.state_dim)
+
+    @property
+    def action(self):
+        return self._col(self.state_dim, self.state_dim + self.action_dim)
+
+    @property
+    def next_state(self):
+        return self._col(self.state_dim + self.action_dim, 2 * self.state_dim + self.action_dim)
+
+    @property
+    def reward(self):
+        return self._col(2 * self.state_dim + self.action_dim, 2 * self.state_dim + self.action_dim + 1)
+
+    @property
+    def done(self):
+        return self._col(2 * self.state_dim + self.action_dim + 1, 2 * self.state_dim + self.action_dim + 2)
