@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- gradient steps/sec of the rl-rep update hot path on MI355X.
+
+One "step" = one `agent.train(buffer, 256)` of BASELINE.json config[1]: vlsac on HalfCheetah-v3 dims
+(S=17, A=6, hidden=256, feature_dim=256, batch=256): 4 feature (VAE-ELBO) steps + critic step + actor and
+temperature step + Polyak updates = 7 optimizer steps, on synthetic replay resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+N>1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
+one process per GPU, replay sharded (each rank owns its own ring and samples its own B=256 minibatch:
+weak scaling, global batch 256*N), gradients of every optimizer step all-reduced over RCCL/xGMI.
+
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel and a
+`cpu_baseline` object (the CPU oracle timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+WORKLOADS = {
+    # name: (agent, S, A, B, ctor kwargs)
+    'vlsac_halfcheetah_f256_b256': ('vlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
+    'sac_halfcheetah_b256': ('sac', 17, 6, 256, dict(hidden_dim=256)),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+REPLAY_N = 65536
+
+
+class Space:
+    def __init__(self, A):
+        self.low, self.high = -np.ones(A, np.float32), np.ones(A, np.float32)
+
+
+def make_agent(alg, S, A, B, kw):
+    if alg == 'vlsac':
+        from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent as cls
+    else:
+        from rlrep_amd.agent.sac.sac_agent import SACAgent as cls
+    return cls(state_dim=S, action_dim=A, action_space=Space(A), max_batch=B, **kw)
+
+
+def synth_buffer(S, A, seed):
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    data = synth.replay(S, A, REPLAY_N, seed=seed)
+    buf = ReplayBuffer(S, A, max_size=REPLAY_N)
+    buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+    return buf, data
+
+
+def dominant_kernel_roofline(agent, B, F, H, reps=200):
+    """Time the heaviest launch of the path (the noise-critic first layer of the critic step: four
+    [B*20 x F] x [F x H] products, target+live heads) standalone with HIP events on the launch stream."""
+    core = agent.core
+    names = core.stages(2)
+    st = [i for i, n in enumerate(names) if n.startswith('noise critic l1/l4')]
+    if not st:
+        return None
+    s = st[0]
+    for _ in range(20):
+        core.run_stage(2, s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        core.run_stage(2, s)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = 4 * 2.0 * (B * 20) * F * H          # algorithmic: 4 heads x 2*M*K*N
+    achieved = flops / (us * 1e-6) / 1e12
+    return {'bound': 'mfma', 'kernel': 'nc_fwd_kernel (critic step, 4 heads)', 'achieved': round(achieved, 2),
+            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            'traffic': None, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
+
+
+def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
+    """The CPU oracle (a from-scratch port of the reference's PyTorch-CPU path, oracle/) on this box."""
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    from oracle.shapes import param_shapes
+    import synth
+    torch.set_num_threads(threads)
+    init = synth.init_like(param_shapes(alg, S, A, **kw))
+    for k in list(init):
+        for s_, d_ in (('critic', 'critic_target'), ('f', 'f_target')):
+            if k.startswith(s_ + '.') and (d_ + k[len(s_):]) in init:
+                init[d_ + k[len(s_):]] = init[k].copy()
+    if alg == 'vlsac':
+        init['critic_target.noise'] = init['critic.noise'].copy()
+    init['log_alpha'] = np.log(np.float64(0.1))
+    o = make_oracle(alg, S, A, init, **kw)
+    rs = np.random.RandomState(5)
+    F = kw.get('feature_dim', 0)
+    nf = kw.get('extra_feature_steps', 0) + 1 if alg != 'sac' else 0
+    tens = {k: torch.from_numpy(v) for k, v in data.items()}
+
+    def one():
+        idx = [rs.randint(0, REPLAY_N, size=B) for _ in range(max(nf, 1))]
+        eps = [torch.from_numpy(rs.standard_normal((B, F)).astype(np.float32)) for _ in range(nf)]
+        eps += [torch.from_numpy(rs.standard_normal((B, A)).astype(np.float32)) for _ in range(2)]
+        o.train([gather_batch(tens, i) for i in idx], eps)
+
+    for _ in range(3):
+        one()
+    t0 = time.time()
+    n = 0
+    while n < 200 and time.time() - t0 < budget_s:
+        one()
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(n / dt, 3), 'unit': 'train()/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} train() calls of the same workload on the CPU oracle (torch {torch.__version__} CPU, '
+                      f'{threads} threads of {os.cpu_count()} logical cores), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--workload', default='vlsac_halfcheetah_f256_b256', choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-threads', type=int, default=int(os.environ.get('RLREP_CPU_THREADS', 16)))
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
+                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if args.no_graph:
+        os.environ['RLREP_GRAPH'] = '0'
+
+    alg, S, A, B, kw = WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    agent = make_agent(alg, S, A, B, kw)
+    buf, data = synth_buffer(S, A, seed=rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent.train(buf, B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.train(buf, B)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    info = agent.train(buf, B)
+    finite = all(np.isfinite(v) for v in info.values())
+
+    if rank == 0:
+        value = world * args.steps / dt
+        out = {
+            'metric': 'gradient steps/sec (encoder+critic+actor) at batch=256',
+            'value': round(value, 2), 'unit': 'train()/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'agent': alg, 'state_dim': S, 'action_dim': A, 'batch_per_gpu': B,
+                       'global_batch': B * world, 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
+                       'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
+                       'parallelism': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)' if world > 1 else 'single GPU',
+                       'hipgraph': bool(agent.use_graph and world == 1)},
+            'optimizer_steps_per_sec': round(value * (7 if alg == 'vlsac' else 3), 1),
+            'samples_per_sec': round(value * B, 1),
+            'metrics_finite': bool(finite),
+        }
+        if alg == 'vlsac':
+            out['roofline'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
+            # whole-train() view: algorithmic 10.59 GFLOP per train() per GPU
+            out['train_flop_frac_of_fp32_peak'] = round(10.59e9 * value / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        if world == 1 and not args.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(alg, S, A, B, kw, data, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

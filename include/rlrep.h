@@ -221,6 +221,13 @@ int32_t rlrep_actor_forward(rlrep_agent* agent, const float* obs_dev, int32_t n,
 /* device float array of n_metrics slots, valid after the stream has passed the producing step */
 const float* rlrep_metrics_dev(rlrep_agent* agent);
 
+/* Profiling hook: launch stage `stage` of step program `program` once (0 feature_bwd, 1 feature_apply,
+ * 2 critic_bwd, 3 critic_apply, 4 actor_bwd, 5 actor_apply, 6 update_target); its inputs are whatever the
+ * previous full step left in the workspace.  rlrep_stage_count/_name enumerate the stages. */
+int32_t rlrep_stage_count(rlrep_agent* agent, int32_t program);
+const char* rlrep_stage_name(rlrep_agent* agent, int32_t program, int32_t stage);
+int32_t rlrep_run_stage(rlrep_agent* agent, int32_t program, int32_t stage, void* stream);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 

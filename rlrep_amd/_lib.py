@@ -101,6 +101,9 @@ def _load():
         'rlrep_actor_apply': (i32, [vp, vp]),
         'rlrep_sync_frozen': (i32, [vp, vp]),
         'rlrep_actor_forward': (i32, [vp, vp, i32, vp, f32, f32, vp, vp]),
+        'rlrep_stage_count': (i32, [vp, i32]),
+        'rlrep_stage_name': (C.c_char_p, [vp, i32, i32]),
+        'rlrep_run_stage': (i32, [vp, i32, i32, vp]),
         'rlrep_metrics_dev': (vp, [vp]),
         'rlrep_last_launch_count': (i32, [vp]),
     }

@@ -232,5 +232,12 @@ class HipCore:
         names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]
         return LazyInfo(names, snap)
 
+    def stages(self, program):
+        n = lib.rlrep_stage_count(self.h, program)
+        return [lib.rlrep_stage_name(self.h, program, i).decode() for i in range(n)]
+
+    def run_stage(self, program, stage):
+        check(lib.rlrep_run_stage(self.h, program, stage, _stream()), 'run_stage')
+
     def launch_count(self):
         return lib.rlrep_last_launch_count(self.h)

@@ -15,9 +15,7 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIN = 3, ACT_TANH 
 // operand loaders of the tile GEMM (see gemm16.hip)
 enum Load : int {
     LD_ROW = 0,     // element(i, kk) = P[(base+i)*ld + kk]           (inner index contiguous)
-    LD_COL = 1,     // element(i, kk) = P[kk*ld + base+i]              (inner index is the row)
-    LD_NCG = 2,     // vlsac noise critic, virtual dPre: GH[b, base+i]/N * elu'(U[kk, base+i]),  b = kk / N
-    LD_NCX = 3      // vlsac noise critic, virtual input: mean[b,c] + exp(clamp(lstd[b,c])) * noise[kk % N, c]
+    LD_COL = 1      // element(i, kk) = P[kk*ld + base+i]              (inner index is the row)
 };
 
 // epilogues
@@ -49,6 +47,9 @@ struct GemmTask {
     int F;               // EPI_DX_REPARAM: column offset of the log-std half
     float scale;         // multiplies acc before the epilogue (1.0 default)
 };
+
+#define GEMM_MAX_TASKS 8
+struct GemmBatch { int ntasks; int pad; GemmTask t[GEMM_MAX_TASKS]; };   // passed by value (kernarg segment)
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)

@@ -13,9 +13,10 @@
 
 // kernel launchers (defined next to the kernels)
 extern "C" {
-int rl_launch_gemm16(int la, int lb, const GemmTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st);
-int rl_launch_nc_fwd(const NcFwdTask* tasks_dev, int ntasks, int total_tiles, int F, int N, hipStream_t st);
-int rl_launch_nc_dx(const NcDxTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st);
+int rl_launch_gemm16(int la, int lb, const GemmBatch* gb, int total_tiles, hipStream_t st);
+int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st);
+int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
+int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);
 int rl_launch_fill_slot(const SlotFill* p, hipStream_t st);
 int rl_launch_philox(const PhiloxFill* p, hipStream_t st);
 int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st);

@@ -148,9 +148,12 @@ struct Builder {
             const int tr = (t.R + 15) / 16;
             t.ntiles = tr * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles;
         }
-        const GemmTask* dev = upload(tasks);
-        const int nt = (int)tasks.size(), total = base_tile;
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, dev, nt, total, st); }, what});
+        if (tasks.size() > GEMM_MAX_TASKS) { fprintf(stderr, "rlrep: too many tasks in stage %s\n", what); abort(); }
+        GemmBatch gb; memset(&gb, 0, sizeof(gb));
+        gb.ntasks = (int)tasks.size();
+        for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
+        const int total = base_tile;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
     }
     void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
     void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
@@ -458,11 +461,18 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         return t;
     };
     auto nc_stage = [&](Program& p, std::vector<NcFwdTask> tasks, const char* what) {
+        // 4 batch rows per workgroup while that keeps <= 4 workgroups per CU, else 8
+        const int g2 = ((long long)tasks.size() * ((B + 3) / 4) * ((H + 63) / 64) <= 1024) ? 1 : 2;
+        NcFwdBatch nb; memset(&nb, 0, sizeof(nb));
         int base_tile = 0;
-        for (auto& t : tasks) { t.tiles_h = (H + 63) / 64; t.ntiles = ((B + 7) / 8) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles; }
-        const NcFwdTask* dev = b.upload(tasks);
-        const int nt = (int)tasks.size(), total = base_tile;
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_fwd(dev, nt, total, F, N, st); }, what});
+        nb.ntasks = (int)tasks.size();
+        for (size_t q = 0; q < tasks.size(); ++q) {
+            NcFwdTask& t = tasks[q];
+            t.tiles_h = (H + 63) / 64; t.ntiles = ((B + 4 * g2 - 1) / (4 * g2)) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles;
+            nb.t[q] = t;
+        }
+        const int total = base_tile;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_fwd(&nb, total, g2, st); }, what});
     };
 
     // ---- critic step (vlsac_agent.py:201-237) ----
@@ -501,15 +511,19 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(GE, H, H, HmC, H, H, B, Gw("critic.l2.weight"), H, Gw("critic.l2.bias")),
                        Builder::dw(GE + BH, H, H, HmC + BH, H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias"))}, "critic dW l3 l2 l5");
         {
-            auto ncdw = [&](float* Ubuf, float* GH, float* gW, float* gb) {
-                GemmTask t = Builder::base();
-                t.A = Ubuf; t.lda = H; t.aux = GH; t.ldaux = H;
-                t.B = noise; t.ldb = F; t.aux3 = gt.HH; t.ldaux3 = 2 * F; t.aux2 = gt.HH ? gt.HH + F : nullptr; t.ldaux2 = 2 * F;
-                t.C = gW; t.ldc = F; t.out2 = gb; t.R = H; t.Cn = F; t.K = N * B; t.ncN = N; t.epi = EPI_DW; t.flags = FLAG_BIASGRAD;
-                return t;
+            NcDwBatch nb; memset(&nb, 0, sizeof(nb));
+            nb.ntasks = 2;
+            int base_tile = 0;
+            auto ncdw = [&](int q, float* Ubuf, float* GH, float* gW, float* gb) {
+                NcDwTask& t = nb.t[q];
+                t.U = Ubuf; t.GH = GH; t.ldgh = H; t.mean = gt.HH; t.lstd = gt.HH ? gt.HH + F : nullptr; t.ld_ml = 2 * F;
+                t.noise = noise; t.gW = gW; t.gb = gb; t.B = B; t.F = F; t.H = H; t.N = N;
+                t.tiles_k = (F + 31) / 32; t.ntiles = ((H + 15) / 16) * t.tiles_k; t.tile_base = base_tile; base_tile += t.ntiles;
             };
-            b.gemm(p, LD_NCG, LD_NCX, {ncdw(U, GHm, Gw("critic.l1.weight"), Gw("critic.l1.bias")),
-                                       ncdw(U + BNH, GHm + BH, Gw("critic.l4.weight"), Gw("critic.l4.bias"))}, "noise critic dW l1/l4");
+            ncdw(0, U, GHm, Gw("critic.l1.weight"), Gw("critic.l1.bias"));
+            ncdw(1, U + BNH, GHm + BH, Gw("critic.l4.weight"), Gw("critic.l4.bias"));
+            const int total = base_tile;
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dw(&nb, total, st); }, "noise critic dW l1/l4"});
         }
         const float ib = 1.0f / (float)B;
         float* m = ag->metrics;
@@ -548,11 +562,8 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             t.W[0] = Pw("critic.l1.weight"); t.W[1] = Pw("critic.l4.weight"); t.noise = noise;
             t.lstd = gt.HH ? gt.HH + F : nullptr; t.ld_l = 2 * F; t.G = GTH; t.ldg = 2 * F;
             t.B = B; t.F = F; t.H = H; t.N = N; t.nheads = 2;
-            t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 7) / 8) * t.tiles_k; t.tile_base = 0;
-            std::vector<NcDxTask> tv{t};
-            const NcDxTask* dev = b.upload(tv);
-            const int total = t.ntiles;
-            p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(dev, 1, total, st); }, "noise critic dX -> (dmean, dlog_std)"});
+            t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 3) / 4) * t.tiles_k; t.tile_base = 0;
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(&t, st); }, "noise critic dX -> (dmean, dlog_std)"});
         }
         b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gt.H2, Hv)}, "ft.heads dx");
         b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gt.H1, Hv)}, "ft.l2 dx");
@@ -860,6 +871,30 @@ int32_t rlrep_actor_forward(rlrep_agent* ag, const float* obs, int32_t n, const 
     if (rc) return rc;
     rc = rl_launch_copy(ag->act_out, action, (long long)n * A, st);
     if (rc) { rl_set_error("actor_forward copy-out: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+static Program* prog_of(rlrep_agent* ag, int id) {
+    switch (id) {
+    case 0: return &ag->feat_bwd; case 1: return &ag->feat_apply; case 2: return &ag->critic_bwd; case 3: return &ag->critic_apply;
+    case 4: return &ag->actor_bwd; case 5: return &ag->actor_apply; case 6: return &ag->upd_target; default: return nullptr;
+    }
+}
+int32_t rlrep_stage_count(rlrep_agent* ag, int32_t program) {
+    Program* p = ag ? prog_of(ag, program) : nullptr;
+    return p ? (int32_t)p->stages.size() : RLREP_ERR_ARG;
+}
+const char* rlrep_stage_name(rlrep_agent* ag, int32_t program, int32_t stage) {
+    Program* p = ag ? prog_of(ag, program) : nullptr;
+    if (!p || stage < 0 || stage >= (int)p->stages.size()) return nullptr;
+    return p->stages[stage].what;
+}
+int32_t rlrep_run_stage(rlrep_agent* ag, int32_t program, int32_t stage, void* stream) {
+    Program* p = ag ? prog_of(ag, program) : nullptr;
+    if (!p || stage < 0 || stage >= (int)p->stages.size()) { rl_set_error("run_stage: bad program/stage"); return RLREP_ERR_ARG; }
+    if (!ag->slot[0].filled) { rl_set_error("run_stage before a full step"); return RLREP_ERR_STATE; }
+    int rc = p->stages[stage].run((hipStream_t)stream);
+    if (rc) { rl_set_error("stage '%s' failed: hip error %d", p->stages[stage].what, rc); return RLREP_ERR_HIP; }
     return 0;
 }
 

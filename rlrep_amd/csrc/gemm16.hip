@@ -21,7 +21,7 @@
 #include "common.h"
 
 template <int LOADER>
-__device__ __forceinline__ void load_frag(const GemmTask& t, const float* __restrict__ P, int ld, int base, int lim,
+__device__ __forceinline__ void load_frag(const float* __restrict__ P, int ld, int base, int lim,
                                           int i, int k0, int K, bool vec, float (&v)[4]) {
     v[0] = v[1] = v[2] = v[3] = 0.f;
     const int idx = base + i;
@@ -35,37 +35,25 @@ __device__ __forceinline__ void load_frag(const GemmTask& t, const float* __rest
 #pragma unroll
             for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[s];
         }
-    } else if (LOADER == LD_COL) {
+    } else {  // LD_COL
         const float* p = P + (size_t)k0 * ld + idx;
 #pragma unroll
         for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[(size_t)s * ld];
-    } else if (LOADER == LD_NCG) {
-        // virtual dPre[(b,n), j] = GH[b,j]/N * elu'(U[(b,n), j]);  k0 is a multiple of 4 and 4 | N
-        const int b = k0 / t.ncN;
-        const float gh = t.aux[(size_t)b * t.ldaux + idx] / (float)t.ncN;
-        const float* p = P + (size_t)k0 * ld + idx;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = gh * elu_grad_from_out(p[(size_t)s * ld]);
-    } else {  // LD_NCX
-        const int b = k0 / t.ncN;
-        const int n0 = k0 - b * t.ncN;
-        const float mu = t.aux3[(size_t)b * t.ldaux3 + idx];
-        const float sg = expf(clamp_lstd(t.aux2[(size_t)b * t.ldaux2 + idx]));
-        const float* p = P + (size_t)n0 * ld + idx;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = mu + sg * p[(size_t)s * ld];
     }
 }
 
+// The task table travels BY VALUE in the kernel-argument segment: the workgroup finds its task and all of its
+// pointers with scalar loads from kernarg memory, one dependent round trip fewer than a table in global memory.
 template <int LA, int LB>
-__global__ __launch_bounds__(256) void gemm16_kernel(const GemmTask* __restrict__ tasks, int ntasks) {
+__global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     __shared__ float red[4][4][64];
     __shared__ float bsum[4][16];
 
     const int bid = blockIdx.x;
     int ti = 0;
-    for (int q = 1; q < ntasks; ++q) if (bid >= tasks[q].tile_base) ti = q;
-    const GemmTask& t = tasks[ti];
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    const GemmTask& t = gb.t[ti];
     const int local = bid - t.tile_base;
     const int tr = local / t.tiles_c, tc = local - tr * t.tiles_c;
     const int r0 = tr * 16, c0 = tc * 16;
@@ -80,23 +68,21 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmTask* __restrict_
     float asum = 0.f;
     const bool want_bias = (t.epi == EPI_DW) && (t.flags & FLAG_BIASGRAD) && (tc == 0);
 
-    float a[4], b[4], an[4], bn[4];
-    int kb = w * 16;
-    if (kb < K) {
-        load_frag<LA>(t, t.A, t.lda, r0, t.R, i, kb + 4 * kq, K, vecA, a);
-        load_frag<LB>(t, t.B, t.ldb, c0, t.Cn, i, kb + 4 * kq, K, vecB, b);
-    }
-    for (; kb < K; kb += 64) {
-        const int kn = kb + 64;
-        if (kn < K) {
-            load_frag<LA>(t, t.A, t.lda, r0, t.R, i, kn + 4 * kq, K, vecA, an);
-            load_frag<LB>(t, t.B, t.ldb, c0, t.Cn, i, kn + 4 * kq, K, vecB, bn);
+    // wave w owns the 16-wide inner chunks w, w+4, w+8, ...; four chunks (all of K <= 256) are loaded
+    // back to back before the first MFMA so that their L2 latencies overlap
+    for (int kb = w * 16; kb < K; kb += 256) {
+        float a[4][4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_frag<LA>(t.A, t.lda, r0, t.R, i, kb + 64 * u + 4 * kq, K, vecA, a[u]);
+            load_frag<LB>(t.B, t.ldb, c0, t.Cn, i, kb + 64 * u + 4 * kq, K, vecB, b[u]);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-        if (want_bias) asum += (a[0] + a[1]) + (a[2] + a[3]);
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { a[s] = an[s]; b[s] = bn[s]; }
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s], acc, 0, 0, 0);
+            if (want_bias) asum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+        }
     }
 
     // cross-wave reduction in fixed order
@@ -164,13 +150,12 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmTask* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
-extern "C" int rl_launch_gemm16(int la, int lb, const GemmTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st) {
+extern "C" int rl_launch_gemm16(int la, int lb, const GemmBatch* gb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     dim3 g(total_tiles), b(256);
-    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW>), g, b, 0, st, tasks_dev, ntasks);
-    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL>), g, b, 0, st, tasks_dev, ntasks);
-    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL>), g, b, 0, st, tasks_dev, ntasks);
-    else if (la == LD_NCG && lb == LD_NCX) hipLaunchKernelGGL((gemm16_kernel<LD_NCG, LD_NCX>), g, b, 0, st, tasks_dev, ntasks);
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW>), g, b, 0, st, *gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL>), g, b, 0, st, *gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL>), g, b, 0, st, *gb);
     else return -1;
     return (int)hipGetLastError();
 }

@@ -77,6 +77,19 @@ struct NcFwdTask {
     int tiles_h, tile_base, ntiles;
 };
 
+#define NC_MAX_TASKS 4
+struct NcFwdBatch { int ntasks; NcFwdTask t[NC_MAX_TASKS]; };     // passed by value (kernarg)
+
+struct NcDwTask {
+    const float* U; const float* GH; int ldgh;     // [B*N, H], [B, H]
+    const float* mean; const float* lstd; int ld_ml;
+    const float* noise;                             // [N, F]
+    float* gW; float* gb;                           // [H, F], [H]
+    int B, F, H, N;
+    int tiles_k, tile_base, ntiles;
+};
+struct NcDwBatch { int ntasks; NcDwTask t[2]; };
+
 struct NcDxTask {
     const float* GH[2]; int ldgh;    // dL/dHm per head [B, H]
     const float* U[2];               // elu outputs per head [B*N, H]

@@ -3,38 +3,75 @@
 //   x[(b,n), :] = mean[b,:] + exp(log_std[b,:]) * noise[n,:]           (n < N = 20, never materialised)
 //   Hm[b, j]    = (1/N) * sum_n elu( W[j,:] . x[(b,n),:] + bias[j] )
 //
-// This is 63 % of the FLOPs of a vlsac train() (ten [B*20 x 256] x [256 x 256] products).  The [B*20,F]
-// input is generated on the fly inside the A-operand fragment from three small LDS-resident tables
-// (8 rows of mean, 8 rows of sigma, the 20 noise rows), so HBM/L2 only see W and the outputs.
+// Ten [B*20 x 256] x [256 x 256] products per train() = 63 % of a vlsac train()'s FLOPs, in three forms:
+//   nc_fwd_kernel : Hm (and the elu outputs U for the backward passes)
+//   nc_dx_kernel  : dL/d(mean, log_std)  (actor step; both heads summed)
+//   nc_dw_kernel  : dL/dW, dL/dbias      (critic step)
+// All three run on v_mfma_f32_16x16x4_f32 (exact fp32).  The [B*20, F] input and the [B*20, H] gradient
+// of the pre-activation are generated on the fly inside the operand fragments; HBM/L2 only see W, U and
+// the [B, .] tensors.
 //
-// Row mapping trick: the 16 rows of an MFMA A-fragment f are assigned (b' = row>>2, n = 4*f + (row&3)).
-// With the 16x16x4 C/D map (row = 4*(lane>>4) + reg) every lane then owns ALL 20 noise rows of one batch
-// row b' = lane>>4 across its 5 accumulator fragments, so the mean over the noise axis is a purely
-// in-register sum of 20 values: no shuffles, no LDS, no atomics.
+// Row-mapping trick (fwd, dx): the 16 rows of MFMA A-fragment f are assigned (b' = row>>2, n = 4*f + (row&3)).
+// With the 16x16x4 C/D map (row = 4*(lane>>4) + reg) every lane then owns ALL 20 noise rows of batch row
+// b' = lane>>4 across its 5 accumulator fragments: the reductions over the noise axis (mean of elu; dmean,
+// dlog_std) are in-register sums of 20 values -- no shuffles, no LDS, no atomics.
+//
+// Occupancy: f32 MFMA issues at 32 cycles/SIMD, so the kernels are MFMA-bound only if every SIMD always has
+// an MFMA ready.  Each kernel is shaped to put >= 2 waves on every SIMD of all 256 CUs and prefetches the
+// next step's operands into registers before issuing the current step's MFMAs.
 #include "common.h"
 #include "kparams.h"
 
 #define NC_NF 5          // N / 4 accumulator fragments per batch-row group (N = 20)
-#define NC_G2 2          // batch-row groups (of 4 rows) per wave -> 8 batch rows per workgroup
 
 extern __shared__ __attribute__((aligned(16))) float nc_smem[];
 
-__global__ __launch_bounds__(256) void nc_fwd_kernel(const NcFwdTask* __restrict__ tasks, int ntasks) {
+__device__ __forceinline__ void ld4(const float* p, bool vec, int valid, float (&v)[4]) {
+    // valid = number of in-range elements (0..4)
+    if (vec && valid == 4) { f32x4 x = *reinterpret_cast<const f32x4*>(p); v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
+    else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = (s < valid) ? p[s] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward.  workgroup = 4 waves = (4*G2 batch rows) x 20 noise rows x 64 hidden units; K loop over F.
+// ------------------------------------------------------------------------------------------------
+template <int G2>
+__global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
     const int bid = blockIdx.x;
     int ti = 0;
-    for (int q = 1; q < ntasks; ++q) if (bid >= tasks[q].tile_base) ti = q;
-    const NcFwdTask& t = tasks[ti];
+#pragma unroll
+    for (int q = 1; q < NC_MAX_TASKS; ++q) if (q < nb.ntasks && bid >= nb.t[q].tile_base) ti = q;
+    const NcFwdTask& t = nb.t[ti];
     const int local = bid - t.tile_base;
     const int tb = local / t.tiles_h, th = local - tb * t.tiles_h;
-    const int b0 = tb * 8, n0 = th * 64;
+    const int RB = 4 * G2;
+    const int b0 = tb * RB, n0 = th * 64;
     const int F = t.F, H = t.H, N = t.N;
     const int Fp = (F + 15) & ~15;
     const int LDS_LD = Fp + 16;
-    float* mu_s = nc_smem;                    // [8][LDS_LD]
-    float* sg_s = mu_s + 8 * LDS_LD;          // [8][LDS_LD]
-    float* nz_s = sg_s + 8 * LDS_LD;          // [N][LDS_LD]
+    float* mu_s = nc_smem;                     // [RB][LDS_LD]
+    float* sg_s = mu_s + RB * LDS_LD;          // [RB][LDS_LD]
+    float* nz_s = sg_s + RB * LDS_LD;          // [N][LDS_LD]
 
-    for (int e = threadIdx.x; e < 8 * Fp; e += 256) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int bp = m16 >> 2, nn = m16 & 3;
+    const int col = n0 + 16 * w + m16;
+    const bool colok = col < H;
+    const bool vecW = ((F & 3) == 0) && ((((uintptr_t)t.W) & 15) == 0);
+    const float* wrow = t.W + (size_t)(colok ? col : 0) * F;
+
+    // first W fragment is in flight while the tables are staged
+    float wv[4], wn[4];
+    {
+        const int k0 = 4 * kq;
+        const int valid = colok ? max(0, min(4, F - k0)) : 0;
+        ld4(wrow + k0, vecW, valid, wv);
+    }
+    for (int e = threadIdx.x; e < RB * Fp; e += 256) {
         const int rr = e / Fp, k = e - rr * Fp;
         float m = 0.f, s = 0.f;
         if (b0 + rr < t.B && k < F) {
@@ -50,33 +87,22 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(const NcFwdTask* __restrict
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int m16 = lane & 15, kq = lane >> 4;
-    const int bp = m16 >> 2, nn = m16 & 3;
-    const int col = n0 + 16 * w + m16;           // B-operand column (hidden unit) of this lane
-    const bool colok = col < H;
-    const bool vecW = ((F & 3) == 0) && ((((uintptr_t)t.W) & 15) == 0);
-
-    f32x4 acc[NC_G2][NC_NF];
+    f32x4 acc[G2][NC_NF];
 #pragma unroll
-    for (int g = 0; g < NC_G2; ++g)
+    for (int g = 0; g < G2; ++g)
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f) acc[g][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int kb = 0; kb < Fp; kb += 16) {
         const int k0 = kb + 4 * kq;
-        float wv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (colok && k0 < F) {
-            const float* wp = t.W + (size_t)col * F + k0;
-            if (vecW) { f32x4 x = *reinterpret_cast<const f32x4*>(wp); wv[0] = x[0]; wv[1] = x[1]; wv[2] = x[2]; wv[3] = x[3]; }
-            else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) if (k0 + s < F) wv[s] = wp[s];
-            }
+        {   // prefetch the next W fragment
+            const int k1 = k0 + 16;
+            const int valid = colok ? max(0, min(4, F - k1)) : 0;
+            if (kb + 16 < Fp) ld4(wrow + k1, vecW, valid, wn);
         }
-        f32x4 mu4[NC_G2], sg4[NC_G2], nz4[NC_NF];
+        f32x4 mu4[G2], sg4[G2], nz4[NC_NF];
 #pragma unroll
-        for (int g = 0; g < NC_G2; ++g) {
+        for (int g = 0; g < G2; ++g) {
             mu4[g] = *reinterpret_cast<const f32x4*>(&mu_s[(4 * g + bp) * LDS_LD + k0]);
             sg4[g] = *reinterpret_cast<const f32x4*>(&sg_s[(4 * g + bp) * LDS_LD + k0]);
         }
@@ -85,17 +111,19 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(const NcFwdTask* __restrict
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int g = 0; g < NC_G2; ++g)
+            for (int g = 0; g < G2; ++g)
 #pragma unroll
                 for (int f = 0; f < NC_NF; ++f)
                     acc[g][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaf(sg4[g][s], nz4[f][s], mu4[g][s]), wv[s], acc[g][f], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wv[s] = wn[s];
     }
 
     if (!colok) return;
     const float bj = t.bias[col];
     const float invN = 1.0f / (float)N;
 #pragma unroll
-    for (int g = 0; g < NC_G2; ++g) {
+    for (int g = 0; g < G2; ++g) {
         const int b = b0 + 4 * g + (lane >> 4);
         if (b >= t.B) continue;
         float sum = 0.f;
@@ -111,111 +139,207 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(const NcFwdTask* __restrict
     }
 }
 
-// dL/d(mean, log_std) of the noise critic's first layer, both heads summed (actor step).
-__global__ __launch_bounds__(256) void nc_dx_kernel(const NcDxTask* __restrict__ tasks, int ntasks) {
+// ------------------------------------------------------------------------------------------------
+// dL/d(mean, log_std), both heads (actor step).
+// workgroup = 8 waves: waves 0-3 head 0, waves 4-7 head 1; wave (w&3) owns 16 feature columns;
+// tile = 4 batch rows x 20 noise rows x 64 feature columns; inner loop over the H hidden units of the head.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
+    __shared__ float red[4][NC_NF][4][64];      // 20 KB: head-1 partial accumulators
     const int bid = blockIdx.x;
-    int ti = 0;
-    for (int q = 1; q < ntasks; ++q) if (bid >= tasks[q].tile_base) ti = q;
-    const NcDxTask& t = tasks[ti];
-    const int local = bid - t.tile_base;
-    const int tb = local / t.tiles_k, tk = local - tb * t.tiles_k;
-    const int b0 = tb * 8, kc0 = tk * 64;
+    const int tb = bid / t.tiles_k, tk = bid - tb * t.tiles_k;
+    const int b0 = tb * 4, kc0 = tk * 64;
     const int F = t.F, H = t.H, N = t.N;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w8 = threadIdx.x >> 6;
+    const int w = w8 & 3, h = (t.nheads > 1) ? (w8 >> 2) : 0;
+    const bool idle = (t.nheads == 1) && (w8 >= 4);
     const int m16 = lane & 15, kq = lane >> 4;
     const int bp = m16 >> 2, nn = m16 & 3;
-    const int kcol = kc0 + 16 * w + m16;          // feature column of this lane (B operand / output)
+    const int kcol = kc0 + 16 * w + m16;
     const bool colok = kcol < F;
     const float invN = 1.0f / (float)N;
     const bool vecG = ((H & 3) == 0) && ((t.ldgh & 3) == 0);
+    const int b = b0 + bp;
+    const bool rowok = b < t.B;
 
-    f32x4 acc[NC_G2][NC_NF];
+    f32x4 acc[NC_NF];
 #pragma unroll
-    for (int g = 0; g < NC_G2; ++g)
-#pragma unroll
-        for (int f = 0; f < NC_NF; ++f) acc[g][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < NC_NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int h = 0; h < t.nheads; ++h) {
-        const float* GH = t.GH[h];
-        const float* U = t.U[h];
-        const float* W = t.W[h];
-        for (int jb = 0; jb < H; jb += 16) {
+    if (!idle) {
+        const float* GH = t.GH[h] + (size_t)(rowok ? b : 0) * t.ldgh;
+        const float* U = t.U[h] + (size_t)(rowok ? b : 0) * N * H;
+        const float* W = t.W[h] + (colok ? kcol : 0);
+        float gh[4], u[NC_NF][4], wv[4], ghn[4], un[NC_NF][4], wn[4];
+        auto load = [&](int jb, float (&g_)[4], float (&u_)[NC_NF][4], float (&w_)[4]) {
             const int j0 = jb + 4 * kq;
-            float wv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (colok) {
+            const int valid = max(0, min(4, H - j0));
+            ld4(GH + j0, vecG, rowok ? valid : 0, g_);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) if (j0 + s < H) wv[s] = W[(size_t)(j0 + s) * F + kcol];
-            }
-            float av[NC_G2][NC_NF][4];
+            for (int f = 0; f < NC_NF; ++f) ld4(U + (size_t)(4 * f + nn) * H + j0, vecG, rowok ? valid : 0, u_[f]);
 #pragma unroll
-            for (int g = 0; g < NC_G2; ++g) {
-                const int b = b0 + 4 * g + bp;
-                float gh[4] = {0.f, 0.f, 0.f, 0.f};
-                const bool rok = (b < t.B) && (j0 < H);
-                if (rok) {
-                    const float* gp = GH + (size_t)b * t.ldgh + j0;
-                    if (vecG) { f32x4 x = *reinterpret_cast<const f32x4*>(gp); gh[0] = x[0]; gh[1] = x[1]; gh[2] = x[2]; gh[3] = x[3]; }
-                    else {
+            for (int s = 0; s < 4; ++s) w_[s] = (colok && j0 + s < H) ? W[(size_t)(j0 + s) * F] : 0.f;
+        };
+        load(0, gh, u, wv);
+        for (int jb = 0; jb < H; jb += 16) {
+            if (jb + 16 < H) load(jb + 16, ghn, un, wn);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) if (j0 + s < H) gh[s] = gp[s];
-                    }
-                }
+            for (int s = 0; s < 4; ++s) {
+                const float gs = gh[s] * invN;
 #pragma unroll
-                for (int f = 0; f < NC_NF; ++f) {
-                    float u[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (rok) {
-                        const float* up = U + ((size_t)b * N + 4 * f + nn) * H + j0;
-                        if (vecG) { f32x4 x = *reinterpret_cast<const f32x4*>(up); u[0] = x[0]; u[1] = x[1]; u[2] = x[2]; u[3] = x[3]; }
-                        else {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) if (j0 + s < H) u[s] = up[s];
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) av[g][f][s] = gh[s] * invN * elu_grad_from_out(u[s]);
-                }
+                for (int f = 0; f < NC_NF; ++f)
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs * elu_grad_from_out(u[f][s]), wv[s], acc[f], 0, 0, 0);
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                gh[s] = ghn[s]; wv[s] = wn[s];
 #pragma unroll
-                for (int g = 0; g < NC_G2; ++g)
-#pragma unroll
-                    for (int f = 0; f < NC_NF; ++f)
-                        acc[g][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][f][s], wv[s], acc[g][f], 0, 0, 0);
+                for (int f = 0; f < NC_NF; ++f) u[f][s] = un[f][s];
+            }
         }
     }
-
-    if (!colok) return;
-    float nz[NC_NF][4];
-#pragma unroll
-    for (int f = 0; f < NC_NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nz[f][r] = t.noise[(size_t)(4 * f + r) * F + kcol];
-#pragma unroll
-    for (int g = 0; g < NC_G2; ++g) {
-        const int b = b0 + 4 * g + (lane >> 4);
-        if (b >= t.B) continue;
-        float dmu = 0.f, dls = 0.f;
+    if (w8 >= 4) {
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { dmu += acc[g][f][r]; dls = fmaf(acc[g][f][r], nz[f][r], dls); }
-        const float l = t.lstd[(size_t)b * t.ld_l + kcol];
-        t.G[(size_t)b * t.ldg + kcol] = dmu;
-        t.G[(size_t)b * t.ldg + F + kcol] = dls * expf(clamp_lstd(l)) * lstd_mask(l);
+            for (int r = 0; r < 4; ++r) red[w][f][r][lane] = acc[f][r];
+    }
+    __syncthreads();
+    if (w8 >= 4 || !colok) return;
+    const int bo = b0 + (lane >> 4);
+    if (bo >= t.B) return;
+    float dmu = 0.f, dls = 0.f;
+#pragma unroll
+    for (int f = 0; f < NC_NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[f][r] + red[w][f][r][lane];
+            dmu += v;
+            dls = fmaf(v, t.noise[(size_t)(4 * f + r) * F + kcol], dls);
+        }
+    const float l = t.lstd[(size_t)bo * t.ld_l + kcol];
+    t.G[(size_t)bo * t.ldg + kcol] = dmu;
+    t.G[(size_t)bo * t.ldg + F + kcol] = dls * expf(clamp_lstd(l)) * lstd_mask(l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dL/dW[j,k] = sum_{(b,n)} dPre[(b,n), j] * x[(b,n), k],   dL/dbias[j] = sum dPre[(b,n), j]
+//   dPre[(b,n), j] = GH[b,j]/N * elu'(U[(b,n), j])
+// workgroup = 8 waves sharing one 16(j) x 32(k) output tile; the 20*B inner rows are dealt to the waves in
+// chunks of 16 rows (lane group kq takes 4 consecutive rows = one batch row b, four noise rows);
+// partial tiles are summed through LDS in fixed wave order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
+    __shared__ float red[8][2][4][64];          // 16 KB
+    __shared__ float bsum[8][16];
+    __shared__ float nz_s[32 * 33];             // noise[n][32 cols of this tile], ld 33
+    const int bid = blockIdx.x;
+    const int ti = (nb.ntasks > 1 && bid >= nb.t[1].tile_base) ? 1 : 0;
+    const NcDwTask& t = nb.t[ti];
+    const int local = bid - t.tile_base;
+    const int tj = local / t.tiles_k, tk = local - tj * t.tiles_k;
+    const int j0 = tj * 16, k0 = tk * 32;
+    const int F = t.F, H = t.H, N = t.N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int j = j0 + i;
+    const bool jok = j < H;
+    const int kc[2] = {k0 + i, k0 + 16 + i};
+    const bool kok[2] = {kc[0] < F, kc[1] < F};
+    const int M = N * t.B;                       // inner length
+    const float invN = 1.0f / (float)N;
+    const bool want_bias = (tk == 0);
+
+    for (int e = threadIdx.x; e < N * 32; e += 512) {
+        const int n = e >> 5, c = e & 31;
+        nz_s[n * 33 + c] = (k0 + c < F) ? t.noise[(size_t)n * F + k0 + c] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    float asum = 0.f;
+    float uv[4], ghv, mu[2], sg[2], uvn[4], ghn = 0.f, mun[2], sgn[2];
+    int n0 = 0, n0n = 0;
+    auto load = [&](int c, float (&u_)[4], float& g_, float (&m_)[2], float (&s_)[2], int& n0_) {
+        const int r0 = 16 * c + 4 * kq;          // first of this lane's 4 inner rows
+        const bool ok = r0 < M;                  // M is a multiple of 4
+        const int b = ok ? r0 / N : 0;
+        n0_ = ok ? r0 - b * N : 0;
+        g_ = (ok && jok) ? t.GH[(size_t)b * t.ldgh + j] * invN : 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) u_[s] = (ok && jok) ? t.U[(size_t)(r0 + s) * H + j] : 1.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            m_[f] = (ok && kok[f]) ? t.mean[(size_t)b * t.ld_ml + kc[f]] : 0.f;
+            s_[f] = (ok && kok[f]) ? expf(clamp_lstd(t.lstd[(size_t)b * t.ld_ml + kc[f]])) : 0.f;
+        }
+    };
+    const int nchunks = (M + 15) / 16;
+    int c = w;
+    if (c < nchunks) load(c, uv, ghv, mu, sg, n0);
+    for (; c < nchunks; c += 8) {
+        if (c + 8 < nchunks) load(c + 8, uvn, ghn, mun, sgn, n0n);
+        float a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = ghv * elu_grad_from_out(uv[s]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], fmaf(sg[f], nz_s[(n0 + s) * 33 + 16 * f + i], mu[f]), acc[f], 0, 0, 0);
+        if (want_bias) asum += (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) uv[s] = uvn[s];
+        ghv = ghn; n0 = n0n;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) { mu[f] = mun[f]; sg[f] = sgn[f]; }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][f][r][lane] = acc[f][r];
+    if (want_bias) {
+        asum += __shfl_xor(asum, 16, 64);
+        asum += __shfl_xor(asum, 32, 64);
+        if (lane < 16) bsum[w][lane] = asum;
+    }
+    __syncthreads();
+    {   // 512 threads -> 16 x 32 outputs
+        const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;     // q: 0..7 -> (frag = q>>2, reg = q&3)
+        const int f = q >> 2, r = q & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) v += red[ww][f][r][ol];
+        const int row = j0 + (ol >> 4) * 4 + r, colk = k0 + 16 * f + (ol & 15);
+        if (row < H && colk < F) t.gW[(size_t)row * F + colk] = v;
+    }
+    if (want_bias && threadIdx.x < 16 && j0 + (int)threadIdx.x < H) {
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) v += bsum[ww][threadIdx.x];
+        t.gb[j0 + threadIdx.x] = v;
     }
 }
 
-extern "C" int rl_launch_nc_fwd(const NcFwdTask* tasks_dev, int ntasks, int total_tiles, int F, int N, hipStream_t st) {
+// ------------------------------------------------------------------------------------------------
+extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st) {
     if (total_tiles <= 0) return 0;
+    const int F = nb->t[0].F, N = nb->t[0].N;
     const int Fp = (F + 15) & ~15;
-    const size_t lds = (size_t)(16 + N) * (Fp + 16) * sizeof(float);
-    hipLaunchKernelGGL(nc_fwd_kernel, dim3(total_tiles), dim3(256), lds, st, tasks_dev, ntasks);
+    const size_t lds = (size_t)(8 * g2 + N) * (Fp + 16) * sizeof(float);
+    if (g2 == 1) hipLaunchKernelGGL(nc_fwd_kernel<1>, dim3(total_tiles), dim3(256), lds, st, *nb);
+    else hipLaunchKernelGGL(nc_fwd_kernel<2>, dim3(total_tiles), dim3(256), lds, st, *nb);
     return (int)hipGetLastError();
 }
 
-extern "C" int rl_launch_nc_dx(const NcDxTask* tasks_dev, int ntasks, int total_tiles, hipStream_t st) {
+extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
+    if (t->ntiles <= 0) return 0;
+    hipLaunchKernelGGL(nc_dx_kernel, dim3(t->ntiles), dim3(512), 0, st, *t);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    hipLaunchKernelGGL(nc_dx_kernel, dim3(total_tiles), dim3(256), 0, st, tasks_dev, ntasks);
+    hipLaunchKernelGGL(nc_dw_kernel, dim3(total_tiles), dim3(512), 0, st, *nb);
     return (int)hipGetLastError();
 }
