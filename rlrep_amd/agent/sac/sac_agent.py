@@ -102,6 +102,7 @@ class SACAgent(object):
         self._bufs = {}
         self._graph = None
         self._inject = None
+        self._pool = None
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
 
     # parameter initialisation (values only; layout is the library's)
@@ -213,7 +214,38 @@ class SACAgent(object):
         end = lay.grad_floats if with_tail else o + n
         dist.all_reduce(self.core.grads[o:end])
 
+    # ---- pooled noise: ALL sample indices and ALL standard-normal noise of one train() come from two
+    # Philox launches into two contiguous buffers (instead of one launch per tensor) ---------------------
+    def _plan(self, B):
+        """(index draws, normal draws) of one train(): lists of keys / (key, shape), in consumption order."""
+        return ['s0'], [('crit', (B, self.action_dim)), ('act', (B, self.action_dim))]
+
+    def _fill_pools(self, buffer, B, g):
+        idx_keys, eps_specs = self._plan(B)
+        ni = len(idx_keys) * B
+        ne = sum(int(np.prod(sh)) for _, sh in eps_specs)
+        ipool = self._buf('pool_idx', (ni,), torch.int32)
+        epool = self._buf('pool_eps', (ne,))
+        if g:
+            self.core.fill_indices_dev(ipool, buffer.size_dev(), self._seed, 1 << 40)
+            self.core.fill_normal_dev(epool, 1.0, self._seed, 2 << 40)
+        else:
+            self._ctr += 1
+            self.core.fill_indices(ipool, buffer.size, self._seed, (1 << 40) + self._ctr)
+            self.core.fill_normal(epool, 1.0, self._seed, (2 << 40) + self._ctr)
+        self._pool = {}
+        for q, k in enumerate(idx_keys):
+            self._pool['idx_' + k] = ipool[q * B:(q + 1) * B]
+        o = 0
+        for k, sh in eps_specs:
+            n = int(np.prod(sh))
+            self._pool['eps_' + k] = epool[o:o + n].view(*sh)
+            o += n
+
     def _sample_into(self, buffer, B, key, slot=0, g=False):
+        if self._inject is None and self._pool is not None and ('idx_' + key) in self._pool:
+            self.core.sample(slot, buffer.ring, self._pool['idx_' + key], B)
+            return
         if self._inject is not None:
             idx = torch.as_tensor(np.asarray(self._inject['idx'].pop(0)), dtype=torch.int32).to(self.core.device)
             self._bufs['idx_' + key] = idx
@@ -229,6 +261,8 @@ class SACAgent(object):
         return (zlib.crc32(key.encode()) % 65521 + 1) << 32
 
     def _eps(self, key, shape, g=False, std=1.0):
+        if self._inject is None and self._pool is not None and ('eps_' + key) in self._pool and std == 1.0:
+            return self._pool['eps_' + key]
         if self._inject is not None:
             e = self._inject['eps'].pop(0)
             t = torch.as_tensor(np.asarray(e)).to(self.core.device)
@@ -246,6 +280,9 @@ class SACAgent(object):
         """The whole train() as a sequence of stream-ordered library calls (captured into a hipGraph when g)."""
         c, W = self.core, self.world_size
         c.begin_train()
+        self._pool = None
+        if self._inject is None:
+            self._fill_pools(buffer, B, g)
         nf = self._feature_iters()
         for i in range(nf):
             self._feature_once(buffer, B, i, g)

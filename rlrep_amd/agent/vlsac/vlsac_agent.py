@@ -58,6 +58,12 @@ class VLSACAgent(SACAgent):
     def _feature_iters(self):
         return self.extra_feature_steps + 1
 
+    def _plan(self, B):
+        n = self._feature_iters()
+        return ([f'f{i}' for i in range(n)],
+                [(f'feat{i}', (B, self.feature_dim)) for i in range(n)] +
+                [('crit', (B, self.action_dim)), ('act', (B, self.action_dim))])
+
     def _feature_once(self, buffer, B, i, g):
         c = self.core
         self._sample_into(buffer, B, f'f{i}', 0, g)

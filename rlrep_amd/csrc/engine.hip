@@ -448,6 +448,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     float* Et = ws.f((size_t)2 * B * H); float* Ec = ws.f((size_t)2 * B * H);
     float* GE = ws.f((size_t)2 * B * H); float* GHm = ws.f((size_t)2 * B * H);
     float* dq = ws.f((size_t)2 * B);
+    float* SIG = ws.f((size_t)B * F);
     float* GTH = ws.f((size_t)B * 2 * F); float* GT2 = ws.f((size_t)B * Hv); float* GT1 = ws.f((size_t)B * Hv);
     const int nblk = qhead_blocks(B);
     float* part_q = ws.f((size_t)4 * nblk); float* part_l = ws.f(nblk);
@@ -488,10 +489,14 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         b.fwd_stage(p, {tn[0]}, "ft.l1(s',a')");
         b.fwd_stage(p, {tn[1]}, "ft.l2");
         b.fwd_stage(p, {tn[2]}, "ft.heads");
-        nc_stage(p, {nc_task(gn.HH, Tw("critic_target.l1.weight"), Tw("critic_target.l1.bias"), HmT, nullptr),
-                     nc_task(gn.HH, Tw("critic_target.l4.weight"), Tw("critic_target.l4.bias"), HmT + BH, nullptr),
-                     nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
-                     nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4 (target+live)");
+        {
+            NcFwdTask live1 = nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U);
+            live1.sigma_out = SIG;
+            nc_stage(p, {nc_task(gn.HH, Tw("critic_target.l1.weight"), Tw("critic_target.l1.bias"), HmT, nullptr),
+                         nc_task(gn.HH, Tw("critic_target.l4.weight"), Tw("critic_target.l4.bias"), HmT + BH, nullptr),
+                         live1,
+                         nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4 (target+live)");
+        }
         b.fwd_stage(p, {Builder::fwd(HmT, H, B, H, Tw("critic_target.l2.weight"), H, Tw("critic_target.l2.bias"), H, Et, H, ACT_ELU),
                         Builder::fwd(HmT + BH, H, B, H, Tw("critic_target.l5.weight"), H, Tw("critic_target.l5.bias"), H, Et + BH, H, ACT_ELU),
                         Builder::fwd(HmC, H, B, H, Pw("critic.l2.weight"), H, Pw("critic.l2.bias"), H, Ec, H, ACT_ELU),
@@ -516,7 +521,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             int base_tile = 0;
             auto ncdw = [&](int q, float* Ubuf, float* GH, float* gW, float* gb) {
                 NcDwTask& t = nb.t[q];
-                t.U = Ubuf; t.GH = GH; t.ldgh = H; t.mean = gt.HH; t.lstd = gt.HH ? gt.HH + F : nullptr; t.ld_ml = 2 * F;
+                t.U = Ubuf; t.GH = GH; t.ldgh = H; t.mean = gt.HH; t.sigma = SIG; t.ld_ml = 2 * F;
                 t.noise = noise; t.gW = gW; t.gb = gb; t.B = B; t.F = F; t.H = H; t.N = N;
                 t.tiles_k = (F + 31) / 32; t.ntiles = ((H + 15) / 16) * t.tiles_k; t.tile_base = base_tile; base_tile += t.ntiles;
             };

@@ -68,6 +68,21 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     float asum = 0.f;
     const bool want_bias = (t.epi == EPI_DW) && (t.flags & FLAG_BIASGRAD) && (tc == 0);
 
+    // this thread's output element is known up front: issue the epilogue's operand loads (bias, saved
+    // activation, accumulate-into value) NOW so their latency overlaps the operand stream
+    const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
+    const int r = r0 + (ol >> 4) * 4 + oreg;
+    const int c = c0 + (ol & 15);
+    const bool inb = (r < t.R) && (c < t.Cn);
+    float* cp = t.C + (size_t)r * t.ldc + c;
+    float e0 = 0.f, cold = 0.f, cold2 = 0.f;
+    if (inb) {
+        if (t.epi == EPI_FWD) { if (t.bias) e0 = t.bias[c]; }
+        else if (t.epi == EPI_DX) { if (t.act != ACT_NONE) e0 = t.aux[(size_t)r * t.ldaux + c]; if (t.flags & FLAG_ACCUM) cold = *cp; }
+        else if (t.epi == EPI_DX_REPARAM) { e0 = t.aux3[(size_t)r * t.ldaux3 + c]; cold = *cp; cold2 = cp[t.F]; }
+        else if (t.flags & FLAG_ACCUM) cold = *cp;
+    }
+
     // wave w owns the 16-wide inner chunks w, w+4, w+8, ...; four chunks (all of K <= 256) are loaded
     // back to back before the first MFMA so that their L2 latencies overlap
     for (int kb = w * 16; kb < K; kb += 256) {
@@ -95,22 +110,18 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     }
     __syncthreads();
 
-    const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
     float v = ((red[0][oreg][ol] + red[1][oreg][ol]) + red[2][oreg][ol]) + red[3][oreg][ol];
     v *= t.scale;
-    const int r = r0 + (ol >> 4) * 4 + oreg;
-    const int c = c0 + (ol & 15);
 
     if (want_bias && threadIdx.x < 16 && r0 + (int)threadIdx.x < t.R) {
         const int q = threadIdx.x;
         t.out2[r0 + q] = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
     }
-    if (r >= t.R || c >= t.Cn) return;
+    if (!inb) return;
 
-    float* cp = t.C + (size_t)r * t.ldc + c;
     switch (t.epi) {
     case EPI_FWD: {
-        float x = v + (t.bias ? t.bias[c] : 0.f);
+        const float x = v + e0;
         float y;
         switch (t.act) {
         case ACT_RELU: y = fmaxf(x, 0.f); break;
@@ -123,26 +134,23 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     } break;
     case EPI_DX: {
         float g = v;
-        if (t.act != ACT_NONE) {
-            const float s = t.aux[(size_t)r * t.ldaux + c];
-            switch (t.act) {
-            case ACT_RELU: g = s > 0.f ? g : 0.f; break;
-            case ACT_ELU: g *= elu_grad_from_out(s); break;
-            case ACT_SIN: g *= cosf(s); break;
-            case ACT_TANH: g *= (1.f - s * s); break;
-            default: break;
-            }
+        switch (t.act) {
+        case ACT_RELU: g = e0 > 0.f ? g : 0.f; break;
+        case ACT_ELU: g *= elu_grad_from_out(e0); break;
+        case ACT_SIN: g *= cosf(e0); break;
+        case ACT_TANH: g *= (1.f - e0 * e0); break;
+        default: break;
         }
-        if (t.flags & FLAG_ACCUM) *cp += g; else *cp = g;
+        *cp = cold + g;
     } break;
-    case EPI_DX_REPARAM: {
-        // aux3 = eps * exp(log_std) * clamp-mask, written by vae_mid_kernel
-        *cp += v;
-        cp[t.F] += v * t.aux3[(size_t)r * t.ldaux3 + c];
-    } break;
+    case EPI_DX_REPARAM:
+        // e0 = eps * exp(log_std) * clamp-mask, written by vae_mid_kernel
+        *cp = cold + v;
+        cp[t.F] = cold2 + v * e0;
+        break;
     case EPI_DW:
     default:
-        if (t.flags & FLAG_ACCUM) *cp += v; else *cp = v;
+        *cp = cold + v;
         break;
     }
 }

@@ -73,6 +73,7 @@ struct NcFwdTask {
     const float* W; const float* bias;   // [H, F], [H]
     float* Hm;                       // [B, H]
     float* U;                        // [B*N, H] elu outputs (nullptr: not stored)
+    float* sigma_out;                // [B, F] exp(clamp(log_std)) (nullptr: not stored)
     int B, F, H, N;
     int tiles_h, tile_base, ntiles;
 };
@@ -82,7 +83,7 @@ struct NcFwdBatch { int ntasks; NcFwdTask t[NC_MAX_TASKS]; };     // passed by v
 
 struct NcDwTask {
     const float* U; const float* GH; int ldgh;     // [B*N, H], [B, H]
-    const float* mean; const float* lstd; int ld_ml;
+    const float* mean; const float* sigma; int ld_ml;   // mean [B,F] (row stride ld_ml), sigma [B,F] dense
     const float* noise;                             // [N, F]
     float* gW; float* gb;                           // [H, F], [H]
     int B, F, H, N;

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         }
         mu_s[rr * LDS_LD + k] = m;
         sg_s[rr * LDS_LD + k] = s;
+        if (t.sigma_out && th == 0 && b0 + rr < t.B && k < F) t.sigma_out[(size_t)(b0 + rr) * F + k] = s;
     }
     for (int e = threadIdx.x; e < N * Fp; e += 256) {
         const int rr = e / Fp, k = e - rr * Fp;
@@ -258,41 +259,47 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
 
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     float asum = 0.f;
-    float uv[4], ghv, mu[2], sg[2], uvn[4], ghn = 0.f, mun[2], sgn[2];
-    int n0 = 0, n0n = 0;
-    auto load = [&](int c, float (&u_)[4], float& g_, float (&m_)[2], float (&s_)[2], int& n0_) {
+    // operands of one 16-row inner chunk, per lane
+    struct Chunk { float u[4]; float gh; float mu[2], sg[2]; int n0; };
+    auto load = [&](int c, Chunk& q) {
         const int r0 = 16 * c + 4 * kq;          // first of this lane's 4 inner rows
         const bool ok = r0 < M;                  // M is a multiple of 4
         const int b = ok ? r0 / N : 0;
-        n0_ = ok ? r0 - b * N : 0;
-        g_ = (ok && jok) ? t.GH[(size_t)b * t.ldgh + j] * invN : 0.f;
+        q.n0 = ok ? r0 - b * N : 0;
+        q.gh = (ok && jok) ? t.GH[(size_t)b * t.ldgh + j] * invN : 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) u_[s] = (ok && jok) ? t.U[(size_t)(r0 + s) * H + j] : 1.f;
+        for (int s = 0; s < 4; ++s) q.u[s] = (ok && jok) ? t.U[(size_t)(r0 + s) * H + j] : 1.f;
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            m_[f] = (ok && kok[f]) ? t.mean[(size_t)b * t.ld_ml + kc[f]] : 0.f;
-            s_[f] = (ok && kok[f]) ? expf(clamp_lstd(t.lstd[(size_t)b * t.ld_ml + kc[f]])) : 0.f;
+            q.mu[f] = (ok && kok[f]) ? t.mean[(size_t)b * t.ld_ml + kc[f]] : 0.f;
+            q.sg[f] = (ok && kok[f]) ? t.sigma[(size_t)b * F + kc[f]] : 0.f;
         }
     };
-    const int nchunks = (M + 15) / 16;
-    int c = w;
-    if (c < nchunks) load(c, uv, ghv, mu, sg, n0);
-    for (; c < nchunks; c += 8) {
-        if (c + 8 < nchunks) load(c + 8, uvn, ghn, mun, sgn, n0n);
+    auto compute = [&](const Chunk& q) {
         float a[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = ghv * elu_grad_from_out(uv[s]);
+        for (int s = 0; s < 4; ++s) a[s] = q.gh * elu_grad_from_out(q.u[s]);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], fmaf(sg[f], nz_s[(n0 + s) * 33 + 16 * f + i], mu[f]), acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], fmaf(q.sg[f], nz_s[(q.n0 + s) * 33 + 16 * f + i], q.mu[f]), acc[f], 0, 0, 0);
         if (want_bias) asum += (a[0] + a[1]) + (a[2] + a[3]);
+    };
+    // wave w takes chunks w, w+8, ...; four of them (32 MFMAs) are in flight ahead of the ones being computed
+    const int nchunks = (M + 15) / 16;
+    Chunk cur[4], nxt[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) uv[s] = uvn[s];
-        ghv = ghn; n0 = n0n;
+    for (int u = 0; u < 4; ++u) load(w + 8 * u, cur[u]);
+    for (int c = w; c < nchunks; c += 32) {
+        if (c + 32 < nchunks) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) { mu[f] = mun[f]; sg[f] = sgn[f]; }
+            for (int u = 0; u < 4; ++u) load(c + 32 + 8 * u, nxt[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) compute(cur[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f)
