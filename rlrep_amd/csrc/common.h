@@ -39,6 +39,8 @@ struct GemmTask {
     const float* aux2;   // LD_NCX: log-std
     const float* aux3;   // EPI_DX_REPARAM: eps*exp(l)*mask;  LD_NCX: mean
     float* out2;         // EPI_FWD+ACT_SIN: pre-activation; EPI_DW: bias gradient
+    const float* r1u;    // EPI_DX: optional rank-1 term added to acc: r1u[r] * r1v[c]
+    const float* r1v;
     int lda, ldb, ldc, ldaux, ldaux2, ldaux3, ldout2;
     int R, Cn, K;        // output R x Cn, inner length K
     int tiles_c, tile_base, ntiles;

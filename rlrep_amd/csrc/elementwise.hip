@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void qhead_critic_kernel(QHeadCritic p) {
     const float alpha = (float)exp(p.alpha_state[0]);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = blockIdx.x * 4 + w; b < p.B; b += gridDim.x * 4) {
-        const size_t ro = (size_t)b * p.H;
+        const size_t ro = (size_t)b * (p.ldE ? p.ldE : p.H);
         const float tq1 = row_dot(p.Et[0] + ro, p.wt[0], p.H, lane) + p.bt[0][0];
         const float tq2 = row_dot(p.Et[1] + ro, p.wt[1], p.H, lane) + p.bt[1][0];
         const float q1 = row_dot(p.Ec[0] + ro, p.wc[0], p.H, lane) + p.bc[0][0];
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
     const float alpha = (float)exp(p.alpha_state[0]);
     float accl = 0.f, accc = 0.f;
     for (int b = blockIdx.x * 4 + w; b < p.B; b += gridDim.x * 4) {
-        const size_t ro = (size_t)b * p.H;
+        const size_t ro = (size_t)b * (p.ldE ? p.ldE : p.H);
         const float q1 = row_dot(p.Ec[0] + ro, p.wc[0], p.H, lane) + p.bc[0][0];
         const float q2 = row_dot(p.Ec[1] + ro, p.wc[1], p.H, lane) + p.bc[1][0];
         // d(-min(q1,q2))/dq_i : -1 to the arg-min head, ties split 1/2 (torch.min backward)

@@ -4,7 +4,7 @@
 // independent tasks (grouped GEMMs, see gemm16.hip), so the number of dependent launches equals the depth
 // of the agent's computation graph.  Tables live in the caller-provided workspace and are uploaded when
 // the batch size changes; the hot path performs no allocation, no host<->device copy and no sync.
-#include "engine.h"
+#include "engine_internal.h"
 #include <cstdarg>
 #include <memory>
 
@@ -16,7 +16,7 @@ void rl_set_error(const char* fmt, ...) {
 // ================================================================================================
 // layout (names = reference state_dict keys; see oracle/shapes.py for the reference order)
 // ================================================================================================
-static void lay_actor(Layout& L, int S, int A, int Ha, int arena, int group) {
+void lay_actor(Layout& L, int S, int A, int Ha, int arena, int group) {
     L.lin("actor.trunk.0", Ha, S, arena, group);          // agent/sac/actor.py:63-74
     L.lin("actor.trunk.2", Ha, Ha, arena, group);
     L.lin("actor.trunk.4", 2 * A, Ha, arena, group);
@@ -29,7 +29,7 @@ static void lay_doubleq(Layout& L, const std::string& m, int SA, int H, int aren
     L.lin(m + ".Q1.4", 1, H, arena, group);
     L.lin(m + ".Q2.4", 1, H, arena, group);
 }
-static void lay_six(Layout& L, const std::string& m, int in_f, int H, int arena, int group) {
+void lay_six(Layout& L, const std::string& m, int in_f, int H, int arena, int group) {
     // l1..l6 critics (vlsac_agent.py:33-41, spedersac_agent.py:26-34, diffsrsac_agent.py:51-59); l1|l4 glued
     L.lin_pair(m + ".l1", H, m + ".l4", H, in_f, arena, group);
     L.lin(m + ".l2", H, H, arena, group);
@@ -68,8 +68,11 @@ bool build_layout(const rlrep_dims& d, Layout& L) {
         L.add("critic.noise", d.num_noise, F, T, -1);                      // quirk Q3: plain attribute
         return true;
     }
+    case RLREP_ALG_CTRLSAC: lay_ctrlsac(d, L); return true;
+    case RLREP_ALG_SPEDERSAC: lay_spedersac(d, L); return true;
+    case RLREP_ALG_DIFFSRSAC: lay_diffsrsac(d, L); return true;
     default:
-        rl_set_error("algorithm %d not built yet", d.alg);
+        rl_set_error("unknown algorithm %d", d.alg);
         return false;
     }
 }
@@ -77,138 +80,14 @@ bool build_layout(const rlrep_dims& d, Layout& L) {
 // ================================================================================================
 // agent
 // ================================================================================================
-struct Slot { float *XE, *XF, *XF2, *XFpi, *R, *D; bool filled = false; };
-
-struct rlrep_agent {
-    rlrep_dims d; rlrep_hyper h; rlrep_arenas a; Layout L; Workspace ws;
-    int B = 0;
-    int* steps = nullptr; int* adam_step = nullptr; float* metrics = nullptr; float* obs_in = nullptr; float* act_out = nullptr;
-    Slot slot[2];
-    // per-call dynamic inputs, read by the by-value parameter blocks at launch time
-    const float* cur_eps = nullptr; const int* cur_idx = nullptr;
-    Program feat_bwd, feat_apply, critic_bwd, critic_apply, actor_bwd, actor_apply, upd_target, infer;
-    int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
-    int last_launches = 0;
-    size_t ws_static = 0;     // workspace bytes used by batch-independent state
-
-    float* P(const std::string& n) const { return a.param_dev ? a.param_dev + L.get(n).off : nullptr; }
-    float* T(const std::string& n) const { return a.target_dev ? a.target_dev + L.get(n).off : nullptr; }
-    float* G(const std::string& n) const { return a.grad_dev ? a.grad_dev + L.get(n).off : nullptr; }
-    float* Gtail() const { return a.grad_dev ? a.grad_dev + L.cur[RLREP_ARENA_PARAM] : nullptr; }
-    float inv_batch() const { return 1.0f / ((float)B * (float)(h.world_size > 0 ? h.world_size : 1)); }
-};
-
-// ------------------------------------------------------------------------------------------------
-// builder helpers
-// ------------------------------------------------------------------------------------------------
-struct Builder {
-    rlrep_agent* ag; Workspace& ws; bool dry;
-    Builder(rlrep_agent* a) : ag(a), ws(a->ws), dry(a->ws.dry) {}
-
-    template <class Tt> const Tt* upload(const std::vector<Tt>& v) {
-        Tt* dev = (Tt*)ws.alloc(v.size() * sizeof(Tt));
-        if (!dry && ws.ok()) {
-            hipError_t e = hipMemcpy(dev, v.data(), v.size() * sizeof(Tt), hipMemcpyHostToDevice);
-            if (e != hipSuccess) rl_set_error("table upload failed: %s", hipGetErrorString(e));
-        }
-        return dev;
-    }
-    Mat mat(int rows, int cols) { return Mat{ws.f((size_t)rows * cols), rows, cols, cols}; }
-
-    // ---- GEMM task constructors -------------------------------------------------------------
-    static GemmTask base() { GemmTask t; memset(&t, 0, sizeof(t)); t.scale = 1.f; return t; }
-    // Y[B,N] = act(X[B,K] W[N,K]^T + b)
-    static GemmTask fwd(const float* X, int ldx, int Bn, int K, const float* W, int ldw, const float* bias, int N,
-                        float* Y, int ldy, int act, float* pre = nullptr, int ldpre = 0) {
-        GemmTask t = base();
-        t.A = X; t.lda = ldx; t.B = W; t.ldb = ldw; t.C = Y; t.ldc = ldy; t.bias = bias;
-        t.R = Bn; t.Cn = N; t.K = K; t.epi = EPI_FWD; t.act = act; t.out2 = pre; t.ldout2 = ldpre;
-        return t;
-    }
-    // dX[B,Kout] (=|+=) (G[B,N] W[N, Kout(+off)]) * act'(aux)
-    static GemmTask dx(const float* Gm, int ldg, int Bn, int N, const float* W, int ldw, float* dX, int lddx, int Kout,
-                       int act, const float* aux, int ldaux, int flags = 0) {
-        GemmTask t = base();
-        t.A = Gm; t.lda = ldg; t.B = W; t.ldb = ldw; t.C = dX; t.ldc = lddx; t.aux = aux; t.ldaux = ldaux;
-        t.R = Bn; t.Cn = Kout; t.K = N; t.epi = EPI_DX; t.act = act; t.flags = flags;
-        return t;
-    }
-    // gW[N,K] = G[M,N]^T X[M,K];  gb[N] = colsum G
-    static GemmTask dw(const float* Gm, int ldg, int N, const float* X, int ldx, int K, int M, float* gW, int ldgw, float* gb) {
-        GemmTask t = base();
-        t.A = Gm; t.lda = ldg; t.B = X; t.ldb = ldx; t.C = gW; t.ldc = ldgw; t.out2 = gb;
-        t.R = N; t.Cn = K; t.K = M; t.epi = EPI_DW; t.flags = gb ? FLAG_BIASGRAD : 0;
-        return t;
-    }
-
-    void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
-        int base_tile = 0;
-        for (auto& t : tasks) {
-            t.tiles_c = (t.Cn + 15) / 16;
-            const int tr = (t.R + 15) / 16;
-            t.ntiles = tr * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles;
-        }
-        if (tasks.size() > GEMM_MAX_TASKS) { fprintf(stderr, "rlrep: too many tasks in stage %s\n", what); abort(); }
-        GemmBatch gb; memset(&gb, 0, sizeof(gb));
-        gb.ntasks = (int)tasks.size();
-        for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
-        const int total = base_tile;
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
-    }
-    void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
-    void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
-    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_COL, LD_COL, t, w); }
-
-    void adam(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau,
-              std::vector<FinTask> fin, const char* what) {
-        const auto& L = ag->L;
-        AdamTask t; memset(&t, 0, sizeof(t));
-        const int64_t off = L.group_off[group];
-        t.p = ag->a.param_dev ? ag->a.param_dev + off : nullptr;
-        t.g = ag->a.grad_dev ? ag->a.grad_dev + off : nullptr;
-        t.m = ag->a.exp_avg_dev ? ag->a.exp_avg_dev + off : nullptr;
-        t.v = ag->a.exp_avg_sq_dev ? ag->a.exp_avg_sq_dev + off : nullptr;
-        t.n = L.group_n[group];
-        t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
-        t.step = ag->adam_step + group;
-        t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau;
-        std::vector<AdamTask> tv{t};
-        const AdamTask* dev = upload(tv);
-        const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
-        const int nfin = (int)fin.size();
-        const int blocks = (int)((t.n + 1023) / 1024);
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(dev, 1, blocks, fdev, nfin, st); }, what});
-    }
-    void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
-        const FinTask* fdev = upload(fin);
-        const int nfin = (int)fin.size();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, st); }, what});
-    }
-
-    static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {
-        FinTask f; memset(&f, 0, sizeof(f));
-        f.kind = FIN_SUM; f.partials = partials; f.count = count; f.stride = stride; f.scale = scale; f.out = out;
-        return f;
-    }
-    static FinTask fin_combine(const float* a, float sa, const float* b, float sb, float* out) {
-        FinTask f; memset(&f, 0, sizeof(f));
-        f.kind = FIN_COMBINE; f.in_a = a; f.in_b = b; f.scale = sa; f.scale_b = sb; f.out = out;
-        return f;
-    }
-    static FinTask fin_copy(const float* a, float* out) {
-        FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_COPY; f.in_a = a; f.out = out; return f;
-    }
-};
-
 // rows processed per qhead block loop: grid <= 128 blocks of 4 waves
-static int qhead_blocks(int B) { int g = (B + 3) / 4; return g > 128 ? 128 : g; }
+int qhead_blocks(int B) { int g = (B + 3) / 4; return g > 128 ? 128 : g; }
 
 // ------------------------------------------------------------------------------------------------
 // shared fragments: actor forward / backward, actor+alpha apply
 // ------------------------------------------------------------------------------------------------
-struct ActorBufs { float *A1, *A2, *AO, *logp, *dA, *Ghead, *GA2, *GA1; };
 
-static ActorBufs alloc_actor(Builder& b, int B, int A, int Ha) {
+ActorBufs alloc_actor(Builder& b, int B, int A, int Ha) {
     ActorBufs r;
     r.A1 = b.ws.f((size_t)B * Ha); r.A2 = b.ws.f((size_t)B * Ha); r.AO = b.ws.f((size_t)B * 2 * A);
     r.logp = b.ws.f(B); r.dA = b.ws.f((size_t)B * A); r.Ghead = b.ws.f((size_t)B * 2 * A);
@@ -217,21 +96,21 @@ static ActorBufs alloc_actor(Builder& b, int B, int A, int Ha) {
 }
 
 // GEMM tasks of the three actor trunk layers on input X[B, S] (row stride ldx)
-static GemmTask actor_l(rlrep_agent* ag, int layer, const float* X, int ldx, const ActorBufs& ab) {
+GemmTask actor_l(rlrep_agent* ag, int layer, const float* X, int ldx, const ActorBufs& ab) {
     const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
     if (layer == 0) return Builder::fwd(X, ldx, B, S, ag->P("actor.trunk.0.weight"), S, ag->P("actor.trunk.0.bias"), Ha, ab.A1, Ha, ACT_ELU);
     if (layer == 1) return Builder::fwd(ab.A1, Ha, B, Ha, ag->P("actor.trunk.2.weight"), Ha, ag->P("actor.trunk.2.bias"), Ha, ab.A2, Ha, ACT_ELU);
     return Builder::fwd(ab.A2, Ha, B, Ha, ag->P("actor.trunk.4.weight"), Ha, ag->P("actor.trunk.4.bias"), 2 * A, ab.AO, 2 * A, ACT_NONE);
 }
 
-static void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, const char* what) {
+void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, const char* what) {
     PolicyFwd pf; memset(&pf, 0, sizeof(pf));
     pf.O = ab.AO; pf.B = ag->B; pf.A = ag->d.action_dim; pf.act = act; pf.ld_act = ld_act; pf.logp = ab.logp;
     p.stages.push_back({[=](hipStream_t st) { PolicyFwd q = pf; q.eps = ag->cur_eps; return rl_launch_policy_fwd(&q, st); }, what});
 }
 
 // policy head backward + trunk backward + weight gradients (X = actor input with row stride ldx)
-static void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx,
+void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx,
                            const float* act, int ld_act) {
     const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
     PolicyBwd pb; memset(&pb, 0, sizeof(pb));
@@ -246,7 +125,7 @@ static void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorB
                "actor dW");
 }
 
-static void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk) {
+void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk) {
     Program& p = ag->actor_apply;
     FinTask fa; memset(&fa, 0, sizeof(fa));
     fa.kind = FIN_ALPHA; fa.partials = ag->Gtail(); fa.count = nblk; fa.stride = 1; fa.scale = ag->inv_batch();
@@ -256,7 +135,7 @@ static void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partia
            {Builder::fin_sum(partial_loss, nblk, 1, 1.0f / (float)ag->B, ag->metrics + M_ACTOR_LOSS), fa}, "adam actor + alpha");
 }
 
-static void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst) {
+void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst) {
     // critic -> critic_target over the whole critic group (identical internal layouts)
     PolyakTask t; memset(&t, 0, sizeof(t));
     t.src = ag->a.param_dev ? ag->a.param_dev + ag->L.group_off[1] : nullptr;
@@ -585,21 +464,31 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog})
         p->stages.clear();
     ag->infer_n = 0;
     Builder b(ag);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
-    for (int i = 0; i < 2; ++i) {
-        Slot& s = ag->slot[i];
-        s.XE = b.ws.f((size_t)B * (2 * S + A)); s.XF = b.ws.f((size_t)B * (S + A)); s.XF2 = b.ws.f((size_t)B * (S + A));
-        s.XFpi = b.ws.f((size_t)B * (S + A)); s.R = b.ws.f(B); s.D = b.ws.f(B); s.filled = false;
-        if (ag->d.alg != RLREP_ALG_SPEDERSAC) break;
+    {
+        // spedersac steps on two minibatches; their [s,a,s'] / [s,a] matrices are allocated back to back so
+        // that phi/mu run as ONE 2B-row GEMM per layer
+        const int ns = (ag->d.alg == RLREP_ALG_SPEDERSAC) ? 2 : 1;
+        float* XE = b.ws.f((size_t)ns * B * (2 * S + A));
+        float* XF = b.ws.f((size_t)ns * B * (S + A));
+        for (int i = 0; i < ns; ++i) {
+            Slot& s = ag->slot[i];
+            s.XE = XE ? XE + (size_t)i * B * (2 * S + A) : nullptr;
+            s.XF = XF ? XF + (size_t)i * B * (S + A) : nullptr;
+            s.XF2 = b.ws.f((size_t)B * (S + A)); s.XFpi = b.ws.f((size_t)B * (S + A)); s.R = b.ws.f(B); s.D = b.ws.f(B); s.filled = false;
+        }
     }
     switch (ag->d.alg) {
     case RLREP_ALG_SAC: build_sac(b, ag); break;
     case RLREP_ALG_VLSAC: build_vlsac(b, ag); break;
-    default: rl_set_error("algorithm %d not built yet", ag->d.alg); return RLREP_ERR_ARG;
+    case RLREP_ALG_CTRLSAC: build_ctrlsac(b, ag); break;
+    case RLREP_ALG_SPEDERSAC: build_spedersac(b, ag); break;
+    case RLREP_ALG_DIFFSRSAC: build_diffsrsac(b, ag); break;
+    default: rl_set_error("unknown algorithm %d", ag->d.alg); return RLREP_ERR_ARG;
     }
     ag->prog_end = ag->ws.used;
     // room for the B<=max_batch inference program (rlrep_actor_forward)
@@ -617,6 +506,11 @@ static bool check_dims(const rlrep_dims* d) {
         if (d->num_noise != 4 * NC_NF_HOST) { rl_set_error("vlsac: num_noise must be %d", 4 * NC_NF_HOST); return false; }
         if (d->feature_dim <= 0 || d->vae_hidden_dim <= 0 || (d->feature_dim & 3)) { rl_set_error("vlsac: feature_dim must be a positive multiple of 4"); return false; }
         if ((size_t)(16 + d->num_noise) * (((d->feature_dim + 15) & ~15) + 16) * 4 > 64 * 1024) { rl_set_error("vlsac: feature_dim too large for the LDS-resident noise tables"); return false; }
+    }
+    if (d->alg == RLREP_ALG_CTRLSAC || d->alg == RLREP_ALG_SPEDERSAC || d->alg == RLREP_ALG_DIFFSRSAC) {
+        if (d->feature_dim <= 0 || d->phi_hidden_dim <= 0 || d->mu_hidden_dim <= 0 || d->phi_hidden_depth < 0 || d->mu_hidden_depth < 0 ||
+            d->phi_hidden_depth > 3 || d->mu_hidden_depth > 3) { rl_set_error("bad representation-network dimensions"); return false; }
+        if (d->alg == RLREP_ALG_DIFFSRSAC && d->num_noise <= 0) { rl_set_error("diffsrsac: num_noise must be positive"); return false; }
     }
     return true;
 }
@@ -804,6 +698,8 @@ static int run(rlrep_agent* ag, const Program& p, void* stream) {
 int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t* idx, void* stream) {
     STEP_PROLOGUE(true)
     if (ag->d.alg == RLREP_ALG_VLSAC && !eps) { rl_set_error("vlsac feature step needs eps[B,F]"); return RLREP_ERR_ARG; }
+    if (ag->d.alg == RLREP_ALG_DIFFSRSAC && (!eps || !idx)) { rl_set_error("diffsrsac feature step needs noise_idx[B] and eps[B,S]"); return RLREP_ERR_ARG; }
+    if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
     return run(ag, ag->feat_bwd, stream);
 }
@@ -846,7 +742,11 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
     return 0;
 }
-int32_t rlrep_sync_frozen(rlrep_agent* ag, void* stream) { (void)stream; return ag ? 0 : RLREP_ERR_ARG; }
+int32_t rlrep_sync_frozen(rlrep_agent* ag, void* stream) {
+    if (!ag) return RLREP_ERR_ARG;
+    ag->last_launches += (int)ag->sync_prog.stages.size();
+    return ag->sync_prog.run((hipStream_t)stream);
+}
 
 int32_t rlrep_actor_forward(rlrep_agent* ag, const float* obs, int32_t n, const float* eps, float lo, float hi, float* action, void* stream) {
     if (!ag || !obs || !action || n <= 0 || n > ag->d.max_batch) { rl_set_error("actor_forward: bad argument"); return RLREP_ERR_ARG; }

@@ -1,0 +1,147 @@
+// Internal definitions shared by engine.hip and agents2.hip (agent state, program builder).
+#pragma once
+#include "engine.h"
+
+struct Slot { float *XE, *XF, *XF2, *XFpi, *R, *D; bool filled = false; };
+
+struct rlrep_agent {
+    rlrep_dims d; rlrep_hyper h; rlrep_arenas a; Layout L; Workspace ws;
+    int B = 0;
+    int* steps = nullptr; int* adam_step = nullptr; float* metrics = nullptr; float* obs_in = nullptr; float* act_out = nullptr;
+    Slot slot[2];
+    // per-call dynamic inputs, read by the by-value parameter blocks at launch time
+    const float* cur_eps = nullptr; const int* cur_idx = nullptr;
+    Program feat_bwd, feat_apply, critic_bwd, critic_apply, actor_bwd, actor_apply, upd_target, infer, sync_prog;
+    int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
+    int last_launches = 0;
+    size_t ws_static = 0;     // workspace bytes used by batch-independent state
+
+    float* P(const std::string& n) const { return a.param_dev ? a.param_dev + L.get(n).off : nullptr; }
+    float* T(const std::string& n) const { return a.target_dev ? a.target_dev + L.get(n).off : nullptr; }
+    float* G(const std::string& n) const { return a.grad_dev ? a.grad_dev + L.get(n).off : nullptr; }
+    float* Gtail() const { return a.grad_dev ? a.grad_dev + L.cur[RLREP_ARENA_PARAM] : nullptr; }
+    float inv_batch() const { return 1.0f / ((float)B * (float)(h.world_size > 0 ? h.world_size : 1)); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// builder helpers
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    rlrep_agent* ag; Workspace& ws; bool dry;
+    Builder(rlrep_agent* a) : ag(a), ws(a->ws), dry(a->ws.dry) {}
+
+    template <class Tt> const Tt* upload(const std::vector<Tt>& v) {
+        Tt* dev = (Tt*)ws.alloc(v.size() * sizeof(Tt));
+        if (!dry && ws.ok()) {
+            hipError_t e = hipMemcpy(dev, v.data(), v.size() * sizeof(Tt), hipMemcpyHostToDevice);
+            if (e != hipSuccess) rl_set_error("table upload failed: %s", hipGetErrorString(e));
+        }
+        return dev;
+    }
+    Mat mat(int rows, int cols) { return Mat{ws.f((size_t)rows * cols), rows, cols, cols}; }
+
+    // ---- GEMM task constructors -------------------------------------------------------------
+    static GemmTask base() { GemmTask t; memset(&t, 0, sizeof(t)); t.scale = 1.f; return t; }
+    // Y[B,N] = act(X[B,K] W[N,K]^T + b)
+    static GemmTask fwd(const float* X, int ldx, int Bn, int K, const float* W, int ldw, const float* bias, int N,
+                        float* Y, int ldy, int act, float* pre = nullptr, int ldpre = 0) {
+        GemmTask t = base();
+        t.A = X; t.lda = ldx; t.B = W; t.ldb = ldw; t.C = Y; t.ldc = ldy; t.bias = bias;
+        t.R = Bn; t.Cn = N; t.K = K; t.epi = EPI_FWD; t.act = act; t.out2 = pre; t.ldout2 = ldpre;
+        return t;
+    }
+    // dX[B,Kout] (=|+=) (G[B,N] W[N, Kout(+off)]) * act'(aux)
+    static GemmTask dx(const float* Gm, int ldg, int Bn, int N, const float* W, int ldw, float* dX, int lddx, int Kout,
+                       int act, const float* aux, int ldaux, int flags = 0) {
+        GemmTask t = base();
+        t.A = Gm; t.lda = ldg; t.B = W; t.ldb = ldw; t.C = dX; t.ldc = lddx; t.aux = aux; t.ldaux = ldaux;
+        t.R = Bn; t.Cn = Kout; t.K = N; t.epi = EPI_DX; t.act = act; t.flags = flags;
+        return t;
+    }
+    // gW[N,K] = G[M,N]^T X[M,K];  gb[N] = colsum G
+    static GemmTask dw(const float* Gm, int ldg, int N, const float* X, int ldx, int K, int M, float* gW, int ldgw, float* gb) {
+        GemmTask t = base();
+        t.A = Gm; t.lda = ldg; t.B = X; t.ldb = ldx; t.C = gW; t.ldc = ldgw; t.out2 = gb;
+        t.R = N; t.Cn = K; t.K = M; t.epi = EPI_DW; t.flags = gb ? FLAG_BIASGRAD : 0;
+        return t;
+    }
+
+    void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
+        int base_tile = 0;
+        for (auto& t : tasks) {
+            t.tiles_c = (t.Cn + 15) / 16;
+            const int tr = (t.R + 15) / 16;
+            t.ntiles = tr * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles;
+        }
+        if (tasks.size() > GEMM_MAX_TASKS) { fprintf(stderr, "rlrep: too many tasks in stage %s\n", what); abort(); }
+        GemmBatch gb; memset(&gb, 0, sizeof(gb));
+        gb.ntasks = (int)tasks.size();
+        for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
+        const int total = base_tile;
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
+    }
+    void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
+    void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
+    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_COL, LD_COL, t, w); }
+
+    void adam(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau,
+              std::vector<FinTask> fin, const char* what) {
+        const auto& L = ag->L;
+        AdamTask t; memset(&t, 0, sizeof(t));
+        const int64_t off = L.group_off[group];
+        t.p = ag->a.param_dev ? ag->a.param_dev + off : nullptr;
+        t.g = ag->a.grad_dev ? ag->a.grad_dev + off : nullptr;
+        t.m = ag->a.exp_avg_dev ? ag->a.exp_avg_dev + off : nullptr;
+        t.v = ag->a.exp_avg_sq_dev ? ag->a.exp_avg_sq_dev + off : nullptr;
+        t.n = L.group_n[group];
+        t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
+        t.step = ag->adam_step + group;
+        t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau;
+        std::vector<AdamTask> tv{t};
+        const AdamTask* dev = upload(tv);
+        const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
+        const int nfin = (int)fin.size();
+        const int blocks = (int)((t.n + 1023) / 1024);
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(dev, 1, blocks, fdev, nfin, st); }, what});
+    }
+    void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
+        const FinTask* fdev = upload(fin);
+        const int nfin = (int)fin.size();
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, st); }, what});
+    }
+
+    static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {
+        FinTask f; memset(&f, 0, sizeof(f));
+        f.kind = FIN_SUM; f.partials = partials; f.count = count; f.stride = stride; f.scale = scale; f.out = out;
+        return f;
+    }
+    static FinTask fin_combine(const float* a, float sa, const float* b, float sb, float* out) {
+        FinTask f; memset(&f, 0, sizeof(f));
+        f.kind = FIN_COMBINE; f.in_a = a; f.in_b = b; f.scale = sa; f.scale_b = sb; f.out = out;
+        return f;
+    }
+    static FinTask fin_copy(const float* a, float* out) {
+        FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_COPY; f.in_a = a; f.out = out; return f;
+    }
+};
+
+
+struct ActorBufs { float *A1, *A2, *AO, *logp, *dA, *Ghead, *GA2, *GA1; };
+
+int qhead_blocks(int B);
+ActorBufs alloc_actor(Builder& b, int B, int A, int Ha);
+GemmTask actor_l(rlrep_agent* ag, int layer, const float* X, int ldx, const ActorBufs& ab);
+void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, const char* what);
+void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx, const float* act, int ld_act);
+void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk);
+void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst);
+
+// agents2.hip
+void lay_ctrlsac(const rlrep_dims& d, Layout& L);
+void lay_spedersac(const rlrep_dims& d, Layout& L);
+void lay_diffsrsac(const rlrep_dims& d, Layout& L);
+void lay_actor(Layout& L, int S, int A, int Ha, int arena, int group);
+void lay_six(Layout& L, const std::string& m, int in_f, int H, int arena, int group);
+void build_ctrlsac(Builder& b, rlrep_agent* ag);
+void build_spedersac(Builder& b, rlrep_agent* ag);
+void build_diffsrsac(Builder& b, rlrep_agent* ag);

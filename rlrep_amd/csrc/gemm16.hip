@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     float e0 = 0.f, cold = 0.f, cold2 = 0.f;
     if (inb) {
         if (t.epi == EPI_FWD) { if (t.bias) e0 = t.bias[c]; }
-        else if (t.epi == EPI_DX) { if (t.act != ACT_NONE) e0 = t.aux[(size_t)r * t.ldaux + c]; if (t.flags & FLAG_ACCUM) cold = *cp; }
+        else if (t.epi == EPI_DX) {
+            if (t.act != ACT_NONE) e0 = t.aux[(size_t)r * t.ldaux + c];
+            if (t.flags & FLAG_ACCUM) cold = *cp;
+            if (t.r1u) cold2 = t.r1u[r] * t.r1v[c];
+        }
         else if (t.epi == EPI_DX_REPARAM) { e0 = t.aux3[(size_t)r * t.ldaux3 + c]; cold = *cp; cold2 = cp[t.F]; }
         else if (t.flags & FLAG_ACCUM) cold = *cp;
     }
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         *cp = y;
     } break;
     case EPI_DX: {
-        float g = v;
+        float g = v + cold2;
         switch (t.act) {
         case ACT_RELU: g = e0 > 0.f ? g : 0.f; break;
         case ACT_ELU: g *= elu_grad_from_out(e0); break;

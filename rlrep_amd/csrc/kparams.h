@@ -47,6 +47,7 @@ struct QHeadCritic {
     const double* alpha_state; float gamma, inv_batch;
     float* dq; float* GE[2]; float* partial;
     int B, H, nblk, train; int* step;
+    int ldE;                   // row stride of Et/Ec/GE (0 -> H)
 };
 
 struct QHeadActor {
@@ -54,6 +55,7 @@ struct QHeadActor {
     const float* logp; const double* alpha_state; float inv_batch, target_entropy;
     float* GE[2]; float* partial_loss; float* partial_c;
     int B, H, nblk; int* step;
+    int ldE;                   // row stride of Ec/GE (0 -> H)
 };
 
 enum FinKind : int { FIN_SUM = 0, FIN_COMBINE = 1, FIN_ALPHA = 2, FIN_COPY = 3 };
@@ -104,3 +106,28 @@ struct NcDxTask {
 
 
 #define NC_NF_HOST 5   /* vlsac noise rows / 4 (noisecritic.hip NC_NF) */
+
+// representation losses (replearn.hip)
+struct InfoNce {
+    float* S; int ldS;                 // [B,B] scores in, dS out (in place)
+    const float* rhat; const float* r; float* drhat;
+    float* partial; int B, nblk; float inv_batch; int* step;
+};
+struct ColSum { const float* X; int ldX; const float* w; float* out; int rows, F; };
+struct SpederRows {
+    const float* phi; const float* mu; const float* mu_r; const float* phibar;
+    const float* theta_w; const float* theta_b; const float* r;
+    float* c; float* drhat; float* partial; int B, F, nblk; float inv_batch; int* step;
+};
+struct SpederGrads {
+    const float* phi; const float* mu; const float* c; const float* drhat; const float* phibar; const float* v;
+    const float* theta_w; float* Gphi; float* Gmu; int B, F; float inv_batch;
+};
+struct DiffsrPerturb {
+    const float* alphabars; const int* idx; const float* s2; int ld_s2; const float* eps;
+    float* XN; float* TGT; int B, S; int* step0; int* step1;
+};
+struct DiffsrScore {
+    float* U; const float* PHI; const float* TGT; const float* alphabars; const int* idx;
+    float* GPHI; float* partial; int B, F, S; float sigma, inv_batch;
+};

@@ -1,0 +1,211 @@
+// Representation-loss kernels of ctrlsac (InfoNCE), spedersac (spectral) and diffsrsac (score matching), gfx950.
+// All are O(B*F) or O(B*B) passes around the GEMMs of gemm16.hip: one wave per row with shuffle reductions,
+// deterministic per-block partial sums, gradients written in the layout the backward GEMMs consume.
+#include "common.h"
+#include "kparams.h"
+
+// ------------------------------------------------------------------------------------------------
+// ctrlsac InfoNCE (agent/ctrlsac/ctrlsac_agent.py:226-233)
+//   L = mean_i( logsumexp_j S_ij - S_ii ) + 0.5*mean_i (rhat_i - r_i)^2
+//   dS = (softmax_row(S) - I)/B  (in place),  drhat = (rhat - r)/B
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void infonce_kernel(InfoNce p) {
+    __shared__ float shp[4][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float accm = 0.f, accr = 0.f;
+    for (int i = blockIdx.x * 4 + w; i < p.B; i += gridDim.x * 4) {
+        float* row = p.S + (size_t)i * p.ldS;
+        float mx = -INFINITY;
+        for (int j = lane; j < p.B; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float se = 0.f;
+        for (int j = lane; j < p.B; j += 64) se += expf(row[j] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        const float sii = row[i];
+        for (int j = lane; j < p.B; j += 64) {
+            const float sm = expf(row[j] - lse);
+            row[j] = (sm - (j == i ? 1.f : 0.f)) * p.inv_batch;
+        }
+        const float dr = p.rhat[i] - p.r[i];
+        if (lane == 0) p.drhat[i] = dr * p.inv_batch;
+        accm += lse - sii;
+        accr += dr * dr;
+    }
+    if (lane == 0) { shp[w][0] = accm; shp[w][1] = accr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.partial[2 * blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
+        p.partial[2 * blockIdx.x + 1] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
+        if (blockIdx.x == 0 && p.step) *p.step += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weighted column sum: out[f] = sum_k w[k] * X[k, f]   (w == nullptr: plain column sum); fixed order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(ColSum p) {
+    __shared__ float sh[4][64];
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + cg;
+    float s = 0.f;
+    if (f < p.F)
+        for (int k = rg; k < p.rows; k += 4) s = fmaf(p.w ? p.w[k] : 1.f, p.X[(size_t)k * p.ldX + f], s);
+    sh[rg][cg] = s;
+    __syncthreads();
+    if (rg == 0 && f < p.F) p.out[f] = ((sh[0][cg] + sh[1][cg]) + sh[2][cg]) + sh[3][cg];
+}
+
+// ------------------------------------------------------------------------------------------------
+// spedersac spectral loss (agent/spedersac/spedersac_agent.py:186-208)
+//   L = -(2/B) sum_i phi_i.mu'_i + (1/B^2) sum_k (Phibar.mu_r,k)^2 + 0.5*mean (theta.phi_i + b - r_i)^2
+// rows kernel: c_k = Phibar.mu_r,k ; d_i = phi_i.mu'_i ; rhat_i ; partial sums
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void speder_rows_kernel(SpederRows p) {
+    __shared__ float shp[4][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = blockIdx.x * 4 + w; i < p.B; i += gridDim.x * 4) {
+        const float* ph = p.phi + (size_t)i * p.F;
+        const float* mu = p.mu + (size_t)i * p.F;
+        const float* mr = p.mu_r + (size_t)i * p.F;
+        float d = 0.f, c = 0.f, rh = 0.f;
+        for (int f = lane; f < p.F; f += 64) {
+            const float x = ph[f];
+            d = fmaf(x, mu[f], d);
+            c = fmaf(mr[f], p.phibar[f], c);
+            rh = fmaf(x, p.theta_w[f], rh);
+        }
+        d = wave_sum(d); c = wave_sum(c); rh = wave_sum(rh) + p.theta_b[0];
+        const float dr = rh - p.r[i];
+        if (lane == 0) { p.c[i] = c; p.drhat[i] = dr * p.inv_batch; }
+        a0 += d; a1 += c * c; a2 += dr * dr;
+    }
+    if (lane == 0) { shp[w][0] = a0; shp[w][1] = a1; shp[w][2] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        p.partial[3 * blockIdx.x + q] = ((shp[0][q] + shp[1][q]) + shp[2][q]) + shp[3][q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.step) *p.step += 1;
+}
+
+// gradients w.r.t. the four feature matrices, written as one [2B, F] block each for phi and mu
+// (rows 0..B-1: batch 1, rows B..2B-1: the "random" batch) so that the backward GEMMs see M = 2B
+__global__ __launch_bounds__(256) void speder_grads_kernel(SpederGrads p) {
+    const long long n = (long long)p.B * p.F;
+    const float k1 = -2.f * p.inv_batch, k2 = 2.f * p.inv_batch * p.inv_batch;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / p.F), f = (int)(e - (long long)i * p.F);
+        p.Gphi[e] = k1 * p.mu[e] + p.drhat[i] * p.theta_w[f];
+        p.Gmu[e] = k1 * p.phi[e];
+        p.Gphi[n + e] = k2 * p.v[f];
+        p.Gmu[n + e] = k2 * p.c[i] * p.phibar[f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// diffsrsac denoising score matching (agent/diffsrsac/diffsrsac_agent.py:271-305)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diffsr_perturb_kernel(DiffsrPerturb p) {
+    const long long n = (long long)p.B * (p.S + 1);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / (p.S + 1)), s = (int)(e - (long long)b * (p.S + 1));
+        const float ab = p.alphabars[p.idx[b]];
+        if (s == p.S) { p.XN[e] = ab; continue; }
+        const float sq = sqrtf(ab), x = p.s2[(size_t)b * p.ld_s2 + s];
+        const float pert = sq * x + sqrtf(1.0f - ab) * p.eps[(size_t)b * p.S + s];
+        p.XN[e] = pert;
+        p.TGT[(size_t)b * p.S + s] = -(pert - sq * x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (p.step0) *p.step0 += 1; if (p.step1) *p.step1 += 1; }
+}
+
+// one workgroup per sample: score_s = sum_z phi_z U[z,s]; loss; dphi_z = sum_s dscore_s U[z,s]; U <- dU = phi_z dscore_s
+__global__ __launch_bounds__(256) void diffsr_score_kernel(DiffsrScore p) {
+    extern __shared__ float sm[];               // [4][S] partial scores, then [S] dscore
+    __shared__ float shl[4];
+    const int b = blockIdx.x, S = p.S, F = p.F;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* U = p.U + (size_t)b * F * S;
+    const float* phi = p.PHI + (size_t)b * F;
+    float* part = sm;                            // [4][S]
+    float* dsc = sm + 4 * S;                     // [S]
+    // pass 1: wave w accumulates z = w, w+4, ... ; lanes over s
+    for (int s = lane; s < S; s += 64) {
+        float a = 0.f;
+        for (int z = w; z < F; z += 4) a = fmaf(phi[z], U[(size_t)z * S + s], a);
+        part[w * S + s] = a;
+    }
+    __syncthreads();
+    const float ab = p.alphabars[p.idx[b]];
+    const float coef = (1.0f - ab) * p.sigma;
+    float l = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const float score = ((part[s] + part[S + s]) + part[2 * S + s]) + part[3 * S + s];
+        const float diff = p.TGT[(size_t)b * S + s] - coef * score;
+        l += diff * diff;
+        dsc[s] = -2.f * coef * diff * p.inv_batch;
+    }
+    const float lb = block_sum_256(l, shl);
+    if (threadIdx.x == 0) p.partial[b] = lb;
+    __syncthreads();
+    // pass 2
+    for (int z = w; z < F; z += 4) {
+        const float pz = phi[z];
+        float a = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float u = U[(size_t)z * S + s], d = dsc[s];
+            a = fmaf(d, u, a);
+            U[(size_t)z * S + s] = pz * d;
+        }
+        a = wave_sum(a);
+        if (lane == 0) p.GPHI[(size_t)b * F + z] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy2_kernel(const float* __restrict__ src, float* __restrict__ d1, float* __restrict__ d2, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = src[i];
+        d1[i] = v;
+        if (d2) d2[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int rows_blocks(int B) { int g = (B + 3) / 4; return g > 128 ? 128 : g; }
+
+extern "C" int rl_launch_infonce(const InfoNce* p, hipStream_t st) {
+    hipLaunchKernelGGL(infonce_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_colsum(const ColSum* p, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((p->F + 63) / 64), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_speder_rows(const SpederRows* p, hipStream_t st) {
+    hipLaunchKernelGGL(speder_rows_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_speder_grads(const SpederGrads* p, hipStream_t st) {
+    long long n = (long long)p->B * p->F;
+    int g = (int)((n + 1023) / 1024); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(speder_grads_kernel, dim3(g), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st) {
+    long long n = (long long)p->B * (p->S + 1);
+    int g = (int)((n + 255) / 256); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(diffsr_perturb_kernel, dim3(g), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st) {
+    hipLaunchKernelGGL(diffsr_score_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_copy2(const float* src, float* d1, float* d2, long long n, hipStream_t st) {
+    int g = (int)((n + 1023) / 1024); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(copy2_kernel, dim3(g), dim3(256), 0, st, src, d1, d2, n);
+    return (int)hipGetLastError();
+}
