@@ -1,0 +1,159 @@
+"""Data-parallel path: replay sharded over ranks, gradients all-reduced per optimizer step.
+
+* CPU (`-m "not gpu"`): 2 gloo ranks check, on the oracle, that the sum over ranks of the gradients of the
+  locally-scaled losses equals the full-batch gradient (the identity the HIP path's 1/(B*world) scaling relies on).
+* GPU (`-m gpu`): 2 ranks share cuda:0 with the gloo backend (RCCL refuses two ranks on one device) and run the
+  real HIP `train()` with world_size=2 (backward -> all_reduce -> apply); both replicas must stay bit-identical
+  and match the CPU oracle run on the concatenated global batch.
+"""
+import os
+import sys
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), HERE, os.path.join(HERE, 'golden')]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(c, rs, nranks):
+    """Per-rank sample indices / noise for ONE train() of the tiny vlsac fixture's agent."""
+    F = c.kw['feature_dim']
+    nf = c.kw['extra_feature_steps'] + 1
+    out = []
+    for _ in range(nranks):
+        idx = [rs.randint(0, c.meta['replay_n'], size=c.B) for _ in range(nf)]
+        eps = [rs.standard_normal((c.B, F)).astype(np.float32) for _ in range(nf)]
+        eps += [rs.standard_normal((c.B, c.A)).astype(np.float32) for _ in range(2)]
+        out.append((idx, eps))
+    return out
+
+
+def _oracle_global(c, per_rank, trains=1):
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    for t in range(trains):
+        pr = per_rank[t]
+        nf = len(pr[0][0])
+        batches = [gather_batch(c.replay, np.concatenate([r[0][i] for r in pr])) for i in range(nf)]
+        eps = [torch.as_tensor(np.concatenate([r[1][i] for r in pr], axis=0)) for i in range(len(pr[0][1]))]
+        o.train(batches, eps)
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: gradient-sum identity over gloo
+# ------------------------------------------------------------------------------------------------
+def _cpu_worker(rank, world, port, q):
+    from fixture_io import Case
+    from oracle import make_oracle
+    from oracle.agents import gather_batch, Batch
+    import torch.nn.functional as Fn
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    c = Case('sac_tiny')
+    rs = np.random.RandomState(3)
+    idx = rs.randint(0, c.meta['replay_n'], size=c.B * world)
+    eps = rs.standard_normal((c.B * world, c.A)).astype(np.float32)
+    full = gather_batch(c.replay, idx)
+    sl = slice(rank * c.B, (rank + 1) * c.B)
+    local = Batch(*(t[sl] for t in full))
+
+    def critic_grads(batch, e, scale):
+        o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+        from oracle.agents import actor_mu_std, squashed_rsample_logp, double_q
+        P = o.P
+        with torch.no_grad():
+            mu, std = actor_mu_std(P, batch.next_state)
+            a2, logp = squashed_rsample_logp(mu, std, torch.as_tensor(e))
+            t1, t2 = double_q(P, 'critic_target', batch.next_state, a2)
+            y = batch.reward + (1 - batch.done) * o.discount * (torch.min(t1, t2) - o.alpha.detach() * logp)
+        q1, q2 = double_q(P, 'critic', batch.state, batch.action)
+        loss = (Fn.mse_loss(q1, y) + Fn.mse_loss(q2, y)) * scale
+        names = o.names('critic')
+        return names, torch.autograd.grad(loss, [P[n] for n in names])
+
+    names, g_local = critic_grads(local, eps[sl], 1.0 / world)      # mean over local B, then /world
+    flat = torch.cat([g.reshape(-1) for g in g_local])
+    dist.all_reduce(flat)                                           # SUM over ranks == global-mean gradient
+    _, g_full = critic_grads(full, eps, 1.0)
+    ref = torch.cat([g.reshape(-1) for g in g_full])
+    err = float((flat - ref).norm() / ref.norm())
+    q.put((rank, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_sum_identity_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        assert err < 1e-5, (rank, err)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the HIP train() with world_size 2
+# ------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, q):
+    from fixture_io import Case
+    from test_hip_parity import make_agent, make_buffer
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    c = Case('vlsac_tiny')
+    agent = make_agent(c)
+    assert agent.world_size == world
+    buf = make_buffer(c)
+    rs = np.random.RandomState(11)
+    for t in range(2):
+        per_rank = _inputs(c, rs, world)
+        agent.train_injected(buf, c.B, *per_rank[rank])
+    torch.cuda.synchronize()
+    st = {k: v.numpy() for k, v in agent.core.state().items()}
+    q.put((rank, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_dp_two_ranks_match_global_batch_oracle():
+    from fixture_io import Case, rel_l2
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    c = Case('vlsac_tiny')
+    rs = np.random.RandomState(11)
+    per_rank = [_inputs(c, rs, world) for _ in range(2)]
+    o = _oracle_global(c, per_rank, trains=2)
+    P = o.state()
+    for k, v in res[0].items():
+        assert np.array_equal(v, res[1][k]), f'replicas diverged at {k}'
+        if k in P and not k.endswith('noise'):
+            assert rel_l2(v, P[k].numpy()) < 1e-4, k

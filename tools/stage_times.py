@@ -1,5 +1,5 @@
 import sys, os, json, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 import numpy as np, torch
 import bench
 alg,S,A,B,kw = bench.WORKLOADS[sys.argv[1] if len(sys.argv)>1 else 'vlsac_halfcheetah_f256_b256']
