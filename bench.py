@@ -31,7 +31,17 @@ WORKLOADS = {
     # name: (agent, S, A, B, ctor kwargs)
     'vlsac_halfcheetah_f256_b256': ('vlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
     'sac_halfcheetah_b256': ('sac', 17, 6, 256, dict(hidden_dim=256)),
+    'sac_pendulum_b64': ('sac', 3, 1, 64, dict(hidden_dim=256)),
+    # main.py:87-104 hard-codes these ctrlsac / spedersac dimensions; BASELINE.json names the 256 / 512 variants
+    'ctrlsac_halfcheetah_f2048_b256': ('ctrlsac', 17, 6, 256, dict(hidden_dim=1024, feature_dim=2048, extra_feature_steps=3)),
+    'ctrlsac_halfcheetah_f256_b256': ('ctrlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
+    'spedersac_ant_f512_b1024': ('spedersac', 111, 8, 1024, dict(
+        phi_and_mu_lr=1e-5, phi_hidden_dim=512, phi_hidden_depth=1, mu_hidden_dim=512, mu_hidden_depth=0,
+        critic_and_actor_lr=3e-4, critic_and_actor_hidden_dim=256, feature_dim=512, hidden_dim=256, extra_feature_steps=5)),
+    'diffsrsac_halfcheetah_b256': ('diffsrsac', 17, 6, 256, dict(hidden_dim=256, extra_feature_steps=3)),
+    'diffsrsac_humanoid_b2048': ('diffsrsac', 376, 17, 2048, dict(hidden_dim=256, extra_feature_steps=3)),
 }
+OPT_STEPS = {'sac': 3, 'vlsac': 7, 'ctrlsac': 7, 'spedersac': 9, 'diffsrsac': 10}
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
 
@@ -42,10 +52,10 @@ class Space:
 
 
 def make_agent(alg, S, A, B, kw):
-    if alg == 'vlsac':
-        from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent as cls
-    else:
-        from rlrep_amd.agent.sac.sac_agent import SACAgent as cls
+    import importlib
+    name = {'sac': 'SACAgent', 'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent', 'spedersac': 'SPEDERSACAgent',
+            'diffsrsac': 'DIFFSRSACAgent'}[alg]
+    cls = getattr(importlib.import_module(f'rlrep_amd.agent.{alg}.{alg}_agent'), name)
     return cls(state_dim=S, action_dim=A, action_space=Space(A), max_batch=B, **kw)
 
 
@@ -93,7 +103,7 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
     torch.set_num_threads(threads)
     init = synth.init_like(param_shapes(alg, S, A, **kw))
     for k in list(init):
-        for s_, d_ in (('critic', 'critic_target'), ('f', 'f_target')):
+        for s_, d_ in (('critic', 'critic_target'), ('f', 'f_target'), ('phi', 'phi_target')):
             if k.startswith(s_ + '.') and (d_ + k[len(s_):]) in init:
                 init[d_ + k[len(s_):]] = init[k].copy()
     if alg == 'vlsac':
@@ -101,13 +111,22 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
     init['log_alpha'] = np.log(np.float64(0.1))
     o = make_oracle(alg, S, A, init, **kw)
     rs = np.random.RandomState(5)
-    F = kw.get('feature_dim', 0)
+    F = kw.get('feature_dim', 256)
     nf = kw.get('extra_feature_steps', 0) + 1 if alg != 'sac' else 0
     tens = {k: torch.from_numpy(v) for k, v in data.items()}
+    if alg == 'diffsrsac':
+        from rlrep_amd.agent.diffsrsac.diffsrsac_agent import generate_alphabars
+        o.P['noise_alphabars'] = torch.from_numpy(generate_alphabars(0.3, 0.1, 1000))
 
     def one():
-        idx = [rs.randint(0, REPLAY_N, size=B) for _ in range(max(nf, 1))]
-        eps = [torch.from_numpy(rs.standard_normal((B, F)).astype(np.float32)) for _ in range(nf)]
+        nb = o.n_batches()
+        idx = [rs.randint(0, REPLAY_N, size=B) for _ in range(nb)]
+        eps = []
+        if alg == 'vlsac':
+            eps = [torch.from_numpy(rs.standard_normal((B, F)).astype(np.float32)) for _ in range(nf)]
+        if alg == 'diffsrsac':
+            for _ in range(nf):
+                eps += [torch.from_numpy(rs.randint(0, 1000, size=B)), torch.from_numpy((0.449 * rs.standard_normal((B, S))).astype(np.float32))]
         eps += [torch.from_numpy(rs.standard_normal((B, A)).astype(np.float32)) for _ in range(2)]
         o.train([gather_batch(tens, i) for i in idx], eps)
 
@@ -115,7 +134,7 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
         one()
     t0 = time.time()
     n = 0
-    while n < 200 and time.time() - t0 < budget_s:
+    while n < 200 and (n < 2 or time.time() - t0 < budget_s):
         one()
         n += 1
     dt = time.time() - t0
@@ -189,7 +208,7 @@ def main():
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
                        'parallelism': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)' if world > 1 else 'single GPU',
                        'hipgraph': bool(agent.use_graph and world == 1)},
-            'optimizer_steps_per_sec': round(value * (7 if alg == 'vlsac' else 3), 1),
+            'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B, 1),
             'metrics_finite': bool(finite),
         }
