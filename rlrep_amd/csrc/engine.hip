@@ -338,11 +338,17 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         NcFwdTask t; memset(&t, 0, sizeof(t));
         t.mean = HH; t.lstd = HH ? HH + F : nullptr; t.ld_ml = 2 * F; t.noise = noise; t.W = W; t.bias = bias; t.Hm = Hm; t.U = Ubuf;
         t.B = B; t.F = F; t.H = H; t.N = N;
+        if (getenv("RLREP_NC_DBG")) t.dbg = atoi(getenv("RLREP_NC_DBG"));
         return t;
     };
     auto nc_stage = [&](Program& p, std::vector<NcFwdTask> tasks, const char* what) {
-        // 4 batch rows per workgroup while that keeps <= 4 workgroups per CU, else 8
-        const int g2 = ((long long)tasks.size() * ((B + 3) / 4) * ((H + 63) / 64) <= 1024) ? 1 : 2;
+        // batch rows per workgroup = 4*g2: the largest tile that still gives every CU a workgroup (more
+        // accumulators per wave amortise the LDS-table staging and the epilogue over more MFMAs)
+        // measured on MI355X (B=256, F=H=256): 4 batch rows per workgroup (4 waves per SIMD) beats 8 and 16 rows
+        // (39.8 / 41.6 / 52.2 us for the 4-head launch): one wave per SIMD cannot keep the f32 MFMA pipe busy
+        // behind the VALU that builds its operands.
+        int g2 = ((long long)tasks.size() * ((B + 3) / 4) * ((H + 63) / 64) <= 2048) ? 1 : 2;
+        if (getenv("RLREP_NC_G2")) g2 = atoi(getenv("RLREP_NC_G2"));
         NcFwdBatch nb; memset(&nb, 0, sizeof(nb));
         int base_tile = 0;
         nb.ntasks = (int)tasks.size();

@@ -76,6 +76,7 @@ struct NcFwdTask {
     float* Hm;                       // [B, H]
     float* U;                        // [B*N, H] elu outputs (nullptr: not stored)
     float* sigma_out;                // [B, F] exp(clamp(log_std)) (nullptr: not stored)
+    int dbg;                         // timing experiments only: 1 skip U store, 2 skip table staging, 4 skip MFMA loop, 8 skip elu
     int B, F, H, N;
     int tiles_h, tile_base, ntiles;
 };

@@ -71,20 +71,45 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         const int valid = colok ? max(0, min(4, F - k0)) : 0;
         ld4(wrow + k0, vecW, valid, wv);
     }
-    for (int e = threadIdx.x; e < RB * Fp; e += 256) {
-        const int rr = e / Fp, k = e - rr * Fp;
-        float m = 0.f, s = 0.f;
-        if (b0 + rr < t.B && k < F) {
-            m = t.mean[(size_t)(b0 + rr) * t.ld_ml + k];
-            s = expf(clamp_lstd(t.lstd[(size_t)(b0 + rr) * t.ld_ml + k]));
+    // Table staging: one wave-wide 16-byte load moves a whole 256-float row; every wave issues ALL of its
+    // row loads back to back (fixed trip count, fully unrolled) so their L2 latencies overlap instead of
+    // serialising (the element-wise loop this replaces cost 7.7 us of a 40 us launch).
+    {
+        constexpr int NROWS = 2 * RB + 4 * NC_NF;          // mean rows, sigma rows, noise rows (N = 20)
+        constexpr int SLOTS = (NROWS + 3) / 4;
+        for (int cb = 0; cb < Fp; cb += 256) {
+            const int k = cb + 4 * lane;
+            f32x4 v[SLOTS];
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                const int row = 4 * q + w;
+                v[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (row < NROWS && k < F) {
+                    if (row < 2 * RB) {
+                        const int rr = row < RB ? row : row - RB;
+                        const float* src = (row < RB ? t.mean : t.lstd) + (size_t)(b0 + rr) * t.ld_ml + k;
+                        if (b0 + rr < t.B) v[q] = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+                        v[q] = *reinterpret_cast<const f32x4*>(t.noise + (size_t)(row - 2 * RB) * F + k);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                const int row = 4 * q + w;
+                if (row >= NROWS || k >= Fp) continue;
+                f32x4 x = v[q];
+                if (row >= RB && row < 2 * RB) {
+                    const int rr = row - RB;
+                    const bool ok = (b0 + rr < t.B) && (k < F);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) x[s] = ok ? expf(clamp_lstd(x[s])) : 0.f;
+                    if (t.sigma_out && th == 0 && ok) *reinterpret_cast<f32x4*>(t.sigma_out + (size_t)(b0 + rr) * F + k) = x;
+                }
+                float* dst = (row < RB ? mu_s + row * LDS_LD : row < 2 * RB ? sg_s + (row - RB) * LDS_LD : nz_s + (row - 2 * RB) * LDS_LD) + k;
+                *reinterpret_cast<f32x4*>(dst) = x;
+            }
         }
-        mu_s[rr * LDS_LD + k] = m;
-        sg_s[rr * LDS_LD + k] = s;
-        if (t.sigma_out && th == 0 && b0 + rr < t.B && k < F) t.sigma_out[(size_t)(b0 + rr) * F + k] = s;
-    }
-    for (int e = threadIdx.x; e < N * Fp; e += 256) {
-        const int rr = e / Fp, k = e - rr * Fp;
-        nz_s[rr * LDS_LD + k] = (k < F) ? t.noise[(size_t)rr * F + k] : 0.f;
     }
     __syncthreads();
 
@@ -94,7 +119,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f) acc[g][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kb = 0; kb < Fp; kb += 16) {
+    for (int kb = 0; kb < ((t.dbg & 4) ? 16 : Fp); kb += 16) {
         const int k0 = kb + 4 * kq;
         {   // prefetch the next W fragment
             const int k1 = k0 + 16;
@@ -132,9 +157,9 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = elu_f(acc[g][f][r] + bj);
+                const float y = (t.dbg & 8) ? acc[g][f][r] + bj : elu_f(acc[g][f][r] + bj);
                 sum += y;
-                if (t.U) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
+                if (t.U && !(t.dbg & 1)) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
             }
         t.Hm[(size_t)b * H + col] = sum * invN;
     }
@@ -147,7 +172,16 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
     __shared__ float red[4][NC_NF][4][64];      // 20 KB: head-1 partial accumulators
-    const int bid = blockIdx.x;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2).  The tiles_k column tiles of one
+    // batch tile read the SAME rows of U, so they are given the same (blockIdx % 8) whenever the grid allows.
+    int bid = blockIdx.x;
+    {
+        const int ntb = t.ntiles / t.tiles_k;
+        if ((ntb & 7) == 0) {
+            const int x = bid & 7, y = bid >> 3;
+            bid = ((y / t.tiles_k) * 8 + x) * t.tiles_k + (y % t.tiles_k);
+        }
+    }
     const int tb = bid / t.tiles_k, tk = bid - tb * t.tiles_k;
     const int b0 = tb * 4, kc0 = tk * 64;
     const int F = t.F, H = t.H, N = t.N;
@@ -233,11 +267,19 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
 __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
     __shared__ float red[8][2][4][64];          // 16 KB
     __shared__ float bsum[8][16];
-    __shared__ float nz_s[32 * 33];             // noise[n][32 cols of this tile], ld 33
+    constexpr int NZLD = 36;                    // 4 rows apart -> 16 banks apart: the four kq lane groups do not collide
+    __shared__ float nz_s[32 * NZLD];           // noise[n][32 cols of this tile]
     const int bid = blockIdx.x;
     const int ti = (nb.ntasks > 1 && bid >= nb.t[1].tile_base) ? 1 : 0;
     const NcDwTask& t = nb.t[ti];
-    const int local = bid - t.tile_base;
+    int local = bid - t.tile_base;
+    {   // XCD-aware order: the tiles_k column tiles of one row tile stream the same 16 columns of U
+        const int ntj = t.ntiles / t.tiles_k;
+        if ((ntj & 7) == 0 && (t.tile_base & 7) == 0) {
+            const int x = local & 7, y = local >> 3;
+            local = ((y / t.tiles_k) * 8 + x) * t.tiles_k + (y % t.tiles_k);
+        }
+    }
     const int tj = local / t.tiles_k, tk = local - tj * t.tiles_k;
     const int j0 = tj * 16, k0 = tk * 32;
     const int F = t.F, H = t.H, N = t.N;
@@ -253,7 +295,7 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
 
     for (int e = threadIdx.x; e < N * 32; e += 512) {
         const int n = e >> 5, c = e & 31;
-        nz_s[n * 33 + c] = (k0 + c < F) ? t.noise[(size_t)n * F + k0 + c] : 0.f;
+        nz_s[n * NZLD + c] = (k0 + c < F) ? t.noise[(size_t)n * F + k0 + c] : 0.f;
     }
     __syncthreads();
 
@@ -261,18 +303,24 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
     float asum = 0.f;
     // operands of one 16-row inner chunk, per lane
     struct Chunk { float u[4]; float gh; float mu[2], sg[2]; int n0; };
+    const float* Uj = t.U + (jok ? j : 0);
+    const float* GHj = t.GH + (jok ? j : 0);
+    const float* MUk[2] = {t.mean + (kok[0] ? kc[0] : 0), t.mean + (kok[1] ? kc[1] : 0)};
+    const float* SGk[2] = {t.sigma + (kok[0] ? kc[0] : 0), t.sigma + (kok[1] ? kc[1] : 0)};
+    const unsigned Nu = (unsigned)N, Hu = (unsigned)H, Fu = (unsigned)F, ldg = (unsigned)t.ldgh, ldm = (unsigned)t.ld_ml;
     auto load = [&](int c, Chunk& q) {
-        const int r0 = 16 * c + 4 * kq;          // first of this lane's 4 inner rows
-        const bool ok = r0 < M;                  // M is a multiple of 4
-        const int b = ok ? r0 / N : 0;
-        q.n0 = ok ? r0 - b * N : 0;
-        q.gh = (ok && jok) ? t.GH[(size_t)b * t.ldgh + j] * invN : 0.f;
+        const unsigned r0 = 16u * (unsigned)c + 4u * (unsigned)kq;     // first of this lane's 4 inner rows
+        const bool ok = r0 < (unsigned)M;                              // M is a multiple of 4
+        const unsigned b = ok ? r0 / Nu : 0u;
+        q.n0 = ok ? (int)(r0 - b * Nu) : 0;
+        q.gh = (ok && jok) ? GHj[b * ldg] * invN : 0.f;
+        const float* up = Uj + (ok ? r0 * Hu : 0u);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) q.u[s] = (ok && jok) ? t.U[(size_t)(r0 + s) * H + j] : 1.f;
+        for (int s = 0; s < 4; ++s) q.u[s] = (ok && jok) ? up[s * Hu] : 1.f;
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            q.mu[f] = (ok && kok[f]) ? t.mean[(size_t)b * t.ld_ml + kc[f]] : 0.f;
-            q.sg[f] = (ok && kok[f]) ? t.sigma[(size_t)b * F + kc[f]] : 0.f;
+            q.mu[f] = (ok && kok[f]) ? MUk[f][b * ldm] : 0.f;
+            q.sg[f] = (ok && kok[f]) ? SGk[f][b * Fu] : 0.f;
         }
     };
     auto compute = [&](const Chunk& q) {
@@ -283,7 +331,7 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], fmaf(q.sg[f], nz_s[(q.n0 + s) * 33 + 16 * f + i], q.mu[f]), acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], fmaf(q.sg[f], nz_s[(q.n0 + s) * NZLD + 16 * f + i], q.mu[f]), acc[f], 0, 0, 0);
         if (want_bias) asum += (a[0] + a[1]) + (a[2] + a[3]);
     };
     // wave w takes chunks w, w+8, ...; four of them (32 MFMAs) are in flight ahead of the ones being computed
@@ -335,7 +383,8 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     const int Fp = (F + 15) & ~15;
     const size_t lds = (size_t)(8 * g2 + N) * (Fp + 16) * sizeof(float);
     if (g2 == 1) hipLaunchKernelGGL(nc_fwd_kernel<1>, dim3(total_tiles), dim3(256), lds, st, *nb);
-    else hipLaunchKernelGGL(nc_fwd_kernel<2>, dim3(total_tiles), dim3(256), lds, st, *nb);
+    else if (g2 == 2) hipLaunchKernelGGL(nc_fwd_kernel<2>, dim3(total_tiles), dim3(256), lds, st, *nb);
+    else hipLaunchKernelGGL(nc_fwd_kernel<4>, dim3(total_tiles), dim3(256), lds, st, *nb);
     return (int)hipGetLastError();
 }
 
