@@ -243,6 +243,11 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dx(GZM, F, B, F, Pw("mu.l3.weight"), Hm, GM2, Hm, Hm, ACT_ELU, M2, Hm)}, "l3 dx");
         b.dx_stage(p, {Builder::dx(pf.G2, Hp, B, Hp, Pw("phi.l2.weight"), Hp, pf.G1, Hp, Hp, ACT_ELU, pf.P1, Hp),
                        Builder::dx(GM2, Hm, B, Hm, Pw("mu.l2.weight"), Hm, GM1, Hm, Hm, ACT_ELU, M1, Hm)}, "l2 dx");
+        {
+            const LT& q0 = ag->L.get("phi.l1.weight");
+            const LT& ql = ag->L.get("phi.l3.bias");
+            b.set_polyak(Tw("phi_target.l1.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
+        }
         b.dw_stage(p, {Builder::dw(pf.GZ, F, F, pf.P2, Hp, Hp, B, Gw("phi.l3.weight"), Hp, Gw("phi.l3.bias")),
                        Builder::dw(GZM, F, F, M2, Hm, Hm, B, Gw("mu.l3.weight"), Hm, Gw("mu.l3.bias")),
                        Builder::dw(pf.G2, Hp, Hp, pf.P1, Hp, Hp, B, Gw("phi.l2.weight"), Hp, Gw("phi.l2.bias")),
@@ -250,6 +255,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(pf.G1, Hp, Hp, s0.XF, SA, SA, B, Gw("phi.l1.weight"), SA, Gw("phi.l1.bias")),
                        Builder::dw(GM1, Hm, Hm, s2, KE, S, B, Gw("mu.l1.weight"), S, Gw("mu.l1.bias")),
                        Builder::dw(DRH, 1, 1, pf.Z, F, F, B, Gw("theta.l.weight"), F, Gw("theta.l.bias"))}, "feature dW");
+        b.clear_polyak();
         const LT& p0 = ag->L.get("phi.l1.weight");
         const LT& pl = ag->L.get("phi.l3.bias");
         float* m = ag->metrics;
@@ -451,7 +457,11 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
             for (int l = 0; l <= phi.depth; ++l) t.push_back(mlp_dw(ag, phi, pf, l, X2, SA));
             for (int l = 0; l <= mu.depth; ++l) t.push_back(mlp_dw(ag, mu, mf, l, S2, KE));
             t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
+            const LT& q0 = ag->L.get(phi.name(0) + ".weight");
+            const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
+            b.set_polyak(ag->T("phi_target.trunk.0.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
             b.dw_stage(p, t, "feature dW");
+            b.clear_polyak();
         }
         const LT& p0 = ag->L.get(phi.name(0) + ".weight");
         const LT& pl = ag->L.get(phi.name(phi.depth) + ".bias");

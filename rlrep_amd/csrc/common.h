@@ -30,6 +30,7 @@ enum Epi : int {
 #define FLAG_ACCUM 1       // C += value instead of C = value
 #define FLAG_BIASGRAD 2    // EPI_DW: also emit the bias gradient (only by column-tile 0)
 
+struct GroupCfg;
 struct GemmTask {
     const float* A;      // operand A (output rows)
     const float* B;      // operand B (output cols)
@@ -48,6 +49,11 @@ struct GemmTask {
     int ncN;             // noise rows (20) for LD_NCG/LD_NCX
     int F;               // EPI_DX_REPARAM: column offset of the log-std half
     float scale;         // multiplies acc before the epilogue (1.0 default)
+    // EPI_DW with the optimizer fused in (single-GPU path): Adam on the tile's own weights (and bias), plus
+    // Polyak into the target copy.  All pointers are bases of tensors laid out like C / out2.
+    float* ad_p; float* ad_m; float* ad_v; float* ad_t;          // weight: param, exp_avg, exp_avg_sq, target (or null)
+    float* ad_pb; float* ad_mb; float* ad_vb; float* ad_tb;      // bias
+    const GroupCfg* ad_grp;
 };
 
 #define GEMM_MAX_TASKS 8
@@ -60,7 +66,7 @@ struct AdamTask {
     float* p; const float* g; float* m; float* v;
     long long n;
     float lr, beta1, beta2, eps;
-    const int* step;            // device step counter (already incremented for this step)
+    const GroupCfg* grp;        // group state (step already bumped for this step)
     // optional Polyak of a sub-range [pol_off, pol_off+pol_n) of p into target
     float* target; long long pol_off, pol_n; float tau;
 };
@@ -88,6 +94,39 @@ __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1
 
 __device__ __forceinline__ float softplus_f(float u) {   // torch F.softplus, beta=1, threshold=20
     return u > 20.f ? u : log1pf(expf(u));
+}
+
+// one Adam update (torch/optim/adam.py::_single_tensor_adam order) + optional Polyak of the new value
+struct AdamScal { float nss, bc2s, w1, w2, b2, eps, tau, omt; };
+__device__ __forceinline__ AdamScal adam_scalars(float lr, float b1, float b2, float eps, float tau, int step) {
+    AdamScal a;
+    const double st = (double)step;
+    const double bc1 = 1.0 - pow((double)b1, st), bc2 = 1.0 - pow((double)b2, st);
+    a.nss = (float)(-((double)lr / bc1));
+    a.bc2s = (float)sqrt(bc2);
+    a.w1 = (float)(1.0 - (double)b1);
+    a.w2 = (float)(1.0 - (double)b2);
+    a.b2 = b2; a.eps = eps; a.tau = tau; a.omt = (float)(1.0 - (double)tau);
+    return a;
+}
+__device__ __forceinline__ void adam_elem(const AdamScal& a, float g, float* p, float* m, float* v, float* target) {
+    float mm = *m, vv = *v, pv = *p;
+    mm = mm + a.w1 * (g - mm);
+    vv = vv * a.b2;
+    vv = vv + (a.w2 * g) * g;
+    const float denom = sqrtf(vv) / a.bc2s + a.eps;
+    pv = pv + a.nss * (mm / denom);
+    *m = mm; *v = vv; *p = pv;
+    if (target) *target = a.tau * pv + a.omt * (*target);
+}
+
+// Per-optimizer-group device state: hyper-parameters (written once at create), the Adam step counter and the
+// bias-correction scalars of the CURRENT step.  The loss kernel of a step program bumps it (one thread, one
+// double-precision pow) so that the optimizer epilogues only read eight floats.
+struct GroupCfg { int step; float lr, b1, b2, eps, tau; AdamScal sc; };
+__device__ __forceinline__ void bump_group(GroupCfg* g) {
+    g->step += 1;
+    g->sc = adam_scalars(g->lr, g->b1, g->b2, g->eps, g->tau, g->step);
 }
 
 // block-wide sum for 256-thread blocks; result valid in thread 0

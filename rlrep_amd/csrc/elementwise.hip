@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void vae_mid_kernel(VaeMid p) {
     const float s = block_sum_256(k, sh);
     if (threadIdx.x == 0) {
         p.partial[blockIdx.x] = s;
-        if (blockIdx.x == 0 && p.step) *p.step += 1;    // Adam step counter of the feature group
+        if (blockIdx.x == 0 && p.step) bump_group(p.step);    // Adam step counter of the feature group
     }
 }
 
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void qhead_critic_kernel(QHeadCritic p) {
         const int i = threadIdx.x;
         p.partial[4 * blockIdx.x + i] = ((shp[0][i] + shp[1][i]) + shp[2][i]) + shp[3][i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.step) *p.step += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.step) bump_group(p.step);
 }
 
 __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
     if (threadIdx.x == 0) {
         p.partial_loss[blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
         p.partial_c[blockIdx.x] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
-        if (blockIdx.x == 0 && p.step) *p.step += 1;
+        if (blockIdx.x == 0 && p.step) bump_group(p.step);
     }
 }
 
@@ -303,7 +303,6 @@ __device__ void finalize_tasks(const FinTask* __restrict__ fin, int nfin, int la
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
                                                    const PolyakTask* __restrict__ pol, int npol,
                                                    const FinTask* __restrict__ fin, int nfin) {
-    __shared__ float sc[3];
     const int bid = blockIdx.x;
     if (bid >= adam_blocks) {
         // trailing block: standalone Polyak tasks are handled by their own blocks below; this one finalises
@@ -318,34 +317,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
         base_blk += nb;
     }
     const AdamTask& t = tasks[ti];
-    if (threadIdx.x == 0) {
-        const double step = (double)(*t.step);
-        const double bc1 = 1.0 - pow((double)t.beta1, step);
-        const double bc2 = 1.0 - pow((double)t.beta2, step);
-        sc[0] = (float)(-((double)t.lr / bc1));     // value = -step_size
-        sc[1] = (float)sqrt(bc2);                    // bias_correction2_sqrt
-    }
-    __syncthreads();
-    const float nss = sc[0], bc2s = sc[1];
-    const float w1 = (float)(1.0 - (double)t.beta1), w2 = (float)(1.0 - (double)t.beta2);
-    const float omt = (float)(1.0 - (double)t.tau);
+    const AdamScal sc = t.grp->sc;
     const long long i0 = (long long)(bid - base_blk) * 1024 + threadIdx.x;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const long long i = i0 + s * 256;
         if (i >= t.n) break;
-        const float g = t.g[i];
-        float m = t.m[i], v = t.v[i], pv = t.p[i];
-        m = m + w1 * (g - m);
-        v = v * t.beta2;
-        v = v + (w2 * g) * g;
-        const float denom = sqrtf(v) / bc2s + t.eps;
-        pv = pv + nss * (m / denom);
-        t.m[i] = m; t.v[i] = v; t.p[i] = pv;
-        if (t.target && i >= t.pol_off && i < t.pol_off + t.pol_n) {
-            float* tp = t.target + (i - t.pol_off);
-            *tp = t.tau * pv + omt * (*tp);
-        }
+        float* tp = (t.target && i >= t.pol_off && i < t.pol_off + t.pol_n) ? t.target + (i - t.pol_off) : nullptr;
+        adam_elem(sc, t.g[i], t.p + i, t.m + i, t.v + i, tp);
     }
 }
 

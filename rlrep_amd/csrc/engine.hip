@@ -297,6 +297,11 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dx(GFH, 2 * F, B, 2 * F, Pw("f.mean_linear.weight"), Hv, GH2f, Hv, Hv, ACT_RELU, gf.H2, Hv)}, "heads dx");
         b.dx_stage(p, {Builder::dx(GH2e, Hv, B, Hv, Pw("encoder.l2.weight"), Hv, GH1e, Hv, Hv, ACT_RELU, ge.H1, Hv),
                        Builder::dx(GH2f, Hv, B, Hv, Pw("f.l2.weight"), Hv, GH1f, Hv, Hv, ACT_RELU, gf.H1, Hv)}, "l2 dx");
+        {
+            const LT& f0 = ag->L.get("f.l1.weight");
+            const LT& fl = ag->L.get("f.log_std_linear.bias");
+            b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
+        }
         b.dw_stage(p, {Builder::dw(GDH, S + 1, S + 1, D1, Hv, Hv, B, Gw("decoder.state_linear.weight"), Hv, Gw("decoder.state_linear.bias")),
                        Builder::dw(GD1, Hv, Hv, Z, F, F, B, Gw("decoder.l1.weight"), F, Gw("decoder.l1.bias")),
                        Builder::dw(GEH, 2 * F, 2 * F, ge.H2, Hv, Hv, B, Gw("encoder.mean_linear.weight"), Hv, Gw("encoder.mean_linear.bias")),
@@ -305,6 +310,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(GH2f, Hv, Hv, gf.H1, Hv, Hv, B, Gw("f.l2.weight"), Hv, Gw("f.l2.bias")),
                        Builder::dw(GH1e, Hv, Hv, s0.XE, KE, KE, B, Gw("encoder.l1.weight"), KE, Gw("encoder.l1.bias")),
                        Builder::dw(GH1f, Hv, Hv, s0.XF, SA, SA, B, Gw("f.l1.weight"), SA, Gw("f.l1.bias"))}, "feature dW");
+        b.clear_polyak();
         // apply: Adam over (encoder, decoder, f) + Polyak f -> f_target (vlsac_agent.py:152-154, 240-242)
         const LT& f0 = ag->L.get("f.l1.weight");
         const LT& flast = ag->L.get("f.log_std_linear.bias");
@@ -409,6 +415,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                 t.U = Ubuf; t.GH = GH; t.ldgh = H; t.mean = gt.HH; t.sigma = SIG; t.ld_ml = 2 * F;
                 t.noise = noise; t.gW = gW; t.gb = gb; t.B = B; t.F = F; t.H = H; t.N = N;
                 t.tiles_k = (F + 31) / 32; t.ntiles = ((H + 15) / 16) * t.tiles_k; t.tile_base = base_tile; base_tile += t.ntiles;
+                if (b.fused() && gW) {
+                    const int64_t ow = gW - ag->a.grad_dev, ob = gb - ag->a.grad_dev;
+                    t.ad_p = ag->a.param_dev + ow; t.ad_m = ag->a.exp_avg_dev + ow; t.ad_v = ag->a.exp_avg_sq_dev + ow;
+                    t.ad_pb = ag->a.param_dev + ob; t.ad_mb = ag->a.exp_avg_dev + ob; t.ad_vb = ag->a.exp_avg_sq_dev + ob;
+                    t.ad_grp = ag->adam_step + 1;
+                }
             };
             ncdw(0, U, GHm, Gw("critic.l1.weight"), Gw("critic.l1.bias"));
             ncdw(1, U + BNH, GHm + BH, Gw("critic.l4.weight"), Gw("critic.l4.bias"));
@@ -525,7 +537,7 @@ static void static_state(rlrep_agent* ag) {
     Workspace& ws = ag->ws;
     ws.used = 0;
     ag->steps = (int*)ws.alloc(sizeof(int) * 8);
-    ag->adam_step = ag->steps + 1;     // [4] groups
+    ag->adam_step = (GroupCfg*)ws.alloc(sizeof(GroupCfg) * 4);     // [4] optimizer groups
     ag->metrics = ws.f(M_COUNT);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
     ag->obs_in = ws.f((size_t)ag->d.max_batch * S);
@@ -604,6 +616,15 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
     static_state(ag.get());
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ag->steps, 0, sizeof(int) * 8 + 0, st);
+    {
+        GroupCfg gc[4]; memset(gc, 0, sizeof(gc));
+        for (int g = 0; g < 4; ++g) {
+            gc[g].lr = g == 1 ? hyper->lr_critic : g == 2 ? hyper->lr_actor : hyper->lr_feature;
+            gc[g].b1 = hyper->beta1; gc[g].b2 = hyper->beta2; gc[g].eps = hyper->adam_eps;
+            gc[g].tau = (g == 0) ? hyper->feature_tau : 0.f;
+        }
+        if (e == hipSuccess) e = hipMemcpy(ag->adam_step, gc, sizeof(gc), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(ag->metrics, 0, sizeof(float) * M_COUNT, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { rl_set_error("create: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }

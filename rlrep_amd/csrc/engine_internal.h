@@ -7,7 +7,7 @@ struct Slot { float *XE, *XF, *XF2, *XFpi, *R, *D; bool filled = false; };
 struct rlrep_agent {
     rlrep_dims d; rlrep_hyper h; rlrep_arenas a; Layout L; Workspace ws;
     int B = 0;
-    int* steps = nullptr; int* adam_step = nullptr; float* metrics = nullptr; float* obs_in = nullptr; float* act_out = nullptr;
+    int* steps = nullptr; GroupCfg* adam_step = nullptr; float* metrics = nullptr; float* obs_in = nullptr; float* act_out = nullptr;
     Slot slot[2];
     // per-call dynamic inputs, read by the by-value parameter blocks at launch time
     const float* cur_eps = nullptr; const int* cur_idx = nullptr;
@@ -80,12 +80,57 @@ struct Builder {
         const int total = base_tile;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
     }
+    // ---- optimizer fusion (single-GPU path) ------------------------------------------------------
+    // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch CAN apply
+    // Adam (and the Polyak of the target copy) to its own tile in the epilogue, saving one launch per optimizer
+    // step.  Measured on MI355X (vlsac, B=256) it LOSES: the 16x16-tile epilogue touches p/m/v in 64-byte segments
+    // and the dW launch grows by 5.4 us, more than the 2.7 us the separate (fully coalesced) Adam launch costs over
+    // a bare finalise launch -- 624 vs 608 us per train().  Kept behind RLREP_FUSE_ADAM=1 for larger layers.
+    bool fused() const { return ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev; }
+    float lr_of(int g) const { return g == 1 ? ag->h.lr_critic : g == 2 ? ag->h.lr_actor : ag->h.lr_feature; }
+    int group_of(int64_t off) const {
+        for (int g = 0; g < 4; ++g) if (ag->L.group_n[g] > 0 && off >= ag->L.group_off[g] && off < ag->L.group_off[g] + ag->L.group_n[g]) return g;
+        return -1;
+    }
+    void attach_adam(std::vector<GemmTask>& tasks, float* target = nullptr, int64_t pol_off = 0, int64_t pol_n = 0, float tau = 0.f) {
+        if (!fused()) return;
+        for (auto& t : tasks) {
+            if (t.epi != EPI_DW || !t.C) continue;
+            const int64_t off = t.C - ag->a.grad_dev;
+            const int g = group_of(off);
+            if (g < 0) continue;
+            t.ad_p = ag->a.param_dev + off; t.ad_m = ag->a.exp_avg_dev + off; t.ad_v = ag->a.exp_avg_sq_dev + off;
+            t.ad_t = (target && off >= pol_off && off < pol_off + pol_n) ? target + (off - pol_off) : nullptr;
+            if (t.out2) {
+                const int64_t ob = t.out2 - ag->a.grad_dev;
+                t.ad_pb = ag->a.param_dev + ob; t.ad_mb = ag->a.exp_avg_dev + ob; t.ad_vb = ag->a.exp_avg_sq_dev + ob;
+                t.ad_tb = (target && ob >= pol_off && ob < pol_off + pol_n) ? target + (ob - pol_off) : nullptr;
+            }
+            t.ad_grp = ag->adam_step + g;
+        }
+    }
+    void dw_stage_opt(Program& p, std::vector<GemmTask> t, const char* w, float* target = nullptr, int64_t pol_off = 0, int64_t pol_n = 0, float tau = 0.f) {
+        attach_adam(t, target, pol_off, pol_n, tau);
+        gemm(p, LD_COL, LD_COL, t, w);
+    }
+
     void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
     void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
-    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_COL, LD_COL, t, w); }
+    // weight-gradient stage; carries the fused optimizer (and the Polyak spec set by set_polyak) when fused()
+    float* pol_target = nullptr; int64_t pol_off = 0, pol_n = 0; float pol_tau = 0.f;
+    void set_polyak(float* target, int64_t off, int64_t n, float tau) { pol_target = target; pol_off = off; pol_n = n; pol_tau = tau; }
+    void clear_polyak() { pol_target = nullptr; pol_off = pol_n = 0; pol_tau = 0.f; }
+    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) {
+        attach_adam(t, pol_target, pol_off, pol_n, pol_tau);
+        gemm(p, LD_COL, LD_COL, t, w);
+    }
 
     void adam(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau,
               std::vector<FinTask> fin, const char* what) {
+        if (fused()) {          // Adam already ran in the dW epilogues: only the metric / temperature finalisation is left
+            if (!fin.empty()) finalize_only(p, fin, what);
+            return;
+        }
         const auto& L = ag->L;
         AdamTask t; memset(&t, 0, sizeof(t));
         const int64_t off = L.group_off[group];
@@ -95,7 +140,7 @@ struct Builder {
         t.v = ag->a.exp_avg_sq_dev ? ag->a.exp_avg_sq_dev + off : nullptr;
         t.n = L.group_n[group];
         t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
-        t.step = ag->adam_step + group;
+        t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau;
         std::vector<AdamTask> tv{t};
         const AdamTask* dev = upload(tv);

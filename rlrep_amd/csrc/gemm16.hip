@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         else if (t.flags & FLAG_ACCUM) cold = *cp;
     }
 
+    AdamScal adsc;
+    if (t.epi == EPI_DW && t.ad_p) adsc = t.ad_grp->sc;
+
     // wave w owns the 16-wide inner chunks w, w+4, w+8, ...; four chunks (all of K <= 256) are loaded
     // back to back before the first MFMA so that their L2 latencies overlap
     for (int kb = w * 16; kb < K; kb += 256) {
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 
     if (want_bias && threadIdx.x < 16 && r0 + (int)threadIdx.x < t.R) {
         const int q = threadIdx.x;
-        t.out2[r0 + q] = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
+        const float gb = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
+        t.out2[r0 + q] = gb;
+        if (t.ad_pb) adam_elem(adsc, gb, t.ad_pb + r0 + q, t.ad_mb + r0 + q, t.ad_vb + r0 + q, t.ad_tb ? t.ad_tb + r0 + q : nullptr);
     }
     if (!inb) return;
 
@@ -153,9 +158,14 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         cp[t.F] = cold2 + v * e0;
         break;
     case EPI_DW:
-    default:
-        *cp = cold + v;
-        break;
+    default: {
+        const float g = cold + v;
+        *cp = g;
+        if (t.ad_p) {
+            const size_t o = (size_t)r * t.ldc + c;
+            adam_elem(adsc, g, t.ad_p + o, t.ad_m + o, t.ad_v + o, t.ad_t ? t.ad_t + o : nullptr);
+        }
+    } break;
     }
 }
 

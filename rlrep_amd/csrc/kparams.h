@@ -1,6 +1,7 @@
 // Kernel parameter blocks shared by the device code and the host-side program builder.
 #pragma once
 #include <stdint.h>
+struct GroupCfg;
 
 struct SlotFill {
     const float* ring; const int* idx;                       // ring gather (ring != nullptr) ...
@@ -32,7 +33,7 @@ struct PolicyBwd {
 struct VaeMid {
     const float* EH; const float* FH; const float* eps;
     float* Z; float* EZ; float* GEH; float* GFH; float* partial;
-    int B, F, nblk; float scale; int* step;
+    int B, F, nblk; float scale; GroupCfg* step;
 };
 
 struct VaeMse {
@@ -46,7 +47,7 @@ struct QHeadCritic {
     const float* logp; const float* R; const float* D;
     const double* alpha_state; float gamma, inv_batch;
     float* dq; float* GE[2]; float* partial;
-    int B, H, nblk, train; int* step;
+    int B, H, nblk, train; GroupCfg* step;
     int ldE;                   // row stride of Et/Ec/GE (0 -> H)
 };
 
@@ -54,7 +55,7 @@ struct QHeadActor {
     const float* Ec[2]; const float* wc[2]; const float* bc[2];
     const float* logp; const double* alpha_state; float inv_batch, target_entropy;
     float* GE[2]; float* partial_loss; float* partial_c;
-    int B, H, nblk; int* step;
+    int B, H, nblk; GroupCfg* step;
     int ldE;                   // row stride of Ec/GE (0 -> H)
 };
 
@@ -91,6 +92,9 @@ struct NcDwTask {
     float* gW; float* gb;                           // [H, F], [H]
     int B, F, H, N;
     int tiles_k, tile_base, ntiles;
+    // optimizer fused into the epilogue (single-GPU path); null ad_p: gradients only
+    float* ad_p; float* ad_m; float* ad_v; float* ad_pb; float* ad_mb; float* ad_vb;
+    const GroupCfg* ad_grp;
 };
 struct NcDwBatch { int ntasks; NcDwTask t[2]; };
 
@@ -112,13 +116,13 @@ struct NcDxTask {
 struct InfoNce {
     float* S; int ldS;                 // [B,B] scores in, dS out (in place)
     const float* rhat; const float* r; float* drhat;
-    float* partial; int B, nblk; float inv_batch; int* step;
+    float* partial; int B, nblk; float inv_batch; GroupCfg* step;
 };
 struct ColSum { const float* X; int ldX; const float* w; float* out; int rows, F; };
 struct SpederRows {
     const float* phi; const float* mu; const float* mu_r; const float* phibar;
     const float* theta_w; const float* theta_b; const float* r;
-    float* c; float* drhat; float* partial; int B, F, nblk; float inv_batch; int* step;
+    float* c; float* drhat; float* partial; int B, F, nblk; float inv_batch; GroupCfg* step;
 };
 struct SpederGrads {
     const float* phi; const float* mu; const float* c; const float* drhat; const float* phibar; const float* v;
@@ -126,7 +130,7 @@ struct SpederGrads {
 };
 struct DiffsrPerturb {
     const float* alphabars; const int* idx; const float* s2; int ld_s2; const float* eps;
-    float* XN; float* TGT; int B, S; int* step0; int* step1;
+    float* XN; float* TGT; int B, S; GroupCfg* step0; GroupCfg* step1;
 };
 struct DiffsrScore {
     float* U; const float* PHI; const float* TGT; const float* alphabars; const int* idx;

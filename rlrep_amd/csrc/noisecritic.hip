@@ -205,32 +205,42 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
         const float* GH = t.GH[h] + (size_t)(rowok ? b : 0) * t.ldgh;
         const float* U = t.U[h] + (size_t)(rowok ? b : 0) * N * H;
         const float* W = t.W[h] + (colok ? kcol : 0);
-        float gh[4], u[NC_NF][4], wv[4], ghn[4], un[NC_NF][4], wn[4];
-        auto load = [&](int jb, float (&g_)[4], float (&u_)[NC_NF][4], float (&w_)[4]) {
+        // operands of one 16-wide inner step (4 hidden units per lane group)
+        struct Step { float gh[4]; float u[NC_NF][4]; float wv[4]; };
+        const unsigned Hu = (unsigned)H, Fu = (unsigned)F;
+        auto load = [&](int jb, Step& q) {
             const int j0 = jb + 4 * kq;
             const int valid = max(0, min(4, H - j0));
-            ld4(GH + j0, vecG, rowok ? valid : 0, g_);
+            ld4(GH + j0, vecG, rowok ? valid : 0, q.gh);
 #pragma unroll
-            for (int f = 0; f < NC_NF; ++f) ld4(U + (size_t)(4 * f + nn) * H + j0, vecG, rowok ? valid : 0, u_[f]);
+            for (int f = 0; f < NC_NF; ++f) ld4(U + (unsigned)(4 * f + nn) * Hu + j0, vecG, rowok ? valid : 0, q.u[f]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) w_[s] = (colok && j0 + s < H) ? W[(size_t)(j0 + s) * F] : 0.f;
+            for (int s = 0; s < 4; ++s) q.wv[s] = (colok && j0 + s < H) ? W[(unsigned)(j0 + s) * Fu] : 0.f;
         };
-        load(0, gh, u, wv);
-        for (int jb = 0; jb < H; jb += 16) {
-            if (jb + 16 < H) load(jb + 16, ghn, un, wn);
+        auto compute = [&](const Step& q) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float gs = gh[s] * invN;
+                const float gs = q.gh[s] * invN;
 #pragma unroll
                 for (int f = 0; f < NC_NF; ++f)
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs * elu_grad_from_out(u[f][s]), wv[s], acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs * elu_grad_from_out(q.u[f][s]), q.wv[s], acc[f], 0, 0, 0);
+            }
+        };
+        // GS steps (GS*20 MFMAs) are in flight ahead of the GS being computed: L2 latency >> one step's MFMAs.
+        // GS = 2 is the deepest that fits 256 VGPRs at 2 waves/SIMD without spilling (GS = 4 spills 44 VGPRs: 45 us).
+        constexpr int GS = 2;
+        Step cur[GS], nxt[GS];
+#pragma unroll
+        for (int g = 0; g < GS; ++g) load(16 * g, cur[g]);
+        for (int jb = 0; jb < H; jb += 16 * GS) {
+            if (jb + 16 * GS < H) {
+#pragma unroll
+                for (int g = 0; g < GS; ++g) load(jb + 16 * GS + 16 * g, nxt[g]);
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                gh[s] = ghn[s]; wv[s] = wn[s];
+            for (int g = 0; g < GS; ++g) if (jb + 16 * g < H) compute(cur[g]);
 #pragma unroll
-                for (int f = 0; f < NC_NF; ++f) u[f][s] = un[f][s];
-            }
+            for (int g = 0; g < GS; ++g) cur[g] = nxt[g];
         }
     }
     if (w8 >= 4) {
@@ -293,6 +303,8 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
     const float invN = 1.0f / (float)N;
     const bool want_bias = (tk == 0);
 
+    AdamScal adsc;
+    if (t.ad_p) { adsc = t.ad_grp->sc; adsc.tau = 0.f; }
     for (int e = threadIdx.x; e < N * 32; e += 512) {
         const int n = e >> 5, c = e & 31;
         nz_s[n * NZLD + c] = (k0 + c < F) ? t.noise[(size_t)n * F + k0 + c] : 0.f;
@@ -366,13 +378,18 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) v += red[ww][f][r][ol];
         const int row = j0 + (ol >> 4) * 4 + r, colk = k0 + 16 * f + (ol & 15);
-        if (row < H && colk < F) t.gW[(size_t)row * F + colk] = v;
+        if (row < H && colk < F) {
+            const size_t o = (size_t)row * F + colk;
+            t.gW[o] = v;
+            if (t.ad_p) adam_elem(adsc, v, t.ad_p + o, t.ad_m + o, t.ad_v + o, nullptr);
+        }
     }
     if (want_bias && threadIdx.x < 16 && j0 + (int)threadIdx.x < H) {
         float v = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) v += bsum[ww][threadIdx.x];
         t.gb[j0 + threadIdx.x] = v;
+        if (t.ad_pb) { const int o = j0 + threadIdx.x; adam_elem(adsc, v, t.ad_pb + o, t.ad_mb + o, t.ad_vb + o, nullptr); }
     }
 }
 

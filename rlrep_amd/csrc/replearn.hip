@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void infonce_kernel(InfoNce p) {
     if (threadIdx.x == 0) {
         p.partial[2 * blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
         p.partial[2 * blockIdx.x + 1] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
-        if (blockIdx.x == 0 && p.step) *p.step += 1;
+        if (blockIdx.x == 0 && p.step) bump_group(p.step);
     }
 }
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void speder_rows_kernel(SpederRows p) {
         const int q = threadIdx.x;
         p.partial[3 * blockIdx.x + q] = ((shp[0][q] + shp[1][q]) + shp[2][q]) + shp[3][q];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.step) *p.step += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.step) bump_group(p.step);
 }
 
 // gradients w.r.t. the four feature matrices, written as one [2B, F] block each for phi and mu
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void diffsr_perturb_kernel(DiffsrPerturb p) {
         p.XN[e] = pert;
         p.TGT[(size_t)b * p.S + s] = -(pert - sq * x);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { if (p.step0) *p.step0 += 1; if (p.step1) *p.step1 += 1; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (p.step0) bump_group(p.step0); if (p.step1) bump_group(p.step1); }
 }
 
 // one workgroup per sample: score_s = sum_z phi_z U[z,s]; loss; dphi_z = sum_s dscore_s U[z,s]; U <- dU = phi_z dscore_s
