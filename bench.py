@@ -161,12 +161,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
                              '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('RLREP_DIST_BACKEND', 'nccl')      # 'gloo' lets two ranks share one GPU in tests
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     if args.no_graph:
         os.environ['RLREP_GRAPH'] = '0'
 

@@ -101,6 +101,8 @@ class SACAgent(object):
         self._ctr = 0
         self._bufs = {}
         self._graph = None
+        self._seg = None
+        self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
         self._inject = None
         self._pool = None
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
@@ -174,6 +176,8 @@ class SACAgent(object):
         self.steps += 1
         if self.use_graph and self.world_size == 1:
             return self._train_graph(buffer, batch_size)
+        if self.use_graph and self.use_graph_dp:
+            return self._train_graph_dp(buffer, batch_size)
         return self._train_eager(buffer, batch_size)
 
     update = train      # BASELINE.json's north_star calls it agent.update()
@@ -212,7 +216,19 @@ class SACAgent(object):
         lay = self.core.layout
         o, n = lay.group_offset[group], lay.group_floats[group]
         end = lay.grad_floats if with_tail else o + n
-        dist.all_reduce(self.core.grads[o:end])
+        view = self.core.grads[o:end]
+        if self._seg is not None:
+            # segmented capture (data parallel + hipGraph): close the graph segment recorded so far, remember the
+            # collective as an eager step, open the next segment.  No RCCL call is ever captured.
+            segs, cur = self._seg
+            cur.capture_end()
+            segs.append(('graph', cur))
+            segs.append(('allreduce', view))
+            nxt = torch.cuda.CUDAGraph()
+            nxt.capture_begin()
+            self._seg = (segs, nxt)
+            return
+        dist.all_reduce(view)
 
     # ---- pooled noise: ALL sample indices and ALL standard-normal noise of one train() come from two
     # Philox launches into two contiguous buffers (instead of one launch per tensor) ---------------------
@@ -326,6 +342,40 @@ class SACAgent(object):
     def _train_eager(self, buffer, B):
         buffer.flush()
         self._body(buffer, B, False)
+        return self.core.info()
+
+    def _train_graph_dp(self, buffer, B):
+        """world_size > 1: the launches between two gradient all-reduces are captured as separate hipGraphs
+        (7 for vlsac) and replayed around eager RCCL all-reduces."""
+        import torch.distributed as dist
+        buffer.flush()
+        buffer.size_dev()
+        key = (id(buffer), B)
+        if self._graph is None or self._graph_key != key:
+            self._sample_into(buffer, B, 'warm', 0, False)
+            self._fill_pools(buffer, B, True)              # allocate the noise pools outside any capture
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                first = torch.cuda.CUDAGraph()
+                first.capture_begin()
+                self._seg = ([], first)
+                try:
+                    self._body(buffer, B, True)
+                    segs, cur = self._seg
+                    cur.capture_end()
+                    segs.append(('graph', cur))
+                finally:
+                    self._seg = None
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._graph, self._graph_key = segs, key
+        for kind, x in self._graph:
+            if kind == 'graph':
+                x.replay()
+            else:
+                dist.all_reduce(x)
         return self.core.info()
 
     def _train_graph(self, buffer, B):

@@ -157,3 +157,40 @@ def test_hip_dp_two_ranks_match_global_batch_oracle():
         assert np.array_equal(v, res[1][k]), f'replicas diverged at {k}'
         if k in P and not k.endswith('noise'):
             assert rel_l2(v, P[k].numpy()) < 1e-4, k
+
+
+def _gpu_graph_worker(rank, world, port, q):
+    from fixture_io import Case
+    from test_hip_parity import make_agent, make_buffer
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    c = Case('vlsac_tiny')
+    agent = make_agent(c)
+    agent.use_graph = True                   # segmented hipGraph capture around the eager all-reduces
+    buf = make_buffer(c)
+    infos = [agent.train(buf, c.B) for _ in range(5)]
+    torch.cuda.synchronize()
+    nseg = sum(1 for k, _ in agent._graph if k == 'graph')
+    st = {k: v.numpy() for k, v in agent.core.state().items()}
+    q.put((rank, st, nseg, float(infos[-1]['vae_loss'])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_dp_segmented_graph_keeps_replicas_identical():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][2] == 7, 'vlsac train() = 6 all-reduces (4 feature, critic, actor+alpha) -> 7 graph segments'
+    for k, v in res[0][1].items():
+        assert np.all(np.isfinite(v)), k
+        assert np.array_equal(v, res[1][1][k]), f'replicas diverged at {k}'
+    assert np.isfinite(res[0][3]) and np.isfinite(res[1][3])
