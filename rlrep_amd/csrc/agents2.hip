@@ -281,8 +281,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         Program& p = ag->critic_bwd;
         b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), phi_fwd(0, s0.XF, pa)}, "actor.l1(s') phi.l1(s,a)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), phi_fwd(1, nullptr, pa)}, "actor.l2 phi.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab), phi_fwd(2, nullptr, pa)}, "actor.head phi.l3");
-        policy_fwd_stage(p, ag, ab, s0.XF2 + S, SA, "policy(s')");
+        actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {phi_fwd(2, nullptr, pa)}, "actor.head phi.l3 + policy");
         b.fwd_stage(p, {phi_fwd(0, s0.XF2, pb)}, "phi.l1(s',a')");
         b.fwd_stage(p, {phi_fwd(1, nullptr, pb)}, "phi.l2");
         b.fwd_stage(p, {phi_fwd(2, nullptr, pb)}, "phi.l3");
@@ -300,8 +299,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         Program& p = ag->actor_bwd;
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
-        policy_fwd_stage(p, ag, ab, s0.XFpi + S, SA, "policy(s)");
+        actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
         b.fwd_stage(p, {phi_fwd(0, s0.XFpi, pa)}, "phi.l1(s,a_pi)");
         b.fwd_stage(p, {phi_fwd(1, nullptr, pa)}, "phi.l2");
         b.fwd_stage(p, {phi_fwd(2, nullptr, pa)}, "phi.l3");
@@ -311,8 +309,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         b.dx_stage(p, {Builder::dx(GE, 2 * H, B, 2 * H, Pw("critic.l1.weight"), F, pa.GZ, F, F, ACT_NONE, nullptr, 0)}, "critic l1|l4 dx");
         b.dx_stage(p, {Builder::dx(pa.GZ, F, B, F, Pw("phi.l3.weight"), Hp, pa.G2, Hp, Hp, ACT_ELU, pa.P2, Hp)}, "phi.l3 dx");
         b.dx_stage(p, {Builder::dx(pa.G2, Hp, B, Hp, Pw("phi.l2.weight"), Hp, pa.G1, Hp, Hp, ACT_ELU, pa.P1, Hp)}, "phi.l2 dx");
-        b.dx_stage(p, {Builder::dx(pa.G1, Hp, B, Hp, Pw("phi.l1.weight") ? Pw("phi.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0)}, "phi.l1 dx(action)");
-        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA);
+        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(pa.G1, Hp, B, Hp, Pw("phi.l1.weight") ? Pw("phi.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0));
         actor_apply_program(b, ag, part_l, nblk);
     }
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
@@ -344,11 +341,11 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
         // actor(s') next to phi(s,a): layer l of both in one launch while both have a layer l
         for (int l = 0; l < 3 || l <= D; ++l) {
             std::vector<GemmTask> t;
-            if (l < 3) t.push_back(actor_l(ag, l, s0.XF2, SA, ab));
+            if (l < 2) t.push_back(actor_l(ag, l, s0.XF2, SA, ab));
             if (l <= D) t.push_back(mlp_fwd(ag, phi, pa, l, s0.XF, SA));
-            b.fwd_stage(p, t, "actor(s') / phi(s,a) layer");
+            if (l == 2) actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, t, "actor.head(s') + policy / phi(s,a) layer");
+            else b.fwd_stage(p, t, "actor(s') / phi(s,a) layer");
         }
-        policy_fwd_stage(p, ag, ab, s0.XF2 + S, SA, "policy(s')");
         for (int l = 0; l <= D; ++l) b.fwd_stage(p, {mlp_fwd(ag, phi, pb, l, s0.XF2, SA)}, "phi(s',a') layer");
         b.fwd_stage(p, {rff_l1(ag, true, Zn, F, H, rt), rff_l1(ag, false, Zc, F, H, rc)}, "critic l1|l4 (sin)");
         {
@@ -381,8 +378,7 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
         Program& p = ag->actor_bwd;
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
-        policy_fwd_stage(p, ag, ab, s0.XFpi + S, SA, "policy(s)");
+        actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
         for (int l = 0; l <= D; ++l) b.fwd_stage(p, {mlp_fwd(ag, phi, pa, l, s0.XFpi, SA)}, "phi(s,a_pi) layer");
         b.fwd_stage(p, {rff_l1(ag, false, Zc, F, H, rc)}, "critic l1|l4 (sin)");
         {
@@ -396,8 +392,7 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
         // dL/dz = G1 [W1;W4]; when phi has hidden layers the elu' of its last hidden activation is NOT applied here
         b.dx_stage(p, {Builder::dx(rc.G1, 2 * H, B, 2 * H, Pw("critic.l1.weight"), F, pa.g[D], F, F, ACT_NONE, nullptr, 0)}, "critic l1|l4 dx");
         for (int l = D; l >= 1; --l) b.dx_stage(p, {mlp_dx(ag, phi, pa, l)}, "phi dx");
-        b.dx_stage(p, {mlp_dx_input(ag, phi, pa, S, A, ab.dA, A)}, "phi dx(action)");
-        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA);
+        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, mlp_dx_input(ag, phi, pa, S, A, ab.dA, A));
         actor_apply_program(b, ag, part_l, nblk);
     }
     (void)GZ;

@@ -24,11 +24,14 @@ enum Epi : int {
     EPI_DX = 1,         // C (=|+=) acc * act'(aux[r,c])
     EPI_DX_REPARAM = 2, // vlsac: C[r,c] += acc ; C[r,c+F] += acc * aux3[r,c]  (aux3 = eps*exp(l)*clamp-mask)
     EPI_DW = 3,         // C = acc (weight gradient), bias gradient = column sums of operand A
-    EPI_DX_TANHOUT = 4  // reserved
+    EPI_FWD_MSE = 4,    // vlsac decoder heads: C <- d(0.5 mse)/d(pred) vs targets x0 (cols < n0) / x1 (col n0); partial sums -> y0
+    EPI_FWD_POLICY = 5, // actor head (2A <= 16): C <- raw [mu|rho]; y0 <- tanh(mu + eps*sigma); y1 <- log pi   (agent/sac/actor.py:76-91)
+    EPI_DX_POLICYBWD = 6 // acc = dL/da: y0 <- dL/d[mu|rho]; no C store
 };
 
 #define FLAG_ACCUM 1       // C += value instead of C = value
 #define FLAG_BIASGRAD 2    // EPI_DW: also emit the bias gradient (only by column-tile 0)
+#define FLAG_DYN_EPS 4     // x2 is the per-call noise pointer (patched into the kernel arguments at launch)
 
 struct GroupCfg;
 struct GemmTask {
@@ -54,6 +57,9 @@ struct GemmTask {
     float* ad_p; float* ad_m; float* ad_v; float* ad_t;          // weight: param, exp_avg, exp_avg_sq, target (or null)
     float* ad_pb; float* ad_mb; float* ad_vb; float* ad_tb;      // bias
     const GroupCfg* ad_grp;
+    // generic operands of the fused loss / policy epilogues
+    const float* x0; const float* x1; const float* x2; float* y0; float* y1; const double* dptr;
+    int ldx0, ldx1, n0; float s0, s1;
 };
 
 #define GEMM_MAX_TASKS 8

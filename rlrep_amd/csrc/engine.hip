@@ -109,14 +109,35 @@ void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* a
     p.stages.push_back({[=](hipStream_t st) { PolicyFwd q = pf; q.eps = ag->cur_eps; return rl_launch_policy_fwd(&q, st); }, what});
 }
 
+void actor_head_stage(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, std::vector<GemmTask> extra, const char* what) {
+    const int A = ag->d.action_dim;
+    GemmTask head = actor_l(ag, 2, nullptr, 0, ab);
+    if (2 * A <= 16 && !getenv("RLREP_NO_FUSE_POLICY")) {
+        head.epi = EPI_FWD_POLICY; head.n0 = A; head.y0 = act; head.ldx0 = ld_act; head.y1 = ab.logp; head.flags |= FLAG_DYN_EPS;
+        extra.insert(extra.begin(), head);
+        b.fwd_stage(p, extra, what);
+    } else {
+        extra.insert(extra.begin(), head);
+        b.fwd_stage(p, extra, what);
+        policy_fwd_stage(p, ag, ab, act, ld_act, "policy");
+    }
+}
+
 // policy head backward + trunk backward + weight gradients (X = actor input with row stride ldx)
 void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx,
-                           const float* act, int ld_act) {
+                           const float* act, int ld_act, GemmTask action_dx) {
     const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
-    PolicyBwd pb; memset(&pb, 0, sizeof(pb));
-    pb.O = ab.AO; pb.act = act; pb.ld_act = ld_act; pb.dA = ab.dA; pb.ld_dA = A;
-    pb.alpha_state = ag->a.alpha_state_dev; pb.inv_batch = ag->inv_batch(); pb.G = ab.Ghead; pb.B = B; pb.A = A;
-    p.stages.push_back({[=](hipStream_t st) { PolicyBwd q = pb; q.eps = ag->cur_eps; return rl_launch_policy_bwd(&q, st); }, "policy_bwd"});
+    if (A <= 16 && !getenv("RLREP_NO_FUSE_POLICY")) {
+        action_dx.epi = EPI_DX_POLICYBWD; action_dx.n0 = A; action_dx.x0 = ab.AO; action_dx.x1 = act; action_dx.ldx1 = ld_act;
+        action_dx.y0 = ab.Ghead; action_dx.dptr = ag->a.alpha_state_dev; action_dx.s0 = ag->inv_batch(); action_dx.flags |= FLAG_DYN_EPS;
+        b.dx_stage(p, {action_dx}, "dx(action) -> dL/d[mu|rho]");
+    } else {
+        b.dx_stage(p, {action_dx}, "dx(action)");
+        PolicyBwd pb; memset(&pb, 0, sizeof(pb));
+        pb.O = ab.AO; pb.act = act; pb.ld_act = ld_act; pb.dA = ab.dA; pb.ld_dA = A;
+        pb.alpha_state = ag->a.alpha_state_dev; pb.inv_batch = ag->inv_batch(); pb.G = ab.Ghead; pb.B = B; pb.A = A;
+        p.stages.push_back({[=](hipStream_t st) { PolicyBwd q = pb; q.eps = ag->cur_eps; return rl_launch_policy_bwd(&q, st); }, "policy_bwd"});
+    }
     b.dx_stage(p, {Builder::dx(ab.Ghead, 2 * A, B, 2 * A, ag->P("actor.trunk.4.weight"), Ha, ab.GA2, Ha, Ha, ACT_ELU, ab.A2, Ha)}, "actor.head dx");
     b.dx_stage(p, {Builder::dx(ab.GA2, Ha, B, Ha, ag->P("actor.trunk.2.weight"), Ha, ab.GA1, Ha, Ha, ACT_ELU, ab.A1, Ha)}, "actor.l2 dx");
     b.dw_stage(p, {Builder::dw(ab.Ghead, 2 * A, 2 * A, ab.A2, Ha, Ha, B, ag->G("actor.trunk.4.weight"), Ha, ag->G("actor.trunk.4.bias")),
@@ -171,8 +192,7 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
         Program& p = ag->critic_bwd;
         b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab)}, "actor.l1(s')");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
-        policy_fwd_stage(p, ag, ab, s0.XF2 + S, SA, "policy(s')");
+        actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {}, "actor.head + policy");
         b.fwd_stage(p, {Builder::fwd(s0.XF2, SA, B, SA, Tw("critic_target.Q1.0.weight"), SA, Tw("critic_target.Q1.0.bias"), 2 * H, E1t, 2 * H, ACT_ELU),
                         Builder::fwd(s0.XF, SA, B, SA, Pw("critic.Q1.0.weight"), SA, Pw("critic.Q1.0.bias"), 2 * H, E1c, 2 * H, ACT_ELU)}, "Q l1");
         b.fwd_stage(p, {Builder::fwd(E1t, 2 * H, B, H, Tw("critic_target.Q1.2.weight"), H, Tw("critic_target.Q1.2.bias"), H, Et, H, ACT_ELU),
@@ -210,8 +230,7 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
         Program& p = ag->actor_bwd;
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
-        policy_fwd_stage(p, ag, ab, s0.XFpi + S, SA, "policy(s)");
+        actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
         b.fwd_stage(p, {Builder::fwd(s0.XFpi, SA, B, SA, Pw("critic.Q1.0.weight"), SA, Pw("critic.Q1.0.bias"), 2 * H, E1c, 2 * H, ACT_ELU)}, "Q l1");
         b.fwd_stage(p, {Builder::fwd(E1c, 2 * H, B, H, Pw("critic.Q1.2.weight"), H, Pw("critic.Q1.2.bias"), H, Ec, H, ACT_ELU),
                         Builder::fwd(E1c + H, 2 * H, B, H, Pw("critic.Q2.2.weight"), H, Pw("critic.Q2.2.bias"), H, Ec + (size_t)B * H, H, ACT_ELU)}, "Q l2");
@@ -226,8 +245,7 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
         b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.Q1.2.weight"), H, G1, 2 * H, H, ACT_ELU, E1c, 2 * H),
                        Builder::dx(GE + (size_t)B * H, H, B, H, Pw("critic.Q2.2.weight"), H, G1 + H, 2 * H, H, ACT_ELU, E1c + H, 2 * H)}, "Q l2 dx");
         // both heads at once: [G1_1 | G1_2] [B,2H] x [W_Q1.0 ; W_Q2.0][:, S:S+A]
-        b.dx_stage(p, {Builder::dx(G1, 2 * H, B, 2 * H, Pw("critic.Q1.0.weight") ? Pw("critic.Q1.0.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0)}, "Q l1 dx(action)");
-        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA);
+        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(G1, 2 * H, B, 2 * H, Pw("critic.Q1.0.weight") ? Pw("critic.Q1.0.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0));
         actor_apply_program(b, ag, part_l, nblk);
     }
     update_target_program(ag, "critic.Q1.0.weight", "critic_target.Q1.0.weight");
@@ -261,12 +279,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     GaussBufs ge{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};
     GaussBufs gf{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};
     float* Z = ws.f((size_t)B * F); float* EZ = ws.f((size_t)B * F);
-    float* D1 = ws.f((size_t)B * Hv); float* DH = ws.f((size_t)B * (S + 1));
+    float* D1 = ws.f((size_t)B * Hv);
     float* GDH = ws.f((size_t)B * (S + 1)); float* GD1 = ws.f((size_t)B * Hv);
     float* GEH = ws.f((size_t)B * 2 * F); float* GFH = ws.f((size_t)B * 2 * F);
     float* GH2e = ws.f((size_t)B * Hv); float* GH1e = ws.f((size_t)B * Hv);
     float* GH2f = ws.f((size_t)B * Hv); float* GH1f = ws.f((size_t)B * Hv);
-    const int nblk_kl = (int)(((long long)B * F + 255) / 256), nblk_mse = (int)(((long long)B * (S + 1) + 255) / 256);
+    const int nblk_kl = (int)(((long long)B * F + 255) / 256), nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
     float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse);
     {
         Program& p = ag->feat_bwd;
@@ -282,11 +300,14 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         vm.EZ = EZ;
         p.stages.push_back({[=](hipStream_t st) { VaeMid q = vm; q.eps = ag->cur_eps; return rl_launch_vae_mid(&q, st); }, "vae_mid"});
         b.fwd_stage(p, {Builder::fwd(Z, F, B, F, Pw("decoder.l1.weight"), F, Pw("decoder.l1.bias"), Hv, D1, Hv, ACT_RELU)}, "dec.l1");
-        b.fwd_stage(p, {Builder::fwd(D1, Hv, B, Hv, Pw("decoder.state_linear.weight"), Hv, Pw("decoder.state_linear.bias"), S + 1, DH, S + 1, ACT_NONE)}, "dec.heads");
-        VaeMse ms; memset(&ms, 0, sizeof(ms));
-        ms.DH = DH; ms.s2 = s0.XE ? s0.XE + SA : nullptr; ms.ld_s2 = KE; ms.r = s0.R; ms.GDH = GDH; ms.partial = part_mse;
-        ms.B = B; ms.S = S; ms.nblk = nblk_mse; ms.scale_s = ag->inv_batch() / (float)S; ms.scale_r = ag->inv_batch();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_vae_mse(&ms, st); }, "vae_mse"});
+        {
+            // decoder heads with the 0.5*mse loss fused into the epilogue: the launch writes d loss / d[s_hat | r_hat]
+            // (GDH) directly and per-tile partial sums of the squared errors (vlsac_agent.py:137-140)
+            GemmTask t = Builder::fwd(D1, Hv, B, Hv, Pw("decoder.state_linear.weight"), Hv, Pw("decoder.state_linear.bias"), S + 1, GDH, S + 1, ACT_NONE);
+            t.epi = EPI_FWD_MSE; t.n0 = S; t.x0 = s0.XE ? s0.XE + SA : nullptr; t.ldx0 = KE; t.x1 = s0.R;
+            t.s0 = ag->inv_batch() / (float)S; t.s1 = ag->inv_batch(); t.y0 = part_mse;
+            b.fwd_stage(p, {t}, "dec.heads + mse");
+        }
         b.dx_stage(p, {Builder::dx(GDH, S + 1, B, S + 1, Pw("decoder.state_linear.weight"), Hv, GD1, Hv, Hv, ACT_RELU, D1, Hv)}, "dec.heads dx");
         {
             GemmTask t = Builder::dx(GD1, Hv, B, Hv, Pw("decoder.l1.weight"), F, GEH, 2 * F, F, ACT_NONE, nullptr, 0);
@@ -375,8 +396,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         gauss_tasks(ag, true, "f_target", s0.XF2, SA, SA, gn, tn);
         b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), tt[0]}, "actor.l1(s') ft.l1(s,a)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), tt[1]}, "actor.l2 ft.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab), tt[2]}, "actor.head ft.heads");
-        policy_fwd_stage(p, ag, ab, s0.XF2 + S, SA, "policy(s')");
+        actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {tt[2]}, "actor.head ft.heads + policy");
         b.fwd_stage(p, {tn[0]}, "ft.l1(s',a')");
         b.fwd_stage(p, {tn[1]}, "ft.l2");
         b.fwd_stage(p, {tn[2]}, "ft.heads");
@@ -441,8 +461,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gt, tt);
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        b.fwd_stage(p, {actor_l(ag, 2, nullptr, 0, ab)}, "actor.head");
-        policy_fwd_stage(p, ag, ab, s0.XFpi + S, SA, "policy(s)");
+        actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
         b.fwd_stage(p, {tt[0]}, "ft.l1(s,a_pi)");
         b.fwd_stage(p, {tt[1]}, "ft.l2");
         b.fwd_stage(p, {tt[2]}, "ft.heads");
@@ -469,8 +488,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         }
         b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gt.H2, Hv)}, "ft.heads dx");
         b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gt.H1, Hv)}, "ft.l2 dx");
-        b.dx_stage(p, {Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0)}, "ft.l1 dx(action)");
-        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA);
+        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0));
         actor_apply_program(b, ag, part_l, nblk);
     }
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");

@@ -78,7 +78,17 @@ struct Builder {
         gb.ntasks = (int)tasks.size();
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         const int total = base_tile;
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
+        bool dyn = false;
+        for (auto& t : tasks) dyn = dyn || (t.flags & FLAG_DYN_EPS);
+        rlrep_agent* a = ag;
+        if (dyn)
+            p.stages.push_back({[=](hipStream_t st) {
+                GemmBatch g2 = gb;
+                for (int q = 0; q < g2.ntasks; ++q) if (g2.t[q].flags & FLAG_DYN_EPS) g2.t[q].x2 = a->cur_eps;
+                return rl_launch_gemm16(la, lb, &g2, total, st);
+            }, what});
+        else
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
     }
     // ---- optimizer fusion (single-GPU path) ------------------------------------------------------
     // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch CAN apply
@@ -177,7 +187,11 @@ int qhead_blocks(int B);
 ActorBufs alloc_actor(Builder& b, int B, int A, int Ha);
 GemmTask actor_l(rlrep_agent* ag, int layer, const float* X, int ldx, const ActorBufs& ab);
 void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, const char* what);
-void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx, const float* act, int ld_act);
+// actor head layer + tanh-Gaussian sampling/log-prob: ONE launch (policy fused into the head GEMM's epilogue) when the
+// [mu|rho] row fits one 16-column tile (2A <= 16), else head launch + policy_fwd_kernel.  `extra` tasks share the launch.
+void actor_head_stage(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, std::vector<GemmTask> extra, const char* what);
+// `action_dx` computes dL/da [B,A] into ab.dA; its epilogue takes over policy_bwd when A <= 16
+void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx, const float* act, int ld_act, GemmTask action_dx);
 void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk);
 void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst);
 

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
             if (t.flags & FLAG_ACCUM) cold = *cp;
             if (t.r1u) cold2 = t.r1u[r] * t.r1v[c];
         }
+        else if (t.epi == EPI_FWD_MSE) { e0 = t.bias[c]; cold = (c < t.n0) ? t.x0[(size_t)r * t.ldx0 + c] : t.x1[r]; }
+        else if (t.epi == EPI_FWD_POLICY) { e0 = t.bias[c]; if (c < t.n0 && t.x2) cold = t.x2[(size_t)r * t.n0 + c]; }
+        else if (t.epi == EPI_DX_POLICYBWD) { e0 = t.x0[(size_t)r * 2 * t.n0 + t.n0 + c]; cold = t.x2[(size_t)r * t.n0 + c]; cold2 = t.x1[(size_t)r * t.ldx1 + c]; }
         else if (t.epi == EPI_DX_REPARAM) { e0 = t.aux3[(size_t)r * t.ldaux3 + c]; cold = *cp; cold2 = cp[t.F]; }
         else if (t.flags & FLAG_ACCUM) cold = *cp;
     }
@@ -126,6 +129,46 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         t.out2[r0 + q] = gb;
         if (t.ad_pb) adam_elem(adsc, gb, t.ad_pb + r0 + q, t.ad_mb + r0 + q, t.ad_vb + r0 + q, t.ad_tb ? t.ad_tb + r0 + q : nullptr);
     }
+    if (t.epi == EPI_FWD_MSE) {
+        // decoder heads of the vlsac ELBO (vlsac_agent.py:137-140): the gradient of 0.5*mse replaces the prediction
+        float es = 0.f, er = 0.f;
+        if (inb) {
+            const float d = (v + e0) - cold;
+            if (c < t.n0) { es = d * d; *cp = d * t.s0; } else { er = d * d; *cp = d * t.s1; }
+        }
+        es = wave_sum(es); er = wave_sum(er);
+        __syncthreads();
+        if (lane == 0) { red[0][0][w] = es; red[0][1][w] = er; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            t.y0[2 * local] = ((red[0][0][0] + red[0][0][1]) + red[0][0][2]) + red[0][0][3];
+            t.y0[2 * local + 1] = ((red[0][1][0] + red[0][1][1]) + red[0][1][2]) + red[0][1][3];
+        }
+        return;
+    }
+    if (t.epi == EPI_FWD_POLICY) {
+        // the whole [mu | rho] row sits in this one 16-column tile: rho_j is the element A lanes to the right
+        const int A = t.n0;
+        float lp = 0.f;
+        if (inb) {
+            const float x0v = v + e0;
+            *cp = x0v;
+            if (c < A) {
+                const int pl = ol + A;
+                const float rho = (((red[0][oreg][pl] + red[1][oreg][pl]) + red[2][oreg][pl]) + red[3][oreg][pl]) * t.scale + t.bias[c + A];
+                const float tt = tanhf(rho);
+                const float l = -5.f + 3.5f * (tt + 1.f);
+                const float sg = expf(l);
+                const float x = x0v + cold * sg;
+                t.y0[(size_t)r * t.ldx0 + c] = tanhf(x);
+                lp = -0.5f * cold * cold - l - 0.91893853320467274f - 2.f * (0.69314718055994531f - x - softplus_f(-2.f * x));
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o, 64);
+        if (inb && c == 0 && t.y1) t.y1[r] = lp;
+        return;
+    }
     if (!inb) return;
 
     switch (t.epi) {
@@ -151,6 +194,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         default: break;
         }
         *cp = cold + g;
+    } break;
+    case EPI_DX_POLICYBWD: {
+        // v = dL/da_c from the critic path; e0 = rho, cold = eps, cold2 = a = tanh(x)
+        const int A = t.n0;
+        const float g = (float)exp(t.dptr[0]) * t.s0;            // dL/dlogpi = alpha / B
+        const float tt = tanhf(e0);
+        const float sg = expf(-5.f + 3.5f * (tt + 1.f));
+        const float y = cold2, e = cold;
+        const float h = v * (1.f - y * y);
+        t.y0[(size_t)r * 2 * A + c] = g * 2.f * y + h;
+        t.y0[(size_t)r * 2 * A + A + c] = (g * (-1.f + 2.f * y * e * sg) + h * e * sg) * 3.5f * (1.f - tt * tt);
     } break;
     case EPI_DX_REPARAM:
         // e0 = eps * exp(log_std) * clamp-mask, written by vae_mid_kernel
