@@ -131,3 +131,74 @@ def test_hip_matches_oracle_fresh_seed(alg):
     for k in st:
         if k in P and not k.endswith('noise'):
             assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, k
+
+
+@pytest.mark.parametrize('alg,B', [('sac', 7), ('vlsac', 100), ('ctrlsac', 33), ('spedersac', 50), ('diffsrsac', 19)])
+def test_ragged_batch_sizes_match_oracle(alg, B):
+    """Batch sizes that are not multiples of the 16-row MFMA tile (and a batch-size change on a live agent)
+    exercise every masked edge of the kernels; compared with the CPU oracle on fresh inputs."""
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    c = Case(alg + '_tiny')
+    rs = np.random.RandomState(1000 + B)
+    agent = make_agent(c, **{})
+    # the fixture's agent was created with max_batch = c.B; recreate with room for B
+    import importlib
+    kw = dict(c.kw)
+    if c.meta.get('patch_vae_hidden'):
+        kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+    agent = type(agent)(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=max(B, c.B),
+                        graph=False, **kw)
+    agent.core.load_state(c.init)
+    buf = make_buffer(c)
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    torch.set_num_threads(4)
+    F = c.kw.get('feature_dim', 0)
+    nf = (c.kw.get('extra_feature_steps', 0) + 1) if alg != 'sac' else 0
+    for t, bsz in enumerate([B, c.B, B]):          # also switches the batch size on the live agent
+        nb = o.n_batches()
+        idx = [rs.randint(0, c.meta['replay_n'], size=bsz) for _ in range(nb)]
+        eps = []
+        if alg == 'vlsac':
+            eps = [rs.standard_normal((bsz, F)).astype(np.float32) for _ in range(nf)]
+        if alg == 'diffsrsac':
+            for _ in range(nf):
+                eps += [rs.randint(0, 1000, size=bsz), (0.449 * rs.standard_normal((bsz, c.S))).astype(np.float32)]
+        eps += [rs.standard_normal((bsz, c.A)).astype(np.float32) for _ in range(2)]
+        info = agent.train_injected(buf, bsz, idx, eps)
+        oinfo = o.train([gather_batch(c.replay, i) for i in idx],
+                        [torch.as_tensor(e) for e in eps])
+        for k, v in oinfo.items():
+            assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (alg, t, bsz, k, info[k], v)
+    st, P = agent.core.state(), o.state()
+    for k in st:
+        if k in P and not k.endswith('noise') and k != 'noise_alphabars':
+            assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, (alg, k)
+
+
+def test_errors_are_loud():
+    """Argument / state errors surface as RuntimeError with the library's message (no silent fallback)."""
+    c = Case('sac_tiny')
+    agent = make_agent(c)
+    with pytest.raises(RuntimeError, match='before set_batch'):
+        agent.core.critic_step(torch.zeros(c.B, c.A, device='cuda'))
+    buf = make_buffer(c)
+    with pytest.raises(RuntimeError, match='max_batch'):
+        agent.train_injected(buf, c.B + 1, [np.zeros(c.B + 1, np.int64)], [np.zeros((c.B + 1, c.A), np.float32)] * 2)
+    with pytest.raises(RuntimeError, match='no feature step'):
+        agent.core.feature_step(None)
+
+
+def test_select_action_matches_oracle_mean():
+    from oracle.agents import actor_mu_std
+    c = Case('vlsac_tiny')
+    agent = make_agent(c)
+    P = {k: torch.as_tensor(v) for k, v in c.init.items()}
+    rs = np.random.RandomState(0)
+    for _ in range(3):
+        s = rs.standard_normal(c.S).astype(np.float32)
+        a = agent.select_action(s)
+        mu, _ = actor_mu_std(P, torch.as_tensor(s)[None])
+        assert np.allclose(a, torch.tanh(mu)[0].numpy(), atol=1e-5), (a, torch.tanh(mu))
+        ae = agent.select_action(s, explore=True)
+        assert ae.shape == (c.A,) and np.all(np.abs(ae) <= 1.0)
