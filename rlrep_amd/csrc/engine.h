@@ -13,7 +13,7 @@
 
 // kernel launchers (defined next to the kernels)
 extern "C" {
-int rl_launch_gemm16(int la, int lb, const GemmBatch* gb, int total_tiles, hipStream_t st);
+int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st);
 int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st);
 int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
 int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);

@@ -67,9 +67,19 @@ struct Builder {
     }
 
     void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
+        // column fragments per workgroup: the widest tile that still leaves >= ~1.5 workgroups per CU; the
+        // epilogues that need a whole row / per-tile partials in one fragment force NF = 1
+        int nf = 1;
+        {
+            bool force1 = getenv("RLREP_NF1") != nullptr;
+            for (auto& t : tasks) force1 = force1 || t.epi == EPI_FWD_POLICY || t.epi == EPI_FWD_MSE || t.epi == EPI_DX_REPARAM;
+            auto count = [&](int f) { long long n = 0; for (auto& t : tasks) n += (long long)((t.R + 15) / 16) * ((t.Cn + 16 * f - 1) / (16 * f)); return n; };
+            if (!force1) { if (count(2) >= 384) nf = 2; if (count(4) >= 384) nf = 4; }
+            if (getenv("RLREP_NF")) nf = atoi(getenv("RLREP_NF")), nf = force1 ? 1 : nf;
+        }
         int base_tile = 0;
         for (auto& t : tasks) {
-            t.tiles_c = (t.Cn + 15) / 16;
+            t.tiles_c = (t.Cn + 16 * nf - 1) / (16 * nf);
             const int tr = (t.R + 15) / 16;
             t.ntiles = tr * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles;
         }
@@ -85,10 +95,10 @@ struct Builder {
             p.stages.push_back({[=](hipStream_t st) {
                 GemmBatch g2 = gb;
                 for (int q = 0; q < g2.ntasks; ++q) if (g2.t[q].flags & FLAG_DYN_EPS) g2.t[q].x2 = a->cur_eps;
-                return rl_launch_gemm16(la, lb, &g2, total, st);
+                return rl_launch_gemm16(la, lb, nf, &g2, total, st);
             }, what});
         else
-            p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, &gb, total, st); }, what});
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, nf, &gb, total, st); }, what});
     }
     // ---- optimizer fusion (single-GPU path) ------------------------------------------------------
     // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch CAN apply
