@@ -74,7 +74,8 @@ typedef struct {
     int32_t mu_hidden_depth;   /* speder, diffsr (ctrlsac: 2 fixed) */
     int32_t num_noise;         /* vlsac critic noise rows (20) / diffsr num_noises (1000) */
     int32_t max_batch;         /* largest batch size this agent will be stepped with */
-    int32_t reserved[3];
+    int32_t rank;              /* data-parallel rank of this replica (0 when world_size == 1) */
+    int32_t reserved[2];
 } rlrep_dims;
 
 /* Hyper-parameters (mirrors the reference constructors' scalar kwargs). */
@@ -208,6 +209,16 @@ int32_t rlrep_critic_backward(rlrep_agent* agent, const float* eps_dev, void* st
 int32_t rlrep_critic_apply(rlrep_agent* agent, void* stream);
 int32_t rlrep_actor_backward(rlrep_agent* agent, const float* eps_dev, void* stream);
 int32_t rlrep_actor_apply(rlrep_agent* agent, void* stream);
+
+/* Batch-coupled representation losses under data parallelism (ctrlsac's in-batch negatives, spedersac's second
+ * moment) need a collective INSIDE the feature backward.  The feature backward is therefore cut into
+ * rlrep_feature_exchange_count()+1 parts; after part k the caller performs exchange k on a library buffer:
+ *   kind 1: all-gather  -- every rank contributes `count` floats at ptr + local_off (in place, rank-major)
+ *   kind 2: all-reduce SUM of `count` floats at ptr.
+ * With world_size == 1 there are no exchanges and rlrep_feature_backward runs everything. */
+int32_t rlrep_feature_exchange_count(rlrep_agent* agent);
+int32_t rlrep_feature_exchange(rlrep_agent* agent, int32_t k, int32_t* kind, float** ptr_dev, int64_t* count, int64_t* local_off);
+int32_t rlrep_feature_backward_part(rlrep_agent* agent, int32_t part, const float* eps_dev, const int32_t* noise_idx_dev, void* stream);
 
 /* ctrlsac: frozen_phi, frozen_phi_target <- phi (ctrlsac_agent.py:344-346). No-op for other agents. */
 int32_t rlrep_sync_frozen(rlrep_agent* agent, void* stream);

@@ -22,8 +22,8 @@ GRAD_TAIL = 256
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'alg', 'state_dim', 'action_dim', 'hidden_dim', 'actor_hidden_dim', 'feature_dim', 'vae_hidden_dim',
-        'phi_hidden_dim', 'phi_hidden_depth', 'mu_hidden_dim', 'mu_hidden_depth', 'num_noise', 'max_batch')] + \
-        [('reserved', C.c_int32 * 3)]
+        'phi_hidden_dim', 'phi_hidden_depth', 'mu_hidden_dim', 'mu_hidden_depth', 'num_noise', 'max_batch', 'rank')] + \
+        [('reserved', C.c_int32 * 2)]
 
 
 class Hyper(C.Structure):
@@ -99,6 +99,9 @@ def _load():
         'rlrep_critic_apply': (i32, [vp, vp]),
         'rlrep_actor_backward': (i32, [vp, vp, vp]),
         'rlrep_actor_apply': (i32, [vp, vp]),
+        'rlrep_feature_exchange_count': (i32, [vp]),
+        'rlrep_feature_exchange': (i32, [vp, i32, P(i32), P(vp), P(i64), P(i64)]),
+        'rlrep_feature_backward_part': (i32, [vp, i32, vp, vp, vp]),
         'rlrep_sync_frozen': (i32, [vp, vp]),
         'rlrep_actor_forward': (i32, [vp, vp, i32, vp, f32, f32, vp, vp]),
         'rlrep_stage_count': (i32, [vp, i32]),

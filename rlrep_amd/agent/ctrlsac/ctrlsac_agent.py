@@ -57,7 +57,7 @@ class CTRLSACAgent(SACAgent):
         c = self.core
         self._sample_into(buffer, B, f'f{i}', 0, g)
         if self.world_size > 1:
-            c.feature_backward(None); self._allreduce(0); c.feature_apply()
+            self._feature_backward_dp(None); self._allreduce(0); c.feature_apply()
         else:
             c.feature_step(None)
 

@@ -83,6 +83,7 @@ class SACAgent(object):
         dims = dict(feature_dim=0, vae_hidden_dim=0, phi_hidden_dim=0, phi_hidden_depth=0, mu_hidden_dim=0,
                     mu_hidden_depth=0, num_noise=0, max_batch=self.max_batch)
         dims.update(self._dims)
+        dims['rank'] = self.rank
         hyper = dict(discount=self.discount, tau=self.tau, feature_tau=float(self.feature_tau),
                      target_entropy=float(self.target_entropy), sigma_scale=0.0,
                      target_update_period=self.target_update_period,
@@ -217,18 +218,39 @@ class SACAgent(object):
         o, n = lay.group_offset[group], lay.group_floats[group]
         end = lay.grad_floats if with_tail else o + n
         view = self.core.grads[o:end]
+        self._collective(lambda: dist.all_reduce(view))
+
+    def _collective(self, fn):
+        """Run a torch.distributed call now, or -- during segmented capture (data parallel + hipGraph) -- close the
+        graph segment recorded so far, remember the collective as an eager step and open the next segment.
+        No RCCL call is ever captured."""
         if self._seg is not None:
-            # segmented capture (data parallel + hipGraph): close the graph segment recorded so far, remember the
-            # collective as an eager step, open the next segment.  No RCCL call is ever captured.
             segs, cur = self._seg
             cur.capture_end()
             segs.append(('graph', cur))
-            segs.append(('allreduce', view))
+            segs.append(('coll', fn))
             nxt = torch.cuda.CUDAGraph()
             nxt.capture_begin()
             self._seg = (segs, nxt)
             return
-        dist.all_reduce(view)
+        fn()
+
+    def _feature_backward_dp(self, eps=None, noise_idx=None):
+        """Feature backward with the collectives that batch-coupled losses need inside it (ctrlsac: all-gather of
+        mu(s') and all-reduce of its gradient; spedersac: all-reduce of Phibar and v); plain backward otherwise."""
+        import torch.distributed as dist
+        c = self.core
+        n = c.feature_exchange_count()
+        for k in range(n + 1):
+            c.feature_backward_part(k, eps, noise_idx)
+            if k < n:
+                kind, buf, count, off = c.feature_exchange(k)
+                if kind == 1:
+                    views = [buf[r * count:(r + 1) * count] for r in range(self.world_size)]
+                    local = views[self.rank]
+                    self._collective(lambda views=views, local=local: dist.all_gather(views, local))
+                else:
+                    self._collective(lambda buf=buf: dist.all_reduce(buf))
 
     # ---- pooled noise: ALL sample indices and ALL standard-normal noise of one train() come from two
     # Philox launches into two contiguous buffers (instead of one launch per tensor) ---------------------
@@ -375,7 +397,7 @@ class SACAgent(object):
             if kind == 'graph':
                 x.replay()
             else:
-                dist.all_reduce(x)
+                x()
         return self.core.info()
 
     def _train_graph(self, buffer, B):

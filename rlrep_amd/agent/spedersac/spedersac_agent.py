@@ -64,6 +64,6 @@ class SPEDERSACAgent(SACAgent):
         self._sample_into(buffer, B, f'f{i}a', 0, g)
         self._sample_into(buffer, B, f'f{i}b', 1, g)
         if self.world_size > 1:
-            c.feature_backward(None); self._allreduce(0); c.feature_apply()
+            self._feature_backward_dp(None); self._allreduce(0); c.feature_apply()
         else:
             c.feature_step(None)

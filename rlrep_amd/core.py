@@ -171,6 +171,21 @@ class HipCore:
     def feature_backward(self, eps=None, noise_idx=None):
         check(lib.rlrep_feature_backward(self.h, _ptr(eps), _ptr(noise_idx), _stream()), 'feature_backward')
 
+    def feature_exchange_count(self):
+        return lib.rlrep_feature_exchange_count(self.h)
+
+    def feature_exchange(self, k):
+        """-> (kind, float32 tensor view of the library buffer, per-rank count, local offset)"""
+        kind, ptr, count, off = C.c_int32(), C.c_void_p(), C.c_int64(), C.c_int64()
+        check(lib.rlrep_feature_exchange(self.h, k, C.byref(kind), C.byref(ptr), C.byref(count), C.byref(off)), 'feature_exchange')
+        total = count.value * (self.hyper.world_size if kind.value == 1 else 1)
+        o = (ptr.value - self.workspace.data_ptr())
+        buf = self.workspace[o:o + 4 * total].view(torch.float32)
+        return kind.value, buf, count.value, off.value
+
+    def feature_backward_part(self, part, eps=None, noise_idx=None):
+        check(lib.rlrep_feature_backward_part(self.h, part, _ptr(eps), _ptr(noise_idx), _stream()), 'feature_backward_part')
+
     def feature_apply(self):
         check(lib.rlrep_feature_apply(self.h, _stream()), 'feature_apply')
 

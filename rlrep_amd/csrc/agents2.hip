@@ -211,9 +211,15 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
 
     // ---- feature step ----
     Phi3 pf = alloc_phi(true);
-    float* M1 = ws.f((size_t)B * Hm); float* M2 = ws.f((size_t)B * Hm); float* ZM = ws.f((size_t)B * F);
-    float* GM2 = ws.f((size_t)B * Hm); float* GM1 = ws.f((size_t)B * Hm); float* GZM = ws.f((size_t)B * F);
-    float* Sx = ws.f((size_t)B * B); float* RH = ws.f(B); float* DRH = ws.f(B);
+    // data parallel: the in-batch negatives span ALL ranks' minibatches.  mu(s') of every rank is
+    // all-gathered into ZMall [W*B, F] (this rank's rows sit at rank*B), the score matrix is [B, W*B], and the
+    // partial dL/dmu'_all [W*B, F] is all-reduced before this rank back-propagates its own B rows.
+    const int Wd = ag->h.world_size > 1 ? ag->h.world_size : 1, rank = Wd > 1 ? d.rank : 0, WB = Wd * B;
+    float* M1 = ws.f((size_t)B * Hm); float* M2 = ws.f((size_t)B * Hm); float* ZMall = ws.f((size_t)WB * F);
+    float* ZM = ZMall ? ZMall + (size_t)rank * B * F : nullptr;
+    float* GM2 = ws.f((size_t)B * Hm); float* GM1 = ws.f((size_t)B * Hm); float* GZMall = ws.f((size_t)WB * F);
+    float* GZM = GZMall ? GZMall + (size_t)rank * B * F : nullptr;
+    float* Sx = ws.f((size_t)B * WB); float* RH = ws.f(B); float* DRH = ws.f(B);
     const int nblk_f = qhead_blocks(B);
     float* part_f = ws.f((size_t)2 * nblk_f);
     {
@@ -222,22 +228,24 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         b.fwd_stage(p, {phi_fwd(1, nullptr, pf), Builder::fwd(M1, Hm, B, Hm, Pw("mu.l2.weight"), Hm, Pw("mu.l2.bias"), Hm, M2, Hm, ACT_ELU)}, "phi.l2 mu.l2");
         b.fwd_stage(p, {phi_fwd(2, nullptr, pf), Builder::fwd(M2, Hm, B, Hm, Pw("mu.l3.weight"), Hm, Pw("mu.l3.bias"), F, ZM, F, ACT_TANH)}, "phi.l3 mu.l3(tanh)");
         // quirk Q6: the score matrix is the GEMM phi mu'^T, not the [B,B,F] broadcast
-        b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZM, F, nullptr, B, Sx, B, ACT_NONE),
+        if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 1, ZMall, (int64_t)B * F, (int64_t)rank * B * F});
+        b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE),
                         Builder::fwd(pf.Z, F, B, F, Pw("theta.l.weight"), F, Pw("theta.l.bias"), 1, RH, 1, ACT_NONE)}, "score matrix + theta");
         InfoNce nc; memset(&nc, 0, sizeof(nc));
-        nc.S = Sx; nc.ldS = B; nc.rhat = RH; nc.r = s0.R; nc.drhat = DRH; nc.partial = part_f; nc.B = B; nc.nblk = nblk_f;
+        nc.S = Sx; nc.ldS = WB; nc.ncols = WB; nc.diag_off = rank * B; nc.rhat = RH; nc.r = s0.R; nc.drhat = DRH; nc.partial = part_f; nc.B = B; nc.nblk = nblk_f;
         nc.inv_batch = ag->inv_batch(); nc.step = ag->adam_step + 0;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_infonce(&nc, st); }, "infonce"});
         {
-            GemmTask t = Builder::dx(Sx, B, B, B, ZM, F, pf.GZ, F, F, ACT_NONE, nullptr, 0);
+            GemmTask t = Builder::dx(Sx, WB, B, WB, ZMall, F, pf.GZ, F, F, ACT_NONE, nullptr, 0);
             t.r1u = DRH; t.r1v = Pw("theta.l.weight");
             b.dx_stage(p, {t}, "dphi = dS mu' + drhat theta");
         }
         {
             GemmTask t = Builder::base();     // dmu'[j,f] = (sum_i dS[i,j] phi[i,f]) * (1 - mu'^2)
-            t.A = Sx; t.lda = B; t.B = pf.Z; t.ldb = F; t.C = GZM; t.ldc = F; t.R = B; t.Cn = F; t.K = B;
-            t.epi = EPI_DX; t.act = ACT_TANH; t.aux = ZM; t.ldaux = F;
-            b.gemm(p, LD_COL, LD_COL, {t}, "dmu' = dS^T phi");
+            t.A = Sx; t.lda = WB; t.B = pf.Z; t.ldb = F; t.C = GZMall; t.ldc = F; t.R = WB; t.Cn = F; t.K = B;
+            t.epi = EPI_DX; t.act = ACT_TANH; t.aux = ZMall; t.ldaux = F;
+            b.gemm(p, LD_COL, LD_COL, {t}, "dmu'_all = dS^T phi");
+            if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, GZMall, (int64_t)WB * F, 0});
         }
         b.dx_stage(p, {Builder::dx(pf.GZ, F, B, F, Pw("phi.l3.weight"), Hp, pf.G2, Hp, Hp, ACT_ELU, pf.P2, Hp),
                        Builder::dx(GZM, F, B, F, Pw("mu.l3.weight"), Hm, GM2, Hm, Hm, ACT_ELU, M2, Hm)}, "l3 dx");
@@ -430,6 +438,8 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         ColSum c1; memset(&c1, 0, sizeof(c1));
         c1.X = PHI ? PHI + BF : nullptr; c1.ldX = F; c1.w = nullptr; c1.out = PHIBAR; c1.rows = B; c1.F = F;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c1, st); }, "Phibar = colsum phi_r"});
+        // data parallel: Phibar and v are sums over the GLOBAL "random" batch: two F-float all-reduces
+        if (ag->h.world_size > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, PHIBAR, (int64_t)F, 0});
         SpederRows sr; memset(&sr, 0, sizeof(sr));
         sr.phi = PHI; sr.mu = MU; sr.mu_r = MU ? MU + BF : nullptr; sr.phibar = PHIBAR; sr.theta_w = ag->P("theta.l.weight"); sr.theta_b = ag->P("theta.l.bias");
         sr.r = s0.R; sr.c = C; sr.drhat = DRH; sr.partial = part_f; sr.B = B; sr.F = F; sr.nblk = nblk_f; sr.inv_batch = ag->inv_batch(); sr.step = ag->adam_step + 0;
@@ -437,6 +447,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         ColSum c2; memset(&c2, 0, sizeof(c2));
         c2.X = MU ? MU + BF : nullptr; c2.ldX = F; c2.w = C; c2.out = V; c2.rows = B; c2.F = F;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c2, st); }, "v = sum_k c_k mu_r,k"});
+        if (ag->h.world_size > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, V, (int64_t)F, 0});
         SpederGrads sg; memset(&sg, 0, sizeof(sg));
         sg.phi = PHI; sg.mu = MU; sg.c = C; sg.drhat = DRH; sg.phibar = PHIBAR; sg.v = V; sg.theta_w = ag->P("theta.l.weight");
         sg.Gphi = pf.g[phi.depth]; sg.Gmu = mf.g[mu.depth]; sg.B = B; sg.F = F; sg.inv_batch = ag->inv_batch();

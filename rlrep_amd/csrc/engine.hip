@@ -503,6 +503,7 @@ static int build_programs(rlrep_agent* ag, int B) {
     for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog})
         p->stages.clear();
     ag->infer_n = 0;
+    ag->feat_cuts.clear();
     Builder b(ag);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
     {
@@ -787,6 +788,30 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
     return 0;
 }
+int32_t rlrep_feature_exchange_count(rlrep_agent* ag) { return ag ? (int32_t)ag->feat_cuts.size() : RLREP_ERR_ARG; }
+int32_t rlrep_feature_exchange(rlrep_agent* ag, int32_t k, int32_t* kind, float** ptr, int64_t* count, int64_t* local_off) {
+    if (!ag || k < 0 || k >= (int)ag->feat_cuts.size() || !kind || !ptr || !count || !local_off) { rl_set_error("feature_exchange: bad argument"); return RLREP_ERR_ARG; }
+    const Exchange& e = ag->feat_cuts[k];
+    *kind = e.kind; *ptr = e.ptr; *count = e.count; *local_off = e.local_off;
+    return 0;
+}
+int32_t rlrep_feature_backward_part(rlrep_agent* ag, int32_t part, const float* eps, const int32_t* idx, void* stream) {
+    STEP_PROLOGUE(true)
+    const int ncut = (int)ag->feat_cuts.size();
+    if (part < 0 || part > ncut) { rl_set_error("feature_backward_part: part %d of %d", part, ncut + 1); return RLREP_ERR_ARG; }
+    if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    ag->cur_eps = eps; ag->cur_idx = idx;
+    const int lo = part == 0 ? 0 : ag->feat_cuts[part - 1].after_stage + 1;
+    const int hi = part == ncut ? (int)ag->feat_bwd.stages.size() : ag->feat_cuts[part].after_stage + 1;
+    if (part == 0) ag->last_launches = 0;
+    for (int i = lo; i < hi; ++i) {
+        int rc = ag->feat_bwd.stages[i].run((hipStream_t)stream);
+        if (rc) { rl_set_error("stage '%s' failed: hip error %d", ag->feat_bwd.stages[i].what, rc); return RLREP_ERR_HIP; }
+    }
+    ag->last_launches += hi - lo;
+    return 0;
+}
+
 int32_t rlrep_sync_frozen(rlrep_agent* ag, void* stream) {
     if (!ag) return RLREP_ERR_ARG;
     ag->last_launches += (int)ag->sync_prog.stages.size();

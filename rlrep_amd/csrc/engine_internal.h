@@ -4,6 +4,8 @@
 
 struct Slot { float *XE, *XF, *XF2, *XFpi, *R, *D; bool filled = false; };
 
+struct Exchange { int after_stage; int kind; float* ptr; int64_t count; int64_t local_off; };
+
 struct rlrep_agent {
     rlrep_dims d; rlrep_hyper h; rlrep_arenas a; Layout L; Workspace ws;
     int B = 0;
@@ -13,6 +15,7 @@ struct rlrep_agent {
     const float* cur_eps = nullptr; const int* cur_idx = nullptr;
     Program feat_bwd, feat_apply, critic_bwd, critic_apply, actor_bwd, actor_apply, upd_target, infer, sync_prog;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
+    std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
     size_t ws_static = 0;     // workspace bytes used by batch-independent state
 

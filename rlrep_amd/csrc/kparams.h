@@ -114,7 +114,8 @@ struct NcDxTask {
 
 // representation losses (replearn.hip)
 struct InfoNce {
-    float* S; int ldS;                 // [B,B] scores in, dS out (in place)
+    float* S; int ldS;                 // [B, ncols] scores in, dS out (in place); ncols = world*B, own rows' diagonal at column diag_off + i
+    int ncols, diag_off;
     const float* rhat; const float* r; float* drhat;
     float* partial; int B, nblk; float inv_batch; GroupCfg* step;
 };

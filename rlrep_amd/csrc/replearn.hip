@@ -16,17 +16,18 @@ __global__ __launch_bounds__(256) void infonce_kernel(InfoNce p) {
     for (int i = blockIdx.x * 4 + w; i < p.B; i += gridDim.x * 4) {
         float* row = p.S + (size_t)i * p.ldS;
         float mx = -INFINITY;
-        for (int j = lane; j < p.B; j += 64) mx = fmaxf(mx, row[j]);
+        const int NC = p.ncols, di = p.diag_off + i;
+        for (int j = lane; j < NC; j += 64) mx = fmaxf(mx, row[j]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float se = 0.f;
-        for (int j = lane; j < p.B; j += 64) se += expf(row[j] - mx);
+        for (int j = lane; j < NC; j += 64) se += expf(row[j] - mx);
         se = wave_sum(se);
         const float lse = mx + logf(se);
-        const float sii = row[i];
-        for (int j = lane; j < p.B; j += 64) {
+        const float sii = row[di];
+        for (int j = lane; j < NC; j += 64) {
             const float sm = expf(row[j] - lse);
-            row[j] = (sm - (j == i ? 1.f : 0.f)) * p.inv_batch;
+            row[j] = (sm - (j == di ? 1.f : 0.f)) * p.inv_batch;
         }
         const float dr = p.rhat[i] - p.r[i];
         if (lane == 0) p.drhat[i] = dr * p.inv_batch;

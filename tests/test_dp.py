@@ -29,13 +29,14 @@ def _free_port():
 
 
 def _inputs(c, rs, nranks):
-    """Per-rank sample indices / noise for ONE train() of the tiny vlsac fixture's agent."""
+    """Per-rank sample indices / noise for ONE train() of a tiny fixture's agent (vlsac / ctrlsac / spedersac)."""
     F = c.kw['feature_dim']
     nf = c.kw['extra_feature_steps'] + 1
+    nb = 2 * nf if c.alg == 'spedersac' else nf
     out = []
     for _ in range(nranks):
-        idx = [rs.randint(0, c.meta['replay_n'], size=c.B) for _ in range(nf)]
-        eps = [rs.standard_normal((c.B, F)).astype(np.float32) for _ in range(nf)]
+        idx = [rs.randint(0, c.meta['replay_n'], size=c.B) for _ in range(nb)]
+        eps = [rs.standard_normal((c.B, F)).astype(np.float32) for _ in range(nf)] if c.alg == 'vlsac' else []
         eps += [rs.standard_normal((c.B, c.A)).astype(np.float32) for _ in range(2)]
         out.append((idx, eps))
     return out
@@ -115,12 +116,12 @@ def test_dp_gradient_sum_identity_gloo():
 # ------------------------------------------------------------------------------------------------
 # GPU: the HIP train() with world_size 2
 # ------------------------------------------------------------------------------------------------
-def _gpu_worker(rank, world, port, q):
+def _gpu_worker(rank, world, port, q, case='vlsac_tiny'):
     from fixture_io import Case
     from test_hip_parity import make_agent, make_buffer
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    c = Case('vlsac_tiny')
+    c = Case(case)
     agent = make_agent(c)
     assert agent.world_size == world
     buf = make_buffer(c)
@@ -136,19 +137,22 @@ def _gpu_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_hip_dp_two_ranks_match_global_batch_oracle():
+@pytest.mark.parametrize('case', ['vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny'])
+def test_hip_dp_two_ranks_match_global_batch_oracle(case):
+    """ctrlsac (in-batch negatives over BOTH ranks' minibatches) and spedersac (global Phibar / v) are exact too:
+    the oracle sees one batch of 2B rows."""
     from fixture_io import Case, rel_l2
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, case)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    c = Case('vlsac_tiny')
+    c = Case(case)
     rs = np.random.RandomState(11)
     per_rank = [_inputs(c, rs, world) for _ in range(2)]
     o = _oracle_global(c, per_rank, trains=2)
