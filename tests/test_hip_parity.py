@@ -202,3 +202,67 @@ def test_select_action_matches_oracle_mean():
         assert np.allclose(a, torch.tanh(mu)[0].numpy(), atol=1e-5), (a, torch.tanh(mu))
         ae = agent.select_action(s, explore=True)
         assert ae.shape == (c.A,) and np.all(np.abs(ae) <= 1.0)
+
+
+def _tweaked_case(alg, tweak):
+    c = Case(alg + '_tiny')
+    c.init = {k: np.array(v, copy=True) for k, v in c.init.items()}
+    tweak(c.init)
+    return c
+
+
+def _run_vs_oracle(c, trains=2, seed=5):
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    agent = make_agent(c)
+    buf = make_buffer(c)
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    rs = np.random.RandomState(seed)
+    F = c.kw.get('feature_dim', 0)
+    nf = (c.kw.get('extra_feature_steps', 0) + 1) if c.alg != 'sac' else 0
+    for t in range(trains):
+        idx = [rs.randint(0, c.meta['replay_n'], size=c.B) for _ in range(o.n_batches())]
+        eps = [rs.standard_normal((c.B, F)).astype(np.float32) for _ in range(nf)] if c.alg == 'vlsac' else []
+        eps += [rs.standard_normal((c.B, c.A)).astype(np.float32) for _ in range(2)]
+        info = agent.train_injected(buf, c.B, idx, eps)
+        oinfo = o.train([gather_batch(c.replay, i) for i in idx], [torch.as_tensor(e) for e in eps])
+        for k, v in oinfo.items():
+            assert np.isfinite(info[k]), (k, info[k])
+            assert abs(info[k] - v) <= 2e-4 * max(abs(v), 1e-2), (c.alg, t, k, info[k], v)
+    st, P = agent.core.state(), o.state()
+    for k in st:
+        if k in P and not k.endswith('noise'):
+            assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, (c.alg, k)
+    return agent, o
+
+
+def test_rare_branches_match_oracle():
+    """Inputs that FORCE the data-dependent branches of the fused kernels (SURVEY.md 7.4 'op KAT' edge cases):
+    log-std clamp edges (gradient masked above 2 / below -20), exact min(Q1,Q2) ties (sub-gradient split 1/2:1/2),
+    tanh saturation with the softplus(-2x) > 20 branch, ELU at its kink."""
+    # (1) clamp: half of f's and the encoder's log-std heads far above +2, the other half far below -20
+    def clamp(P):
+        for m in ('f', 'f_target', 'encoder'):
+            b = P[m + '.log_std_linear.bias']
+            b[: len(b) // 2] = 7.0
+            b[len(b) // 2:] = -30.0
+    agent, o = _run_vs_oracle(_tweaked_case('vlsac', clamp))
+    g = agent.core.view('f.log_std_linear.weight', 'grad').cpu().numpy()
+    assert np.all(g == 0.0), 'clamped log-std heads must receive exactly zero gradient'
+    # (2) ties: both Q heads identical -> q1 == q2 bit for bit in the actor step
+    def tie(P):
+        for k in list(P):
+            if k.startswith('critic.Q2.'):
+                P[k] = P[k.replace('.Q2.', '.Q1.')].copy()
+            if k.startswith('critic_target.Q2.'):
+                P[k] = P[k.replace('.Q2.', '.Q1.')].copy()
+    _run_vs_oracle(_tweaked_case('sac', tie), trains=1)
+    # (3) saturation: huge actor mean -> |x| > 10: tanh(x) == +-1 in fp32, softplus threshold branch, log-prob stays finite
+    def saturate(P):
+        P['actor.trunk.4.bias'][: len(P['actor.trunk.4.bias']) // 2] = np.array([14.0, -14.0, 11.0])[: len(P['actor.trunk.4.bias']) // 2]
+    _run_vs_oracle(_tweaked_case('sac', saturate), trains=1)
+    # (4) ELU kink: zero first-layer critic weights and biases -> pre-activations exactly 0
+    def kink(P):
+        P['critic.Q1.0.weight'][:] = 0.0
+        P['critic.Q1.0.bias'][:] = 0.0
+    _run_vs_oracle(_tweaked_case('sac', kink), trains=1)
