@@ -183,6 +183,31 @@ class SACAgent(object):
 
     update = train      # BASELINE.json's north_star calls it agent.update()
 
+    # ---- checkpoint / resume (absent in the reference: `--save_model` is parsed and never read, main.py:37) ------
+    def state_snapshot(self):
+        c = self.core
+        torch.cuda.synchronize()
+        steps_dev = None
+        return {'alg': self.ALG, 'params': c.params.cpu(), 'targets': c.targets.cpu(), 'exp_avg': c.exp_avg.cpu(),
+                'exp_avg_sq': c.exp_avg_sq.cpu(), 'alpha_state': c.alpha_state.cpu(), 'device_state': c.device_state().cpu(),
+                'steps': self.steps, 'noise_ctr': self._ctr, 'seed': self._seed, 'layout': list(c.order)}
+
+    def save(self, path):
+        torch.save(self.state_snapshot(), path)
+
+    def load(self, path_or_snapshot):
+        snap = torch.load(path_or_snapshot) if isinstance(path_or_snapshot, (str, bytes, os.PathLike)) else path_or_snapshot
+        c = self.core
+        if snap['alg'] != self.ALG or snap['layout'] != list(c.order) or snap['params'].numel() != c.params.numel():
+            raise RuntimeError('checkpoint does not match this agent (algorithm / dimensions differ)')
+        for k, dst in (('params', c.params), ('targets', c.targets), ('exp_avg', c.exp_avg), ('exp_avg_sq', c.exp_avg_sq),
+                       ('alpha_state', c.alpha_state)):
+            dst.copy_(snap[k])
+        c.device_state().copy_(snap['device_state'])
+        self.steps, self._ctr, self._seed = snap['steps'], snap['noise_ctr'], snap['seed']
+        self._graph = None
+        torch.cuda.synchronize()
+
     # ---- internals ----------------------------------------------------------------------------
     def _set_batch(self, batch, slot=0):
         self._B = int(batch.state.shape[0])

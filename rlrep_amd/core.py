@@ -254,5 +254,11 @@ class HipCore:
     def run_stage(self, program, stage):
         check(lib.rlrep_run_stage(self.h, program, stage, _stream()), 'run_stage')
 
+    def device_state(self):
+        """uint8 view of the library's batch-independent device state (train() counter, per-group Adam step
+        counters and scalars, metric slots): what a checkpoint must carry besides the arenas."""
+        end = self._metrics_ptr - self.workspace.data_ptr() + 4 * METRIC_SLOTS
+        return self.workspace[:end]
+
     def launch_count(self):
         return lib.rlrep_last_launch_count(self.h)

@@ -76,6 +76,17 @@ class ReplayBuffer(object):
         self.ring[:n].copy_(torch.from_numpy(rows))
         self.size, self.ptr, self._staged = n, n % self.max_size, 0
 
+    def save(self, path):
+        self.flush()
+        torch.cuda.synchronize() if self.device.type == 'cuda' else None
+        np.savez_compressed(path, ring=self.ring[:self.size].cpu().numpy(), ptr=self.ptr, size=self.size)
+
+    def restore(self, path):
+        z = np.load(path)
+        n = int(z['size'])
+        self.ring[:n].copy_(torch.from_numpy(z['ring']))
+        self.ptr, self.size, self._staged = int(z['ptr']), n, 0
+
     def size_dev(self):
         """int32[1] device scalar holding `size` (read by the graph-replayed index generator)."""
         if self._size_pushed != self.size:
