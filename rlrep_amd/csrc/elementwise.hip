@@ -318,19 +318,47 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
     }
     const AdamTask& t = tasks[ti];
     const AdamScal sc = t.grp->sc;
-    const long long i0 = (long long)(bid - base_blk) * 1024 + threadIdx.x;
+    // 16 bytes per lane per array: group offsets/sizes and the Polyak sub-range are multiples of 4 floats (arena layout)
+    const long long i = ((long long)(bid - base_blk) * 256 + threadIdx.x) * 4;
+    if (i >= t.n) return;
+    const bool vec = (i + 4 <= t.n) && ((t.pol_off & 3) == 0) && ((t.pol_n & 3) == 0) &&
+                     (((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v) | ((uintptr_t)t.target)) & 15) == 0);
+    if (vec) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
+        f32x4 p4 = *reinterpret_cast<f32x4*>(t.p + i), m4 = *reinterpret_cast<f32x4*>(t.m + i), v4 = *reinterpret_cast<f32x4*>(t.v + i);
+        const bool pol = t.target && i >= t.pol_off && i < t.pol_off + t.pol_n;
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        if (pol) t4 = *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off));
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const long long i = i0 + s * 256;
-        if (i >= t.n) break;
-        float* tp = (t.target && i >= t.pol_off && i < t.pol_off + t.pol_n) ? t.target + (i - t.pol_off) : nullptr;
-        adam_elem(sc, t.g[i], t.p + i, t.m + i, t.v + i, tp);
+        for (int s = 0; s < 4; ++s) {
+            float pp = p4[s], mm = m4[s], vv = v4[s], tt = t4[s];
+            adam_elem(sc, g[s], &pp, &mm, &vv, pol ? &tt : nullptr);
+            p4[s] = pp; m4[s] = mm; v4[s] = vv; t4[s] = tt;
+        }
+        *reinterpret_cast<f32x4*>(t.p + i) = p4; *reinterpret_cast<f32x4*>(t.m + i) = m4; *reinterpret_cast<f32x4*>(t.v + i) = v4;
+        if (pol) *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off)) = t4;
+    } else {
+        for (int s = 0; s < 4 && i + s < t.n; ++s) {
+            const long long e = i + s;
+            float* tp = (t.target && e >= t.pol_off && e < t.pol_off + t.pol_n) ? t.target + (e - t.pol_off) : nullptr;
+            adam_elem(sc, t.g[e], t.p + e, t.m + e, t.v + e, tp);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void polyak_kernel(PolyakTask t) {
     if (t.steps && ((*t.steps) % t.period) != 0) return;
     const float omt = (float)(1.0 - (double)t.tau);
+    if ((t.n & 3) == 0 && (((uintptr_t)t.src | (uintptr_t)t.dst) & 15) == 0) {
+        for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < t.n; i += (long long)gridDim.x * 1024) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(t.src + i);
+            f32x4 b = *reinterpret_cast<f32x4*>(t.dst + i);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[s] = t.tau * a[s] + omt * b[s];
+            *reinterpret_cast<f32x4*>(t.dst + i) = b;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (long long)gridDim.x * 256)
         t.dst[i] = t.tau * t.src[i] + omt * t.dst[i];
 }
@@ -390,7 +418,7 @@ extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {
-    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(t->n, 256, 1024)), dim3(256), 0, st, *t);
+    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(t->n, 1024, 1024)), dim3(256), 0, st, *t);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_counter_inc(int* c, hipStream_t st) {
