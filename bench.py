@@ -44,6 +44,7 @@ WORKLOADS = {
 OPT_STEPS = {'sac': 3, 'vlsac': 7, 'ctrlsac': 7, 'spedersac': 9, 'diffsrsac': 10}
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
+NC_FWD_TRAFFIC_BYTES = int((2 * 3103.5 + 11446.6) * 1024)   # 17.7 MB vs 11.0 MB algorithmic (U out 10.5 MB + inputs)
 
 
 class Space:
@@ -91,7 +92,9 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     achieved = flops / (us * 1e-6) / 1e12
     return {'bound': 'mfma', 'kernel': 'nc_fwd_kernel (critic step, 4 heads)', 'achieved': round(achieved, 2),
             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': None, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
+            # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
+            # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)
+            'traffic': NC_FWD_TRAFFIC_BYTES, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
 
 
 def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):

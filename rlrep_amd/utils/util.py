@@ -1,25 +1,26 @@
-"""Host utilities with the reference's names (utils/util.py:10-104).  No gym import: only its name was
-used by the reference, and the agents here never needed it."""
+"""Host-side helpers under the reference's names (utils/util.py:10-104): `unpack_batch`, `Timer`, `eval_policy`,
+`weight_init`, `MLP`, `mlp`, `to_np`.  No gym import (the reference only needed the module's name)."""
 import time
+
 import numpy as np
 import torch
 from torch import nn
 
 
 def unpack_batch(batch):
-    # utils/util.py:10-11: note the order differs from the Batch field order
-    return batch.state, batch.action, batch.next_state, batch.reward, batch.done
+    """(state, action, next_state, reward, done) -- NOT the Batch field order (utils/util.py:10-11)."""
+    return tuple(getattr(batch, f) for f in ('state', 'action', 'next_state', 'reward', 'done'))
 
 
 class Timer:
-    """utils/util.py:14-37."""
+    """Wall-clock bookkeeping for the launcher's `Steps per sec` line (utils/util.py:14-37)."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        now = time.time()
-        self._start_time, self._step_time, self._step = now, now, 0
+        self._start_time = self._step_time = time.time()
+        self._step = 0
 
     def set_step(self, step):
         self._step, self._step_time = step, time.time()
@@ -29,49 +30,47 @@ class Timer:
 
     def steps_per_sec(self, step):
         now = time.time()
-        sps = (step - self._step) / (now - self._step_time)
+        rate = (step - self._step) / max(now - self._step_time, 1e-12)
         self._step, self._step_time = step, now
-        return sps
+        return rate
 
 
 def eval_policy(policy, eval_env, eval_episodes=10):
-    """utils/util.py:40-57 (pre-0.26 gym API: reset() -> obs, step() -> 4-tuple)."""
-    total = 0.
+    """Mean undiscounted return of the deterministic policy over `eval_episodes` episodes (pre-0.26 gym API)."""
+    returns = []
     for _ in range(eval_episodes):
-        state, done = eval_env.reset(), False
+        obs, done, ret = eval_env.reset(), False, 0.0
         while not done:
-            state, reward, done, _ = eval_env.step(policy.select_action(np.array(state)))
-            total += reward
-    avg = total / eval_episodes
-    print('---------------------------------------')
-    print(f'Evaluation over {eval_episodes} episodes: {avg:.3f}')
-    print('---------------------------------------')
+            obs, reward, done, _ = eval_env.step(policy.select_action(np.asarray(obs)))
+            ret += reward
+        returns.append(ret)
+    avg = float(np.mean(returns))
+    bar = '-' * 39
+    print(f'{bar}\nEvaluation over {eval_episodes} episodes: {avg:.3f}\n{bar}')
     return avg
 
 
 def weight_init(m):
-    """utils/util.py:61-66: orthogonal weights, zero bias."""
+    """Orthogonal weights / zero bias for every nn.Linear (applied with Module.apply)."""
     if isinstance(m, nn.Linear):
         nn.init.orthogonal_(m.weight.data)
-        if hasattr(m.bias, 'data'):
-            m.bias.data.fill_(0.0)
+        if m.bias is not None:
+            m.bias.data.zero_()
 
 
 def mlp(input_dim, hidden_dim, output_dim, hidden_depth, output_mod=None):
-    """utils/util.py:85-96: Linear(+ELU)*depth, Linear."""
-    dims = [input_dim] + [hidden_dim] * hidden_depth
-    mods = []
-    for a, b in zip(dims[:-1], dims[1:]):
-        mods += [nn.Linear(a, b), nn.ELU(inplace=True)]
-    mods.append(nn.Linear(dims[-1], output_dim))
+    """nn.Sequential of `hidden_depth` x (Linear, ELU) + Linear; Linear layers sit at indices 0, 2, 4, ..."""
+    widths = [input_dim] + [hidden_dim] * hidden_depth
+    layers = []
+    for fan_in, fan_out in zip(widths, widths[1:]):
+        layers.extend((nn.Linear(fan_in, fan_out), nn.ELU(inplace=True)))
+    layers.append(nn.Linear(widths[-1], output_dim))
     if output_mod is not None:
-        mods.append(output_mod)
-    return nn.Sequential(*mods)
+        layers.append(output_mod)
+    return nn.Sequential(*layers)
 
 
 class MLP(nn.Module):
-    """utils/util.py:69-82."""
-
     def __init__(self, input_dim, hidden_dim, output_dim, hidden_depth, output_mod=None):
         super().__init__()
         self.trunk = mlp(input_dim, hidden_dim, output_dim, hidden_depth, output_mod)
@@ -84,6 +83,4 @@ class MLP(nn.Module):
 def to_np(t):
     if t is None:
         return None
-    if t.nelement() == 0:
-        return np.array([])
-    return t.cpu().detach().numpy()
+    return np.array([]) if t.nelement() == 0 else t.detach().cpu().numpy()
