@@ -22,29 +22,37 @@
 // the row-contiguous case) and feeds them to four successive MFMAs.
 #include "common.h"
 
-template <int LOADER>
-__device__ __forceinline__ void load_frag(const float* __restrict__ P, int ld, int base, int lim,
-                                          int i, int k0, int K, bool vec, float (&v)[4]) {
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    const int idx = base + i;
-    if (idx >= lim || k0 >= K) return;
+// BRANCH-FREE operand fetch.  Out-of-range rows / inner indices are handled by CLAMPING the address into the
+// matrix and zeroing the value with a select: no exec-masked branch around any load.  (With `if (in_range) load`
+// hipcc wraps every load in s_cbranch_execz + s_waitcnt vmcnt(0): 147 branches and 21 full drains in a kernel
+// with 16 MFMAs, i.e. the eight 16-byte loads a wave needs were serialised instead of overlapped.)
+template <int LOADER, bool VEC>
+__device__ __forceinline__ void load_raw(const float* __restrict__ P, int ld, int base, int lim,
+                                         int i, int k0, int K, float (&v)[4]) {
+    const int idx = min(base + i, lim - 1);
     if (LOADER == LD_ROW) {
-        const float* p = P + (size_t)idx * ld + k0;
-        if (vec) {
-            f32x4 x = *reinterpret_cast<const f32x4*>(p);
+        if (VEC) {                       // K % 4 == 0, 16-byte aligned rows: the 4 indices are valid together
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)idx * ld + min(k0, K - 4));
             v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
         } else {
+            const float* p = P + (size_t)idx * ld;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[s];
+            for (int s = 0; s < 4; ++s) v[s] = p[min(k0 + s, K - 1)];
         }
     } else {  // LD_COL
-        const float* p = P + (size_t)k0 * ld + idx;
+        const float* p = P + idx;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) if (k0 + s < K) v[s] = p[(size_t)s * ld];
+        for (int s = 0; s < 4; ++s) v[s] = p[(size_t)min(k0 + s, K - 1) * ld];
     }
 }
+// zero what the clamped load fetched from outside the matrix
+__device__ __forceinline__ void mask_frag(int base, int lim, int i, int k0, int K, float (&v)[4]) {
+    const bool rok = (base + i) < lim;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = (rok && k0 + s < K) ? v[s] : 0.f;
+}
 
-template <int LA, int LB, int NF>
+template <int LA, int LB, int NF, bool VA, bool VB>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
@@ -60,9 +68,6 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int K = t.K;
-
-    const bool vecA = (LA == LD_ROW) && ((t.lda & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)t.A) & 15) == 0);
-    const bool vecB = (LB == LD_ROW) && ((t.ldb & 3) == 0) && ((K & 3) == 0) && ((((uintptr_t)t.B) & 15) == 0);
 
     f32x4 acc[NF];
 #pragma unroll
@@ -103,9 +108,18 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         float a[4][4], b[4][NF][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            load_frag<LA>(t.A, t.lda, r0, t.R, i, kb + 64 * u + 4 * kq, K, vecA, a[u]);
+            load_raw<LA, VA>(t.A, t.lda, r0, t.R, i, kb + 64 * u + 4 * kq, K, a[u]);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) load_frag<LB>(t.B, t.ldb, c0 + 16 * f, t.Cn, i, kb + 64 * u + 4 * kq, K, vecB, b[u][f]);
+            for (int f = 0; f < NF; ++f) load_raw<LB, VB>(t.B, t.ldb, c0 + 16 * f, t.Cn, i, kb + 64 * u + 4 * kq, K, b[u][f]);
+        }
+        // every load of the group is issued before anything consumes one (hipcc otherwise sinks each load next to
+        // its MFMA and drains vmcnt(0) in between: eight serialised L2 round trips instead of one)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mask_frag(r0, t.R, i, kb + 64 * u + 4 * kq, K, a[u]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) mask_frag(c0 + 16 * f, t.Cn, i, kb + 64 * u + 4 * kq, K, b[u][f]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -247,19 +261,34 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
-template <int LA, int LB>
+template <int LA, int LB, bool VA, bool VB>
 static void launch_nf(int nf, dim3 g, hipStream_t st, const GemmBatch& gb) {
-    if (nf == 1) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1>), g, dim3(256), 0, st, gb);
-    else if (nf == 2) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 2>), g, dim3(256), 0, st, gb);
-    else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 4>), g, dim3(256), 0, st, gb);
+    if (nf == 1) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB>), g, dim3(256), 0, st, gb);
+    else if (nf == 2) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 2, VA, VB>), g, dim3(256), 0, st, gb);
+    else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 4, VA, VB>), g, dim3(256), 0, st, gb);
+}
+
+// 16-byte operand loads are legal for a launch only if EVERY task of it has 4-float-aligned rows and inner length
+static bool all_vec(const GemmBatch& gb, bool opB) {
+    for (int q = 0; q < gb.ntasks; ++q) {
+        const GemmTask& t = gb.t[q];
+        const float* p = opB ? t.B : t.A;
+        const int ld = opB ? t.ldb : t.lda;
+        if ((ld & 3) || (t.K & 3) || (((uintptr_t)p) & 15)) return false;
+    }
+    return true;
 }
 
 extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     dim3 g(total_tiles);
-    if (la == LD_ROW && lb == LD_ROW) launch_nf<LD_ROW, LD_ROW>(nf, g, st, *gb);
-    else if (la == LD_ROW && lb == LD_COL) launch_nf<LD_ROW, LD_COL>(nf, g, st, *gb);
-    else if (la == LD_COL && lb == LD_COL) launch_nf<LD_COL, LD_COL>(nf, g, st, *gb);
+    if (la == LD_ROW && lb == LD_ROW) {
+        if (all_vec(*gb, false) && all_vec(*gb, true)) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb);
+        else launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
+    } else if (la == LD_ROW && lb == LD_COL) {
+        if (all_vec(*gb, false)) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb);
+        else launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
+    } else if (la == LD_COL && lb == LD_COL) launch_nf<LD_COL, LD_COL, false, false>(nf, g, st, *gb);
     else return -1;
     return (int)hipGetLastError();
 }

@@ -107,6 +107,7 @@ struct NcDxTask {
     float* G; int ldg;               // out [B, 2F]: (dmean | dlog_std)
     int B, F, H, N, nheads;
     int tiles_k, tile_base, ntiles;
+    int dbg;                         // timing experiments only: 1 skip MFMA, 2 skip U/GH staging, 4 skip W loads, 8 skip barrier
 };
 
 

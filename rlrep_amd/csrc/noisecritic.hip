@@ -167,11 +167,26 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
 
 // ------------------------------------------------------------------------------------------------
 // dL/d(mean, log_std), both heads (actor step).
-// workgroup = 8 waves: waves 0-3 head 0, waves 4-7 head 1; wave (w&3) owns 16 feature columns;
+// workgroup = 8 waves: waves 0-3 consume head 0, waves 4-7 head 1; wave (w&3) owns 16 feature columns;
 // tile = 4 batch rows x 20 noise rows x 64 feature columns; inner loop over the H hidden units of the head.
+//
+// The A operand dPre[(b,n), j] = GH[b,j]/N * elu'(U[(b,n), j]) is needed by all four column-group waves of a
+// head, so it is produced ONCE per workgroup: all 512 threads load their share of the [80 x 16] U tile of each head
+// with one 16-byte load, apply elu' and the GH scale, and park the result in an LDS ring; the consumer waves only
+// issue ds_read_b128 + MFMA.  Pipeline per inner step s: global loads at iteration s-3 (registers), LDS write at
+// s-2, consumed at s -- two iterations (>= 1280 MFMA cycles per SIMD) cover the L2/MALL latency of U, which the
+// previous (register-prefetch, per-wave) version could not (WAIT_ANY 45 % of wave cycles, profiles/r01_pmc_summary).
 // ------------------------------------------------------------------------------------------------
+#define NCDX_RING 4
+#define NCDX_ALD 20          // LDS row stride of the A tile in floats (16 + 4 pad, keeps 16-byte alignment)
+
 __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
-    __shared__ float red[4][NC_NF][4][64];      // 20 KB: head-1 partial accumulators
+    __shared__ __attribute__((aligned(16))) float a_s[NCDX_RING][2][80 * NCDX_ALD];   // 51 KB
+    __shared__ float red[4][NC_NF][4][64];                                            // 20 KB: head-1 partial accumulators
+#ifdef NCDX_PAD_LDS
+    __shared__ float pad_one_wg_per_cu[NCDX_PAD_LDS];    // experiment: > 80 KB total LDS forbids two workgroups per CU
+    if (t.B < 0) pad_one_wg_per_cu[threadIdx.x] = 0.f;
+#endif
     // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2).  The tiles_k column tiles of one
     // batch tile read the SAME rows of U, so they are given the same (blockIdx % 8) whenever the grid allows.
     int bid = blockIdx.x;
@@ -182,68 +197,99 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
             bid = ((y / t.tiles_k) * 8 + x) * t.tiles_k + (y % t.tiles_k);
         }
     }
+    if (t.dbg & 16) return;
     const int tb = bid / t.tiles_k, tk = bid - tb * t.tiles_k;
     const int b0 = tb * 4, kc0 = tk * 64;
     const int F = t.F, H = t.H, N = t.N;
-    const int lane = threadIdx.x & 63, w8 = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
     const int w = w8 & 3, h = (t.nheads > 1) ? (w8 >> 2) : 0;
-    const bool idle = (t.nheads == 1) && (w8 >= 4);
+    const bool consumer = (t.nheads > 1) || (w8 < 4);
     const int m16 = lane & 15, kq = lane >> 4;
     const int bp = m16 >> 2, nn = m16 & 3;
     const int kcol = kc0 + 16 * w + m16;
     const bool colok = kcol < F;
     const float invN = 1.0f / (float)N;
     const bool vecG = ((H & 3) == 0) && ((t.ldgh & 3) == 0);
-    const int b = b0 + bp;
-    const bool rowok = b < t.B;
+    const int T = (H + 15) / 16;                                  // inner steps per head
+
+    // ---- loader role: element q of the step's 2 x [80 x 16] tile = (head, row, 4-wide j group) ----
+    // q in [0, 640): thread tid owns q = tid and (tid < 128) q = 512 + tid
+    struct LReg { float u[4]; float g[4]; };
+    auto lq = [&](int q, int& hh, int& row, int& jq) { hh = q / 320; const int e = q - hh * 320; row = e >> 2; jq = e & 3; };
+    auto lload = [&](int q, int step, LReg& r) {
+        int hh, row, jq; lq(q, hh, row, jq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { r.u[s] = 1.f; r.g[s] = 0.f; }
+        if (hh >= t.nheads) return;
+        const int lb = row / 20, n = row - lb * 20, b = b0 + lb, j0 = step * 16 + 4 * jq;
+        if (b >= t.B || j0 >= H) return;
+        const int valid = min(4, H - j0);
+        ld4(t.U[hh] + ((size_t)b * N + n) * H + j0, vecG, valid, r.u);
+        ld4(t.GH[hh] + (size_t)b * t.ldgh + j0, vecG, valid, r.g);
+    };
+    auto lwrite = [&](int q, int step, const LReg& r) {
+        int hh, row, jq; lq(q, hh, row, jq);
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = r.g[s] * invN * elu_grad_from_out(r.u[s]);
+        *reinterpret_cast<f32x4*>(&a_s[step % NCDX_RING][hh][row * NCDX_ALD + 4 * jq]) = v;
+    };
+    const bool two = tid < 128;
+    LReg ra0, rb0, ra1, rb1;                                      // two register sets x (first, second element); named, never
+                                                                  // runtime-indexed (a runtime index would put them in scratch)
+    // prologue: steps 0 and 1 staged synchronously, step 2 in flight in register set 0
+    for (int s0 = 0; s0 < 2 && s0 < T; ++s0) {
+        lload(tid, s0, ra0); if (two) lload(512 + tid, s0, rb0);
+        lwrite(tid, s0, ra0); if (two) lwrite(512 + tid, s0, rb0);
+    }
+    if (2 < T) { lload(tid, 2, ra0); if (two) lload(512 + tid, 2, rb0); }
+    __syncthreads();
 
     f32x4 acc[NC_NF];
 #pragma unroll
     for (int f = 0; f < NC_NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* W = t.W[h] + (colok ? kcol : 0);
+    const unsigned Fu = (unsigned)F;
+    float wv[4], wn[4];
+    auto wload = [&](int step, float (&o)[4]) {
+        const int j0 = step * 16 + 4 * kq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[s] = (consumer && colok && j0 + s < H) ? W[(unsigned)(j0 + s) * Fu] : 0.f;
+    };
+    wload(0, wv);
 
-    if (!idle) {
-        const float* GH = t.GH[h] + (size_t)(rowok ? b : 0) * t.ldgh;
-        const float* U = t.U[h] + (size_t)(rowok ? b : 0) * N * H;
-        const float* W = t.W[h] + (colok ? kcol : 0);
-        // operands of one 16-wide inner step (4 hidden units per lane group)
-        struct Step { float gh[4]; float u[NC_NF][4]; float wv[4]; };
-        const unsigned Hu = (unsigned)H, Fu = (unsigned)F;
-        auto load = [&](int jb, Step& q) {
-            const int j0 = jb + 4 * kq;
-            const int valid = max(0, min(4, H - j0));
-            ld4(GH + j0, vecG, rowok ? valid : 0, q.gh);
+    // one inner step; (an, bn) = register set that receives step+3, (ao, bo) = set holding step+2
+    auto iter = [&](int step, LReg& an, LReg& bn, LReg& ao, LReg& bo) {
+        const int ls = step + 3;
+        // program order matters: vmcnt retires in order, so the W fragment (needed at the END of this iteration) is
+        // issued BEFORE the U/GH loads (needed an iteration later); waiting for W then leaves the U loads in flight
+        if (step + 1 < T && !(t.dbg & 4)) wload(step + 1, wn);
+        if (ls < T && !(t.dbg & 2)) { lload(tid, ls, an); if (two) lload(512 + tid, ls, bn); }
+        if (consumer) {
+            const float* as = &a_s[step % NCDX_RING][h][0];
+            f32x4 a4[NC_NF];
 #pragma unroll
-            for (int f = 0; f < NC_NF; ++f) ld4(U + (unsigned)(4 * f + nn) * Hu + j0, vecG, rowok ? valid : 0, q.u[f]);
+            for (int f = 0; f < NC_NF; ++f) a4[f] = *reinterpret_cast<const f32x4*>(&as[(bp * 20 + 4 * f + nn) * NCDX_ALD + 4 * kq]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) q.wv[s] = (colok && j0 + s < H) ? W[(unsigned)(j0 + s) * Fu] : 0.f;
-        };
-        auto compute = [&](const Step& q) {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float gs = q.gh[s] * invN;
-#pragma unroll
-                for (int f = 0; f < NC_NF; ++f)
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs * elu_grad_from_out(q.u[f][s]), q.wv[s], acc[f], 0, 0, 0);
-            }
-        };
-        // GS steps (GS*20 MFMAs) are in flight ahead of the GS being computed: L2 latency >> one step's MFMAs.
-        // GS = 2 is the deepest that fits 256 VGPRs at 2 waves/SIMD without spilling (GS = 4 spills 44 VGPRs: 45 us).
-        constexpr int GS = 2;
-        Step cur[GS], nxt[GS];
-#pragma unroll
-        for (int g = 0; g < GS; ++g) load(16 * g, cur[g]);
-        for (int jb = 0; jb < H; jb += 16 * GS) {
-            if (jb + 16 * GS < H) {
-#pragma unroll
-                for (int g = 0; g < GS; ++g) load(jb + 16 * GS + 16 * g, nxt[g]);
-            }
-#pragma unroll
-            for (int g = 0; g < GS; ++g) if (jb + 16 * g < H) compute(cur[g]);
-#pragma unroll
-            for (int g = 0; g < GS; ++g) cur[g] = nxt[g];
+                for (int f = 0; f < NC_NF; ++f) {
+                    if (t.dbg & 1) acc[f][s] += a4[f][s] * wv[s];
+                    else acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[f][s], wv[s], acc[f], 0, 0, 0);
+                }
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wv[s] = wn[s];
+        if (step + 2 < T && !(t.dbg & 2)) { lwrite(tid, step + 2, ao); if (two) lwrite(512 + tid, step + 2, bo); }
+        if (!(t.dbg & 8)) __syncthreads();
+    };
+    for (int step = 0; step < ((t.dbg & 64) ? 0 : T); step += 2) {
+        iter(step, ra1, rb1, ra0, rb0);                            // step even: step+2 sits in set 0, step+3 goes to set 1
+        if (step + 1 < T) iter(step + 1, ra0, rb0, ra1, rb1);
     }
-    if (w8 >= 4) {
+
+    if (t.dbg & 32) { if (acc[0][0] == 123.456f) t.G[0] = 1.f; return; }
+    if (w8 >= 4 && t.nheads > 1) {
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
@@ -258,7 +304,7 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
     for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = acc[f][r] + red[w][f][r][lane];
+            const float v = acc[f][r] + (t.nheads > 1 ? red[w][f][r][lane] : 0.f);
             dmu += v;
             dls = fmaf(v, t.noise[(size_t)(4 * f + r) * F + kcol], dls);
         }

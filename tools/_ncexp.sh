@@ -1,2 +1,1 @@
-python tools/stage_times.py 2>&1 | grep -E "noise critic|train\(\)|sum of"
-timeout 300 python -m pytest tests/test_hip_parity.py -m gpu -q -k vlsac 2>&1 | tail -2
+for d in 16 47 79 111 64 32; do echo -n "dbg=$d "; RLREP_NCDX_DBG=$d python tools/stage_times.py 2>&1 | grep -E "noise critic dX"; done
