@@ -35,23 +35,29 @@ enum Epi : int {
 
 struct GroupCfg;
 struct GemmTask {
+    // ---- hot block: read by every tile in ONE scalar-load burst (first 112 bytes) -------------------
     const float* A;      // operand A (output rows)
     const float* B;      // operand B (output cols)
     float* C;
     const float* bias;   // EPI_FWD: bias[Cn];  EPI_DW: unused
     const float* aux;    // EPI_DX: saved activation (or pre-activation for sin);  LD_NCG: GH
-    const float* aux2;   // LD_NCX: log-std
-    const float* aux3;   // EPI_DX_REPARAM: eps*exp(l)*mask;  LD_NCX: mean
-    float* out2;         // EPI_FWD+ACT_SIN: pre-activation; EPI_DW: bias gradient
     const float* r1u;    // EPI_DX: optional rank-1 term added to acc: r1u[r] * r1v[c]
     const float* r1v;
-    int lda, ldb, ldc, ldaux, ldaux2, ldaux3, ldout2;
+    int lda, ldb, ldc, ldaux;
     int R, Cn, K;        // output R x Cn, inner length K
-    int tiles_c, tile_base, ntiles;
+    int tiles_c, tile_base;
     int epi, act, flags;
+    float scale;         // multiplies acc before the epilogue (1.0 default)
+    int n0;              // fused loss / policy epilogues: column split (S or A)
+    float* out2;         // EPI_FWD+ACT_SIN: pre-activation; EPI_DW: bias gradient
+    int ldout2;
+    int ntiles;
+    // ---- cold block: only the epilogue that needs a field reads it ---------------------------------
+    const float* aux2;   // LD_NCX: log-std
+    const float* aux3;   // EPI_DX_REPARAM: eps*exp(l)*mask;  LD_NCX: mean
+    int ldaux2, ldaux3;
     int ncN;             // noise rows (20) for LD_NCG/LD_NCX
     int F;               // EPI_DX_REPARAM: column offset of the log-std half
-    float scale;         // multiplies acc before the epilogue (1.0 default)
     // EPI_DW with the optimizer fused in (single-GPU path): Adam on the tile's own weights (and bias), plus
     // Polyak into the target copy.  All pointers are bases of tensors laid out like C / out2.
     float* ad_p; float* ad_m; float* ad_v; float* ad_t;          // weight: param, exp_avg, exp_avg_sq, target (or null)
@@ -59,7 +65,7 @@ struct GemmTask {
     const GroupCfg* ad_grp;
     // generic operands of the fused loss / policy epilogues
     const float* x0; const float* x1; const float* x2; float* y0; float* y1; const double* dptr;
-    int ldx0, ldx1, n0; float s0, s1;
+    int ldx0, ldx1; float s0, s1;
 };
 
 #define GEMM_MAX_TASKS 8

@@ -365,7 +365,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         NcFwdTask t; memset(&t, 0, sizeof(t));
         t.mean = HH; t.lstd = HH ? HH + F : nullptr; t.ld_ml = 2 * F; t.noise = noise; t.W = W; t.bias = bias; t.Hm = Hm; t.U = Ubuf;
         t.B = B; t.F = F; t.H = H; t.N = N;
-        if (getenv("RLREP_NC_DBG")) t.dbg = atoi(getenv("RLREP_NC_DBG"));
         return t;
     };
     auto nc_stage = [&](Program& p, std::vector<NcFwdTask> tasks, const char* what) {
@@ -483,7 +482,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             t.W[0] = Pw("critic.l1.weight"); t.W[1] = Pw("critic.l4.weight"); t.noise = noise;
             t.lstd = gt.HH ? gt.HH + F : nullptr; t.ld_l = 2 * F; t.G = GTH; t.ldg = 2 * F;
             t.B = B; t.F = F; t.H = H; t.N = N; t.nheads = 2;
-            if (getenv("RLREP_NCDX_DBG")) t.dbg = atoi(getenv("RLREP_NCDX_DBG"));
             t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 3) / 4) * t.tiles_k; t.tile_base = 0;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(&t, st); }, "noise critic dX -> (dmean, dlog_std)"});
         }

@@ -52,6 +52,37 @@ __device__ __forceinline__ void mask_frag(int base, int lim, int i, int k0, int 
     for (int s = 0; s < 4; ++s) v[s] = (rok && k0 + s < K) ? v[s] : 0.f;
 }
 
+// NU 16-wide inner chunks of wave w (NU = 4 covers K <= 256 in one go): EVERY load of the group is issued before
+// anything consumes one (hipcc otherwise sinks each load next to its MFMA and drains vmcnt(0) in between: eight
+// serialised L2 round trips instead of one)
+template <int LA, int LB, int NF, bool VA, bool VB, int NU>
+__device__ __forceinline__ void mac_group(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                          int r0, int R, int c0, int Cn, int i, int k0, int K,
+                                          f32x4 (&acc)[NF], float& asum, bool want_bias) {
+    float a[NU][4], b[NU][NF][4];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        load_raw<LA, VA>(A, lda, r0, R, i, k0 + 64 * u, K, a[u]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) load_raw<LB, VB>(B, ldb, c0 + 16 * f, Cn, i, k0 + 64 * u, K, b[u][f]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        mask_frag(r0, R, i, k0 + 64 * u, K, a[u]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) mask_frag(c0 + 16 * f, Cn, i, k0 + 64 * u, K, b[u][f]);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][f][s], acc[f], 0, 0, 0);
+        if (want_bias) asum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+    }
+}
+
 template <int LA, int LB, int NF, bool VA, bool VB>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
@@ -62,73 +93,116 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 #pragma unroll
     for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
     const GemmTask& t = gb.t[ti];
-    const int local = bid - t.tile_base;
-    const int tr = local / t.tiles_c, tc = local - tr * t.tiles_c;
+    // the hot block of the task record, fetched as one burst of scalar loads
+    const float* const pA = t.A; const float* const pB = t.B; float* const pC = t.C;
+    const float* const pbias = t.bias; const float* const paux = t.aux;
+    const float* const pr1u = t.r1u; const float* const pr1v = t.r1v;
+    const int lda = t.lda, ldb = t.ldb, ldc = t.ldc, ldaux = t.ldaux;
+    const int R = t.R, Cn = t.Cn, K = t.K, tiles_c = t.tiles_c, tile_base = t.tile_base;
+    const int epi = t.epi, act = t.act, flags = t.flags, n0 = t.n0;
+    const float scale = t.scale;
+    float* const pout2 = t.out2; const int ldout2 = t.ldout2;
+
+    const int local = bid - tile_base;
+    const int tr = local / tiles_c, tc = local - tr * tiles_c;
     const int r0 = tr * 16, c0 = tc * 16 * NF;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int K = t.K;
 
     f32x4 acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    const bool want_bias = (t.epi == EPI_DW) && (t.flags & FLAG_BIASGRAD) && (tc == 0);
+    const bool want_bias = (epi == EPI_DW) && (flags & FLAG_BIASGRAD) && (tc == 0);
 
-    // this thread's output elements are known up front: issue the epilogue's operand loads (bias, saved
-    // activation, accumulate-into value) NOW so their latency overlaps the operand stream
+    // This thread's output elements are known up front, so the epilogue's operands (bias, saved activation,
+    // accumulate-into value, ...) are fetched NOW and their latency overlaps the operand stream.  The epilogue
+    // kind only selects up to four SLOT descriptors (base, row stride, column stride, offset, column window) in
+    // scalar code; the loads themselves are generic and branch-free (a lane outside its window reads the slot's
+    // base address and the value is discarded), so nothing waits on them before the epilogue.
+    const float* sp[4] = {nullptr, nullptr, nullptr, nullptr};
+    int srs[4] = {0, 0, 0, 0}, scs[4] = {1, 1, 1, 1}, sof[4] = {0, 0, 0, 0}, slo[4] = {0, 0, 0, 0}, shi[4] = {Cn, Cn, Cn, Cn};
+    switch (epi) {
+    case EPI_FWD: sp[0] = pbias; break;
+    case EPI_DX:
+        if (act != ACT_NONE) { sp[0] = paux; srs[0] = ldaux; }
+        if (flags & FLAG_ACCUM) { sp[1] = pC; srs[1] = ldc; }
+        if (pr1u) { sp[2] = pr1u; srs[2] = 1; scs[2] = 0; sp[3] = pr1v; }
+        break;
+    case EPI_FWD_MSE:
+        sp[0] = pbias;
+        sp[1] = t.x0; srs[1] = t.ldx0; shi[1] = n0;
+        sp[2] = t.x1; srs[2] = 1; scs[2] = 0; slo[2] = n0;
+        break;
+    case EPI_FWD_POLICY:
+        sp[0] = pbias;
+        sp[1] = t.x2; srs[1] = n0; shi[1] = n0;
+        break;
+    case EPI_DX_POLICYBWD:
+        sp[0] = t.x0; srs[0] = 2 * n0; sof[0] = n0;
+        sp[1] = t.x2; srs[1] = n0;
+        sp[2] = t.x1; srs[2] = t.ldx1;
+        break;
+    case EPI_DX_REPARAM:
+        sp[0] = t.aux3; srs[0] = t.ldaux3;
+        sp[1] = pC; srs[1] = ldc;
+        sp[2] = pC; srs[2] = ldc; sof[2] = t.F;
+        break;
+    default:
+        if (flags & FLAG_ACCUM) { sp[1] = pC; srs[1] = ldc; }
+    }
     const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
     const int r = r0 + (ol >> 4) * 4 + oreg;
-    float e0[NF], cold[NF], cold2[NF];
+    // The loads are volatile inline asm: as plain C++ loads hipcc sinks them below the reduction barrier, next to
+    // their first use (a serialised L2 round trip in the epilogue).  The compiler does not count asm loads in its
+    // vmcnt bookkeeping; they are OLDER than every operand load of the main loop and vmcnt retires in order, so the
+    // compiler's own counted waits stay correct, and the values are claimed by the explicit wait after the loop.
+    float ev[4][NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        e0[f] = cold[f] = cold2[f] = 0.f;
-        const int c = c0 + 16 * f + (ol & 15);
-        if (r >= t.R || c >= t.Cn) continue;
-        float* cp = t.C + (size_t)r * t.ldc + c;
-        if (t.epi == EPI_FWD) { if (t.bias) e0[f] = t.bias[c]; }
-        else if (t.epi == EPI_DX) {
-            if (t.act != ACT_NONE) e0[f] = t.aux[(size_t)r * t.ldaux + c];
-            if (t.flags & FLAG_ACCUM) cold[f] = *cp;
-            if (t.r1u) cold2[f] = t.r1u[r] * t.r1v[c];
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ev[q][f] = 0.f;
+        if (sp[q]) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int c = c0 + 16 * f + (ol & 15);
+                const bool ok = (r < R) && (c >= slo[q]) && (c < shi[q]);
+                const float* p = sp[q] + (ok ? (size_t)r * srs[q] + (size_t)(c * scs[q] + sof[q]) : (size_t)0);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(ev[q][f]) : "v"(p));
+            }
         }
-        else if (t.epi == EPI_FWD_MSE) { e0[f] = t.bias[c]; cold[f] = (c < t.n0) ? t.x0[(size_t)r * t.ldx0 + c] : t.x1[r]; }
-        else if (t.epi == EPI_FWD_POLICY) { e0[f] = t.bias[c]; if (c < t.n0 && t.x2) cold[f] = t.x2[(size_t)r * t.n0 + c]; }
-        else if (t.epi == EPI_DX_POLICYBWD) { e0[f] = t.x0[(size_t)r * 2 * t.n0 + t.n0 + c]; cold[f] = t.x2[(size_t)r * t.n0 + c]; cold2[f] = t.x1[(size_t)r * t.ldx1 + c]; }
-        else if (t.epi == EPI_DX_REPARAM) { e0[f] = t.aux3[(size_t)r * t.ldaux3 + c]; cold[f] = *cp; cold2[f] = cp[t.F]; }
-        else if (t.flags & FLAG_ACCUM) cold[f] = *cp;
     }
 
     AdamScal adsc;
-    if (t.epi == EPI_DW && t.ad_p) adsc = t.ad_grp->sc;
+    if (epi == EPI_DW && t.ad_p) adsc = t.ad_grp->sc;
 
-    // wave w owns the 16-wide inner chunks w, w+4, w+8, ...; four chunks (all of K <= 256) are loaded
-    // back to back before the first MFMA so that their L2 latencies overlap
+    // wave w owns the 16-wide inner chunks w, w+4, w+8, ...
     for (int kb = w * 16; kb < K; kb += 256) {
-        float a[4][4], b[4][NF][4];
+        const int k0 = kb + 4 * kq;
+        const int nu = (K - kb + 63) >> 6;           // chunks of this group that touch the matrix (uniform per wave)
+        if (nu >= 4) mac_group<LA, LB, NF, VA, VB, 4>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        else if (nu == 1) mac_group<LA, LB, NF, VA, VB, 1>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        else if (nu == 2) mac_group<LA, LB, NF, VA, VB, 2>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        else mac_group<LA, LB, NF, VA, VB, 3>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+    }
+
+    // claim the epilogue operands (long since arrived: the operand stream behind them has been consumed) and
+    // discard what out-of-window lanes fetched
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            load_raw<LA, VA>(t.A, t.lda, r0, t.R, i, kb + 64 * u + 4 * kq, K, a[u]);
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) load_raw<LB, VB>(t.B, t.ldb, c0 + 16 * f, t.Cn, i, kb + 64 * u + 4 * kq, K, b[u][f]);
-        }
-        // every load of the group is issued before anything consumes one (hipcc otherwise sinks each load next to
-        // its MFMA and drains vmcnt(0) in between: eight serialised L2 round trips instead of one)
-        __builtin_amdgcn_sched_barrier(0);
+        for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ev[q][f]));
+    float e0[NF], cold[NF], cold2[NF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            mask_frag(r0, t.R, i, kb + 64 * u + 4 * kq, K, a[u]);
+    for (int f = 0; f < NF; ++f) {
+        const int c = c0 + 16 * f + (ol & 15);
+        float m[4];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) mask_frag(c0 + 16 * f, t.Cn, i, kb + 64 * u + 4 * kq, K, b[u][f]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][f][s], acc[f], 0, 0, 0);
-            if (want_bias) asum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
-        }
+        for (int q = 0; q < 4; ++q) m[q] = ((r < R) && (c >= slo[q]) && (c < shi[q])) ? ev[q][f] : 0.f;
+        e0[f] = m[0];
+        cold[f] = (epi == EPI_FWD_MSE) ? m[1] + m[2] : m[1];
+        cold2[f] = (epi == EPI_DX) ? m[2] * m[3] : m[2];
     }
 
     // cross-wave reduction in fixed order
@@ -143,24 +217,24 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     }
     __syncthreads();
 
-    if (want_bias && threadIdx.x < 16 && r0 + (int)threadIdx.x < t.R) {
+    if (want_bias && threadIdx.x < 16 && r0 + (int)threadIdx.x < R) {
         const int q = threadIdx.x;
         const float gbv = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
-        t.out2[r0 + q] = gbv;
+        pout2[r0 + q] = gbv;
         if (t.ad_pb) adam_elem(adsc, gbv, t.ad_pb + r0 + q, t.ad_mb + r0 + q, t.ad_vb + r0 + q, t.ad_tb ? t.ad_tb + r0 + q : nullptr);
     }
 
-    if (t.epi == EPI_FWD_MSE) {
+    if (epi == EPI_FWD_MSE) {
         // decoder heads of the vlsac ELBO (vlsac_agent.py:137-140): the gradient of 0.5*mse replaces the prediction
         float es = 0.f, er = 0.f;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const int c = c0 + 16 * f + (ol & 15);
-            if (r >= t.R || c >= t.Cn) continue;
-            const float v = (((red[0][f][oreg][ol] + red[1][f][oreg][ol]) + red[2][f][oreg][ol]) + red[3][f][oreg][ol]) * t.scale;
+            if (r >= R || c >= Cn) continue;
+            const float v = (((red[0][f][oreg][ol] + red[1][f][oreg][ol]) + red[2][f][oreg][ol]) + red[3][f][oreg][ol]) * scale;
             const float d = (v + e0[f]) - cold[f];
-            float* cp = t.C + (size_t)r * t.ldc + c;
-            if (c < t.n0) { es += d * d; *cp = d * t.s0; } else { er += d * d; *cp = d * t.s1; }
+            float* cp = pC + (size_t)r * ldc + c;
+            if (c < n0) { es += d * d; *cp = d * t.s0; } else { er += d * d; *cp = d * t.s1; }
         }
         es = wave_sum(es); er = wave_sum(er);
         __syncthreads();
@@ -172,19 +246,19 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         }
         return;
     }
-    if (t.epi == EPI_FWD_POLICY) {
+    if (epi == EPI_FWD_POLICY) {
         // (NF == 1 launches only) the whole [mu | rho] row sits in this one 16-column tile: rho_j is A lanes to the right
-        const int A = t.n0;
+        const int A = n0;
         const int c = c0 + (ol & 15);
-        const bool inb = (r < t.R) && (c < t.Cn);
+        const bool inb = (r < R) && (c < Cn);
         float lp = 0.f;
         if (inb) {
-            const float v = (((red[0][0][oreg][ol] + red[1][0][oreg][ol]) + red[2][0][oreg][ol]) + red[3][0][oreg][ol]) * t.scale;
+            const float v = (((red[0][0][oreg][ol] + red[1][0][oreg][ol]) + red[2][0][oreg][ol]) + red[3][0][oreg][ol]) * scale;
             const float x0v = v + e0[0];
-            t.C[(size_t)r * t.ldc + c] = x0v;
+            pC[(size_t)r * ldc + c] = x0v;
             if (c < A) {
                 const int pl = ol + A;
-                const float rho = (((red[0][0][oreg][pl] + red[1][0][oreg][pl]) + red[2][0][oreg][pl]) + red[3][0][oreg][pl]) * t.scale + t.bias[c + A];
+                const float rho = (((red[0][0][oreg][pl] + red[1][0][oreg][pl]) + red[2][0][oreg][pl]) + red[3][0][oreg][pl]) * scale + pbias[c + A];
                 const float tt = tanhf(rho);
                 const float l = -5.f + 3.5f * (tt + 1.f);
                 const float sg = expf(l);
@@ -202,17 +276,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int c = c0 + 16 * f + (ol & 15);
-        if (r >= t.R || c >= t.Cn) continue;
-        const float v = (((red[0][f][oreg][ol] + red[1][f][oreg][ol]) + red[2][f][oreg][ol]) + red[3][f][oreg][ol]) * t.scale;
-        float* cp = t.C + (size_t)r * t.ldc + c;
-        switch (t.epi) {
+        if (r >= R || c >= Cn) continue;
+        const float v = (((red[0][f][oreg][ol] + red[1][f][oreg][ol]) + red[2][f][oreg][ol]) + red[3][f][oreg][ol]) * scale;
+        float* cp = pC + (size_t)r * ldc + c;
+        switch (epi) {
         case EPI_FWD: {
             const float x = v + e0[f];
             float y;
-            switch (t.act) {
+            switch (act) {
             case ACT_RELU: y = fmaxf(x, 0.f); break;
             case ACT_ELU: y = elu_f(x); break;
-            case ACT_SIN: y = sinf(x); t.out2[(size_t)r * t.ldout2 + c] = x; break;
+            case ACT_SIN: y = sinf(x); pout2[(size_t)r * ldout2 + c] = x; break;
             case ACT_TANH: y = tanhf(x); break;
             default: y = x;
             }
@@ -220,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         } break;
         case EPI_DX: {
             float g = v + cold2[f];
-            switch (t.act) {
+            switch (act) {
             case ACT_RELU: g = e0[f] > 0.f ? g : 0.f; break;
             case ACT_ELU: g *= elu_grad_from_out(e0[f]); break;
             case ACT_SIN: g *= cosf(e0[f]); break;
@@ -231,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         } break;
         case EPI_DX_POLICYBWD: {
             // v = dL/da_c from the critic path; e0 = rho, cold = eps, cold2 = a = tanh(x)
-            const int A = t.n0;
+            const int A = n0;
             const float g = (float)exp(t.dptr[0]) * t.s0;            // dL/dlogpi = alpha / B
             const float tt = tanhf(e0[f]);
             const float sg = expf(-5.f + 3.5f * (tt + 1.f));
@@ -250,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
             const float g = cold[f] + v;
             *cp = g;
             if (t.ad_p) {
-                const size_t o = (size_t)r * t.ldc + c;
+                const size_t o = (size_t)r * ldc + c;
                 adam_elem(adsc, g, t.ad_p + o, t.ad_m + o, t.ad_v + o, t.ad_t ? t.ad_t + o : nullptr);
             }
         } break;

@@ -77,7 +77,6 @@ struct NcFwdTask {
     float* Hm;                       // [B, H]
     float* U;                        // [B*N, H] elu outputs (nullptr: not stored)
     float* sigma_out;                // [B, F] exp(clamp(log_std)) (nullptr: not stored)
-    int dbg;                         // timing experiments only: 1 skip U store, 2 skip table staging, 4 skip MFMA loop, 8 skip elu
     int B, F, H, N;
     int tiles_h, tile_base, ntiles;
 };
@@ -107,7 +106,6 @@ struct NcDxTask {
     float* G; int ldg;               // out [B, 2F]: (dmean | dlog_std)
     int B, F, H, N, nheads;
     int tiles_k, tile_base, ntiles;
-    int dbg;                         // timing experiments only: 1 skip MFMA, 2 skip U/GH staging, 4 skip W loads, 8 skip barrier
 };
 
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f) acc[g][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kb = 0; kb < ((t.dbg & 4) ? 16 : Fp); kb += 16) {
+    for (int kb = 0; kb < Fp; kb += 16) {
         const int k0 = kb + 4 * kq;
         {   // prefetch the next W fragment
             const int k1 = k0 + 16;
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = (t.dbg & 8) ? acc[g][f][r] + bj : elu_f(acc[g][f][r] + bj);
+                const float y = elu_f(acc[g][f][r] + bj);
                 sum += y;
-                if (t.U && !(t.dbg & 1)) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
+                if (t.U) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
             }
         t.Hm[(size_t)b * H + col] = sum * invN;
     }
@@ -180,13 +180,10 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
 #define NCDX_RING 4
 #define NCDX_ALD 20          // LDS row stride of the A tile in floats (16 + 4 pad, keeps 16-byte alignment)
 
+template <bool VEC>
 __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
     __shared__ __attribute__((aligned(16))) float a_s[NCDX_RING][2][80 * NCDX_ALD];   // 51 KB
     __shared__ float red[4][NC_NF][4][64];                                            // 20 KB: head-1 partial accumulators
-#ifdef NCDX_PAD_LDS
-    __shared__ float pad_one_wg_per_cu[NCDX_PAD_LDS];    // experiment: > 80 KB total LDS forbids two workgroups per CU
-    if (t.B < 0) pad_one_wg_per_cu[threadIdx.x] = 0.f;
-#endif
     // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2).  The tiles_k column tiles of one
     // batch tile read the SAME rows of U, so they are given the same (blockIdx % 8) whenever the grid allows.
     int bid = blockIdx.x;
@@ -197,7 +194,6 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
             bid = ((y / t.tiles_k) * 8 + x) * t.tiles_k + (y % t.tiles_k);
         }
     }
-    if (t.dbg & 16) return;
     const int tb = bid / t.tiles_k, tk = bid - tb * t.tiles_k;
     const int b0 = tb * 4, kc0 = tk * 64;
     const int F = t.F, H = t.H, N = t.N;
@@ -209,62 +205,108 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
     const int kcol = kc0 + 16 * w + m16;
     const bool colok = kcol < F;
     const float invN = 1.0f / (float)N;
-    const bool vecG = ((H & 3) == 0) && ((t.ldgh & 3) == 0);
     const int T = (H + 15) / 16;                                  // inner steps per head
 
     // ---- loader role: element q of the step's 2 x [80 x 16] tile = (head, row, 4-wide j group) ----
-    // q in [0, 640): thread tid owns q = tid and (tid < 128) q = 512 + tid
+    // q in [0, 640): thread tid owns q = tid and (tid < 128) q = 512 + tid.  All loads are BRANCH-FREE: rows / heads /
+    // inner indices outside the problem are clamped to a valid address and the value is zeroed when it is written to
+    // LDS (conditional loads compile to s_cbranch_execz + s_waitcnt vmcnt(0) per load: 359 branches and 21 full
+    // drains in the previous build of this kernel).
     struct LReg { float u[4]; float g[4]; };
-    auto lq = [&](int q, int& hh, int& row, int& jq) { hh = q / 320; const int e = q - hh * 320; row = e >> 2; jq = e & 3; };
-    auto lload = [&](int q, int step, LReg& r) {
-        int hh, row, jq; lq(q, hh, row, jq);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { r.u[s] = 1.f; r.g[s] = 0.f; }
-        if (hh >= t.nheads) return;
-        const int lb = row / 20, n = row - lb * 20, b = b0 + lb, j0 = step * 16 + 4 * jq;
-        if (b >= t.B || j0 >= H) return;
-        const int valid = min(4, H - j0);
-        ld4(t.U[hh] + ((size_t)b * N + n) * H + j0, vecG, valid, r.u);
-        ld4(t.GH[hh] + (size_t)b * t.ldgh + j0, vecG, valid, r.g);
+    struct LSrc { const float* up; const float* gp; int jq; int lofs; bool ok; };
+    auto lsrc = [&](int q) {
+        LSrc o;
+        const int hh = q / 320, e = q - hh * 320, row = e >> 2;
+        o.jq = e & 3;
+        const int hc = min(hh, t.nheads - 1);
+        const int lb = row / 20, n = row - lb * 20;
+        const int b = min(b0 + lb, t.B - 1);
+        o.up = (hc ? t.U[1] : t.U[0]) + ((size_t)b * N + n) * H;
+        o.gp = (hc ? t.GH[1] : t.GH[0]) + (size_t)b * t.ldgh;
+        o.lofs = hh * (80 * NCDX_ALD) + row * NCDX_ALD + 4 * o.jq;
+        o.ok = (hh < t.nheads) && (b0 + lb < t.B);
+        return o;
     };
-    auto lwrite = [&](int q, int step, const LReg& r) {
-        int hh, row, jq; lq(q, hh, row, jq);
+    const LSrc sa = lsrc(tid), sb = lsrc(512 + (tid & 127));
+    auto lload = [&](const LSrc& src, int step, LReg& r) {
+        const int j0 = step * 16 + 4 * src.jq;
+        if (VEC) {
+            const int jc = min(j0, H - 4);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(src.up + jc);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(src.gp + jc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { r.u[s] = u[s]; r.g[s] = g[s]; }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { const int jc = min(j0 + s, H - 1); r.u[s] = src.up[jc]; r.g[s] = src.gp[jc]; }
+        }
+    };
+    auto lwrite = [&](const LSrc& src, int step, const LReg& r) {
+        const int j0 = step * 16 + 4 * src.jq;
+        // clamped loads returned finite in-matrix values, so out-of-range elements are removed by a zero SCALE (a
+        // select on the whole expression is compiled into control flow around it)
         f32x4 v;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = r.g[s] * invN * elu_grad_from_out(r.u[s]);
-        *reinterpret_cast<f32x4*>(&a_s[step % NCDX_RING][hh][row * NCDX_ALD + 4 * jq]) = v;
+        for (int s = 0; s < 4; ++s) {
+            const float m = (src.ok && j0 + (VEC ? 0 : s) < H) ? invN : 0.f;
+            const float u = r.u[s];
+            v[s] = (r.g[s] * m) * fminf(u + 1.f, 1.f);          // elu'(out) = out > 0 ? 1 : out + 1 = min(out + 1, 1)
+        }
+        *reinterpret_cast<f32x4*>(&a_s[step % NCDX_RING][0][src.lofs]) = v;
     };
     const bool two = tid < 128;
     LReg ra0, rb0, ra1, rb1;                                      // two register sets x (first, second element); named, never
                                                                   // runtime-indexed (a runtime index would put them in scratch)
-    // prologue: steps 0 and 1 staged synchronously, step 2 in flight in register set 0
-    for (int s0 = 0; s0 < 2 && s0 < T; ++s0) {
-        lload(tid, s0, ra0); if (two) lload(512 + tid, s0, rb0);
-        lwrite(tid, s0, ra0); if (two) lwrite(512 + tid, s0, rb0);
-    }
-    if (2 < T) { lload(tid, 2, ra0); if (two) lload(512 + tid, 2, rb0); }
-    __syncthreads();
-
-    f32x4 acc[NC_NF];
-#pragma unroll
-    for (int f = 0; f < NC_NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* W = t.W[h] + (colok ? kcol : 0);
     const unsigned Fu = (unsigned)F;
     float wv[4], wn[4];
     auto wload = [&](int step, float (&o)[4]) {
         const int j0 = step * 16 + 4 * kq;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) o[s] = (consumer && colok && j0 + s < H) ? W[(unsigned)(j0 + s) * Fu] : 0.f;
+        for (int s = 0; s < 4; ++s) o[s] = W[(unsigned)min(j0 + s, H - 1) * Fu];
     };
+    auto wmask = [&](int step, float (&o)[4]) {
+        const int j0 = step * 16 + 4 * kq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[s] = (consumer && colok && j0 + s < H) ? o[s] : 0.f;
+    };
+    // epilogue operands (this lane's noise column and log-std), fetched now as volatile asm loads so that hipcc cannot
+    // sink them below the final barrier; they are older than every load of the pipeline below and vmcnt retires in
+    // order, so the compiler's counted waits stay valid; claimed by the explicit wait before the epilogue
+    float nzv[20], lsv;
+    {
+        const int kc = colok ? kcol : 0;
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
+            const float* p = t.noise + (size_t)min(q, N - 1) * F + kc;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(nzv[q]) : "v"(p));
+        }
+        const float* p = t.lstd + (size_t)min(b0 + (lane >> 4), t.B - 1) * t.ld_l + kc;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lsv) : "v"(p));
+    }
+    // prologue: steps 0 and 1 are fetched together (one round trip), staged, and step 2 is left in flight in set 0
+    lload(sa, 0, ra0); if (two) lload(sb, 0, rb0);
+    if (1 < T) { lload(sa, 1, ra1); if (two) lload(sb, 1, rb1); }
     wload(0, wv);
+    __builtin_amdgcn_sched_barrier(0);
+    lwrite(sa, 0, ra0); if (two) lwrite(sb, 0, rb0);
+    if (1 < T) { lwrite(sa, 1, ra1); if (two) lwrite(sb, 1, rb1); }
+    if (2 < T) { lload(sa, 2, ra0); if (two) lload(sb, 2, rb0); }
+    wmask(0, wv);
+    __syncthreads();
+
+    f32x4 acc[NC_NF];
+#pragma unroll
+    for (int f = 0; f < NC_NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // one inner step; (an, bn) = register set that receives step+3, (ao, bo) = set holding step+2
     auto iter = [&](int step, LReg& an, LReg& bn, LReg& ao, LReg& bo) {
         const int ls = step + 3;
         // program order matters: vmcnt retires in order, so the W fragment (needed at the END of this iteration) is
         // issued BEFORE the U/GH loads (needed an iteration later); waiting for W then leaves the U loads in flight
-        if (step + 1 < T && !(t.dbg & 4)) wload(step + 1, wn);
-        if (ls < T && !(t.dbg & 2)) { lload(tid, ls, an); if (two) lload(512 + tid, ls, bn); }
+        if (step + 1 < T) wload(step + 1, wn);
+        if (ls < T) { lload(sa, ls, an); if (two) lload(sb, ls, bn); }
+        __builtin_amdgcn_sched_barrier(0);
         if (consumer) {
             const float* as = &a_s[step % NCDX_RING][h][0];
             f32x4 a4[NC_NF];
@@ -273,28 +315,32 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int f = 0; f < NC_NF; ++f) {
-                    if (t.dbg & 1) acc[f][s] += a4[f][s] * wv[s];
-                    else acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[f][s], wv[s], acc[f], 0, 0, 0);
-                }
+                for (int f = 0; f < NC_NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[f][s], wv[s], acc[f], 0, 0, 0);
         }
+        if (step + 1 < T) {
+            wmask(step + 1, wn);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wv[s] = wn[s];
-        if (step + 2 < T && !(t.dbg & 2)) { lwrite(tid, step + 2, ao); if (two) lwrite(512 + tid, step + 2, bo); }
-        if (!(t.dbg & 8)) __syncthreads();
+            for (int s = 0; s < 4; ++s) wv[s] = wn[s];
+        }
+        if (step + 2 < T) { lwrite(sa, step + 2, ao); if (two) lwrite(sb, step + 2, bo); }
+        __syncthreads();
     };
-    for (int step = 0; step < ((t.dbg & 64) ? 0 : T); step += 2) {
+    for (int step = 0; step < T; step += 2) {
         iter(step, ra1, rb1, ra0, rb0);                            // step even: step+2 sits in set 0, step+3 goes to set 1
         if (step + 1 < T) iter(step + 1, ra0, rb0, ra1, rb1);
     }
 
-    if (t.dbg & 32) { if (acc[0][0] == 123.456f) t.G[0] = 1.f; return; }
-    if (w8 >= 4 && t.nheads > 1) {
+    // head-1 partial sums travel through LDS (with one head, waves 4-7 never issued an MFMA: they deposit zeros)
+    if (w8 >= 4) {
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[w][f][r][lane] = acc[f][r];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // claim the epilogue operands fetched in the prologue
+#pragma unroll
+    for (int q = 0; q < 20; ++q) asm volatile("" : "+v"(nzv[q]));
+    asm volatile("" : "+v"(lsv));
     __syncthreads();
     if (w8 >= 4 || !colok) return;
     const int bo = b0 + (lane >> 4);
@@ -304,13 +350,12 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
     for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = acc[f][r] + (t.nheads > 1 ? red[w][f][r][lane] : 0.f);
+            const float v = acc[f][r] + red[w][f][r][lane];
             dmu += v;
-            dls = fmaf(v, t.noise[(size_t)(4 * f + r) * F + kcol], dls);
+            dls = fmaf(v, nzv[4 * f + r], dls);
         }
-    const float l = t.lstd[(size_t)bo * t.ld_l + kcol];
     t.G[(size_t)bo * t.ldg + kcol] = dmu;
-    t.G[(size_t)bo * t.ldg + F + kcol] = dls * expf(clamp_lstd(l)) * lstd_mask(l);
+    t.G[(size_t)bo * t.ldg + F + kcol] = dls * expf(clamp_lstd(lsv)) * lstd_mask(lsv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -453,7 +498,11 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
 
 extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
     if (t->ntiles <= 0) return 0;
-    hipLaunchKernelGGL(nc_dx_kernel, dim3(t->ntiles), dim3(512), 0, st, *t);
+    // 16-byte loads of U / GH rows need 4-float-aligned rows in every head
+    bool vec = ((t->H & 3) == 0) && ((t->ldgh & 3) == 0);
+    for (int h = 0; h < t->nheads; ++h) vec = vec && ((((uintptr_t)t->U[h]) | ((uintptr_t)t->GH[h])) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(nc_dx_kernel<true>, dim3(t->ntiles), dim3(512), 0, st, *t);
+    else hipLaunchKernelGGL(nc_dx_kernel<false>, dim3(t->ntiles), dim3(512), 0, st, *t);
     return (int)hipGetLastError();
 }
 
