@@ -646,6 +646,7 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
     if (e == hipSuccess) e = hipMemsetAsync(ag->metrics, 0, sizeof(float) * M_COUNT, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { rl_set_error("create: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    if (rl_nc_init() != 0) { rl_set_error("create: cannot reserve LDS for the noise-critic kernels"); return RLREP_ERR_HIP; }
     int rc = build_programs(ag.get(), dims->max_batch);
     if (rc != 0) return rc;
     *out = ag.release();

@@ -364,12 +364,24 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
 // workgroup = 8 waves sharing one 16(j) x 32(k) output tile; the 20*B inner rows are dealt to the waves in
 // chunks of 16 rows (lane group kq takes 4 consecutive rows = one batch row b, four noise rows);
 // partial tiles are summed through LDS in fixed wave order.
+//
+// Only U is streamed (4 dword loads per lane and chunk).  Everything indexed by the batch row alone -- the tile's 32
+// columns of mean and sigma, its 16 columns of GH/N -- is staged ONCE per block of NCDW_BB batch rows in LDS
+// (row strides 80 / 16 floats: the two batch rows a chunk can touch fall on disjoint banks).  That takes the loads in
+// flight per group of four chunks from 36 to 16, so that THREE groups (48 < the 63 the vmcnt counter can track)
+// are in flight behind the group being multiplied, in four named register sets: 3 x 1024 MFMA cycles x 2 waves per
+// SIMD cover the L2/MALL latency of U.  (The previous version kept one group ahead, copied it with `cur = nxt` --
+// a full vmcnt(0) drain per iteration -- and ran at 32 us for 11 us of MFMA work.)
 // ------------------------------------------------------------------------------------------------
+#define NCDW_BB 256          // batch rows per staged block
+#define NCDW_TLD 80          // [mean 32 | sigma 32 | pad 16]
 __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
     __shared__ float red[8][2][4][64];          // 16 KB
     __shared__ float bsum[8][16];
     constexpr int NZLD = 36;                    // 4 rows apart -> 16 banks apart: the four kq lane groups do not collide
     __shared__ float nz_s[32 * NZLD];           // noise[n][32 cols of this tile]
+    float* tab_s = nc_smem;                     // [NCDW_BB][NCDW_TLD]
+    float* gh_s = nc_smem + NCDW_BB * NCDW_TLD; // [NCDW_BB][16]   (already scaled by 1/N)
     const int bid = blockIdx.x;
     const int ti = (nb.ntasks > 1 && bid >= nb.t[1].tile_base) ? 1 : 0;
     const NcDwTask& t = nb.t[ti];
@@ -383,74 +395,144 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
     }
     const int tj = local / t.tiles_k, tk = local - tj * t.tiles_k;
     const int j0 = tj * 16, k0 = tk * 32;
-    const int F = t.F, H = t.H, N = t.N;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int F = t.F, H = t.H, B = t.B;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int j = j0 + i;
     const bool jok = j < H;
-    const int kc[2] = {k0 + i, k0 + 16 + i};
-    const bool kok[2] = {kc[0] < F, kc[1] < F};
-    const int M = N * t.B;                       // inner length
-    const float invN = 1.0f / (float)N;
+    const float invN = 1.0f / (float)(4 * NC_NF);
     const bool want_bias = (tk == 0);
 
     AdamScal adsc;
     if (t.ad_p) { adsc = t.ad_grp->sc; adsc.tau = 0.f; }
-    for (int e = threadIdx.x; e < N * 32; e += 512) {
+    for (int e = tid; e < 4 * NC_NF * 32; e += 512) {
         const int n = e >> 5, c = e & 31;
-        nz_s[n * NZLD + c] = (k0 + c < F) ? t.noise[(size_t)n * F + k0 + c] : 0.f;
+        nz_s[n * NZLD + c] = t.noise[(size_t)n * F + min(k0 + c, F - 1)];      // columns past F are never stored
     }
-    __syncthreads();
 
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     float asum = 0.f;
-    // operands of one 16-row inner chunk, per lane
-    struct Chunk { float u[4]; float gh; float mu[2], sg[2]; int n0; };
     const float* Uj = t.U + (jok ? j : 0);
-    const float* GHj = t.GH + (jok ? j : 0);
-    const float* MUk[2] = {t.mean + (kok[0] ? kc[0] : 0), t.mean + (kok[1] ? kc[1] : 0)};
-    const float* SGk[2] = {t.sigma + (kok[0] ? kc[0] : 0), t.sigma + (kok[1] ? kc[1] : 0)};
-    const unsigned Nu = (unsigned)N, Hu = (unsigned)H, Fu = (unsigned)F, ldg = (unsigned)t.ldgh, ldm = (unsigned)t.ld_ml;
-    auto load = [&](int c, Chunk& q) {
-        const unsigned r0 = 16u * (unsigned)c + 4u * (unsigned)kq;     // first of this lane's 4 inner rows
-        const bool ok = r0 < (unsigned)M;                              // M is a multiple of 4
-        const unsigned b = ok ? r0 / Nu : 0u;
-        q.n0 = ok ? (int)(r0 - b * Nu) : 0;
-        q.gh = (ok && jok) ? GHj[b * ldg] * invN : 0.f;
-        const float* up = Uj + (ok ? r0 * Hu : 0u);
+    const unsigned Hu = (unsigned)H;
+    struct Chunk { float u[4]; };
+    // 16-byte table loads when the whole tile is inside the matrices and rows are 4-float aligned (uniform)
+    const bool vecT = (k0 + 32 <= F) && (j0 + 16 <= H) && (((F | H | t.ld_ml | t.ldgh) & 3) == 0) &&
+                      (((((uintptr_t)t.mean) | ((uintptr_t)t.sigma) | ((uintptr_t)t.GH)) & 15) == 0);
+
+    for (int bb0 = 0; bb0 < B; bb0 += NCDW_BB) {
+        const int nb_rows = min(NCDW_BB, B - bb0);
+        const int Mb = 4 * NC_NF * nb_rows;                    // inner rows of this block (a multiple of 4)
+        const float* Ub = Uj + (size_t)bb0 * (4 * NC_NF) * Hu;
+        // BRANCH-FREE fetch: rows past the block are clamped to its last 4-row group and contribute gh = 0
+        auto load = [&](int c, Chunk& q) {
+            const unsigned r0 = min(16u * (unsigned)c + 4u * (unsigned)kq, (unsigned)Mb - 4u);
+            const float* up = Ub + r0 * Hu;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) q.u[s] = (ok && jok) ? up[s * Hu] : 1.f;
+            for (int s = 0; s < 4; ++s) q.u[s] = up[s * Hu];
+        };
+        Chunk S0[4], S1[4], S2[4], S3[4];
+        auto loadg = [&](int g, Chunk (&S)[4]) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            q.mu[f] = (ok && kok[f]) ? MUk[f][b * ldm] : 0.f;
-            q.sg[f] = (ok && kok[f]) ? SGk[f][b * Fu] : 0.f;
+            for (int u = 0; u < 4; ++u) load(w + 8 * u + 32 * g, S[u]);
+        };
+        // the first four groups of U go out BEFORE the tables are staged: one combined round trip instead of two
+        loadg(0, S0); loadg(1, S1); loadg(2, S2); loadg(3, S3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (bb0) __syncthreads();                              // the previous block's tables are still being read
+        // ---- stage the block's tables (clamped addresses; whatever lies past F / H / B is multiplied by gh = 0) ----
+#pragma unroll
+        for (int e = tid; e < NCDW_BB * 16; e += 512) {        // 16 float4 per row: 8 mean + 8 sigma
+            const int rb = e >> 4, q = e & 15, c4 = (q & 7) * 4;
+            const int bsrc = bb0 + min(rb, nb_rows - 1);
+            const float* src = (q < 8) ? t.mean + (size_t)bsrc * t.ld_ml : t.sigma + (size_t)bsrc * F;
+            f32x4 v;
+            if (vecT) v = *reinterpret_cast<const f32x4*>(src + k0 + c4);
+            else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] = src[min(k0 + c4 + s, F - 1)];
+            }
+            *reinterpret_cast<f32x4*>(&tab_s[rb * NCDW_TLD + (q < 8 ? 0 : 32) + c4]) = v;
         }
-    };
-    auto compute = [&](const Chunk& q) {
-        float a[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = q.gh * elu_grad_from_out(q.u[s]);
+        for (int e = tid; e < NCDW_BB * 4; e += 512) {         // 4 float4 per row of GH
+            const int rb = e >> 2, c4 = (e & 3) * 4;
+            const bool rok = rb < nb_rows;
+            const float* src = t.GH + (size_t)(bb0 + min(rb, nb_rows - 1)) * t.ldgh;
+            f32x4 v;
+            if (vecT) {
+                v = *reinterpret_cast<const f32x4*>(src + j0 + c4);
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+                for (int s = 0; s < 4; ++s) v[s] *= rok ? invN : 0.f;
+            } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], fmaf(q.sg[f], nz_s[(q.n0 + s) * NZLD + 16 * f + i], q.mu[f]), acc[f], 0, 0, 0);
-        if (want_bias) asum += (a[0] + a[1]) + (a[2] + a[3]);
-    };
-    // wave w takes chunks w, w+8, ...; four of them (32 MFMAs) are in flight ahead of the ones being computed
-    const int nchunks = (M + 15) / 16;
-    Chunk cur[4], nxt[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) load(w + 8 * u, cur[u]);
-    for (int c = w; c < nchunks; c += 32) {
-        if (c + 32 < nchunks) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) load(c + 32 + 8 * u, nxt[u]);
+                for (int s = 0; s < 4; ++s) v[s] = src[min(j0 + c4 + s, H - 1)] * ((rok && j0 + c4 + s < H) ? invN : 0.f);
+            }
+            *reinterpret_cast<f32x4*>(&gh_s[rb * 16 + c4]) = v;
         }
+        __syncthreads();
+
+        // One chunk in two stages: prep() turns the loaded U values and the LDS tables into the 4 A values and 8 B
+        // values of the chunk's MFMAs; mac() issues them.  compg() runs prep(u+1) in the shadow of mac(u): with the LDS
+        // reads issued just in time, every chunk exposed 2-3 LDS latencies per 256 MFMA cycles.
+        struct Prep { float a[4], x0[4], x1[4]; };
+        auto prep = [&](int c, const Chunk& q, Prep& o) {
+            const unsigned r0 = 16u * (unsigned)c + 4u * (unsigned)kq;
+            const bool ok = r0 < (unsigned)Mb;
+            const unsigned rc = ok ? r0 : (unsigned)Mb - 4u;
+            const unsigned lb = rc / 20u, n0 = rc - lb * 20u;
+            const float ghr = gh_s[lb * 16 + i];
+            const float gh = ok ? ghr : 0.f;
+            const float* tb = &tab_s[lb * NCDW_TLD + i];
+            const float mu0 = tb[0], mu1 = tb[16], sg0 = tb[32], sg1 = tb[48];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) compute(cur[u]);
+            for (int s = 0; s < 4; ++s) {
+                const float* nz = &nz_s[(n0 + s) * NZLD + i];
+                o.a[s] = gh * fminf(q.u[s] + 1.f, 1.f);          // elu'(out) = min(out + 1, 1)
+                o.x0[s] = fmaf(sg0, nz[0], mu0);
+                o.x1[s] = fmaf(sg1, nz[16], mu1);
+            }
+        };
+        auto mac = [&](const Prep& o) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[s], o.x0[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[s], o.x1[s], acc[1], 0, 0, 0);
+            }
+            if (want_bias) asum += (o.a[0] + o.a[1]) + (o.a[2] + o.a[3]);
+        };
+        // wave w takes chunks w, w+8, ... in GROUPS of four (32 MFMAs); named sets, never copied
+        const int nchunks = (Mb + 15) / 16;
+        const int ngroups = (nchunks + 31) / 32;
+        auto compg = [&](int g, const Chunk (&S)[4]) {
+            const int c = w + 32 * g;
+            Prep p0, p1;
+            prep(c, S[0], p0);
+            __builtin_amdgcn_sched_barrier(0);
+            prep(c + 8, S[1], p1); mac(p0);
+            __builtin_amdgcn_sched_barrier(0);
+            prep(c + 16, S[2], p0); mac(p1);
+            __builtin_amdgcn_sched_barrier(0);
+            prep(c + 24, S[3], p1); mac(p0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(p1);
+        };
+        // Issue order is the SAME on every path that loads (the s_waitcnt immediates are static: a load that is issued
+        // on one path only would force the conservative count, i.e. a full drain, on all of them).  Set k is refilled
+        // with group g+4+k right after group g+k has been multiplied; only the last trip issues nothing.
+        for (int g = 0; g < ngroups; g += 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 4 < ngroups) {
+                compg(g, S0);     loadg(g + 4, S0); __builtin_amdgcn_sched_barrier(0);
+                compg(g + 1, S1); loadg(g + 5, S1); __builtin_amdgcn_sched_barrier(0);
+                compg(g + 2, S2); loadg(g + 6, S2); __builtin_amdgcn_sched_barrier(0);
+                compg(g + 3, S3); loadg(g + 7, S3);
+            } else {
+                compg(g, S0);
+                if (g + 1 < ngroups) compg(g + 1, S1);
+                if (g + 2 < ngroups) compg(g + 2, S2);
+                if (g + 3 < ngroups) compg(g + 3, S3);
+            }
+        }
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -487,6 +569,7 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st) {
     if (total_tiles <= 0) return 0;
+    for (int q = 0; q < nb->ntasks; ++q) if (nb->t[q].N != 4 * NC_NF) return -2;      // the row mapping is built for N = 20
     const int F = nb->t[0].F, N = nb->t[0].N;
     const int Fp = (F + 15) & ~15;
     const size_t lds = (size_t)(8 * g2 + N) * (Fp + 16) * sizeof(float);
@@ -498,6 +581,7 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
 
 extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
     if (t->ntiles <= 0) return 0;
+    if (t->N != 4 * NC_NF) return -2;
     // 16-byte loads of U / GH rows need 4-float-aligned rows in every head
     bool vec = ((t->H & 3) == 0) && ((t->ldgh & 3) == 0);
     for (int h = 0; h < t->nheads; ++h) vec = vec && ((((uintptr_t)t->U[h]) | ((uintptr_t)t->GH[h])) & 15) == 0;
@@ -506,8 +590,16 @@ extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// one-time setup (agent creation, never inside a stream capture): nc_dw needs more dynamic LDS than the 64 KB default
+extern "C" int rl_nc_init() {
+    const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);
+    return (int)hipFuncSetAttribute((const void*)nc_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 extern "C" int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    hipLaunchKernelGGL(nc_dw_kernel, dim3(total_tiles), dim3(512), 0, st, *nb);
+    for (int q = 0; q < nb->ntasks; ++q) if (nb->t[q].N != 4 * NC_NF || nb->t[q].B <= 0) return -2;
+    const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);          // 96 KB of staged per-batch-row tables
+    hipLaunchKernelGGL(nc_dw_kernel, dim3(total_tiles), dim3(512), lds, st, *nb);
     return (int)hipGetLastError();
 }
