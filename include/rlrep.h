@@ -16,6 +16,8 @@
  *                                (+ update_feature_target: vlsac :240-242, ctrlsac :253-255, speder :221-223)
  *   rlrep_critic_step         <- critic_step              sac_agent.py:105-135 and per-agent overrides
  *   rlrep_actor_alpha_step    <- update_actor_and_alpha   sac_agent.py:138-166 and per-agent overrides
+ *   rlrep_prefetch_policy     <- (no counterpart: reorders the forward half of update_actor_and_alpha, sac_agent.py:141-150,
+ *                                into critic_step's launches)
  *   rlrep_update_target       <- update_target            sac_agent.py:99-102
  *   rlrep_train               <- train                    sac_agent.py:169-188, vlsac_agent.py:245-273, ...
  *   rlrep_set_batch           <- Batch / unpack_batch     utils/buffer.py:7-10, utils/util.py:10-11
@@ -195,6 +197,14 @@ const int32_t* rlrep_steps_dev(rlrep_agent* agent);
 int32_t rlrep_feature_step(rlrep_agent* agent, const float* eps_dev, const int32_t* noise_idx_dev, void* stream);
 int32_t rlrep_critic_step(rlrep_agent* agent, const float* eps_dev, void* stream);
 int32_t rlrep_actor_alpha_step(rlrep_agent* agent, const float* eps_dev, void* stream);
+/* Optional launch saving for the sequence critic step -> actor step ON THE SAME BATCH (what train() does,
+ * sac_agent.py:180-187): the forward half of update_actor_and_alpha (policy on s, features of (s, a_pi)) reads
+ * nothing critic_step writes, so the library can run it inside the critic step's launches.  Call
+ * rlrep_prefetch_policy(agent, eps_actor) right before rlrep_critic_step / _backward with the noise the actor step
+ * will be given; the following rlrep_actor_alpha_step / _backward called with the SAME eps pointer then resumes after
+ * its forward half.  Returns 1 if armed, 0 if this agent / shape has no such variant (then nothing changes), < 0 on
+ * error.  Any new batch or feature step in between disarms it; results are identical either way. */
+int32_t rlrep_prefetch_policy(rlrep_agent* agent, const float* eps_actor_dev);
 /* Polyak critic -> critic_target iff (steps % target_update_period == 0), steps kept on the device. */
 int32_t rlrep_update_target(rlrep_agent* agent, void* stream);
 /* steps += 1 (device counter; graph-replay safe) */

@@ -89,6 +89,7 @@ def _load():
         'rlrep_fill_normal_dev': (i32, [vp, i64, f32, u64, u64, vp, vp]),
         'rlrep_steps_dev': (vp, [vp]),
         'rlrep_feature_step': (i32, [vp, vp, vp, vp]),
+        'rlrep_prefetch_policy': (i32, [vp, vp]),
         'rlrep_critic_step': (i32, [vp, vp, vp]),
         'rlrep_actor_alpha_step': (i32, [vp, vp, vp]),
         'rlrep_update_target': (i32, [vp, vp]),

@@ -353,6 +353,8 @@ class SACAgent(object):
             self._sample_into(buffer, B, 's0', 0, g)
         self._between_feature_and_critic()
         e1 = self._eps('crit', (B, self.action_dim), g)
+        e2 = self._eps('act', (B, self.action_dim), g)
+        c.prefetch_policy(e2)      # the actor step's forward half rides in the critic step's launches (same batch)
         if W > 1:
             if self._critic_trains():
                 c.critic_backward(e1); self._allreduce(1); c.critic_apply()
@@ -360,7 +362,6 @@ class SACAgent(object):
                 c.critic_step(e1)
         else:
             c.critic_step(e1)
-        e2 = self._eps('act', (B, self.action_dim), g)
         if W > 1:
             c.actor_backward(e2); self._allreduce(2, True); c.actor_apply()
         else:

@@ -189,6 +189,13 @@ class HipCore:
     def feature_apply(self):
         check(lib.rlrep_feature_apply(self.h, _stream()), 'feature_apply')
 
+    def prefetch_policy(self, eps_actor):
+        """Arm the critic step to also run the forward half of the actor step (same batch, noise `eps_actor`)."""
+        rc = lib.rlrep_prefetch_policy(self.h, _ptr(eps_actor))
+        if rc < 0:
+            check(rc, 'prefetch_policy')
+        return rc == 1
+
     def critic_step(self, eps):
         check(lib.rlrep_critic_step(self.h, _ptr(eps), _stream()), 'critic_step')
 

@@ -32,6 +32,7 @@ enum Epi : int {
 #define FLAG_ACCUM 1       // C += value instead of C = value
 #define FLAG_BIASGRAD 2    // EPI_DW: also emit the bias gradient (only by column-tile 0)
 #define FLAG_DYN_EPS 4     // x2 is the per-call noise pointer (patched into the kernel arguments at launch)
+#define FLAG_DYN_EPS2 8    // x2 is the noise pointer of the policy forward that rides along (rlrep_prefetch_policy)
 
 struct GroupCfg;
 struct GemmTask {

@@ -112,8 +112,9 @@ struct Stage { std::function<int(hipStream_t)> run; const char* what; };
 
 struct Program {
     std::vector<Stage> stages;
-    int run(hipStream_t st) const {
-        for (auto& s : stages) {
+    int run(hipStream_t st, size_t first = 0) const {
+        for (size_t q = first; q < stages.size(); ++q) {
+            const Stage& s = stages[q];
             int rc = s.run(st);
             if (rc != 0) { rl_set_error("stage '%s' failed: hip error %d", s.what, rc); return RLREP_ERR_HIP; }
         }

@@ -109,12 +109,18 @@ void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* a
     p.stages.push_back({[=](hipStream_t st) { PolicyFwd q = pf; q.eps = ag->cur_eps; return rl_launch_policy_fwd(&q, st); }, what});
 }
 
-void actor_head_stage(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, std::vector<GemmTask> extra, const char* what) {
-    const int A = ag->d.action_dim;
+// the tanh-Gaussian sampling runs in the head GEMM's epilogue when [mu | rho] fits one 16-column tile
+bool policy_fusable(const rlrep_agent* ag) { return 2 * ag->d.action_dim <= 16 && !getenv("RLREP_NO_FUSE_POLICY"); }
+GemmTask policy_head_task(rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, int dyn_flag) {
     GemmTask head = actor_l(ag, 2, nullptr, 0, ab);
-    if (2 * A <= 16 && !getenv("RLREP_NO_FUSE_POLICY")) {
-        head.epi = EPI_FWD_POLICY; head.n0 = A; head.y0 = act; head.ldx0 = ld_act; head.y1 = ab.logp; head.flags |= FLAG_DYN_EPS;
-        extra.insert(extra.begin(), head);
+    head.epi = EPI_FWD_POLICY; head.n0 = ag->d.action_dim; head.y0 = act; head.ldx0 = ld_act; head.y1 = ab.logp; head.flags |= dyn_flag;
+    return head;
+}
+
+void actor_head_stage(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, std::vector<GemmTask> extra, const char* what) {
+    GemmTask head = actor_l(ag, 2, nullptr, 0, ab);
+    if (policy_fusable(ag)) {
+        extra.insert(extra.begin(), policy_head_task(ag, ab, act, ld_act, FLAG_DYN_EPS));
         b.fwd_stage(p, extra, what);
     } else {
         extra.insert(extra.begin(), head);
@@ -346,9 +352,11 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     }
 
     // ---- critic / actor shared buffers ----
-    ActorBufs ab = alloc_actor(b, B, A, Ha);
+    ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
+    ActorBufs ab_pi = alloc_actor(b, B, A, Ha);                                              // policy on s  (actor step)
     GaussBufs gt{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s, a)
     GaussBufs gn{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s', a')
+    GaussBufs gp{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s, a_pi)
     float* HmT = ws.f((size_t)2 * B * H); float* HmC = ws.f((size_t)2 * B * H);
     float* U = ws.f((size_t)2 * B * N * H);
     float* Et = ws.f((size_t)2 * B * H); float* Ec = ws.f((size_t)2 * B * H);
@@ -388,17 +396,30 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     };
 
     // ---- critic step (vlsac_agent.py:201-237) ----
-    {
-        Program& p = ag->critic_bwd;
-        GemmTask tt[3], tn[3];
+    // hoist = true builds the variant that also carries the forward half of the FOLLOWING actor step (policy on s,
+    // f_target on (s, a_pi)): those GEMMs read nothing the critic update writes, and as extra tasks of launches that
+    // exist anyway they take six launches (~5 us each at B = 256) off the critical path of train().
+    auto critic_program = [&](Program& p, bool hoist) {
+        GemmTask tt[3], tn[3], tp[3];
         gauss_tasks(ag, true, "f_target", s0.XF, SA, SA, gt, tt);
         gauss_tasks(ag, true, "f_target", s0.XF2, SA, SA, gn, tn);
-        b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), tt[0]}, "actor.l1(s') ft.l1(s,a)");
-        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), tt[1]}, "actor.l2 ft.l2");
-        actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {tt[2]}, "actor.head ft.heads + policy");
-        b.fwd_stage(p, {tn[0]}, "ft.l1(s',a')");
-        b.fwd_stage(p, {tn[1]}, "ft.l2");
-        b.fwd_stage(p, {tn[2]}, "ft.heads");
+        gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gp, tp);
+        if (hoist) {
+            b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi), tt[0]}, "actor.l1(s') actor.l1(s) ft.l1(s,a)");
+            b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi), tt[1]}, "actor.l2 x2 ft.l2");
+            b.fwd_stage(p, {policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2), tt[2]},
+                        "actor.head x2 ft.heads + policy");
+            b.fwd_stage(p, {tn[0], tp[0]}, "ft.l1(s',a') ft.l1(s,a_pi)");
+            b.fwd_stage(p, {tn[1], tp[1]}, "ft.l2 x2");
+            b.fwd_stage(p, {tn[2], tp[2]}, "ft.heads x2");
+        } else {
+            b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), tt[0]}, "actor.l1(s') ft.l1(s,a)");
+            b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), tt[1]}, "actor.l2 ft.l2");
+            actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {tt[2]}, "actor.head ft.heads + policy");
+            b.fwd_stage(p, {tn[0]}, "ft.l1(s',a')");
+            b.fwd_stage(p, {tn[1]}, "ft.l2");
+            b.fwd_stage(p, {tn[2]}, "ft.heads");
+        }
         {
             NcFwdTask live1 = nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U);
             live1.sigma_out = SIG;
@@ -446,6 +467,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             const int total = base_tile;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dw(&nb, total, st); }, "noise critic dW l1/l4"});
         }
+    };
+    critic_program(ag->critic_bwd, false);
+    if (policy_fusable(ag) && !getenv("RLREP_NO_HOIST")) critic_program(ag->critic_bwd_h, true);
+    {
         const float ib = 1.0f / (float)B;
         float* m = ag->metrics;
         b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f,
@@ -457,20 +482,21 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     {
         Program& p = ag->actor_bwd;
         GemmTask tt[3];
-        gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gt, tt);
-        b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
-        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
+        gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gp, tt);
+        b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "actor.l1(s)");
+        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab_pi)}, "actor.l2");
+        actor_head_stage(b, p, ag, ab_pi, s0.XFpi + S, SA, {}, "actor.head + policy");
         b.fwd_stage(p, {tt[0]}, "ft.l1(s,a_pi)");
         b.fwd_stage(p, {tt[1]}, "ft.l2");
         b.fwd_stage(p, {tt[2]}, "ft.heads");
-        nc_stage(p, {nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
-                     nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4");
+        ag->actor_resume = (int)p.stages.size();      // everything above is what critic_bwd_h already did
+        nc_stage(p, {nc_task(gp.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
+                     nc_task(gp.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4");
         b.fwd_stage(p, {Builder::fwd(HmC, H, B, H, Pw("critic.l2.weight"), H, Pw("critic.l2.bias"), H, Ec, H, ACT_ELU),
                         Builder::fwd(HmC + BH, H, B, H, Pw("critic.l5.weight"), H, Pw("critic.l5.bias"), H, Ec + BH, H, ACT_ELU)}, "critic l2/l5");
         QHeadActor q; memset(&q, 0, sizeof(q));
         q.Ec[0] = Ec; q.Ec[1] = Ec + BH; q.wc[0] = q.wc[1] = Pw("critic.l3.weight"); q.bc[0] = q.bc[1] = Pw("critic.l3.bias");
-        q.logp = ab.logp; q.alpha_state = ag->a.alpha_state_dev; q.inv_batch = ag->inv_batch(); q.target_entropy = ag->h.target_entropy;
+        q.logp = ab_pi.logp; q.alpha_state = ag->a.alpha_state_dev; q.inv_batch = ag->inv_batch(); q.target_entropy = ag->h.target_entropy;
         q.GE[0] = GE; q.GE[1] = GE + BH; q.partial_loss = part_l; q.partial_c = ag->Gtail();
         q.B = B; q.H = H; q.nblk = nblk; q.step = ag->adam_step + 2;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_actor(&q, st); }, "qhead actor"});
@@ -480,14 +506,14 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             NcDxTask t; memset(&t, 0, sizeof(t));
             t.GH[0] = GHm; t.GH[1] = GHm + BH; t.ldgh = H; t.U[0] = U; t.U[1] = U + BNH;
             t.W[0] = Pw("critic.l1.weight"); t.W[1] = Pw("critic.l4.weight"); t.noise = noise;
-            t.lstd = gt.HH ? gt.HH + F : nullptr; t.ld_l = 2 * F; t.G = GTH; t.ldg = 2 * F;
+            t.lstd = gp.HH ? gp.HH + F : nullptr; t.ld_l = 2 * F; t.G = GTH; t.ldg = 2 * F;
             t.B = B; t.F = F; t.H = H; t.N = N; t.nheads = 2;
             t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 3) / 4) * t.tiles_k; t.tile_base = 0;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(&t, st); }, "noise critic dX -> (dmean, dlog_std)"});
         }
-        b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gt.H2, Hv)}, "ft.heads dx");
-        b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gt.H1, Hv)}, "ft.l2 dx");
-        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0));
+        b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gp.H2, Hv)}, "ft.heads dx");
+        b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gp.H1, Hv)}, "ft.l2 dx");
+        actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
         actor_apply_program(b, ag, part_l, nblk);
     }
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
@@ -499,9 +525,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h})
         p->stages.clear();
-    ag->infer_n = 0;
+    ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr;
     ag->feat_cuts.clear();
     Builder b(ag);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
@@ -667,6 +693,7 @@ static int ensure_batch(rlrep_agent* ag, int B) {
 
 int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, void* stream) {
     if (!ag || !bt || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("set_batch: bad argument"); return RLREP_ERR_ARG; }
+    ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     int rc = ensure_batch(ag, bt->batch);
     if (rc) return rc;
     Slot& s = ag->slot[slot];
@@ -692,6 +719,7 @@ int32_t rlrep_replay_add(rlrep_agent* ag, float* ring_dev, int64_t capacity, int
 
 int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev, const int32_t* idx_dev, int32_t batch, void* stream) {
     if (!ag || !ring_dev || !idx_dev || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("replay_sample: bad argument"); return RLREP_ERR_ARG; }
+    ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;
     Slot& s = ag->slot[slot];
@@ -747,13 +775,28 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (ag->d.alg == RLREP_ALG_DIFFSRSAC && (!eps || !idx)) { rl_set_error("diffsrsac feature step needs noise_idx[B] and eps[B,S]"); return RLREP_ERR_ARG; }
     if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
+    ag->pi_ready = nullptr;                                       // f_target is about to change
     return run(ag, ag->feat_bwd, stream);
 }
 int32_t rlrep_feature_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(true) return run(ag, ag->feat_apply, stream); }
+int32_t rlrep_prefetch_policy(rlrep_agent* ag, const float* eps_actor) {
+    if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
+    ag->hoist_req = nullptr;
+    if (!eps_actor || ag->critic_bwd_h.stages.empty()) return 0;      // not supported for this agent / shape: nothing armed
+    ag->hoist_req = eps_actor;
+    return 1;
+}
 int32_t rlrep_critic_backward(rlrep_agent* ag, const float* eps, void* stream) {
     STEP_PROLOGUE(false)
     if (!eps) { rl_set_error("critic step needs eps[B,A]"); return RLREP_ERR_ARG; }
     ag->cur_eps = eps; ag->last_launches = 0;
+    ag->pi_ready = nullptr;
+    if (ag->hoist_req) {
+        ag->cur_eps2 = ag->hoist_req; ag->hoist_req = nullptr;
+        const int rc = run(ag, ag->critic_bwd_h, stream);
+        if (rc == 0) ag->pi_ready = ag->cur_eps2;
+        return rc;
+    }
     return run(ag, ag->critic_bwd, stream);
 }
 int32_t rlrep_critic_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(false) return run(ag, ag->critic_apply, stream); }
@@ -761,7 +804,12 @@ int32_t rlrep_actor_backward(rlrep_agent* ag, const float* eps, void* stream) {
     STEP_PROLOGUE(false)
     if (!eps) { rl_set_error("actor step needs eps[B,A]"); return RLREP_ERR_ARG; }
     ag->cur_eps = eps; ag->last_launches = 0;
-    return run(ag, ag->actor_bwd, stream);
+    // resume after the forward half iff the critic step of this train() ran it with exactly this noise
+    const size_t first = (ag->pi_ready && ag->pi_ready == eps) ? (size_t)ag->actor_resume : 0;
+    ag->pi_ready = nullptr;
+    if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    ag->last_launches += (int)(ag->actor_bwd.stages.size() - first);
+    return ag->actor_bwd.run((hipStream_t)stream, first);
 }
 int32_t rlrep_actor_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(false) return run(ag, ag->actor_apply, stream); }
 
@@ -800,7 +848,7 @@ int32_t rlrep_feature_backward_part(rlrep_agent* ag, int32_t part, const float* 
     const int ncut = (int)ag->feat_cuts.size();
     if (part < 0 || part > ncut) { rl_set_error("feature_backward_part: part %d of %d", part, ncut + 1); return RLREP_ERR_ARG; }
     if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
-    ag->cur_eps = eps; ag->cur_idx = idx;
+    ag->cur_eps = eps; ag->cur_idx = idx; ag->pi_ready = nullptr;
     const int lo = part == 0 ? 0 : ag->feat_cuts[part - 1].after_stage + 1;
     const int hi = part == ncut ? (int)ag->feat_bwd.stages.size() : ag->feat_cuts[part].after_stage + 1;
     if (part == 0) ag->last_launches = 0;
@@ -852,7 +900,8 @@ int32_t rlrep_actor_forward(rlrep_agent* ag, const float* obs, int32_t n, const 
 static Program* prog_of(rlrep_agent* ag, int id) {
     switch (id) {
     case 0: return &ag->feat_bwd; case 1: return &ag->feat_apply; case 2: return &ag->critic_bwd; case 3: return &ag->critic_apply;
-    case 4: return &ag->actor_bwd; case 5: return &ag->actor_apply; case 6: return &ag->upd_target; default: return nullptr;
+    case 4: return &ag->actor_bwd; case 5: return &ag->actor_apply; case 6: return &ag->upd_target; case 7: return &ag->critic_bwd_h;
+    default: return nullptr;
     }
 }
 int32_t rlrep_stage_count(rlrep_agent* ag, int32_t program) {

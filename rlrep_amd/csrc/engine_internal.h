@@ -14,6 +14,11 @@ struct rlrep_agent {
     // per-call dynamic inputs, read by the by-value parameter blocks at launch time
     const float* cur_eps = nullptr; const int* cur_idx = nullptr;
     Program feat_bwd, feat_apply, critic_bwd, critic_apply, actor_bwd, actor_apply, upd_target, infer, sync_prog;
+    // The forward half of the actor step (policy on s, features of (s, a_pi)) depends on nothing the critic step
+    // changes, so its GEMMs can ride along in the critic step's launches (critic_bwd_h) and the actor step then
+    // resumes at stage actor_resume.  Armed per train() by rlrep_prefetch_policy; see there for the protocol.
+    Program critic_bwd_h; int actor_resume = 0;
+    const float* cur_eps2 = nullptr; const float* hoist_req = nullptr; const float* pi_ready = nullptr;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
@@ -92,12 +97,15 @@ struct Builder {
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         const int total = base_tile;
         bool dyn = false;
-        for (auto& t : tasks) dyn = dyn || (t.flags & FLAG_DYN_EPS);
+        for (auto& t : tasks) dyn = dyn || (t.flags & (FLAG_DYN_EPS | FLAG_DYN_EPS2));
         rlrep_agent* a = ag;
         if (dyn)
             p.stages.push_back({[=](hipStream_t st) {
                 GemmBatch g2 = gb;
-                for (int q = 0; q < g2.ntasks; ++q) if (g2.t[q].flags & FLAG_DYN_EPS) g2.t[q].x2 = a->cur_eps;
+                for (int q = 0; q < g2.ntasks; ++q) {
+                    if (g2.t[q].flags & FLAG_DYN_EPS) g2.t[q].x2 = a->cur_eps;
+                    if (g2.t[q].flags & FLAG_DYN_EPS2) g2.t[q].x2 = a->cur_eps2;
+                }
                 return rl_launch_gemm16(la, lb, nf, &g2, total, st);
             }, what});
         else
@@ -203,6 +211,8 @@ void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* a
 // actor head layer + tanh-Gaussian sampling/log-prob: ONE launch (policy fused into the head GEMM's epilogue) when the
 // [mu|rho] row fits one 16-column tile (2A <= 16), else head launch + policy_fwd_kernel.  `extra` tasks share the launch.
 void actor_head_stage(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, std::vector<GemmTask> extra, const char* what);
+bool policy_fusable(const rlrep_agent* ag);
+GemmTask policy_head_task(rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, int dyn_flag);
 // `action_dx` computes dL/da [B,A] into ab.dA; its epilogue takes over policy_bwd when A <= 16
 void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx, const float* act, int ld_act, GemmTask action_dx);
 void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk);

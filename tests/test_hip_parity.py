@@ -266,3 +266,31 @@ def test_rare_branches_match_oracle():
         P['critic.Q1.0.weight'][:] = 0.0
         P['critic.Q1.0.bias'][:] = 0.0
     _run_vs_oracle(_tweaked_case('sac', kink), trains=1)
+
+
+def test_policy_prefetch_is_equivalent():
+    """rlrep_prefetch_policy only regroups launches: train() with the actor step's forward half riding in the critic
+    step's launches equals train() with the two steps run back to back (and the actor step gets shorter)."""
+    c = Case('vlsac_tiny')
+    outs, launches = [], []
+    for hoist in (True, False):
+        agent = make_agent(c)
+        buf = make_buffer(c)
+        armed = []
+        if not hoist:
+            agent.core.prefetch_policy = lambda eps: False
+        else:
+            orig = agent.core.prefetch_policy
+            agent.core.prefetch_policy = lambda eps, orig=orig: armed.append(orig(eps)) or armed[-1]
+        infos = [agent.train_injected(buf, c.B, tr['idx'], tr['eps']) for tr in c.trains]
+        if hoist:
+            assert armed and all(armed), 'vlsac_tiny must support the prefetched policy forward'
+        launches.append(agent.core.launch_count())
+        outs.append((infos, {k: v.numpy().copy() for k, v in agent.core.state().items()}))
+    (ia, sa), (ib, sb) = outs
+    for x, y in zip(ia, ib):
+        for k in y:
+            assert abs(x[k] - y[k]) <= 1e-6 * max(abs(y[k]), 1e-2), k
+    for k in sb:
+        assert rel_l2(sa[k], sb[k]) < 1e-6, k
+    assert launches[0] < launches[1], launches
