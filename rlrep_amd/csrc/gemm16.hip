@@ -22,6 +22,33 @@
 // the row-contiguous case) and feeds them to four successive MFMAs.
 #include "common.h"
 
+#ifdef RL_TIMING
+// Instrumented build (tools/exp/gemm_timeline.py): thread 0 of every 8th workgroup records the 100 MHz wall clock at
+// entry and exit and the shader clock at entry, once its task record is in registers, after its MFMAs, after the
+// reduction barrier and at exit.  Slot = launch sequence number (bumped by workgroup 0 at exit) * 2048 + blockIdx.x.
+struct RlTimRec { unsigned long long w0, w4, c[5]; int grid, bid; unsigned tag, valid; };
+__device__ RlTimRec* g_tim = nullptr;
+__device__ unsigned g_tim_launch = 0, g_tim_cap = 0;
+extern "C" int rl_timing_buffer(void* buf, unsigned cap) {
+    unsigned zero = 0;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tim), &buf, sizeof(buf));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tim_launch), &zero, sizeof(zero));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tim_cap), &cap, sizeof(cap));
+    return (int)e;
+}
+extern "C" unsigned rl_timing_count() { unsigned n = 0; (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tim_launch), sizeof(n)); return n; }
+#define TIM_ON (threadIdx.x == 0 && (blockIdx.x & 7) == 0)
+#define TIM(k) do { if (TIM_ON) tim_c[k] = clock64(); } while (0)
+#define TIM_FIN() do { if (threadIdx.x == 0 && g_tim) { if (TIM_ON) { tim_c[4] = clock64(); const unsigned long long w4 = wall_clock64(); \
+    const unsigned slot = tim_lid * 2048u + blockIdx.x; \
+    if (slot < g_tim_cap) { RlTimRec r; r.w0 = tim_w0; r.w4 = w4; for (int q = 0; q < 5; ++q) r.c[q] = tim_c[q]; r.grid = gridDim.x; r.bid = blockIdx.x; \
+    r.tag = (unsigned)(((uintptr_t)pC) >> 4) ^ ((unsigned)epi << 28); r.valid = 1; g_tim[slot] = r; } } \
+    if (blockIdx.x == 0) atomicAdd(&g_tim_launch, 1u); } } while (0)
+#else
+#define TIM(k) do {} while (0)
+#define TIM_FIN() do {} while (0)
+#endif
+
 // BRANCH-FREE operand fetch.  Out-of-range rows / inner indices are handled by CLAMPING the address into the
 // matrix and zeroing the value with a select: no exec-masked branch around any load.  (With `if (in_range) load`
 // hipcc wraps every load in s_cbranch_execz + s_waitcnt vmcnt(0): 147 branches and 21 full drains in a kernel
@@ -88,6 +115,11 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
 
+#ifdef RL_TIMING
+    unsigned long long tim_c[5] = {0, 0, 0, 0, 0}, tim_w0 = 0; unsigned tim_lid = 0;
+    if (threadIdx.x == 0) { tim_lid = *(volatile unsigned*)&g_tim_launch; if (TIM_ON) tim_w0 = wall_clock64(); }
+#endif
+    TIM(0);
     const int bid = blockIdx.x;
     int ti = 0;
 #pragma unroll
@@ -103,6 +135,10 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     const float scale = t.scale;
     float* const pout2 = t.out2; const int ldout2 = t.ldout2;
 
+#ifdef RL_TIMING
+    asm volatile("" :: "s"(R), "s"(epi));
+#endif
+    TIM(1);
     const int local = bid - tile_base;
     const int tr = local / tiles_c, tc = local - tr * tiles_c;
     const int r0 = tr * 16, c0 = tc * 16 * NF;
@@ -186,6 +222,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         else mac_group<LA, LB, NF, VA, VB, 3>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
     }
 
+    TIM(2);
     // claim the epilogue operands (long since arrived: the operand stream behind them has been consumed) and
     // discard what out-of-window lanes fetched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -216,6 +253,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         if (lane < 16) bsum[w][lane] = asum;
     }
     __syncthreads();
+    TIM(3);
 
     if (want_bias && threadIdx.x < 16 && r0 + (int)threadIdx.x < R) {
         const int q = threadIdx.x;
@@ -244,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
             t.y0[2 * local] = ((red[0][0][0][0] + red[0][0][0][1]) + red[0][0][0][2]) + red[0][0][0][3];
             t.y0[2 * local + 1] = ((red[0][0][1][0] + red[0][0][1][1]) + red[0][0][1][2]) + red[0][0][1][3];
         }
-        return;
+        TIM_FIN(); return;
     }
     if (epi == EPI_FWD_POLICY) {
         // (NF == 1 launches only) the whole [mu | rho] row sits in this one 16-column tile: rho_j is A lanes to the right
@@ -270,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o, 64);
         if (inb && c == 0 && t.y1) t.y1[r] = lp;
-        return;
+        TIM_FIN(); return;
     }
 
 #pragma unroll
@@ -330,6 +368,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         } break;
         }
     }
+    TIM_FIN();
 }
 
 // ------------------------------------------------------------------------------------------------

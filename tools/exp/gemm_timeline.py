@@ -1,0 +1,48 @@
+"""In-kernel timeline of every gemm16 launch of one graph-replayed train() (needs the -DRL_TIMING build:
+   rm rlrep_amd/csrc/.obj/gemm16.o; EXTRA_FLAGS=-DRL_TIMING bash rlrep_amd/csrc/build.sh).
+   Times are the 100 MHz wall clock (10 ns ticks) read by thread 0 of each workgroup."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
+import numpy as np, torch
+import bench
+from rlrep_amd import _lib
+
+lib = _lib.lib
+raw = C.CDLL(_lib.LIB_PATH)
+raw.rl_timing_buffer.argtypes = [C.c_void_p, C.c_uint]; raw.rl_timing_buffer.restype = C.c_int
+raw.rl_timing_count.restype = C.c_uint
+alg, S, A, B, kw = bench.WORKLOADS['vlsac_halfcheetah_f256_b256']
+torch.manual_seed(0)
+agent = bench.make_agent(alg, S, A, B, kw)
+buf, _ = bench.synth_buffer(S, A, 0)
+for _ in range(20): agent.train(buf, B)
+torch.cuda.synchronize()
+NL = 80; CAP = NL * 2048
+tb = torch.zeros(CAP * 9, dtype=torch.int64, device='cuda')          # RlTimRec is 72 bytes
+assert raw.rl_timing_buffer(C.c_void_p(tb.data_ptr()), CAP) == 0
+for _ in range(3): agent.train(buf, B)
+torch.cuda.synchronize()
+tb.zero_(); torch.cuda.synchronize()
+assert raw.rl_timing_buffer(C.c_void_p(tb.data_ptr()), CAP) == 0     # reset the launch counter
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); agent.train(buf, B); e1.record()
+torch.cuda.synchronize()
+print('this train(): %.1f us by events' % (e0.elapsed_time(e1) * 1e3))
+nl = raw.rl_timing_count()
+rec = tb.cpu().numpy().reshape(CAP, 9)
+print(f'{nl} gemm16 launches; wall times in us (100 MHz clock), phases in shader cycles / 2200 = us')
+print(' #   WGs  gap_prev  ramp   span  | median per sampled WG: record  loads+mfma  reduce  epilogue   life (max)')
+prev = None; tot = 0.0
+for k in range(nl):
+    r = rec[k * 2048:(k + 1) * 2048]; r = r[(r[:, 8] >> 32) == 1]
+    if not len(r): continue
+    w0, w4, c = r[:, 0], r[:, 1], r[:, 2:7]
+    grid = int(r[0, 7] & 0xffffffff)
+    gap = (w0.min() - prev) / 100 if prev is not None else 0.0
+    ph = np.median(np.diff(c, axis=1), axis=0) / 2200.0
+    life = (c[:, 4] - c[:, 0]) / 2200.0
+    print(f"{k:3d} {grid:5d}  {gap:7.2f} {(w0.max()-w0.min())/100:6.2f} {(w4.max()-w0.min())/100:6.2f}  |  {ph[0]:6.2f} {ph[1]:9.2f} {ph[2]:8.2f} {ph[3]:8.2f}   {np.median(life):6.2f} ({life.max():.2f})")
+    tot += (w4.max() - w0.min()) / 100
+    prev = w4.max()
+print('sum of gemm16 kernel spans %.1f us' % tot)
