@@ -207,7 +207,11 @@ int32_t rlrep_actor_alpha_step(rlrep_agent* agent, const float* eps_dev, void* s
 int32_t rlrep_prefetch_policy(rlrep_agent* agent, const float* eps_actor_dev);
 /* Polyak critic -> critic_target iff (steps % target_update_period == 0), steps kept on the device. */
 int32_t rlrep_update_target(rlrep_agent* agent, void* stream);
-/* steps += 1 (device counter; graph-replay safe) */
+/* steps += 1 (device counter; graph-replay safe).  Also opens a train() bracket that rlrep_update_target closes: inside
+ * it the Polyak critic -> critic_target (same tau, same steps % period gate) is performed by the critic step's Adam
+ * launch and rlrep_update_target only closes the bracket -- nothing in between reads critic_target (train():
+ * sac_agent.py:169-190).  Without a preceding rlrep_begin_train every entry point does exactly what its reference
+ * method does. */
 int32_t rlrep_begin_train(rlrep_agent* agent, void* stream);
 
 /* Split entry points for data-parallel training: backward part writes the group's gradient arena

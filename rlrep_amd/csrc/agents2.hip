@@ -302,6 +302,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(dq + B, 1, 1, Ec + H, 2 * H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias")),
                        Builder::dw(GE, 2 * H, 2 * H, pa.Z, F, F, B, Gw("critic.l1.weight"), F, Gw("critic.l1.bias"))}, "critic dW");
         b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, critic_fins(ag, part_q, nblk), "adam critic");
+        critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
     }
     {
         Program& p = ag->actor_bwd;
@@ -372,6 +373,7 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
                            Builder::dw(rc.GE + BH, H, H, rc.S1 + H, 2 * H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias")),
                            Builder::dw(rc.G1, 2 * H, 2 * H, Zc, F, F, B, Gw("critic.l1.weight"), F, Gw("critic.l1.bias"))}, "critic dW");
             b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, critic_fins(ag, part_q, nblk), "adam critic");
+            critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
         } else {
             // diffsrsac (quirk Q11): metrics only.  q_loss_reg == q_loss_noreg (lambda = 0, Q12); q2 := q1 (Q13)
             const float ib = 1.0f / (float)B;

@@ -70,7 +70,10 @@ struct GemmTask {
 };
 
 #define GEMM_MAX_TASKS 8
-struct GemmBatch { int ntasks; int pad; GemmTask t[GEMM_MAX_TASKS]; };   // passed by value (kernarg segment)
+struct FinTask;
+// passed by value (kernarg segment).  nfin > 0: the launch has one extra trailing workgroup that runs the step's metric
+// finalisation / temperature update (the optimizer itself then runs in the EPI_DW epilogues: GemmTask::ad_*)
+struct GemmBatch { int ntasks; int nfin; const FinTask* fin; GemmTask t[GEMM_MAX_TASKS]; };
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)
@@ -82,6 +85,7 @@ struct AdamTask {
     const GroupCfg* grp;        // group state (step already bumped for this step)
     // optional Polyak of a sub-range [pol_off, pol_off+pol_n) of p into target
     float* target; long long pol_off, pol_n; float tau;
+    const int* pol_steps; int pol_period;     // if pol_steps != nullptr: Polyak only when *pol_steps % pol_period == 0
 };
 
 struct PolyakTask {

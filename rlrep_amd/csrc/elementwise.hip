@@ -262,44 +262,6 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
 // fused multi-tensor Adam (+ Polyak of a sub-range) + metric finalisation + temperature update
 // torch/optim/adam.py::_single_tensor_adam operation order; SURVEY Appendix A.11/A.12
 // ------------------------------------------------------------------------------------------------
-__device__ void finalize_tasks(const FinTask* __restrict__ fin, int nfin, int lane) {
-    for (int q = 0; q < nfin; ++q) {
-        const FinTask f = fin[q];
-        if (f.kind == FIN_SUM) {
-            float s = 0.f;
-            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
-            s = wave_sum(s);
-            if (lane == 0) *f.out = s * f.scale;
-        } else if (f.kind == FIN_COMBINE) {
-            if (lane == 0) *f.out = f.scale * (*f.in_a) + f.scale_b * (*f.in_b);
-        } else if (f.kind == FIN_COPY) {
-            if (lane == 0) *f.out = *f.in_a;
-        } else if (f.kind == FIN_ALPHA) {
-            // L_alpha = mean(exp(log_alpha) * c), c detached; d/dlog_alpha = alpha * mean(c); fp64 Adam (quirk Q1)
-            float s = 0.f;
-            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
-            s = wave_sum(s);
-            if (lane == 0) {
-                double* st = f.alpha_state;           // log_alpha, m, v, step
-                const float mean_c = s * f.scale;
-                const double alpha = exp(st[0]);
-                *f.out = (float)alpha * mean_c;       // alpha_loss (fp32 product as in the reference)
-                if (f.learn) {
-                    const double g = (double)mean_c * alpha;
-                    const double b1 = (double)f.beta1, b2 = (double)f.beta2;
-                    st[3] += 1.0;
-                    st[1] = st[1] + (1.0 - b1) * (g - st[1]);
-                    st[2] = st[2] * b2 + (1.0 - b2) * g * g;
-                    const double bc1 = 1.0 - pow(b1, st[3]), bc2 = 1.0 - pow(b2, st[3]);
-                    const double denom = sqrt(st[2]) / sqrt(bc2) + (double)f.eps;
-                    st[0] = st[0] - ((double)f.lr / bc1) * (st[1] / denom);
-                }
-                *f.out2 = (float)exp(st[0]);          // info['alpha'] is read after the optimizer step
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
                                                    const PolyakTask* __restrict__ pol, int npol,
                                                    const FinTask* __restrict__ fin, int nfin) {
@@ -318,6 +280,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
     }
     const AdamTask& t = tasks[ti];
     const AdamScal sc = t.grp->sc;
+    const bool pol_on = t.target && (!t.pol_steps || ((*t.pol_steps) % t.pol_period) == 0);
     // 16 bytes per lane per array: group offsets/sizes and the Polyak sub-range are multiples of 4 floats (arena layout)
     const long long i = ((long long)(bid - base_blk) * 256 + threadIdx.x) * 4;
     if (i >= t.n) return;
@@ -326,7 +289,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
     if (vec) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
         f32x4 p4 = *reinterpret_cast<f32x4*>(t.p + i), m4 = *reinterpret_cast<f32x4*>(t.m + i), v4 = *reinterpret_cast<f32x4*>(t.v + i);
-        const bool pol = t.target && i >= t.pol_off && i < t.pol_off + t.pol_n;
+        const bool pol = pol_on && i >= t.pol_off && i < t.pol_off + t.pol_n;
         f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
         if (pol) t4 = *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off));
 #pragma unroll
@@ -340,7 +303,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
     } else {
         for (int s = 0; s < 4 && i + s < t.n; ++s) {
             const long long e = i + s;
-            float* tp = (t.target && e >= t.pol_off && e < t.pol_off + t.pol_n) ? t.target + (e - t.pol_off) : nullptr;
+            float* tp = (pol_on && e >= t.pol_off && e < t.pol_off + t.pol_n) ? t.target + (e - t.pol_off) : nullptr;
             adam_elem(sc, t.g[e], t.p + e, t.m + e, t.v + e, tp);
         }
     }

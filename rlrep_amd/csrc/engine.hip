@@ -152,14 +152,15 @@ void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab
                "actor dW");
 }
 
-void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk) {
-    Program& p = ag->actor_apply;
+std::vector<FinTask> actor_fins(rlrep_agent* ag, const float* partial_loss, int nblk) {
     FinTask fa; memset(&fa, 0, sizeof(fa));
     fa.kind = FIN_ALPHA; fa.partials = ag->Gtail(); fa.count = nblk; fa.stride = 1; fa.scale = ag->inv_batch();
     fa.out = ag->metrics + M_ALPHA_LOSS; fa.out2 = ag->metrics + M_ALPHA; fa.alpha_state = ag->a.alpha_state_dev;
     fa.lr = ag->h.lr_actor; fa.beta1 = ag->h.beta1; fa.beta2 = ag->h.beta2; fa.eps = ag->h.adam_eps; fa.learn = ag->h.learn_alpha;
-    b.adam(p, 2, ag->h.lr_actor, nullptr, 0, 0, 0.f,
-           {Builder::fin_sum(partial_loss, nblk, 1, 1.0f / (float)ag->B, ag->metrics + M_ACTOR_LOSS), fa}, "adam actor + alpha");
+    return {Builder::fin_sum(partial_loss, nblk, 1, 1.0f / (float)ag->B, ag->metrics + M_ACTOR_LOSS), fa};
+}
+void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk) {
+    b.adam(ag->actor_apply, 2, ag->h.lr_actor, nullptr, 0, 0, 0.f, actor_fins(ag, partial_loss, nblk), "adam actor + alpha");
 }
 
 void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst) {
@@ -170,6 +171,13 @@ void update_target_program(rlrep_agent* ag, const std::string& first_src, const 
     (void)first_src;
     t.n = ag->L.group_n[1]; t.tau = ag->h.tau; t.steps = ag->steps; t.period = ag->h.target_update_period;
     ag->upd_target.stages.push_back({[=](hipStream_t st) { return rl_launch_polyak(&t, st); }, "polyak critic"});
+}
+// critic Adam with the target update folded in (same Polyak, same period gate, run by the Adam launch's own lanes)
+void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins) {
+    if (getenv("RLREP_NO_FOLD_TARGET")) return;
+    float* dst = ag->a.target_dev ? ag->a.target_dev + ag->L.get(first_dst).off : nullptr;
+    b.adam(ag->critic_apply_f, 1, ag->h.lr_critic, dst, ag->L.group_off[1], ag->L.group_n[1], ag->h.tau, fins, "adam critic + polyak critic",
+           ag->steps, ag->h.target_update_period);
 }
 
 // ================================================================================================
@@ -224,12 +232,13 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(G1, 2 * H, 2 * H, s0.XF, SA, SA, B, ag->G("critic.Q1.0.weight"), SA, ag->G("critic.Q1.0.bias"))}, "Q dW");
         // sac reports q_loss = mse1+mse2 and q2 := q1 (quirk Q13)
         const float ib = 1.0f / (float)B;
-        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f,
-               {Builder::fin_sum(part_q + 0, nblk, 4, ib, ag->metrics + M_TMP0),
+        const std::vector<FinTask> cfins = {Builder::fin_sum(part_q + 0, nblk, 4, ib, ag->metrics + M_TMP0),
                 Builder::fin_sum(part_q + 1, nblk, 4, ib, ag->metrics + M_TMP1),
                 Builder::fin_combine(ag->metrics + M_TMP0, 1.f, ag->metrics + M_TMP1, 1.f, ag->metrics + M_Q1_LOSS),
                 Builder::fin_sum(part_q + 2, nblk, 4, ib, ag->metrics + M_Q1),
-                Builder::fin_copy(ag->metrics + M_Q1, ag->metrics + M_Q2)}, "adam critic");
+                Builder::fin_copy(ag->metrics + M_Q1, ag->metrics + M_Q2)};
+        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, cfins, "adam critic");
+        critic_apply_folded(b, ag, "critic_target.Q1.0.weight", cfins);
     }
     // ---- actor step ----
     {
@@ -277,6 +286,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     const int SA = S + A, KE = 2 * S + A;
     Slot& s0 = ag->slot[0];
     Workspace& ws = b.ws;
+    b.allow_fuse = true;       // every parameter tensor of the three groups gets exactly one weight-gradient task below
     auto Pw = [&](const char* n) { return ag->P(n); };
     auto Tw = [&](const char* n) { return ag->T(n); };
     auto Gw = [&](const char* n) { return ag->G(n); };
@@ -329,6 +339,13 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             const LT& fl = ag->L.get("f.log_std_linear.bias");
             b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
         }
+        const std::vector<FinTask> feat_fins = {
+            Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
+            Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
+            Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
+            Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
+            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)};
+        b.stash_fin(feat_fins);
         b.dw_stage(p, {Builder::dw(GDH, S + 1, S + 1, D1, Hv, Hv, B, Gw("decoder.state_linear.weight"), Hv, Gw("decoder.state_linear.bias")),
                        Builder::dw(GD1, Hv, Hv, Z, F, F, B, Gw("decoder.l1.weight"), F, Gw("decoder.l1.bias")),
                        Builder::dw(GEH, 2 * F, 2 * F, ge.H2, Hv, Hv, B, Gw("encoder.mean_linear.weight"), Hv, Gw("encoder.mean_linear.bias")),
@@ -342,13 +359,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         const LT& f0 = ag->L.get("f.l1.weight");
         const LT& flast = ag->L.get("f.log_std_linear.bias");
         const int64_t fn = flast.off + flast.rows - f0.off;
-        float* m = ag->metrics;
-        b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau,
-               {Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), m + M_KL),
-                Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), m + M_S_LOSS),
-                Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, m + M_R_LOSS),
-                Builder::fin_combine(m + M_R_LOSS, 1.f, m + M_S_LOSS, 1.f, m + M_FEAT_A),
-                Builder::fin_combine(m + M_FEAT_A, 1.f, m + M_KL, 1.f, m + M_FEAT_TOTAL)}, "adam feature + polyak f");
+        b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau, feat_fins, "adam feature + polyak f");
     }
 
     // ---- critic / actor shared buffers ----
@@ -399,6 +410,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     // hoist = true builds the variant that also carries the forward half of the FOLLOWING actor step (policy on s,
     // f_target on (s, a_pi)): those GEMMs read nothing the critic update writes, and as extra tasks of launches that
     // exist anyway they take six launches (~5 us each at B = 256) off the critical path of train().
+    const std::vector<FinTask> cfins = {
+        Builder::fin_sum(part_q + 0, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1_LOSS), Builder::fin_sum(part_q + 1, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2_LOSS),
+        Builder::fin_sum(part_q + 2, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1), Builder::fin_sum(part_q + 3, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2)};
     auto critic_program = [&](Program& p, bool hoist) {
         GemmTask tt[3], tn[3], tp[3];
         gauss_tasks(ag, true, "f_target", s0.XF, SA, SA, gt, tt);
@@ -443,6 +457,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_critic(&q, st); }, "qhead critic"});
         b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.l2.weight"), H, GHm, H, H, ACT_NONE, nullptr, 0),
                        Builder::dx(GE + BH, H, B, H, Pw("critic.l5.weight"), H, GHm + BH, H, H, ACT_NONE, nullptr, 0)}, "critic l2/l5 dx");
+        b.stash_fin(cfins);
         b.dw_stage(p, {Builder::dw(dq, 1, 1, Ec, H, H, 2 * B, Gw("critic.l3.weight"), H, Gw("critic.l3.bias")),     // shared l3: heads stacked
                        Builder::dw(GE, H, H, HmC, H, H, B, Gw("critic.l2.weight"), H, Gw("critic.l2.bias")),
                        Builder::dw(GE + BH, H, H, HmC + BH, H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias"))}, "critic dW l3 l2 l5");
@@ -470,13 +485,8 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     };
     critic_program(ag->critic_bwd, false);
     if (policy_fusable(ag) && !getenv("RLREP_NO_HOIST")) critic_program(ag->critic_bwd_h, true);
-    {
-        const float ib = 1.0f / (float)B;
-        float* m = ag->metrics;
-        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f,
-               {Builder::fin_sum(part_q + 0, nblk, 4, ib, m + M_Q1_LOSS), Builder::fin_sum(part_q + 1, nblk, 4, ib, m + M_Q2_LOSS),
-                Builder::fin_sum(part_q + 2, nblk, 4, ib, m + M_Q1), Builder::fin_sum(part_q + 3, nblk, 4, ib, m + M_Q2)}, "adam critic");
-    }
+    b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, cfins, "adam critic");
+    critic_apply_folded(b, ag, "critic_target.l1.weight", cfins);
 
     // ---- actor + temperature step (vlsac_agent.py:165-198) ----
     {
@@ -513,6 +523,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         }
         b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gp.H2, Hv)}, "ft.heads dx");
         b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gp.H1, Hv)}, "ft.l2 dx");
+        b.stash_fin(actor_fins(ag, part_l, nblk));
         actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
         actor_apply_program(b, ag, part_l, nblk);
     }
@@ -525,9 +536,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f})
         p->stages.clear();
-    ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr;
+    ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
     ag->feat_cuts.clear();
     Builder b(ag);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
@@ -665,7 +676,7 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
         for (int g = 0; g < 4; ++g) {
             gc[g].lr = g == 1 ? hyper->lr_critic : g == 2 ? hyper->lr_actor : hyper->lr_feature;
             gc[g].b1 = hyper->beta1; gc[g].b2 = hyper->beta2; gc[g].eps = hyper->adam_eps;
-            gc[g].tau = (g == 0) ? hyper->feature_tau : 0.f;
+            gc[g].tau = (g == 0) ? hyper->feature_tau : (g == 1) ? hyper->tau : 0.f;    // Polyak rate of the group's target copy
         }
         if (e == hipSuccess) e = hipMemcpy(ag->adam_step, gc, sizeof(gc), hipMemcpyHostToDevice);
     }
@@ -799,7 +810,14 @@ int32_t rlrep_critic_backward(rlrep_agent* ag, const float* eps, void* stream) {
     }
     return run(ag, ag->critic_bwd, stream);
 }
-int32_t rlrep_critic_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(false) return run(ag, ag->critic_apply, stream); }
+int32_t rlrep_critic_apply(rlrep_agent* ag, void* stream) {
+    STEP_PROLOGUE(false)
+    if (ag->in_train && !ag->target_done && !ag->critic_apply_f.stages.empty()) {
+        ag->target_done = true;
+        return run(ag, ag->critic_apply_f, stream);
+    }
+    return run(ag, ag->critic_apply, stream);
+}
 int32_t rlrep_actor_backward(rlrep_agent* ag, const float* eps, void* stream) {
     STEP_PROLOGUE(false)
     if (!eps) { rl_set_error("actor step needs eps[B,A]"); return RLREP_ERR_ARG; }
@@ -827,6 +845,9 @@ int32_t rlrep_actor_alpha_step(rlrep_agent* ag, const float* eps, void* stream) 
 }
 int32_t rlrep_update_target(rlrep_agent* ag, void* stream) {
     if (!ag) return RLREP_ERR_ARG;
+    const bool done = ag->target_done;
+    ag->in_train = ag->target_done = false;
+    if (done) return 0;                                  // already folded into this train()'s critic Adam launch
     ag->last_launches += (int)ag->upd_target.stages.size();
     return ag->upd_target.run((hipStream_t)stream);
 }
@@ -834,6 +855,7 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     if (!ag) return RLREP_ERR_ARG;
     int rc = rl_launch_counter_inc(ag->steps, (hipStream_t)stream);
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
+    ag->in_train = true; ag->target_done = false;
     return 0;
 }
 int32_t rlrep_feature_exchange_count(rlrep_agent* ag) { return ag ? (int32_t)ag->feat_cuts.size() : RLREP_ERR_ARG; }

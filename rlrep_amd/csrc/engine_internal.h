@@ -18,6 +18,10 @@ struct rlrep_agent {
     // changes, so its GEMMs can ride along in the critic step's launches (critic_bwd_h) and the actor step then
     // resumes at stage actor_resume.  Armed per train() by rlrep_prefetch_policy; see there for the protocol.
     Program critic_bwd_h; int actor_resume = 0;
+    // Inside a rlrep_begin_train .. rlrep_update_target bracket the Polyak critic -> critic_target is folded into the
+    // critic's Adam launch (critic_apply_f): nothing between the two reads critic_target, and the update_target launch
+    // (~2 us + a launch boundary) disappears.  Outside a bracket every entry point does exactly what its name says.
+    Program critic_apply_f; bool in_train = false, target_done = false;
     const float* cur_eps2 = nullptr; const float* hoist_req = nullptr; const float* pi_ready = nullptr;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
@@ -94,6 +98,10 @@ struct Builder {
         if (tasks.size() > GEMM_MAX_TASKS) { fprintf(stderr, "rlrep: too many tasks in stage %s\n", what); abort(); }
         GemmBatch gb; memset(&gb, 0, sizeof(gb));
         gb.ntasks = (int)tasks.size();
+        if (la == LD_COL && lb == LD_COL && fused() && !pending_fin.empty()) {
+            gb.fin = upload(pending_fin); gb.nfin = (int)pending_fin.size();
+            pending_fin.clear(); fin_attached = true;
+        }
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         const int total = base_tile;
         bool dyn = false;
@@ -112,12 +120,22 @@ struct Builder {
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, nf, &gb, total, st); }, what});
     }
     // ---- optimizer fusion (single-GPU path) ------------------------------------------------------
-    // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch CAN apply
-    // Adam (and the Polyak of the target copy) to its own tile in the epilogue, saving one launch per optimizer
-    // step.  Measured on MI355X (vlsac, B=256) it LOSES: the 16x16-tile epilogue touches p/m/v in 64-byte segments
-    // and the dW launch grows by 5.4 us, more than the 2.7 us the separate (fully coalesced) Adam launch costs over
-    // a bare finalise launch -- 624 vs 608 us per train().  Kept behind RLREP_FUSE_ADAM=1 for larger layers.
-    bool fused() const { return ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev; }
+    // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch applies Adam (and
+    // the Polyak of the target copy) to its own tile in the epilogue, and the step's metric finalisation / temperature
+    // update rides in the same launch as one extra workgroup: the separate optimizer launch (~4.5 us + ~1.7 us of
+    // launch boundary at B = 256, six per vlsac train()) disappears.  The parameter / moment tiles are prefetched with
+    // the other epilogue operands before the inner loop, so the weight-gradient launch itself barely grows.  (A first
+    // version read p/m/v after the reduction and still needed a finalise launch: 624 vs 608 us per train(), slower.)
+    // A step program opts in (allow_fuse) only if every parameter tensor receives exactly ONE weight-gradient task.
+    bool allow_fuse = false;
+    // MEASURED (MI355X, vlsac B = 256): still a loss.  Adam is bandwidth work (28 bytes per parameter, ~17 MB per feature
+    // step): the separate launch streams it with 16-byte lanes in 4.5 us, the 16 x 16 tile epilogue moves the same
+    // bytes in 64-byte row segments and the weight-gradient launches grow by 3.8 / 2.6 / 2.2 / 1.7 us (feature /
+    // critic / noise-critic / actor) -- 544 vs 533 us per train().  Opt-in with RLREP_FUSE_ADAM=1.
+    bool fused() const { return allow_fuse && ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev; }
+    std::vector<FinTask> pending_fin; bool fin_attached = false;
+    // hand the finalisation tasks of the step to the NEXT weight-gradient stage (fused mode; ignored otherwise)
+    void stash_fin(std::vector<FinTask> f) { pending_fin = fused() ? f : std::vector<FinTask>(); fin_attached = false; }
     float lr_of(int g) const { return g == 1 ? ag->h.lr_critic : g == 2 ? ag->h.lr_actor : ag->h.lr_feature; }
     int group_of(int64_t off) const {
         for (int g = 0; g < 4; ++g) if (ag->L.group_n[g] > 0 && off >= ag->L.group_off[g] && off < ag->L.group_off[g] + ag->L.group_n[g]) return g;
@@ -157,9 +175,10 @@ struct Builder {
     }
 
     void adam(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau,
-              std::vector<FinTask> fin, const char* what) {
-        if (fused()) {          // Adam already ran in the dW epilogues: only the metric / temperature finalisation is left
-            if (!fin.empty()) finalize_only(p, fin, what);
+              std::vector<FinTask> fin, const char* what, const int* pol_steps = nullptr, int pol_period = 1) {
+        if (fused()) {          // Adam ran in the dW epilogues; the finalisation rode along unless nobody stashed it
+            if (!fin.empty() && !fin_attached) finalize_only(p, fin, what);
+            fin_attached = false;
             return;
         }
         const auto& L = ag->L;
@@ -172,7 +191,7 @@ struct Builder {
         t.n = L.group_n[group];
         t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
         t.grp = ag->adam_step + group;
-        t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau;
+        t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = pol_steps; t.pol_period = pol_period;
         std::vector<AdamTask> tv{t};
         const AdamTask* dev = upload(tv);
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
@@ -216,6 +235,8 @@ GemmTask policy_head_task(rlrep_agent* ag, const ActorBufs& ab, float* act, int 
 // `action_dx` computes dL/da [B,A] into ab.dA; its epilogue takes over policy_bwd when A <= 16
 void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx, const float* act, int ld_act, GemmTask action_dx);
 void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk);
+std::vector<FinTask> actor_fins(rlrep_agent* ag, const float* partial_loss, int nblk);
+void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins);
 void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst);
 
 // agents2.hip

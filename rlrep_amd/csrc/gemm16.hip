@@ -21,6 +21,7 @@
 // freely as long as A and B agree, so each lane takes FOUR CONSECUTIVE inner indices (one 16-byte load in
 // the row-contiguous case) and feeds them to four successive MFMAs.
 #include "common.h"
+#include "kparams.h"
 
 #ifdef RL_TIMING
 // Instrumented build (tools/exp/gemm_timeline.py): thread 0 of every 8th workgroup records the 100 MHz wall clock at
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 #endif
     TIM(0);
     const int bid = blockIdx.x;
+    if (gb.nfin > 0 && bid == (int)gridDim.x - 1) {      // trailing workgroup: metric finalisation / temperature update
+        if (threadIdx.x < 64) finalize_tasks(gb.fin, gb.nfin, threadIdx.x);
+        return;
+    }
     int ti = 0;
 #pragma unroll
     for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     // kind only selects up to four SLOT descriptors (base, row stride, column stride, offset, column window) in
     // scalar code; the loads themselves are generic and branch-free (a lane outside its window reads the slot's
     // base address and the value is discarded), so nothing waits on them before the epilogue.
-    const float* sp[4] = {nullptr, nullptr, nullptr, nullptr};
-    int srs[4] = {0, 0, 0, 0}, scs[4] = {1, 1, 1, 1}, sof[4] = {0, 0, 0, 0}, slo[4] = {0, 0, 0, 0}, shi[4] = {Cn, Cn, Cn, Cn};
+    const float* sp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int srs[5] = {0, 0, 0, 0, 0}, scs[5] = {1, 1, 1, 1, 1}, sof[5] = {0, 0, 0, 0, 0}, slo[5] = {0, 0, 0, 0, 0}, shi[5] = {Cn, Cn, Cn, Cn, Cn};
     switch (epi) {
     case EPI_FWD: sp[0] = pbias; break;
     case EPI_DX:
@@ -184,8 +189,12 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         sp[1] = pC; srs[1] = ldc;
         sp[2] = pC; srs[2] = ldc; sof[2] = t.F;
         break;
-    default:
+    default:   // EPI_DW
         if (flags & FLAG_ACCUM) { sp[1] = pC; srs[1] = ldc; }
+        if (t.ad_p) {      // optimizer fused in: the tile of the parameter, its Adam moments (and its Polyak target)
+            sp[0] = t.ad_p; sp[2] = t.ad_m; sp[3] = t.ad_v; sp[4] = t.ad_t;
+            srs[0] = srs[2] = srs[3] = srs[4] = ldc;
+        }
     }
     const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
     const int r = r0 + (ol >> 4) * 4 + oreg;
@@ -193,9 +202,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     // their first use (a serialised L2 round trip in the epilogue).  The compiler does not count asm loads in its
     // vmcnt bookkeeping; they are OLDER than every operand load of the main loop and vmcnt retires in order, so the
     // compiler's own counted waits stay correct, and the values are claimed by the explicit wait after the loop.
-    float ev[4][NF];
+    float ev[5][NF];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 5; ++q) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) ev[q][f] = 0.f;
         if (sp[q]) {
@@ -209,8 +218,19 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         }
     }
 
+    // fused optimizer: Adam scalars of the group, and (column-tile 0 only) the bias element this thread will update
     AdamScal adsc;
-    if (epi == EPI_DW && t.ad_p) adsc = t.ad_grp->sc;
+    const bool fuse_opt = (epi == EPI_DW) && t.ad_p;
+    if (fuse_opt) adsc = t.ad_grp->sc;
+    float bpv = 0.f, bmv = 0.f, bvv = 0.f, btv = 0.f;
+    const bool bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
+    if (bias_opt) {
+        const int o = r0 + threadIdx.x;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(bpv) : "v"(t.ad_pb + o));
+        asm volatile("global_load_dword %0, %1, off" : "+v"(bmv) : "v"(t.ad_mb + o));
+        asm volatile("global_load_dword %0, %1, off" : "+v"(bvv) : "v"(t.ad_vb + o));
+        if (t.ad_tb) asm volatile("global_load_dword %0, %1, off" : "+v"(btv) : "v"(t.ad_tb + o));
+    }
 
     // wave w owns the 16-wide inner chunks w, w+4, w+8, ...
     for (int kb = w * 16; kb < K; kb += 256) {
@@ -227,19 +247,21 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     // discard what out-of-window lanes fetched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 5; ++q)
 #pragma unroll
         for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(ev[q][f]));
-    float e0[NF], cold[NF], cold2[NF];
+    asm volatile("" : "+v"(bpv), "+v"(bmv), "+v"(bvv), "+v"(btv));
+    float e0[NF], cold[NF], cold2[NF], cold3[NF], cold4[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int c = c0 + 16 * f + (ol & 15);
-        float m[4];
+        float m[5];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[q] = ((r < R) && (c >= slo[q]) && (c < shi[q])) ? ev[q][f] : 0.f;
+        for (int q = 0; q < 5; ++q) m[q] = ((r < R) && (c >= slo[q]) && (c < shi[q])) ? ev[q][f] : 0.f;
         e0[f] = m[0];
         cold[f] = (epi == EPI_FWD_MSE) ? m[1] + m[2] : m[1];
         cold2[f] = (epi == EPI_DX) ? m[2] * m[3] : m[2];
+        cold3[f] = m[3]; cold4[f] = m[4];
     }
 
     // cross-wave reduction in fixed order
@@ -259,7 +281,11 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         const int q = threadIdx.x;
         const float gbv = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
         pout2[r0 + q] = gbv;
-        if (t.ad_pb) adam_elem(adsc, gbv, t.ad_pb + r0 + q, t.ad_mb + r0 + q, t.ad_vb + r0 + q, t.ad_tb ? t.ad_tb + r0 + q : nullptr);
+        if (bias_opt) {
+            adam_elem(adsc, gbv, &bpv, &bmv, &bvv, t.ad_tb ? &btv : nullptr);
+            t.ad_pb[r0 + q] = bpv; t.ad_mb[r0 + q] = bmv; t.ad_vb[r0 + q] = bvv;
+            if (t.ad_tb) t.ad_tb[r0 + q] = btv;
+        }
     }
 
     if (epi == EPI_FWD_MSE) {
@@ -361,9 +387,12 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
         default: {
             const float g = cold[f] + v;
             *cp = g;
-            if (t.ad_p) {
+            if (fuse_opt) {      // e0 / cold2 / cold3 / cold4 = parameter, exp_avg, exp_avg_sq, Polyak target (prefetched)
                 const size_t o = (size_t)r * ldc + c;
-                adam_elem(adsc, g, t.ad_p + o, t.ad_m + o, t.ad_v + o, t.ad_t ? t.ad_t + o : nullptr);
+                float pv = e0[f], mv = cold2[f], vv = cold3[f], tv = cold4[f];
+                adam_elem(adsc, g, &pv, &mv, &vv, t.ad_t ? &tv : nullptr);
+                t.ad_p[o] = pv; t.ad_m[o] = mv; t.ad_v[o] = vv;
+                if (t.ad_t) t.ad_t[o] = tv;
             }
         } break;
         }
@@ -394,7 +423,7 @@ static bool all_vec(const GemmBatch& gb, bool opB) {
 
 extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    dim3 g(total_tiles);
+    dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
     if (la == LD_ROW && lb == LD_ROW) {
         if (all_vec(*gb, false) && all_vec(*gb, true)) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb);
         else launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);

@@ -69,6 +69,49 @@ struct FinTask {
     double* alpha_state; float lr, beta1, beta2, eps; int learn;
 };
 
+// Metric finalisation + temperature update, run by ONE wave: the trailing block of the Adam launch, or (optimizer fused
+// into the weight-gradient launch) the extra trailing workgroup of that launch.
+// torch/optim/adam.py::_single_tensor_adam operation order; SURVEY Appendix A.11/A.12
+#ifdef __HIPCC__
+__device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin, int lane) {
+    for (int q = 0; q < nfin; ++q) {
+        const FinTask f = fin[q];
+        if (f.kind == FIN_SUM) {
+            float s = 0.f;
+            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
+            s = wave_sum(s);
+            if (lane == 0) *f.out = s * f.scale;
+        } else if (f.kind == FIN_COMBINE) {
+            if (lane == 0) *f.out = f.scale * (*f.in_a) + f.scale_b * (*f.in_b);
+        } else if (f.kind == FIN_COPY) {
+            if (lane == 0) *f.out = *f.in_a;
+        } else if (f.kind == FIN_ALPHA) {
+            // L_alpha = mean(exp(log_alpha) * c), c detached; d/dlog_alpha = alpha * mean(c); fp64 Adam (quirk Q1)
+            float s = 0.f;
+            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
+            s = wave_sum(s);
+            if (lane == 0) {
+                double* st = f.alpha_state;           // log_alpha, m, v, step
+                const float mean_c = s * f.scale;
+                const double alpha = exp(st[0]);
+                *f.out = (float)alpha * mean_c;       // alpha_loss (fp32 product as in the reference)
+                if (f.learn) {
+                    const double g = (double)mean_c * alpha;
+                    const double b1 = (double)f.beta1, b2 = (double)f.beta2;
+                    st[3] += 1.0;
+                    st[1] = st[1] + (1.0 - b1) * (g - st[1]);
+                    st[2] = st[2] * b2 + (1.0 - b2) * g * g;
+                    const double bc1 = 1.0 - pow(b1, st[3]), bc2 = 1.0 - pow(b2, st[3]);
+                    const double denom = sqrt(st[2]) / sqrt(bc2) + (double)f.eps;
+                    st[0] = st[0] - ((double)f.lr / bc1) * (st[1] / denom);
+                }
+                *f.out2 = (float)exp(st[0]);          // info['alpha'] is read after the optimizer step
+            }
+        }
+    }
+}
+#endif
+
 // vlsac noise critic (noisecritic.hip)
 struct NcFwdTask {
     const float* mean; const float* lstd; int ld_ml;

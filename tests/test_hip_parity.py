@@ -98,6 +98,13 @@ def test_hip_matches_reference_golden(name):
         err = _cmp(st[k].numpy(), v, c.full)
         worst['param'] = max(worst['param'], err)
         assert err < 1e-4, (name, k, err)
+        # Polyak'd copies move by tau * (a few Adam steps): compare the MOVEMENT, the absolute check above cannot see
+        # a target update that never ran
+        if c.full and 'target' in k and k in c.init:
+            d_ref = np.asarray(v, np.float64) - np.asarray(c.init[k], np.float64)
+            d_mine = st[k].numpy().astype(np.float64) - np.asarray(c.init[k], np.float64)
+            if np.linalg.norm(d_ref) > 1e-9:
+                assert rel_l2(d_mine, d_ref) < 2e-2, (name, k, 'target movement', rel_l2(d_mine, d_ref))
     print(f'{name}: worst info {worst["info"]:.2e} grad {worst["grad"]:.2e} param {worst["param"]:.2e}')
 
 
