@@ -190,6 +190,19 @@ int32_t rlrep_fill_normal_dev(float* dst_dev, int64_t n, float std, uint64_t see
                               const int32_t* counter_dev, void* stream);
 const int32_t* rlrep_steps_dev(rlrep_agent* agent);
 
+/* ---- launch-saving forms of the sampling calls (graph-replayed train()) -------------------------
+ * rlrep_train_prologue == rlrep_begin_train + rlrep_fill_indices_dev(idx_pool) + rlrep_fill_normal_dev(eps_pool) +
+ * rlrep_replay_sample(slot 0, ring, idx_pool[0:batch]) in ONE launch (same generator streams, same results): the
+ * gather recomputes its indices from the counter-based generator instead of waiting for the pool.  The following
+ * rlrep_replay_sample(agent, 0, ring, idx_pool, batch, ..) is recognised and skipped.
+ * rlrep_prefetch_batch arms the gather of the NEXT minibatch (slot 0) to ride in the next optimizer launch
+ * (rlrep_*_apply / *_step): by then the current step has finished reading the slot.  The matching
+ * rlrep_replay_sample(agent, 0, ring, idx, batch, ..) is then skipped.  Returns 1 if armed, 0 if not (batch size change). */
+int32_t rlrep_train_prologue(rlrep_agent* agent, const float* ring_dev, const int32_t* size_dev, int32_t* idx_pool_dev, int64_t n_idx,
+                             float* eps_pool_dev, int64_t n_eps, uint64_t seed, uint64_t idx_offset, uint64_t eps_offset,
+                             int32_t batch, void* stream);
+int32_t rlrep_prefetch_batch(rlrep_agent* agent, const float* ring_dev, const int32_t* idx_dev, int32_t batch);
+
 /* ---- step programs ------------------------------------------------------------------------ */
 /* eps pointers: caller-provided standard-normal noise (parity runs inject the oracle's tensors).
  *   vlsac feature: eps[B,F];  diffsr feature: noise_idx int32[B] + eps[B,S] (already scaled by sigma);

@@ -48,6 +48,7 @@ def _world():
 
 class SACAgent(object):
     ALG = 'sac'
+    PREFETCH_CHAIN = True     # every pooled index key is a slot-0 minibatch, consumed in _plan() order
     MODULES = ('critic', 'critic_target', 'actor')
     FEATURE_KEYS = ()
     CRITIC_KEYS = ('q_loss', 'q1', 'q2')
@@ -106,6 +107,7 @@ class SACAgent(object):
         self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
         self._inject = None
         self._pool = None
+        self._next_key = {}
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
 
     # parameter initialisation (values only; layout is the library's)
@@ -289,9 +291,12 @@ class SACAgent(object):
         ne = sum(int(np.prod(sh)) for _, sh in eps_specs)
         ipool = self._buf('pool_idx', (ni,), torch.int32)
         epool = self._buf('pool_eps', (ne,))
-        if g:
+        if g and os.environ.get('RLREP_NO_PROLOGUE'):
             self.core.fill_indices_dev(ipool, buffer.size_dev(), self._seed, 1 << 40)
             self.core.fill_normal_dev(epool, 1.0, self._seed, 2 << 40)
+        elif g:
+            # one launch: steps += 1, both pools and the gather of the first minibatch (first B pool indices)
+            self.core.train_prologue(buffer.ring, buffer.size_dev(), ipool, epool, self._seed, 1 << 40, 2 << 40, B)
         else:
             self._ctr += 1
             self.core.fill_indices(ipool, buffer.size, self._seed, (1 << 40) + self._ctr)
@@ -299,6 +304,9 @@ class SACAgent(object):
         self._pool = {}
         for q, k in enumerate(idx_keys):
             self._pool['idx_' + k] = ipool[q * B:(q + 1) * B]
+        # slot-0 batches in the order they are consumed: after gathering one, the next is armed to ride in the
+        # step's optimizer launch (rlrep_prefetch_batch)
+        self._next_key = dict(zip(idx_keys, idx_keys[1:])) if (g and self.PREFETCH_CHAIN) else {}
         o = 0
         for k, sh in eps_specs:
             n = int(np.prod(sh))
@@ -308,6 +316,9 @@ class SACAgent(object):
     def _sample_into(self, buffer, B, key, slot=0, g=False):
         if self._inject is None and self._pool is not None and ('idx_' + key) in self._pool:
             self.core.sample(slot, buffer.ring, self._pool['idx_' + key], B)
+            nxt = self._next_key.get(key) if slot == 0 else None
+            if nxt is not None:
+                self.core.prefetch_batch(buffer.ring, self._pool['idx_' + nxt], B)
             return
         if self._inject is not None:
             idx = torch.as_tensor(np.asarray(self._inject['idx'].pop(0)), dtype=torch.int32).to(self.core.device)
@@ -342,10 +353,14 @@ class SACAgent(object):
     def _body(self, buffer, B, g):
         """The whole train() as a sequence of stream-ordered library calls (captured into a hipGraph when g)."""
         c, W = self.core, self.world_size
-        c.begin_train()
         self._pool = None
-        if self._inject is None:
-            self._fill_pools(buffer, B, g)
+        self._next_key = {}
+        if self._inject is None and g and not os.environ.get('RLREP_NO_PROLOGUE'):
+            self._fill_pools(buffer, B, g)          # includes begin_train (rlrep_train_prologue)
+        else:
+            c.begin_train()
+            if self._inject is None:
+                self._fill_pools(buffer, B, g)
         nf = self._feature_iters()
         for i in range(nf):
             self._feature_once(buffer, B, i, g)

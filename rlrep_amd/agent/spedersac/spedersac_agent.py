@@ -8,6 +8,7 @@ from rlrep_amd.agent.sac.sac_agent import SACAgent, device  # noqa: F401
 
 class SPEDERSACAgent(SACAgent):
     ALG = 'spedersac'
+    PREFETCH_CHAIN = False    # two slots per feature step: batches are gathered by plain replay_sample calls
     MODULES = ('critic', 'critic_target', 'actor', 'phi', 'phi_target', 'mu', 'theta')
     FEATURE_KEYS = ('total_loss', 'model_loss', 'r_loss')
     CRITIC_KEYS = ('q1_loss', 'q2_loss', 'q1', 'q2')

@@ -161,6 +161,19 @@ class HipCore:
     def sample(self, slot, ring, idx, batch):
         check(lib.rlrep_replay_sample(self.h, slot, _ptr(ring), _ptr(idx), int(batch), _stream()), 'replay_sample')
 
+    def prefetch_batch(self, ring, idx, batch):
+        """Arm the gather of the next minibatch (slot 0) to ride in the next optimizer launch."""
+        rc = lib.rlrep_prefetch_batch(self.h, _ptr(ring), _ptr(idx), int(batch))
+        if rc < 0:
+            check(rc, 'prefetch_batch')
+        return rc == 1
+
+    def train_prologue(self, ring, size_dev, idx_pool, eps_pool, seed, idx_offset, eps_offset, batch):
+        """begin_train + index pool + noise pool + gather of the first minibatch, one launch."""
+        check(lib.rlrep_train_prologue(self.h, _ptr(ring), _ptr(size_dev), _ptr(idx_pool), idx_pool.numel(), _ptr(eps_pool),
+                                       eps_pool.numel(), int(seed), int(idx_offset), int(eps_offset), int(batch), _stream()),
+              'train_prologue')
+
     # ---- steps --------------------------------------------------------------------------------
     def begin_train(self):
         check(lib.rlrep_begin_train(self.h, _stream()), 'begin_train')

@@ -8,14 +8,25 @@
 // minibatch slot fill: replay-ring gather (idx) or five separate arrays (reference Batch fields)
 // reference: utils/buffer.py:39-48 (sample), utils/util.py:10-11 (unpack_batch)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fill_slot_kernel(SlotFill p) {
+struct IdxGen { int on; unsigned long long seed, off; uint32_t stream_id; int hi; };
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1);
+__device__ __forceinline__ int philox_index(const IdxGen& g, int e) {       // element e of a kind-1 PhiloxFill stream
+    const long long q = e >> 2;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)g.off, (uint32_t)(g.off >> 32) ^ g.stream_id};
+    philox4x32_10(c, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+    const uint32_t v = (e & 3) == 0 ? c[0] : (e & 3) == 1 ? c[1] : (e & 3) == 2 ? c[2] : c[3];
+    return (int)(((unsigned long long)v * (unsigned long long)g.hi) >> 32);
+}
+// blocks [0, nblocks) of a launch cooperate on one slot fill
+__device__ __forceinline__ void fill_slot_body(const SlotFill& p, const IdxGen& gen, int block, int nblocks) {
     const int row_w = 2 * p.S + p.A + 2;
     const long long total = (long long)p.B * row_w;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    for (long long e = (long long)block * 256 + threadIdx.x; e < total; e += (long long)nblocks * 256) {
         const int b = (int)(e / row_w), c = (int)(e - (long long)b * row_w);
         float v;
         if (p.ring) {
-            v = p.ring[(size_t)p.idx[b] * row_w + c];
+            const int src = gen.on ? philox_index(gen, b) : p.idx[b];
+            v = p.ring[(size_t)src * row_w + c];
         } else {
             if (c < p.S) v = p.s[(size_t)b * p.S + c];
             else if (c < p.S + p.A) v = p.a[(size_t)b * p.A + (c - p.S)];
@@ -41,6 +52,10 @@ __global__ __launch_bounds__(256) void fill_slot_kernel(SlotFill p) {
         }
     }
 }
+__global__ __launch_bounds__(256) void fill_slot_kernel(SlotFill p) {
+    IdxGen none; none.on = 0;
+    fill_slot_body(p, none, blockIdx.x, gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011): counter-based, replayable under hipGraph (counter from device)
@@ -56,12 +71,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
-__global__ __launch_bounds__(256) void philox_fill_kernel(PhiloxFill p) {
-    const unsigned long long step = p.step_dev ? (unsigned long long)(*p.step_dev) : 0ull;
+__device__ __forceinline__ void philox_fill_body(const PhiloxFill& p, int block, int nblocks) {
+    const unsigned long long step = p.step_dev ? (unsigned long long)(*p.step_dev + p.step_add) : 0ull;
     const unsigned long long off = p.offset + step;
     const int hi = p.hi_dev ? *p.hi_dev : p.hi;
     const long long nq = (p.n + 3) / 4;
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+    for (long long q = (long long)block * 256 + threadIdx.x; q < nq; q += (long long)nblocks * 256) {
         uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)off, (uint32_t)(off >> 32) ^ p.stream_id};
         philox4x32_10(c, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
         float out[4];
@@ -84,6 +99,26 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(PhiloxFill p) {
             if (p.kind == 0) p.dst_f[e] = out[s];
             else p.dst_i[e] = (int)(((unsigned long long)c[s] * (unsigned long long)hi) >> 32);   // uniform in [0,hi)
         }
+    }
+}
+__global__ __launch_bounds__(256) void philox_fill_kernel(PhiloxFill p) { philox_fill_body(p, blockIdx.x, gridDim.x); }
+
+__global__ __launch_bounds__(256) void train_prologue_kernel(TrainPrologue p) {
+    const int bid = blockIdx.x;
+    if (bid < p.nb_idx) philox_fill_body(p.idx, bid, p.nb_idx);
+    else if (bid < p.nb_idx + p.nb_eps) philox_fill_body(p.eps, bid - p.nb_idx, p.nb_eps);
+    else {
+        IdxGen g; g.on = 1; g.seed = p.idx.seed; g.stream_id = p.idx.stream_id;
+        g.off = p.idx.offset + (unsigned long long)(*p.idx.step_dev + p.idx.step_add);
+        g.hi = p.idx.hi_dev ? *p.idx.hi_dev : p.idx.hi;
+        fill_slot_body(p.fill, g, bid - p.nb_idx - p.nb_eps, p.nb_fill);
+    }
+    // steps += 1 once EVERY block has read the old value: the block that draws the last ticket does it
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int tk = atomicAdd(p.ticket, 1);
+        if (tk == (int)gridDim.x - 1) { *p.counter += 1; *p.ticket = 0; }
     }
 }
 
@@ -264,10 +299,17 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
                                                    const PolyakTask* __restrict__ pol, int npol,
-                                                   const FinTask* __restrict__ fin, int nfin) {
+                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks) {
     const int bid = blockIdx.x;
-    if (bid >= adam_blocks) {
-        // trailing block: standalone Polyak tasks are handled by their own blocks below; this one finalises
+    if (bid > adam_blocks) {
+        // rlrep_prefetch_batch: the gather of the NEXT minibatch rides here (the step that owned the slot has finished
+        // reading it: its weight-gradient launch precedes this one)
+        IdxGen none; none.on = 0;
+        fill_slot_body(sf, none, bid - adam_blocks - 1, fill_blocks);
+        return;
+    }
+    if (bid == adam_blocks) {
+        // trailing block: finalises the step's metrics / temperature
         if (threadIdx.x < 64) finalize_tasks(fin, nfin, threadIdx.x);
         return;
     }
@@ -375,9 +417,18 @@ extern "C" int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st) {
     hipLaunchKernelGGL(qhead_actor_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
-extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, hipStream_t st) {
-    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1), dim3(256), 0, st, tasks, ntasks, adam_blocks,
-                       (const PolyakTask*)nullptr, 0, fin, nfin);
+extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, hipStream_t st) {
+    SlotFill none = SlotFill();
+    const int fb = sf ? grid_for((long long)sf->B * (2 * sf->S + sf->A + 2), 256, 2048) : 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb), dim3(256), 0, st, tasks, ntasks, adam_blocks,
+                       (const PolyakTask*)nullptr, 0, fin, nfin, sf ? *sf : none, fb);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st) {
+    p->nb_idx = grid_for((p->idx.n + 3) / 4, 256, 2048);
+    p->nb_eps = grid_for((p->eps.n + 3) / 4, 256, 2048);
+    p->nb_fill = grid_for((long long)p->fill.B * (2 * p->fill.S + p->fill.A + 2), 256, 2048);
+    hipLaunchKernelGGL(train_prologue_kernel, dim3(p->nb_idx + p->nb_eps + p->nb_fill), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {

@@ -539,6 +539,7 @@ static int build_programs(rlrep_agent* ag, int B) {
     for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f})
         p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
+    ag->pf_armed = ag->pf_done = false;
     ag->feat_cuts.clear();
     Builder b(ag);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
@@ -704,6 +705,7 @@ static int ensure_batch(rlrep_agent* ag, int B) {
 
 int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, void* stream) {
     if (!ag || !bt || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("set_batch: bad argument"); return RLREP_ERR_ARG; }
+    if (slot == 0) { ag->pf_done = false; ag->pf_armed = false; }
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     int rc = ensure_batch(ag, bt->batch);
     if (rc) return rc;
@@ -728,8 +730,53 @@ int32_t rlrep_replay_add(rlrep_agent* ag, float* ring_dev, int64_t capacity, int
     return 0;
 }
 
+static void slot_fill_params(rlrep_agent* ag, int slot, const float* ring_dev, const int32_t* idx_dev, SlotFill& p) {
+    Slot& s = ag->slot[slot];
+    memset(&p, 0, sizeof(p));
+    p.ring = ring_dev; p.idx = idx_dev; p.B = ag->B; p.S = ag->d.state_dim; p.A = ag->d.action_dim;
+    p.XE = s.XE; p.XF = s.XF; p.XF2 = s.XF2; p.XFpi = s.XFpi; p.R = s.R; p.D = s.D;
+}
+
+int32_t rlrep_prefetch_batch(rlrep_agent* ag, const float* ring_dev, const int32_t* idx_dev, int32_t batch) {
+    if (!ag || !ring_dev || !idx_dev) { rl_set_error("prefetch_batch: bad argument"); return RLREP_ERR_ARG; }
+    ag->pf_armed = false;
+    if (batch != ag->B || getenv("RLREP_NO_PREFETCH_BATCH")) return 0;      // would need a rebuild: let replay_sample do it
+    slot_fill_params(ag, 0, ring_dev, idx_dev, ag->pf_fill);
+    ag->pf_ring = ring_dev; ag->pf_idx = idx_dev; ag->pf_armed = true;
+    return 1;
+}
+
+int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32_t* size_dev, int32_t* idx_pool_dev, int64_t n_idx,
+                             float* eps_pool_dev, int64_t n_eps, uint64_t seed, uint64_t idx_offset, uint64_t eps_offset,
+                             int32_t batch, void* stream) {
+    if (!ag || !ring_dev || !size_dev || !idx_pool_dev || !eps_pool_dev || n_idx < batch || n_eps <= 0 || batch <= 0) {
+        rl_set_error("train_prologue: bad argument"); return RLREP_ERR_ARG;
+    }
+    ag->pi_ready = nullptr; ag->hoist_req = nullptr; ag->pf_armed = false; ag->pf_done = false;
+    int rc = ensure_batch(ag, batch);
+    if (rc) return rc;
+    TrainPrologue tp; memset(&tp, 0, sizeof(tp));
+    tp.idx.dst_i = idx_pool_dev; tp.idx.n = n_idx; tp.idx.kind = 1; tp.idx.hi = 1; tp.idx.hi_dev = size_dev;
+    tp.idx.seed = seed; tp.idx.offset = idx_offset; tp.idx.step_dev = ag->steps; tp.idx.step_add = 1;
+    tp.eps.dst_f = eps_pool_dev; tp.eps.n = n_eps; tp.eps.kind = 0; tp.eps.std = 1.0f;
+    tp.eps.seed = seed; tp.eps.offset = eps_offset; tp.eps.step_dev = ag->steps; tp.eps.step_add = 1;
+    slot_fill_params(ag, 0, ring_dev, nullptr, tp.fill);
+    tp.counter = ag->steps; tp.ticket = ag->steps + 1;
+    rc = rl_launch_train_prologue(&tp, (hipStream_t)stream);
+    if (rc) { rl_set_error("train_prologue: hip error %d", rc); return RLREP_ERR_HIP; }
+    ag->slot[0].filled = true;
+    ag->pf_done = true; ag->pf_ring = ring_dev; ag->pf_idx = idx_pool_dev;     // the first `batch` pool entries are in slot 0
+    ag->in_train = true; ag->target_done = false;
+    return 0;
+}
+
 int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev, const int32_t* idx_dev, int32_t batch, void* stream) {
     if (!ag || !ring_dev || !idx_dev || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("replay_sample: bad argument"); return RLREP_ERR_ARG; }
+    if (slot == 0 && ag->pf_done && ring_dev == ag->pf_ring && idx_dev == ag->pf_idx && batch == ag->B && ag->slot[0].filled) {
+        ag->pf_done = false;                                   // this very gather already ran (train prologue / optimizer launch)
+        return 0;
+    }
+    if (slot == 0) ag->pf_done = false;
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;

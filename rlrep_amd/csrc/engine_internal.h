@@ -22,6 +22,10 @@ struct rlrep_agent {
     // critic's Adam launch (critic_apply_f): nothing between the two reads critic_target, and the update_target launch
     // (~2 us + a launch boundary) disappears.  Outside a bracket every entry point does exactly what its name says.
     Program critic_apply_f; bool in_train = false, target_done = false;
+    // rlrep_prefetch_batch: slot-0 gather that the next optimizer launch performs; pf_done: the matching
+    // rlrep_replay_sample(slot 0, pf_ring, pf_idx, B) is then a no-op
+    SlotFill pf_fill; bool pf_armed = false, pf_done = false; const float* pf_ring = nullptr; const int* pf_idx = nullptr;
+    int* ticket = nullptr;
     const float* cur_eps2 = nullptr; const float* hoist_req = nullptr; const float* pi_ready = nullptr;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
@@ -197,12 +201,18 @@ struct Builder {
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
         const int nfin = (int)fin.size();
         const int blocks = (int)((t.n + 1023) / 1024);
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(dev, 1, blocks, fdev, nfin, st); }, what});
+        rlrep_agent* a = ag;
+        p.stages.push_back({[=](hipStream_t st) {
+            // a minibatch armed by rlrep_prefetch_batch is gathered by extra blocks of this launch
+            const SlotFill* sf = a->pf_armed ? &a->pf_fill : nullptr;
+            if (sf) { a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; }
+            return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, st);
+        }, what});
     }
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, st); }, what});
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, st); }, what});
     }
 
     static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {

@@ -15,6 +15,17 @@ struct PhiloxFill {
     int kind;                  // 0: normal*std -> dst_f ; 1: uniform int in [0,hi) -> dst_i
     float std; int hi; const int* hi_dev;
     unsigned long long seed, offset; const int* step_dev; uint32_t stream_id;
+    int step_add;              // added to *step_dev (1 inside the train prologue, whose launch increments the counter LAST)
+};
+
+// One launch at the top of a graph-replayed train(): the index pool, the noise pool, the gather of the FIRST minibatch
+// (its indices are recomputed from the counter-based generator, so the gather does not wait for the pool) and the
+// steps += 1 of rlrep_begin_train (done by whichever block finishes last).  Replaces four dependent launches.
+struct TrainPrologue {
+    PhiloxFill idx, eps;
+    SlotFill fill;             // fill.idx == nullptr: row b uses element b of the `idx` stream
+    int nb_idx, nb_eps, nb_fill;
+    int* counter; int* ticket;
 };
 
 struct PolicyFwd {

@@ -301,3 +301,36 @@ def test_policy_prefetch_is_equivalent():
     for k in sb:
         assert rel_l2(sa[k], sb[k]) < 1e-6, k
     assert launches[0] < launches[1], launches
+
+
+@pytest.mark.parametrize('name', ['vlsac_tiny', 'sac_tiny', 'spedersac_tiny'])
+def test_graph_prologue_and_batch_prefetch_are_equivalent(name):
+    """Graph-replayed train(): the one-launch prologue (steps += 1, pools, first gather) and the gathers that ride in the
+    optimizer launches produce exactly what the separate begin_train / fill / replay_sample launches produce."""
+    c = Case(name)
+    outs = []
+    for fused in (True, False):
+        kw = dict(c.kw)
+        if c.meta.get('patch_vae_hidden'):
+            kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+        cls = type(make_agent(c))
+        agent = cls(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, graph=True, seed=1234, **kw)
+        agent.core.load_state(c.init)
+        buf = make_buffer(c)
+        core = agent.core
+        if not fused:
+            def prologue(ring, size_dev, ipool, epool, seed, ioff, eoff, B, core=core):
+                core.begin_train()
+                core.fill_indices_dev(ipool, size_dev, seed, ioff)
+                core.fill_normal_dev(epool, 1.0, seed, eoff)
+            core.train_prologue = prologue
+            core.prefetch_batch = lambda ring, idx, B: False
+        infos = [agent.train(buf, c.B) for _ in range(4)]
+        torch.cuda.synchronize()
+        outs.append((infos, {k: v.numpy().copy() for k, v in core.state().items()}))
+    (ia, sa), (ib, sb) = outs
+    for x, y in zip(ia, ib):
+        for k in y:
+            assert abs(float(x[k]) - float(y[k])) <= 1e-6 * max(abs(float(y[k])), 1e-2), (name, k, x[k], y[k])
+    for k in sb:
+        assert rel_l2(sa[k], sb[k]) < 1e-6, (name, k)
