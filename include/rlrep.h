@@ -218,6 +218,12 @@ int32_t rlrep_actor_alpha_step(rlrep_agent* agent, const float* eps_dev, void* s
  * its forward half.  Returns 1 if armed, 0 if this agent / shape has no such variant (then nothing changes), < 0 on
  * error.  Any new batch or feature step in between disarms it; results are identical either way. */
 int32_t rlrep_prefetch_policy(rlrep_agent* agent, const float* eps_actor_dev);
+/* One step earlier, for agents whose critic / actor steps reuse the minibatch of the LAST feature step (vlsac: train()
+ * samples once per feature iteration and keeps the last batch, vlsac_agent.py:246-262): armed before that feature step,
+ * BOTH policy forwards (on s' with eps_critic for the critic step's TD target, on s with eps_actor for the actor step)
+ * ride in its first launches, and the critic step called with the same eps_critic pointer starts with the three
+ * f_target forwards side by side.  Returns 1 if armed, 0 if the agent has no such variant. */
+int32_t rlrep_prefetch_policy_early(rlrep_agent* agent, const float* eps_critic_dev, const float* eps_actor_dev);
 /* Polyak critic -> critic_target iff (steps % target_update_period == 0), steps kept on the device. */
 int32_t rlrep_update_target(rlrep_agent* agent, void* stream);
 /* steps += 1 (device counter; graph-replay safe).  Also opens a train() bracket that rlrep_update_target closes: inside

@@ -90,6 +90,7 @@ def _load():
         'rlrep_steps_dev': (vp, [vp]),
         'rlrep_feature_step': (i32, [vp, vp, vp, vp]),
         'rlrep_prefetch_policy': (i32, [vp, vp]),
+        'rlrep_prefetch_policy_early': (i32, [vp, vp, vp]),
         'rlrep_prefetch_batch': (i32, [vp, vp, vp, i32]),
         'rlrep_train_prologue': (i32, [vp, vp, vp, vp, i64, vp, i64, u64, u64, u64, i32, vp]),
         'rlrep_critic_step': (i32, [vp, vp, vp]),

@@ -108,6 +108,7 @@ class SACAgent(object):
         self._inject = None
         self._pool = None
         self._next_key = {}
+        self._early_key = None
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
 
     # parameter initialisation (values only; layout is the library's)
@@ -312,6 +313,9 @@ class SACAgent(object):
             n = int(np.prod(sh))
             self._pool['eps_' + k] = epool[o:o + n].view(*sh)
             o += n
+        # the critic / actor steps reuse the last feature minibatch: both policy forwards can ride in its feature step
+        self._early_key = idx_keys[-1] if (g and self.PREFETCH_CHAIN and self._feature_iters() > 0
+                                           and 'eps_crit' in self._pool and 'eps_act' in self._pool) else None
 
     def _sample_into(self, buffer, B, key, slot=0, g=False):
         if self._inject is None and self._pool is not None and ('idx_' + key) in self._pool:
@@ -319,6 +323,9 @@ class SACAgent(object):
             nxt = self._next_key.get(key) if slot == 0 else None
             if nxt is not None:
                 self.core.prefetch_batch(buffer.ring, self._pool['idx_' + nxt], B)
+            if slot == 0 and key == self._early_key:
+                # this is the minibatch the critic and actor steps will reuse: both policy forwards ride in its feature step
+                self.core.prefetch_policy_early(self._pool['eps_crit'], self._pool['eps_act'])
             return
         if self._inject is not None:
             idx = torch.as_tensor(np.asarray(self._inject['idx'].pop(0)), dtype=torch.int32).to(self.core.device)
@@ -355,6 +362,7 @@ class SACAgent(object):
         c, W = self.core, self.world_size
         self._pool = None
         self._next_key = {}
+        self._early_key = None
         if self._inject is None and g and not os.environ.get('RLREP_NO_PROLOGUE'):
             self._fill_pools(buffer, B, g)          # includes begin_train (rlrep_train_prologue)
         else:

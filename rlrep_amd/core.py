@@ -209,6 +209,13 @@ class HipCore:
             check(rc, 'prefetch_policy')
         return rc == 1
 
+    def prefetch_policy_early(self, eps_critic, eps_actor):
+        """Arm the NEXT feature step (the last one of this train()) to also run both policy forwards."""
+        rc = lib.rlrep_prefetch_policy_early(self.h, _ptr(eps_critic), _ptr(eps_actor))
+        if rc < 0:
+            check(rc, 'prefetch_policy_early')
+        return rc == 1
+
     def critic_step(self, eps):
         check(lib.rlrep_critic_step(self.h, _ptr(eps), _stream()), 'critic_step')
 

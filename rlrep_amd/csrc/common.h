@@ -33,6 +33,7 @@ enum Epi : int {
 #define FLAG_BIASGRAD 2    // EPI_DW: also emit the bias gradient (only by column-tile 0)
 #define FLAG_DYN_EPS 4     // x2 is the per-call noise pointer (patched into the kernel arguments at launch)
 #define FLAG_DYN_EPS2 8    // x2 is the noise pointer of the policy forward that rides along (rlrep_prefetch_policy)
+#define FLAG_DYN_EPS3 16   // x2 is the critic step's policy noise while that policy rides in the last feature step
 
 struct GroupCfg;
 struct GemmTask {

@@ -302,14 +302,23 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     float* GH2f = ws.f((size_t)B * Hv); float* GH1f = ws.f((size_t)B * Hv);
     const int nblk_kl = (int)(((long long)B * F + 255) / 256), nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
     float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse);
-    {
-        Program& p = ag->feat_bwd;
+    // actor buffers are needed by the feature program variant that carries the policy forwards
+    ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
+    ActorBufs ab_pi = alloc_actor(b, B, A, Ha);                                              // policy on s  (actor step)
+    auto feature_program = [&](Program& p, bool early) {
         GemmTask te[3], tf[3];
         gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
         gauss_tasks(ag, false, "f", s0.XF, SA, SA, gf, tf);
-        b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
-        b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
-        b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
+        if (early) {
+            b.fwd_stage(p, {te[0], tf[0], actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "enc.l1 f.l1 actor.l1(s') actor.l1(s)");
+            b.fwd_stage(p, {te[1], tf[1], actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi)}, "enc.l2 f.l2 actor.l2 x2");
+            b.fwd_stage(p, {te[2], tf[2], policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
+                        "enc.heads f.heads actor.head x2 + policy");
+        } else {
+            b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
+            b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
+            b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
+        }
         VaeMid vm; memset(&vm, 0, sizeof(vm));
         vm.EH = ge.HH; vm.FH = gf.HH; vm.Z = Z; vm.GEH = GEH; vm.GFH = GFH; vm.partial = part_kl;
         vm.B = B; vm.F = F; vm.nblk = nblk_kl; vm.scale = ag->inv_batch() / (float)F; vm.step = ag->adam_step + 0;
@@ -339,13 +348,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             const LT& fl = ag->L.get("f.log_std_linear.bias");
             b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
         }
-        const std::vector<FinTask> feat_fins = {
+        b.stash_fin({
             Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
             Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
             Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
             Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
-            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)};
-        b.stash_fin(feat_fins);
+            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)});
         b.dw_stage(p, {Builder::dw(GDH, S + 1, S + 1, D1, Hv, Hv, B, Gw("decoder.state_linear.weight"), Hv, Gw("decoder.state_linear.bias")),
                        Builder::dw(GD1, Hv, Hv, Z, F, F, B, Gw("decoder.l1.weight"), F, Gw("decoder.l1.bias")),
                        Builder::dw(GEH, 2 * F, 2 * F, ge.H2, Hv, Hv, B, Gw("encoder.mean_linear.weight"), Hv, Gw("encoder.mean_linear.bias")),
@@ -355,7 +363,18 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(GH1e, Hv, Hv, s0.XE, KE, KE, B, Gw("encoder.l1.weight"), KE, Gw("encoder.l1.bias")),
                        Builder::dw(GH1f, Hv, Hv, s0.XF, SA, SA, B, Gw("f.l1.weight"), SA, Gw("f.l1.bias"))}, "feature dW");
         b.clear_polyak();
+    };
+    feature_program(ag->feat_bwd, false);
+    const bool can_hoist = policy_fusable(ag) && !getenv("RLREP_NO_HOIST");
+    if (can_hoist && !getenv("RLREP_NO_EARLY_POLICY")) feature_program(ag->feat_bwd_h, true);
+    {
         // apply: Adam over (encoder, decoder, f) + Polyak f -> f_target (vlsac_agent.py:152-154, 240-242)
+        const std::vector<FinTask> feat_fins = {
+            Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
+            Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
+            Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
+            Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
+            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)};
         const LT& f0 = ag->L.get("f.l1.weight");
         const LT& flast = ag->L.get("f.log_std_linear.bias");
         const int64_t fn = flast.off + flast.rows - f0.off;
@@ -363,8 +382,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     }
 
     // ---- critic / actor shared buffers ----
-    ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
-    ActorBufs ab_pi = alloc_actor(b, B, A, Ha);                                              // policy on s  (actor step)
     GaussBufs gt{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s, a)
     GaussBufs gn{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s', a')
     GaussBufs gp{ws.f((size_t)B * Hv), ws.f((size_t)B * Hv), ws.f((size_t)B * 2 * F)};      // f_target(s, a_pi)
@@ -413,12 +430,16 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     const std::vector<FinTask> cfins = {
         Builder::fin_sum(part_q + 0, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1_LOSS), Builder::fin_sum(part_q + 1, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2_LOSS),
         Builder::fin_sum(part_q + 2, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1), Builder::fin_sum(part_q + 3, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2)};
-    auto critic_program = [&](Program& p, bool hoist) {
+    auto critic_program = [&](Program& p, int hoist) {      // 0: plain, 1: carries the actor step's forward half, 2: both policies ran already
         GemmTask tt[3], tn[3], tp[3];
         gauss_tasks(ag, true, "f_target", s0.XF, SA, SA, gt, tt);
         gauss_tasks(ag, true, "f_target", s0.XF2, SA, SA, gn, tn);
         gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gp, tp);
-        if (hoist) {
+        if (hoist == 2) {
+            b.fwd_stage(p, {tt[0], tn[0], tp[0]}, "ft.l1(s,a) ft.l1(s',a') ft.l1(s,a_pi)");
+            b.fwd_stage(p, {tt[1], tn[1], tp[1]}, "ft.l2 x3");
+            b.fwd_stage(p, {tt[2], tn[2], tp[2]}, "ft.heads x3");
+        } else if (hoist == 1) {
             b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi), tt[0]}, "actor.l1(s') actor.l1(s) ft.l1(s,a)");
             b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi), tt[1]}, "actor.l2 x2 ft.l2");
             b.fwd_stage(p, {policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2), tt[2]},
@@ -483,8 +504,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dw(&nb, total, st); }, "noise critic dW l1/l4"});
         }
     };
-    critic_program(ag->critic_bwd, false);
-    if (policy_fusable(ag) && !getenv("RLREP_NO_HOIST")) critic_program(ag->critic_bwd_h, true);
+    critic_program(ag->critic_bwd, 0);
+    if (can_hoist) critic_program(ag->critic_bwd_h, 1);
+    if (!ag->feat_bwd_h.stages.empty()) critic_program(ag->critic_bwd_h2, 2);
     b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, cfins, "adam critic");
     critic_apply_folded(b, ag, "critic_target.l1.weight", cfins);
 
@@ -536,10 +558,11 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2})
         p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
     ag->pf_armed = ag->pf_done = false;
+    ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     ag->feat_cuts.clear();
     Builder b(ag);
     const int S = ag->d.state_dim, A = ag->d.action_dim;
@@ -707,6 +730,7 @@ int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, vo
     if (!ag || !bt || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("set_batch: bad argument"); return RLREP_ERR_ARG; }
     if (slot == 0) { ag->pf_done = false; ag->pf_armed = false; }
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
+    ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, bt->batch);
     if (rc) return rc;
     Slot& s = ag->slot[slot];
@@ -753,6 +777,7 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
         rl_set_error("train_prologue: bad argument"); return RLREP_ERR_ARG;
     }
     ag->pi_ready = nullptr; ag->hoist_req = nullptr; ag->pf_armed = false; ag->pf_done = false;
+    ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;
     TrainPrologue tp; memset(&tp, 0, sizeof(tp));
@@ -778,6 +803,7 @@ int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev
     }
     if (slot == 0) ag->pf_done = false;
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
+    ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;
     Slot& s = ag->slot[slot];
@@ -834,9 +860,25 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
     ag->pi_ready = nullptr;                                       // f_target is about to change
+    ag->early_ready_crit = ag->early_ready_act = nullptr;
+    if (ag->early_crit && !ag->feat_bwd_h.stages.empty()) {
+        ag->cur_eps3 = ag->early_crit; ag->cur_eps2 = ag->early_act;
+        ag->early_crit = ag->early_act = nullptr;
+        const int rc = run(ag, ag->feat_bwd_h, stream);
+        if (rc == 0) { ag->early_ready_crit = ag->cur_eps3; ag->early_ready_act = ag->cur_eps2; }
+        return rc;
+    }
+    ag->early_crit = ag->early_act = nullptr;
     return run(ag, ag->feat_bwd, stream);
 }
 int32_t rlrep_feature_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(true) return run(ag, ag->feat_apply, stream); }
+int32_t rlrep_prefetch_policy_early(rlrep_agent* ag, const float* eps_critic, const float* eps_actor) {
+    if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
+    ag->early_crit = ag->early_act = nullptr;
+    if (!eps_critic || !eps_actor || ag->feat_bwd_h.stages.empty() || ag->critic_bwd_h2.stages.empty()) return 0;
+    ag->early_crit = eps_critic; ag->early_act = eps_actor;
+    return 1;
+}
 int32_t rlrep_prefetch_policy(rlrep_agent* ag, const float* eps_actor) {
     if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
     ag->hoist_req = nullptr;
@@ -849,6 +891,14 @@ int32_t rlrep_critic_backward(rlrep_agent* ag, const float* eps, void* stream) {
     if (!eps) { rl_set_error("critic step needs eps[B,A]"); return RLREP_ERR_ARG; }
     ag->cur_eps = eps; ag->last_launches = 0;
     ag->pi_ready = nullptr;
+    if (ag->early_ready_crit && ag->early_ready_crit == eps) {      // both policy forwards already ran (last feature step)
+        const float* act_eps = ag->early_ready_act;
+        ag->early_ready_crit = ag->early_ready_act = nullptr; ag->hoist_req = nullptr;
+        const int rc = run(ag, ag->critic_bwd_h2, stream);
+        if (rc == 0) ag->pi_ready = act_eps;
+        return rc;
+    }
+    ag->early_ready_crit = ag->early_ready_act = nullptr;
     if (ag->hoist_req) {
         ag->cur_eps2 = ag->hoist_req; ag->hoist_req = nullptr;
         const int rc = run(ag, ag->critic_bwd_h, stream);
@@ -970,6 +1020,7 @@ static Program* prog_of(rlrep_agent* ag, int id) {
     switch (id) {
     case 0: return &ag->feat_bwd; case 1: return &ag->feat_apply; case 2: return &ag->critic_bwd; case 3: return &ag->critic_apply;
     case 4: return &ag->actor_bwd; case 5: return &ag->actor_apply; case 6: return &ag->upd_target; case 7: return &ag->critic_bwd_h;
+    case 8: return &ag->feat_bwd_h; case 9: return &ag->critic_bwd_h2;
     default: return nullptr;
     }
 }

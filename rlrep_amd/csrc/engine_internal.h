@@ -27,6 +27,12 @@ struct rlrep_agent {
     SlotFill pf_fill; bool pf_armed = false, pf_done = false; const float* pf_ring = nullptr; const int* pf_idx = nullptr;
     int* ticket = nullptr;
     const float* cur_eps2 = nullptr; const float* hoist_req = nullptr; const float* pi_ready = nullptr;
+    // One step further: when the critic / actor steps reuse the LAST feature step's minibatch (vlsac), BOTH policy
+    // forwards (on s' for the critic step, on s for the actor step) ride in that feature step's first three launches
+    // (feat_bwd_h) and the critic step starts with all three f_target forwards in the same launches (critic_bwd_h2).
+    Program feat_bwd_h, critic_bwd_h2;
+    const float* cur_eps3 = nullptr; const float* early_crit = nullptr; const float* early_act = nullptr;   // armed request
+    const float* early_ready_crit = nullptr; const float* early_ready_act = nullptr;                        // done by feat_bwd_h
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
@@ -109,7 +115,7 @@ struct Builder {
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         const int total = base_tile;
         bool dyn = false;
-        for (auto& t : tasks) dyn = dyn || (t.flags & (FLAG_DYN_EPS | FLAG_DYN_EPS2));
+        for (auto& t : tasks) dyn = dyn || (t.flags & (FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3));
         rlrep_agent* a = ag;
         if (dyn)
             p.stages.push_back({[=](hipStream_t st) {
@@ -117,6 +123,7 @@ struct Builder {
                 for (int q = 0; q < g2.ntasks; ++q) {
                     if (g2.t[q].flags & FLAG_DYN_EPS) g2.t[q].x2 = a->cur_eps;
                     if (g2.t[q].flags & FLAG_DYN_EPS2) g2.t[q].x2 = a->cur_eps2;
+                    if (g2.t[q].flags & FLAG_DYN_EPS3) g2.t[q].x2 = a->cur_eps3;
                 }
                 return rl_launch_gemm16(la, lb, nf, &g2, total, st);
             }, what});
@@ -205,7 +212,7 @@ struct Builder {
         p.stages.push_back({[=](hipStream_t st) {
             // a minibatch armed by rlrep_prefetch_batch is gathered by extra blocks of this launch
             const SlotFill* sf = a->pf_armed ? &a->pf_fill : nullptr;
-            if (sf) { a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; }
+            if (sf) { a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; a->early_ready_crit = a->early_ready_act = nullptr; }
             return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, st);
         }, what});
     }

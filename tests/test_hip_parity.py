@@ -325,6 +325,7 @@ def test_graph_prologue_and_batch_prefetch_are_equivalent(name):
                 core.fill_normal_dev(epool, 1.0, seed, eoff)
             core.train_prologue = prologue
             core.prefetch_batch = lambda ring, idx, B: False
+            core.prefetch_policy_early = lambda e1, e2: False
         infos = [agent.train(buf, c.B) for _ in range(4)]
         torch.cuda.synchronize()
         outs.append((infos, {k: v.numpy().copy() for k, v in core.state().items()}))
