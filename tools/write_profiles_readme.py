@@ -1,63 +1,59 @@
-# profiles, round 1
+#!/usr/bin/env python3
+"""Regenerate profiles/<tag>_README.md from the committed summaries (run after tools/summarize_profiles.py)."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'summarize_profiles.py'), tag], capture_output=True, text=True).stdout
+table = '\n'.join(l for l in out.split('\n\nbench:')[0].split('\n')[2:] if 'at::native' not in l)
+b = json.loads(open(os.path.join(ROOT, 'profiles', f'{tag}_bench.json')).read())
+pmc = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_summary.json')))
 
-All files here are produced by `python tools/summarize_profiles.py r01` (+ `tools/write_profiles_readme.py`) from
+
+def row(k):
+    d = pmc[k]; wc = max(d.get('SQ_WAVE_CYCLES', 0), 1)
+    return (f"| `{k}` | {d.get('SQ_INSTS_MFMA', 0):.0f} | {100 * d.get('SQ_WAIT_ANY', 0) / wc:.0f} % | {100 * d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / wc:.0f} % | "
+            f"{d.get('FETCH_SIZE', 0) / 1024:.1f} | {d.get('WRITE_SIZE', 0) / 1024:.1f} | {d.get('SQ_LDS_BANK_CONFLICT', 0):.0f} |")
+
+
+keys = [k for k in ('nc_fwd_kernel<1>', 'nc_dw_kernel', 'nc_dx_kernel<true>', 'gemm16_kernel<0, 0, 1, true, true>', 'gemm16_kernel<0, 1, 1, true, false>',
+                    'gemm16_kernel<1, 1, 4, false, false>', 'adam_kernel', 'train_prologue_kernel') if k in pmc]
+txt = f'''# profiles, round 1
+
+All files here are produced by `python tools/summarize_profiles.py {tag}` (+ `tools/write_profiles_readme.py`) from
 rocprofv3 output collected on one MI355X (gpurun box) with these commands (`cd /tmp; export TMPDIR=/tmp` first):
 
-* `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01b -- python3 bench.py --steps 300 --warmup 30 --no-cpu`
-  -> `r01_vlsac_b256_kernel_stats.csv` (workload vlsac_halfcheetah_f256_b256, hipGraph replay; 331 train() calls incl.
+* `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_{tag}b -- python3 bench.py --steps 300 --warmup 30 --no-cpu`
+  -> `{tag}_vlsac_b256_kernel_stats.csv` (workload vlsac_halfcheetah_f256_b256, hipGraph replay; 331 train() calls incl.
   capture/warm-up, plus bench.py's roofline loop: 220 extra critic-stage `nc_fwd_kernel` launches)
 * three separate `--pmc` passes, `--kernel-trace` only (`tools/_pmc.sh`, eager launches, 25 train() calls each)
-  -> `r01_pmc_summary.json` (per-kernel mean over dispatches of the per-dispatch sums)
-* un-profiled `python bench.py` on the same box -> `r01_bench.json`
+  -> `{tag}_pmc_summary.json` (per-kernel mean over dispatches of the per-dispatch sums)
+* un-profiled `python bench.py` on the same box -> `{tag}_bench.json`
 
 | kernel (gemm16 template args: loader A, loader B, NF, 16-byte A, 16-byte B) | calls | avg us | % of GPU time |
 |---|---|---|---|
-| `gemm16_kernel<0, 1, 1, true, false>` | 6289 | 5.59 | 18.6 |
-| `nc_fwd_kernel<1>` | 882 | 31.83 | 14.9 |
-| `gemm16_kernel<0, 0, 1, true, true>` | 4303 | 5.60 | 12.8 |
-| `gemm16_kernel<0, 0, 2, true, true>` | 1986 | 7.68 | 8.1 |
-| `adam_kernel` | 1986 | 6.88 | 7.2 |
-| `gemm16_kernel<1, 1, 4, false, false>` | 1324 | 9.89 | 6.9 |
-| `nc_dw_kernel` | 331 | 27.27 | 4.8 |
-| `nc_dx_kernel<true>` | 331 | 23.57 | 4.1 |
-| `gemm16_kernel<0, 1, 1, false, false>` | 1324 | 5.49 | 3.9 |
-| `vae_mid_kernel` | 1324 | 4.78 | 3.4 |
-| `gemm16_kernel<0, 0, 1, false, false>` | 993 | 5.97 | 3.1 |
-| `gemm16_kernel<0, 0, 2, false, false>` | 662 | 6.50 | 2.3 |
-| `gemm16_kernel<0, 0, 4, true, true>` | 331 | 11.34 | 2.0 |
-| `gemm16_kernel<1, 1, 1, false, false>` | 662 | 5.60 | 2.0 |
-| `train_prologue_kernel` | 331 | 11.10 | 1.9 |
-| `qhead_critic_kernel` | 331 | 10.12 | 1.8 |
-| `qhead_actor_kernel` | 331 | 7.40 | 1.3 |
-| `__amd_rocclr_copyBuffer` | 384 | 4.34 | 0.9 |
+{table}
 
 Under rocprofv3 every dispatch interval includes the inter-kernel boundary (the trace shows zero gaps), so the small
 kernels read ~5.5 us each; un-profiled, a chain of trivial graph-captured kernels costs 1.77 us per launch on this box
 and the instrumented timeline (`tools/exp/gemm_timeline.py`) puts a gemm16 launch at 3.3-5.7 us of kernel span plus
 1.4-2.2 us to the first wave of the next launch.
 
-bench.py (un-profiled): **1819.77 train()/s**, 0.5495 ms per train().  Box-to-box spread of this number
+bench.py (un-profiled): **{b['value']} {b['unit']}**, {b['ms_per_step']} ms per train().  Box-to-box spread of this number
 over the gpurun pool is about 5 % (the same build measured 533 and 557 us per train() on two boxes).
 
-roofline: `{"bound": "mfma", "kernel": "nc_fwd_kernel (critic step, 4 heads)", "achieved": 78.76, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.5007, "traffic": 18077286, "us_per_launch": 34.08, "flop_per_launch": 2684354560.0}`
+roofline: `{json.dumps(b['roofline'])}`
 
-cpu_baseline: `{"value": 23.086, "unit": "train()/s", "cores": 16, "kind": "port", "sample": "200 train() calls of the same workload on the CPU oracle (torch 2.10.0+rocm7.0 CPU, 16 threads of 256 logical cores), 8.7 s"}`
+cpu_baseline: `{json.dumps(b['cpu_baseline'])}`
 
 `nc_fwd_kernel<1>` is launched twice per train() (critic step: 4 heads, 2.68 GFLOP; actor step: 2 heads, 1.34 GFLOP)
 plus 220 times by bench.py's roofline loop (critic-step launch), so its average above is a mix of ~34 us and ~21 us
 launches; `roofline.us_per_launch` times the critic-step launch alone with HIP events on the launch stream.
 
-## PMC counters (`r01_pmc_summary.json`), per launch
+## PMC counters (`{tag}_pmc_summary.json`), per launch
 
 | kernel | MFMA insts | WAIT_ANY / WAVE_CYCLES | VALU_MFMA_BUSY / WAVE_CYCLES | FETCH_SIZE MB (raw) | WRITE_SIZE MB | LDS bank-conflict cycles |
 |---|---|---|---|---|---|---|
-| `nc_fwd_kernel<1>` | 1248075 | 19 % | 64 % | 3.0 | 11.2 | 0 |
-| `nc_dw_kernel` | 655360 | 39 % | 68 % | 12.7 | 0.5 | 262144 |
-| `nc_dx_kernel<true>` | 655360 | 37 % | 77 % | 7.5 | 0.5 | 983040 |
-| `gemm16_kernel<0, 0, 1, true, true>` | 20344 | 65 % | 17 % | 1.5 | 0.3 | 0 |
-| `gemm16_kernel<0, 1, 1, true, false>` | 31151 | 59 % | 20 % | 3.0 | 0.4 | 0 |
-| `gemm16_kernel<1, 1, 4, false, false>` | 124928 | 45 % | 38 % | 9.5 | 1.9 | 0 |
-| `adam_kernel` | 0 | 80 % | 0 % | 3.3 | 4.9 | 0 |
+''' + '\n'.join(row(k) for k in keys) + '''
 
 VALU_MFMA_BUSY / (launch time x 1024 SIMDs x 2.2 GHz) is the chip-wide MFMA utilisation: 52 % for the critic-stage
 `nc_fwd` launch (matches `roofline.frac`), 37 % for `nc_dw`, 41 % for `nc_dx`.
@@ -74,3 +70,6 @@ against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs).  `nc_dw
 * `icache`, `ijump`  cold instruction fetch: no measurable penalty (straight-line or taken branches)
 * `loadlat`, `xcdlat`  first load of the previous kernel's output: 470 cycles same XCD, 810-2200 cycles other XCD;
   workgroup -> XCD placement is round-robin on blockIdx.x
+'''
+open(os.path.join(ROOT, 'profiles', f'{tag}_README.md'), 'w').write(txt)
+print('wrote', f'profiles/{tag}_README.md')
