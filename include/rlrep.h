@@ -272,6 +272,21 @@ int32_t rlrep_stage_count(rlrep_agent* agent, int32_t program);
 const char* rlrep_stage_name(rlrep_agent* agent, int32_t program, int32_t stage);
 int32_t rlrep_run_stage(rlrep_agent* agent, int32_t program, int32_t stage, void* stream);
 
+/* Unit-test hook: ONE product on the path's GEMM engines with caller buffers (tests/test_gemm_engines.py checks both
+ * engines against NumPy on every operand layout, epilogue, ragged edge and split-K plan).
+ *   C[R,Cn] = epilogue( sum_k opA(r,k) * opB(c,k) )
+ *   la / lb: 0 = row-major operand [rows, K] (ld = row stride), 1 = k-major operand [K, rows]
+ *   epi: 0 forward: act(acc + bias)        (act: 0 none, 1 relu, 2 elu, 3 sin (+ pre-activation to out2), 4 tanh)
+ *        1 dX:      acc * act'(aux), flags & 1: C += ...
+ *        3 dW:      acc, flags & 1: C += ..., flags & 2: out2[r] = sum_k opA(r,k) (bias gradient)
+ *   engine: 0 = 16-row tile engine (gemm16), 1 = LDS-tiled engine (gemm_lds); bt (0 auto, 64, 128) and splits
+ *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats).
+ * Returns 0, or RLREP_ERR_ARG when the engine cannot run the shape (alignment rules in gemm_lds.hip). */
+int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, int32_t lda, const float* b_dev, int32_t ldb,
+                   float* c_dev, int32_t ldc, int32_t rows, int32_t cols, int32_t inner, int32_t epi, int32_t act, int32_t flags,
+                   const float* bias_dev, const float* aux_dev, int32_t ldaux, float* out2_dev, int32_t bt, int32_t splits,
+                   float* workspace_dev, int64_t workspace_floats, void* stream);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 

@@ -68,6 +68,10 @@ struct GemmTask {
     // generic operands of the fused loss / policy epilogues
     const float* x0; const float* x1; const float* x2; float* y0; float* y1; const double* dptr;
     int ldx0, ldx1; float s0, s1;
+    // gemm_lds.hip only: split-K plan (splits > 1: partial tiles go to slab [splits][R][Cn], bias partials to
+    // bslab [splits][R]; the finishing launch adds them in split order) -- zero for gemm16 launches
+    int splits, kchunk, fin_base;
+    float* slab; float* bslab;
 };
 
 #define GEMM_MAX_TASKS 8

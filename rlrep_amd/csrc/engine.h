@@ -14,6 +14,11 @@
 // kernel launchers (defined next to the kernels)
 extern "C" {
 int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st);
+int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st);
+int rl_gemm_lds_align_ok(const GemmTask* t, int la, int lb);
+int rl_gemm_lds_dims_ok(const GemmTask* t, int la, int lb);
+int rl_gemm_lds_ptrs_ok(const GemmTask* t);
+void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* kchunk);
 int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st);
 int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
 int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);

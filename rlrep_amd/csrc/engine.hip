@@ -1042,6 +1042,45 @@ int32_t rlrep_run_stage(rlrep_agent* ag, int32_t program, int32_t stage, void* s
     return 0;
 }
 
+int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32_t lda, const float* B, int32_t ldb,
+                   float* Cm, int32_t ldc, int32_t R, int32_t Cn, int32_t K, int32_t epi, int32_t act, int32_t flags,
+                   const float* bias, const float* aux, int32_t ldaux, float* out2, int32_t bt, int32_t splits,
+                   float* wsp, int64_t ws_floats, void* stream) {
+    if (!A || !B || !Cm || R <= 0 || Cn <= 0 || K <= 0 || (epi != EPI_FWD && epi != EPI_DX && epi != EPI_DW)) { rl_set_error("gemm: bad argument"); return RLREP_ERR_ARG; }
+    GemmTask t; memset(&t, 0, sizeof(t));
+    t.scale = 1.f; t.A = A; t.lda = lda; t.B = B; t.ldb = ldb; t.C = Cm; t.ldc = ldc; t.R = R; t.Cn = Cn; t.K = K;
+    t.epi = epi; t.act = act; t.flags = flags & FLAG_ACCUM;
+    if (epi == EPI_FWD) { t.bias = bias; t.out2 = out2; t.ldout2 = ldc; }
+    if (epi == EPI_DX) { t.aux = aux; t.ldaux = ldaux; }
+    if (epi == EPI_DW && (flags & FLAG_BIASGRAD) && out2) { t.flags |= FLAG_BIASGRAD; t.out2 = out2; }
+    GemmBatch gb; memset(&gb, 0, sizeof(gb)); gb.ntasks = 1;
+    int rc;
+    if (engine == 0) {
+        t.tiles_c = (Cn + 15) / 16; t.ntiles = ((R + 15) / 16) * t.tiles_c; t.tile_base = 0;
+        gb.t[0] = t;
+        rc = rl_launch_gemm16(la, lb, 1, &gb, t.ntiles, (hipStream_t)stream);
+    } else {
+        if (!rl_gemm_lds_align_ok(&t, la, lb) || !rl_gemm_lds_ptrs_ok(&t)) { rl_set_error("gemm: shape/alignment not eligible for the LDS-tiled engine"); return RLREP_ERR_ARG; }
+        int pbt = 0, psp = 1, pkc = 0;
+        rl_gemm_lds_plan(&t, &pbt, &psp, &pkc);
+        if (bt == 64 || bt == 128) pbt = bt;
+        if (splits > 0) { psp = splits; pkc = ((K + psp - 1) / psp + 31) / 32 * 32; psp = (K + pkc - 1) / pkc; }
+        t.splits = psp; t.kchunk = pkc;
+        int fin = 0;
+        if (psp > 1) {
+            const bool bg = (t.flags & FLAG_BIASGRAD) != 0;
+            if (!wsp || ws_floats < (int64_t)psp * R * (Cn + 1)) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
+            t.slab = wsp; t.bslab = wsp + (size_t)psp * R * Cn; t.fin_base = 0;
+            fin = (int)(((long long)R * (Cn / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
+        }
+        t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
+        gb.t[0] = t;
+        rc = rl_launch_gemm_lds(pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
+    }
+    if (rc != 0) { rl_set_error("gemm: launch failed (%d)", rc); return rc < 0 ? RLREP_ERR_ARG : RLREP_ERR_HIP; }
+    return 0;
+}
+
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
 int32_t rlrep_last_launch_count(rlrep_agent* ag) { return ag ? ag->last_launches : 0; }
 

@@ -88,7 +88,51 @@ struct Builder {
         return t;
     }
 
+    // Route every task of a stage to the engine that suits its size: the LDS-tiled kernel (gemm_lds.hip; 128- or 64-wide
+    // tiles, split-K for small outputs with a long inner dimension) for the large layers of ctrlsac / spedersac /
+    // diffsrsac, the 16-row tile engine for everything else.  The routing and the split-K slabs depend on dimensions
+    // only, so the dry sizing pass and the real pass allocate identically; a task whose pointers turn out not to be
+    // 16-byte aligned simply stays on gemm16 and leaves its slab unused.
     void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
+        std::vector<GemmTask> small, big128, big64;
+        const bool combo = (la == LD_ROW && lb == LD_ROW) || (la == LD_ROW && lb == LD_COL) || (la == LD_COL && lb == LD_COL);
+        const bool use_lds = combo && !fused() && !getenv("RLREP_NO_GEMM_LDS");
+        for (auto& t : tasks) {
+            if (use_lds && rl_gemm_lds_dims_ok(&t, la, lb)) {
+                int bt = 0, sp = 1, kc = 0;
+                rl_gemm_lds_plan(&t, &bt, &sp, &kc);
+                const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
+                float* slab = sp > 1 ? ws.f((size_t)sp * t.R * t.Cn) : nullptr;
+                float* bslab = (sp > 1 && bias) ? ws.f((size_t)sp * t.R) : nullptr;
+                if (dry || rl_gemm_lds_ptrs_ok(&t)) {
+                    t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab;
+                    (bt == 128 ? big128 : big64).push_back(t);
+                    continue;
+                }
+            }
+            small.push_back(t);
+        }
+        if (!big128.empty()) gemm_lds_stage(p, la, lb, 128, big128, what);
+        if (!big64.empty()) gemm_lds_stage(p, la, lb, 64, big64, what);
+        if (!small.empty()) gemm_small(p, la, lb, small, what);
+    }
+    void gemm_lds_stage(Program& p, int la, int lb, int bt, std::vector<GemmTask> tasks, const char* what) {
+        int base = 0, fin = 0;
+        for (auto& t : tasks) {
+            t.tiles_c = (t.Cn + bt - 1) / bt;
+            t.ntiles = ((t.R + bt - 1) / bt) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
+            if (t.splits > 1) {
+                const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
+                t.fin_base = fin;
+                fin += (int)(((long long)t.R * (t.Cn / 4) + 255) / 256) + (bias ? (t.R + 255) / 256 : 0);
+            }
+        }
+        GemmBatch gb; memset(&gb, 0, sizeof(gb));
+        gb.ntasks = (int)tasks.size();
+        for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm_lds(bt, la, lb, &gb, base, fin, st); }, what});
+    }
+    void gemm_small(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
         // column fragments per workgroup: the widest tile that still leaves >= ~1.5 workgroups per CU; the
         // epilogues that need a whole row / per-tile partials in one fragment force NF = 1
         int nf = 1;

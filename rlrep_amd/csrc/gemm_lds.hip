@@ -1,0 +1,349 @@
+// gemm_lds: the LDS-tiled fp32-MFMA GEMM of the update path for the LARGE layers (gfx950).
+//
+// gemm16.hip gives every workgroup one 16 x 64 tile and streams operands L2 -> VGPR: right for the 256-wide layers of
+// the headline configuration (latency-bound), wrong for ctrlsac at F = 2048 / H = 1024, spedersac at M = 2048 and
+// diffsrsac's nabla-mu head (2048 x 512 x 96 256, 202 GFLOP per pass), where every operand element would be re-read
+// from L2 by 16..128 workgroups.  Here a workgroup (4 waves, 2 x 2) owns a BT x BT output tile (BT = 128 or 64),
+// the K loop walks 32-deep slices that are staged global -> VGPR -> LDS (double-buffered, ONE barrier per slice: the
+// loads of slice t+1 are issued before the MFMAs of slice t and written to the other buffer after them), and each
+// wave runs (BT/32)^2 accumulators of v_mfma_f32_16x16x4_f32 -- exact fp32, same peak as the VALU (157.3 TF).
+//
+// The same GemmTask table as gemm16 (common.h) drives it, with the three operand-layout combinations of the path:
+//   forward   Y = X W^T        A row-major [R,K],  B row-major [Cn,K]   (LD_ROW, LD_ROW)
+//   dX        dX = G W         A row-major [R,K],  B k-major   [K,Cn]   (LD_ROW, LD_COL)
+//   dW        dW = G^T X       A k-major   [K,R],  B k-major   [K,Cn]   (LD_COL, LD_COL)
+// LDS images: a row-major operand is kept [row][36] (k contiguous, +4 pad: the ds_read_b64 fragment reads of a
+// half-wave hit 32 distinct bank pairs), a k-major operand [k][BT+8] (row contiguous, the two k-rows a half-wave reads
+// sit 16 banks apart).  MFMA k-slots are permuted identically for A and B: MFMA m of an 8-deep group takes
+// k = 2*(lane>>4) + (m&1), so a row-major fragment is one 8-byte LDS read feeding two MFMAs.
+//
+// Small outputs with a long inner dimension (dX of the nabla-mu head: 2048 x 512 over K = 96 256; every M = 256 layer
+// of ctrlsac) are split along K over `splits` workgroups per tile; partial tiles go to a slab and a finishing launch
+// adds them in split order (deterministic) and applies the epilogue.  No float atomics anywhere.
+#include "common.h"
+#include "kparams.h"
+
+#define GL_BK 32
+#define GL_KCS 36
+
+template <int BT, int LD> struct GlTile {
+    static constexpr int RCS = BT + 8;
+    static constexpr int FLOATS = (LD == LD_ROW) ? BT * GL_KCS : GL_BK * RCS;
+    static constexpr int NL = BT / 32;          // 16-byte loads per thread per slice
+};
+
+// ---- staging: global -> registers (branch-free: clamped address, value zeroed by a select) ----------------------
+template <int BT, int LD>
+__device__ __forceinline__ void gl_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend,
+                                              f32x4 (&v)[BT / 32]) {
+#pragma unroll
+    for (int j = 0; j < BT / 32; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        if (LD == LD_ROW) {
+            const int row = idx >> 3, kc = (idx & 7) * 4;
+            const int r = min(base + row, lim - 1), k = min(k0 + kc, kend - 4);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
+            const bool ok = (k0 + kc) < kend;
+            v[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            constexpr int Q = BT / 4;
+            const int kk = idx / Q, i4 = (idx % Q) * 4;
+            const int k = min(k0 + kk, kend - 1), i = min(base + i4, lim - 4);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
+            const bool ok = (k0 + kk < kend) && (base + i4 < lim);
+            v[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+template <int BT, int LD>
+__device__ __forceinline__ void gl_stage_write(float* __restrict__ S, const f32x4 (&v)[BT / 32]) {
+#pragma unroll
+    for (int j = 0; j < BT / 32; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        if (LD == LD_ROW) {
+            const int row = idx >> 3, kc = (idx & 7) * 4;
+            *reinterpret_cast<f32x4*>(S + row * GL_KCS + kc) = v[j];
+        } else {
+            constexpr int Q = BT / 4;
+            const int kk = idx / Q, i4 = (idx % Q) * 4;
+            *reinterpret_cast<f32x4*>(S + kk * (BT + 8) + i4) = v[j];
+        }
+    }
+}
+
+// fragments of the j-th 8-deep group: f[t][e] = operand(row wbase + 16 t + i, k = 8 j + 2 kq + e)
+template <int BT, int LD, int T>
+__device__ __forceinline__ void gl_frag(const float* __restrict__ S, int wbase, int i, int kq, int j, float (&f)[T][2]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (LD == LD_ROW) {
+            const float2 x = *reinterpret_cast<const float2*>(S + (wbase + t * 16 + i) * GL_KCS + 8 * j + 2 * kq);
+            f[t][0] = x.x; f[t][1] = x.y;
+        } else {
+            const float* p = S + (8 * j + 2 * kq) * (BT + 8) + wbase + t * 16 + i;
+            f[t][0] = p[0]; f[t][1] = p[BT + 8];
+        }
+    }
+}
+
+// ---- epilogue of four consecutive output columns (shared by the main kernel and the split-K finisher) -----------
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ void gl_epilogue4(const GemmTask& t, int r, int c, f32x4 v) {
+    v *= t.scale;
+    float* cp = t.C + (size_t)r * t.ldc + c;
+    if (t.epi == EPI_FWD) {
+        if (t.bias) v += ld4(t.bias + c);
+        f32x4 y;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x = v[q];
+            switch (t.act) {
+            case ACT_RELU: y[q] = fmaxf(x, 0.f); break;
+            case ACT_ELU: y[q] = elu_f(x); break;
+            case ACT_SIN: y[q] = sinf(x); break;
+            case ACT_TANH: y[q] = tanhf(x); break;
+            default: y[q] = x;
+            }
+        }
+        if (t.act == ACT_SIN) st4(t.out2 + (size_t)r * t.ldout2 + c, v);
+        st4(cp, y);
+    } else if (t.epi == EPI_DX) {
+        if (t.r1u) v += t.r1u[r] * ld4(t.r1v + c);
+        if (t.act != ACT_NONE) {
+            const f32x4 a = ld4(t.aux + (size_t)r * t.ldaux + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                switch (t.act) {
+                case ACT_RELU: v[q] = a[q] > 0.f ? v[q] : 0.f; break;
+                case ACT_ELU: v[q] *= elu_grad_from_out(a[q]); break;
+                case ACT_SIN: v[q] *= cosf(a[q]); break;
+                case ACT_TANH: v[q] *= (1.f - a[q] * a[q]); break;
+                default: break;
+                }
+            }
+        }
+        if (t.flags & FLAG_ACCUM) v += ld4(cp);
+        st4(cp, v);
+    } else {            // EPI_DW
+        if (t.flags & FLAG_ACCUM) v += ld4(cp);
+        st4(cp, v);
+    }
+}
+
+// bijective XCD remap: workgroups with equal (index % 8) share an XCD; give each class a contiguous run of tiles
+__device__ __forceinline__ int gl_xcd_remap(int local, int n) {
+    const int q = n >> 3, r = n & 7, x = local & 7, y = local >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+}
+
+template <int BT, int LA, int LB>
+__global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(GemmBatch gb) {
+    constexpr int WT = BT / 2, TT = WT / 16;
+    constexpr int SA = GlTile<BT, LA>::FLOATS, SB = GlTile<BT, LB>::FLOATS;
+    constexpr int EPF = 4 * WT * (WT + 4);
+    constexpr int LDSF = (2 * (SA + SB) > EPF) ? 2 * (SA + SB) : EPF;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+
+    const int bid = blockIdx.x;
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    const GemmTask& t = gb.t[ti];
+    const float* const pA = t.A; const float* const pB = t.B;
+    const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
+    const int tiles_c = t.tiles_c, splits = t.splits, kchunk = t.kchunk;
+    const int tiles_r = (R + BT - 1) / BT;
+
+    const int local = gl_xcd_remap(bid - t.tile_base, t.ntiles);
+    const int per_split = tiles_r * tiles_c;
+    const int split = local / per_split, rem = local - split * per_split;
+    const int tc = rem / tiles_r, tr = rem - tc * tiles_r;
+    const int r0 = tr * BT, c0 = tc * BT;
+    const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg + GL_BK - 1) / GL_BK;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int i = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[TT][TT];
+#pragma unroll
+    for (int a = 0; a < TT; ++a)
+#pragma unroll
+        for (int b = 0; b < TT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float asum[TT];
+#pragma unroll
+    for (int a = 0; a < TT; ++a) asum[a] = 0.f;
+
+    f32x4 va[BT / 32], vb[BT / 32];
+    gl_stage_load<BT, LA>(pA, lda, r0, R, kbeg, kend, va);
+    gl_stage_load<BT, LB>(pB, ldb, c0, Cn, kbeg, kend, vb);
+    gl_stage_write<BT, LA>(lds, va);
+    gl_stage_write<BT, LB>(lds + SA, vb);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // slice kt+1 (past the end: a clamped, zeroed re-read that nobody consumes) -- issued before the MFMAs of slice kt
+        const int kn = kbeg + GL_BK * (kt + 1);
+        gl_stage_load<BT, LA>(pA, lda, r0, R, kn, kend, va);
+        gl_stage_load<BT, LB>(pB, ldb, c0, Cn, kn, kend, vb);
+        const float* As = lds + cur * (SA + SB);
+        const float* Bs = As + SA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float fa[TT][2], fb[TT][2];
+            gl_frag<BT, LA, TT>(As, wr * WT, i, kq, j, fa);
+            gl_frag<BT, LB, TT>(Bs, wc * WT, i, kq, j, fb);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int a = 0; a < TT; ++a)
+#pragma unroll
+                    for (int b = 0; b < TT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+            if (LA == LD_COL) {
+#pragma unroll
+                for (int a = 0; a < TT; ++a) asum[a] += fa[a][0] + fa[a][1];
+            }
+        }
+        float* Sn = lds + (cur ^ 1) * (SA + SB);
+        gl_stage_write<BT, LA>(Sn, va);
+        gl_stage_write<BT, LB>(Sn + SA, vb);
+        __syncthreads();
+    }
+
+    // bias gradient (EPI_DW): row sums of operand A, taken from the fragments the column-0 waves of column-tile 0 consumed
+    if (LA == LD_COL && t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && tc == 0 && wc == 0) {
+#pragma unroll
+        for (int a = 0; a < TT; ++a) {
+            float s = asum[a];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const int r = r0 + wr * WT + a * 16 + lane;
+            if (lane < 16 && r < R) {
+                if (splits > 1) t.bslab[(size_t)split * R + r] = s; else t.out2[r] = s;
+            }
+        }
+    }
+
+    // accumulators -> this wave's LDS patch -> 16-byte row segments (coalesced stores, vector epilogue operands)
+    float* E = lds + w * (WT * (WT + 4));
+#pragma unroll
+    for (int a = 0; a < TT; ++a)
+#pragma unroll
+        for (int b = 0; b < TT; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) E[(a * 16 + 4 * kq + q) * (WT + 4) + b * 16 + i] = acc[a][b][q];
+    constexpr int LPR = WT / 4, RPI = 64 / LPR;
+#pragma unroll 4
+    for (int it = 0; it < WT / RPI; ++it) {
+        const int rr = it * RPI + lane / LPR, cc = (lane % LPR) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * (WT + 4) + cc);
+        const int r = r0 + wr * WT + rr, c = c0 + wc * WT + cc;
+        if (r < R && c < Cn) {
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * Cn + c, v);
+            else gl_epilogue4(t, r, c, v);
+        }
+    }
+}
+
+// split-K finisher: out = epilogue(sum over splits, in split order); bias gradient likewise
+__global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GemmBatch gb) {
+    const int bid = blockIdx.x;
+    int ti = -1;
+#pragma unroll
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && gb.t[q].splits > 1 && bid >= gb.t[q].fin_base) ti = q;
+    if (ti < 0) return;
+    const GemmTask& t = gb.t[ti];
+    const int lb = bid - t.fin_base;
+    const int R = t.R, Cn = t.Cn, C4 = Cn >> 2;
+    const long long nvec = (long long)R * C4;
+    const int nb_main = (int)((nvec + 255) / 256);
+    if (lb < nb_main) {
+        const long long e = (long long)lb * 256 + threadIdx.x;
+        if (e >= nvec) return;
+        const int r = (int)(e / C4), c = (int)(e - (long long)r * C4) * 4;
+        const float* p = t.slab + (size_t)r * Cn + c;
+        const size_t stride = (size_t)R * Cn;
+        f32x4 v = ld4(p);
+        for (int s = 1; s < t.splits; ++s) v += ld4(p + s * stride);
+        gl_epilogue4(t, r, c, v);
+    } else if (t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD)) {
+        const int r = (lb - nb_main) * 256 + threadIdx.x;
+        if (r >= R) return;
+        float s = t.bslab[r];
+        for (int q = 1; q < t.splits; ++q) s += t.bslab[(size_t)q * R + r];
+        t.out2[r] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int BT>
+static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_ROW, LD_ROW>), g, dim3(256), 0, st, gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_ROW, LD_COL>), g, dim3(256), 0, st, gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_COL, LD_COL>), g, dim3(256), 0, st, gb);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
+extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st) {
+    if (total_tiles <= 0) return 0;
+    int rc = bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb);
+    if (rc != 0) return rc;
+    if (fin_blocks > 0) {
+        hipLaunchKernelGGL(gemm_lds_fin_kernel, dim3(fin_blocks), dim3(256), 0, st, *gb);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}
+
+// Can this task run here?  Alignment rules (16-byte operand / epilogue vectors) ...
+extern "C" int rl_gemm_lds_align_ok(const GemmTask* t, int la, int lb) {
+    if (t->epi != EPI_FWD && t->epi != EPI_DX && t->epi != EPI_DW) return 0;
+    if (t->ad_p) return 0;
+    if ((t->K & 3) || (t->Cn & 3) || (t->ldc & 3) || (t->lda & 3) || (t->ldb & 3)) return 0;
+    if (la == LD_COL && (t->R & 3)) return 0;
+    if (t->epi == EPI_DX && t->act != ACT_NONE && (t->ldaux & 3)) return 0;
+    if (t->epi == EPI_FWD && t->act == ACT_SIN && (t->ldout2 & 3)) return 0;
+    return 1;
+}
+// ... and is it large enough to be worth leaving the latency-tuned 16-row engine?  Judged by dimensions alone, so
+// that the dry sizing pass and the real pass of the program builder agree.
+extern "C" int rl_gemm_lds_dims_ok(const GemmTask* t, int la, int lb) {
+    if (!rl_gemm_lds_align_ok(t, la, lb) || t->K < 64) return 0;
+    return 2.0 * t->R * t->Cn * t->K >= 2.5e8;
+}
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+extern "C" int rl_gemm_lds_ptrs_ok(const GemmTask* t) {
+    if (!al16(t->A) || !al16(t->B) || !al16(t->C)) return 0;
+    if (t->epi == EPI_FWD && t->bias && !al16(t->bias)) return 0;
+    if (t->epi == EPI_FWD && t->act == ACT_SIN && !al16(t->out2)) return 0;
+    if (t->epi == EPI_DX && t->act != ACT_NONE && !al16(t->aux)) return 0;
+    if (t->epi == EPI_DX && t->r1u && !al16(t->r1v)) return 0;
+    return 1;
+}
+// tile edge and split count for a task (dimensions only)
+extern "C" void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* kchunk) {
+    auto tiles = [&](int b) { return (long long)((t->R + b - 1) / b) * ((t->Cn + b - 1) / b); };
+    auto spl = [&](int b) {
+        const long long n = tiles(b);
+        long long s = (256 + n - 1) / n;
+        const long long mx = t->K / 256 > 1 ? t->K / 256 : 1;
+        if (s > mx) s = mx;
+        if (s > 32) s = 32;
+        if (s < 1) s = 1;
+        return (int)s;
+    };
+    int b = 128, s = spl(128);
+    if (tiles(128) * s < 256) { b = 64; s = spl(64); }
+    int kc = ((t->K + s - 1) / s + GL_BK - 1) / GL_BK * GL_BK;
+    s = (t->K + kc - 1) / kc;
+    *bt = b; *splits = s; *kchunk = kc;
+}

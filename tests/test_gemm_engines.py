@@ -1,0 +1,168 @@
+"""GPU unit tests of the path's two GEMM engines through the C ABI (rlrep_gemm): the 16-row tile engine (gemm16.hip)
+and the LDS-tiled engine (gemm_lds.hip) against a float64 NumPy product, on every operand layout the step programs
+use (forward X W^T, dX = G W, dW = G^T X), every generic epilogue, ragged tile edges and every split-K plan.
+
+Tolerance: 1e-5 relative L2 per output (fp32 MFMA is an exact fma chain; the only difference to NumPy is summation
+order), well inside the 1e-4 parity bar of BASELINE.json."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ACT = {'none': 0, 'relu': 1, 'elu': 2, 'sin': 3, 'tanh': 4}
+
+
+def _act(x, a):
+    if a == 'relu':
+        return np.maximum(x, 0)
+    if a == 'elu':
+        return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    if a == 'sin':
+        return np.sin(x)
+    if a == 'tanh':
+        return np.tanh(x)
+    return x
+
+
+def _dact(aux, a):
+    if a == 'relu':
+        return (aux > 0).astype(np.float64)
+    if a == 'elu':
+        return np.where(aux > 0, 1.0, aux + 1.0)
+    if a == 'sin':
+        return np.cos(aux)
+    if a == 'tanh':
+        return 1.0 - aux * aux
+    return np.ones_like(aux)
+
+
+def _dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0):
+    """mode: 'fwd' (A [R,K], B [Cn,K]), 'dx' (A [R,K], B [K,Cn]), 'dw' (A [K,R], B [K,Cn]).  Returns (got, want, extra)."""
+    from rlrep_amd import _lib
+    rs = np.random.RandomState(seed)
+    la, lb = {'fwd': (0, 0), 'dx': (0, 1), 'dw': (1, 1)}[mode]
+    A = rs.standard_normal((K, R) if la else (R, K)).astype(np.float32)
+    Bm = rs.standard_normal((K, Cn) if lb else (Cn, K)).astype(np.float32)
+    A64 = (A.T if la else A).astype(np.float64)
+    B64 = (Bm.T if lb else Bm).astype(np.float64)
+    A = (A / np.sqrt(K)).astype(np.float32)           # keep outputs O(1)
+    prod = (A.T if la else A).astype(np.float64) @ B64.T
+    C0 = rs.standard_normal((R, Cn)).astype(np.float32)
+    dA, dB, dC = _dev(A), _dev(Bm), _dev(C0)
+    bias_v = aux = out2 = None
+    epi = {'fwd': 0, 'dx': 1, 'dw': 3}[mode]
+    flags = 1 if accum else 0
+    extra_want = None
+    if mode == 'fwd':
+        bias_v = rs.standard_normal(Cn).astype(np.float32) if bias else None
+        pre = prod + (bias_v.astype(np.float64) if bias else 0.0)
+        want = _act(pre, act)
+        out2 = torch.zeros(R, Cn, device='cuda')
+        if act == 'sin':
+            extra_want = pre
+    elif mode == 'dx':
+        aux = rs.standard_normal((R, Cn)).astype(np.float32)
+        want = prod * _dact(aux.astype(np.float64), act) + (C0 if accum else 0.0)
+    else:
+        want = prod + (C0 if accum else 0.0)
+        out2 = torch.zeros(R, device='cuda')
+        flags |= 2
+        extra_want = (A.T if la else A).astype(np.float64).sum(axis=1)
+    d_bias = _dev(bias_v) if bias_v is not None else None
+    d_aux = _dev(aux) if aux is not None else None
+    # split-K slabs: splits * R * (Cn + 1) floats; the automatic plan never exceeds ~256 tiles' worth beyond the output
+    ws_floats = splits * R * (Cn + 1) if splits else min(32 * R * (Cn + 1), 5_000_000 + 2 * (R + 128) * (Cn + 129))
+    ws = torch.zeros(max(1, ws_floats), device='cuda')
+    rc = _lib.lib.rlrep_gemm(engine, la, lb, _ptr(dA), dA.shape[1], _ptr(dB), dB.shape[1], _ptr(dC), Cn, R, Cn, K, epi, ACT[act], flags,
+                             _ptr(d_bias), _ptr(d_aux), Cn, _ptr(out2), bt, splits, _ptr(ws), ws.numel(),
+                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'gemm')
+    torch.cuda.synchronize()
+    got = dC.cpu().numpy().astype(np.float64)
+    extra = None
+    if extra_want is not None:
+        extra = (out2.cpu().numpy().astype(np.float64), extra_want)
+    return got, want, extra
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def check(engine, mode, R, Cn, K, **kw):
+    got, want, extra = run_gemm(engine, mode, R, Cn, K, **kw)
+    assert np.all(np.isfinite(got)), (engine, mode, R, Cn, K, kw)
+    assert rel(got, want) < 1e-5, (engine, mode, R, Cn, K, kw, rel(got, want))
+    if extra is not None:
+        assert rel(extra[0], extra[1]) < 1e-5, ('second output', engine, mode, R, Cn, K, kw, rel(extra[0], extra[1]))
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+@pytest.mark.parametrize('bt', [64, 128])
+def test_lds_engine_layouts_and_tiles(mode, bt):
+    """exact multiples of the tile, one split"""
+    check(1, mode, 256, 256, 128, bt=bt, splits=1, seed=1)
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+@pytest.mark.parametrize('bt', [64, 128])
+def test_lds_engine_ragged_edges(mode, bt):
+    """rows / columns / inner length that end inside a tile and inside a 32-deep slice (dW needs R % 4 == 0)"""
+    check(1, mode, 148, 92, 100, bt=bt, splits=1, seed=2)
+    check(1, mode, 36, 260, 68, bt=bt, splits=1, seed=3)
+    if mode != 'dw':
+        check(1, mode, 33, 64, 64, bt=bt, splits=1, seed=4)        # odd row count (row-major A only)
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+@pytest.mark.parametrize('splits', [2, 3, 7])
+def test_lds_engine_split_k(mode, splits):
+    """split-K slabs + finishing launch, including a last split shorter than the others and K not a multiple of 32"""
+    check(1, mode, 128, 192, 708, bt=64, splits=splits, seed=5, accum=(mode != 'fwd'))
+    check(1, mode, 200, 128, 1024, bt=128, splits=splits, seed=6)
+
+
+@pytest.mark.parametrize('act', ['relu', 'elu', 'sin', 'tanh'])
+def test_lds_engine_epilogues(act):
+    check(1, 'fwd', 192, 128, 96, act=act, bt=64, splits=1, seed=7)
+    check(1, 'fwd', 192, 128, 512, act=act, bt=64, splits=2, seed=8)
+    check(1, 'dx', 192, 128, 96, act=act, bt=128, splits=1, seed=9, accum=True)
+    check(1, 'dx', 192, 128, 512, act=act, bt=64, splits=4, seed=10)
+    check(1, 'fwd', 64, 64, 64, act='none', bias=False, bt=64, splits=1, seed=11)
+
+
+def test_lds_engine_auto_plan_matches_path_shapes():
+    """the shapes the step programs actually route here, with the planner's own tile / split choice"""
+    check(1, 'fwd', 256, 1024, 1024, act='elu', seed=12)        # ctrlsac phi.l2 (M = 256: 64-wide tiles, split-K 4)
+    check(1, 'dx', 256, 1024, 2048, act='elu', seed=13)         # ctrlsac phi.l3 dx
+    check(1, 'dw', 1024, 1024, 256, seed=14)                    # ctrlsac phi.l2 dW
+    check(1, 'fwd', 2048, 512, 512, act='elu', seed=15)         # spedersac phi layer (both batches)
+    check(1, 'fwd', 2048, 2560, 512, seed=16)                   # diffsrsac nabla-mu head (scaled-down width)
+    check(1, 'dx', 2048, 512, 2560, act='elu', seed=17)         # ... its dX: small output, long inner dimension
+    check(1, 'dw', 2560, 512, 2048, seed=18)
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+def test_engines_agree(mode):
+    """the two engines compute the same product (different summation order only)"""
+    a, want, _ = run_gemm(0, mode, 96, 80, 160, seed=20)
+    b, _, _ = run_gemm(1, mode, 96, 80, 160, bt=64, splits=1, seed=20)
+    assert rel(a, want) < 1e-5 and rel(b, want) < 1e-5 and rel(a, b) < 1e-5
+
+
+def test_lds_engine_rejects_unaligned_shapes():
+    from rlrep_amd import _lib
+    x = torch.zeros(64 * 64, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    # inner length not a multiple of 4
+    rc = _lib.lib.rlrep_gemm(1, 0, 0, x.data_ptr(), 30, x.data_ptr(), 30, x.data_ptr(), 64, 16, 64, 30, 0, 0, 0, None, None, 0, None, 0, 0, None, 0, st)
+    assert rc < 0 and b'not eligible' in _lib.lib.rlrep_last_error()
