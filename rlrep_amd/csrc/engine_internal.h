@@ -101,9 +101,9 @@ struct Builder {
             if (use_lds && rl_gemm_lds_dims_ok(&t, la, lb)) {
                 int bt = 0, sp = 1, kc = 0;
                 rl_gemm_lds_plan(&t, &bt, &sp, &kc);
-                const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
+                // (the bias-gradient flag depends on a pointer that is null in the dry pass: reserve for every dW task)
                 float* slab = sp > 1 ? ws.f((size_t)sp * t.R * t.Cn) : nullptr;
-                float* bslab = (sp > 1 && bias) ? ws.f((size_t)sp * t.R) : nullptr;
+                float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
                 if (dry || rl_gemm_lds_ptrs_ok(&t)) {
                     t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab;
                     (bt == 128 ? big128 : big64).push_back(t);

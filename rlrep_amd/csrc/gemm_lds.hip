@@ -329,17 +329,19 @@ extern "C" int rl_gemm_lds_ptrs_ok(const GemmTask* t) {
     if (t->epi == EPI_DX && t->r1u && !al16(t->r1v)) return 0;
     return 1;
 }
-// tile edge and split count for a task (dimensions only)
+// tile edge and split count for a task (dimensions only).  128-wide tiles run two workgroups per CU, so a grid that
+// already has >= 256 of them is left alone and a smaller one is split along K towards 512 workgroups (each split keeps
+// at least eight 32-deep slices); outputs too small for that use 64-wide tiles under the same rule.
 extern "C" void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* kchunk) {
     auto tiles = [&](int b) { return (long long)((t->R + b - 1) / b) * ((t->Cn + b - 1) / b); };
     auto spl = [&](int b) {
         const long long n = tiles(b);
-        long long s = (256 + n - 1) / n;
+        if (n >= 256) return 1;
+        long long s = (512 + n - 1) / n;
         const long long mx = t->K / 256 > 1 ? t->K / 256 : 1;
         if (s > mx) s = mx;
         if (s > 32) s = 32;
-        if (s < 1) s = 1;
-        return (int)s;
+        return (int)(s < 1 ? 1 : s);
     };
     int b = 128, s = spl(128);
     if (tiles(128) * s < 256) { b = 64; s = spl(64); }
