@@ -11,7 +11,7 @@ import re
 import torch  # noqa: F401  (must precede the CDLL load, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'librlrep_hip.so')
+LIB_PATH = os.environ.get('RLREP_LIB') or os.path.join(_HERE, 'lib', 'librlrep_hip.so')     # RLREP_LIB: A/B builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'rlrep.h')
 
 ALG = {'sac': 0, 'vlsac': 1, 'ctrlsac': 2, 'spedersac': 3, 'diffsrsac': 4}

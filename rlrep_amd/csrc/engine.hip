@@ -1064,6 +1064,7 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         int pbt = 0, psp = 1, pkc = 0;
         rl_gemm_lds_plan(&t, &pbt, &psp, &pkc);
         if (bt == 64 || bt == 128) pbt = bt;
+        if (engine == 2) pbt = 128;
         if (splits > 0) { psp = splits; pkc = ((K + psp - 1) / psp + 31) / 32 * 32; psp = (K + pkc - 1) / pkc; }
         t.splits = psp; t.kchunk = pkc;
         int fin = 0;
@@ -1075,7 +1076,7 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         }
         t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;
-        rc = rl_launch_gemm_lds(pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
+        rc = rl_launch_gemm_lds(engine == 2 ? 129 : pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
     }
     if (rc != 0) { rl_set_error("gemm: launch failed (%d)", rc); return rc < 0 ? RLREP_ERR_ARG : RLREP_ERR_HIP; }
     return 0;

@@ -94,7 +94,7 @@ struct Builder {
     // only, so the dry sizing pass and the real pass allocate identically; a task whose pointers turn out not to be
     // 16-byte aligned simply stays on gemm16 and leaves its slab unused.
     void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
-        std::vector<GemmTask> small, big128, big64;
+        std::vector<GemmTask> small, big128, big64, bigx3;
         const bool combo = (la == LD_ROW && lb == LD_ROW) || (la == LD_ROW && lb == LD_COL) || (la == LD_COL && lb == LD_COL);
         const bool use_lds = combo && !fused() && !getenv("RLREP_NO_GEMM_LDS");
         for (auto& t : tasks) {
@@ -106,21 +106,25 @@ struct Builder {
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
                 if (dry || rl_gemm_lds_ptrs_ok(&t)) {
                     t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab;
-                    (bt == 128 ? big128 : big64).push_back(t);
+                    // the 200-GFLOP products (diffsrsac's nabla-mu head) run the same tile on the bf16 pipe (bf16x3, fp32-accurate)
+                    const bool x3 = bt == 128 && 2.0 * t.R * t.Cn * t.K >= 2e10 && !getenv("RLREP_NO_X3");
+                    (x3 ? bigx3 : bt == 128 ? big128 : big64).push_back(t);
                     continue;
                 }
             }
             small.push_back(t);
         }
+        if (!bigx3.empty()) gemm_lds_stage(p, la, lb, 129, bigx3, what);
         if (!big128.empty()) gemm_lds_stage(p, la, lb, 128, big128, what);
         if (!big64.empty()) gemm_lds_stage(p, la, lb, 64, big64, what);
         if (!small.empty()) gemm_small(p, la, lb, small, what);
     }
     void gemm_lds_stage(Program& p, int la, int lb, int bt, std::vector<GemmTask> tasks, const char* what) {
         int base = 0, fin = 0;
+        const int edge = bt == 129 ? 128 : bt;       // 129: the 128-wide tile on the bf16 pipe
         for (auto& t : tasks) {
-            t.tiles_c = (t.Cn + bt - 1) / bt;
-            t.ntiles = ((t.R + bt - 1) / bt) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
+            t.tiles_c = (t.Cn + edge - 1) / edge;
+            t.ntiles = ((t.R + edge - 1) / edge) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
             if (t.splits > 1) {
                 const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
                 t.fin_base = fin;

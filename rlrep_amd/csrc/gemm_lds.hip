@@ -281,6 +281,212 @@ __global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GemmBatch gb) {
     }
 }
 
+// ================================================================================================
+// bf16x3: the same 128 x 128 tile on the BF16 matrix pipe at fp32 accuracy, for the 200-GFLOP products of diffsrsac.
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the fp32-MFMA rate.  Every fp32 operand x is split EXACTLY into three
+// bf16 pieces x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significand bits), and the
+// product keeps the six partial products of weight >= 2^-16: a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2).  Each is exact in
+// the fp32 accumulator, the dropped ones are <= 2^-24 |a||b|: the result differs from the fp32-MFMA engine by a few ulp
+// (tests/test_gemm_engines.py holds both engines to 1e-5 of a float64 product; typical 2e-7) at 6/16 of its matrix
+// cycles.  The split runs once per staged element on the VALU (v_cvt_pk_bf16_f32 + shifts + subtracts, ~5.5 ops per
+// element) while the co-resident workgroup's waves hold the matrix pipe: one LDS buffer (three bf16 images per operand,
+// 80-byte rows: conflict-free 16-byte fragment reads), two barriers per 32-deep slice, two workgroups per CU.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef X3_STAGGER
+#define X3_STAGGER 24                /* s_sleep units (64 cycles) */
+#endif
+#define X3_RSB 80                    /* image row stride in bytes: 32 bf16 + 16 bytes pad */
+#define X3_IMGB (128 * X3_RSB)       /* bytes per image */
+
+__device__ __forceinline__ unsigned x3_pk(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+__device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = x3_pk(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = x3_pk(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = x3_pk(s0, s1);
+}
+
+// every thread stages four row slots x four consecutive k: e[slot][k]
+template <int LD>
+__device__ __forceinline__ void x3_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[4][4]) {
+    if (LD == LD_ROW) {
+        const int kc = (threadIdx.x & 7) * 4;
+        const int k = min(k0 + kc, kend - 4);
+        const bool ok = (k0 + kc) < kend;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[j][q] = ok ? x[q] : 0.f;
+        }
+    } else {
+        const int i4 = 4 * (threadIdx.x & 31), kg = 4 * (threadIdx.x >> 5);
+        const int i = min(base + i4, lim - 4);
+        const bool iok = (base + i4) < lim;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = min(k0 + kg + q, kend - 1);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
+            const bool ok = iok && (k0 + kg + q) < kend;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r][q] = ok ? x[r] : 0.f;
+        }
+    }
+}
+template <int LD>
+__device__ __forceinline__ void x3_stage_write(unsigned char* __restrict__ img, const float (&e)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (LD == LD_ROW) ? (int)(threadIdx.x >> 3) + 32 * j : 4 * (int)(threadIdx.x & 31) + j;
+        const int kc = (LD == LD_ROW) ? (int)(threadIdx.x & 7) * 4 : 4 * (int)(threadIdx.x >> 5);
+        u32x2 hi, mid, lo;
+        unsigned h, m, l;
+        x3_split2(e[j][0], e[j][1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+        x3_split2(e[j][2], e[j][3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        unsigned char* p = img + row * X3_RSB + kc * 2;
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + X3_IMGB) = mid;
+        *reinterpret_cast<u32x2*>(p + 2 * X3_IMGB) = lo;
+    }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBatch gb) {
+    constexpr int BT = 128, WT = 64;
+    constexpr int EPB = 4 * WT * (WT + 4) * 4;                   // epilogue patches, bytes
+    constexpr int STB = 6 * X3_IMGB;                             // six images
+    constexpr int LDSB = EPB > STB ? EPB : STB;
+    __shared__ __attribute__((aligned(16))) float lds[LDSB / 4];
+    unsigned char* const L = reinterpret_cast<unsigned char*>(lds);
+
+    const int bid = blockIdx.x;
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    const GemmTask& t = gb.t[ti];
+    const float* const pA = t.A; const float* const pB = t.B;
+    const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
+    const int tiles_c = t.tiles_c, splits = t.splits, kchunk = t.kchunk;
+    const int tiles_r = (R + BT - 1) / BT;
+    const int local = gl_xcd_remap(bid - t.tile_base, t.ntiles);
+    const int per_split = tiles_r * tiles_c;
+    const int split = local / per_split, rem = local - split * per_split;
+    const int tc = rem / tiles_r, tr = rem - tc * tiles_r;
+    const int r0 = tr * BT, c0 = tc * BT;
+    const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg + GL_BK - 1) / GL_BK;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const bool want_bias = (LA == LD_COL) && t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && tc == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float ea[4][4], eb[4][4];
+    x3_stage_load<LA>(pA, lda, r0, R, kbeg, kend, ea);
+    x3_stage_load<LB>(pB, ldb, c0, Cn, kbeg, kend, eb);
+
+    // The two workgroups of a CU alternate a VALU phase (split + LDS write) and a matrix phase; started together they
+    // stay in step and each pipe idles half the time.  Workgroups are dealt one per CU before any CU gets its second
+    // (observed, speed only), so delaying every second group of 256 by about one VALU phase puts the pair in anti-phase.
+    if (X3_STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(X3_STAGGER);
+
+    const unsigned char* const fa = L + (wr * WT + r32) * X3_RSB + 16 * hh;
+    const unsigned char* const fb = L + 3 * X3_IMGB + (wc * WT + r32) * X3_RSB + 16 * hh;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (want_bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rs[j] += (ea[j][0] + ea[j][1]) + (ea[j][2] + ea[j][3]);
+        }
+        x3_stage_write<LA>(L, ea);
+        x3_stage_write<LB>(L + 3 * X3_IMGB, eb);
+        __syncthreads();
+        const int kn = kbeg + GL_BK * (kt + 1);
+        x3_stage_load<LA>(pA, lda, r0, R, kn, kend, ea);
+        x3_stage_load<LB>(pB, ldb, c0, Cn, kn, kend, eb);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    a[tt][m] = *reinterpret_cast<const bf16x8*>(fa + tt * 32 * X3_RSB + m * X3_IMGB + 32 * c);
+                    b[tt][m] = *reinterpret_cast<const bf16x8*>(fb + tt * 32 * X3_RSB + m * X3_IMGB + 32 * c);
+                }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    f32x16 v = acc[x][y];
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], v, 0, 0, 0);
+                    acc[x][y] = v;
+                }
+        }
+        __syncthreads();
+    }
+
+    // bias gradient: this thread's four rows (k-major A: rows 4*(tid&31).., one of eight k groups) -> LDS -> fixed-order sum
+    if (want_bias) {
+        float* part = lds;                                   // [128][8]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(4 * (threadIdx.x & 31) + j) * 8 + (threadIdx.x >> 5)] = rs[j];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const float* q = part + threadIdx.x * 8;
+            const float s = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])));
+            const int r = r0 + threadIdx.x;
+            if (r < R) { if (splits > 1) t.bslab[(size_t)split * R + r] = s; else t.out2[r] = s; }
+        }
+        __syncthreads();
+    }
+
+    // accumulators (32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> LDS patch -> row segments
+    float* E = lds + w * (WT * (WT + 4));
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) E[(x * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * (WT + 4) + y * 32 + r32] = acc[x][y][q];
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * (WT + 4) + cc);
+        const int r = r0 + wr * WT + rr, c = c0 + wc * WT + cc;
+        if (r < R && c < Cn) {
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * Cn + c, v);
+            else gl_epilogue4(t, r, c, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -293,9 +499,19 @@ static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
     return (int)hipGetLastError();
 }
 
+static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(256), 0, st, gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(256), 0, st, gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(256), 0, st, gb);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
+// bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3)
 extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    int rc = bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb);
+    int rc = bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb)
+           : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb);
     if (rc != 0) return rc;
     if (fin_blocks > 0) {
         hipLaunchKernelGGL(gemm_lds_fin_kernel, dim3(fin_blocks), dim3(256), 0, st, *gb);

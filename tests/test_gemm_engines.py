@@ -80,7 +80,7 @@ def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, s
     d_bias = _dev(bias_v) if bias_v is not None else None
     d_aux = _dev(aux) if aux is not None else None
     # split-K slabs: splits * R * (Cn + 1) floats; the automatic plan never exceeds ~256 tiles' worth beyond the output
-    ws_floats = splits * R * (Cn + 1) if splits else min(32 * R * (Cn + 1), 5_000_000 + 2 * (R + 128) * (Cn + 129))
+    ws_floats = splits * R * (Cn + 1) if splits else min(32 * R * (Cn + 1), 10_000_000 + 2 * (R + 128) * (Cn + 129))
     ws = torch.zeros(max(1, ws_floats), device='cuda')
     rc = _lib.lib.rlrep_gemm(engine, la, lb, _ptr(dA), dA.shape[1], _ptr(dB), dB.shape[1], _ptr(dC), Cn, R, Cn, K, epi, ACT[act], flags,
                              _ptr(d_bias), _ptr(d_aux), Cn, _ptr(out2), bt, splits, _ptr(ws), ws.numel(),
@@ -149,6 +149,37 @@ def test_lds_engine_auto_plan_matches_path_shapes():
     check(1, 'fwd', 2048, 2560, 512, seed=16)                   # diffsrsac nabla-mu head (scaled-down width)
     check(1, 'dx', 2048, 512, 2560, act='elu', seed=17)         # ... its dX: small output, long inner dimension
     check(1, 'dw', 2560, 512, 2048, seed=18)
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+def test_bf16x3_engine_is_fp32_accurate(mode):
+    """engine 2: 128-wide tiles on the bf16 matrix pipe with every operand split exactly into three bf16 pieces and the
+    six significant partial products kept -- held to the same 1e-5 as the fp32-MFMA engines (measured ~2e-7), on exact
+    tiles, ragged edges, split-K and wide-dynamic-range operands"""
+    check(2, mode, 256, 256, 128, splits=1, seed=31)
+    check(2, mode, 148, 92, 100, splits=1, seed=32)
+    check(2, mode, 200, 128, 1024, splits=3, seed=33, accum=(mode != 'fwd'))
+    check(2, mode, 384, 640, 512, act='elu' if mode != 'dw' else 'none', seed=34)
+    got, want, _ = run_gemm(2, mode, 256, 128, 256, splits=1, seed=35)
+    ref, _, _ = run_gemm(1, mode, 256, 128, 256, bt=128, splits=1, seed=35)
+    assert rel(got, want) < 2e-6 and rel(ref, want) < 2e-6, (rel(got, want), rel(ref, want))
+
+
+def test_bf16x3_engine_wide_dynamic_range():
+    """operands spanning 12 decades: the split is exact per element, so the error stays relative to sum |a||b|"""
+    from rlrep_amd import _lib
+    rs = np.random.RandomState(40)
+    R, Cn, K = 128, 128, 256
+    A = (rs.standard_normal((R, K)) * 10.0 ** rs.uniform(-6, 6, (R, K))).astype(np.float32)
+    B = (rs.standard_normal((Cn, K)) * 10.0 ** rs.uniform(-6, 6, (Cn, K))).astype(np.float32)
+    dA, dB, dC = _dev(A), _dev(B), torch.zeros(R, Cn, device='cuda')
+    rc = _lib.lib.rlrep_gemm(2, 0, 0, dA.data_ptr(), K, dB.data_ptr(), K, dC.data_ptr(), Cn, R, Cn, K, 0, 0, 0, None, None, Cn, None,
+                             0, 1, None, 0, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'gemm')
+    got = dC.cpu().numpy().astype(np.float64)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+    assert np.all(np.abs(got - want) <= 4e-6 * bound + 1e-30), float(np.max(np.abs(got - want) / bound))
 
 
 @pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])

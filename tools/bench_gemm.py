@@ -31,7 +31,7 @@ def run(engine, mode, R, Cn, K, reps, bt=0, splits=0):
     A = torch.randn((K, R) if la else (R, K), device='cuda')
     B = torch.randn((K, Cn) if lb else (Cn, K), device='cuda')
     C = torch.empty(R, Cn, device='cuda')
-    ws = torch.empty(min(32 * R * (Cn + 1), 5_000_000 + 2 * (R + 128) * (Cn + 129)), device='cuda')
+    ws = torch.empty(min(32 * R * (Cn + 1), 10_000_000 + 2 * (R + 128) * (Cn + 129)), device='cuda')
     epi = {'fwd': 0, 'dx': 1, 'dw': 3}[mode]
     st = torch.cuda.current_stream().cuda_stream
 
@@ -56,8 +56,8 @@ if __name__ == '__main__':
         fl = 2.0 * R * Cn * K
         reps = 5 if fl > 5e10 else 50
         line = f'{name:28s} {mode:3s} {R:6d} x {Cn:6d} x {K:6d}  {fl / 1e9:8.2f} GF'
-        for eng, label in ((0, 'gemm16'), (1, 'gemm_lds')):
-            if eng == 0 and fl > 3e11 and os.environ.get('SKIP_SLOW'):
+        for eng, label in ((0, 'gemm16'), (1, 'gemm_lds'), (2, 'bf16x3')):
+            if (eng == 0 and fl > 3e10 and os.environ.get('SKIP_SLOW')) or (eng == 2 and fl < 1e9):
                 continue
             us = run(eng, mode, R, Cn, K, reps)
             line += f' | {label} {us:9.1f} us {fl / us / 1e6:6.1f} TF'
