@@ -1,0 +1,118 @@
+"""GPU parity at the LARGE dimensions of BASELINE configs 3-5, where the step programs route their GEMMs to the
+LDS-tiled engine (gemm_lds.hip: fp32-MFMA 64/128 tiles, split-K) and, for diffsrsac's nabla-mu head, to its bf16x3
+variant.  No golden fixture exists at these sizes (the parameters alone are 25-200 MB), so the check is HIP vs the CPU
+oracle on synthetic parameters / replay / injected noise, at sizes the oracle finishes in seconds.
+
+Tolerance: BASELINE.json's 1e-4 relative (metrics: |x-ref| <= 1e-4*max(|ref|,1e-2); parameters: relative L2 per tensor)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from fixture_io import rel_l2      # puts tests/golden on sys.path
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Space:
+    def __init__(self, A):
+        self.low, self.high = -np.ones(A, np.float32), np.ones(A, np.float32)
+
+
+def _retie(alg, P):
+    ties = [('critic', 'critic_target')]
+    if alg in ('ctrlsac', 'spedersac'):
+        ties.append(('phi', 'phi_target'))
+    for s, d in ties:
+        for k in list(P):
+            if k.startswith(s + '.') and (d + k[len(s):]) in P:
+                P[d + k[len(s):]] = P[k].copy()
+    if alg == 'ctrlsac':
+        for d in ('frozen_phi', 'frozen_phi_target'):
+            for k in list(P):
+                if k.startswith('phi.') and (d + k[3:]) in P:
+                    P[d + k[3:]] = P[k].copy()
+
+
+def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=()):
+    import importlib
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    from oracle.shapes import param_shapes
+    mod, name = cls_path
+    cls = getattr(importlib.import_module(mod), name)
+    init = synth.init_like(param_shapes(alg, S, A, **kw), seed=99)
+    _retie(alg, init)
+    init['log_alpha'] = np.log(np.float64(0.1))
+    agent = cls(state_dim=S, action_dim=A, action_space=_Space(A), max_batch=B, graph=False, **kw)
+    if alg == 'diffsrsac':
+        init['noise_alphabars'] = agent.core.state()['noise_alphabars'].numpy().copy()
+    agent.core.load_state(init)
+    names = [agent.core.stages(p) for p in range(7)]
+    flat = ' | '.join(n for st in names for n in st)
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    data = synth.replay(S, A, replay_n, seed=3)
+    buf = ReplayBuffer(S, A, max_size=replay_n)
+    buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+    o = make_oracle(alg, S, A, init, **kw)
+    if alg == 'diffsrsac':
+        o.P['noise_alphabars'] = torch.from_numpy(init['noise_alphabars'])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rs = np.random.RandomState(11)
+    nf = kw.get('extra_feature_steps', 0) + 1
+    tens = {k: torch.from_numpy(v) for k, v in data.items()}
+    for t in range(trains):
+        idx = [rs.randint(0, replay_n, size=B) for _ in range(o.n_batches())]
+        eps = []
+        if alg == 'diffsrsac':
+            for _ in range(nf):
+                eps += [rs.randint(0, 1000, size=B), (0.449 * rs.standard_normal((B, S))).astype(np.float32)]
+        eps += [rs.standard_normal((B, A)).astype(np.float32) for _ in range(2)]
+        info = agent.train_injected(buf, B, idx, eps)
+        oinfo = o.train([gather_batch(tens, i) for i in idx], [torch.as_tensor(e) for e in eps])
+        for k, v in oinfo.items():
+            assert np.isfinite(info[k]), (alg, k)
+            assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (alg, t, k, info[k], v)
+    st, P = agent.core.state(), o.state()
+    worst = 0.0
+    for k in st:
+        if k in P and not k.endswith('noise') and k != 'noise_alphabars':
+            e = rel_l2(st[k].numpy(), P[k].numpy())
+            worst = max(worst, e)
+            assert e < 1e-4, (alg, k, e)
+    print(f'{alg} S={S} B={B}: worst parameter rel-L2 after {trains} train(): {worst:.2e}')
+    return agent
+
+
+def test_ctrlsac_main_py_dimensions():
+    """ctrlsac as main.py:87-91 builds it: feature_dim 2048, hidden 1024, B = 256 (M = 256 layers: 64-wide tiles + split-K)"""
+    _run('ctrlsac', ('rlrep_amd.agent.ctrlsac.ctrlsac_agent', 'CTRLSACAgent'), 17, 6, 256,
+         dict(hidden_dim=1024, feature_dim=2048, extra_feature_steps=1))
+
+
+def test_spedersac_ant_dimensions_two_trains():
+    _run('spedersac', ('rlrep_amd.agent.spedersac.spedersac_agent', 'SPEDERSACAgent'), 111, 8, 1024,
+         dict(phi_and_mu_lr=1e-5, phi_hidden_dim=512, phi_hidden_depth=1, mu_hidden_dim=512, mu_hidden_depth=0,
+              critic_and_actor_lr=3e-4, critic_and_actor_hidden_dim=256, feature_dim=512, hidden_dim=256, extra_feature_steps=1),
+         trains=2)
+
+
+def test_diffsrsac_wide_nabla_mu_head_on_bf16x3():
+    """S = 76, F = 256, B = 1024: the nabla-mu head is 1024 x 512 x 19 456 (20 GFLOP per pass) -- the size class that the
+    builder sends to the bf16x3 tile (Humanoid: 2048 x 512 x 96 256)"""
+    _run('diffsrsac', ('rlrep_amd.agent.diffsrsac.diffsrsac_agent', 'DIFFSRSACAgent'), 76, 8, 1024,
+         dict(hidden_dim=256, extra_feature_steps=1))
+
+
+def test_large_engines_off_gives_the_same_step(monkeypatch):
+    """RLREP_NO_GEMM_LDS=1 keeps every GEMM on the 16-row engine: same train() within fp32 summation-order noise"""
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('RLREP_NO_GEMM_LDS', '1')
+        a = _run('ctrlsac', ('rlrep_amd.agent.ctrlsac.ctrlsac_agent', 'CTRLSACAgent'), 17, 6, 128,
+                 dict(hidden_dim=512, feature_dim=1024, extra_feature_steps=0))
+        outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})
+    for k in outs[0]:
+        assert rel_l2(outs[0][k], outs[1][k]) < 1e-5, k
