@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(TrainPrologue p) {
         fill_slot_body(p.fill, g, bid - p.nb_idx - p.nb_eps, p.nb_fill);
     }
     // steps += 1 once EVERY block has read the old value: the block that draws the last ticket does it
+    // (no fence: the barrier is passed only by threads whose reads of the counter have returned -- their values were
+    // used above -- and the increment is ordered behind every block's ticket; the agent-scope fence that used to sit
+    // here was executed by ~300 blocks and cost most of this launch's 11 us)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const int tk = atomicAdd(p.ticket, 1);
         if (tk == (int)gridDim.x - 1) { *p.counter += 1; *p.ticket = 0; }
     }

@@ -106,8 +106,10 @@ struct Builder {
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
                 if (dry || rl_gemm_lds_ptrs_ok(&t)) {
                     t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab;
-                    // the 200-GFLOP products (diffsrsac's nabla-mu head) run the same tile on the bf16 pipe (bf16x3, fp32-accurate)
-                    const bool x3 = bt == 128 && 2.0 * t.R * t.Cn * t.K >= 2e10 && !getenv("RLREP_NO_X3");
+                    // products of >= 2 GFLOP with a row-major A (forward, dX: e.g. diffsrsac's 202-GFLOP nabla-mu head) run the
+                    // 128-wide tile on the bf16 pipe (bf16x3, fp32-accurate): 159 / 137 TF against 110 on the fp32 pipe; the
+                    // k-major/k-major weight-gradient form stays on fp32 MFMA (its staging does not pay: 107 vs 116 TF)
+                    const bool x3 = bt == 128 && la == LD_ROW && 2.0 * t.R * t.Cn * t.K >= 2e9 && !getenv("RLREP_NO_X3");
                     (x3 ? bigx3 : bt == 128 ? big128 : big64).push_back(t);
                     continue;
                 }

@@ -298,6 +298,7 @@ typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef X3_STAGGER
 #define X3_STAGGER 24                /* s_sleep units (64 cycles) */
@@ -317,55 +318,71 @@ __device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsi
     lo = x3_pk(s0, s1);
 }
 
-// every thread stages four row slots x four consecutive k: e[slot][k]
+// 512 threads stage a 128 x 32 slice: every thread two row slots x four consecutive k (row-major operand) or four rows x
+// two consecutive k (k-major operand): e[slot][..]
 template <int LD>
-__device__ __forceinline__ void x3_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[4][4]) {
+__device__ __forceinline__ void x3_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[8]) {
     if (LD == LD_ROW) {
         const int kc = (threadIdx.x & 7) * 4;
         const int k = min(k0 + kc, kend - 4);
         const bool ok = (k0 + kc) < kend;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
+        for (int j = 0; j < 2; ++j) {
+            const int r = min(base + (int)(threadIdx.x >> 3) + 64 * j, lim - 1);
             const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[j][q] = ok ? x[q] : 0.f;
+            for (int q = 0; q < 4; ++q) e[4 * j + q] = ok ? x[q] : 0.f;
         }
     } else {
-        const int i4 = 4 * (threadIdx.x & 31), kg = 4 * (threadIdx.x >> 5);
-        const int i = min(base + i4, lim - 4);
-        const bool iok = (base + i4) < lim;
+        // k-major operand: one row, eight consecutive k per thread.  A wave-instruction reads 64 consecutive rows of one
+        // k (256 contiguous bytes) and the row's eight k land in ONE 16-byte LDS write per image; the 4-rows-per-thread
+        // form (16-byte global loads) scattered its LDS writes 320 bytes apart: 16-way bank conflicts, dW at 82 TF
+        const int i = min(base + (int)(threadIdx.x & 127), lim - 1), kg = 8 * (threadIdx.x >> 7);
+        const bool iok = (base + (int)(threadIdx.x & 127)) < lim;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const int k = min(k0 + kg + q, kend - 1);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
-            const bool ok = iok && (k0 + kg + q) < kend;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r][q] = ok ? x[r] : 0.f;
+            const float x = P[(size_t)k * ld + i];
+            e[q] = (iok && (k0 + kg + q) < kend) ? x : 0.f;
         }
     }
 }
 template <int LD>
-__device__ __forceinline__ void x3_stage_write(unsigned char* __restrict__ img, const float (&e)[4][4]) {
+__device__ __forceinline__ void x3_stage_write(unsigned char* __restrict__ img, const float (&e)[8]) {
+    if (LD == LD_ROW) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (LD == LD_ROW) ? (int)(threadIdx.x >> 3) + 32 * j : 4 * (int)(threadIdx.x & 31) + j;
-        const int kc = (LD == LD_ROW) ? (int)(threadIdx.x & 7) * 4 : 4 * (int)(threadIdx.x >> 5);
-        u32x2 hi, mid, lo;
-        unsigned h, m, l;
-        x3_split2(e[j][0], e[j][1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
-        x3_split2(e[j][2], e[j][3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        for (int j = 0; j < 2; ++j) {
+            const int row = (int)(threadIdx.x >> 3) + 64 * j, kc = (int)(threadIdx.x & 7) * 4;
+            u32x2 hi, mid, lo;
+            unsigned h, m, l;
+            x3_split2(e[4 * j], e[4 * j + 1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+            x3_split2(e[4 * j + 2], e[4 * j + 3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+            unsigned char* p = img + row * X3_RSB + kc * 2;
+            *reinterpret_cast<u32x2*>(p) = hi;
+            *reinterpret_cast<u32x2*>(p + X3_IMGB) = mid;
+            *reinterpret_cast<u32x2*>(p + 2 * X3_IMGB) = lo;
+        }
+    } else {
+        const int row = (int)(threadIdx.x & 127), kc = 8 * (int)(threadIdx.x >> 7);
+        u32x4 hi, mid, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h, m, l;
+            x3_split2(e[2 * q], e[2 * q + 1], h, m, l); hi[q] = h; mid[q] = m; lo[q] = l;
+        }
         unsigned char* p = img + row * X3_RSB + kc * 2;
-        *reinterpret_cast<u32x2*>(p) = hi;
-        *reinterpret_cast<u32x2*>(p + X3_IMGB) = mid;
-        *reinterpret_cast<u32x2*>(p + 2 * X3_IMGB) = lo;
+        *reinterpret_cast<u32x4*>(p) = hi;
+        *reinterpret_cast<u32x4*>(p + X3_IMGB) = mid;
+        *reinterpret_cast<u32x4*>(p + 2 * X3_IMGB) = lo;
     }
 }
 
+// 8 waves as 4 (rows) x 2 (columns): a wave owns 32 x 64 of the tile = two 32x32 accumulators; four waves per SIMD with
+// two workgroups per CU, so split (VALU), fragment reads (LDS) and the matrix pipe overlap across waves
 template <int LA, int LB>
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBatch gb) {
-    constexpr int BT = 128, WT = 64;
-    constexpr int EPB = 4 * WT * (WT + 4) * 4;                   // epilogue patches, bytes
+__global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmBatch gb) {
+    constexpr int BT = 128;
+    constexpr int EPB = 8 * 32 * 68 * 4;                         // epilogue patches [32][68] per wave, bytes
     constexpr int STB = 6 * X3_IMGB;                             // six images
     constexpr int LDSB = EPB > STB ? EPB : STB;
     __shared__ __attribute__((aligned(16))) float lds[LDSB / 4];
@@ -393,32 +410,27 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBatch gb) {
     const int r32 = lane & 31, hh = lane >> 5;
     const bool want_bias = (LA == LD_COL) && t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && tc == 0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+    float rs = 0.f;
 
-    float ea[4][4], eb[4][4];
+    float ea[8], eb[8];
     x3_stage_load<LA>(pA, lda, r0, R, kbeg, kend, ea);
     x3_stage_load<LB>(pB, ldb, c0, Cn, kbeg, kend, eb);
 
     // The two workgroups of a CU alternate a VALU phase (split + LDS write) and a matrix phase; started together they
-    // stay in step and each pipe idles half the time.  Workgroups are dealt one per CU before any CU gets its second
-    // (observed, speed only), so delaying every second group of 256 by about one VALU phase puts the pair in anti-phase.
+    // stay in step.  Workgroups are dealt one per CU before any CU gets its second (observed, speed only), so delaying
+    // every second group of 256 by about one VALU phase starts the pair in anti-phase.
     if (X3_STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(X3_STAGGER);
 
-    const unsigned char* const fa = L + (wr * WT + r32) * X3_RSB + 16 * hh;
-    const unsigned char* const fb = L + 3 * X3_IMGB + (wc * WT + r32) * X3_RSB + 16 * hh;
+    const unsigned char* const fa = L + (wr * 32 + r32) * X3_RSB + 16 * hh;
+    const unsigned char* const fb = L + 3 * X3_IMGB + (wc * 64 + r32) * X3_RSB + 16 * hh;
 
     for (int kt = 0; kt < nk; ++kt) {
-        if (want_bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rs[j] += (ea[j][0] + ea[j][1]) + (ea[j][2] + ea[j][3]);
-        }
+        if (want_bias) rs += ((ea[0] + ea[1]) + (ea[2] + ea[3])) + ((ea[4] + ea[5]) + (ea[6] + ea[7]));
         x3_stage_write<LA>(L, ea);
         x3_stage_write<LB>(L + 3 * X3_IMGB, eb);
         __syncthreads();
@@ -427,40 +439,36 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBatch gb) {
         x3_stage_load<LB>(pB, ldb, c0, Cn, kn, kend, eb);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            bf16x8 a[2][3], b[2][3];
+            bf16x8 a[3], b[2][3];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int m = 0; m < 3; ++m) {
+                a[m] = *reinterpret_cast<const bf16x8*>(fa + m * X3_IMGB + 32 * c);
+                b[0][m] = *reinterpret_cast<const bf16x8*>(fb + m * X3_IMGB + 32 * c);
+                b[1][m] = *reinterpret_cast<const bf16x8*>(fb + 32 * X3_RSB + m * X3_IMGB + 32 * c);
+            }
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    a[tt][m] = *reinterpret_cast<const bf16x8*>(fa + tt * 32 * X3_RSB + m * X3_IMGB + 32 * c);
-                    b[tt][m] = *reinterpret_cast<const bf16x8*>(fb + tt * 32 * X3_RSB + m * X3_IMGB + 32 * c);
-                }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    f32x16 v = acc[x][y];
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], v, 0, 0, 0);
-                    acc[x][y] = v;
-                }
+            for (int y = 0; y < 2; ++y) {
+                f32x16 v = acc[y];
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[y][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[y][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[y][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][0], v, 0, 0, 0);
+                acc[y] = v;
+            }
         }
         __syncthreads();
     }
 
-    // bias gradient: this thread's four rows (k-major A: rows 4*(tid&31).., one of eight k groups) -> LDS -> fixed-order sum
+    // bias gradient: this thread's row (k-major A: row tid & 127, one of four k groups) -> LDS -> fixed-order sum
     if (want_bias) {
-        float* part = lds;                                   // [128][8]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) part[(4 * (threadIdx.x & 31) + j) * 8 + (threadIdx.x >> 5)] = rs[j];
+        float* part = lds;                                   // [128][4]
+        part[(threadIdx.x & 127) * 4 + (threadIdx.x >> 7)] = rs;
         __syncthreads();
         if (threadIdx.x < 128) {
-            const float* q = part + threadIdx.x * 8;
-            const float s = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])));
+            const float* q = part + threadIdx.x * 4;
+            const float s = (q[0] + q[1]) + (q[2] + q[3]);
             const int r = r0 + threadIdx.x;
             if (r < R) { if (splits > 1) t.bslab[(size_t)split * R + r] = s; else t.out2[r] = s; }
         }
@@ -468,18 +476,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBatch gb) {
     }
 
     // accumulators (32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> LDS patch -> row segments
-    float* E = lds + w * (WT * (WT + 4));
+    float* E = lds + w * (32 * 68);
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int y = 0; y < 2; ++y)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) E[(x * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh) * (WT + 4) + y * 32 + r32] = acc[x][y][q];
+        for (int q = 0; q < 16; ++q) E[((q & 3) + 8 * (q >> 2) + 4 * hh) * 68 + y * 32 + r32] = acc[y][q];
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * (WT + 4) + cc);
-        const int r = r0 + wr * WT + rr, c = c0 + wc * WT + cc;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * 68 + cc);
+        const int r = r0 + wr * 32 + rr, c = c0 + wc * 64 + cc;
         if (r < R && c < Cn) {
             if (splits > 1) st4(t.slab + ((size_t)split * R + r) * Cn + c, v);
             else gl_epilogue4(t, r, c, v);
@@ -500,9 +506,9 @@ static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
 }
 
 static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
-    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(256), 0, st, gb);
-    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(256), 0, st, gb);
-    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(256), 0, st, gb);
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(512), 0, st, gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, gb);
     else return -1;
     return (int)hipGetLastError();
 }

@@ -99,8 +99,8 @@ def test_spedersac_ant_dimensions_two_trains():
 
 
 def test_diffsrsac_wide_nabla_mu_head_on_bf16x3():
-    """S = 76, F = 256, B = 1024: the nabla-mu head is 1024 x 512 x 19 456 (20 GFLOP per pass) -- the size class that the
-    builder sends to the bf16x3 tile (Humanoid: 2048 x 512 x 96 256)"""
+    """S = 76, F = 256, B = 1024: the nabla-mu head is 1024 x 512 x 19 456 (20 GFLOP per pass) -- the size class whose
+    forward and dX the builder sends to the bf16x3 tile (Humanoid: 2048 x 512 x 96 256)"""
     _run('diffsrsac', ('rlrep_amd.agent.diffsrsac.diffsrsac_agent', 'DIFFSRSACAgent'), 76, 8, 1024,
          dict(hidden_dim=256, extra_feature_steps=1))
 

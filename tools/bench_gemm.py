@@ -52,11 +52,17 @@ def run(engine, mode, R, Cn, K, reps, bt=0, splits=0):
 
 
 if __name__ == '__main__':
+    only = os.environ.get('ONLY')          # substring of a shape name
+    engines = [int(x) for x in os.environ.get('ENGINES', '0,1,2').split(',')]
     for name, mode, R, Cn, K in SHAPES:
+        if only and only not in name:
+            continue
         fl = 2.0 * R * Cn * K
         reps = 5 if fl > 5e10 else 50
         line = f'{name:28s} {mode:3s} {R:6d} x {Cn:6d} x {K:6d}  {fl / 1e9:8.2f} GF'
         for eng, label in ((0, 'gemm16'), (1, 'gemm_lds'), (2, 'bf16x3')):
+            if eng not in engines:
+                continue
             if (eng == 0 and fl > 3e10 and os.environ.get('SKIP_SLOW')) or (eng == 2 and fl < 1e9):
                 continue
             us = run(eng, mode, R, Cn, K, reps)
