@@ -34,6 +34,11 @@ enum Epi : int {
 #define FLAG_DYN_EPS 4     // x2 is the per-call noise pointer (patched into the kernel arguments at launch)
 #define FLAG_DYN_EPS2 8    // x2 is the noise pointer of the policy forward that rides along (rlrep_prefetch_policy)
 #define FLAG_DYN_EPS3 16   // x2 is the critic step's policy noise while that policy rides in the last feature step
+// gemm_lds.hip: operand / output not eligible for 16-byte accesses (row stride, inner length or pointer not a multiple of 4
+// floats, e.g. the K = 119 first layers of spedersac): that side falls back to clamped 4-byte accesses
+#define FLAG_SCALAR_A 32
+#define FLAG_SCALAR_B 64
+#define FLAG_SCALAR_C 128
 
 struct GroupCfg;
 struct GemmTask {

@@ -1060,7 +1060,8 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         gb.t[0] = t;
         rc = rl_launch_gemm16(la, lb, 1, &gb, t.ntiles, (hipStream_t)stream);
     } else {
-        if (!rl_gemm_lds_align_ok(&t, la, lb) || !rl_gemm_lds_ptrs_ok(&t)) { rl_set_error("gemm: shape/alignment not eligible for the LDS-tiled engine"); return RLREP_ERR_ARG; }
+        t.flags |= rl_gemm_lds_dim_flags(&t, la, lb) | rl_gemm_lds_ptr_flags(&t);
+        if (engine == 2 && (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B | FLAG_SCALAR_C))) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
         int pbt = 0, psp = 1, pkc = 0;
         rl_gemm_lds_plan(&t, &pbt, &psp, &pkc);
         if (bt == 64 || bt == 128) pbt = bt;
@@ -1070,9 +1071,9 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         int fin = 0;
         if (psp > 1) {
             const bool bg = (t.flags & FLAG_BIASGRAD) != 0;
-            if (!wsp || ws_floats < (int64_t)psp * R * (Cn + 1)) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
-            t.slab = wsp; t.bslab = wsp + (size_t)psp * R * Cn; t.fin_base = 0;
-            fin = (int)(((long long)R * (Cn / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
+            if (!wsp || ws_floats < (int64_t)psp * R * (((Cn + 3) & ~3) + 1)) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
+            t.slab = wsp; t.bslab = wsp + (size_t)psp * R * ((Cn + 3) & ~3); t.fin_base = 0;
+            fin = (int)(((long long)R * ((Cn + 3) / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
         }
         t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;

@@ -102,14 +102,16 @@ struct Builder {
                 int bt = 0, sp = 1, kc = 0;
                 rl_gemm_lds_plan(&t, &bt, &sp, &kc);
                 // (the bias-gradient flag depends on a pointer that is null in the dry pass: reserve for every dW task)
-                float* slab = sp > 1 ? ws.f((size_t)sp * t.R * t.Cn) : nullptr;
+                float* slab = sp > 1 ? ws.f((size_t)sp * t.R * ((t.Cn + 3) & ~3)) : nullptr;
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
                 if (dry || rl_gemm_lds_ptrs_ok(&t)) {
                     t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab;
+                    t.flags |= rl_gemm_lds_dim_flags(&t, la, lb) | (dry ? 0 : rl_gemm_lds_ptr_flags(&t));
                     // products of >= 2 GFLOP with a row-major A (forward, dX: e.g. diffsrsac's 202-GFLOP nabla-mu head) run the
                     // 128-wide tile on the bf16 pipe (bf16x3, fp32-accurate): 159 / 137 TF against 110 on the fp32 pipe; the
                     // k-major/k-major weight-gradient form stays on fp32 MFMA (its staging does not pay: 107 vs 116 TF)
-                    const bool x3 = bt == 128 && la == LD_ROW && 2.0 * t.R * t.Cn * t.K >= 2e9 && !getenv("RLREP_NO_X3");
+                    const bool x3 = bt == 128 && la == LD_ROW && 2.0 * t.R * t.Cn * t.K >= 2e9 && !getenv("RLREP_NO_X3") &&
+                                    !(t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
                     (x3 ? bigx3 : bt == 128 ? big128 : big64).push_back(t);
                     continue;
                 }
@@ -130,7 +132,7 @@ struct Builder {
             if (t.splits > 1) {
                 const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
                 t.fin_base = fin;
-                fin += (int)(((long long)t.R * (t.Cn / 4) + 255) / 256) + (bias ? (t.R + 255) / 256 : 0);
+                fin += (int)(((long long)t.R * ((t.Cn + 3) / 4) + 255) / 256) + (bias ? (t.R + 255) / 256 : 0);
             }
         }
         GemmBatch gb; memset(&gb, 0, sizeof(gb));

@@ -33,25 +33,48 @@ template <int BT, int LD> struct GlTile {
 };
 
 // ---- staging: global -> registers (branch-free: clamped address, value zeroed by a select) ----------------------
+// `vec`: 16-byte loads are legal for this operand (workgroup-uniform); otherwise four clamped 4-byte loads per slot
 template <int BT, int LD>
-__device__ __forceinline__ void gl_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend,
+__device__ __forceinline__ void gl_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, bool vec,
                                               f32x4 (&v)[BT / 32]) {
+    if (vec) {
 #pragma unroll
-    for (int j = 0; j < BT / 32; ++j) {
-        const int idx = threadIdx.x + 256 * j;
-        if (LD == LD_ROW) {
-            const int row = idx >> 3, kc = (idx & 7) * 4;
-            const int r = min(base + row, lim - 1), k = min(k0 + kc, kend - 4);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
-            const bool ok = (k0 + kc) < kend;
-            v[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
-        } else {
-            constexpr int Q = BT / 4;
-            const int kk = idx / Q, i4 = (idx % Q) * 4;
-            const int k = min(k0 + kk, kend - 1), i = min(base + i4, lim - 4);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
-            const bool ok = (k0 + kk < kend) && (base + i4 < lim);
-            v[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < BT / 32; ++j) {
+            const int idx = threadIdx.x + 256 * j;
+            if (LD == LD_ROW) {
+                const int row = idx >> 3, kc = (idx & 7) * 4;
+                const int r = min(base + row, lim - 1), k = min(k0 + kc, kend - 4);
+                const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
+                const bool ok = (k0 + kc) < kend;
+                v[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+                constexpr int Q = BT / 4;
+                const int kk = idx / Q, i4 = (idx % Q) * 4;
+                const int k = min(k0 + kk, kend - 1), i = min(base + i4, lim - 4);
+                const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
+                const bool ok = (k0 + kk < kend) && (base + i4 < lim);
+                v[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < BT / 32; ++j) {
+            const int idx = threadIdx.x + 256 * j;
+            f32x4 x;
+            if (LD == LD_ROW) {
+                const int row = idx >> 3, kc = (idx & 7) * 4;
+                const float* p = P + (size_t)min(base + row, lim - 1) * ld;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float y = p[min(k0 + kc + q, kend - 1)]; x[q] = (k0 + kc + q) < kend ? y : 0.f; }
+            } else {
+                constexpr int Q = BT / 4;
+                const int kk = idx / Q, i4 = (idx % Q) * 4;
+                const float* p = P + (size_t)min(k0 + kk, kend - 1) * ld;
+                const bool kok = (k0 + kk) < kend;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float y = p[min(base + i4 + q, lim - 1)]; x[q] = (kok && (base + i4 + q) < lim) ? y : 0.f; }
+            }
+            v[j] = x;
         }
     }
 }
@@ -91,7 +114,45 @@ __device__ __forceinline__ void gl_frag(const float* __restrict__ S, int wbase, 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// one output element (outputs whose row stride / width / pointers rule out 16-byte accesses)
+__device__ __forceinline__ void gl_epilogue1(const GemmTask& t, int r, int c, float v) {
+    v *= t.scale;
+    float* cp = t.C + (size_t)r * t.ldc + c;
+    if (t.epi == EPI_FWD) {
+        if (t.bias) v += t.bias[c];
+        float y;
+        switch (t.act) {
+        case ACT_RELU: y = fmaxf(v, 0.f); break;
+        case ACT_ELU: y = elu_f(v); break;
+        case ACT_SIN: y = sinf(v); t.out2[(size_t)r * t.ldout2 + c] = v; break;
+        case ACT_TANH: y = tanhf(v); break;
+        default: y = v;
+        }
+        *cp = y;
+    } else if (t.epi == EPI_DX) {
+        if (t.r1u) v += t.r1u[r] * t.r1v[c];
+        if (t.act != ACT_NONE) {
+            const float a = t.aux[(size_t)r * t.ldaux + c];
+            switch (t.act) {
+            case ACT_RELU: v = a > 0.f ? v : 0.f; break;
+            case ACT_ELU: v *= elu_grad_from_out(a); break;
+            case ACT_SIN: v *= cosf(a); break;
+            case ACT_TANH: v *= (1.f - a * a); break;
+            default: break;
+            }
+        }
+        *cp = ((t.flags & FLAG_ACCUM) ? *cp : 0.f) + v;
+    } else {
+        *cp = ((t.flags & FLAG_ACCUM) ? *cp : 0.f) + v;
+    }
+}
+
 __device__ __forceinline__ void gl_epilogue4(const GemmTask& t, int r, int c, f32x4 v) {
+    if (t.flags & FLAG_SCALAR_C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (c + q < t.Cn) gl_epilogue1(t, r, c + q, v[q]);
+        return;
+    }
     v *= t.scale;
     float* cp = t.C + (size_t)r * t.ldc + c;
     if (t.epi == EPI_FWD) {
@@ -178,9 +239,10 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
 #pragma unroll
     for (int a = 0; a < TT; ++a) asum[a] = 0.f;
 
+    const bool vecA = !(t.flags & FLAG_SCALAR_A), vecB = !(t.flags & FLAG_SCALAR_B);
     f32x4 va[BT / 32], vb[BT / 32];
-    gl_stage_load<BT, LA>(pA, lda, r0, R, kbeg, kend, va);
-    gl_stage_load<BT, LB>(pB, ldb, c0, Cn, kbeg, kend, vb);
+    gl_stage_load<BT, LA>(pA, lda, r0, R, kbeg, kend, vecA, va);
+    gl_stage_load<BT, LB>(pB, ldb, c0, Cn, kbeg, kend, vecB, vb);
     gl_stage_write<BT, LA>(lds, va);
     gl_stage_write<BT, LB>(lds + SA, vb);
     __syncthreads();
@@ -189,8 +251,8 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
         const int cur = kt & 1;
         // slice kt+1 (past the end: a clamped, zeroed re-read that nobody consumes) -- issued before the MFMAs of slice kt
         const int kn = kbeg + GL_BK * (kt + 1);
-        gl_stage_load<BT, LA>(pA, lda, r0, R, kn, kend, va);
-        gl_stage_load<BT, LB>(pB, ldb, c0, Cn, kn, kend, vb);
+        gl_stage_load<BT, LA>(pA, lda, r0, R, kn, kend, vecA, va);
+        gl_stage_load<BT, LB>(pB, ldb, c0, Cn, kn, kend, vecB, vb);
         const float* As = lds + cur * (SA + SB);
         const float* Bs = As + SA;
 #pragma unroll
@@ -245,7 +307,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
         const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * (WT + 4) + cc);
         const int r = r0 + wr * WT + rr, c = c0 + wc * WT + cc;
         if (r < R && c < Cn) {
-            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * Cn + c, v);
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
             else gl_epilogue4(t, r, c, v);
         }
     }
@@ -260,15 +322,15 @@ __global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GemmBatch gb) {
     if (ti < 0) return;
     const GemmTask& t = gb.t[ti];
     const int lb = bid - t.fin_base;
-    const int R = t.R, Cn = t.Cn, C4 = Cn >> 2;
+    const int R = t.R, Cn = t.Cn, C4 = (Cn + 3) >> 2;          // slab rows are padded to a multiple of 4 floats
     const long long nvec = (long long)R * C4;
     const int nb_main = (int)((nvec + 255) / 256);
     if (lb < nb_main) {
         const long long e = (long long)lb * 256 + threadIdx.x;
         if (e >= nvec) return;
         const int r = (int)(e / C4), c = (int)(e - (long long)r * C4) * 4;
-        const float* p = t.slab + (size_t)r * Cn + c;
-        const size_t stride = (size_t)R * Cn;
+        const float* p = t.slab + ((size_t)r * C4) * 4 + c;
+        const size_t stride = (size_t)R * C4 * 4;
         f32x4 v = ld4(p);
         for (int s = 1; s < t.splits; ++s) v += ld4(p + s * stride);
         gl_epilogue4(t, r, c, v);
@@ -487,7 +549,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmBatch gb) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * 68 + cc);
         const int r = r0 + wr * 32 + rr, c = c0 + wc * 64 + cc;
         if (r < R && c < Cn) {
-            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * Cn + c, v);
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
             else gl_epilogue4(t, r, c, v);
         }
     }
@@ -526,31 +588,42 @@ extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, i
     return rc;
 }
 
-// Can this task run here?  Alignment rules (16-byte operand / epilogue vectors) ...
+// Which sides of a task can use 16-byte accesses?  (dimensions only; pointers are checked by rl_gemm_lds_ptr_flags)
+extern "C" int rl_gemm_lds_dim_flags(const GemmTask* t, int la, int lb) {
+    int f = 0;
+    if ((t->lda & 3) || (la == LD_ROW ? (t->K & 3) : (t->R & 3))) f |= FLAG_SCALAR_A;
+    if ((t->ldb & 3) || (lb == LD_ROW ? (t->K & 3) : (t->Cn & 3))) f |= FLAG_SCALAR_B;
+    if ((t->Cn & 3) || (t->ldc & 3)) f |= FLAG_SCALAR_C;
+    if (t->epi == EPI_DX && t->act != ACT_NONE && (t->ldaux & 3)) f |= FLAG_SCALAR_C;
+    if (t->epi == EPI_FWD && t->act == ACT_SIN && (t->ldout2 & 3)) f |= FLAG_SCALAR_C;
+    return f;
+}
 extern "C" int rl_gemm_lds_align_ok(const GemmTask* t, int la, int lb) {
     if (t->epi != EPI_FWD && t->epi != EPI_DX && t->epi != EPI_DW) return 0;
     if (t->ad_p) return 0;
-    if ((t->K & 3) || (t->Cn & 3) || (t->ldc & 3) || (t->lda & 3) || (t->ldb & 3)) return 0;
-    if (la == LD_COL && (t->R & 3)) return 0;
-    if (t->epi == EPI_DX && t->act != ACT_NONE && (t->ldaux & 3)) return 0;
-    if (t->epi == EPI_FWD && t->act == ACT_SIN && (t->ldout2 & 3)) return 0;
+    (void)la; (void)lb;
     return 1;
 }
-// ... and is it large enough to be worth leaving the latency-tuned 16-row engine?  Judged by dimensions alone, so
-// that the dry sizing pass and the real pass of the program builder agree.
+// Is the task large enough to be worth leaving the latency-tuned 16-row engine?  Judged by dimensions alone, so that the
+// dry sizing pass and the real pass of the program builder agree.
 extern "C" int rl_gemm_lds_dims_ok(const GemmTask* t, int la, int lb) {
     if (!rl_gemm_lds_align_ok(t, la, lb) || t->K < 64) return 0;
-    return 2.0 * t->R * t->Cn * t->K >= 2.5e8;
+    return 2.0 * t->R * t->Cn * t->K >= 2.0e8;
 }
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-extern "C" int rl_gemm_lds_ptrs_ok(const GemmTask* t) {
-    if (!al16(t->A) || !al16(t->B) || !al16(t->C)) return 0;
-    if (t->epi == EPI_FWD && t->bias && !al16(t->bias)) return 0;
-    if (t->epi == EPI_FWD && t->act == ACT_SIN && !al16(t->out2)) return 0;
-    if (t->epi == EPI_DX && t->act != ACT_NONE && !al16(t->aux)) return 0;
-    if (t->epi == EPI_DX && t->r1u && !al16(t->r1v)) return 0;
-    return 1;
+// pointer alignment adds to the scalar flags (never a reason to leave the engine)
+extern "C" int rl_gemm_lds_ptr_flags(const GemmTask* t) {
+    int f = 0;
+    if (!al16(t->A)) f |= FLAG_SCALAR_A;
+    if (!al16(t->B)) f |= FLAG_SCALAR_B;
+    if (!al16(t->C)) f |= FLAG_SCALAR_C;
+    if (t->epi == EPI_FWD && t->bias && !al16(t->bias)) f |= FLAG_SCALAR_C;
+    if (t->epi == EPI_FWD && t->act == ACT_SIN && !al16(t->out2)) f |= FLAG_SCALAR_C;
+    if (t->epi == EPI_DX && t->act != ACT_NONE && !al16(t->aux)) f |= FLAG_SCALAR_C;
+    if (t->epi == EPI_DX && t->r1u && !al16(t->r1v)) f |= FLAG_SCALAR_C;
+    return f;
 }
+extern "C" int rl_gemm_lds_ptrs_ok(const GemmTask* t) { (void)t; return 1; }
 // tile edge and split count for a task (dimensions only).  128-wide tiles run two workgroups per CU, so a grid that
 // already has >= 256 of them is left alone and a smaller one is split along K towards 512 workgroups (each split keeps
 // at least eight 32-deep slices); outputs too small for that use 64-wide tiles under the same rule.

@@ -80,7 +80,7 @@ def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, s
     d_bias = _dev(bias_v) if bias_v is not None else None
     d_aux = _dev(aux) if aux is not None else None
     # split-K slabs: splits * R * (Cn + 1) floats; the automatic plan never exceeds ~256 tiles' worth beyond the output
-    ws_floats = splits * R * (Cn + 1) if splits else min(32 * R * (Cn + 1), 10_000_000 + 2 * (R + 128) * (Cn + 129))
+    ws_floats = splits * R * (Cn + 5) if splits else min(32 * R * (Cn + 5), 10_000_000 + 2 * (R + 128) * (Cn + 133))
     ws = torch.zeros(max(1, ws_floats), device='cuda')
     rc = _lib.lib.rlrep_gemm(engine, la, lb, _ptr(dA), dA.shape[1], _ptr(dB), dB.shape[1], _ptr(dC), Cn, R, Cn, K, epi, ACT[act], flags,
                              _ptr(d_bias), _ptr(d_aux), Cn, _ptr(out2), bt, splits, _ptr(ws), ws.numel(),
@@ -190,10 +190,20 @@ def test_engines_agree(mode):
     assert rel(a, want) < 1e-5 and rel(b, want) < 1e-5 and rel(a, b) < 1e-5
 
 
-def test_lds_engine_rejects_unaligned_shapes():
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+def test_lds_engine_unaligned_shapes_use_scalar_accesses(mode):
+    """row strides / inner lengths / widths that are not multiples of 4 floats (spedersac's K = 119 and 111 first layers,
+    their [512, 119] weight gradients): the affected side falls back to clamped 4-byte accesses, split-K included"""
+    check(1, mode, 260, 119, 119, bt=64, splits=1, seed=50, act='elu' if mode != 'dw' else 'none')
+    check(1, mode, 128, 119, 333, bt=64, splits=3, seed=51, accum=(mode != 'fwd'))
+    check(1, mode, 132, 64, 111, bt=128, splits=1, seed=52)
+    check(1, mode, 2048 if mode != 'dw' else 512, 512 if mode != 'dw' else 119, 119 if mode != 'dw' else 2048, seed=53)
+
+
+def test_bf16x3_engine_rejects_unaligned_shapes():
     from rlrep_amd import _lib
     x = torch.zeros(64 * 64, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
-    # inner length not a multiple of 4
-    rc = _lib.lib.rlrep_gemm(1, 0, 0, x.data_ptr(), 30, x.data_ptr(), 30, x.data_ptr(), 64, 16, 64, 30, 0, 0, 0, None, None, 0, None, 0, 0, None, 0, st)
+    # inner length not a multiple of 4: fine for engine 1 (scalar staging), refused by the bf16x3 tile
+    rc = _lib.lib.rlrep_gemm(2, 0, 0, x.data_ptr(), 30, x.data_ptr(), 30, x.data_ptr(), 64, 16, 64, 30, 0, 0, 0, None, None, 0, None, 0, 0, None, 0, st)
     assert rc < 0 and b'not eligible' in _lib.lib.rlrep_last_error()
