@@ -42,6 +42,11 @@ WORKLOADS = {
     'diffsrsac_humanoid_b2048': ('diffsrsac', 376, 17, 2048, dict(hidden_dim=256, extra_feature_steps=3)),
 }
 OPT_STEPS = {'sac': 3, 'vlsac': 7, 'ctrlsac': 7, 'spedersac': 9, 'diffsrsac': 10}
+# algorithmic GFLOP per train() (2*MAC; SURVEY.md 8d, "algorithmic" column: the minimum that produces the reference's outputs)
+ALG_GFLOP = {'vlsac_halfcheetah_f256_b256': 10.59, 'sac_halfcheetah_b256': 0.582, 'sac_pendulum_b64': 0.136,
+             'ctrlsac_halfcheetah_f2048_b256': 59.44, 'ctrlsac_halfcheetah_f256_b256': 2.82, 'spedersac_ant_f512_b1024': 32.88,
+             'diffsrsac_halfcheetah_b256': 15.15, 'diffsrsac_humanoid_b2048': 2450.0}
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md); the bf16x3 tile executes 6 bf16 MFMA flops per algorithmic fp32 flop
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
 NC_FWD_TRAFFIC_BYTES = int((2 * 3103.5 + 11446.6) * 1024)   # 17.7 MB vs 11.0 MB algorithmic (U out 10.5 MB + inputs)
@@ -95,6 +100,34 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
             # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
             # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)
             'traffic': NC_FWD_TRAFFIC_BYTES, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
+
+
+def big_gemm_roofline(agent, B, S, F, Hn, reps=20):
+    """diffsrsac: the nabla-mu head forward, [B, Hn] x [Hn, F*S] (202 GFLOP at Humanoid dims), timed as its stage of the
+    feature program with HIP events on the launch stream.  It runs on the bf16 pipe as an exact three-way split (bf16x3):
+    `achieved` counts ALGORITHMIC fp32 flops against the fp32-MFMA peak; the executed bf16 rate is 6x that."""
+    core = agent.core
+    names = core.stages(0)
+    st = [i for i, n in enumerate(names) if n.startswith('phi / nabla-mu layer')]
+    if not st:
+        return None
+    s = st[-1]
+    for _ in range(3):
+        core.run_stage(0, s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        core.run_stage(0, s)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = 2.0 * B * Hn * (F * S) + 2.0 * B * 256 * F          # the head + phi's last layer riding in the same stage
+    achieved = flops / (us * 1e-6) / 1e12
+    return {'bound': 'mfma', 'kernel': 'gemm_x3_kernel<row,row> (nabla-mu head forward, bf16x3) + phi last layer', 'achieved': round(achieved, 2),
+            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'us_per_launch': round(us, 1), 'flop_per_launch': flops,
+            'executed_bf16_tflops': round(6 * achieved, 1), 'frac_of_bf16_peak': round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)}
 
 
 def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
@@ -221,8 +254,13 @@ def main():
         }
         if alg == 'vlsac':
             out['roofline'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
-            # whole-train() view: algorithmic 10.59 GFLOP per train() per GPU
-            out['train_flop_frac_of_fp32_peak'] = round(10.59e9 * value / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        elif alg == 'diffsrsac':
+            out['roofline'] = big_gemm_roofline(agent, B, S, 256, 512)
+        # whole-train() view: algorithmic GFLOP per train() per GPU against the fp32 peak
+        gf = ALG_GFLOP.get(args.workload)
+        if gf:
+            out['algorithmic_gflop_per_train'] = gf
+            out['train_flop_frac_of_fp32_peak'] = round(gf * 1e9 * value / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(alg, S, A, B, kw, data, args.cpu_threads)
         print(json.dumps(out), flush=True)

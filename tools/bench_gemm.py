@@ -12,6 +12,7 @@ SHAPES = [
     ('ctrlsac phi.l2 fwd', 'fwd', 256, 1024, 1024),
     ('ctrlsac phi.l3 fwd', 'fwd', 256, 2048, 1024),
     ('ctrlsac critic l1|l4 fwd', 'fwd', 256, 2048, 2048),
+    ('ctrlsac critic l1|l4 dx', 'dx', 256, 2048, 2048),
     ('ctrlsac score matrix', 'fwd', 256, 256, 2048),
     ('ctrlsac phi.l3 dx', 'dx', 256, 1024, 2048),
     ('ctrlsac phi.l2 dW', 'dw', 1024, 1024, 256),
