@@ -258,7 +258,7 @@ class SACAgent(object):
             segs.append(('graph', cur))
             segs.append(('coll', fn))
             nxt = torch.cuda.CUDAGraph()
-            nxt.capture_begin()
+            nxt.capture_begin(capture_error_mode='thread_local')
             self._seg = (segs, nxt)
             return
         fn()
@@ -430,7 +430,8 @@ class SACAgent(object):
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 first = torch.cuda.CUDAGraph()
-                first.capture_begin()
+                # thread-local capture mode: the process group's watchdog thread may query events while we capture
+                first.capture_begin(capture_error_mode='thread_local')
                 self._seg = ([], first)
                 try:
                     self._body(buffer, B, True)

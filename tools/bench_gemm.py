@@ -27,7 +27,7 @@ SHAPES = [
 ]
 
 
-def run(engine, mode, R, Cn, K, reps, bt=0, splits=0):
+def run(engine, mode, R, Cn, K, reps, bt=int(os.environ.get('BT', 0)), splits=int(os.environ.get('SPLITS', 0))):
     la, lb = {'fwd': (0, 0), 'dx': (0, 1), 'dw': (1, 1)}[mode]
     A = torch.randn((K, R) if la else (R, K), device='cuda')
     B = torch.randn((K, Cn) if lb else (Cn, K), device='cuda')
