@@ -189,6 +189,75 @@ __global__ __launch_bounds__(256) void diffsr_score_kernel(DiffsrScore p) {
     }
 }
 
+// The same with 16-byte accesses (S % 4 == 0, e.g. Humanoid's 376): a wave walks a row of U as 16-byte lanes (two per
+// lane up to S = 512), four rows in flight per wave; 583 -> us at Humanoid dims, where this kernel moves 2.4 GB per call.
+__global__ __launch_bounds__(256) void diffsr_score_vec_kernel(DiffsrScore p) {
+    extern __shared__ float sm[];               // [4][S] partial scores, then [S] dscore
+    __shared__ float shl[4];
+    const int b = blockIdx.x, S = p.S, F = p.F, S4 = S >> 2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* U = p.U + (size_t)b * F * S;
+    const float* phi = p.PHI + (size_t)b * F;
+    float* part = sm;                            // [4][S]
+    float* dsc = sm + 4 * S;                     // [S]
+    const int c0 = lane, c1 = lane + 64;
+    const bool ok0 = c0 < S4, ok1 = c1 < S4;
+    const int q0 = ok0 ? c0 : 0, q1 = ok1 ? c1 : 0;
+    // pass 1: wave w accumulates rows z = w, w+4, ...
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int z = w; z < F; z += 16) {
+        f32x4 u0[4], u1[4]; float pz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int zz = min(z + 4 * k, F - 1);
+            const f32x4* row = reinterpret_cast<const f32x4*>(U + (size_t)zz * S);
+            u0[k] = row[q0]; u1[k] = row[q1];
+            pz[k] = (z + 4 * k < F) ? phi[zz] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0 += pz[k] * u0[k]; a1 += pz[k] * u1[k]; }
+    }
+    if (ok0) *reinterpret_cast<f32x4*>(part + w * S + 4 * c0) = a0;
+    if (ok1) *reinterpret_cast<f32x4*>(part + w * S + 4 * c1) = a1;
+    __syncthreads();
+    const float ab = p.alphabars[p.idx[b]];
+    const float coef = (1.0f - ab) * p.sigma;
+    float l = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const float score = ((part[s] + part[S + s]) + part[2 * S + s]) + part[3 * S + s];
+        const float diff = p.TGT[(size_t)b * S + s] - coef * score;
+        l += diff * diff;
+        dsc[s] = -2.f * coef * diff * p.inv_batch;
+    }
+    const float lb = block_sum_256(l, shl);
+    if (threadIdx.x == 0) p.partial[b] = lb;
+    __syncthreads();
+    // pass 2: dphi_z = sum_s dscore_s U[z,s];  U <- dU = phi_z dscore_s
+    const f32x4 d0 = ok0 ? *reinterpret_cast<const f32x4*>(dsc + 4 * c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 d1 = ok1 ? *reinterpret_cast<const f32x4*>(dsc + 4 * c1) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = w; z < F; z += 16) {
+        f32x4 u0[4], u1[4]; float pz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int zz = min(z + 4 * k, F - 1);
+            const f32x4* row = reinterpret_cast<const f32x4*>(U + (size_t)zz * S);
+            u0[k] = row[q0]; u1[k] = row[q1];
+            pz[k] = phi[zz];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (z + 4 * k >= F) break;
+            const f32x4 t0 = d0 * u0[k], t1 = d1 * u1[k];
+            float a = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t1[0] + t1[1]) + (t1[2] + t1[3]));
+            a = wave_sum(a);
+            f32x4* row = reinterpret_cast<f32x4*>(U + (size_t)(z + 4 * k) * S);
+            if (ok0) row[c0] = pz[k] * d0;
+            if (ok1) row[c1] = pz[k] * d1;
+            if (lane == 0) p.GPHI[(size_t)b * F + z + 4 * k] = a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void copy2_kernel(const float* __restrict__ src, float* __restrict__ d1, float* __restrict__ d2, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float v = src[i];
@@ -225,7 +294,10 @@ extern "C" int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st) 
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st) {
-    hipLaunchKernelGGL(diffsr_score_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);
+    if ((p->S & 3) == 0 && p->S <= 512 && ((((uintptr_t)p->U) & 15) == 0))
+        hipLaunchKernelGGL(diffsr_score_vec_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);
+    else
+        hipLaunchKernelGGL(diffsr_score_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_copy2(const float* src, float* d1, float* d2, long long n, hipStream_t st) {

@@ -45,6 +45,46 @@ json.dump(pmc, open(os.path.join(P, f'{tag}_pmc_summary.json'), 'w'), indent=1, 
 
 bench = open(os.path.join(G, f'bench_{tag}b.json')).read().strip().splitlines()[-1]
 open(os.path.join(P, f'{tag}_bench.json'), 'w').write(bench + '\n')
+# ---- the large-dimension workloads (BASELINE configs 3-5) and the GEMM engines ----------------------------------
+extra = {}
+for wl in ('ctrlsac_halfcheetah_f2048_b256', 'spedersac_ant_f512_b1024', 'diffsrsac_humanoid_b2048'):
+    fs = glob.glob(os.path.join(G, f'prof_{wl}', '*', '*_kernel_stats.csv'))
+    if fs:
+        src = max(fs, key=os.path.getmtime)
+        rws = [r for r in csv.DictReader(open(src)) if 'at::native' not in r['Name'] and 'rocclr' not in r['Name']]
+        with open(os.path.join(P, f'{tag}_{wl}_kernel_stats.csv'), 'w') as f:
+            w = csv.DictWriter(f, fieldnames=list(rws[0].keys())); w.writeheader(); w.writerows(rws[:20])
+        extra[wl] = [(short(r['Name']), int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage'])) for r in rws[:8]]
+lines = []
+for f in sorted(glob.glob(os.path.join(G, 'bench_*.log'))):
+    last = [l for l in open(f).read().strip().splitlines() if l.startswith('{')]
+    if last:
+        lines.append(last[-1])
+seen = {}
+for l in lines:
+    d = json.loads(l); seen[d['config']['workload']] = l          # one line per workload (latest file wins)
+open(os.path.join(P, f'{tag}_bench_all.jsonl'), 'w').write('\n'.join(seen[k] for k in sorted(seen)) + '\n')
+gp = {}
+for sub in ('pmc_gemm', 'pmc_gemm2'):
+    files = glob.glob(os.path.join(G, sub, '*', '*_counter_collection.csv'))
+    if not files:
+        continue
+    acc = {}
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+        k = short(r['Kernel_Name'])
+        if 'gemm' not in k:
+            continue
+        d = acc.setdefault(k, {}).setdefault(r['Counter_Name'], {})
+        d[r['Dispatch_Id']] = d.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
+    for k, cs in acc.items():
+        for c, per in cs.items():
+            gp.setdefault(k, {})[c] = round(sum(per.values()) / len(per), 1)
+json.dump(gp, open(os.path.join(P, f'{tag}_pmc_gemm_4096.json'), 'w'), indent=1, sort_keys=True)
+if os.path.exists(os.path.join(G, 'bench_gemm.log')):
+    keep = [l for l in open(os.path.join(G, 'bench_gemm.log')).read().splitlines() if ' GF |' in l]
+    open(os.path.join(P, f'{tag}_gemm_engines.txt'), 'w').write('\n'.join(keep) + '\n')
+json.dump(extra, open(os.path.join(P, f'{tag}_large_workloads_top_kernels.json'), 'w'), indent=1)
+
 print('\n'.join(table))
 b = json.loads(bench)
 print('\nbench:', b['value'], b['unit'], b['ms_per_step'], 'ms;', 'roofline', json.dumps(b['roofline']))

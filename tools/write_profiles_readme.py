@@ -65,11 +65,44 @@ against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs).  `nc_dw
 ## Micro-benchmarks behind the design decisions (`tools/exp/*.hip`, run with gpurun; results quoted in DESIGN.md)
 
 * `gridbar`   in-kernel device-wide barrier: 13-41 us per phase at 256-512 workgroups vs 1.9-2.0 us per graph launch
-* `mfma_peak` sustained v_mfma_f32_16x16x4_f32: 75 / 113 / 118 / 127 TFLOP/s at 1 / 2 / 4 / 8 waves per SIMD
+* `mfma_peak` sustained v_mfma_f32_16x16x4_f32 (5 accumulators): 81 / 122 / 126 / 129 TFLOP/s at 1 / 2 / 4 / 8 waves per SIMD (52 cycles per
+  MFMA for a wave alone on its SIMD); v_mfma_f32_32x32x2_f32: 83 / 108 / 130 TF with 1 / 2 / 4 accumulators at one wave per SIMD, 143 TF at two
 * `kernarg`   dependent scalar loads from the kernel-argument segment: hidden (1.77 us per launch with or without)
 * `icache`, `ijump`  cold instruction fetch: no measurable penalty (straight-line or taken branches)
 * `loadlat`, `xcdlat`  first load of the previous kernel's output: 470 cycles same XCD, 810-2200 cycles other XCD;
   workgroup -> XCD placement is round-robin on blockIdx.x
+'''
+# ---- large-dimension workloads and the LDS-tiled GEMM engines ----------------------------------------------------
+big = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_large_workloads_top_kernels.json')))
+allb = {json.loads(l)['config']['workload']: json.loads(l) for l in open(os.path.join(ROOT, 'profiles', f'{tag}_bench_all.jsonl'))}
+gp = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_gemm_4096.json')))
+txt += '''
+## The other workloads of bench.py (`--workload ...`; un-profiled lines in `''' + tag + '''_bench_all.jsonl`)
+
+| workload | train()/s | ms per train() | algorithmic GFLOP per train() (SURVEY 8d) | fraction of the 157.3 TF fp32 peak |
+|---|---|---|---|---|
+''' + '\n'.join(f"| `{k}` | {v['value']} | {v['ms_per_step']} | {v.get('algorithmic_gflop_per_train', '')} | {v.get('train_flop_frac_of_fp32_peak', '')} |" for k, v in sorted(allb.items())) + '''
+
+Top kernels of the three large-dimension workloads (`rocprofv3 --kernel-trace --stats -- python3 bench.py --workload W --steps 60|6 --no-cpu`,
+full tables in `''' + tag + '''_<workload>_kernel_stats.csv`; `gemm_lds_kernel<tile, loader A, loader B>`, loader 0 = row-major, 1 = k-major):
+
+'''
+for wl, rows in big.items():
+    txt += f'`{wl}`\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n' + '\n'.join(f'| `{n}` | {c} | {a:.1f} | {pc:.1f} |' for n, c, a, pc in rows) + '\n\n'
+txt += '''## GEMM engines on the path's large shapes (`python tools/bench_gemm.py`, HIP events, `''' + tag + '''_gemm_engines.txt`)
+
+```
+''' + open(os.path.join(ROOT, 'profiles', f'{tag}_gemm_engines.txt')).read() + '''```
+
+PMC at 4096^3 (`tools/_pmc_gemm.sh`, two `--pmc` passes with `--kernel-trace` only; `''' + tag + '''_pmc_gemm_4096.json`, per launch, summed over XCDs):
+
+| kernel | MFMA insts | VALU_MFMA_BUSY cycles | GRBM_GUI_ACTIVE / 8 (cycles) | matrix-pipe utilisation = BUSY / (cycles x 1024 SIMDs) | WAIT_INST_LDS / WAVE_CYCLES | LDS bank-conflict / LDS active cycles |
+|---|---|---|---|---|---|---|
+''' + '\n'.join(f"| `{k}` | {d['SQ_INSTS_MFMA']:.0f} | {d['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} | {d['GRBM_GUI_ACTIVE'] / 8:.0f} | {100 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.0f} % | {100 * d['SQ_WAIT_INST_LDS'] / d['SQ_WAVE_CYCLES']:.0f} % | {100 * d['SQ_LDS_BANK_CONFLICT'] / d['SQ_LDS_IDX_ACTIVE']:.0f} % |" for k, d in gp.items()) + '''
+
+The fp32-MFMA tile keeps the matrix pipe ~77 % busy (123 TF of 157.3); the bf16x3 tile issues 6 bf16 MFMAs per fp32 product and
+holds its pipe ~54 % busy at a lower clock (184 TF fp32-equivalent = 1.10 PF executed bf16): it is bound by LDS issue (three
+bf16 images per operand: WAIT_INST_LDS) and by the split's VALU work, not by the matrix pipe.
 '''
 open(os.path.join(ROOT, 'profiles', f'{tag}_README.md'), 'w').write(txt)
 print('wrote', f'profiles/{tag}_README.md')
