@@ -288,6 +288,12 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, i
                    const float* bias_dev, const float* aux_dev, int32_t ldaux, float* out2_dev, int32_t bt, int32_t splits,
                    float* workspace_dev, int64_t workspace_floats, void* stream);
 
+/* Host-only (no GPU call): the GEMM engine the program builder picks for a product of these dimensions and layouts --
+ * *engine 0 = 16-row tile engine, 1 = LDS-tiled fp32-MFMA, 2 = LDS-tiled bf16x3 -- with its tile edge (64 / 128), split-K
+ * plan and which sides fall back to 4-byte accesses (bit 0: A, bit 1: B, bit 2: C). */
+int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t rows, int32_t cols, int32_t inner, int32_t lda, int32_t ldb, int32_t ldc,
+                        int32_t* engine, int32_t* tile, int32_t* splits, int32_t* kchunk, int32_t* scalar_sides);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 

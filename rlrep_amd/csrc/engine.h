@@ -20,6 +20,7 @@ int rl_gemm_lds_dims_ok(const GemmTask* t, int la, int lb);
 int rl_gemm_lds_ptrs_ok(const GemmTask* t);
 int rl_gemm_lds_dim_flags(const GemmTask* t, int la, int lb);
 int rl_gemm_lds_ptr_flags(const GemmTask* t);
+int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_flags, int* splits, int* kchunk, int* flags);
 void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* kchunk);
 int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st);
 int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);

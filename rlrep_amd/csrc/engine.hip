@@ -1083,6 +1083,21 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
     return 0;
 }
 
+int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
+                        int32_t* engine, int32_t* tile, int32_t* splits, int32_t* kchunk, int32_t* scalar_sides) {
+    if (R <= 0 || Cn <= 0 || K <= 0 || !engine) { rl_set_error("gemm_plan: bad argument"); return RLREP_ERR_ARG; }
+    GemmTask t; memset(&t, 0, sizeof(t));
+    t.R = R; t.Cn = Cn; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.epi = la == LD_COL ? EPI_DW : EPI_FWD;
+    int sp = 1, kc = 0, fl = 0;
+    const int code = rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl);
+    *engine = code == 0 ? 0 : code == 129 ? 2 : 1;
+    if (tile) *tile = code == 0 ? 16 : code == 129 ? 128 : code;
+    if (splits) *splits = code ? sp : 1;
+    if (kchunk) *kchunk = code ? kc : K;
+    if (scalar_sides) *scalar_sides = code ? (((fl & FLAG_SCALAR_A) ? 1 : 0) | ((fl & FLAG_SCALAR_B) ? 2 : 0) | ((fl & FLAG_SCALAR_C) ? 4 : 0)) : 0;
+    return 0;
+}
+
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
 int32_t rlrep_last_launch_count(rlrep_agent* ag) { return ag ? ag->last_launches : 0; }
 

@@ -95,26 +95,18 @@ struct Builder {
     // 16-byte aligned simply stays on gemm16 and leaves its slab unused.
     void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
         std::vector<GemmTask> small, big128, big64, bigx3;
-        const bool combo = (la == LD_ROW && lb == LD_ROW) || (la == LD_ROW && lb == LD_COL) || (la == LD_COL && lb == LD_COL);
-        const bool use_lds = combo && !fused() && !getenv("RLREP_NO_GEMM_LDS");
         for (auto& t : tasks) {
-            if (use_lds && rl_gemm_lds_dims_ok(&t, la, lb)) {
-                int bt = 0, sp = 1, kc = 0;
-                rl_gemm_lds_plan(&t, &bt, &sp, &kc);
+            int sp = 1, kc = 0, fl = 0;
+            // dimensions decide the engine and the slab reservation (identical in the dry and the real pass) ...
+            if (!fused() && rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl)) {
                 // (the bias-gradient flag depends on a pointer that is null in the dry pass: reserve for every dW task)
                 float* slab = sp > 1 ? ws.f((size_t)sp * t.R * ((t.Cn + 3) & ~3)) : nullptr;
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
-                if (dry || rl_gemm_lds_ptrs_ok(&t)) {
-                    t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab;
-                    t.flags |= rl_gemm_lds_dim_flags(&t, la, lb) | (dry ? 0 : rl_gemm_lds_ptr_flags(&t));
-                    // products of >= 2 GFLOP with a row-major A (forward, dX: e.g. diffsrsac's 202-GFLOP nabla-mu head) run the
-                    // 128-wide tile on the bf16 pipe (bf16x3, fp32-accurate): 159 / 137 TF against 110 on the fp32 pipe; the
-                    // k-major/k-major weight-gradient form stays on fp32 MFMA (its staging does not pay: 107 vs 116 TF)
-                    const bool x3 = bt == 128 && la == LD_ROW && 2.0 * t.R * t.Cn * t.K >= 2e9 && !getenv("RLREP_NO_X3") &&
-                                    !(t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
-                    (x3 ? bigx3 : bt == 128 ? big128 : big64).push_back(t);
-                    continue;
-                }
+                // ... pointer alignment can only add scalar-access flags (and take bf16x3 away)
+                const int code = rl_gemm_lds_route(&t, la, lb, dry ? 0 : rl_gemm_lds_ptr_flags(&t), &sp, &kc, &fl);
+                t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab; t.flags |= fl;
+                (code == 129 ? bigx3 : code == 128 ? big128 : big64).push_back(t);
+                continue;
             }
             small.push_back(t);
         }

@@ -644,3 +644,19 @@ extern "C" void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* k
     s = (t->K + kc - 1) / kc;
     *bt = b; *splits = s; *kchunk = kc;
 }
+
+// The program builder's routing decision for one task, from dimensions alone (pointer alignment may add scalar flags
+// later, which also rules out bf16x3): returns 0 = stays on the 16-row engine, 64 / 128 = fp32-MFMA tile, 129 = the 128-wide
+// tile on the bf16 pipe.  Products of >= 2 GFLOP with a row-major A (forward, dX: diffsrsac's 202-GFLOP nabla-mu head) take
+// bf16x3: 159 / 137 TF against 110 on the fp32 pipe; the k-major/k-major weight-gradient form stays on fp32 MFMA (107 vs 116).
+extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_flags, int* splits, int* kchunk, int* flags) {
+    const bool combo = (la == LD_ROW && lb == LD_ROW) || (la == LD_ROW && lb == LD_COL) || (la == LD_COL && lb == LD_COL);
+    if (!combo || getenv("RLREP_NO_GEMM_LDS") || !rl_gemm_lds_dims_ok(t, la, lb)) return 0;
+    int bt = 0;
+    rl_gemm_lds_plan(t, &bt, splits, kchunk);
+    *flags = rl_gemm_lds_dim_flags(t, la, lb) | extra_flags;
+    const bool x3 = bt == 128 && la == LD_ROW && 2.0 * t->R * t->Cn * t->K >= 2e9 && !getenv("RLREP_NO_X3") &&
+                    !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
+    return x3 ? 129 : bt;
+}
+

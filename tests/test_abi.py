@@ -58,3 +58,47 @@ def test_bad_arguments_are_rejected_with_a_message():
     info = _lib.LayoutInfo()
     assert _lib.lib.rlrep_layout(C.byref(d), C.byref(info), None, 0) < 0
     assert _lib.lib.rlrep_last_error()
+
+
+def _plan(la, lb, R, Cn, K, lda=None, ldb=None, ldc=None):
+    from rlrep_amd import _lib
+    lda = lda if lda is not None else (R if la else K)
+    ldb = ldb if ldb is not None else (Cn if lb else K)
+    ldc = ldc if ldc is not None else Cn
+    out = [C.c_int32() for _ in range(5)]
+    assert _lib.lib.rlrep_gemm_plan(la, lb, R, Cn, K, lda, ldb, ldc, *[C.byref(o) for o in out]) == 0
+    return dict(zip(('engine', 'tile', 'splits', 'kchunk', 'scalar'), (o.value for o in out)))
+
+
+def test_gemm_routing_of_the_path_shapes():
+    """Host-only routing of the program builder (rlrep_gemm_plan): which engine / tile / split-K plan each layer class of
+    the five agents gets.  The split plan must cover the inner dimension exactly once."""
+    # the headline configuration's 256-wide layers stay on the latency-tuned 16-row engine
+    assert _plan(0, 0, 256, 256, 256)['engine'] == 0
+    assert _plan(0, 0, 256, 512, 256)['engine'] == 0
+    assert _plan(1, 1, 256, 256, 256)['engine'] == 0
+    # ctrlsac main.py dims: M = 256 layers -> 64-wide tiles + split-K; weight gradients -> 64-wide tiles, no split
+    p = _plan(0, 0, 256, 1024, 1024)
+    assert (p['engine'], p['tile']) == (1, 64) and p['splits'] == 4 and p['splits'] * p['kchunk'] >= 1024 > (p['splits'] - 1) * p['kchunk']
+    p = _plan(1, 1, 1024, 1024, 256)
+    assert (p['engine'], p['tile'], p['splits']) == (1, 64, 1)
+    # spedersac: both batches as one M = 2048 problem; the K = 119 first layer and its [512, 119] weight gradient use scalar sides
+    assert _plan(0, 0, 2048, 512, 512)['engine'] == 1
+    p = _plan(0, 0, 2048, 512, 119)
+    assert p['engine'] == 1 and p['scalar'] == 3          # A and B rows of 119 floats
+    p = _plan(1, 1, 512, 119, 2048, lda=512, ldb=119, ldc=119)
+    assert p['engine'] == 1 and p['scalar'] == 6 and p['splits'] > 1
+    # diffsrsac Humanoid nabla-mu head: forward and dX on the bf16 pipe, dW on fp32 MFMA, dX split along its long K
+    assert _plan(0, 0, 2048, 96256, 512) == dict(engine=2, tile=128, splits=1, kchunk=512, scalar=0)
+    p = _plan(0, 1, 2048, 512, 96256)
+    assert p['engine'] == 2 and p['splits'] == 8 and p['splits'] * p['kchunk'] >= 96256 > (p['splits'] - 1) * p['kchunk'] and p['kchunk'] % 32 == 0
+    p = _plan(1, 1, 96256, 512, 2048)
+    assert (p['engine'], p['tile'], p['splits']) == (1, 128, 1)
+    # every plan over a sweep: splits cover K, chunks are multiples of the 32-deep slice, tiles are 64 or 128
+    for R in (256, 1000, 2048, 4096):
+        for Cn in (256, 520, 2048):
+            for K in (64, 256, 1000, 4096, 50000):
+                p = _plan(0, 0, R, Cn, K)
+                if p['engine']:
+                    assert p['tile'] in (64, 128) and p['kchunk'] % 32 == 0 and 1 <= p['splits'] <= 32
+                    assert p['splits'] * p['kchunk'] >= K > (p['splits'] - 1) * p['kchunk'], (R, Cn, K, p)
