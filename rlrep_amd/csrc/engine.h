@@ -26,6 +26,7 @@ int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t 
 int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
 int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);
 int rl_nc_init();
+int rl_nc_fwd_cols();
 int rl_launch_fill_slot(const SlotFill* p, hipStream_t st);
 int rl_launch_philox(const PhiloxFill* p, hipStream_t st);
 int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st);

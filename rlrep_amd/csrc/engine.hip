@@ -416,7 +416,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         nb.ntasks = (int)tasks.size();
         for (size_t q = 0; q < tasks.size(); ++q) {
             NcFwdTask& t = tasks[q];
-            t.tiles_h = (H + 63) / 64; t.ntiles = ((B + 4 * g2 - 1) / (4 * g2)) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles;
+            t.tiles_h = (H + rl_nc_fwd_cols() - 1) / rl_nc_fwd_cols(); t.ntiles = ((B + 4 * g2 - 1) / (4 * g2)) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles;
             nb.t[q] = t;
         }
         const int total = base_tile;

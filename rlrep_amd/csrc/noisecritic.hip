@@ -26,6 +26,18 @@
 
 extern __shared__ __attribute__((aligned(16))) float nc_smem[];
 
+#ifdef RL_TIMING_NC
+// Instrumented build (tools/exp/nc_timeline.py): thread 0 of every workgroup stamps the shader clock at entry, after the table
+// staging barrier, after the MFMA loop and at exit, plus the 100 MHz wall clock at entry / exit.
+__device__ unsigned long long g_nc_tim[6 * 4096];
+extern "C" int rl_nc_timing_fetch(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_nc_tim), sizeof(unsigned long long) * n);
+}
+#define NCT(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_nc_tim[6 * blockIdx.x + (k)] = (k) < 4 ? clock64() : wall_clock64(); } while (0)
+#else
+#define NCT(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ void ld4(const float* p, bool vec, int valid, float (&v)[4]) {
     // valid = number of in-range elements (0..4)
     if (vec && valid == 4) { f32x4 x = *reinterpret_cast<const f32x4*>(p); v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
@@ -38,9 +50,12 @@ __device__ __forceinline__ void ld4(const float* p, bool vec, int valid, float (
 // ------------------------------------------------------------------------------------------------
 // forward.  workgroup = 4 waves = (4*G2 batch rows) x 20 noise rows x 64 hidden units; K loop over F.
 // ------------------------------------------------------------------------------------------------
-template <int G2>
-__global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
+// NW waves per workgroup = 16 * NW hidden units: the tables depend on the batch rows only, so a wider workgroup stages them
+// once for more columns (NW = 8: half the table traffic and staging time of NW = 4 at the same waves per SIMD)
+template <int G2, int NW>
+__global__ __launch_bounds__(64 * NW) void nc_fwd_kernel(NcFwdBatch nb) {
     const int bid = blockIdx.x;
+    NCT(0); NCT(4);
     int ti = 0;
 #pragma unroll
     for (int q = 1; q < NC_MAX_TASKS; ++q) if (q < nb.ntasks && bid >= nb.t[q].tile_base) ti = q;
@@ -48,7 +63,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
     const int local = bid - t.tile_base;
     const int tb = local / t.tiles_h, th = local - tb * t.tiles_h;
     const int RB = 4 * G2;
-    const int b0 = tb * RB, n0 = th * 64;
+    const int b0 = tb * RB, n0 = th * (16 * NW);
     const int F = t.F, H = t.H, N = t.N;
     const int Fp = (F + 15) & ~15;
     const int LDS_LD = Fp + 16;
@@ -76,13 +91,13 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
     // serialising (the element-wise loop this replaces cost 7.7 us of a 40 us launch).
     {
         constexpr int NROWS = 2 * RB + 4 * NC_NF;          // mean rows, sigma rows, noise rows (N = 20)
-        constexpr int SLOTS = (NROWS + 3) / 4;
+        constexpr int SLOTS = (NROWS + NW - 1) / NW;
         for (int cb = 0; cb < Fp; cb += 256) {
             const int k = cb + 4 * lane;
             f32x4 v[SLOTS];
 #pragma unroll
             for (int q = 0; q < SLOTS; ++q) {
-                const int row = 4 * q + w;
+                const int row = NW * q + w;
                 v[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (row < NROWS && k < F) {
                     if (row < 2 * RB) {
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
             }
 #pragma unroll
             for (int q = 0; q < SLOTS; ++q) {
-                const int row = 4 * q + w;
+                const int row = NW * q + w;
                 if (row >= NROWS || k >= Fp) continue;
                 f32x4 x = v[q];
                 if (row >= RB && row < 2 * RB) {
@@ -112,6 +127,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         }
     }
     __syncthreads();
+    NCT(1);
 
     f32x4 acc[G2][NC_NF];
 #pragma unroll
@@ -119,6 +135,10 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
 #pragma unroll
         for (int f = 0; f < NC_NF; ++f) acc[g][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // (A variant with two named register sets, which issued the LDS table reads and the W fragment of chunk c+1 before the MFMAs
+    // of chunk c, measured the same 47.8k cycles per workgroup for this loop -- tools/exp/nc_timeline.py: staging 4.9k, loop
+    // 48.2k, epilogue 3.6k cycles at 2.1 GHz.  The loop runs at 85 % of 32 cycles per MFMA, the rate tools/exp/mfma_peak.hip
+    // measures for four waves per SIMD: 126 of 157 TF.)
     for (int kb = 0; kb < Fp; kb += 16) {
         const int k0 = kb + 4 * kq;
         {   // prefetch the next W fragment
@@ -145,6 +165,7 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         for (int s = 0; s < 4; ++s) wv[s] = wn[s];
     }
 
+    NCT(2);
     if (!colok) return;
     const float bj = t.bias[col];
     const float invN = 1.0f / (float)N;
@@ -157,12 +178,13 @@ __global__ __launch_bounds__(256) void nc_fwd_kernel(NcFwdBatch nb) {
         for (int f = 0; f < NC_NF; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float y = elu_f(acc[g][f][r] + bj);
+                const float y = elu_fast(acc[g][f][r] + bj);
                 sum += y;
                 if (t.U) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
             }
         t.Hm[(size_t)b * H + col] = sum * invN;
     }
+    NCT(3); NCT(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -567,15 +589,27 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// hidden units per nc_fwd workgroup (64 or 128); the builder sizes tiles_h with it
+extern "C" int rl_nc_fwd_cols() {
+    static const int v = [] { const char* e = getenv("RLREP_NC_COLS"); const int x = e ? atoi(e) : 128; return x == 64 ? 64 : 128; }();
+    return v;
+}
 extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     for (int q = 0; q < nb->ntasks; ++q) if (nb->t[q].N != 4 * NC_NF) return -2;      // the row mapping is built for N = 20
     const int F = nb->t[0].F, N = nb->t[0].N;
     const int Fp = (F + 15) & ~15;
     const size_t lds = (size_t)(8 * g2 + N) * (Fp + 16) * sizeof(float);
-    if (g2 == 1) hipLaunchKernelGGL(nc_fwd_kernel<1>, dim3(total_tiles), dim3(256), lds, st, *nb);
-    else if (g2 == 2) hipLaunchKernelGGL(nc_fwd_kernel<2>, dim3(total_tiles), dim3(256), lds, st, *nb);
-    else hipLaunchKernelGGL(nc_fwd_kernel<4>, dim3(total_tiles), dim3(256), lds, st, *nb);
+    const int nw = rl_nc_fwd_cols() / 16;
+    if (nw == 8) {
+        if (g2 == 1) hipLaunchKernelGGL((nc_fwd_kernel<1, 8>), dim3(total_tiles), dim3(512), lds, st, *nb);
+        else if (g2 == 2) hipLaunchKernelGGL((nc_fwd_kernel<2, 8>), dim3(total_tiles), dim3(512), lds, st, *nb);
+        else hipLaunchKernelGGL((nc_fwd_kernel<4, 8>), dim3(total_tiles), dim3(512), lds, st, *nb);
+    } else {
+        if (g2 == 1) hipLaunchKernelGGL((nc_fwd_kernel<1, 4>), dim3(total_tiles), dim3(256), lds, st, *nb);
+        else if (g2 == 2) hipLaunchKernelGGL((nc_fwd_kernel<2, 4>), dim3(total_tiles), dim3(256), lds, st, *nb);
+        else hipLaunchKernelGGL((nc_fwd_kernel<4, 4>), dim3(total_tiles), dim3(256), lds, st, *nb);
+    }
     return (int)hipGetLastError();
 }
 
