@@ -229,10 +229,12 @@ def main():
 
     for _ in range(args.warmup):
         agent.train(buf, B)
+    agent.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.train(buf, B)
+    agent.flush()           # pipelined graph mode: the last train()'s critic / actor steps belong inside the timed window
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -253,6 +253,22 @@ int32_t rlrep_feature_exchange_count(rlrep_agent* agent);
 int32_t rlrep_feature_exchange(rlrep_agent* agent, int32_t k, int32_t* kind, float** ptr_dev, int64_t* count, int64_t* local_off);
 int32_t rlrep_feature_backward_part(rlrep_agent* agent, int32_t part, const float* eps_dev, const int32_t* noise_idx_dev, void* stream);
 
+/* ---- deferred critic / actor steps (vlsac) ---------------------------------------------------
+ * The feature steps of train(t+1) read nothing that the critic and actor steps of train(t) write, and the critic / actor steps
+ * read only f_target, the last minibatch, their policy noise and the step counter from the feature side.  rlrep_defer_snapshot
+ * copies exactly those (ONE launch) after the last feature step of train(t); rlrep_deferred_critic_actor then runs critic_step,
+ * update_actor_and_alpha and the (period-gated) critic-target Polyak of train(t) against the snapshot, so a caller may issue it
+ * on a second stream / graph branch next to train(t+1)'s feature steps.  Same arithmetic and the same sequence of updates
+ * per parameter as the sequential entry points (tests/test_hip_parity.py::test_deferred_pipeline_is_equivalent); the caller
+ * must order: snapshot(t) after feature steps(t) AND after deferred(t-1); anything that reads the critic / actor (select_action,
+ * checkpoints, metrics of those steps) after deferred(t).  rlrep_defer_supported: 1 if built for this agent. */
+int32_t rlrep_defer_supported(rlrep_agent* agent);
+int32_t rlrep_defer_snapshot(rlrep_agent* agent, const float* eps_critic_dev, const float* eps_actor_dev, void* stream);
+int32_t rlrep_deferred_critic_actor(rlrep_agent* agent, void* stream);
+/* Host-only: closes a rlrep_begin_train / rlrep_train_prologue bracket without launching anything (the critic-target update of a
+ * deferred train() runs inside rlrep_deferred_critic_actor). */
+int32_t rlrep_end_train(rlrep_agent* agent);
+
 /* ctrlsac: frozen_phi, frozen_phi_target <- phi (ctrlsac_agent.py:344-346). No-op for other agents. */
 int32_t rlrep_sync_frozen(rlrep_agent* agent, void* stream);
 

@@ -110,6 +110,11 @@ class SACAgent(object):
         self._next_key = {}
         self._early_key = None
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
+        # critic / actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (vlsac; _train_graph_pipelined)
+        self.use_pipeline = bool(int(os.environ.get('RLREP_PIPELINE', '1'))) and hip_kwargs.get('pipeline', True)
+        self._pipe = None
+        self._pending = False
+        self.core.before_read = self.flush
 
     # parameter initialisation (values only; layout is the library's)
     def _orth(self, name, gain=1.0):
@@ -156,6 +161,7 @@ class SACAgent(object):
         return self.core.alpha_state[0]
 
     def select_action(self, state, explore=False):
+        self.flush()
         obs = torch.as_tensor(np.asarray(state, dtype=np.float32)).reshape(1, -1).to(self.core.device)
         eps = self._noise('sel', (1, self.action_dim)) if explore else None
         action = self.core.actor_forward(obs, eps, *self.action_range)
@@ -163,14 +169,17 @@ class SACAgent(object):
         return util.to_np(action[0])
 
     def update_target(self):
+        self.flush()
         self.core.update_target()
 
     def critic_step(self, batch, eps=None):
+        self.flush()
         self._set_batch(batch)
         self.core.critic_step(self._noise('crit', (self._B, self.action_dim)) if eps is None else eps)
         return self.core.info(self.CRITIC_KEYS)
 
     def update_actor_and_alpha(self, batch, eps=None):
+        self.flush()
         self._set_batch(batch)
         self.core.actor_step(self._noise('act', (self._B, self.action_dim)) if eps is None else eps)
         return self.core.info(self.ACTOR_KEYS)
@@ -179,6 +188,8 @@ class SACAgent(object):
         """One train step (sac_agent.py:169-188)."""
         self.steps += 1
         if self.use_graph and self.world_size == 1:
+            if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
+                return self._train_graph_pipelined(buffer, batch_size)
             return self._train_graph(buffer, batch_size)
         if self.use_graph and self.use_graph_dp:
             return self._train_graph_dp(buffer, batch_size)
@@ -189,6 +200,7 @@ class SACAgent(object):
     # ---- checkpoint / resume (absent in the reference: `--save_model` is parsed and never read, main.py:37) ------
     def state_snapshot(self):
         c = self.core
+        self.flush()
         torch.cuda.synchronize()
         steps_dev = None
         return {'alg': self.ALG, 'params': c.params.cpu(), 'targets': c.targets.cpu(), 'exp_avg': c.exp_avg.cpu(),
@@ -209,6 +221,7 @@ class SACAgent(object):
         c.device_state().copy_(snap['device_state'])
         self.steps, self._ctr, self._seed = snap['steps'], snap['noise_ctr'], snap['seed']
         self._graph = None
+        self._pipe, self._pending = None, False
         torch.cuda.synchronize()
 
     # ---- internals ----------------------------------------------------------------------------
@@ -402,6 +415,7 @@ class SACAgent(object):
         order.  Used by the parity tests and smoke(): 'fixed seeds' parity is
         injected-noise parity, the torch/NumPy generators cannot be reproduced on the device."""
         self.steps += 1
+        self.flush()
         buffer.flush()
         self._inject = dict(idx=list(idx), eps=list(eps))
         try:
@@ -411,6 +425,7 @@ class SACAgent(object):
         return self.core.info()
 
     def _train_eager(self, buffer, B):
+        self.flush()
         buffer.flush()
         self._body(buffer, B, False)
         return self.core.info()
@@ -449,6 +464,102 @@ class SACAgent(object):
             else:
                 x()
         return self.core.info()
+
+    # ---- pipelined graph mode ---------------------------------------------------------------------------------------
+    # train(t) = feature steps(t) -> critic(t) -> actor(t).  Feature steps read and write (encoder, decoder, f, f_target); critic
+    # and actor read f_target / the last minibatch / their noise and write (critic, critic_target, actor, log_alpha).  With those
+    # reads snapshotted (rlrep_defer_snapshot) the critic and actor steps of train(t) are independent of the feature steps of
+    # train(t+1), and the steady-state graph runs them as TWO CONCURRENT BRANCHES: the dependent-launch chain per train() drops
+    # from 71 launches to max(48 feature, 25 critic+actor).  Every parameter sees exactly the updates, in exactly the order, of
+    # the sequential train(); `flush()` (called by everything that looks at the critic / actor: select_action, checkpoints,
+    # reading a returned info dict, the eager step methods) runs the one pending critic+actor pair.
+    def _feature_part(self, buffer, B):
+        self._pool = None
+        self._next_key = {}
+        self._fill_pools(buffer, B, True)           # rlrep_train_prologue: steps += 1, pools, first gather
+        self._early_key = None                      # both policy forwards belong to the deferred branch
+        for i in range(self._feature_iters()):
+            self._feature_once(buffer, B, i, True)
+        return self._pool['eps_crit'], self._pool['eps_act']
+
+    def _train_graph_pipelined(self, buffer, B):
+        buffer.flush()
+        buffer.size_dev()
+        key = (id(buffer), B)
+        c = self.core
+        if self._pipe is None or self._pipe['key'] != key:
+            self.flush()
+            self._sample_into(buffer, B, 'warm', 0, False)      # sizes the library's tables for B outside any capture
+            idx_keys, eps_specs = self._plan(B)
+            self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
+            self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
+            torch.cuda.synchronize()
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            first, steady, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(first, stream=s1):
+                ec, ea = self._feature_part(buffer, B)
+                c.defer_snapshot(ec, ea)
+                c.end_train()
+            with torch.cuda.graph(steady, stream=s1):
+                fork = torch.cuda.Event()
+                fork.record()
+                s2.wait_event(fork)
+                c.deferred_critic_actor()                       # branch 1 (s1): critic + actor of the previous train()
+                with torch.cuda.stream(s2):                      # branch 2 (s2): this train()'s feature steps
+                    ec, ea = self._feature_part(buffer, B)
+                    join = torch.cuda.Event()
+                    join.record()
+                torch.cuda.current_stream().wait_event(join)
+                c.defer_snapshot(ec, ea)
+                c.end_train()
+            with torch.cuda.graph(tail, stream=s1):
+                c.deferred_critic_actor()
+            # two-stream form of the same schedule (RLREP_PIPELINE=2): the branches as two graphs on two HIP streams
+            feat, snap = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(feat, stream=s1):
+                ec, ea = self._feature_part(buffer, B)
+                c.end_train()
+            with torch.cuda.graph(snap, stream=s1):
+                c.defer_snapshot(ec, ea)
+            self._pipe = dict(key=key, first=first, steady=steady, tail=tail, feat=feat, snap=snap, sa=torch.cuda.Stream(), sb=torch.cuda.Stream(),      # (stream priorities were tried: 1.56-1.84 k train()/s against 2.32 k)
+                              ev_ca=torch.cuda.Event(), ev_snap=torch.cuda.Event(), mode=int(os.environ.get('RLREP_PIPELINE', '1')))
+        P = self._pipe
+        if P['mode'] == 2:
+            cur = torch.cuda.current_stream()
+            sa, sb = P['sa'], P['sb']
+            if not self._pending:
+                sb.wait_stream(cur)
+                sa.wait_stream(cur)
+            with torch.cuda.stream(sb):
+                P['feat'].replay()                       # feature steps of this train()
+                if self._pending:
+                    sb.wait_event(P['ev_ca'])            # the snapshot must not overtake the previous critic / actor pair
+                P['snap'].replay()
+                P['ev_snap'].record(sb)
+            with torch.cuda.stream(sa):
+                sa.wait_event(P['ev_snap'])
+                P['tail'].replay()                       # critic + actor of this train(), beside the NEXT call's feature steps
+                P['ev_ca'].record(sa)
+            self._pending = 2
+            return self.core.info(lazy_source=self._flushed_metrics)
+        (P['steady'] if self._pending else P['first']).replay()
+        self._pending = True
+        return self.core.info(lazy_source=self._flushed_metrics)
+
+    def _flushed_metrics(self):
+        self.flush()
+        return self.core.metrics_tensor().clone()
+
+    def flush(self):
+        """Run the pending critic + actor steps of the last pipelined train() (no-op otherwise)."""
+        if self._pending == 2:                         # two-stream form: the pair is already in flight on its own stream
+            self._pending = False
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._pipe['sa'])
+            cur.wait_stream(self._pipe['sb'])
+        elif self._pending:
+            self._pending = False
+            self._pipe['tail'].replay()
 
     def _train_graph(self, buffer, B):
         buffer.flush()

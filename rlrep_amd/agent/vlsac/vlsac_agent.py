@@ -45,6 +45,7 @@ class VLSACAgent(SACAgent):
     # ---- reference surface --------------------------------------------------------------------
     def feature_step(self, batch, eps=None):
         """vlsac_agent.py:126-162 (+ update_feature_target :240-242, fused into the optimizer launch)."""
+        self.flush()
         self._set_batch(batch)
         self.core.feature_step(self._noise('feat', (self._B, self.feature_dim)) if eps is None else eps)
         return self.core.info(self.FEATURE_KEYS)

@@ -35,7 +35,8 @@ class LazyInfo(dict):
 
     def _fetch(self):
         if not self._done:
-            vals = self._snap.cpu().numpy()
+            snap = self._snap() if callable(self._snap) else self._snap     # callable: fetched (and flushed) on first read
+            vals = snap.cpu().numpy()
             for i, n in enumerate(self._names):
                 if n:
                     dict.__setitem__(self, n, float(vals[i]))
@@ -146,6 +147,8 @@ class HipCore:
                 dst.copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(dst.shape))
 
     def state(self):
+        if getattr(self, 'before_read', None) is not None:
+            self.before_read()             # e.g. the agent's flush() of a pending deferred critic / actor pair
         out = {k: self.view(k).detach().cpu().clone() for k in self.order}
         out['log_alpha'] = self.alpha_state[0].detach().cpu().clone()
         return out
@@ -237,6 +240,19 @@ class HipCore:
     def update_target(self):
         check(lib.rlrep_update_target(self.h, _stream()), 'update_target')
 
+    # ---- deferred critic / actor steps (include/rlrep.h: the feature steps of train(t+1) may run beside them) --------
+    def defer_supported(self):
+        return lib.rlrep_defer_supported(self.h) == 1
+
+    def defer_snapshot(self, eps_critic, eps_actor):
+        check(lib.rlrep_defer_snapshot(self.h, _ptr(eps_critic), _ptr(eps_actor), _stream()), 'defer_snapshot')
+
+    def deferred_critic_actor(self):
+        check(lib.rlrep_deferred_critic_actor(self.h, _stream()), 'deferred_critic_actor')
+
+    def end_train(self):
+        check(lib.rlrep_end_train(self.h), 'end_train')
+
     def sync_frozen(self):
         check(lib.rlrep_sync_frozen(self.h, _stream()), 'sync_frozen')
 
@@ -269,8 +285,8 @@ class HipCore:
             self._mt = self.workspace[off:off + 4 * METRIC_SLOTS].view(torch.float32)
         return self._mt
 
-    def info(self, keys=None):
-        snap = self.metrics_tensor().clone()
+    def info(self, keys=None, lazy_source=None):
+        snap = lazy_source if lazy_source is not None else self.metrics_tensor().clone()
         names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]
         return LazyInfo(names, snap)
 

@@ -376,6 +376,19 @@ __global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 
+// segments laid end to end: element e of the concatenation belongs to the first segment whose end > e
+__global__ __launch_bounds__(256) void copy_segs_kernel(CopySegs p) {
+    const long long total = p.end[p.n - 1];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        int q = 0;
+#pragma unroll
+        for (int k = 0; k < COPY_MAX_SEGS - 1; ++k) if (k < p.n - 1 && e >= p.end[k]) q = k + 1;
+        const long long base = q ? p.end[q - 1] : 0;
+        p.dst[q][e - base] = p.src[q][e - base];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.isrc) *p.idst = *p.isrc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -439,6 +452,11 @@ extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {
 }
 extern "C" int rl_launch_counter_inc(int* c, hipStream_t st) {
     hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, c);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_copy_segs(const CopySegs* p, hipStream_t st) {
+    if (p->n <= 0) return 0;
+    hipLaunchKernelGGL(copy_segs_kernel, dim3(grid_for(p->end[p->n - 1], 1024, 1024)), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_copy(const float* src, float* dst, long long n, hipStream_t st) {

@@ -40,6 +40,7 @@ int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st);
 int rl_launch_polyak(const PolyakTask* t, hipStream_t st);
 int rl_launch_counter_inc(int* c, hipStream_t st);
 int rl_launch_copy(const float* src, float* dst, long long n, hipStream_t st);
+int rl_launch_copy_segs(const CopySegs* p, hipStream_t st);
 }
 
 void rl_set_error(const char* fmt, ...);

@@ -173,11 +173,11 @@ void update_target_program(rlrep_agent* ag, const std::string& first_src, const 
     ag->upd_target.stages.push_back({[=](hipStream_t st) { return rl_launch_polyak(&t, st); }, "polyak critic"});
 }
 // critic Adam with the target update folded in (same Polyak, same period gate, run by the Adam launch's own lanes)
-void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins) {
-    if (getenv("RLREP_NO_FOLD_TARGET")) return;
+void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins, Program* into, const int* steps) {
+    if (!into && getenv("RLREP_NO_FOLD_TARGET")) return;
     float* dst = ag->a.target_dev ? ag->a.target_dev + ag->L.get(first_dst).off : nullptr;
-    b.adam(ag->critic_apply_f, 1, ag->h.lr_critic, dst, ag->L.group_off[1], ag->L.group_n[1], ag->h.tau, fins, "adam critic + polyak critic",
-           ag->steps, ag->h.target_update_period);
+    b.adam(into ? *into : ag->critic_apply_f, 1, ag->h.lr_critic, dst, ag->L.group_off[1], ag->L.group_n[1], ag->h.tau, fins, "adam critic + polyak critic",
+           steps ? steps : ag->steps, ag->h.target_update_period);
 }
 
 // ================================================================================================
@@ -511,8 +511,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     critic_apply_folded(b, ag, "critic_target.l1.weight", cfins);
 
     // ---- actor + temperature step (vlsac_agent.py:165-198) ----
-    {
-        Program& p = ag->actor_bwd;
+    auto actor_program = [&](Program& p, int& resume) {
         GemmTask tt[3];
         gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gp, tt);
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "actor.l1(s)");
@@ -521,7 +520,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         b.fwd_stage(p, {tt[0]}, "ft.l1(s,a_pi)");
         b.fwd_stage(p, {tt[1]}, "ft.l2");
         b.fwd_stage(p, {tt[2]}, "ft.heads");
-        ag->actor_resume = (int)p.stages.size();      // everything above is what critic_bwd_h already did
+        resume = (int)p.stages.size();                // everything above is what critic_bwd_h already did
         nc_stage(p, {nc_task(gp.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
                      nc_task(gp.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4");
         b.fwd_stage(p, {Builder::fwd(HmC, H, B, H, Pw("critic.l2.weight"), H, Pw("critic.l2.bias"), H, Ec, H, ACT_ELU),
@@ -547,9 +546,42 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gp.H1, Hv)}, "ft.l2 dx");
         b.stash_fin(actor_fins(ag, part_l, nblk));
         actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
-        actor_apply_program(b, ag, part_l, nblk);
-    }
+    };
+    actor_program(ag->actor_bwd, ag->actor_resume);
+    actor_apply_program(b, ag, part_l, nblk);
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
+
+    // ---- deferred variants: the same critic / actor programs against the snapshot (see rlrep_agent::slot_d) ----
+    {
+        const LT& f0 = ag->L.get("f_target.l1.weight");
+        const LT& fl = ag->L.get("f_target.log_std_linear.bias");
+        const int64_t nft = fl.off + fl.rows - f0.off;
+        Slot d; d.XE = nullptr; d.XF = ws.f((size_t)B * SA); d.XF2 = ws.f((size_t)B * SA); d.XFpi = ws.f((size_t)B * SA); d.R = ws.f(B); d.D = ws.f(B);
+        ag->slot_d = d;
+        ag->ft_snap = ws.f((size_t)nft); ag->eps_snap = ws.f((size_t)2 * B * A); ag->steps_snap = (int*)ws.alloc(sizeof(int) * 4);
+        CopySegs& cs = ag->snap_segs; memset(&cs, 0, sizeof(cs));
+        long long end = 0; int n = 0;
+        auto seg = [&](const float* src, float* dst, long long cnt) { cs.src[n] = src; cs.dst[n] = dst; end += cnt; cs.end[n] = end; ++n; };
+        seg(s0.XF, d.XF, (long long)B * SA); seg(s0.XF2, d.XF2, (long long)B * SA); seg(s0.XFpi, d.XFpi, (long long)B * SA);
+        seg(s0.R, d.R, B); seg(s0.D, d.D, B);
+        seg(ag->a.target_dev ? ag->a.target_dev + f0.off : nullptr, ag->ft_snap, nft);
+        seg(nullptr, ag->eps_snap, (long long)B * A);                      // critic-step policy noise (patched per call)
+        seg(nullptr, ag->eps_snap ? ag->eps_snap + (size_t)B * A : nullptr, (long long)B * A);   // actor-step policy noise
+        cs.n = n; cs.isrc = ag->steps; cs.idst = ag->steps_snap;
+        // build against the snapshot: slot 0 and f_target.* are redirected while the two programs are constructed
+        const Slot keep = ag->slot[0];
+        ag->slot[0].XF = d.XF; ag->slot[0].XF2 = d.XF2; ag->slot[0].XFpi = d.XFpi; ag->slot[0].R = d.R; ag->slot[0].D = d.D;
+        ag->ft_override = ag->ft_snap ? ag->ft_snap : (const float*)nullptr;
+        const bool redirect = !b.dry;                                      // the dry pass only sizes the workspace
+        if (!redirect) ag->ft_override = nullptr;
+        critic_program(ag->critic_bwd_d, can_hoist ? 1 : 0);
+        actor_program(ag->actor_bwd_d, ag->actor_resume_d);
+        if (!can_hoist) ag->actor_resume_d = 0;
+        ag->ft_override = nullptr;
+        ag->slot[0] = keep;
+        critic_apply_folded(b, ag, "critic_target.l1.weight", cfins, &ag->critic_apply_d, ag->steps_snap);
+        ag->snap_valid = false;
+    }
 }
 
 // ================================================================================================
@@ -558,7 +590,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2, &ag->critic_bwd_d, &ag->critic_apply_d, &ag->actor_bwd_d})
         p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
     ag->pf_armed = ag->pf_done = false;
@@ -953,6 +985,40 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     int rc = rl_launch_counter_inc(ag->steps, (hipStream_t)stream);
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
     ag->in_train = true; ag->target_done = false;
+    return 0;
+}
+int32_t rlrep_defer_supported(rlrep_agent* ag) { return (ag && !ag->critic_bwd_d.stages.empty() && !ag->actor_bwd_d.stages.empty()) ? 1 : 0; }
+int32_t rlrep_defer_snapshot(rlrep_agent* ag, const float* eps_critic, const float* eps_actor, void* stream) {
+    if (!ag || !eps_critic || !eps_actor) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
+    if (!rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
+    if (!ag->slot[0].filled) { rl_set_error("defer_snapshot before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    CopySegs cs = ag->snap_segs;
+    cs.src[cs.n - 2] = eps_critic; cs.src[cs.n - 1] = eps_actor;
+    const int rc = rl_launch_copy_segs(&cs, (hipStream_t)stream);
+    if (rc) { rl_set_error("defer_snapshot: hip error %d", rc); return RLREP_ERR_HIP; }
+    ag->snap_valid = true;
+    return 0;
+}
+int32_t rlrep_deferred_critic_actor(rlrep_agent* ag, void* stream) {
+    if (!ag || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
+    if (!ag->snap_valid) { rl_set_error("deferred critic/actor steps before rlrep_defer_snapshot"); return RLREP_ERR_STATE; }
+    const float* e_crit = ag->eps_snap; const float* e_act = ag->eps_snap + (size_t)ag->B * ag->d.action_dim;
+    const float* keep1 = ag->cur_eps; const float* keep2 = ag->cur_eps2;
+    ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0;
+    int rc = run(ag, ag->critic_bwd_d, stream);
+    if (!rc) rc = run(ag, ag->critic_apply_d, stream);
+    if (!rc) {
+        ag->cur_eps = e_act;
+        ag->last_launches += (int)(ag->actor_bwd_d.stages.size() - ag->actor_resume_d);
+        rc = ag->actor_bwd_d.run((hipStream_t)stream, (size_t)ag->actor_resume_d);
+    }
+    if (!rc) rc = run(ag, ag->actor_apply, stream);
+    ag->cur_eps = keep1; ag->cur_eps2 = keep2;
+    return rc;
+}
+int32_t rlrep_end_train(rlrep_agent* ag) {
+    if (!ag) return RLREP_ERR_ARG;
+    ag->in_train = ag->target_done = false;
     return 0;
 }
 int32_t rlrep_feature_exchange_count(rlrep_agent* ag) { return ag ? (int32_t)ag->feat_cuts.size() : RLREP_ERR_ARG; }

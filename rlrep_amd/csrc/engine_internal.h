@@ -33,13 +33,24 @@ struct rlrep_agent {
     Program feat_bwd_h, critic_bwd_h2;
     const float* cur_eps3 = nullptr; const float* early_crit = nullptr; const float* early_act = nullptr;   // armed request
     const float* early_ready_crit = nullptr; const float* early_ready_act = nullptr;                        // done by feat_bwd_h
+    // DEFERRED critic / actor steps (vlsac): the feature steps of train(t+1) read nothing the critic and actor steps of train(t)
+    // write (and vice versa, once f_target, the minibatch, the policy noise and the step counter are snapshotted), so a caller may
+    // run [critic, actor of t] and [feature steps of t+1] as two concurrent branches.  rlrep_defer_snapshot takes the snapshot
+    // (one launch) after the last feature step; rlrep_deferred_critic_actor runs the two steps against it.  Same arithmetic,
+    // same order of updates per parameter; only the overlap changes.
+    Slot slot_d; float* ft_snap = nullptr; float* eps_snap = nullptr; int* steps_snap = nullptr;
+    const float* ft_override = nullptr;       // while the deferred programs are built: f_target.* resolves into ft_snap
+    Program critic_bwd_d, critic_apply_d, actor_bwd_d; int actor_resume_d = 0; CopySegs snap_segs; bool snap_valid = false;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
     size_t ws_static = 0;     // workspace bytes used by batch-independent state
 
     float* P(const std::string& n) const { return a.param_dev ? a.param_dev + L.get(n).off : nullptr; }
-    float* T(const std::string& n) const { return a.target_dev ? a.target_dev + L.get(n).off : nullptr; }
+    float* T(const std::string& n) const {
+        if (ft_override && n.compare(0, 9, "f_target.") == 0) return const_cast<float*>(ft_override) + (L.get(n).off - L.get("f_target.l1.weight").off);
+        return a.target_dev ? a.target_dev + L.get(n).off : nullptr;
+    }
     float* G(const std::string& n) const { return a.grad_dev ? a.grad_dev + L.get(n).off : nullptr; }
     float* Gtail() const { return a.grad_dev ? a.grad_dev + L.cur[RLREP_ARENA_PARAM] : nullptr; }
     float inv_batch() const { return 1.0f / ((float)B * (float)(h.world_size > 0 ? h.world_size : 1)); }
@@ -297,7 +308,7 @@ GemmTask policy_head_task(rlrep_agent* ag, const ActorBufs& ab, float* act, int 
 void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx, const float* act, int ld_act, GemmTask action_dx);
 void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk);
 std::vector<FinTask> actor_fins(rlrep_agent* ag, const float* partial_loss, int nblk);
-void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins);
+void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins, Program* into = nullptr, const int* steps = nullptr);
 void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst);
 
 // agents2.hip

@@ -28,6 +28,10 @@ struct TrainPrologue {
     int* counter; int* ticket;
 };
 
+// up to 10 float segments + one int copied by ONE launch (rlrep_defer_snapshot)
+#define COPY_MAX_SEGS 10
+struct CopySegs { int n; const float* src[COPY_MAX_SEGS]; float* dst[COPY_MAX_SEGS]; long long end[COPY_MAX_SEGS]; const int* isrc; int* idst; };
+
 struct PolicyFwd {
     const float* O; const float* eps; int B, A;
     float* act; int ld_act; float* logp;

@@ -335,3 +335,39 @@ def test_graph_prologue_and_batch_prefetch_are_equivalent(name):
             assert abs(float(x[k]) - float(y[k])) <= 1e-6 * max(abs(float(y[k])), 1e-2), (name, k, x[k], y[k])
     for k in sb:
         assert rel_l2(sa[k], sb[k]) < 1e-6, (name, k)
+
+
+def test_deferred_pipeline_is_equivalent():
+    """Pipelined graph mode (critic + actor of train(t) as a graph branch beside the feature steps of train(t+1), against a
+    snapshot of f_target / minibatch / noise / step counter) leaves every parameter, Adam moment and target exactly where the
+    sequential graph mode leaves it -- also with select_action() (which must see the finished actor) between train() calls."""
+    c = Case('vlsac_tiny')
+    outs = []
+    for pipe in (True, False):
+        kw = dict(c.kw)
+        if c.meta.get('patch_vae_hidden'):
+            kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+        cls = type(make_agent(c))
+        agent = cls(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, graph=True, pipeline=pipe,
+                    seed=4321, **kw)
+        agent.core.load_state(c.init)
+        buf = make_buffer(c)
+        acts = []
+        for t in range(7):
+            info = agent.train(buf, c.B)
+            if t in (2, 5):
+                acts.append(agent.select_action(np.full(c.S, 0.1 * t, np.float32)))
+        last = {k: float(v) for k, v in info.items()}
+        if pipe:
+            assert agent._pipe is not None, 'vlsac must take the pipelined path'
+        st = {k: v.numpy().copy() for k, v in agent.core.state().items()}
+        m = {k: agent.core.exp_avg.cpu().numpy().copy() for k in ('m',)}
+        outs.append((st, m, acts, last))
+    (sa, ma, aa, ia), (sb, mb, ab_, ib) = outs
+    for k in sb:
+        assert rel_l2(sa[k], sb[k]) < 1e-6, k
+    assert rel_l2(ma['m'], mb['m']) < 1e-6
+    for x, y in zip(aa, ab_):
+        assert np.allclose(x, y, atol=1e-6)
+    for k in ib:
+        assert abs(ia[k] - ib[k]) <= 1e-6 * max(abs(ib[k]), 1e-2), (k, ia[k], ib[k])
