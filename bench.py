@@ -255,7 +255,9 @@ def main():
                        'global_batch': B * world, 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
                        'parallelism': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)' if world > 1 else 'single GPU',
-                       'hipgraph': (bool(agent.use_graph) if world == 1 else ('segments between collectives' if agent.use_graph and agent.use_graph_dp else False))},
+                       'hipgraph': (bool(agent.use_graph) if world == 1 else ('segments between collectives' if agent.use_graph and agent.use_graph_dp else False)),
+                       # critic + actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (same updates, same order)
+                       'deferred_critic_actor_branch': bool(getattr(agent, '_pipe', None))},
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B, 1),
             'metrics_finite': bool(finite),

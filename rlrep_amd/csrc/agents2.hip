@@ -284,9 +284,8 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
     float* dq = ws.f((size_t)2 * B);
     const int nblk = qhead_blocks(B);
     float* part_q = ws.f((size_t)4 * nblk); float* part_l = ws.f(nblk);
-    {
+    auto critic_program = [&](Program& p) {
         // quirk Q8: frozen_phi_target == frozen_phi == phi at this point of train(); the programs read phi directly
-        Program& p = ag->critic_bwd;
         b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), phi_fwd(0, s0.XF, pa)}, "actor.l1(s') phi.l1(s,a)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), phi_fwd(1, nullptr, pa)}, "actor.l2 phi.l2");
         actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {phi_fwd(2, nullptr, pa)}, "actor.head phi.l3 + policy");
@@ -301,11 +300,8 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         b.dw_stage(p, {Builder::dw(dq, 1, 1, Ec, 2 * H, H, B, Gw("critic.l2.weight"), H, Gw("critic.l2.bias")),
                        Builder::dw(dq + B, 1, 1, Ec + H, 2 * H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias")),
                        Builder::dw(GE, 2 * H, 2 * H, pa.Z, F, F, B, Gw("critic.l1.weight"), F, Gw("critic.l1.bias"))}, "critic dW");
-        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, critic_fins(ag, part_q, nblk), "adam critic");
-        critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
-    }
-    {
-        Program& p = ag->actor_bwd;
+    };
+    auto actor_program = [&](Program& p) {
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
         actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
@@ -319,9 +315,23 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         b.dx_stage(p, {Builder::dx(pa.GZ, F, B, F, Pw("phi.l3.weight"), Hp, pa.G2, Hp, Hp, ACT_ELU, pa.P2, Hp)}, "phi.l3 dx");
         b.dx_stage(p, {Builder::dx(pa.G2, Hp, B, Hp, Pw("phi.l2.weight"), Hp, pa.G1, Hp, Hp, ACT_ELU, pa.P1, Hp)}, "phi.l2 dx");
         actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(pa.G1, Hp, B, Hp, Pw("phi.l1.weight") ? Pw("phi.l1.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0));
-        actor_apply_program(b, ag, part_l, nblk);
-    }
+    };
+    critic_program(ag->critic_bwd);
+    b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, critic_fins(ag, part_q, nblk), "adam critic");
+    critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+    actor_program(ag->actor_bwd);
+    actor_apply_program(b, ag, part_l, nblk);
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
+    // deferred variants: the critic / actor programs against frozen_phi (refreshed by the snapshot: sync_prog) and the minibatch copy
+    if (ag->h.world_size <= 1) {
+        const LT& q0 = ag->L.get("phi.l1.weight");
+        const LT& ql = ag->L.get("phi.l3.bias");
+        const Slot keep = defer_begin(b, ag, "phi.", "phi.l1.weight", Pw("phi.l1.weight"), Tw("frozen_phi.l1.weight"), ql.off + ql.rows - q0.off, true);
+        critic_program(ag->critic_bwd_d);
+        actor_program(ag->actor_bwd_d);
+        ag->actor_resume_d = 0;
+        defer_end(b, ag, keep, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+    }
 }
 
 // ================================================================================================
@@ -345,8 +355,7 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
     const size_t BH = (size_t)B * H;
     const int D = phi.depth;
     float* Zc = pa.act[D]; float* Zn = pb.act[D];
-    {
-        Program& p = ag->critic_bwd;
+    auto critic_program = [&](Program& p, Program& papply, bool emit_apply) {
         // actor(s') next to phi(s,a): layer l of both in one launch while both have a layer l
         for (int l = 0; l < 3 || l <= D; ++l) {
             std::vector<GemmTask> t;
@@ -372,20 +381,21 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
                            Builder::dw(rc.GE, H, H, rc.S1, 2 * H, H, B, Gw("critic.l2.weight"), H, Gw("critic.l2.bias")),
                            Builder::dw(rc.GE + BH, H, H, rc.S1 + H, 2 * H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias")),
                            Builder::dw(rc.G1, 2 * H, 2 * H, Zc, F, F, B, Gw("critic.l1.weight"), F, Gw("critic.l1.bias"))}, "critic dW");
-            b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, critic_fins(ag, part_q, nblk), "adam critic");
-            critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
-        } else {
+            if (emit_apply) {
+                b.adam(papply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, critic_fins(ag, part_q, nblk), "adam critic");
+                critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+            }
+        } else if (emit_apply) {
             // diffsrsac (quirk Q11): metrics only.  q_loss_reg == q_loss_noreg (lambda = 0, Q12); q2 := q1 (Q13)
             const float ib = 1.0f / (float)B;
             float* m = ag->metrics;
-            b.finalize_only(ag->critic_apply, {Builder::fin_sum(part_q + 0, nblk, 4, ib, m + M_TMP0), Builder::fin_sum(part_q + 1, nblk, 4, ib, m + M_TMP1),
+            b.finalize_only(papply, {Builder::fin_sum(part_q + 0, nblk, 4, ib, m + M_TMP0), Builder::fin_sum(part_q + 1, nblk, 4, ib, m + M_TMP1),
                                                Builder::fin_combine(m + M_TMP0, 1.f, m + M_TMP1, 1.f, m + M_Q1_LOSS),
                                                Builder::fin_copy(m + M_Q1_LOSS, m + M_Q2_LOSS),
                                                Builder::fin_sum(part_q + 2, nblk, 4, ib, m + M_Q1), Builder::fin_copy(m + M_Q1, m + M_Q2)}, "critic metrics");
         }
-    }
-    {
-        Program& p = ag->actor_bwd;
+    };
+    auto actor_program = [&](Program& p) {
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
         actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
@@ -403,10 +413,24 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
         b.dx_stage(p, {Builder::dx(rc.G1, 2 * H, B, 2 * H, Pw("critic.l1.weight"), F, pa.g[D], F, F, ACT_NONE, nullptr, 0)}, "critic l1|l4 dx");
         for (int l = D; l >= 1; --l) b.dx_stage(p, {mlp_dx(ag, phi, pa, l)}, "phi dx");
         actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, mlp_dx_input(ag, phi, pa, S, A, ab.dA, A));
-        actor_apply_program(b, ag, part_l, nblk);
-    }
+    };
+    critic_program(ag->critic_bwd, ag->critic_apply, true);
+    actor_program(ag->actor_bwd);
+    actor_apply_program(b, ag, part_l, nblk);
     (void)GZ;
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
+    // deferred variants (spedersac: critic and actor read the LIVE phi, so the snapshot carries a copy of it)
+    if (train_critic && ag->h.world_size <= 1) {
+        const LT& q0 = ag->L.get(phi.name(0) + ".weight");
+        const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
+        const std::string pre = phi.prefix + ".", first = phi.name(0) + ".weight";
+        const Slot keep = defer_begin(b, ag, pre.c_str(), first.c_str(), ag->P(first), nullptr, ql.off + ql.rows - q0.off, false);
+        Program unused;
+        critic_program(ag->critic_bwd_d, unused, false);
+        actor_program(ag->actor_bwd_d);
+        ag->actor_resume_d = 0;
+        defer_end(b, ag, keep, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+    }
 }
 
 // ================================================================================================

@@ -555,33 +555,42 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     {
         const LT& f0 = ag->L.get("f_target.l1.weight");
         const LT& fl = ag->L.get("f_target.log_std_linear.bias");
-        const int64_t nft = fl.off + fl.rows - f0.off;
-        Slot d; d.XE = nullptr; d.XF = ws.f((size_t)B * SA); d.XF2 = ws.f((size_t)B * SA); d.XFpi = ws.f((size_t)B * SA); d.R = ws.f(B); d.D = ws.f(B);
-        ag->slot_d = d;
-        ag->ft_snap = ws.f((size_t)nft); ag->eps_snap = ws.f((size_t)2 * B * A); ag->steps_snap = (int*)ws.alloc(sizeof(int) * 4);
-        CopySegs& cs = ag->snap_segs; memset(&cs, 0, sizeof(cs));
-        long long end = 0; int n = 0;
-        auto seg = [&](const float* src, float* dst, long long cnt) { cs.src[n] = src; cs.dst[n] = dst; end += cnt; cs.end[n] = end; ++n; };
-        seg(s0.XF, d.XF, (long long)B * SA); seg(s0.XF2, d.XF2, (long long)B * SA); seg(s0.XFpi, d.XFpi, (long long)B * SA);
-        seg(s0.R, d.R, B); seg(s0.D, d.D, B);
-        seg(ag->a.target_dev ? ag->a.target_dev + f0.off : nullptr, ag->ft_snap, nft);
-        seg(nullptr, ag->eps_snap, (long long)B * A);                      // critic-step policy noise (patched per call)
-        seg(nullptr, ag->eps_snap ? ag->eps_snap + (size_t)B * A : nullptr, (long long)B * A);   // actor-step policy noise
-        cs.n = n; cs.isrc = ag->steps; cs.idst = ag->steps_snap;
-        // build against the snapshot: slot 0 and f_target.* are redirected while the two programs are constructed
-        const Slot keep = ag->slot[0];
-        ag->slot[0].XF = d.XF; ag->slot[0].XF2 = d.XF2; ag->slot[0].XFpi = d.XFpi; ag->slot[0].R = d.R; ag->slot[0].D = d.D;
-        ag->ft_override = ag->ft_snap ? ag->ft_snap : (const float*)nullptr;
-        const bool redirect = !b.dry;                                      // the dry pass only sizes the workspace
-        if (!redirect) ag->ft_override = nullptr;
+        const Slot keep = defer_begin(b, ag, "f_target.", "f_target.l1.weight", ag->a.target_dev ? ag->a.target_dev + f0.off : nullptr, nullptr,
+                                      fl.off + fl.rows - f0.off, false);
         critic_program(ag->critic_bwd_d, can_hoist ? 1 : 0);
         actor_program(ag->actor_bwd_d, ag->actor_resume_d);
         if (!can_hoist) ag->actor_resume_d = 0;
-        ag->ft_override = nullptr;
-        ag->slot[0] = keep;
-        critic_apply_folded(b, ag, "critic_target.l1.weight", cfins, &ag->critic_apply_d, ag->steps_snap);
-        ag->snap_valid = false;
+        defer_end(b, ag, keep, "critic_target.l1.weight", cfins);
     }
+}
+
+Slot defer_begin(Builder& b, rlrep_agent* ag, const char* prefix, const char* first, const float* block_src, float* block_dst, int64_t block_n, bool external_block) {
+    Workspace& ws = b.ws;
+    const int B = ag->B, S = ag->d.state_dim, A = ag->d.action_dim, SA = S + A;
+    Slot& s0 = ag->slot[0];
+    Slot d; d.XE = nullptr; d.XF = ws.f((size_t)B * SA); d.XF2 = ws.f((size_t)B * SA); d.XFpi = ws.f((size_t)B * SA); d.R = ws.f(B); d.D = ws.f(B);
+    ag->slot_d = d;
+    float* snap = external_block ? block_dst : (block_n > 0 ? ws.f((size_t)block_n) : nullptr);
+    ag->ft_snap = snap; ag->eps_snap = ws.f((size_t)2 * B * A); ag->steps_snap = (int*)ws.alloc(sizeof(int) * 4);
+    CopySegs& cs = ag->snap_segs; memset(&cs, 0, sizeof(cs));
+    long long end = 0; int n = 0;
+    auto seg = [&](const float* src, float* dst, long long cnt) { cs.src[n] = src; cs.dst[n] = dst; end += cnt; cs.end[n] = end; ++n; };
+    seg(s0.XF, d.XF, (long long)B * SA); seg(s0.XF2, d.XF2, (long long)B * SA); seg(s0.XFpi, d.XFpi, (long long)B * SA);
+    seg(s0.R, d.R, B); seg(s0.D, d.D, B);
+    if (!external_block && block_n > 0) seg(block_src, snap, block_n);
+    seg(nullptr, ag->eps_snap, (long long)B * A);                      // critic-step policy noise (patched per call)
+    seg(nullptr, ag->eps_snap ? ag->eps_snap + (size_t)B * A : nullptr, (long long)B * A);   // actor-step policy noise
+    cs.n = n; cs.isrc = ag->steps; cs.idst = ag->steps_snap;
+    const Slot keep = s0;
+    s0.XF = d.XF; s0.XF2 = d.XF2; s0.XFpi = d.XFpi; s0.R = d.R; s0.D = d.D;
+    ag->ov_base = b.dry ? nullptr : snap; ag->ov_prefix = prefix; ag->ov_first = first;      // the dry pass only sizes the workspace
+    return keep;
+}
+void defer_end(Builder& b, rlrep_agent* ag, const Slot& keep, const std::string& critic_target_first, std::vector<FinTask> cfins) {
+    ag->ov_base = nullptr;
+    ag->slot[0] = keep;
+    critic_apply_folded(b, ag, critic_target_first, cfins, &ag->critic_apply_d, ag->steps_snap);
+    ag->snap_valid = false;
 }
 
 // ================================================================================================
@@ -992,6 +1001,10 @@ int32_t rlrep_defer_snapshot(rlrep_agent* ag, const float* eps_critic, const flo
     if (!ag || !eps_critic || !eps_actor) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
     if (!rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
     if (!ag->slot[0].filled) { rl_set_error("defer_snapshot before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    if (!ag->sync_prog.stages.empty()) {          // ctrlsac: frozen_phi, frozen_phi_target <- phi is the parameter snapshot
+        const int rs = ag->sync_prog.run((hipStream_t)stream);
+        if (rs) return rs;
+    }
     CopySegs cs = ag->snap_segs;
     cs.src[cs.n - 2] = eps_critic; cs.src[cs.n - 1] = eps_actor;
     const int rc = rl_launch_copy_segs(&cs, (hipStream_t)stream);

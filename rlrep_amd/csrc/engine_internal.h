@@ -39,18 +39,21 @@ struct rlrep_agent {
     // (one launch) after the last feature step; rlrep_deferred_critic_actor runs the two steps against it.  Same arithmetic,
     // same order of updates per parameter; only the overlap changes.
     Slot slot_d; float* ft_snap = nullptr; float* eps_snap = nullptr; int* steps_snap = nullptr;
-    const float* ft_override = nullptr;       // while the deferred programs are built: f_target.* resolves into ft_snap
+    // while the deferred programs are built, tensors named ov_prefix* resolve into the snapshot block ov_base (same internal layout
+    // as the block that starts at ov_first): vlsac f_target.* -> its copy, ctrlsac phi.* -> frozen_phi.*, spedersac phi.trunk.* -> copy
+    const float* ov_base = nullptr; std::string ov_prefix, ov_first;
     Program critic_bwd_d, critic_apply_d, actor_bwd_d; int actor_resume_d = 0; CopySegs snap_segs; bool snap_valid = false;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
     size_t ws_static = 0;     // workspace bytes used by batch-independent state
 
-    float* P(const std::string& n) const { return a.param_dev ? a.param_dev + L.get(n).off : nullptr; }
-    float* T(const std::string& n) const {
-        if (ft_override && n.compare(0, 9, "f_target.") == 0) return const_cast<float*>(ft_override) + (L.get(n).off - L.get("f_target.l1.weight").off);
-        return a.target_dev ? a.target_dev + L.get(n).off : nullptr;
+    float* overridden(const std::string& n) const {
+        if (!ov_base || n.compare(0, ov_prefix.size(), ov_prefix) != 0) return nullptr;
+        return const_cast<float*>(ov_base) + (L.get(n).off - L.get(ov_first).off);
     }
+    float* P(const std::string& n) const { if (float* o = overridden(n)) return o; return a.param_dev ? a.param_dev + L.get(n).off : nullptr; }
+    float* T(const std::string& n) const { if (float* o = overridden(n)) return o; return a.target_dev ? a.target_dev + L.get(n).off : nullptr; }
     float* G(const std::string& n) const { return a.grad_dev ? a.grad_dev + L.get(n).off : nullptr; }
     float* Gtail() const { return a.grad_dev ? a.grad_dev + L.cur[RLREP_ARENA_PARAM] : nullptr; }
     float inv_batch() const { return 1.0f / ((float)B * (float)(h.world_size > 0 ? h.world_size : 1)); }
@@ -310,6 +313,12 @@ void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss,
 std::vector<FinTask> actor_fins(rlrep_agent* ag, const float* partial_loss, int nblk);
 void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins, Program* into = nullptr, const int* steps = nullptr);
 void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst);
+// Deferred critic / actor programs (rlrep_agent::slot_d): defer_begin allocates the snapshot (minibatch, policy noise, step counter and,
+// unless `external_block`, a copy of the `block_n` floats at `block_src`; an external block is refreshed by the agent's own sync program), redirects slot 0 and the tensors named `prefix`* (block
+// starting at tensor `first`) and returns the saved slot; the caller then emits its critic / actor programs a second time into
+// critic_bwd_d / actor_bwd_d and calls defer_end.
+Slot defer_begin(Builder& b, rlrep_agent* ag, const char* prefix, const char* first, const float* block_src, float* block_dst, int64_t block_n, bool external_block);
+void defer_end(Builder& b, rlrep_agent* ag, const Slot& keep, const std::string& critic_target_first, std::vector<FinTask> cfins);
 
 // agents2.hip
 void lay_ctrlsac(const rlrep_dims& d, Layout& L);

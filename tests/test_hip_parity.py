@@ -337,11 +337,12 @@ def test_graph_prologue_and_batch_prefetch_are_equivalent(name):
         assert rel_l2(sa[k], sb[k]) < 1e-6, (name, k)
 
 
-def test_deferred_pipeline_is_equivalent():
+@pytest.mark.parametrize('name', ['vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny'])
+def test_deferred_pipeline_is_equivalent(name):
     """Pipelined graph mode (critic + actor of train(t) as a graph branch beside the feature steps of train(t+1), against a
     snapshot of f_target / minibatch / noise / step counter) leaves every parameter, Adam moment and target exactly where the
     sequential graph mode leaves it -- also with select_action() (which must see the finished actor) between train() calls."""
-    c = Case('vlsac_tiny')
+    c = Case(name)
     outs = []
     for pipe in (True, False):
         kw = dict(c.kw)
@@ -359,7 +360,7 @@ def test_deferred_pipeline_is_equivalent():
                 acts.append(agent.select_action(np.full(c.S, 0.1 * t, np.float32)))
         last = {k: float(v) for k, v in info.items()}
         if pipe:
-            assert agent._pipe is not None, 'vlsac must take the pipelined path'
+            assert agent._pipe is not None, f'{name} must take the pipelined path'
         st = {k: v.numpy().copy() for k, v in agent.core.state().items()}
         m = {k: agent.core.exp_avg.cpu().numpy().copy() for k in ('m',)}
         outs.append((st, m, acts, last))
