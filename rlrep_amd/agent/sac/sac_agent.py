@@ -36,6 +36,56 @@ class ArenaModule(nn.Module):
             mod.register_parameter(parts[-1], nn.Parameter(core.view(name), requires_grad=False))
 
 
+_STREAM_PAIR = {}
+
+
+def _concurrent_stream_pair(core):
+    """Two torch streams that really run side by side.  ROCm maps HIP streams onto a handful of hardware queues (4 by default) and
+    two streams that share one are serialised -- measured here: the same two launch chains overlapped 1.8x or 1.00x depending only on
+    which streams they were given.  So candidates are TIMED: two short kernel chains back to back on one stream against one chain on
+    each stream of a pair; the first pair that overlaps is kept for the life of the process."""
+    dev = core.device
+    if dev in _STREAM_PAIR:
+        return _STREAM_PAIR[dev]
+    import time
+    cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    bufs = [torch.empty(1 << 21, device=dev) for _ in range(2)]
+
+    def chain(k):
+        for _ in range(6):
+            core.fill_normal(bufs[k], 1.0, 1, 2)
+
+    def timed(fn):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    def serial():
+        with torch.cuda.stream(cands[0]):
+            chain(0); chain(1)
+
+    serial()
+    t_seq = timed(serial)
+    pair = (cands[0], cands[1])
+    for i in range(len(cands)):
+        for j in range(i + 1, len(cands)):
+            def both(a=cands[i], b=cands[j]):
+                with torch.cuda.stream(a):
+                    chain(0)
+                with torch.cuda.stream(b):
+                    chain(1)
+            if timed(both) < 0.72 * t_seq:
+                _STREAM_PAIR[dev] = (cands[i], cands[j])
+                return _STREAM_PAIR[dev]
+    _STREAM_PAIR[dev] = pair            # nothing overlapped (single hardware queue?): still correct, just not concurrent
+    return pair
+
+
 def _world():
     try:
         import torch.distributed as dist
@@ -514,17 +564,20 @@ class SACAgent(object):
                 c.end_train()
             with torch.cuda.graph(tail, stream=s1):
                 c.deferred_critic_actor()
-            # two-stream form of the same schedule (RLREP_PIPELINE=2): the branches as two graphs on two HIP streams
+            # two-stream form of the same schedule (default; RLREP_PIPELINE=1 selects the in-graph branches above): the branches as
+            # graphs on two HIP streams that were timed to be concurrent -- in-graph branches pay ~2.6 us per launch pair
+            # (tools/exp/twochains.hip) and landed at 2.4 k train()/s
             feat, snap = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(feat, stream=s1):
                 ec, ea = self._feature_part(buffer, B)
                 c.end_train()
             with torch.cuda.graph(snap, stream=s1):
                 c.defer_snapshot(ec, ea)
-            self._pipe = dict(key=key, first=first, steady=steady, tail=tail, feat=feat, snap=snap, sa=torch.cuda.Stream(), sb=torch.cuda.Stream(),      # (stream priorities were tried: 1.56-1.84 k train()/s against 2.32 k)
-                              ev_ca=torch.cuda.Event(), ev_snap=torch.cuda.Event(), mode=int(os.environ.get('RLREP_PIPELINE', '1')))
+            sa, sb = _concurrent_stream_pair(c)       # (stream priorities were also tried: 1.56-1.84 k train()/s against 2.32 k)
+            self._pipe = dict(key=key, first=first, steady=steady, tail=tail, feat=feat, snap=snap, sa=sa, sb=sb,
+                              ev_ca=torch.cuda.Event(), ev_snap=torch.cuda.Event(), mode=int(os.environ.get('RLREP_PIPELINE', '2')))
         P = self._pipe
-        if P['mode'] == 2:
+        if P['mode'] != 1:
             cur = torch.cuda.current_stream()
             sa, sb = P['sa'], P['sb']
             if not self._pending:
