@@ -104,6 +104,7 @@ __device__ __forceinline__ void philox_fill_body(const PhiloxFill& p, int block,
 __global__ __launch_bounds__(256) void philox_fill_kernel(PhiloxFill p) { philox_fill_body(p, blockIdx.x, gridDim.x); }
 
 __global__ __launch_bounds__(256) void train_prologue_kernel(TrainPrologue p) {
+    __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const int bid = blockIdx.x;
     if (bid < p.nb_idx) philox_fill_body(p.idx, bid, p.nb_idx);
     else if (bid < p.nb_idx + p.nb_eps) philox_fill_body(p.eps, bid - p.nb_idx, p.nb_eps);
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void policy_bwd_kernel(PolicyBwd p) {
 // vlsac ELBO pieces (agent/vlsac/vlsac_agent.py:135-150)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vae_mid_kernel(VaeMid p) {
+    __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     __shared__ float sh[4];
     const int F = p.F;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
                                                    const PolyakTask* __restrict__ pol, int npol,
                                                    const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks) {
+    __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const int bid = blockIdx.x;
     if (bid > adam_blocks) {
         // rlrep_prefetch_batch: the gather of the NEXT minibatch rides here (the step that owned the slot has finished
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src
 
 // segments laid end to end: element e of the concatenation belongs to the first segment whose end > e
 __global__ __launch_bounds__(256) void copy_segs_kernel(CopySegs p) {
+    __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const long long total = p.end[p.n - 1];
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         int q = 0;
