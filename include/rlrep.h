@@ -260,11 +260,12 @@ int32_t rlrep_feature_backward_part(rlrep_agent* agent, int32_t part, const floa
  * update_actor_and_alpha and the (period-gated) critic-target Polyak of train(t) against the snapshot, so a caller may issue it
  * on a second stream / graph branch next to train(t+1)'s feature steps.  Same arithmetic and the same sequence of updates
  * per parameter as the sequential entry points (tests/test_hip_parity.py::test_deferred_pipeline_is_equivalent); the caller
- * must order: snapshot(t) after feature steps(t) AND after deferred(t-1); anything that reads the critic / actor (select_action,
- * checkpoints, metrics of those steps) after deferred(t).  rlrep_defer_supported: 1 if built for this agent. */
-int32_t rlrep_defer_supported(rlrep_agent* agent);
-int32_t rlrep_defer_snapshot(rlrep_agent* agent, const float* eps_critic_dev, const float* eps_actor_dev, void* stream);
-int32_t rlrep_deferred_critic_actor(rlrep_agent* agent, void* stream);
+ * must order: snapshot(t) into set s after feature steps(t) AND after the deferred pair that last used set s; deferred(t) after
+ * snapshot(t) and after deferred(t-1); anything that reads the critic / actor (select_action, checkpoints, metrics of those steps)
+ * after deferred(t).  There are two sets, so with set = t & 1 a snapshot only waits for the pair of train(t-2). */
+int32_t rlrep_defer_supported(rlrep_agent* agent);          /* number of snapshot sets (2) or 0 */
+int32_t rlrep_defer_snapshot(rlrep_agent* agent, int32_t set, const float* eps_critic_dev, const float* eps_actor_dev, void* stream);
+int32_t rlrep_deferred_critic_actor(rlrep_agent* agent, int32_t set, void* stream);
 /* Host-only: closes a rlrep_begin_train / rlrep_train_prologue bracket without launching anything (the critic-target update of a
  * deferred train() runs inside rlrep_deferred_critic_actor). */
 int32_t rlrep_end_train(rlrep_agent* agent);

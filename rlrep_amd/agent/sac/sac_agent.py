@@ -544,59 +544,76 @@ class SACAgent(object):
             self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
             self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
             torch.cuda.synchronize()
+            mode = int(os.environ.get('RLREP_PIPELINE', '2'))
             s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-            first, steady, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(first, stream=s1):
-                ec, ea = self._feature_part(buffer, B)
-                c.defer_snapshot(ec, ea)
-                c.end_train()
-            with torch.cuda.graph(steady, stream=s1):
-                fork = torch.cuda.Event()
-                fork.record()
-                s2.wait_event(fork)
-                c.deferred_critic_actor()                       # branch 1 (s1): critic + actor of the previous train()
-                with torch.cuda.stream(s2):                      # branch 2 (s2): this train()'s feature steps
+            P = dict(key=key, mode=mode, t=0)
+            if mode == 1:
+                # one graph per train(): the two branches inside it (snapshot set 0 only).  In-graph branches cost ~2.6 us per launch
+                # pair on this runtime (tools/exp/twochains.hip); kept as the single-stream form.
+                first, steady, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(first, stream=s1):
                     ec, ea = self._feature_part(buffer, B)
-                    join = torch.cuda.Event()
-                    join.record()
-                torch.cuda.current_stream().wait_event(join)
-                c.defer_snapshot(ec, ea)
-                c.end_train()
-            with torch.cuda.graph(tail, stream=s1):
-                c.deferred_critic_actor()
-            # two-stream form of the same schedule (default; RLREP_PIPELINE=1 selects the in-graph branches above): the branches as
-            # graphs on two HIP streams that were timed to be concurrent -- in-graph branches pay ~2.6 us per launch pair
-            # (tools/exp/twochains.hip) and landed at 2.4 k train()/s
-            feat, snap = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(feat, stream=s1):
-                ec, ea = self._feature_part(buffer, B)
-                c.end_train()
-            with torch.cuda.graph(snap, stream=s1):
-                c.defer_snapshot(ec, ea)
-            sa, sb = _concurrent_stream_pair(c)       # (stream priorities were also tried: 1.56-1.84 k train()/s against 2.32 k)
-            self._pipe = dict(key=key, first=first, steady=steady, tail=tail, feat=feat, snap=snap, sa=sa, sb=sb,
-                              ev_ca=torch.cuda.Event(), ev_snap=torch.cuda.Event(), mode=int(os.environ.get('RLREP_PIPELINE', '2')))
+                    c.defer_snapshot(ec, ea, 0)
+                    c.end_train()
+                with torch.cuda.graph(steady, stream=s1):
+                    fork = torch.cuda.Event()
+                    fork.record()
+                    s2.wait_event(fork)
+                    c.deferred_critic_actor(0)                      # branch 1 (s1): critic + actor of the previous train()
+                    with torch.cuda.stream(s2):                      # branch 2 (s2): this train()'s feature steps
+                        ec, ea = self._feature_part(buffer, B)
+                        join = torch.cuda.Event()
+                        join.record()
+                    torch.cuda.current_stream().wait_event(join)
+                    c.defer_snapshot(ec, ea, 0)
+                    c.end_train()
+                with torch.cuda.graph(tail, stream=s1):
+                    c.deferred_critic_actor(0)
+                P.update(first=first, steady=steady, tail=tail)
+            else:
+                # two streams that were TIMED to be concurrent; train(t) uses snapshot set t & 1:
+                #   stream F : [feature steps(t) + snapshot(t -> set)]            after the critic/actor pair of t-2 (same set)
+                #   stream CA: [critic + actor(t) from set]                       after snapshot(t)
+                fs, ca = [], []
+                for k in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s1):
+                        ec, ea = self._feature_part(buffer, B)
+                        c.defer_snapshot(ec, ea, k)
+                        c.end_train()
+                    fs.append(g)
+                for k in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s1):
+                        c.deferred_critic_actor(k)
+                    ca.append(g)
+                s_ca, s_f = _concurrent_stream_pair(c)
+                P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
+                         ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
+            self._pipe = P
         P = self._pipe
-        if P['mode'] != 1:
-            cur = torch.cuda.current_stream()
-            sa, sb = P['sa'], P['sb']
-            if not self._pending:
-                sb.wait_stream(cur)
-                sa.wait_stream(cur)
-            with torch.cuda.stream(sb):
-                P['feat'].replay()                       # feature steps of this train()
-                if self._pending:
-                    sb.wait_event(P['ev_ca'])            # the snapshot must not overtake the previous critic / actor pair
-                P['snap'].replay()
-                P['ev_snap'].record(sb)
-            with torch.cuda.stream(sa):
-                sa.wait_event(P['ev_snap'])
-                P['tail'].replay()                       # critic + actor of this train(), beside the NEXT call's feature steps
-                P['ev_ca'].record(sa)
-            self._pending = 2
+        if P['mode'] == 1:
+            (P['steady'] if self._pending else P['first']).replay()
+            self._pending = True
             return self.core.info(lazy_source=self._flushed_metrics)
-        (P['steady'] if self._pending else P['first']).replay()
-        self._pending = True
+        k = P['t'] & 1
+        P['t'] += 1
+        s_ca, s_f = P['s_ca'], P['s_f']
+        if not self._pending:
+            cur = torch.cuda.current_stream()
+            s_f.wait_stream(cur)
+            s_ca.wait_stream(cur)
+        with torch.cuda.stream(s_f):
+            if P['used'][k]:
+                s_f.wait_event(P['ev_ca'][k])                  # the pair that read this set last (train t-2)
+            P['fs'][k].replay()
+            P['ev_snap'][k].record(s_f)
+        with torch.cuda.stream(s_ca):
+            s_ca.wait_event(P['ev_snap'][k])
+            P['ca'][k].replay()
+            P['ev_ca'][k].record(s_ca)
+        P['used'][k] = True
+        self._pending = 2
         return self.core.info(lazy_source=self._flushed_metrics)
 
     def _flushed_metrics(self):
@@ -604,12 +621,12 @@ class SACAgent(object):
         return self.core.metrics_tensor().clone()
 
     def flush(self):
-        """Run the pending critic + actor steps of the last pipelined train() (no-op otherwise)."""
+        """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""
         if self._pending == 2:                         # two-stream form: the pair is already in flight on its own stream
             self._pending = False
             cur = torch.cuda.current_stream()
-            cur.wait_stream(self._pipe['sa'])
-            cur.wait_stream(self._pipe['sb'])
+            cur.wait_stream(self._pipe['s_ca'])
+            cur.wait_stream(self._pipe['s_f'])
         elif self._pending:
             self._pending = False
             self._pipe['tail'].replay()

@@ -242,13 +242,13 @@ class HipCore:
 
     # ---- deferred critic / actor steps (include/rlrep.h: the feature steps of train(t+1) may run beside them) --------
     def defer_supported(self):
-        return lib.rlrep_defer_supported(self.h) == 1
+        return lib.rlrep_defer_supported(self.h) == 2
 
-    def defer_snapshot(self, eps_critic, eps_actor):
-        check(lib.rlrep_defer_snapshot(self.h, _ptr(eps_critic), _ptr(eps_actor), _stream()), 'defer_snapshot')
+    def defer_snapshot(self, eps_critic, eps_actor, set=0):
+        check(lib.rlrep_defer_snapshot(self.h, int(set), _ptr(eps_critic), _ptr(eps_actor), _stream()), 'defer_snapshot')
 
-    def deferred_critic_actor(self):
-        check(lib.rlrep_deferred_critic_actor(self.h, _stream()), 'deferred_critic_actor')
+    def deferred_critic_actor(self, set=0):
+        check(lib.rlrep_deferred_critic_actor(self.h, int(set), _stream()), 'deferred_critic_actor')
 
     def end_train(self):
         check(lib.rlrep_end_train(self.h), 'end_train')

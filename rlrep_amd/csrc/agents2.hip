@@ -322,15 +322,18 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
     actor_program(ag->actor_bwd);
     actor_apply_program(b, ag, part_l, nblk);
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
-    // deferred variants: the critic / actor programs against frozen_phi (refreshed by the snapshot: sync_prog) and the minibatch copy
+    // deferred variants: the critic / actor programs against a snapshot set (phi copy + minibatch copy); the snapshot launch also runs
+    // sync_prog (frozen_phi* <- phi), which belongs to the end of the feature steps
     if (ag->h.world_size <= 1) {
         const LT& q0 = ag->L.get("phi.l1.weight");
         const LT& ql = ag->L.get("phi.l3.bias");
-        const Slot keep = defer_begin(b, ag, "phi.", "phi.l1.weight", Pw("phi.l1.weight"), Tw("frozen_phi.l1.weight"), ql.off + ql.rows - q0.off, true);
-        critic_program(ag->critic_bwd_d);
-        actor_program(ag->actor_bwd_d);
-        ag->actor_resume_d = 0;
-        defer_end(b, ag, keep, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+        for (int set = 0; set < 2; ++set) {
+            const Slot keep = defer_begin(b, ag, set, "phi.", "phi.l1.weight", Pw("phi.l1.weight"), ql.off + ql.rows - q0.off);
+            critic_program(ag->dset[set].critic_bwd);
+            actor_program(ag->dset[set].actor_bwd);
+            ag->dset[set].actor_resume = 0;
+            defer_end(b, ag, set, keep, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+        }
     }
 }
 
@@ -424,12 +427,14 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
         const LT& q0 = ag->L.get(phi.name(0) + ".weight");
         const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
         const std::string pre = phi.prefix + ".", first = phi.name(0) + ".weight";
-        const Slot keep = defer_begin(b, ag, pre.c_str(), first.c_str(), ag->P(first), nullptr, ql.off + ql.rows - q0.off, false);
-        Program unused;
-        critic_program(ag->critic_bwd_d, unused, false);
-        actor_program(ag->actor_bwd_d);
-        ag->actor_resume_d = 0;
-        defer_end(b, ag, keep, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+        for (int set = 0; set < 2; ++set) {
+            const Slot keep = defer_begin(b, ag, set, pre.c_str(), first.c_str(), ag->P(first), ql.off + ql.rows - q0.off);
+            Program unused;
+            critic_program(ag->dset[set].critic_bwd, unused, false);
+            actor_program(ag->dset[set].actor_bwd);
+            ag->dset[set].actor_resume = 0;
+            defer_end(b, ag, set, keep, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
+        }
     }
 }
 

@@ -83,7 +83,7 @@ struct GemmTask {
 struct FinTask;
 // passed by value (kernarg segment).  nfin > 0: the launch has one extra trailing workgroup that runs the step's metric
 // finalisation / temperature update (the optimizer itself then runs in the EPI_DW epilogues: GemmTask::ad_*)
-struct GemmBatch { int ntasks; int nfin; const FinTask* fin; GemmTask t[GEMM_MAX_TASKS]; };
+struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)

@@ -551,46 +551,50 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     actor_apply_program(b, ag, part_l, nblk);
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
 
-    // ---- deferred variants: the same critic / actor programs against the snapshot (see rlrep_agent::slot_d) ----
-    {
+    // ---- deferred variants: the same critic / actor programs against a snapshot set (see rlrep_agent::dset) ----
+    for (int set = 0; set < 2; ++set) {
         const LT& f0 = ag->L.get("f_target.l1.weight");
         const LT& fl = ag->L.get("f_target.log_std_linear.bias");
-        const Slot keep = defer_begin(b, ag, "f_target.", "f_target.l1.weight", ag->a.target_dev ? ag->a.target_dev + f0.off : nullptr, nullptr,
-                                      fl.off + fl.rows - f0.off, false);
-        critic_program(ag->critic_bwd_d, can_hoist ? 1 : 0);
-        actor_program(ag->actor_bwd_d, ag->actor_resume_d);
-        if (!can_hoist) ag->actor_resume_d = 0;
-        defer_end(b, ag, keep, "critic_target.l1.weight", cfins);
+        const Slot keep = defer_begin(b, ag, set, "f_target.", "f_target.l1.weight", ag->a.target_dev ? ag->a.target_dev + f0.off : nullptr,
+                                      fl.off + fl.rows - f0.off);
+        critic_program(ag->dset[set].critic_bwd, can_hoist ? 1 : 0);
+        actor_program(ag->dset[set].actor_bwd, ag->dset[set].actor_resume);
+        if (!can_hoist) ag->dset[set].actor_resume = 0;
+        defer_end(b, ag, set, keep, "critic_target.l1.weight", cfins);
     }
 }
 
-Slot defer_begin(Builder& b, rlrep_agent* ag, const char* prefix, const char* first, const float* block_src, float* block_dst, int64_t block_n, bool external_block) {
+Slot defer_begin(Builder& b, rlrep_agent* ag, int set, const char* prefix, const char* first, const float* block_src, int64_t block_n) {
     Workspace& ws = b.ws;
     const int B = ag->B, S = ag->d.state_dim, A = ag->d.action_dim, SA = S + A;
     Slot& s0 = ag->slot[0];
+    rlrep_agent::DeferSet& D = ag->dset[set];
     Slot d; d.XE = nullptr; d.XF = ws.f((size_t)B * SA); d.XF2 = ws.f((size_t)B * SA); d.XFpi = ws.f((size_t)B * SA); d.R = ws.f(B); d.D = ws.f(B);
-    ag->slot_d = d;
-    float* snap = external_block ? block_dst : (block_n > 0 ? ws.f((size_t)block_n) : nullptr);
-    ag->ft_snap = snap; ag->eps_snap = ws.f((size_t)2 * B * A); ag->steps_snap = (int*)ws.alloc(sizeof(int) * 4);
-    CopySegs& cs = ag->snap_segs; memset(&cs, 0, sizeof(cs));
+    D.slot = d;
+    D.block = block_n > 0 ? ws.f((size_t)block_n) : nullptr;
+    D.eps = ws.f((size_t)2 * B * A); D.steps = (int*)ws.alloc(sizeof(int) * 4);
+    CopySegs& cs = D.segs; memset(&cs, 0, sizeof(cs));
     long long end = 0; int n = 0;
     auto seg = [&](const float* src, float* dst, long long cnt) { cs.src[n] = src; cs.dst[n] = dst; end += cnt; cs.end[n] = end; ++n; };
     seg(s0.XF, d.XF, (long long)B * SA); seg(s0.XF2, d.XF2, (long long)B * SA); seg(s0.XFpi, d.XFpi, (long long)B * SA);
     seg(s0.R, d.R, B); seg(s0.D, d.D, B);
-    if (!external_block && block_n > 0) seg(block_src, snap, block_n);
-    seg(nullptr, ag->eps_snap, (long long)B * A);                      // critic-step policy noise (patched per call)
-    seg(nullptr, ag->eps_snap ? ag->eps_snap + (size_t)B * A : nullptr, (long long)B * A);   // actor-step policy noise
-    cs.n = n; cs.isrc = ag->steps; cs.idst = ag->steps_snap;
+    if (block_n > 0) seg(block_src, D.block, block_n);
+    seg(nullptr, D.eps, (long long)B * A);                             // critic-step policy noise (patched per call)
+    seg(nullptr, D.eps ? D.eps + (size_t)B * A : nullptr, (long long)B * A);   // actor-step policy noise
+    cs.n = n; cs.isrc = ag->steps; cs.idst = D.steps;
     const Slot keep = s0;
     s0.XF = d.XF; s0.XF2 = d.XF2; s0.XFpi = d.XFpi; s0.R = d.R; s0.D = d.D;
-    ag->ov_base = b.dry ? nullptr : snap; ag->ov_prefix = prefix; ag->ov_first = first;      // the dry pass only sizes the workspace
+    ag->ov_base = b.dry ? nullptr : D.block; ag->ov_prefix = prefix; ag->ov_first = first;      // the dry pass only sizes the workspace
+    ag->dcur = set;
+    b.low_prio = true;
     return keep;
 }
-void defer_end(Builder& b, rlrep_agent* ag, const Slot& keep, const std::string& critic_target_first, std::vector<FinTask> cfins) {
+void defer_end(Builder& b, rlrep_agent* ag, int set, const Slot& keep, const std::string& critic_target_first, std::vector<FinTask> cfins) {
     ag->ov_base = nullptr;
     ag->slot[0] = keep;
-    critic_apply_folded(b, ag, critic_target_first, cfins, &ag->critic_apply_d, ag->steps_snap);
-    ag->snap_valid = false;
+    b.low_prio = false;
+    critic_apply_folded(b, ag, critic_target_first, cfins, &ag->dset[set].critic_apply, ag->dset[set].steps);
+    ag->dset[set].valid = false;
 }
 
 // ================================================================================================
@@ -599,7 +603,7 @@ void defer_end(Builder& b, rlrep_agent* ag, const Slot& keep, const std::string&
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2, &ag->critic_bwd_d, &ag->critic_apply_d, &ag->actor_bwd_d})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2, &ag->dset[0].critic_bwd, &ag->dset[0].critic_apply, &ag->dset[0].actor_bwd, &ag->dset[1].critic_bwd, &ag->dset[1].critic_apply, &ag->dset[1].actor_bwd})
         p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
     ag->pf_armed = ag->pf_done = false;
@@ -996,34 +1000,40 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     ag->in_train = true; ag->target_done = false;
     return 0;
 }
-int32_t rlrep_defer_supported(rlrep_agent* ag) { return (ag && !ag->critic_bwd_d.stages.empty() && !ag->actor_bwd_d.stages.empty()) ? 1 : 0; }
-int32_t rlrep_defer_snapshot(rlrep_agent* ag, const float* eps_critic, const float* eps_actor, void* stream) {
-    if (!ag || !eps_critic || !eps_actor) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
+int32_t rlrep_defer_supported(rlrep_agent* ag) {
+    if (!ag) return 0;
+    int n = 0;
+    for (int k = 0; k < 2; ++k) if (!ag->dset[k].critic_bwd.stages.empty() && !ag->dset[k].actor_bwd.stages.empty()) ++n;
+    return n == 2 ? 2 : 0;
+}
+int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_critic, const float* eps_actor, void* stream) {
+    if (!ag || !eps_critic || !eps_actor || set < 0 || set > 1) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
     if (!rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
     if (!ag->slot[0].filled) { rl_set_error("defer_snapshot before set_batch / replay_sample"); return RLREP_ERR_STATE; }
-    if (!ag->sync_prog.stages.empty()) {          // ctrlsac: frozen_phi, frozen_phi_target <- phi is the parameter snapshot
+    if (!ag->sync_prog.stages.empty()) {          // ctrlsac: frozen_phi, frozen_phi_target <- phi (ctrlsac_agent.py:344-346) belongs to the end of the feature steps
         const int rs = ag->sync_prog.run((hipStream_t)stream);
         if (rs) return rs;
     }
-    CopySegs cs = ag->snap_segs;
+    CopySegs cs = ag->dset[set].segs;
     cs.src[cs.n - 2] = eps_critic; cs.src[cs.n - 1] = eps_actor;
     const int rc = rl_launch_copy_segs(&cs, (hipStream_t)stream);
     if (rc) { rl_set_error("defer_snapshot: hip error %d", rc); return RLREP_ERR_HIP; }
-    ag->snap_valid = true;
+    ag->dset[set].valid = true;
     return 0;
 }
-int32_t rlrep_deferred_critic_actor(rlrep_agent* ag, void* stream) {
-    if (!ag || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
-    if (!ag->snap_valid) { rl_set_error("deferred critic/actor steps before rlrep_defer_snapshot"); return RLREP_ERR_STATE; }
-    const float* e_crit = ag->eps_snap; const float* e_act = ag->eps_snap + (size_t)ag->B * ag->d.action_dim;
+int32_t rlrep_deferred_critic_actor(rlrep_agent* ag, int32_t set, void* stream) {
+    if (!ag || set < 0 || set > 1 || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
+    rlrep_agent::DeferSet& D = ag->dset[set];
+    if (!D.valid) { rl_set_error("deferred critic/actor steps before rlrep_defer_snapshot of this set"); return RLREP_ERR_STATE; }
+    const float* e_crit = D.eps; const float* e_act = D.eps + (size_t)ag->B * ag->d.action_dim;
     const float* keep1 = ag->cur_eps; const float* keep2 = ag->cur_eps2;
     ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0;
-    int rc = run(ag, ag->critic_bwd_d, stream);
-    if (!rc) rc = run(ag, ag->critic_apply_d, stream);
+    int rc = run(ag, D.critic_bwd, stream);
+    if (!rc) rc = run(ag, D.critic_apply, stream);
     if (!rc) {
         ag->cur_eps = e_act;
-        ag->last_launches += (int)(ag->actor_bwd_d.stages.size() - ag->actor_resume_d);
-        rc = ag->actor_bwd_d.run((hipStream_t)stream, (size_t)ag->actor_resume_d);
+        ag->last_launches += (int)(D.actor_bwd.stages.size() - D.actor_resume);
+        rc = D.actor_bwd.run((hipStream_t)stream, (size_t)D.actor_resume);
     }
     if (!rc) rc = run(ag, ag->actor_apply, stream);
     ag->cur_eps = keep1; ag->cur_eps2 = keep2;

@@ -38,11 +38,16 @@ struct rlrep_agent {
     // run [critic, actor of t] and [feature steps of t+1] as two concurrent branches.  rlrep_defer_snapshot takes the snapshot
     // (one launch) after the last feature step; rlrep_deferred_critic_actor runs the two steps against it.  Same arithmetic,
     // same order of updates per parameter; only the overlap changes.
-    Slot slot_d; float* ft_snap = nullptr; float* eps_snap = nullptr; int* steps_snap = nullptr;
+    // TWO snapshot sets (ping-pong): train(t) uses set t & 1, so the snapshot of train(t+1) never has to wait for the critic / actor
+    // pair of train(t) -- only for that of train(t-1), which is long finished.
+    struct DeferSet {
+        Slot slot; float* block = nullptr; float* eps = nullptr; int* steps = nullptr; CopySegs segs;
+        Program critic_bwd, critic_apply, actor_bwd; int actor_resume = 0; bool valid = false;
+    };
+    DeferSet dset[2]; int dcur = 0;             // dcur: the set the programs under construction belong to
     // while the deferred programs are built, tensors named ov_prefix* resolve into the snapshot block ov_base (same internal layout
-    // as the block that starts at ov_first): vlsac f_target.* -> its copy, ctrlsac phi.* -> frozen_phi.*, spedersac phi.trunk.* -> copy
+    // as the block that starts at ov_first): vlsac f_target.*, ctrlsac phi.*, spedersac phi.trunk.*
     const float* ov_base = nullptr; std::string ov_prefix, ov_first;
-    Program critic_bwd_d, critic_apply_d, actor_bwd_d; int actor_resume_d = 0; CopySegs snap_segs; bool snap_valid = false;
     int infer_n = 0; float infer_lo = -1.f, infer_hi = 1.f; size_t prog_end = 0;
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
@@ -166,6 +171,7 @@ struct Builder {
         if (tasks.size() > GEMM_MAX_TASKS) { fprintf(stderr, "rlrep: too many tasks in stage %s\n", what); abort(); }
         GemmBatch gb; memset(&gb, 0, sizeof(gb));
         gb.ntasks = (int)tasks.size();
+        gb.low_prio = low_prio ? 1 : 0;
         if (la == LD_COL && lb == LD_COL && fused() && !pending_fin.empty()) {
             gb.fin = upload(pending_fin); gb.nfin = (int)pending_fin.size();
             pending_fin.clear(); fin_attached = true;
@@ -196,6 +202,7 @@ struct Builder {
     // the other epilogue operands before the inner loop, so the weight-gradient launch itself barely grows.  (A first
     // version read p/m/v after the reduction and still needed a finalise launch: 624 vs 608 us per train(), slower.)
     // A step program opts in (allow_fuse) only if every parameter tensor receives exactly ONE weight-gradient task.
+    bool low_prio = false;        // set while the deferred critic / actor programs are built: their chain has slack next to the feature chain
     bool allow_fuse = false;
     // MEASURED (MI355X, vlsac B = 256): still a loss.  Adam is bandwidth work (28 bytes per parameter, ~17 MB per feature
     // step): the separate launch streams it with 16-byte lanes in 4.5 us, the 16 x 16 tile epilogue moves the same
@@ -313,12 +320,12 @@ void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss,
 std::vector<FinTask> actor_fins(rlrep_agent* ag, const float* partial_loss, int nblk);
 void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins, Program* into = nullptr, const int* steps = nullptr);
 void update_target_program(rlrep_agent* ag, const std::string& first_src, const std::string& first_dst);
-// Deferred critic / actor programs (rlrep_agent::slot_d): defer_begin allocates the snapshot (minibatch, policy noise, step counter and,
-// unless `external_block`, a copy of the `block_n` floats at `block_src`; an external block is refreshed by the agent's own sync program), redirects slot 0 and the tensors named `prefix`* (block
-// starting at tensor `first`) and returns the saved slot; the caller then emits its critic / actor programs a second time into
-// critic_bwd_d / actor_bwd_d and calls defer_end.
-Slot defer_begin(Builder& b, rlrep_agent* ag, const char* prefix, const char* first, const float* block_src, float* block_dst, int64_t block_n, bool external_block);
-void defer_end(Builder& b, rlrep_agent* ag, const Slot& keep, const std::string& critic_target_first, std::vector<FinTask> cfins);
+// Deferred critic / actor programs (rlrep_agent::dset): defer_begin(set) allocates that set's snapshot (minibatch, policy noise, step
+// counter and a copy of the `block_n` floats at `block_src`), redirects slot 0 and the tensors named `prefix`* (block starting at tensor
+// `first`) and returns the saved slot; the caller then emits its critic / actor programs into dset[set].critic_bwd / .actor_bwd and
+// calls defer_end.
+Slot defer_begin(Builder& b, rlrep_agent* ag, int set, const char* prefix, const char* first, const float* block_src, int64_t block_n);
+void defer_end(Builder& b, rlrep_agent* ag, int set, const Slot& keep, const std::string& critic_target_first, std::vector<FinTask> cfins);
 
 // agents2.hip
 void lay_ctrlsac(const rlrep_dims& d, Layout& L);

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     TIM(0);
     // latency-critical launch: win the issue arbitration against the waves of a noise-critic launch that may be running on the
     // other stream of the deferred pipeline (405.8 vs 429.7 us per train(); alone on the chip it changes nothing)
-    __builtin_amdgcn_s_setprio(3);
+    if (!gb.low_prio) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x;
     if (gb.nfin > 0 && bid == (int)gridDim.x - 1) {      // trailing workgroup: metric finalisation / temperature update
         if (threadIdx.x < 64) finalize_tasks(gb.fin, gb.nfin, threadIdx.x);

@@ -11,26 +11,26 @@ for _ in range(30):
     agent.train(buf, B)
 agent.flush(); torch.cuda.synchronize()
 P = agent._pipe
-sa, sb = P['sa'], P['sb']
+sa, sb = P['s_ca'], P['s_f']
 def t(fn, n=300):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
 def feat_only():
-    with torch.cuda.stream(sb): P['feat'].replay(); P['snap'].replay()
+    with torch.cuda.stream(sb): P['fs'][0].replay()
 def ca_only():
-    with torch.cuda.stream(sa): P['tail'].replay()
+    with torch.cuda.stream(sa): P['ca'][0].replay()
 def both_nowait():
-    with torch.cuda.stream(sb): P['feat'].replay(); P['snap'].replay()
-    with torch.cuda.stream(sa): P['tail'].replay()
+    with torch.cuda.stream(sb): P['fs'][0].replay()
+    with torch.cuda.stream(sa): P['ca'][0].replay()
 def both_wait():
     with torch.cuda.stream(sb):
         P['feat'].replay(); sb.wait_event(P['ev_ca']); P['snap'].replay(); P['ev_snap'].record(sb)
     with torch.cuda.stream(sa):
-        sa.wait_event(P['ev_snap']); P['tail'].replay(); P['ev_ca'].record(sa)
+        sa.wait_event(P['ev_snap']); P['ca'][0].replay(); P['ev_ca'].record(sa)
 def both_samestream():
-    with torch.cuda.stream(sb): P['feat'].replay(); P['snap'].replay(); P['tail'].replay()
+    with torch.cuda.stream(sb): P['fs'][0].replay(); P['ca'][0].replay()
 print('feature graph + snapshot alone      %.1f us' % t(feat_only))
 print('critic+actor graph alone            %.1f us' % t(ca_only))
 print('both, one stream                    %.1f us' % t(both_samestream))
@@ -41,10 +41,10 @@ print('agent.train()                       %.1f us' % t(lambda: agent.train(buf,
 import itertools
 def concurrent(a, b):
     def one():
-        with torch.cuda.stream(a): P['tail'].replay(); P['tail'].replay()
+        with torch.cuda.stream(a): P['ca'][0].replay(); P['ca'][0].replay()
     def two():
-        with torch.cuda.stream(a): P['tail'].replay()
-        with torch.cuda.stream(b): P['tail'].replay()
+        with torch.cuda.stream(a): P['ca'][0].replay()
+        with torch.cuda.stream(b): P['ca'][0].replay()
     return t(two, 20) < 0.8 * t(one, 20)
 hi = [torch.cuda.Stream(priority=-1) for _ in range(6)]
 for name, fa, fb in (('feature chain high priority', sa, None), ('critic/actor chain high priority', None, sb)):
@@ -56,6 +56,6 @@ for name, fa, fb in (('feature chain high priority', sa, None), ('critic/actor c
             with torch.cuda.stream(b):
                 P['feat'].replay(); b.wait_event(P['ev_ca']); P['snap'].replay(); P['ev_snap'].record(b)
             with torch.cuda.stream(a):
-                a.wait_event(P['ev_snap']); P['tail'].replay(); P['ev_ca'].record(a)
+                a.wait_event(P['ev_snap']); P['ca'][0].replay(); P['ev_ca'].record(a)
         print('%-34s %.1f us' % (name, t(both)))
         break
