@@ -38,8 +38,11 @@ kernels read ~5.5 us each; un-profiled, a chain of trivial graph-captured kernel
 and the instrumented timeline (`tools/exp/gemm_timeline.py`) puts a gemm16 launch at 3.3-5.7 us of kernel span plus
 1.4-2.2 us to the first wave of the next launch.
 
-bench.py (un-profiled): **{b['value']} {b['unit']}**, {b['ms_per_step']} ms per train().  Box-to-box spread of this number
-over the gpurun pool is about 5 % (the same build measured 533 and 557 us per train() on two boxes).
+bench.py (un-profiled): **{b['value']} {b['unit']}**, {b['ms_per_step']} ms per train() -- graph mode with the critic + actor steps of
+train(t) on a second stream beside the feature steps of train(t+1) (`config.deferred_critic_actor_branch`; DESIGN.md 2 and 5.0);
+`RLREP_PIPELINE=0` gives the strictly sequential graph: 1 840-1 900 train()/s (0.53-0.54 ms).  Box-to-box spread over the gpurun pool
+is about 5 %.  The kernel table above was collected in the same (pipelined) mode: under rocprofv3 the two streams' kernels are
+serialised, so it shows per-kernel durations, not the overlap.
 
 roofline: `{json.dumps(b['roofline'])}`
 
@@ -55,8 +58,9 @@ launches; `roofline.us_per_launch` times the critic-step launch alone with HIP e
 |---|---|---|---|---|---|---|
 ''' + '\n'.join(row(k) for k in keys) + '''
 
-VALU_MFMA_BUSY / (launch time x 1024 SIMDs x 2.2 GHz) is the chip-wide MFMA utilisation: 52 % for the critic-stage
-`nc_fwd` launch (matches `roofline.frac`), 37 % for `nc_dw`, 41 % for `nc_dx`.
+VALU_MFMA_BUSY / (launch time x 1024 SIMDs x clock) is the chip-wide MFMA utilisation: 39.9 M busy cycles over 30.8 us x 1024 SIMDs x
+2.1 GHz (the clock the chip holds under this load, tools/exp/nc_timeline.py) = 60 % for the critic-stage `nc_fwd` launch
+(`roofline.frac` prices the same launch against the 2.4 GHz spec peak: 0.55), ~40 % for `nc_dw` and `nc_dx`.
 FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane streaming reads) applies to
 `nc_fwd`'s table staging and gives bench.py's `roofline.traffic` = 2 x FETCH + WRITE = 17.7 MB per critic-stage launch
 against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs).  `nc_dw` / `nc_dx` read U (10.5 MB) once:
