@@ -235,7 +235,9 @@ class SACAgent(object):
         return self.core.info(self.ACTOR_KEYS)
 
     def train(self, buffer, batch_size):
-        """One train step (sac_agent.py:169-188)."""
+        """One train step (sac_agent.py:169-188).  In pipelined graph mode (vlsac / ctrlsac / spedersac on one GPU) the critic and
+        actor steps of this call may still be in flight when it returns; everything that looks at them waits (`flush()`), including
+        reading the returned info dict -- which therefore has to be read before the NEXT train() call to describe THIS one."""
         self.steps += 1
         if self.use_graph and self.world_size == 1:
             if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
@@ -599,9 +601,9 @@ class SACAgent(object):
         k = P['t'] & 1
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
+        cur = torch.cuda.current_stream()
+        s_f.wait_stream(cur)                               # replay rows staged by ReplayBuffer.add() land on the caller's stream
         if not self._pending:
-            cur = torch.cuda.current_stream()
-            s_f.wait_stream(cur)
             s_ca.wait_stream(cur)
         with torch.cuda.stream(s_f):
             if P['used'][k]:
