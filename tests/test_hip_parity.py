@@ -372,3 +372,33 @@ def test_deferred_pipeline_is_equivalent(name):
         assert np.allclose(x, y, atol=1e-6)
     for k in ib:
         assert abs(ia[k] - ib[k]) <= 1e-6 * max(abs(ib[k]), 1e-2), (k, ia[k], ib[k])
+
+
+@pytest.mark.parametrize('alg,S,A,B,kw', [
+    ('vlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
+    ('ctrlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
+])
+def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw):
+    """400 pipelined train() calls at the BASELINE dimensions (two streams, two snapshot sets, device Philox) end in exactly the
+    parameters, moments and targets of 400 sequential ones: any missing dependency between the two launch chains would show here
+    (tools/exp/pipe_soak.py runs the same check for 2000 calls: 0.0 difference for vlsac, ctrlsac and spedersac)."""
+    import importlib
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    name = {'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent'}[alg]
+    cls = getattr(importlib.import_module(f'rlrep_amd.agent.{alg}.{alg}_agent'), name)
+    data = synth.replay(S, A, 8192, seed=0)
+    outs = []
+    for pipe in (True, False):
+        torch.manual_seed(0)
+        agent = cls(state_dim=S, action_dim=A, action_space=_Space(A, 1.0), max_batch=B, pipeline=pipe, seed=99, **kw)
+        buf = ReplayBuffer(S, A, max_size=8192)
+        buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+        for i in range(400):
+            agent.train(buf, B)
+            if i == 250:
+                agent.select_action(np.zeros(S, np.float32))
+        outs.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
+        outs[-1]['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy()
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
