@@ -243,6 +243,14 @@ def main():
         dt = float(tt.item())
     info = agent.train(buf, B)
     finite = all(np.isfinite(v) for v in info.values())
+    # the same loop with the metric dict READ after every train() (a device sync per call, as the reference's .item()s do)
+    n_sync = min(args.steps, 300)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(n_sync):
+        float(agent.train(buf, B)[next(iter(info))])
+    barrier()
+    dt_sync = time.perf_counter() - t1
 
     if rank == 0:
         value = world * args.steps / dt
@@ -261,6 +269,7 @@ def main():
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B, 1),
             'metrics_finite': bool(finite),
+            'value_with_per_step_metric_fetch': round(world * n_sync / dt_sync, 2),
         }
         if alg == 'vlsac':
             out['roofline'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
