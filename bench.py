@@ -49,7 +49,10 @@ ALG_GFLOP = {'vlsac_halfcheetah_f256_b256': 10.59, 'sac_halfcheetah_b256': 0.582
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md); the bf16x3 tile executes 6 bf16 MFMA flops per algorithmic fp32 flop
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
-NC_FWD_TRAFFIC_BYTES = int((2 * 3103.5 + 11446.6) * 1024)   # 17.7 MB vs 11.0 MB algorithmic (U out 10.5 MB + inputs)
+# HBM-side bytes per nc_fwd launch from the PMC passes in profiles/r01_pmc_summary.json (FETCH_SIZE 3071.8 KB raw, x2 for 16-byte streaming
+# reads on gfx950, + WRITE_SIZE 11446.6 KB; mean over the critic- and actor-stage launches of the profiled run): 17.6 MB against
+# 11.0 MB algorithmic for the critic-stage launch (10.5 MB of ELU outputs written + tables and weights read)
+NC_FWD_TRAFFIC_BYTES = int((2 * 3071.8 + 11446.6) * 1024)
 
 
 class Space:
