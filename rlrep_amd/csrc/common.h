@@ -39,6 +39,12 @@ enum Epi : int {
 #define FLAG_SCALAR_A 32
 #define FLAG_SCALAR_B 64
 #define FLAG_SCALAR_C 128
+// gemm16.hip: the A operand is not read from memory but is the output of a fused SHORT product that precedes this one in the chain,
+//   A[i][k] = ( sum_{j < K1} X[i][j] * Wt[j][k] ) * relu'(M[i][k]),   K1 <= 32,  Wt k-major ([K1][K]: lanes read consecutive k),
+// recomputed by every tile for its 16 rows (x0 = X, ldx0; x1 = Wt, ldx1; n0 = K1; x2 = M, ldaux2 its row stride; y0 = where column
+// tile 0 stores A for the weight-gradient pass, ldout2 its row stride).  vlsac: dL/d(dec.l1 output) = (dL/d[s_hat|r_hat] [B,18]) W_heads
+// rides in the dec.l1 dX launch instead of being a launch of its own.
+#define FLAG_PRE 256
 
 struct GroupCfg;
 struct GemmTask {

@@ -333,11 +333,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             t.s0 = ag->inv_batch() / (float)S; t.s1 = ag->inv_batch(); t.y0 = part_mse;
             b.fwd_stage(p, {t}, "dec.heads + mse");
         }
-        b.dx_stage(p, {Builder::dx(GDH, S + 1, B, S + 1, Pw("decoder.state_linear.weight"), Hv, GD1, Hv, Hv, ACT_RELU, D1, Hv)}, "dec.heads dx");
         {
             GemmTask t = Builder::dx(GD1, Hv, B, Hv, Pw("decoder.l1.weight"), F, GEH, 2 * F, F, ACT_NONE, nullptr, 0);
             t.epi = EPI_DX_REPARAM; t.aux3 = EZ; t.ldaux3 = F; t.F = F;
-            b.dx_stage(p, {t}, "dec.l1 dx -> (dmean, dlog_std)");
+            // the K = 18 product dL/d(dec.l1 output) = d[s_hat|r_hat] W_heads rides in the dec.l1 dX launch (one launch less per feature step)
+            b.dx_stage12(p, Builder::dx(GDH, S + 1, B, S + 1, Pw("decoder.state_linear.weight"), Hv, GD1, Hv, Hv, ACT_RELU, D1, Hv), t,
+                         "dec.heads dx", "dec.l1 dx -> (dmean, dlog_std)");
         }
         b.dx_stage(p, {Builder::dx(GEH, 2 * F, B, 2 * F, Pw("encoder.mean_linear.weight"), Hv, GH2e, Hv, Hv, ACT_RELU, ge.H2, Hv),
                        Builder::dx(GFH, 2 * F, B, 2 * F, Pw("f.mean_linear.weight"), Hv, GH2f, Hv, Hv, ACT_RELU, gf.H2, Hv)}, "heads dx");

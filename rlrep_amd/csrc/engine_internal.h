@@ -161,6 +161,7 @@ struct Builder {
             auto count = [&](int f) { long long n = 0; for (auto& t : tasks) n += (long long)((t.R + 15) / 16) * ((t.Cn + 16 * f - 1) / (16 * f)); return n; };
             if (!force1) { if (count(2) >= 384) nf = 2; if (count(4) >= 384) nf = 4; }
             if (getenv("RLREP_NF")) nf = atoi(getenv("RLREP_NF")), nf = force1 ? 1 : nf;
+            if (!tasks.empty() && (tasks[0].flags & FLAG_PRE)) nf = 1;
         }
         int base_tile = 0;
         for (auto& t : tasks) {
@@ -241,6 +242,18 @@ struct Builder {
 
     void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
     void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
+    // Two consecutive dX stages of which the FIRST has a short inner length (<= 32) and a ReLU mask: one launch in which every tile of
+    // the second recomputes its 16 rows of the first (gemm16.hip, FLAG_PRE).  Falls back to the two stages when the pair does not fit.
+    void dx_stage12(Program& p, GemmTask d1, GemmTask d2, const char* w1, const char* w2) {
+        const bool ok = !getenv("RLREP_NO_FUSE_DX") && d1.epi == EPI_DX && d1.act == ACT_RELU && !(d1.flags & FLAG_ACCUM) && !d1.r1u && d1.K <= 32 &&
+                        d1.scale == 1.f && d2.A == d1.C && d2.lda == d1.ldc && d2.K == d1.Cn && d2.R == d1.R &&
+                        (d2.epi == EPI_DX || d2.epi == EPI_DX_REPARAM) && ((d2.R + 15) / 16) * ((d2.Cn + 15) / 16) < 384 * 2;
+        if (!ok) { dx_stage(p, {d1}, w1); dx_stage(p, {d2}, w2); return; }
+        GemmTask t = d2;
+        t.flags |= FLAG_PRE;
+        t.x0 = d1.A; t.ldx0 = d1.lda; t.x1 = d1.B; t.ldx1 = d1.ldb; t.n0 = d1.K; t.x2 = d1.aux; t.ldaux2 = d1.ldaux; t.y0 = d1.C; t.ldout2 = d1.ldc;
+        gemm_small(p, LD_ROW, LD_COL, {t}, w2);
+    }
     // weight-gradient stage; carries the fused optimizer (and the Polyak spec set by set_polyak) when fused()
     float* pol_target = nullptr; int64_t pol_off = 0, pol_n = 0; float pol_tau = 0.f;
     void set_polyak(float* target, int64_t off, int64_t n, float tau) { pol_target = target; pol_off = off; pol_n = n; pol_tau = tau; }

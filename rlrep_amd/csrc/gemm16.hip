@@ -111,7 +111,78 @@ __device__ __forceinline__ void mac_group(const float* __restrict__ A, int lda, 
     }
 }
 
-template <int LA, int LB, int NF, bool VA, bool VB>
+// ---- fused short product (FLAG_PRE) ---------------------------------------------------------------------------------------------
+// By MFMA with the operand roles swapped: the row operand is a Wt fragment (16 values of k for one inner index j: consecutive addresses
+// across the 16 lanes), the column operand the X fragment (16 batch rows).  The result tile D has col = lane & 15 = batch row and
+// row = 4 (lane >> 4) + reg = k offset 4 kq + reg inside the wave's 16-wide chunk -- exactly the "four consecutive inner indices per
+// lane" layout in which the main loop wants its A operand: no lane movement, no LDS.  (The same construction for the FIRST layers of the
+// MLPs, whose weights are stored [k][j] with 92-byte rows, made every fragment load touch 16-23 cache lines and lost: DESIGN.md 5.0.)
+struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const float* M; int ldm; float* out; int ldo; };
+
+template <int LB, int NF, bool VB, int NU>
+__device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
+                                              int i, int kq, int kb, int K, bool store, f32x4 (&acc)[NF]) {
+    float xf[2][4], wf[NU][2][4], mk[NU][4], b[NU][NF][4];
+    const int K1 = ps.K1;
+    const float* xrow = ps.X + (size_t)min(r0 + i, R - 1) * ps.ldx;
+    const float* mrow = ps.M + (size_t)min(r0 + i, R - 1) * ps.ldm;
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xf[jc][m] = xrow[min(16 * jc + 4 * kq + m, K1 - 1)];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int kcol = min(kb + 64 * u + i, K - 1);
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wf[u][jc][m] = ps.Wt[(size_t)min(16 * jc + 4 * kq + m, K1 - 1) * ps.ldw + kcol];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) mk[u][m] = mrow[min(kb + 64 * u + 4 * kq + m, K - 1)];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) load_raw<LB, VB>(B, ldb, c0 + 16 * f, Cn, i, kb + 4 * kq + 64 * u, K, b[u][f]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // zero what the clamped loads fetched beyond K1 (inner index); rows beyond R / k beyond K are masked when A is formed
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xf[jc][m] = (16 * jc + 4 * kq + m) < K1 ? xf[jc][m] : 0.f;
+    f32x4 D[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) D[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc) {
+        if (16 * jc >= K1) break;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) D[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jc][m], xf[jc][m], D[u], 0, 0, 0);
+    }
+    const bool rok = (r0 + i) < R;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        float a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float g = mk[u][m] > 0.f ? D[u][m] : 0.f;
+            a[m] = (rok && (kb + 64 * u + 4 * kq + m) < K) ? g : 0.f;
+        }
+        if (store && rok) {
+            float* op = ps.out + (size_t)(r0 + i) * ps.ldo + kb + 64 * u + 4 * kq;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) if (kb + 64 * u + 4 * kq + m < K) op[m] = a[m];
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) mask_frag(c0 + 16 * f, Cn, i, kb + 4 * kq + 64 * u, K, b[u][f]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[u][f][m], acc[f], 0, 0, 0);
+    }
+}
+
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
@@ -236,6 +307,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     }
 
     // wave w owns the 16-wide inner chunks w, w+4, w+8, ...
+    if constexpr (PRE) {
+        PreSrc ps; ps.X = t.x0; ps.ldx = t.ldx0; ps.Wt = t.x1; ps.ldw = t.ldx1; ps.K1 = n0; ps.M = t.x2; ps.ldm = t.ldaux2; ps.out = t.y0; ps.ldo = t.ldout2;
+        const bool store = (tc == 0) && ps.out;
+        for (int kb = w * 16; kb < K; kb += 256) {
+            const int nu = (K - kb + 63) >> 6;
+            if (nu >= 4) mac_group_pre<LB, NF, VB, 4>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            else if (nu == 1) mac_group_pre<LB, NF, VB, 1>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            else if (nu == 2) mac_group_pre<LB, NF, VB, 2>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            else mac_group_pre<LB, NF, VB, 3>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+        }
+    } else
     for (int kb = w * 16; kb < K; kb += 256) {
         const int k0 = kb + 4 * kq;
         const int nu = (K - kb + 63) >> 6;           // chunks of this group that touch the matrix (uniform per wave)
@@ -427,6 +509,12 @@ static bool all_vec(const GemmBatch& gb, bool opB) {
 extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
+    if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch (dX form): every task carries FLAG_PRE
+        for (int q = 0; q < gb->ntasks; ++q) if (!(gb->t[q].flags & FLAG_PRE)) return -3;
+        if (la != LD_ROW || lb != LD_COL || nf != 1) return -3;
+        hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+        return (int)hipGetLastError();
+    }
     if (la == LD_ROW && lb == LD_ROW) {
         if (all_vec(*gb, false) && all_vec(*gb, true)) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb);
         else launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
