@@ -264,6 +264,8 @@ class SACAgent(object):
 
     def load(self, path_or_snapshot):
         snap = torch.load(path_or_snapshot) if isinstance(path_or_snapshot, (str, bytes, os.PathLike)) else path_or_snapshot
+        self.flush()                                   # nothing of a pipelined train() may still be writing the arenas
+        torch.cuda.synchronize()
         c = self.core
         if snap['alg'] != self.ALG or snap['layout'] != list(c.order) or snap['params'].numel() != c.params.numel():
             raise RuntimeError('checkpoint does not match this agent (algorithm / dimensions differ)')

@@ -402,3 +402,36 @@ def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw):
         outs[-1]['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy()
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_deferred_pipeline_batch_change_and_checkpoint():
+    """Pipelined graph mode across a batch-size change (graphs and snapshot sets are rebuilt) and a save / load round trip: same final
+    state as sequential graph mode doing the same things."""
+    c = Case('vlsac_tiny')
+    outs = []
+    for pipe in (True, False):
+        kw = dict(c.kw)
+        if c.meta.get('patch_vae_hidden'):
+            kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+        cls = type(make_agent(c))
+        agent = cls(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, graph=True, pipeline=pipe,
+                    seed=2024, **kw)
+        agent.core.load_state(c.init)
+        buf = make_buffer(c)
+        for _ in range(3):
+            agent.train(buf, c.B)
+        for _ in range(3):
+            agent.train(buf, c.B // 2)
+        snap = agent.state_snapshot()
+        for _ in range(2):
+            agent.train(buf, c.B)
+        mid = {k: v.numpy().copy() for k, v in agent.core.state().items()}
+        agent.load(snap)
+        for _ in range(2):
+            agent.train(buf, c.B)
+        end = {k: v.numpy().copy() for k, v in agent.core.state().items()}
+        for k in mid:
+            assert np.array_equal(mid[k], end[k]), ('resume', pipe, k)
+        outs.append(end)
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
