@@ -266,6 +266,9 @@ int32_t rlrep_feature_backward_part(rlrep_agent* agent, int32_t part, const floa
 int32_t rlrep_defer_supported(rlrep_agent* agent);          /* number of snapshot sets (2) or 0 */
 int32_t rlrep_defer_snapshot(rlrep_agent* agent, int32_t set, const float* eps_critic_dev, const float* eps_actor_dev, void* stream);
 int32_t rlrep_deferred_critic_actor(rlrep_agent* agent, int32_t set, void* stream);
+/* The same in four parts for data-parallel callers (all-reduce of the critic / actor gradient slices after parts 0 and 2):
+ * 0 critic backward, 1 critic apply (+ period-gated critic-target Polyak), 2 actor backward, 3 actor + temperature apply. */
+int32_t rlrep_deferred_part(rlrep_agent* agent, int32_t set, int32_t part, void* stream);
 /* Host-only: closes a rlrep_begin_train / rlrep_train_prologue bracket without launching anything (the critic-target update of a
  * deferred train() runs inside rlrep_deferred_critic_actor). */
 int32_t rlrep_end_train(rlrep_agent* agent);

@@ -109,6 +109,7 @@ def _load():
         'rlrep_defer_supported': (i32, [vp]),
         'rlrep_defer_snapshot': (i32, [vp, i32, vp, vp, vp]),
         'rlrep_deferred_critic_actor': (i32, [vp, i32, vp]),
+        'rlrep_deferred_part': (i32, [vp, i32, i32, vp]),
         'rlrep_end_train': (i32, [vp]),
         'rlrep_sync_frozen': (i32, [vp, vp]),
         'rlrep_actor_forward': (i32, [vp, vp, i32, vp, f32, f32, vp, vp]),

@@ -162,6 +162,7 @@ class SACAgent(object):
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
         # critic / actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (vlsac; _train_graph_pipelined)
         self.use_pipeline = bool(int(os.environ.get('RLREP_PIPELINE', '1'))) and hip_kwargs.get('pipeline', True)
+        self.use_pipeline_dp = bool(int(os.environ.get('RLREP_PIPELINE_DP', '1')))
         self._pipe = None
         self._pending = False
         self.core.before_read = self.flush
@@ -244,6 +245,8 @@ class SACAgent(object):
                 return self._train_graph_pipelined(buffer, batch_size)
             return self._train_graph(buffer, batch_size)
         if self.use_graph and self.use_graph_dp:
+            if self.use_pipeline and self.use_pipeline_dp and self._feature_iters() > 0 and self.ALG == 'vlsac' and self.core.defer_supported():
+                return self._train_graph_dp_pipelined(buffer, batch_size)
             return self._train_graph_dp(buffer, batch_size)
         return self._train_eager(buffer, batch_size)
 
@@ -493,7 +496,9 @@ class SACAgent(object):
         key = (id(buffer), B)
         if self._graph is None or self._graph_key != key:
             self._sample_into(buffer, B, 'warm', 0, False)
-            self._fill_pools(buffer, B, True)              # allocate the noise pools outside any capture
+            idx_keys, eps_specs = self._plan(B)            # allocate the pools outside any capture (no launch: the train
+            self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)   # prologue would count a step and draw from the generator)
+            self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
             torch.cuda.synchronize()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -620,13 +625,105 @@ class SACAgent(object):
         self._pending = 2
         return self.core.info(lazy_source=self._flushed_metrics)
 
+    # ---- data parallel + deferred critic / actor chain ---------------------------------------------------------------------------
+    # The two launch chains of the pipelined mode, each cut into hipGraph segments at its gradient all-reduces (feature chain: 4,
+    # critic/actor chain: 2).  ONE process group, ONE fixed issue order per train() on every rank (no cross-rank ordering hazard); the
+    # critic/actor items of train(t) are issued INTERLEAVED with the feature items of train(t+1) in the order their gradients become
+    # ready (f0, critic, f1, actor, f2, f3), so the communicator's in-order queue does not hold a ready all-reduce behind an unready one.
+    _DP_ORDER = ('F', 'C', 'F', 'C', 'C', 'F', 'F', 'C', 'C', 'F', 'F', 'F', 'F', 'F')   # gF0 gC0 cF0 cC gC1 gF1 cF1 cA gC2 gF2 cF2 gF3 cF3 gF4
+
+    def _capture_segments(self, fn):
+        first = torch.cuda.CUDAGraph()
+        first.capture_begin(capture_error_mode='thread_local')
+        self._seg = ([], first)
+        try:
+            fn()
+            segs, cur = self._seg
+            cur.capture_end()
+            segs.append(('graph', cur))
+        finally:
+            self._seg = None
+        return segs
+
+    def _train_graph_dp_pipelined(self, buffer, B):
+        buffer.flush()
+        buffer.size_dev()
+        key = (id(buffer), B)
+        c = self.core
+        if self._pipe is None or self._pipe['key'] != key:
+            self.flush()
+            self._sample_into(buffer, B, 'warm', 0, False)
+            idx_keys, eps_specs = self._plan(B)
+            self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
+            self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
+            torch.cuda.synchronize()
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            fs, cs = [], []
+            with torch.cuda.stream(cap):
+                for k in range(2):
+                    def feature_chain(k=k):
+                        ec, ea = self._feature_part(buffer, B)
+                        c.defer_snapshot(ec, ea, k)
+                        c.end_train()
+                    fs.append(self._capture_segments(feature_chain))
+
+                    def ca_chain(k=k):
+                        c.deferred_part(k, 0); self._allreduce(1); c.deferred_part(k, 1)
+                        c.deferred_part(k, 2); self._allreduce(2, True); c.deferred_part(k, 3)
+                    cs.append(self._capture_segments(ca_chain))
+            torch.cuda.current_stream().wait_stream(cap)
+            torch.cuda.synchronize()
+            s_ca, s_f = _concurrent_stream_pair(c)
+            self._pipe = dict(key=key, mode=3, t=0, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
+                              ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False], prev=None)
+        P = self._pipe
+        k = P['t'] & 1
+        P['t'] += 1
+        s_ca, s_f = P['s_ca'], P['s_f']
+        cur = torch.cuda.current_stream()
+        s_f.wait_stream(cur)
+        if P['used'][k]:
+            s_f.wait_event(P['ev_ca'][k])                  # the pair that read this snapshot set last (train t-2)
+        F = list(P['fs'][k])
+        prev = P['prev']
+        C = list(P['cs'][prev]) if prev is not None else []
+        if C:
+            s_ca.wait_event(P['ev_snap'][prev])
+        order = list(self._DP_ORDER) if C and len(F) == 9 and len(C) == 5 else ['F'] * len(F) + ['C'] * len(C)
+        for chain in order:
+            kind, x = (F if chain == 'F' else C).pop(0)
+            with torch.cuda.stream(s_f if chain == 'F' else s_ca):
+                x.replay() if kind == 'graph' else x()
+        assert not F and not C
+        P['ev_snap'][k].record(s_f)
+        if prev is not None:
+            P['ev_ca'][prev].record(s_ca)
+        P['used'][k] = True
+        P['prev'] = k
+        self._pending = 3
+        return self.core.info(lazy_source=self._flushed_metrics)
+
     def _flushed_metrics(self):
         self.flush()
         return self.core.metrics_tensor().clone()
 
     def flush(self):
         """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""
-        if self._pending == 2:                         # two-stream form: the pair is already in flight on its own stream
+        if self._pending == 3:                         # data parallel: the last train()'s critic / actor chain has not been issued yet
+            self._pending = False
+            P = self._pipe
+            prev, s_ca = P['prev'], P['s_ca']
+            s_ca.wait_event(P['ev_snap'][prev])
+            with torch.cuda.stream(s_ca):
+                for kind, x in P['cs'][prev]:
+                    x.replay() if kind == 'graph' else x()
+            P['ev_ca'][prev].record(s_ca)
+            P['prev'] = None
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(s_ca)
+            cur.wait_stream(P['s_f'])
+        elif self._pending == 2:                       # two-stream form: the pair is already in flight on its own stream
             self._pending = False
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._pipe['s_ca'])

@@ -250,6 +250,9 @@ class HipCore:
     def deferred_critic_actor(self, set=0):
         check(lib.rlrep_deferred_critic_actor(self.h, int(set), _stream()), 'deferred_critic_actor')
 
+    def deferred_part(self, set, part):
+        check(lib.rlrep_deferred_part(self.h, int(set), int(part), _stream()), 'deferred_part')
+
     def end_train(self):
         check(lib.rlrep_end_train(self.h), 'end_train')
 

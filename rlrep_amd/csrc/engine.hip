@@ -1022,24 +1022,27 @@ int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_crit
     ag->dset[set].valid = true;
     return 0;
 }
-int32_t rlrep_deferred_critic_actor(rlrep_agent* ag, int32_t set, void* stream) {
-    if (!ag || set < 0 || set > 1 || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
+// part: 0 critic backward, 1 critic apply (+ period-gated critic-target Polyak), 2 actor backward, 3 actor + temperature apply; -1 all.
+// Data parallel callers all-reduce the critic / actor gradient slices between 0 and 1 and between 2 and 3.
+int32_t rlrep_deferred_part(rlrep_agent* ag, int32_t set, int32_t part, void* stream) {
+    if (!ag || set < 0 || set > 1 || part < -1 || part > 3 || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
     rlrep_agent::DeferSet& D = ag->dset[set];
     if (!D.valid) { rl_set_error("deferred critic/actor steps before rlrep_defer_snapshot of this set"); return RLREP_ERR_STATE; }
     const float* e_crit = D.eps; const float* e_act = D.eps + (size_t)ag->B * ag->d.action_dim;
     const float* keep1 = ag->cur_eps; const float* keep2 = ag->cur_eps2;
-    ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0;
-    int rc = run(ag, D.critic_bwd, stream);
-    if (!rc) rc = run(ag, D.critic_apply, stream);
-    if (!rc) {
+    int rc = 0;
+    if (part == -1 || part == 0) { ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0; rc = run(ag, D.critic_bwd, stream); }
+    if (!rc && (part == -1 || part == 1)) rc = run(ag, D.critic_apply, stream);
+    if (!rc && (part == -1 || part == 2)) {
         ag->cur_eps = e_act;
         ag->last_launches += (int)(D.actor_bwd.stages.size() - D.actor_resume);
         rc = D.actor_bwd.run((hipStream_t)stream, (size_t)D.actor_resume);
     }
-    if (!rc) rc = run(ag, ag->actor_apply, stream);
+    if (!rc && (part == -1 || part == 3)) rc = run(ag, ag->actor_apply, stream);
     ag->cur_eps = keep1; ag->cur_eps2 = keep2;
     return rc;
 }
+int32_t rlrep_deferred_critic_actor(rlrep_agent* ag, int32_t set, void* stream) { return rlrep_deferred_part(ag, set, -1, stream); }
 int32_t rlrep_end_train(rlrep_agent* ag) {
     if (!ag) return RLREP_ERR_ARG;
     ag->in_train = ag->target_done = false;

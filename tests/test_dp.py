@@ -171,6 +171,7 @@ def _gpu_graph_worker(rank, world, port, q):
     c = Case('vlsac_tiny')
     agent = make_agent(c)
     agent.use_graph = True                   # segmented hipGraph capture around the eager all-reduces
+    agent.use_pipeline_dp = False            # the sequential form (the pipelined one has its own test below)
     buf = make_buffer(c)
     infos = [agent.train(buf, c.B) for _ in range(5)]
     torch.cuda.synchronize()
@@ -198,3 +199,51 @@ def test_hip_dp_segmented_graph_keeps_replicas_identical():
         assert np.all(np.isfinite(v)), k
         assert np.array_equal(v, res[1][1][k]), f'replicas diverged at {k}'
     assert np.isfinite(res[0][3]) and np.isfinite(res[1][3])
+
+
+def _gpu_pipe_worker(rank, world, port, q, pipelined):
+    from fixture_io import Case
+    from test_hip_parity import make_agent, make_buffer
+    os.environ['RLREP_PIPELINE_DP'] = '1' if pipelined else '0'
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    c = Case('vlsac_tiny')
+    agent = make_agent(c, seed=31)
+    agent.use_graph = True
+    buf = make_buffer(c)
+    for t in range(7):
+        info = agent.train(buf, c.B)
+        if t == 3:
+            agent.select_action(np.zeros(c.S, np.float32))
+    last = float(info['q1_loss'])
+    torch.cuda.synchronize()
+    took = bool(agent._pipe is not None and agent._pipe.get('mode') == 3)
+    st = {k: v.numpy() for k, v in agent.core.state().items()}
+    q.put((rank, st, took, last))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_dp_pipelined_equals_sequential_dp():
+    """Data parallel + deferred critic/actor chain (two streams, graph segments between the six all-reduces, one process group, fixed
+    interleaved issue order) ends in exactly the state of the sequential data-parallel train(), on both ranks."""
+    out = {}
+    for pipelined in (True, False):
+        world, port = 2, _free_port()
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_gpu_pipe_worker, args=(r, world, port, q, pipelined)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {r[0]: r for r in (q.get(timeout=600) for _ in range(world))}
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert res[0][2] == pipelined and res[1][2] == pipelined
+        for k, v in res[0][1].items():
+            assert np.array_equal(v, res[1][1][k]), f'replicas diverged at {k} (pipelined={pipelined})'
+        out[pipelined] = res[0]
+    for k, v in out[True][1].items():
+        assert np.array_equal(v, out[False][1][k]), f'pipelined != sequential at {k}'
+    assert out[True][3] == out[False][3]
