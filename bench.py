@@ -208,7 +208,13 @@ def main():
                              '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dist = None
-    if world > 1:
+    force_dp = world == 1 and os.environ.get('RLREP_FORCE_DP') == '1'    # rehearsal: DP step forms over a one-rank RCCL group
+    if force_dp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('RLREP_DIST_BACKEND', 'nccl')      # 'gloo' lets two ranks share one GPU in tests
@@ -265,8 +271,8 @@ def main():
             'config': {'workload': args.workload, 'agent': alg, 'state_dim': S, 'action_dim': A, 'batch_per_gpu': B,
                        'global_batch': B * world, 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
-                       'parallelism': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)' if world > 1 else 'single GPU',
-                       'hipgraph': (bool(agent.use_graph) if world == 1 else ('segments between collectives' if agent.use_graph and agent.use_graph_dp else False)),
+                       'parallelism': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)' if (world > 1 or force_dp) else 'single GPU',
+                       'hipgraph': (bool(agent.use_graph) if not agent._dp else ('segments between collectives' if agent.use_graph and agent.use_graph_dp else False)),
                        # critic + actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (same updates, same order)
                        'deferred_critic_actor_branch': bool(getattr(agent, '_pipe', None))},
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),

@@ -155,6 +155,9 @@ class SACAgent(object):
         self._graph = None
         self._seg = None
         self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
+        # backward -> all-reduce -> apply form of every optimizer step.  RLREP_FORCE_DP=1 takes it with a one-rank process group too
+        # (sac / vlsac: rehearses the RCCL stream / graph-segment machinery on a single GPU; tests/test_dp.py)
+        self._dp = self.world_size > 1 or (self.ALG in ('sac', 'vlsac') and bool(int(os.environ.get('RLREP_FORCE_DP', '0'))))
         self._inject = None
         self._pool = None
         self._next_key = {}
@@ -240,7 +243,7 @@ class SACAgent(object):
         actor steps of this call may still be in flight when it returns; everything that looks at them waits (`flush()`), including
         reading the returned info dict -- which therefore has to be read before the NEXT train() call to describe THIS one."""
         self.steps += 1
-        if self.use_graph and self.world_size == 1:
+        if self.use_graph and not self._dp:
             if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
                 return self._train_graph_pipelined(buffer, batch_size)
             return self._train_graph(buffer, batch_size)
@@ -429,7 +432,7 @@ class SACAgent(object):
 
     def _body(self, buffer, B, g):
         """The whole train() as a sequence of stream-ordered library calls (captured into a hipGraph when g)."""
-        c, W = self.core, self.world_size
+        c, W = self.core, (2 if self._dp else 1)
         self._pool = None
         self._next_key = {}
         self._early_key = None

@@ -69,7 +69,7 @@ class VLSACAgent(SACAgent):
         c = self.core
         self._sample_into(buffer, B, f'f{i}', 0, g)
         eps = self._eps(f'feat{i}', (B, self.feature_dim), g)
-        if self.world_size > 1:
+        if self._dp:
             c.feature_backward(eps); self._allreduce(0); c.feature_apply()
         else:
             c.feature_step(eps)

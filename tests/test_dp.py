@@ -247,3 +247,60 @@ def test_hip_dp_pipelined_equals_sequential_dp():
     for k, v in out[True][1].items():
         assert np.array_equal(v, out[False][1][k]), f'pipelined != sequential at {k}'
     assert out[True][3] == out[False][3]
+
+
+def _gpu_rccl_worker(port, q, mode):
+    """mode: 'single' (no process group), 'dp' (sequential DP over a one-rank RCCL group), 'dp_pipe' (pipelined DP, same group)."""
+    from fixture_io import Case
+    from test_hip_parity import make_agent, make_buffer
+    try:
+        if mode != 'single':
+            os.environ['RLREP_FORCE_DP'] = '1'
+            os.environ['RLREP_PIPELINE_DP'] = '1' if mode == 'dp_pipe' else '0'
+            torch.cuda.set_device(0)
+            dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+        c = Case('vlsac_tiny')
+        agent = make_agent(c, seed=17)
+        agent.use_graph = True
+        buf = make_buffer(c)
+        for t in range(9):
+            info = agent.train(buf, c.B)
+            if t == 4:
+                agent.select_action(np.zeros(c.S, np.float32))
+        last = float(info['q1_loss'])
+        torch.cuda.synchronize()
+        form = 'pipe' if agent._pipe is not None else 'graph'
+        if mode == 'dp_pipe':
+            assert agent._pipe['mode'] == 3
+        if mode == 'dp':
+            assert sum(1 for k, _ in agent._graph if k == 'coll') == 6
+        st = {k: v.numpy() for k, v in agent.core.state().items()}
+        q.put((mode, st, last, form))
+        if mode != 'single':
+            dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((mode, traceback.format_exc(), None, None))
+
+
+@pytest.mark.gpu
+def test_hip_dp_over_rccl_one_rank_equals_single_gpu():
+    """The data-parallel train() forms (graph segments around eager all-reduces; and the two-stream pipelined one) run over the REAL
+    RCCL backend -- a one-rank group, the only RCCL configuration a one-GPU box allows -- and, the all-reduce being the identity there,
+    must end in exactly the single-GPU state.  Rehearses ProcessGroupNCCL's stream hand-offs, its watchdog thread beside hipGraph
+    capture, and the two issuing streams sharing one communicator."""
+    out = {}
+    ctx = mp.get_context('spawn')
+    for mode in ('single', 'dp', 'dp_pipe'):
+        q = ctx.Queue()
+        p = ctx.Process(target=_gpu_rccl_worker, args=(_free_port(), q, mode))
+        p.start()
+        res = q.get(timeout=280)
+        p.join(timeout=120)
+        assert isinstance(res[1], dict), res[1]
+        assert p.exitcode == 0
+        out[mode] = res
+    for mode in ('dp', 'dp_pipe'):
+        for k, v in out['single'][1].items():
+            assert np.array_equal(v, out[mode][1][k]), f'{mode} != single GPU at {k}'
+        assert out[mode][2] == out['single'][2]
