@@ -314,6 +314,12 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, i
 int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t rows, int32_t cols, int32_t inner, int32_t lda, int32_t ldb, int32_t ldc,
                         int32_t* engine, int32_t* tile, int32_t* splits, int32_t* kchunk, int32_t* scalar_sides);
 
+/* Host-only: the engine the builder picks for the vlsac noise critic's first layer (vlsac_agent.py:44-63) with `heads` heads in one
+ * launch -- *engine 0 = fp32 MFMA, 1 = bf16x3 (needs F % 32 == 0 and 16-byte rows; RLREP_NC_X3=0 turns it off) -- and its
+ * workgroup tile: *rows batch rows x *cols hidden units. */
+int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t batch, int32_t feature_dim, int32_t hidden_dim,
+                          int32_t* engine, int32_t* rows, int32_t* cols);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 

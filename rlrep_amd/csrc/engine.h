@@ -27,6 +27,7 @@ int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
 int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);
 int rl_nc_init();
 int rl_nc_fwd_cols();
+void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols);
 int rl_launch_fill_slot(const SlotFill* p, hipStream_t st);
 int rl_launch_philox(const PhiloxFill* p, hipStream_t st);
 int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st);

@@ -410,14 +410,15 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         // measured on MI355X (B=256, F=H=256): 4 batch rows per workgroup (4 waves per SIMD) beats 8 and 16 rows
         // (39.8 / 41.6 / 52.2 us for the 4-head launch): one wave per SIMD cannot keep the f32 MFMA pipe busy
         // behind the VALU that builds its operands.
-        int g2 = ((long long)tasks.size() * ((B + 3) / 4) * ((H + 63) / 64) <= 2048) ? 1 : 2;
-        if (getenv("RLREP_NC_G2")) g2 = atoi(getenv("RLREP_NC_G2"));
+        // (the bf16x3 engine, when the shapes allow it, takes 8 rows: rl_nc_fwd_plan)
+        int g2 = 1, engine = 0, cols = 128;
+        rl_nc_fwd_plan(tasks.data(), (int)tasks.size(), &engine, &g2, &cols);
         NcFwdBatch nb; memset(&nb, 0, sizeof(nb));
         int base_tile = 0;
-        nb.ntasks = (int)tasks.size();
+        nb.ntasks = (int)tasks.size(); nb.engine = engine; nb.cols = cols;
         for (size_t q = 0; q < tasks.size(); ++q) {
             NcFwdTask& t = tasks[q];
-            t.tiles_h = (H + rl_nc_fwd_cols() - 1) / rl_nc_fwd_cols(); t.ntiles = ((B + 4 * g2 - 1) / (4 * g2)) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles;
+            t.tiles_h = (H + cols - 1) / cols; t.ntiles = ((B + 4 * g2 - 1) / (4 * g2)) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles;
             nb.t[q] = t;
         }
         const int total = base_tile;
@@ -1188,6 +1189,18 @@ int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K
     if (splits) *splits = code ? sp : 1;
     if (kchunk) *kchunk = code ? kc : K;
     if (scalar_sides) *scalar_sides = code ? (((fl & FLAG_SCALAR_A) ? 1 : 0) | ((fl & FLAG_SCALAR_B) ? 2 : 0) | ((fl & FLAG_SCALAR_C) ? 4 : 0)) : 0;
+    return 0;
+}
+
+int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t B, int32_t F, int32_t H, int32_t* engine, int32_t* rows, int32_t* cols) {
+    if (heads <= 0 || heads > NC_MAX_TASKS || B <= 0 || F <= 0 || H <= 0 || !engine) { rl_set_error("nc_fwd_plan: bad argument"); return RLREP_ERR_ARG; }
+    NcFwdTask t[NC_MAX_TASKS]; memset(t, 0, sizeof(t));
+    for (int q = 0; q < heads; ++q) { t[q].B = B; t[q].F = F; t[q].H = H; t[q].N = 20; t[q].ld_ml = 2 * F; }
+    int e = 0, g2 = 1, c = 128;
+    rl_nc_fwd_plan(t, heads, &e, &g2, &c);
+    *engine = e;
+    if (rows) *rows = 4 * g2;
+    if (cols) *cols = c;
     return 0;
 }
 

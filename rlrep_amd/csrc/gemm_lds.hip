@@ -355,30 +355,13 @@ __global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GemmBatch gb) {
 // element) while the co-resident workgroup's waves hold the matrix pipe: one LDS buffer (three bf16 images per operand,
 // 80-byte rows: conflict-free 16-byte fragment reads), two barriers per 32-deep slice, two workgroups per CU.
 // ================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#include "x3.h"
 
 #ifndef X3_STAGGER
 #define X3_STAGGER 24                /* s_sleep units (64 cycles) */
 #endif
 #define X3_RSB 80                    /* image row stride in bytes: 32 bf16 + 16 bytes pad */
 #define X3_IMGB (128 * X3_RSB)       /* bytes per image */
-
-__device__ __forceinline__ unsigned x3_pk(float a, float b) {
-    const f32x2v v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
-}
-__device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = x3_pk(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
-    mid = x3_pk(r0, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
-    lo = x3_pk(s0, s1);
-}
 
 // 512 threads stage a 128 x 32 slice: every thread two row slots x four consecutive k (row-major operand) or four rows x
 // two consecutive k (k-major operand): e[slot][..]

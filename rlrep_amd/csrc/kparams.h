@@ -140,7 +140,7 @@ struct NcFwdTask {
 };
 
 #define NC_MAX_TASKS 4
-struct NcFwdBatch { int ntasks; NcFwdTask t[NC_MAX_TASKS]; };     // passed by value (kernarg)
+struct NcFwdBatch { int ntasks; int engine; int cols; NcFwdTask t[NC_MAX_TASKS]; };     // passed by value (kernarg)
 
 struct NcDwTask {
     const float* U; const float* GH; int ldgh;     // [B*N, H], [B, H]

@@ -19,8 +19,10 @@
 // Occupancy: f32 MFMA issues at 32 cycles/SIMD, so the kernels are MFMA-bound only if every SIMD always has
 // an MFMA ready.  Each kernel is shaped to put >= 2 waves on every SIMD of all 256 CUs and prefetches the
 // next step's operands into registers before issuing the current step's MFMAs.
+#include <type_traits>
 #include "common.h"
 #include "kparams.h"
+#include "x3.h"
 
 #define NC_NF 5          // N / 4 accumulator fragments per batch-row group (N = 20)
 
@@ -180,7 +182,221 @@ __global__ __launch_bounds__(64 * NW) void nc_fwd_kernel(NcFwdBatch nb) {
             for (int r = 0; r < 4; ++r) {
                 const float y = elu_fast(acc[g][f][r] + bj);
                 sum += y;
+#ifndef RL_NC_NOU
                 if (t.U) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
+#endif
+            }
+        t.Hm[(size_t)b * H + col] = sum * invN;
+    }
+    NCT(3); NCT(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward on the BF16 matrix pipe at fp32 accuracy (bf16x3, x3.h): v_mfma_f32_16x16x32_bf16 has the C/D map of the fp32
+// 16x16x4 instruction, so the row-mapping trick and the epilogue above carry over unchanged; six bf16 MFMAs of 16 cycles
+// replace eight fp32 MFMAs of 32 per 16 x 16 x 32 block (0.375x the matrix cycles).
+//
+// workgroup = NW waves = 8 batch rows x 20 noise rows x (16 NW) hidden units, K loop in steps of 32.
+// The operand x = mean + sigma * noise is generated AND split once per workgroup, not per wave (the split is ~5.5 VALU ops per
+// element and the matrix pipe only leaves two VALU issue slots per MFMA): thread (k chunk, batch row, noise group of 5) builds
+// its 5 x KV elements of the step, splits them and writes the three bf16 images [160 rows][32 k] (80-byte rows, fragment
+// order: rows (5g + f) 16 .. + 15 are fragment f of batch group g) into one of two LDS buffers; the waves read their A
+// fragments with ds_read_b128 (conflict-free) and split their own 16 x 32 W fragment in registers.  Global operands of step
+// s + 2 are loaded into registers while step s is multiplied; one barrier per step.
+// ------------------------------------------------------------------------------------------------
+#define NX_RSB 80
+#define NX_ROWS 160
+#define NX_IMGB (NX_ROWS * NX_RSB)
+#define NX_BUFB (3 * NX_IMGB)
+
+// LDS fragment reads as inline asm: hipcc otherwise keeps ONE register set per operand image and puts s_waitcnt lgkmcnt(0) between
+// every ds_read and the MFMA that uses it (it re-sinks explicit prefetches, and sched_group_barrier pipelines came out scrambled).
+// The reads of fragment j + 1 are issued, then `s_waitcnt lgkmcnt(3)` claims fragment j (LDS returns in order: at most the three
+// newest reads are still in flight); compiler-issued LDS traffic in between only makes the wait more conservative.
+template <int OFF> __device__ __forceinline__ void nx_read(u32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int J> __device__ __forceinline__ void nx_fload(u32x4 (&d)[3], unsigned addr) {
+    nx_read<J * 16 * NX_RSB>(d[0], addr);
+    nx_read<J * 16 * NX_RSB + NX_IMGB>(d[1], addr);
+    nx_read<J * 16 * NX_RSB + 2 * NX_IMGB>(d[2], addr);
+}
+template <int PENDING> __device__ __forceinline__ void nx_claim(u32x4 (&d)[3]) {
+    if (PENDING) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
+}
+
+template <int KV> struct NxVec;
+template <> struct NxVec<4> { typedef f32x4 T; };
+template <> struct NxVec<2> { typedef f32x2v T; };
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void nc_fwd_x3_kernel(NcFwdBatch nb) {
+    constexpr int NT = 64 * NW, KV = 1024 / NT, NKC = 32 / KV, G2 = 2;
+    typedef typename NxVec<KV>::T vec_t;
+    unsigned char* const L = reinterpret_cast<unsigned char*>(nc_smem);
+    const int bid = blockIdx.x;
+    NCT(0); NCT(4);
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < NC_MAX_TASKS; ++q) if (q < nb.ntasks && bid >= nb.t[q].tile_base) ti = q;
+    const NcFwdTask& t = nb.t[ti];
+    const int local = bid - t.tile_base;
+    const int tb = local / t.tiles_h, th = local - tb * t.tiles_h;
+    const int b0 = tb * 8, n0 = th * (16 * NW);
+    const int F = t.F, H = t.H, N = t.N;
+    const int S = F >> 5;                                   // K steps (F % 32 == 0, checked by the launcher)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m16 = lane & 15, kq = lane >> 4;
+
+    // ---- producer role ----
+    const int kc = tid % NKC, pb = (tid / NKC) & 7, ng = tid / (NKC * 8);
+    const bool okb = b0 + pb < t.B;
+    const int bsrc = min(b0 + pb, t.B - 1);
+    const float* const pmu = t.mean + (size_t)bsrc * t.ld_ml + kc * KV;
+    const float* const pls = t.lstd + (size_t)bsrc * t.ld_ml + kc * KV;
+    const float* const pnz = t.noise + (size_t)(5 * ng) * F + kc * KV;
+    int wofs[5];                                            // byte offset of this thread's chunk in an image, per noise row
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int n = 5 * ng + i;
+        wofs[i] = (((pb >> 2) * 5 + (n >> 2)) * 16 + (pb & 3) * 4 + (n & 3)) * NX_RSB + kc * KV * 2;
+    }
+    float* const sig_dst = (t.sigma_out && th == 0 && ng == 0 && okb) ? t.sigma_out + (size_t)(b0 + pb) * F + kc * KV : nullptr;
+
+    // ---- consumer role ----
+    const int col = n0 + 16 * w + m16;
+    const bool colok = col < H;
+    const float* const wrow = t.W + (size_t)min(col, H - 1) * F + 8 * kq;
+    const int aofs = m16 * NX_RSB + kq * 16;
+
+    // (a second register set for these, loaded at the START of step s for step s + 2, measured slower: 30.9k vs 26.7k cycles for
+    // the eight steps -- the step is bound by vector-instruction issue, not by the latency of these loads)
+    vec_t rmu, rls, rnz[5];
+    f32x4 rw0, rw1;
+    auto gload = [&](int s) {
+        const int k = 32 * s;
+        rmu = *reinterpret_cast<const vec_t*>(pmu + k);
+        rls = *reinterpret_cast<const vec_t*>(pls + k);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) rnz[i] = *reinterpret_cast<const vec_t*>(pnz + (size_t)i * F + k);
+    };
+    auto wload = [&](int s) {
+        rw0 = *reinterpret_cast<const f32x4*>(wrow + 32 * s);
+        rw1 = *reinterpret_cast<const f32x4*>(wrow + 32 * s + 4);
+    };
+    float sg[KV];
+    auto produce_begin = [&]() {
+#pragma unroll
+        for (int q = 0; q < KV; ++q) sg[q] = okb ? __expf(clamp_lstd(rls[q])) : 0.f;
+    };
+    auto produce_row = [&](int i, unsigned char* buf) {
+        unsigned h[KV / 2], m[KV / 2], l[KV / 2];
+#pragma unroll
+        for (int q = 0; q < KV / 2; ++q) {
+            const float x0 = okb ? fmaf(sg[2 * q], rnz[i][2 * q], rmu[2 * q]) : 0.f;
+            const float x1 = okb ? fmaf(sg[2 * q + 1], rnz[i][2 * q + 1], rmu[2 * q + 1]) : 0.f;
+            x3_split2(x0, x1, h[q], m[q], l[q]);
+        }
+        unsigned char* p = buf + wofs[i];
+        if (KV == 4) {
+            *reinterpret_cast<u32x2*>(p) = (u32x2){h[0], h[KV / 2 - 1]};
+            *reinterpret_cast<u32x2*>(p + NX_IMGB) = (u32x2){m[0], m[KV / 2 - 1]};
+            *reinterpret_cast<u32x2*>(p + 2 * NX_IMGB) = (u32x2){l[0], l[KV / 2 - 1]};
+        } else {
+            *reinterpret_cast<unsigned*>(p) = h[0];
+            *reinterpret_cast<unsigned*>(p + NX_IMGB) = m[0];
+            *reinterpret_cast<unsigned*>(p + 2 * NX_IMGB) = l[0];
+        }
+    };
+
+    f32x4 acc[G2][NC_NF];
+#pragma unroll
+    for (int g = 0; g < G2; ++g)
+#pragma unroll
+        for (int f = 0; f < NC_NF; ++f) acc[g][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)aofs;
+
+    // One K step.  MORE = not the last step: the producer half (images of step s + 1, one noise row per two fragments; global
+    // operands of step s + 2) is interleaved with the fragments in program order.
+    auto step = [&](int s, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const unsigned aaddr = lds0 + (unsigned)((s & 1) * NX_BUFB);
+        unsigned char* const nxt = L + ((s + 1) & 1) * NX_BUFB;
+        u32x4 fa[2][3];
+        nx_fload<0>(fa[0], aaddr);
+        u32x4 bh, bm, bl;
+        {
+            unsigned h, m, l;
+            x3_split2(rw0[0], rw0[1], h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
+            x3_split2(rw0[2], rw0[3], h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
+            x3_split2(rw1[0], rw1[1], h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
+            x3_split2(rw1[2], rw1[3], h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
+        }
+        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
+        if (MORE) { wload(s + 1); produce_begin(); }
+#define NX_FRAG(J)                                                                                                     \
+        {                                                                                                              \
+            if ((J) + 1 < G2 * NC_NF) nx_fload<((J) + 1 < G2 * NC_NF ? (J) + 1 : 0)>(fa[((J) + 1) & 1], aaddr);        \
+            if (MORE && ((J) & 1) == 0) produce_row((J) >> 1, nxt);                                                    \
+            nx_claim<((J) + 1 < G2 * NC_NF)>(fa[(J) & 1]);                                                             \
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[(J) & 1][0]), Am = __builtin_bit_cast(bf16x8, fa[(J) & 1][1]), \
+                         Al = __builtin_bit_cast(bf16x8, fa[(J) & 1][2]);                                              \
+            f32x4 c = acc[(J) / NC_NF][(J) % NC_NF];                                                                   \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);                                           \
+            acc[(J) / NC_NF][(J) % NC_NF] = c;                                                                         \
+        }
+        NX_FRAG(0) NX_FRAG(1) NX_FRAG(2) NX_FRAG(3) NX_FRAG(4) NX_FRAG(5) NX_FRAG(6) NX_FRAG(7) NX_FRAG(8) NX_FRAG(9)
+#undef NX_FRAG
+        if (MORE) gload(min(s + 2, S - 1));                 // (the last one re-reads step S - 1: no branch)
+        __syncthreads();
+    };
+
+    gload(0); wload(0);
+    produce_begin();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) produce_row(i, L);
+    gload(S > 1 ? 1 : 0);
+    __syncthreads();
+    NCT(1);
+    for (int s = 0; s + 1 < S; ++s) step(s, std::true_type{});
+    step(S - 1, std::false_type{});
+    NCT(2);
+
+    if (sig_dst) {          // exp(clamp(log_std)) for the backward passes: one thread group of column tile 0 per batch row
+        for (int s = 0; s < S; ++s) {
+            const vec_t ls = *reinterpret_cast<const vec_t*>(pls + 32 * s);
+            vec_t o;
+#pragma unroll
+            for (int q = 0; q < KV; ++q) o[q] = expf(clamp_lstd(ls[q]));
+            *reinterpret_cast<vec_t*>(sig_dst + 32 * s) = o;
+        }
+    }
+
+    if (!colok) return;
+    const float bj = t.bias[col];
+    const float invN = 1.0f / (float)N;
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+        const int b = b0 + 4 * g + (lane >> 4);
+        if (b >= t.B) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int f = 0; f < NC_NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = elu_fast(acc[g][f][r] + bj);
+                sum += y;
+#ifndef RL_NC_NOU
+                if (t.U) t.U[((size_t)b * N + 4 * f + r) * H + col] = y;
+#endif
             }
         t.Hm[(size_t)b * H + col] = sum * invN;
     }
@@ -594,13 +810,43 @@ extern "C" int rl_nc_fwd_cols() {
     static const int v = [] { const char* e = getenv("RLREP_NC_COLS"); const int x = e ? atoi(e) : 128; return x == 64 ? 64 : 128; }();
     return v;
 }
+// Tiling of one nc_fwd launch: engine (0 fp32 MFMA, 1 bf16x3), batch-row groups per workgroup (g2, 4 rows each) and hidden
+// units per workgroup.  bf16x3 needs 32-deep K steps and 16-byte rows everywhere; RLREP_NC_X3=0 (or RLREP_NO_X3) keeps fp32.
+extern "C" void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols) {
+    const int B = tasks[0].B, F = tasks[0].F, H = tasks[0].H;
+    const char* ex = getenv("RLREP_NC_X3");                 // read per plan (agent construction), so a test can flip it
+    const bool want_x3 = (ex ? atoi(ex) != 0 : true) && !getenv("RLREP_NO_X3");
+    bool x3 = want_x3 && (F % 32) == 0 && F >= 64;
+    for (int q = 0; q < ntasks; ++q) {
+        const NcFwdTask& t = tasks[q];
+        x3 = x3 && t.N == 4 * NC_NF && (t.ld_ml & 3) == 0 && t.F == F && t.H == H && t.B == B &&
+             ((((uintptr_t)t.mean) | ((uintptr_t)t.lstd) | ((uintptr_t)t.noise) | ((uintptr_t)t.W) | ((uintptr_t)t.sigma_out)) & 15) == 0;
+    }
+    if (x3) {
+        *engine = 1; *g2 = 2;
+        const long long wg128 = (long long)ntasks * ((B + 7) / 8) * ((H + 127) / 128);
+        const char* e = getenv("RLREP_NC_X3_COLS");
+        *cols = e ? (atoi(e) == 64 ? 64 : 128) : (wg128 >= 256 ? 128 : 64);
+        return;
+    }
+    *engine = 0;
+    *cols = rl_nc_fwd_cols();
+    *g2 = ((long long)ntasks * ((B + 3) / 4) * ((H + 63) / 64) <= 2048) ? 1 : 2;
+    if (getenv("RLREP_NC_G2")) *g2 = atoi(getenv("RLREP_NC_G2"));
+}
 extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     for (int q = 0; q < nb->ntasks; ++q) if (nb->t[q].N != 4 * NC_NF) return -2;      // the row mapping is built for N = 20
     const int F = nb->t[0].F, N = nb->t[0].N;
+    if (nb->engine == 1) {
+        if ((F % 32) != 0 || g2 != 2) return -3;
+        if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
+        else hipLaunchKernelGGL((nc_fwd_x3_kernel<4>), dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
+        return (int)hipGetLastError();
+    }
     const int Fp = (F + 15) & ~15;
     const size_t lds = (size_t)(8 * g2 + N) * (Fp + 16) * sizeof(float);
-    const int nw = rl_nc_fwd_cols() / 16;
+    const int nw = nb->cols / 16;
     if (nw == 8) {
         if (g2 == 1) hipLaunchKernelGGL((nc_fwd_kernel<1, 8>), dim3(total_tiles), dim3(512), lds, st, *nb);
         else if (g2 == 2) hipLaunchKernelGGL((nc_fwd_kernel<2, 8>), dim3(total_tiles), dim3(512), lds, st, *nb);
@@ -627,6 +873,9 @@ extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
 // one-time setup (agent creation, never inside a stream capture): nc_dw needs more dynamic LDS than the 64 KB default
 extern "C" int rl_nc_init() {
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute((const void*)nc_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 

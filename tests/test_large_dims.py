@@ -45,6 +45,9 @@ def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=())
     init = synth.init_like(param_shapes(alg, S, A, **kw), seed=99)
     _retie(alg, init)
     init['log_alpha'] = np.log(np.float64(0.1))
+    if alg == 'vlsac':
+        init['critic.noise'] = np.random.RandomState(5).standard_normal(init['critic.noise'].shape).astype(np.float32)   # N(0,1) buffer
+        init['critic_target.noise'] = init['critic.noise'].copy()                       # quirk Q3: same buffer in both copies
     agent = cls(state_dim=S, action_dim=A, action_space=_Space(A), max_batch=B, graph=False, **kw)
     if alg == 'diffsrsac':
         init['noise_alphabars'] = agent.core.state()['noise_alphabars'].numpy().copy()
@@ -65,6 +68,8 @@ def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=())
     for t in range(trains):
         idx = [rs.randint(0, replay_n, size=B) for _ in range(o.n_batches())]
         eps = []
+        if alg == 'vlsac':
+            eps = [rs.standard_normal((B, kw['feature_dim'])).astype(np.float32) for _ in range(nf)]
         if alg == 'diffsrsac':
             for _ in range(nf):
                 eps += [rs.randint(0, 1000, size=B), (0.449 * rs.standard_normal((B, S))).astype(np.float32)]
@@ -113,6 +118,35 @@ def test_large_engines_off_gives_the_same_step(monkeypatch):
             monkeypatch.setenv('RLREP_NO_GEMM_LDS', '1')
         a = _run('ctrlsac', ('rlrep_amd.agent.ctrlsac.ctrlsac_agent', 'CTRLSACAgent'), 17, 6, 128,
                  dict(hidden_dim=512, feature_dim=1024, extra_feature_steps=0))
+        outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})
+    for k in outs[0]:
+        assert rel_l2(outs[0][k], outs[1][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize('S,A,B,F,H', [(17, 6, 256, 256, 256), (11, 3, 100, 96, 72), (9, 2, 37, 64, 40)])
+def test_vlsac_noise_critic_first_layer_on_bf16x3(S, A, B, F, H, monkeypatch):
+    """vlsac at dimensions whose noise-critic first layer (vlsac_agent.py:44-63; 63 % of a train()'s FLOPs) runs on the bf16x3
+    engine (noisecritic.hip nc_fwd_x3_kernel): the headline shape, and ragged ones -- batch not a multiple of the 8-row tile,
+    hidden width not a multiple of 16, three and two K steps -- against the CPU oracle, two train() calls each."""
+    import ctypes as C
+    from rlrep_amd import _lib
+    monkeypatch.delenv('RLREP_NC_X3', raising=False)
+    out = [C.c_int32() for _ in range(3)]
+    assert _lib.lib.rlrep_nc_fwd_plan(2, B, F, H, *[C.byref(o) for o in out]) == 0 and out[0].value == 1
+    _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), S, A, B,
+         dict(hidden_dim=H, feature_dim=F, extra_feature_steps=1), trains=2)
+
+
+def test_vlsac_noise_critic_engines_agree(monkeypatch):
+    """RLREP_NC_X3=0 keeps the first layer on fp32 MFMA: the same two train() calls end within fp32 rounding of the bf16x3 run."""
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('RLREP_NC_X3', '0')
+        else:
+            monkeypatch.delenv('RLREP_NC_X3', raising=False)
+        a = _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), 17, 6, 128,
+                 dict(hidden_dim=128, feature_dim=128, extra_feature_steps=0), trains=2)
         outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})
     for k in outs[0]:
         assert rel_l2(outs[0][k], outs[1][k]) < 1e-5, k
