@@ -98,11 +98,24 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 4 * 2.0 * (B * 20) * F * H          # algorithmic: 4 heads x 2*M*K*N
     achieved = flops / (us * 1e-6) / 1e12
-    return {'bound': 'mfma', 'kernel': 'nc_fwd_kernel (critic step, 4 heads)', 'achieved': round(achieved, 2),
-            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
-            # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)
-            'traffic': NC_FWD_TRAFFIC_BYTES, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
+    import ctypes as C
+    from rlrep_amd import _lib
+    plan = [C.c_int32() for _ in range(3)]
+    _lib.lib.rlrep_nc_fwd_plan(4, B, F, H, *[C.byref(o) for o in plan])
+    x3 = plan[0].value == 1
+    # bf16x3 engine: six bf16 MFMA flops are executed per algorithmic fp32 flop, so the ceiling for ALGORITHMIC flops is the dense
+    # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NC_X3=0) it is the fp32 MFMA peak
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
+    out = {'bound': 'mfma', 'kernel': ('nc_fwd_x3_kernel<%d> (critic step, 4 heads, bf16x3)' % (plan[2].value // 16)) if x3 else 'nc_fwd_kernel (critic step, 4 heads)',
+           'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+           # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
+           # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)
+           'traffic': NC_FWD_TRAFFIC_BYTES, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
+    if x3:
+        out['note'] = 'achieved = algorithmic fp32 flops / time; peak = dense bf16 MFMA peak (2500 TF) / 6 executed flops per product'
+        out['executed_bf16_tflops'] = round(6 * achieved, 1)
+        out['vs_fp32_mfma_peak'] = round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)
+    return out
 
 
 def big_gemm_roofline(agent, B, S, F, Hn, reps=20):

@@ -225,6 +225,11 @@ template <int PENDING> __device__ __forceinline__ void nx_claim(u32x4 (&d)[3]) {
     if (PENDING) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
 }
+// claim a fragment while NEWER reads (a multiple of three, at most 12) are still in flight
+template <int NEWER> __device__ __forceinline__ void nx_claim_n(u32x4 (&d)[3]) {
+    static_assert(NEWER >= 0 && NEWER <= 12 && NEWER % 3 == 0, "reads in flight behind the claimed fragment");
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "n"(NEWER));
+}
 
 template <int KV> struct NxVec;
 template <> struct NxVec<4> { typedef f32x4 T; };
@@ -597,6 +602,196 @@ __global__ __launch_bounds__(512) void nc_dx_kernel(NcDxTask t) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dL/d(mean, log_std) on the BF16 matrix pipe at fp32 accuracy (bf16x3): the same tile as nc_dx_kernel (4 batch rows x 20 noise
+// rows x 64 feature columns, one wave per 16 columns) with the machinery of nc_fwd_x3_kernel: the A operand
+// dPre[(b,n), j] = GH[b,j]/N * elu'(U[(b,n), j]) is generated and split ONCE per workgroup into three bf16 images [80 rows][32 j]
+// in LDS (two buffers, one barrier per 32-deep step), the waves read their fragments with pipelined inline-asm ds_read_b128 and
+// split their own 32 x 16 W fragment in registers.  The inner loop runs over BOTH heads (K = nheads * H), so no partial sums
+// cross waves: the epilogue is the in-register reduction over the noise rows.  Needs H % 32 == 0 and 8-byte rows.
+// ------------------------------------------------------------------------------------------------
+#define NDX_ROWS 80
+#define NDX_IMGB (NDX_ROWS * NX_RSB)
+#define NDX_BUFB (3 * NDX_IMGB)
+
+template <int OFF> __device__ __forceinline__ void ndx_fload_at(u32x4 (&d)[3], unsigned addr) {
+    nx_read<OFF>(d[0], addr); nx_read<OFF + NDX_IMGB>(d[1], addr); nx_read<OFF + 2 * NDX_IMGB>(d[2], addr);
+}
+
+__global__ __launch_bounds__(512) void nc_dx_x3_kernel(NcDxTask t) {
+    // 8 waves, two roles: waves 0-3 CONSUME (split their W fragment, read the A fragments, 30 MFMAs per step, epilogue), waves 4-7
+    // PRODUCE (stream U and GH, build and split dPre, write the images of the next step).  With one workgroup per CU that puts one
+    // wave of each role on every SIMD: the producer's vector work runs in the shadow of the consumer's MFMAs (as one role per wave,
+    // 256 threads, the step was their SUM: 2.0k cycles for 480 of MFMA).
+    __shared__ __attribute__((aligned(16))) unsigned char L[2 * NDX_BUFB];      // 38.4 KB
+    int bid = blockIdx.x;
+    NCT(0); NCT(4);
+    {   // XCD-aware tile order (as nc_dx_kernel): the column tiles of one batch tile read the same rows of U
+        const int ntb = t.ntiles / t.tiles_k;
+        if ((ntb & 7) == 0) {
+            const int x = bid & 7, y = bid >> 3;
+            bid = ((y / t.tiles_k) * 8 + x) * t.tiles_k + (y % t.tiles_k);
+        }
+    }
+    const int tb = bid / t.tiles_k, tk = bid - tb * t.tiles_k;
+    const int b0 = tb * 4, kc0 = tk * 64;
+    const int F = t.F, H = t.H, N = t.N;
+    const int SH = H >> 5;                                  // 32-deep steps per head
+    const int S = SH * t.nheads;
+    const int w8 = threadIdx.x >> 6;
+
+    if (w8 >= 4) {
+        // ================= producer: thread = (j pair jc, batch row pb, noise group ng of 5 rows) =================
+        const int tid = threadIdx.x - 256;
+        const int jc = tid & 15, pb = tid >> 6, ng = (tid >> 4) & 3;
+        const bool okb = b0 + pb < t.B;
+        const int bsrc = min(b0 + pb, t.B - 1);
+        const size_t urow = ((size_t)bsrc * N + 5 * ng) * H + 2 * jc;
+        const size_t grow = (size_t)bsrc * t.ldgh + 2 * jc;
+        const float m = okb ? 1.0f / (float)N : 0.f;
+        int wofs[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int n = 5 * ng + i;
+            wofs[i] = ((n >> 2) * 16 + pb * 4 + (n & 3)) * NX_RSB + jc * 4;
+        }
+        struct PReg { f32x2v u[5], g; };
+        auto gload = [&](int s, PReg& r) {
+            s = min(s, S - 1);                              // past the end: re-read the last step (no branch), never produced
+            const int h = s >= SH ? 1 : 0, j0 = 32 * (s - h * SH);
+            const float* up = (h ? t.U[1] : t.U[0]) + urow + j0;
+            const float* gp = (h ? t.GH[1] : t.GH[0]) + grow + j0;
+            r.g = *reinterpret_cast<const f32x2v*>(gp);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) r.u[i] = *reinterpret_cast<const f32x2v*>(up + (size_t)i * H);
+        };
+        auto produce = [&](const PReg& r, unsigned char* buf) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float a0 = (r.g[0] * m) * fminf(r.u[i][0] + 1.f, 1.f);      // elu'(out) = min(out + 1, 1)
+                const float a1 = (r.g[1] * m) * fminf(r.u[i][1] + 1.f, 1.f);
+                unsigned h, md, l;
+                x3_split2(a0, a1, h, md, l);
+                unsigned char* p = buf + wofs[i];
+                *reinterpret_cast<unsigned*>(p) = h;
+                *reinterpret_cast<unsigned*>(p + NDX_IMGB) = md;
+                *reinterpret_cast<unsigned*>(p + 2 * NDX_IMGB) = l;
+            }
+        };
+        // two named register sets, loads two steps ahead of their use.  (Four sets / four steps ahead measured the same: the step is
+        // bound by vector-instruction ISSUE on the SIMD the two roles share -- consumer 460 cycles of W split + 240 of MFMA issue,
+        // producer ~500 -- not by the latency of U; tools/exp/nc_timeline.py.)
+        PReg ra, rb;
+        gload(0, ra); gload(1, rb);
+        produce(ra, L);
+        gload(2, ra);
+        __syncthreads();
+        for (int s = 0; s < S; s += 2) {
+            if (s + 1 < S) produce(rb, L + NDX_BUFB);       // images of step s + 1
+            gload(s + 3, rb);
+            __syncthreads();
+            if (s + 1 < S) {
+                if (s + 2 < S) produce(ra, L);              // images of step s + 2
+                gload(s + 4, ra);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ================= consumer =================
+    const int lane = threadIdx.x & 63, w = w8;
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int kcol = kc0 + 16 * w + m16;
+    const bool colok = kcol < F;
+    const int kcl = colok ? kcol : 0;
+    const int aofs = m16 * NX_RSB + kq * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)aofs;
+    struct WReg { float v[8]; };
+    auto wload = [&](int s, WReg& r) {
+        s = min(s, S - 1);
+        const int h = s >= SH ? 1 : 0, j0 = 32 * (s - h * SH);
+        const float* wp = (h ? t.W[1] : t.W[0]) + (size_t)(j0 + 8 * kq) * F + kcl;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r.v[q] = wp[(size_t)q * F];
+    };
+    // epilogue operands (this lane's noise column and log-std): volatile asm loads, older than every load of the loop
+    float nzv[20], lsv;
+    {
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
+            const float* p = t.noise + (size_t)min(q, N - 1) * F + kcl;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(nzv[q]) : "v"(p));
+        }
+        const float* p = t.lstd + (size_t)min(b0 + (lane >> 4), t.B - 1) * t.ld_l + kcl;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lsv) : "v"(p));
+    }
+    f32x4 acc[NC_NF];
+#pragma unroll
+    for (int f = 0; f < NC_NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    WReg wa, wb;                                            // W fragments of steps s and s + 1; refilled two steps ahead
+    wload(0, wa); wload(1, wb);
+    __syncthreads();
+    NCT(1);
+    auto cstep = [&](int s, WReg& rw) {
+        const unsigned aaddr = lds0 + (unsigned)((s & 1) * NDX_BUFB);
+        // two register sets, one fragment ahead (all five fragments in flight at the step start measured slower: 1.8k vs 1.5k cycles)
+        u32x4 fa[2][3];
+        ndx_fload_at<0>(fa[0], aaddr);
+        u32x4 bh, bm, bl;
+        {
+            unsigned h, m, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { x3_split2(rw.v[2 * q], rw.v[2 * q + 1], h, m, l); bh[q] = h; bm[q] = m; bl[q] = l; }
+        }
+        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
+        wload(s + 2, rw);
+#define NDX_FRAG(J)                                                                                                    \
+        {                                                                                                              \
+            if ((J) + 1 < NC_NF) ndx_fload_at<((J) + 1 < NC_NF ? (J) + 1 : 0) * 16 * NX_RSB>(fa[((J) + 1) & 1], aaddr); \
+            nx_claim<((J) + 1 < NC_NF)>(fa[(J) & 1]);                                                                  \
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[(J) & 1][0]), Am = __builtin_bit_cast(bf16x8, fa[(J) & 1][1]), \
+                         Al = __builtin_bit_cast(bf16x8, fa[(J) & 1][2]);                                              \
+            f32x4 c = acc[(J)];                                                                                        \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);                                           \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);                                           \
+            acc[(J)] = c;                                                                                              \
+        }
+        NDX_FRAG(0) NDX_FRAG(1) NDX_FRAG(2) NDX_FRAG(3) NDX_FRAG(4)
+#undef NDX_FRAG
+        __syncthreads();
+    };
+    for (int s = 0; s < S; s += 2) {
+        cstep(s, wa);
+        if (s + 1 < S) cstep(s + 1, wb);
+    }
+
+    NCT(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // claim the epilogue operands fetched in the prologue
+#pragma unroll
+    for (int q = 0; q < 20; ++q) asm volatile("" : "+v"(nzv[q]));
+    asm volatile("" : "+v"(lsv));
+    if (!colok) return;
+    const int bo = b0 + (lane >> 4);
+    if (bo >= t.B) return;
+    float dmu = 0.f, dls = 0.f;
+#pragma unroll
+    for (int f = 0; f < NC_NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[f][r];
+            dmu += v;
+            dls = fmaf(v, nzv[4 * f + r], dls);
+        }
+    t.G[(size_t)bo * t.ldg + kcol] = dmu;
+    t.G[(size_t)bo * t.ldg + F + kcol] = dls * expf(clamp_lstd(lsv)) * lstd_mask(lsv);
+    NCT(3); NCT(5);
+}
+
+// ------------------------------------------------------------------------------------------------
 // dL/dW[j,k] = sum_{(b,n)} dPre[(b,n), j] * x[(b,n), k],   dL/dbias[j] = sum dPre[(b,n), j]
 //   dPre[(b,n), j] = GH[b,j]/N * elu'(U[(b,n), j])
 // workgroup = 8 waves sharing one 16(j) x 32(k) output tile; the 20*B inner rows are dealt to the waves in
@@ -859,12 +1054,24 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     return (int)hipGetLastError();
 }
 
+// engine of the dX launch: 1 = bf16x3 (H % 32 == 0, even row strides, 8-byte aligned U / GH; RLREP_NC_X3=0 keeps fp32 MFMA)
+extern "C" int rl_nc_dx_engine(const NcDxTask* t) {
+    const char* ex = getenv("RLREP_NC_X3");
+    if ((ex && atoi(ex) == 0) || getenv("RLREP_NO_X3")) return 0;
+    if (t->N != 4 * NC_NF || (t->H % 32) != 0 || (t->ldgh & 1) || t->nheads < 1 || t->nheads > 2 || t->tiles_k != (t->F + 63) / 64) return 0;
+    for (int h = 0; h < t->nheads; ++h) if (((((uintptr_t)t->U[h]) | ((uintptr_t)t->GH[h])) & 7) != 0) return 0;
+    return 1;
+}
 extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
     if (t->ntiles <= 0) return 0;
     if (t->N != 4 * NC_NF) return -2;
     // 16-byte loads of U / GH rows need 4-float-aligned rows in every head
     bool vec = ((t->H & 3) == 0) && ((t->ldgh & 3) == 0);
     for (int h = 0; h < t->nheads; ++h) vec = vec && ((((uintptr_t)t->U[h]) | ((uintptr_t)t->GH[h])) & 15) == 0;
+    if (rl_nc_dx_engine(t) == 1) {
+        hipLaunchKernelGGL(nc_dx_x3_kernel, dim3(t->ntiles), dim3(512), 0, st, *t);
+        return (int)hipGetLastError();
+    }
     if (vec) hipLaunchKernelGGL(nc_dx_kernel<true>, dim3(t->ntiles), dim3(512), 0, st, *t);
     else hipLaunchKernelGGL(nc_dx_kernel<false>, dim3(t->ntiles), dim3(512), 0, st, *t);
     return (int)hipGetLastError();

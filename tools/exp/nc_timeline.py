@@ -14,10 +14,11 @@ buf, _ = bench.synth_buffer(S, A, 0)
 for _ in range(5):
     agent.train(buf, B)
 core = agent.core
-names = core.stages(2)
-s = [i for i, n in enumerate(names) if n.startswith('noise critic l1/l4')][0]
+PROG = int(os.environ.get('NCT_PROG', '2')); PREFIX = os.environ.get('NCT_STAGE', 'noise critic l1/l4')     # e.g. NCT_PROG=4 NCT_STAGE='noise critic dX'
+names = core.stages(PROG)
+s = [i for i, n in enumerate(names) if n.startswith(PREFIX)][0]
 for _ in range(5):
-    core.run_stage(2, s)
+    core.run_stage(PROG, s)
 torch.cuda.synchronize()
 n = 6 * 4096
 host = (C.c_ulonglong * n)()
