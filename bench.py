@@ -106,7 +106,7 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     # bf16x3 engine: six bf16 MFMA flops are executed per algorithmic fp32 flop, so the ceiling for ALGORITHMIC flops is the dense
     # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NC_X3=0) it is the fp32 MFMA peak
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-    out = {'bound': 'mfma', 'kernel': ('nc_fwd_x3_kernel<%d> (critic step, 4 heads, bf16x3)' % (plan[2].value // 16)) if x3 else 'nc_fwd_kernel (critic step, 4 heads)',
+    out = {'bound': 'mfma', 'kernel': ('nc_fwd_x3_kernel<%d> (critic step, 4 heads, bf16x3)' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel (critic step, 4 heads)',
            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
            # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
            # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)

@@ -153,7 +153,7 @@ struct NcDwTask {
     float* ad_p; float* ad_m; float* ad_v; float* ad_pb; float* ad_mb; float* ad_vb;
     const GroupCfg* ad_grp;
 };
-struct NcDwBatch { int ntasks; NcDwTask t[2]; };
+struct NcDwBatch { int ntasks; int lean; NcDwTask t[2]; };      // lean: the 128-VGPR variant (launch beside the feature chain)
 
 struct NcDxTask {
     const float* GH[2]; int ldgh;    // dL/dHm per head [B, H]

@@ -196,13 +196,12 @@ __global__ __launch_bounds__(64 * NW) void nc_fwd_kernel(NcFwdBatch nb) {
 // 16x16x4 instruction, so the row-mapping trick and the epilogue above carry over unchanged; six bf16 MFMAs of 16 cycles
 // replace eight fp32 MFMAs of 32 per 16 x 16 x 32 block (0.375x the matrix cycles).
 //
-// workgroup = NW waves = 8 batch rows x 20 noise rows x (16 NW) hidden units, K loop in steps of 32.
+// workgroup = 8 batch rows x 20 noise rows x 64 or 128 hidden units, K loop in steps of 32.
 // The operand x = mean + sigma * noise is generated AND split once per workgroup, not per wave (the split is ~5.5 VALU ops per
-// element and the matrix pipe only leaves two VALU issue slots per MFMA): thread (k chunk, batch row, noise group of 5) builds
-// its 5 x KV elements of the step, splits them and writes the three bf16 images [160 rows][32 k] (80-byte rows, fragment
-// order: rows (5g + f) 16 .. + 15 are fragment f of batch group g) into one of two LDS buffers; the waves read their A
-// fragments with ds_read_b128 (conflict-free) and split their own 16 x 32 W fragment in registers.  Global operands of step
-// s + 2 are loaded into registers while step s is multiplied; one barrier per step.
+// element and the matrix pipe only leaves two VALU issue slots per MFMA): the three bf16 images [160 rows][32 k] of a step
+// (80-byte rows, fragment order: rows (5g + f) 16 .. + 15 are fragment f of batch group g) live in one of two LDS buffers; the
+// consuming waves read their A fragments with ds_read_b128 and split their own 16 x 32 W fragments in registers; one barrier
+// per step.
 // ------------------------------------------------------------------------------------------------
 #define NX_RSB 80
 #define NX_ROWS 160
@@ -235,8 +234,207 @@ template <int KV> struct NxVec;
 template <> struct NxVec<4> { typedef f32x4 T; };
 template <> struct NxVec<2> { typedef f32x2v T; };
 
+// CG = 16-column groups per consumer wave (1: 64 hidden units per workgroup, 2: 128).  8 waves in two roles, one of each on every SIMD:
+//   waves 0-3 CONSUME: split their CG W fragments, read the ten A fragments (two register sets, one fragment ahead), 60 CG MFMAs per
+//              step, ELU / mean-over-noise epilogue;
+//   waves 4-7 PRODUCE: thread (k chunk of 4, batch row, noise group of 5) builds and splits its 20 elements of the NEXT step and writes
+//              the three images; the tables of the step after that are already in flight (two named register sets).
+// As one role per wave the step cost the SUM of the two instruction streams (the bf16 MFMA holds the vector issue port for 8 of its
+// 16 cycles, so the split -- ~5.5 VALU per element -- does not hide behind a wave's own MFMAs): 3.3k cycles per step at two waves
+// per SIMD, against 1.9k of matrix-pipe time.
+template <int CG>
+__global__ __launch_bounds__(512) void nc_fwd_x3_kernel(NcFwdBatch nb) {
+    constexpr int G2 = 2, KV = 4, NFR = G2 * NC_NF;
+    unsigned char* const L = reinterpret_cast<unsigned char*>(nc_smem);
+    const int bid = blockIdx.x;
+    NCT(0); NCT(4);
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < NC_MAX_TASKS; ++q) if (q < nb.ntasks && bid >= nb.t[q].tile_base) ti = q;
+    const NcFwdTask& t = nb.t[ti];
+    const int local = bid - t.tile_base;
+    const int tb = local / t.tiles_h, th = local - tb * t.tiles_h;
+    const int b0 = tb * 8, n0 = th * (64 * CG);
+    const int F = t.F, H = t.H, N = t.N;
+    const int S = F >> 5;                                   // K steps (F % 32 == 0, checked by the launcher)
+    const int w8 = threadIdx.x >> 6;
+
+    if (w8 >= 4) {
+        // ================= producer =================
+        const int tid = threadIdx.x - 256;
+        const int kc = tid & 7, pb = (tid >> 3) & 7, ng = tid >> 6;
+        const bool okb = b0 + pb < t.B;
+        const int bsrc = min(b0 + pb, t.B - 1);
+        const float* const pmu = t.mean + (size_t)bsrc * t.ld_ml + kc * KV;
+        const float* const pls = t.lstd + (size_t)bsrc * t.ld_ml + kc * KV;
+        const float* const pnz = t.noise + (size_t)(5 * ng) * F + kc * KV;
+        int wofs[5];                                        // byte offset of this thread's chunk in an image, per noise row
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int n = 5 * ng + i;
+            wofs[i] = (((pb >> 2) * 5 + (n >> 2)) * 16 + (pb & 3) * 4 + (n & 3)) * NX_RSB + kc * KV * 2;
+        }
+        struct PReg { f32x4 mu, ls, nz[5]; };
+        auto gload = [&](int s, PReg& r) {
+            const int k = 32 * min(s, S - 1);               // past the end: re-read the last step (no branch), never produced
+            r.mu = *reinterpret_cast<const f32x4*>(pmu + k);
+            r.ls = *reinterpret_cast<const f32x4*>(pls + k);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) r.nz[i] = *reinterpret_cast<const f32x4*>(pnz + (size_t)i * F + k);
+        };
+        auto produce = [&](const PReg& r, unsigned char* buf) {
+            float sg[KV];
+#pragma unroll
+            for (int q = 0; q < KV; ++q) sg[q] = okb ? __expf(clamp_lstd(r.ls[q])) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                u32x2 h, m, l;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float x0 = okb ? fmaf(sg[2 * q], r.nz[i][2 * q], r.mu[2 * q]) : 0.f;
+                    const float x1 = okb ? fmaf(sg[2 * q + 1], r.nz[i][2 * q + 1], r.mu[2 * q + 1]) : 0.f;
+                    unsigned hh, mm, ll;
+                    x3_split2(x0, x1, hh, mm, ll);
+                    h[q] = hh; m[q] = mm; l[q] = ll;
+                }
+                unsigned char* p = buf + wofs[i];
+                *reinterpret_cast<u32x2*>(p) = h;
+                *reinterpret_cast<u32x2*>(p + NX_IMGB) = m;
+                *reinterpret_cast<u32x2*>(p + 2 * NX_IMGB) = l;
+            }
+        };
+        PReg ra, rb;
+        gload(0, ra); gload(1, rb);
+        produce(ra, L);
+        gload(2, ra);
+        __syncthreads();
+        for (int s = 0; s < S; s += 2) {
+            if (s + 1 < S) produce(rb, L + NX_BUFB);        // images of step s + 1
+            gload(s + 3, rb);
+            __syncthreads();
+            if (s + 1 < S) {
+                if (s + 2 < S) produce(ra, L);              // images of step s + 2
+                gload(s + 4, ra);
+                __syncthreads();
+            }
+        }
+        // exp(clamp(log_std)) for the backward passes: the producer threads of column tile 0, noise group 0, after their last image
+        if (t.sigma_out && th == 0 && ng == 0 && okb) {
+            float* const sig_dst = t.sigma_out + (size_t)(b0 + pb) * F + kc * KV;
+            for (int s = 0; s < S; ++s) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(pls + 32 * s);
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < KV; ++q) o[q] = expf(clamp_lstd(ls[q]));
+                *reinterpret_cast<f32x4*>(sig_dst + 32 * s) = o;
+            }
+        }
+        return;
+    }
+
+    // ================= consumer =================
+    const int lane = threadIdx.x & 63, w = w8;
+    const int m16 = lane & 15, kq = lane >> 4;
+    int col[CG]; bool colok[CG]; const float* wrow[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        col[c] = n0 + 16 * (CG * w + c) + m16;
+        colok[c] = col[c] < H;
+        wrow[c] = t.W + (size_t)min(col[c], H - 1) * F + 8 * kq;
+    }
+    const int aofs = m16 * NX_RSB + kq * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)aofs;
+    struct WReg { f32x4 v[CG][2]; };
+    auto wload = [&](int s, WReg& r) {
+        const int k = 32 * min(s, S - 1);
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            r.v[c][0] = *reinterpret_cast<const f32x4*>(wrow[c] + k);
+            r.v[c][1] = *reinterpret_cast<const f32x4*>(wrow[c] + k + 4);
+        }
+    };
+    f32x4 acc[CG][NFR];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) acc[c][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    WReg wa, wb;                                            // W fragments of steps s and s + 1; refilled two steps ahead
+    wload(0, wa); wload(1, wb);
+    __syncthreads();
+    NCT(1);
+    auto cstep = [&](int s, WReg& rw) {
+        const unsigned aaddr = lds0 + (unsigned)((s & 1) * NX_BUFB);
+        u32x4 fa[2][3];
+        nx_fload<0>(fa[0], aaddr);
+        bf16x8 Bh[CG], Bm[CG], Bl[CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            u32x4 bh, bm, bl;
+            unsigned h, m, l;
+            x3_split2(rw.v[c][0][0], rw.v[c][0][1], h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
+            x3_split2(rw.v[c][0][2], rw.v[c][0][3], h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
+            x3_split2(rw.v[c][1][0], rw.v[c][1][1], h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
+            x3_split2(rw.v[c][1][2], rw.v[c][1][3], h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
+            Bh[c] = __builtin_bit_cast(bf16x8, bh); Bm[c] = __builtin_bit_cast(bf16x8, bm); Bl[c] = __builtin_bit_cast(bf16x8, bl);
+        }
+        wload(s + 2, rw);
+#define NX_FRAG(J)                                                                                                     \
+        {                                                                                                              \
+            if ((J) + 1 < NFR) nx_fload<((J) + 1 < NFR ? (J) + 1 : 0)>(fa[((J) + 1) & 1], aaddr);                      \
+            nx_claim<((J) + 1 < NFR)>(fa[(J) & 1]);                                                                    \
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[(J) & 1][0]), Am = __builtin_bit_cast(bf16x8, fa[(J) & 1][1]), \
+                         Al = __builtin_bit_cast(bf16x8, fa[(J) & 1][2]);                                              \
+            _Pragma("unroll") for (int c = 0; c < CG; ++c) {                                                           \
+                f32x4 d = acc[c][(J)];                                                                                 \
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[c], d, 0, 0, 0);                                    \
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[c], d, 0, 0, 0);                                    \
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm[c], d, 0, 0, 0);                                    \
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh[c], d, 0, 0, 0);                                    \
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm[c], d, 0, 0, 0);                                    \
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[c], d, 0, 0, 0);                                    \
+                acc[c][(J)] = d;                                                                                       \
+            }                                                                                                          \
+        }
+        NX_FRAG(0) NX_FRAG(1) NX_FRAG(2) NX_FRAG(3) NX_FRAG(4) NX_FRAG(5) NX_FRAG(6) NX_FRAG(7) NX_FRAG(8) NX_FRAG(9)
+#undef NX_FRAG
+        __syncthreads();
+    };
+    for (int s = 0; s < S; s += 2) {
+        cstep(s, wa);
+        if (s + 1 < S) cstep(s + 1, wb);
+    }
+    NCT(2);
+
+    const float invN = 1.0f / (float)N;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        if (!colok[c]) continue;
+        const float bj = t.bias[col[c]];
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int b = b0 + 4 * g + (lane >> 4);
+            if (b >= t.B) continue;
+            float sum = 0.f;
+#pragma unroll
+            for (int f = 0; f < NC_NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = elu_fast(acc[c][g * NC_NF + f][r] + bj);
+                    sum += y;
+                    if (t.U) t.U[((size_t)b * N + 4 * f + r) * H + col[c]] = y;
+                }
+            t.Hm[(size_t)b * H + col[c]] = sum * invN;
+        }
+    }
+    NCT(3); NCT(5);
+}
+
+// The one-role form of the same step (every wave produces its share of the images AND consumes): NW = 8 waves = 128 hidden units.
+// Kept for the four-head critic launch: 156 VGPRs x 2 waves per SIMD leave room for any launch of the feature chain beside it,
+// which the two-role kernel at two column groups per wave (174) does not.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void nc_fwd_x3_kernel(NcFwdBatch nb) {
+__global__ __launch_bounds__(64 * NW) void nc_fwd_x3w_kernel(NcFwdBatch nb) {
     constexpr int NT = 64 * NW, KV = 1024 / NT, NKC = 32 / KV, G2 = 2;
     typedef typename NxVec<KV>::T vec_t;
     unsigned char* const L = reinterpret_cast<unsigned char*>(nc_smem);
@@ -808,7 +1006,13 @@ __global__ __launch_bounds__(512) void nc_dx_x3_kernel(NcDxTask t) {
 // ------------------------------------------------------------------------------------------------
 #define NCDW_BB 256          // batch rows per staged block
 #define NCDW_TLD 80          // [mean 32 | sigma 32 | pad 16]
-__global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
+// LEAN: the variant for the deferred critic / actor chain, which runs BESIDE the latency-bound feature chain of the next train().  A
+// 16-row-engine workgroup (one wave per SIMD, 100-196 VGPRs) can only start on a CU whose SIMDs still have that many registers free:
+// the full variant (233 VGPRs x 2 waves per SIMD) leaves 46 and so blocked every feature-chain launch for its whole 25 us; capped at
+// 128 VGPRs (two register sets of U in flight instead of four) it is slower alone and the pair of chains 7 % faster (2480 -> 2650
+// train()/s).
+template <bool LEAN>
+__global__ __launch_bounds__(512, LEAN ? 4 : 2) void nc_dw_kernel(NcDwBatch nb) {
     __shared__ float red[8][2][4][64];          // 16 KB
     __shared__ float bsum[8][16];
     constexpr int NZLD = 36;                    // 4 rows apart -> 16 banks apart: the four kq lane groups do not collide
@@ -863,13 +1067,14 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) q.u[s] = up[s * Hu];
         };
-        Chunk S0[4], S1[4], S2[4], S3[4];
+        Chunk S0[4], S1[4], S2[LEAN ? 1 : 4], S3[LEAN ? 1 : 4];
         auto loadg = [&](int g, Chunk (&S)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) load(w + 8 * u + 32 * g, S[u]);
         };
-        // the first four groups of U go out BEFORE the tables are staged: one combined round trip instead of two
-        loadg(0, S0); loadg(1, S1); loadg(2, S2); loadg(3, S3);
+        // the first four (LEAN: two) groups of U go out BEFORE the tables are staged: one combined round trip instead of two
+        loadg(0, S0); loadg(1, S1);
+        if constexpr (!LEAN) { loadg(2, S2); loadg(3, S3); }
         __builtin_amdgcn_sched_barrier(0);
         if (bb0) __syncthreads();                              // the previous block's tables are still being read
         // ---- stage the block's tables (clamped addresses; whatever lies past F / H / B is multiplied by gh = 0) ----
@@ -952,6 +1157,18 @@ __global__ __launch_bounds__(512) void nc_dw_kernel(NcDwBatch nb) {
         // Issue order is the SAME on every path that loads (the s_waitcnt immediates are static: a load that is issued
         // on one path only would force the conservative count, i.e. a full drain, on all of them).  Set k is refilled
         // with group g+4+k right after group g+k has been multiplied; only the last trip issues nothing.
+        if constexpr (LEAN) {
+            for (int g = 0; g < ngroups; g += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < ngroups) {
+                    compg(g, S0);     loadg(g + 2, S0); __builtin_amdgcn_sched_barrier(0);
+                    compg(g + 1, S1); loadg(g + 3, S1);          // (past the end: clamped addresses, never multiplied)
+                } else {
+                    compg(g, S0);
+                    if (g + 1 < ngroups) compg(g + 1, S1);
+                }
+            }
+        } else
         for (int g = 0; g < ngroups; g += 4) {
             __builtin_amdgcn_sched_barrier(0);
             if (g + 4 < ngroups) {
@@ -1035,8 +1252,10 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     const int F = nb->t[0].F, N = nb->t[0].N;
     if (nb->engine == 1) {
         if ((F % 32) != 0 || g2 != 2) return -3;
-        if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
-        else hipLaunchKernelGGL((nc_fwd_x3_kernel<4>), dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
+        static const int wide = [] { const char* e = getenv("RLREP_NC_X3_WIDE"); return e ? atoi(e) : 1; }();
+        if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
+        else if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<2>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
+        else hipLaunchKernelGGL((nc_fwd_x3_kernel<1>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
         return (int)hipGetLastError();
     }
     const int Fp = (F + 15) & ~15;
@@ -1080,16 +1299,20 @@ extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
 // one-time setup (agent creation, never inside a stream capture): nc_dw needs more dynamic LDS than the 64 KB default
 extern "C" int rl_nc_init() {
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    hipError_t e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3w_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)nc_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)nc_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 extern "C" int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     for (int q = 0; q < nb->ntasks; ++q) if (nb->t[q].N != 4 * NC_NF || nb->t[q].B <= 0) return -2;
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);          // 96 KB of staged per-batch-row tables
-    hipLaunchKernelGGL(nc_dw_kernel, dim3(total_tiles), dim3(512), lds, st, *nb);
+    if (nb->lean) hipLaunchKernelGGL(nc_dw_kernel<true>, dim3(total_tiles), dim3(512), lds, st, *nb);
+    else hipLaunchKernelGGL(nc_dw_kernel<false>, dim3(total_tiles), dim3(512), lds, st, *nb);
     return (int)hipGetLastError();
 }

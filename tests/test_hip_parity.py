@@ -378,11 +378,14 @@ def test_deferred_pipeline_is_equivalent(name):
     ('vlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
     ('ctrlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
 ])
-def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw):
+def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw, monkeypatch):
     """400 pipelined train() calls at the BASELINE dimensions (two streams, two snapshot sets, device Philox) end in exactly the
     parameters, moments and targets of 400 sequential ones: any missing dependency between the two launch chains would show here
-    (tools/exp/pipe_soak.py runs the same check for 2000 calls: 0.0 difference for vlsac, ctrlsac and spedersac)."""
+    (tools/exp/pipe_soak.py runs the same check for 2000 calls: 0.0 difference for vlsac, ctrlsac and spedersac).
+    RLREP_NC_DW_FULL=1: both forms on the SAME noise-critic dW kernel -- the deferred chain's default is the 128-VGPR build of it,
+    whose results differ from the 233-VGPR build in the last bit (test_lean_noise_critic_dw_matches_full below)."""
     import importlib
+    monkeypatch.setenv('RLREP_NC_DW_FULL', '1')
     import synth
     from rlrep_amd.utils.buffer import ReplayBuffer
     name = {'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent'}[alg]
@@ -402,6 +405,28 @@ def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw):
         outs[-1]['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy()
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_lean_noise_critic_dw_matches_full():
+    """The deferred chain's register-capped noise-critic dW kernel (nc_dw_kernel<true>, 128 VGPRs so that feature-chain launches can
+    start beside it) against the full build the sequential form uses: 40 train() calls at the headline dimensions, parameters within
+    1e-6 relative (measured 5e-9: last-bit rounding, same summation order)."""
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
+    data = synth.replay(17, 6, 8192, seed=0)
+    outs = []
+    for pipe in (True, False):
+        torch.manual_seed(0)
+        agent = VLSACAgent(state_dim=17, action_dim=6, action_space=_Space(6, 1.0), max_batch=256, pipeline=pipe, seed=99,
+                           hidden_dim=256, feature_dim=256, extra_feature_steps=3)
+        buf = ReplayBuffer(17, 6, max_size=8192)
+        buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+        for i in range(40):
+            agent.train(buf, 256)
+        outs.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
+    for k in outs[1]:
+        assert rel_l2(outs[0][k], outs[1][k]) < 1e-6, k
 
 
 def test_deferred_pipeline_batch_change_and_checkpoint():
