@@ -49,10 +49,10 @@ ALG_GFLOP = {'vlsac_halfcheetah_f256_b256': 10.59, 'sac_halfcheetah_b256': 0.582
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md); the bf16x3 tile executes 6 bf16 MFMA flops per algorithmic fp32 flop
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
-# HBM-side bytes per nc_fwd launch from the PMC passes in profiles/r01_pmc_summary.json (FETCH_SIZE 3071.8 KB raw, x2 for 16-byte streaming
-# reads on gfx950, + WRITE_SIZE 11446.6 KB; mean over the critic- and actor-stage launches of the profiled run): 17.6 MB against
-# 11.0 MB algorithmic for the critic-stage launch (10.5 MB of ELU outputs written + tables and weights read)
-NC_FWD_TRAFFIC_BYTES = int((2 * 3071.8 + 11446.6) * 1024)
+# HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r01_pmc_summary.json (nc_fwd_x3w_kernel<8>:
+# FETCH_SIZE 3251.0 KB raw, x2 for 16-byte reads on gfx950, + WRITE_SIZE 11520.0 KB): 18.5 MB against 11.0 MB algorithmic (10.5 MB of
+# ELU outputs written + tables and weights read once; every XCD's L2 fetches its own copy of the 1 MB of weights)
+NC_FWD_TRAFFIC_BYTES = int((2 * 3251.0 + 11520.0) * 1024)
 
 
 class Space:
@@ -106,7 +106,9 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     # bf16x3 engine: six bf16 MFMA flops are executed per algorithmic fp32 flop, so the ceiling for ALGORITHMIC flops is the dense
     # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NC_X3=0) it is the fp32 MFMA peak
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-    out = {'bound': 'mfma', 'kernel': ('nc_fwd_x3_kernel<%d> (critic step, 4 heads, bf16x3)' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel (critic step, 4 heads)',
+    wide = plan[2].value == 128 and os.environ.get('RLREP_NC_X3_WIDE', '1') != '0'      # the launcher's choice (noisecritic.hip rl_launch_nc_fwd)
+    kname = ('nc_fwd_x3w_kernel<8>' if wide else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
+    out = {'bound': 'mfma', 'kernel': kname + (' (critic step, 4 heads, bf16x3)' if x3 else ' (critic step, 4 heads)'),
            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
            # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
            # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)

@@ -15,7 +15,8 @@ def row(k):
             f"{d.get('FETCH_SIZE', 0) / 1024:.1f} | {d.get('WRITE_SIZE', 0) / 1024:.1f} | {d.get('SQ_LDS_BANK_CONFLICT', 0):.0f} |")
 
 
-keys = [k for k in ('nc_fwd_kernel<1>', 'nc_dw_kernel', 'nc_dx_kernel<true>', 'gemm16_kernel<0, 0, 1, true, true>', 'gemm16_kernel<0, 1, 1, true, false>',
+keys = [k for k in ('nc_fwd_x3w_kernel<8>', 'nc_fwd_x3_kernel<1>', 'nc_fwd_kernel<1>', 'nc_dw_kernel<false>', 'nc_dw_kernel<true>', 'nc_dw_kernel', 'nc_dx_x3_kernel', 'nc_dx_kernel<true>',
+                    'gemm16_kernel<0, 0, 1, true, true>', 'gemm16_kernel<0, 1, 1, true, false>',
                     'gemm16_kernel<1, 1, 4, false, false>', 'adam_kernel', 'train_prologue_kernel') if k in pmc]
 txt = f'''# profiles, round 1
 
@@ -24,7 +25,7 @@ rocprofv3 output collected on one MI355X (gpurun box) with these commands (`cd /
 
 * `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_{tag}b -- python3 bench.py --steps 300 --warmup 30 --no-cpu`
   -> `{tag}_vlsac_b256_kernel_stats.csv` (workload vlsac_halfcheetah_f256_b256, hipGraph replay; 331 train() calls incl.
-  capture/warm-up, plus bench.py's roofline loop: 220 extra critic-stage `nc_fwd_kernel` launches)
+  capture/warm-up, plus bench.py's roofline loop: 220 extra critic-stage `nc_fwd_x3w_kernel<8>` launches)
 * three separate `--pmc` passes, `--kernel-trace` only (`tools/_pmc.sh`, eager launches, 25 train() calls each)
   -> `{tag}_pmc_summary.json` (per-kernel mean over dispatches of the per-dispatch sums)
 * un-profiled `python bench.py` on the same box -> `{tag}_bench.json`
@@ -40,7 +41,7 @@ and the instrumented timeline (`tools/exp/gemm_timeline.py`) puts a gemm16 launc
 
 bench.py (un-profiled): **{b['value']} {b['unit']}**, {b['ms_per_step']} ms per train() -- graph mode with the critic + actor steps of
 train(t) on a second stream beside the feature steps of train(t+1) (`config.deferred_critic_actor_branch`; DESIGN.md 2 and 5.0);
-`RLREP_PIPELINE=0` gives the strictly sequential graph: 1 840-1 900 train()/s (0.53-0.54 ms).  Box-to-box spread over the gpurun pool
+`RLREP_PIPELINE=0` gives the strictly sequential graph: 1 990-2 010 train()/s (0.50 ms).  Box-to-box spread over the gpurun pool
 is about 5 %.  The kernel table above was collected in the same (pipelined) mode: under rocprofv3 the two streams' kernels are
 serialised, so it shows per-kernel durations, not the overlap.
 
@@ -48,9 +49,11 @@ roofline: `{json.dumps(b['roofline'])}`
 
 cpu_baseline: `{json.dumps(b['cpu_baseline'])}`
 
-`nc_fwd_kernel<1>` is launched twice per train() (critic step: 4 heads, 2.68 GFLOP; actor step: 2 heads, 1.34 GFLOP)
-plus 220 times by bench.py's roofline loop (critic-step launch), so its average above is a mix of ~34 us and ~21 us
-launches; `roofline.us_per_launch` times the critic-step launch alone with HIP events on the launch stream.
+The noise-critic first layer runs on the bf16 pipe as an exact three-way split (bf16x3, `csrc/x3.h`): `nc_fwd_x3w_kernel<8>` is the critic
+step's four-head launch (2.68 GFLOP; also bench.py's roofline loop, 220 launches), `nc_fwd_x3_kernel<1>` the actor step's two-head launch
+(1.34 GFLOP), `nc_dx_x3_kernel` the actor step's dL/d(mean, log_std); the weight gradient `nc_dw_kernel` stays on fp32 MFMA (`<true>` = the
+128-VGPR build the deferred chain uses, `<false>` = the 233-VGPR build of the sequential form and of the eager PMC passes).
+`roofline.us_per_launch` times the four-head launch alone with HIP events on the launch stream.
 
 ## PMC counters (`{tag}_pmc_summary.json`), per launch
 
@@ -58,13 +61,15 @@ launches; `roofline.us_per_launch` times the critic-step launch alone with HIP e
 |---|---|---|---|---|---|---|
 ''' + '\n'.join(row(k) for k in keys) + '''
 
-VALU_MFMA_BUSY / (launch time x 1024 SIMDs x clock) is the chip-wide MFMA utilisation: 39.9 M busy cycles over 30.8 us x 1024 SIMDs x
-2.1 GHz (the clock the chip holds under this load, tools/exp/nc_timeline.py) = 60 % for the critic-stage `nc_fwd` launch
-(`roofline.frac` prices the same launch against the 2.4 GHz spec peak: 0.55), ~40 % for `nc_dw` and `nc_dx`.
-FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane streaming reads) applies to
-`nc_fwd`'s table staging and gives bench.py's `roofline.traffic` = 2 x FETCH + WRITE = 17.7 MB per critic-stage launch
-against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs).  `nc_dw` / `nc_dx` read U (10.5 MB) once:
-12.7 / 7.5 MB raw with dword / 16-byte loads (uncalibrated / half-counted access widths).
+VALU_MFMA_BUSY / (launch time x 1024 SIMDs x clock) is the chip-wide matrix-pipe utilisation: 15.7 M busy cycles (983 040 bf16 MFMAs x 16)
+over 21.2 us x 1024 SIMDs x 2.1 GHz = 34 % for the four-head `nc_fwd_x3w_kernel<8>` launch -- the same product on fp32 MFMA kept its pipe
+60 % busy for 30.8 us.  The x3 kernels are bound by vector-instruction ISSUE, not by the matrix pipe: SQ_INSTS_VALU / SQ_INSTS_MFMA = 4.3
+(forward) and 5.9 (dX) with the bf16 MFMA holding the issue port for 8 of its 16 cycles (tools/exp/nc_timeline.py: 3.3k cycles per 32-deep
+step for 1.9k of matrix-pipe time).  `roofline.frac` prices the launch against 2500 / 6 = 417 TF (six bf16 MFMA flops per fp32 product).
+FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane reads) gives bench.py's `roofline.traffic` =
+2 x FETCH + WRITE = 18.5 MB per four-head launch against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs; each XCD's L2
+fetches its own copy of the 1 MB of weights).  `nc_dw` / `nc_dx_x3` read U (10.5 MB) once: 12.7 / 7.5 MB raw with dword / 8-byte loads
+(uncalibrated / half-counted access widths); the four column tiles of a batch tile that share rows of U are placed on one XCD.
 
 ## Micro-benchmarks behind the design decisions (`tools/exp/*.hip`, run with gpurun; results quoted in DESIGN.md)
 
