@@ -544,7 +544,16 @@ class SACAgent(object):
             self._feature_once(buffer, B, i, True)
         return self._pool['eps_crit'], self._pool['eps_act']
 
+    def _order_buffer_writes(self):
+        """ReplayBuffer hook: the caller's stream is about to overwrite ring rows / the size scalar that the feature chain of the
+        pipelined train() in flight may still be sampling from on its own stream -- make the caller's stream wait for that chain."""
+        P = self._pipe
+        if P is not None and self._pending in (2, 3) and P.get('last_f') is not None:
+            torch.cuda.current_stream().wait_event(P['last_f'])
+
     def _train_graph_pipelined(self, buffer, B):
+        if getattr(buffer, 'before_device_write', 0) is None:
+            buffer.before_device_write = self._order_buffer_writes
         buffer.flush()
         buffer.size_dev()
         key = (id(buffer), B)
@@ -612,7 +621,13 @@ class SACAgent(object):
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
         cur = torch.cuda.current_stream()
-        s_f.wait_stream(cur)                               # replay rows staged by ReplayBuffer.add() land on the caller's stream
+        # replay rows staged by ReplayBuffer.add() land on the caller's stream: order the feature chain after them -- but only when the
+        # buffer has enqueued something since the last call (or the chains were idle): the event record + wait pair is ~5 us of the
+        # feature chain's critical path, and a back-to-back train() loop has nothing to wait for
+        seen = (getattr(buffer, 'device_epoch', None), cur.cuda_stream)
+        if not self._pending or seen[0] is None or P.get('seen') != seen:
+            s_f.wait_stream(cur)
+            P['seen'] = seen
         if not self._pending:
             s_ca.wait_stream(cur)
         with torch.cuda.stream(s_f):
@@ -620,6 +635,7 @@ class SACAgent(object):
                 s_f.wait_event(P['ev_ca'][k])                  # the pair that read this set last (train t-2)
             P['fs'][k].replay()
             P['ev_snap'][k].record(s_f)
+            P['last_f'] = P['ev_snap'][k]
         with torch.cuda.stream(s_ca):
             s_ca.wait_event(P['ev_snap'][k])
             P['ca'][k].replay()
@@ -649,6 +665,8 @@ class SACAgent(object):
         return segs
 
     def _train_graph_dp_pipelined(self, buffer, B):
+        if getattr(buffer, 'before_device_write', 0) is None:
+            buffer.before_device_write = self._order_buffer_writes
         buffer.flush()
         buffer.size_dev()
         key = (id(buffer), B)
@@ -700,6 +718,7 @@ class SACAgent(object):
                 x.replay() if kind == 'graph' else x()
         assert not F and not C
         P['ev_snap'][k].record(s_f)
+        P['last_f'] = P['ev_snap'][k]
         if prev is not None:
             P['ev_ca'][prev].record(s_ca)
         P['used'][k] = True

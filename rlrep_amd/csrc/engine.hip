@@ -487,7 +487,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         {
             NcDwBatch nb; memset(&nb, 0, sizeof(nb));
             nb.ntasks = 2;
-            nb.lean = (b.low_prio && !getenv("RLREP_NC_DW_FULL")) ? 1 : 0;     // deferred chain: leave registers for the feature chain's launches
+            nb.lean = ((b.low_prio || getenv("RLREP_NC_DW_LEAN")) && !getenv("RLREP_NC_DW_FULL")) ? 1 : 0;     // deferred chain: leave registers for the feature chain's launches
             int base_tile = 0;
             auto ncdw = [&](int q, float* Ubuf, float* GH, float* gW, float* gb) {
                 NcDwTask& t = nb.t[q];

@@ -460,3 +460,36 @@ def test_deferred_pipeline_batch_change_and_checkpoint():
         outs.append(end)
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_deferred_pipeline_sees_rows_added_between_calls():
+    """ReplayBuffer.add() stages rows on the caller's stream; a pipelined train() orders its feature chain after them only when the buffer
+    has enqueued something since the last call (`device_epoch`).  A ring that starts with B rows and grows by three rows before every
+    call: every draw depends on the new size and, soon, on the new rows -- same final state as the sequential graph mode."""
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    c = Case('vlsac_tiny')
+    rs = np.random.RandomState(4)
+    extra = [(rs.standard_normal(c.S).astype(np.float32), rs.uniform(-1, 1, c.A).astype(np.float32), rs.standard_normal(c.S).astype(np.float32),
+              float(rs.standard_normal()), float(rs.rand() < 0.1)) for _ in range(60)]
+    outs = []
+    for pipe in (True, False):
+        kw = dict(c.kw)
+        if c.meta.get('patch_vae_hidden'):
+            kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+        cls = type(make_agent(c))
+        agent = cls(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, graph=True, pipeline=pipe,
+                    seed=77, **kw)
+        agent.core.load_state(c.init)
+        buf = ReplayBuffer(c.S, c.A, max_size=64)
+        r = c.replay
+        buf.load(r['state'][:c.B], r['action'][:c.B], r['next_state'][:c.B], r['reward'][:c.B], r['done'][:c.B])
+        it = iter(extra)
+        for t in range(16):
+            for _ in range(3):
+                buf.add(*next(it))
+            agent.train(buf, c.B)
+            if t % 5 == 4:
+                agent.train(buf, c.B)          # and a call with nothing new in the buffer
+        outs.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -79,3 +79,62 @@ if P and P.get('mode') == 2:
             P['s_ca'].wait_event(ev[k]); P['ca'][k].replay(); ev[2 + k].record(P['s_ca'])
     torch.cuda.synchronize()
     print(f'both chains on the chosen pair, with the snapshot / reuse events: {1e6 * (time.perf_counter() - t0) / 500:.1f} us per iteration')
+
+
+# Which heavy launch of the critic / actor chain costs the feature chain how much?  Each one alone, 4x per graph, beside the feature chain.
+if P and P.get('mode') == 2:
+    c = agent.core
+    heavy = []
+    for prog in (2, 4):
+        for i, n in enumerate(c.stages(prog)):
+            if n.startswith('noise critic'):
+                heavy.append((prog, i, n))
+    t0 = time.perf_counter()
+    for i in range(300): 
+        with torch.cuda.stream(P['s_f']): P['fs'][i & 1].replay()
+    torch.cuda.synchronize()
+    f_alone = 1e6 * (time.perf_counter() - t0) / 300
+    for prog, i, n in heavy:
+        for _ in range(3): c.run_stage(prog, i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=P['s_ca']):
+            for _ in range(4): c.run_stage(prog, i)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(P['s_ca']):
+            t0 = time.perf_counter()
+            for _ in range(300): g.replay()
+            P['s_ca'].synchronize()
+            alone = 1e6 * (time.perf_counter() - t0) / 300
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(300):
+            with torch.cuda.stream(P['s_f']): P['fs'][k & 1].replay()
+            with torch.cuda.stream(P['s_ca']): g.replay()
+        torch.cuda.synchronize()
+        both = 1e6 * (time.perf_counter() - t0) / 300
+        print(f'4 x [{n}]: {alone:.1f} us alone; feature chain {f_alone:.1f} -> {both:.1f} us beside it = +{(both - f_alone) / alone:.2f} us per us')
+
+if P and P.get('mode') == 2:
+    # the rest of the critic / actor programs (everything but the four noise-critic launches), as one graph beside the feature chain
+    c = agent.core
+    rest = [(prog, i) for prog in (2, 3, 4, 5) for i, n in enumerate(c.stages(prog)) if not n.startswith('noise critic')]
+    for prog, i in rest: c.run_stage(prog, i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=P['s_ca']):
+        for prog, i in rest: c.run_stage(prog, i)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(P['s_ca']):
+        t0 = time.perf_counter()
+        for _ in range(300): g.replay()
+        P['s_ca'].synchronize()
+        alone = 1e6 * (time.perf_counter() - t0) / 300
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(300):
+        with torch.cuda.stream(P['s_f']): P['fs'][k & 1].replay()
+        with torch.cuda.stream(P['s_ca']): g.replay()
+    torch.cuda.synchronize()
+    both = 1e6 * (time.perf_counter() - t0) / 300
+    print(f'{len(rest)} small launches of the critic / actor programs: {alone:.1f} us alone; feature chain {f_alone:.1f} -> {both:.1f} us beside them')
