@@ -26,6 +26,8 @@ int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t 
 int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
 int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);
 int rl_nc_init();
+int rl_nc_dw_engine(int fused_optimizer);
+int rl_nc_dw_splits(int B, int F, int H, int ntasks);
 int rl_nc_fwd_cols();
 void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols);
 int rl_launch_fill_slot(const SlotFill* p, hipStream_t st);

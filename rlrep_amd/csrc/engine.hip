@@ -503,6 +503,17 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             };
             ncdw(0, U, GHm, Gw("critic.l1.weight"), Gw("critic.l1.bias"));
             ncdw(1, U + BNH, GHm + BH, Gw("critic.l4.weight"), Gw("critic.l4.bias"));
+            // bf16x3 split-K form: 64 x 64 tiles x splits, partial tiles in workspace slabs (reserved in the dry pass as well)
+            nb.splits = rl_nc_dw_splits(B, F, H, 2);
+            nb.slab = ws.f((size_t)2 * nb.splits * H * F);
+            nb.bslab = ws.f((size_t)2 * nb.splits * H);
+            nb.engine = rl_nc_dw_engine(b.fused() ? 1 : 0);
+            if (nb.engine == 1) {
+                base_tile = 0;
+                for (int q = 0; q < 2; ++q) {
+                    nb.t[q].ntiles = ((H + 63) / 64) * ((F + 63) / 64) * nb.splits; nb.t[q].tile_base = base_tile; base_tile += nb.t[q].ntiles;
+                }
+            }
             const int total = base_tile;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dw(&nb, total, st); }, "noise critic dW l1/l4"});
         }

@@ -153,7 +153,9 @@ struct NcDwTask {
     float* ad_p; float* ad_m; float* ad_v; float* ad_pb; float* ad_mb; float* ad_vb;
     const GroupCfg* ad_grp;
 };
-struct NcDwBatch { int ntasks; int lean; NcDwTask t[2]; };      // lean: the 128-VGPR variant (launch beside the feature chain)
+// lean: the 128-VGPR build of the fp32 kernel (launch beside the feature chain).  engine 1 = bf16x3 split-K form: `splits` row ranges
+// per 64 x 64 output tile, partial tiles in slab [task][split][H][F], bias partials in bslab [task][split][H], summed by a finishing launch
+struct NcDwBatch { int ntasks; int lean; int engine; int splits; float* slab; float* bslab; NcDwTask t[2]; };
 
 struct NcDxTask {
     const float* GH[2]; int ldgh;    // dL/dHm per head [B, H]

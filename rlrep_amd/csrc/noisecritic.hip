@@ -1217,6 +1217,218 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 2) void nc_dw_kernel(NcDwBatch nb) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// dW / db on the BF16 matrix pipe at fp32 accuracy (bf16x3), as a split-K GEMM with generated operands:
+//   dW[j, k] = sum_r dPre[r, j] * x[r, k],   r = (b, n) over 20 B rows,   dPre = GH[b, j]/N * elu'(U[r, j]),   x = mean + sigma * noise.
+// Output tile 64 (j) x 64 (k) per workgroup, `splits` ranges of batch rows per tile (B = 256, 8 splits: 640 rows = twenty 32-deep
+// steps); 8 waves in two roles as in nc_dx_x3_kernel: waves 4-7 build and split BOTH operands of the next step -- thread (column, row
+// octet) loads 8 rows of U for its j and the tables for its k, and writes one 16-byte chunk per image: the images are [column][32 r],
+// i.e. already transposed for the MFMA (a lane needs 8 consecutive r of one column) -- waves 0-3 own a 32 x 32 quarter of the tile
+// (four 16 x 16 accumulators, 24 MFMAs and 12 fragment reads per step).  Against the fp32 kernel above (16 x 32 tiles, every dPre
+// element regenerated by 8 workgroups and every x element by 16): 4x / 4x, 100 VGPRs instead of 233, no spills.  Partial tiles and
+// bias partials go to slabs; nc_dw_fin_kernel adds them in split order (no float atomics: bit-reproducible).
+// ------------------------------------------------------------------------------------------------
+#define NDW_IMGB (64 * NX_RSB)                 /* one image: 64 columns x 80-byte rows */
+#define NDW_OPB (3 * NDW_IMGB)                 /* one operand: three images */
+#define NDW_BUFB (2 * NDW_OPB)                 /* one step: A and B */
+
+template <int OFF> __device__ __forceinline__ void ndw_fload_at(u32x4 (&d)[3], unsigned addr) {
+    nx_read<OFF>(d[0], addr); nx_read<OFF + NDW_IMGB>(d[1], addr); nx_read<OFF + 2 * NDW_IMGB>(d[2], addr);
+}
+
+__global__ __launch_bounds__(512) void nc_dw_x3_kernel(NcDwBatch nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char L[2 * NDW_BUFB];      // 61 440 B
+    const int bid = blockIdx.x;
+    const int q = (nb.ntasks > 1 && bid >= nb.t[1].tile_base) ? 1 : 0;
+    const NcDwTask& t = nb.t[q];
+    const int F = t.F, H = t.H, B = t.B;
+    constexpr int N = 4 * NC_NF;                                     // 20 noise rows (checked by the launcher): divisions by it compile to mul-shift
+    const int TK = (F + 63) >> 6, TJ = (H + 63) >> 6;
+    int local = bid - t.tile_base;
+    {   // XCD-aware order: the TK column tiles of one (split, row tile) stream the same rows of U -- same blockIdx % 8, same L2
+        const int ngrp = TJ * nb.splits;
+        if ((ngrp & 7) == 0 && (t.tile_base & 7) == 0) {
+            const int x = local & 7, y = local >> 3;
+            local = ((y / TK) * 8 + x) * TK + (y % TK);
+        }
+    }
+    const int sp = local / (TJ * TK); local -= sp * (TJ * TK);
+    const int tj = local / TK, tk = local - tj * TK;
+    const int j0 = tj * 64, k0 = tk * 64;
+    const int bs = (B + nb.splits - 1) / nb.splits;                 // batch rows per split
+    const int bbeg = min(sp * bs, B), nbr = min(bs, B - bbeg);
+    const int nrows = N * nbr;                                       // inner rows of this split
+    const int S = (nrows + 31) >> 5;
+    const int w8 = threadIdx.x >> 6;
+    float* const slab = nb.slab + ((size_t)(q * nb.splits + sp) * H) * F;
+    if (nbr <= 0) {                                                   // a split without rows (tiny batches): its partials are zero
+        for (int e = threadIdx.x; e < 64 * 64; e += 512) {
+            const int jj = j0 + (e >> 6), kk = k0 + (e & 63);
+            if (jj < H && kk < F) slab[(size_t)jj * F + kk] = 0.f;
+        }
+        if (tk == 0 && threadIdx.x < 64 && j0 + (int)threadIdx.x < H) nb.bslab[(size_t)(q * nb.splits + sp) * H + j0 + threadIdx.x] = 0.f;
+        return;
+    }
+
+    if (w8 >= 4) {
+        // ================= producer: thread = (column c of BOTH 64-wide operands, row octet rq) =================
+        const int tid = threadIdx.x - 256;
+        const int c = tid & 63, rq = tid >> 6;
+        const int j = min(j0 + c, H - 1), k = min(k0 + c, F - 1);
+        const float invN = 1.0f / (float)N;
+        const float* const Uc = t.U + (size_t)bbeg * N * H + j;
+        const float* const Gc = t.GH + (size_t)bbeg * t.ldgh + j;
+        const float* const Mc = t.mean + (size_t)bbeg * t.ld_ml + k;
+        const float* const Sc = t.sigma + (size_t)bbeg * F + k;
+        const float* const Zc = t.noise + k;
+        const int wofs = c * NX_RSB + rq * 16;
+        // The octet r0 .. r0 + 7 is two groups of four rows, and a group never straddles a batch row or the end of the split (N and the
+        // row count are multiples of 4): per GROUP one batch row lb[h], one validity flag -- folded into the group's GH / sigma / mean
+        // values (zero them and the rows contribute nothing), so the per-element work is add, min, mul (dPre) and one fma (x).
+        // Static register indices only (a runtime index would put the set in scratch).
+        struct PReg { float u[8], g[2], mu[2], sg[2], nz[8]; };
+        auto gload = [&](int s, PReg& r) {
+            const int r0 = 32 * min(s, S - 1) + 8 * rq;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rg = min(r0 + 4 * h, nrows - 4);           // clamped group start (still a multiple of 4)
+                const int lb = rg / N, n0 = rg - lb * N;
+                const float* up = Uc + (size_t)rg * H;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r.u[4 * h + e] = up[(size_t)e * H]; r.nz[4 * h + e] = Zc[(size_t)(n0 + e) * F]; }
+                r.g[h] = Gc[(size_t)lb * t.ldgh]; r.mu[h] = Mc[(size_t)lb * t.ld_ml]; r.sg[h] = Sc[(size_t)lb * F];
+            }
+        };
+        float bsum = 0.f;
+        auto produce = [&](int s, const PReg& r, unsigned char* buf) {
+            const int r0 = 32 * s + 8 * rq;
+            float a[8], x[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool valid = r0 + 4 * h < nrows;
+                const float g = valid ? r.g[h] * invN : 0.f, mu = valid ? r.mu[h] : 0.f, sg = valid ? r.sg[h] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[4 * h + e] = g * fminf(r.u[4 * h + e] + 1.f, 1.f);            // elu'(out) = min(out + 1, 1)
+                    x[4 * h + e] = fmaf(sg, r.nz[4 * h + e], mu);
+                    bsum += a[4 * h + e];
+                }
+            }
+            u32x4 ah, am, al, xh, xm, xl;
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                unsigned h, m, l;
+                x3_split2(a[2 * p2], a[2 * p2 + 1], h, m, l); ah[p2] = h; am[p2] = m; al[p2] = l;
+                x3_split2(x[2 * p2], x[2 * p2 + 1], h, m, l); xh[p2] = h; xm[p2] = m; xl[p2] = l;
+            }
+            unsigned char* pa = buf + wofs;
+            *reinterpret_cast<u32x4*>(pa) = ah;
+            *reinterpret_cast<u32x4*>(pa + NDW_IMGB) = am;
+            *reinterpret_cast<u32x4*>(pa + 2 * NDW_IMGB) = al;
+            *reinterpret_cast<u32x4*>(pa + NDW_OPB) = xh;
+            *reinterpret_cast<u32x4*>(pa + NDW_OPB + NDW_IMGB) = xm;
+            *reinterpret_cast<u32x4*>(pa + NDW_OPB + 2 * NDW_IMGB) = xl;
+        };
+        PReg ra, rb;
+        gload(0, ra); gload(1, rb);
+        produce(0, ra, L);
+        gload(2, ra);
+        __syncthreads();
+        for (int s = 0; s < S; s += 2) {
+            if (s + 1 < S) produce(s + 1, rb, L + NDW_BUFB);
+            gload(s + 3, rb);
+            __syncthreads();
+            if (s + 1 < S) {
+                if (s + 2 < S) produce(s + 2, ra, L);
+                gload(s + 4, ra);
+                __syncthreads();
+            }
+        }
+        // bias partial of this split: sum over the four row octets of a column (fixed order), column tile 0 only
+        float* const red = reinterpret_cast<float*>(L);              // the image buffers are free: every consumer is past its last barrier
+        __syncthreads();
+        red[rq * 64 + c] = bsum;
+        __syncthreads();
+        if (tk == 0 && rq == 0 && j0 + c < H)
+            nb.bslab[(size_t)(q * nb.splits + sp) * H + j0 + c] = ((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c];
+        return;
+    }
+
+    // ================= consumer: wave (wj, wk) owns rows j0 + 32 wj .. + 31, columns k0 + 32 wk .. + 31 of the tile =================
+    const int lane = threadIdx.x & 63, w = w8;
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int wj = w >> 1, wk = w & 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)(m16 * NX_RSB + kq * 16);
+    const unsigned aofs = (unsigned)(32 * wj * NX_RSB), bofs = (unsigned)(NDW_OPB + 32 * wk * NX_RSB);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const unsigned base = lds0 + (unsigned)((s & 1) * NDW_BUFB);
+        u32x4 fa[2][3], fb[2][3];
+        ndw_fload_at<0>(fa[0], base + aofs);
+        ndw_fload_at<0>(fb[0], base + bofs);
+        ndw_fload_at<16 * NX_RSB>(fa[1], base + aofs);
+        ndw_fload_at<16 * NX_RSB>(fb[1], base + bofs);
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]));
+#define NDW_MM(A, Bq)                                                                                                   \
+        {                                                                                                               \
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[A][0]), Am = __builtin_bit_cast(bf16x8, fa[A][1]), Al = __builtin_bit_cast(bf16x8, fa[A][2]); \
+            const bf16x8 Bh = __builtin_bit_cast(bf16x8, fb[Bq][0]), Bm = __builtin_bit_cast(bf16x8, fb[Bq][1]), Bl = __builtin_bit_cast(bf16x8, fb[Bq][2]); \
+            f32x4 d = acc[A][Bq];                                                                                       \
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, d, 0, 0, 0);                                            \
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, d, 0, 0, 0);                                            \
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, d, 0, 0, 0);                                            \
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, d, 0, 0, 0);                                            \
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, d, 0, 0, 0);                                            \
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, d, 0, 0, 0);                                            \
+            acc[A][Bq] = d;                                                                                             \
+        }
+        NDW_MM(0, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]));
+        NDW_MM(0, 1) NDW_MM(1, 0) NDW_MM(1, 1)
+#undef NDW_MM
+        __syncthreads();
+    }
+    __syncthreads();                                                 // (the producers' bias reduction: two more barriers for every wave)
+    __syncthreads();
+    // partial tile -> slab: C/D map col = lane & 15 (k), row = 4 (lane >> 4) + reg (j)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int kk = k0 + 32 * wk + 16 * b2 + m16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = j0 + 32 * wj + 16 * a + 4 * kq + r;
+                if (jj < H && kk < F) slab[(size_t)jj * F + kk] = acc[a][b2][r];
+            }
+        }
+}
+
+// sums the split partials in split order: gW = sum_sp slab[sp], gb = sum_sp bslab[sp]
+__global__ __launch_bounds__(256) void nc_dw_fin_kernel(NcDwBatch nb) {
+    const int q = blockIdx.y;
+    const NcDwTask& t = nb.t[q];
+    const size_t HF = (size_t)t.H * t.F;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float* s0 = nb.slab + (size_t)q * nb.splits * HF;
+    if (e < HF) {
+        float v = s0[e];
+        for (int sp = 1; sp < nb.splits; ++sp) v += s0[(size_t)sp * HF + e];
+        t.gW[e] = v;
+    }
+    if (e < (size_t)t.H) {
+        const float* b0 = nb.bslab + (size_t)q * nb.splits * t.H;
+        float v = b0[e];
+        for (int sp = 1; sp < nb.splits; ++sp) v += b0[(size_t)sp * t.H + e];
+        t.gb[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // hidden units per nc_fwd workgroup (64 or 128); the builder sizes tiles_h with it
 extern "C" int rl_nc_fwd_cols() {
     static const int v = [] { const char* e = getenv("RLREP_NC_COLS"); const int x = e ? atoi(e) : 128; return x == 64 ? 64 : 128; }();
@@ -1308,9 +1520,33 @@ extern "C" int rl_nc_init() {
     return (int)hipFuncSetAttribute((const void*)nc_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+// engine of the dW launch: 1 = bf16x3 split-K (needs slabs from the caller and no fused optimizer; RLREP_NC_X3=0 / RLREP_NC_DW_X3=0 keep fp32)
+extern "C" int rl_nc_dw_engine(int fused_optimizer) {
+    const char* ex = getenv("RLREP_NC_X3");
+    const char* ed = getenv("RLREP_NC_DW_X3");
+    if ((ex && atoi(ex) == 0) || (ed && atoi(ed) == 0) || getenv("RLREP_NO_X3") || fused_optimizer) return 0;
+    return 1;
+}
+extern "C" int rl_nc_dw_splits(int B, int F, int H, int ntasks) {
+    const int tiles = ((H + 63) / 64) * ((F + 63) / 64) * ntasks;
+    const char* e = getenv("RLREP_NC_DW_SPLITS");
+    int sp = e ? atoi(e) : (256 + tiles - 1) / tiles;                 // about one workgroup per CU
+    sp = sp < 1 ? 1 : sp > 16 ? 16 : sp;
+    const int maxsp = (B + 7) / 8;                                    // at least 8 batch rows (five 32-deep steps) per split
+    return sp > maxsp ? (maxsp < 1 ? 1 : maxsp) : sp;
+}
 extern "C" int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     for (int q = 0; q < nb->ntasks; ++q) if (nb->t[q].N != 4 * NC_NF || nb->t[q].B <= 0) return -2;
+    if (nb->engine == 1) {
+        if (!nb->slab || !nb->bslab || nb->splits < 1) return -3;
+        const NcDwTask& t0 = nb->t[0];
+        for (int q = 1; q < nb->ntasks; ++q) if (nb->t[q].H != t0.H || nb->t[q].F != t0.F || nb->t[q].B != t0.B) return -3;
+        hipLaunchKernelGGL(nc_dw_x3_kernel, dim3(total_tiles), dim3(512), 0, st, *nb);
+        const size_t HF = (size_t)t0.H * t0.F;
+        hipLaunchKernelGGL(nc_dw_fin_kernel, dim3((unsigned)((HF + 255) / 256), nb->ntasks), dim3(256), 0, st, *nb);
+        return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);          // 96 KB of staged per-batch-row tables
     if (nb->lean) hipLaunchKernelGGL(nc_dw_kernel<true>, dim3(total_tiles), dim3(512), lds, st, *nb);
     else hipLaunchKernelGGL(nc_dw_kernel<false>, dim3(total_tiles), dim3(512), lds, st, *nb);
