@@ -15,7 +15,7 @@ def row(k):
             f"{d.get('FETCH_SIZE', 0) / 1024:.1f} | {d.get('WRITE_SIZE', 0) / 1024:.1f} | {d.get('SQ_LDS_BANK_CONFLICT', 0):.0f} |")
 
 
-keys = [k for k in ('nc_fwd_x3w_kernel<8>', 'nc_fwd_x3_kernel<1>', 'nc_fwd_kernel<1>', 'nc_dw_kernel<false>', 'nc_dw_kernel<true>', 'nc_dw_kernel', 'nc_dx_x3_kernel', 'nc_dx_kernel<true>',
+keys = [k for k in ('nc_fwd_x3w_kernel<8>', 'nc_fwd_x3_kernel<1>', 'nc_fwd_kernel<1>', 'nc_dw_x3_kernel', 'nc_dw_fin_kernel', 'nc_dw_kernel<false>', 'nc_dw_kernel<true>', 'nc_dw_kernel', 'nc_dx_x3_kernel', 'nc_dx_kernel<true>',
                     'gemm16_kernel<0, 0, 1, true, true>', 'gemm16_kernel<0, 1, 1, true, false>',
                     'gemm16_kernel<1, 1, 4, false, false>', 'adam_kernel', 'train_prologue_kernel') if k in pmc]
 txt = f'''# profiles, round 1
@@ -41,7 +41,7 @@ and the instrumented timeline (`tools/exp/gemm_timeline.py`) puts a gemm16 launc
 
 bench.py (un-profiled): **{b['value']} {b['unit']}**, {b['ms_per_step']} ms per train() -- graph mode with the critic + actor steps of
 train(t) on a second stream beside the feature steps of train(t+1) (`config.deferred_critic_actor_branch`; DESIGN.md 2 and 5.0);
-`RLREP_PIPELINE=0` gives the strictly sequential graph: 1 990-2 010 train()/s (0.50 ms).  Box-to-box spread over the gpurun pool
+`RLREP_PIPELINE=0` gives the strictly sequential graph: 2 020-2 040 train()/s (0.49 ms).  Box-to-box spread over the gpurun pool
 is about 5 %.  The kernel table above was collected in the same (pipelined) mode: under rocprofv3 the two streams' kernels are
 serialised, so it shows per-kernel durations, not the overlap.
 
@@ -51,8 +51,8 @@ cpu_baseline: `{json.dumps(b['cpu_baseline'])}`
 
 The noise-critic first layer runs on the bf16 pipe as an exact three-way split (bf16x3, `csrc/x3.h`): `nc_fwd_x3w_kernel<8>` is the critic
 step's four-head launch (2.68 GFLOP; also bench.py's roofline loop, 220 launches), `nc_fwd_x3_kernel<1>` the actor step's two-head launch
-(1.34 GFLOP), `nc_dx_x3_kernel` the actor step's dL/d(mean, log_std); the weight gradient `nc_dw_kernel` stays on fp32 MFMA (`<true>` = the
-128-VGPR build the deferred chain uses, `<false>` = the 233-VGPR build of the sequential form and of the eager PMC passes).
+(1.34 GFLOP), `nc_dx_x3_kernel` the actor step's dL/d(mean, log_std), `nc_dw_x3_kernel` (+ `nc_dw_fin_kernel`, the fixed-order sum of its
+split-K slabs) the critic step's weight gradient (1.34 GFLOP).
 `roofline.us_per_launch` times the four-head launch alone with HIP events on the launch stream.
 
 ## PMC counters (`{tag}_pmc_summary.json`), per launch
@@ -68,8 +68,8 @@ over 21.2 us x 1024 SIMDs x 2.1 GHz = 34 % for the four-head `nc_fwd_x3w_kernel<
 step for 1.9k of matrix-pipe time).  `roofline.frac` prices the launch against 2500 / 6 = 417 TF (six bf16 MFMA flops per fp32 product).
 FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane reads) gives bench.py's `roofline.traffic` =
 2 x FETCH + WRITE = 18.5 MB per four-head launch against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs; each XCD's L2
-fetches its own copy of the 1 MB of weights).  `nc_dw` / `nc_dx_x3` read U (10.5 MB) once: 12.7 / 7.5 MB raw with dword / 8-byte loads
-(uncalibrated / half-counted access widths); the four column tiles of a batch tile that share rows of U are placed on one XCD.
+fetches its own copy of the 1 MB of weights).  `nc_dw_x3` / `nc_dx_x3` read U (10.5 MB) once with dword / 8-byte loads (uncalibrated /
+half-counted access widths in FETCH_SIZE); the column tiles that share rows of U are placed on one XCD.
 
 ## Micro-benchmarks behind the design decisions (`tools/exp/*.hip`, run with gpurun; results quoted in DESIGN.md)
 
