@@ -123,13 +123,16 @@ def test_large_engines_off_gives_the_same_step(monkeypatch):
         assert rel_l2(outs[0][k], outs[1][k]) < 1e-5, k
 
 
-@pytest.mark.parametrize('S,A,B,F,H', [(17, 6, 256, 256, 256), (11, 3, 100, 96, 72), (9, 2, 37, 64, 40), (11, 3, 50, 96, 96)])
+@pytest.mark.parametrize('S,A,B,F,H', [(17, 6, 256, 256, 256), (11, 3, 100, 96, 72), (9, 2, 37, 64, 40), (11, 3, 50, 96, 96),
+                                       (5, 2, 5, 64, 32), (9, 4, 260, 64, 32)])
 def test_vlsac_noise_critic_first_layer_on_bf16x3(S, A, B, F, H, monkeypatch):
     """vlsac at dimensions whose noise-critic first layer (vlsac_agent.py:44-63; 63 % of a train()'s FLOPs) runs on the bf16x3
     engine (noisecritic.hip nc_fwd_x3_kernel): the headline shape, and ragged ones -- batch not a multiple of the 8-row tile,
     hidden width not a multiple of 16, three and two K steps -- against the CPU oracle, two train() calls each.  The last case
     (H = 96) also takes the bf16x3 form of the dX launch (nc_dx_x3_kernel: H % 32 == 0) with a batch that is not a multiple of its
-    4-row tile and F = 96 = one and a half of its 64-column tiles."""
+    4-row tile and F = 96 = one and a half of its 64-column tiles; the weight gradient is the bf16x3 split-K kernel in every case
+    (nc_dw_x3_kernel: ragged last split, partial 64-wide tiles).  The last two: a batch smaller than one tile, and one split of 260 rows
+    over 8 ranges."""
     import ctypes as C
     from rlrep_amd import _lib
     monkeypatch.delenv('RLREP_NC_X3', raising=False)
