@@ -106,8 +106,10 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     # bf16x3 engine: six bf16 MFMA flops are executed per algorithmic fp32 flop, so the ceiling for ALGORITHMIC flops is the dense
     # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NC_X3=0) it is the fp32 MFMA peak
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-    wide = plan[2].value == 128 and os.environ.get('RLREP_NC_X3_WIDE', '1') != '0'      # the launcher's choice (noisecritic.hip rl_launch_nc_fwd)
-    kname = ('nc_fwd_x3w_kernel<8>' if wide else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
+    # the launcher's choice for a 128-wide tile (noisecritic.hip rl_launch_nc_fwd): 32x32x16 one-role kernel, else the 16x16x32 one-role one
+    quad = plan[2].value == 128 and os.environ.get('RLREP_NC_X3_Q', '1') != '0'
+    wide = plan[2].value == 128 and os.environ.get('RLREP_NC_X3_WIDE', '1') != '0'
+    kname = ('nc_fwd_x3q_kernel' if quad else 'nc_fwd_x3w_kernel<8>' if wide else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
     out = {'bound': 'mfma', 'kernel': kname + (' (critic step, 4 heads, bf16x3)' if x3 else ' (critic step, 4 heads)'),
            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
            # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json

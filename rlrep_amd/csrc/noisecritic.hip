@@ -606,6 +606,192 @@ __global__ __launch_bounds__(64 * NW) void nc_fwd_x3w_kernel(NcFwdBatch nb) {
     NCT(3); NCT(5);
 }
 
+// The same step on v_mfma_f32_32x32x16_bf16 (one-role, 4 waves x 32 hidden units = 128 per workgroup, ONE wave per SIMD): a 32x32x16
+// MFMA holds the vector issue port for 8 of its 32 cycles instead of 8 of 16, so the producer's VALU work fits in the shadow of the
+// wave's own MFMAs; a 16-byte fragment read feeds 2x the flops; 322 VGPRs per SIMD stay free for the feature chain.
+// Row mapping: the C/D map of the 32x32 tile gives lane half h = lane >> 5 the rows 8 q + 4 h + i (q, i < 4) of every tile, 16 of its
+// 32 rows; over the five tiles of a step's 160 rows that is 80 slots sigma = 16 t + 4 q + i, which are dealt to (batch row 4 h + sigma / 20,
+// noise row sigma % 20): every lane again owns ALL 20 noise rows of four batch rows for its column, in compile-time register positions.
+typedef float nq_f32x16 __attribute__((ext_vector_type(16)));
+template <int T5, int KB> __device__ __forceinline__ void nq_fload(u32x4 (&d)[3], unsigned addr) {
+    nx_read<T5 * 32 * NX_RSB + KB * 32>(d[0], addr);
+    nx_read<T5 * 32 * NX_RSB + KB * 32 + NX_IMGB>(d[1], addr);
+    nx_read<T5 * 32 * NX_RSB + KB * 32 + 2 * NX_IMGB>(d[2], addr);
+}
+
+__global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
+    constexpr int KV = 4;
+    unsigned char* const L = reinterpret_cast<unsigned char*>(nc_smem);
+    const int bid = blockIdx.x;
+    NCT(0); NCT(4);
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < NC_MAX_TASKS; ++q) if (q < nb.ntasks && bid >= nb.t[q].tile_base) ti = q;
+    const NcFwdTask& t = nb.t[ti];
+    const int local = bid - t.tile_base;
+    const int tb = local / t.tiles_h, th = local - tb * t.tiles_h;
+    const int b0 = tb * 8, n0 = th * 128;
+    const int F = t.F, H = t.H, N = t.N;
+    const int S = F >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    // ---- producer role: thread = (k chunk of 4, batch row, noise group of 5) ----
+    const int kc = tid & 7, pb = (tid >> 3) & 7, ng = tid >> 6;
+    const bool okb = b0 + pb < t.B;
+    const int bsrc = min(b0 + pb, t.B - 1);
+    const float* const pmu = t.mean + (size_t)bsrc * t.ld_ml + kc * KV;
+    const float* const pls = t.lstd + (size_t)bsrc * t.ld_ml + kc * KV;
+    const float* const pnz = t.noise + (size_t)(5 * ng) * F + kc * KV;
+    int wofs[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int sig = (pb & 3) * 20 + 5 * ng + i, rem = sig & 15;
+        const int lrow = 32 * (sig >> 4) + 8 * (rem >> 2) + 4 * (pb >> 2) + (rem & 3);
+        wofs[i] = lrow * NX_RSB + kc * KV * 2;
+    }
+    float* const sig_dst = (t.sigma_out && th == 0 && ng == 0 && okb) ? t.sigma_out + (size_t)(b0 + pb) * F + kc * KV : nullptr;
+
+    // ---- consumer role: 32 columns per wave ----
+    const int c32 = lane & 31, half = lane >> 5;
+    const int col = n0 + 32 * w + c32;
+    const bool colok = col < H;
+    const float* const wrow = t.W + (size_t)min(col, H - 1) * F + 8 * half;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)(c32 * NX_RSB + half * 16);
+
+    f32x4 rmu, rls, rnz[5];
+    f32x4 rw[2][2];
+    auto gload = [&](int s) {
+        const int k = 32 * s;
+        rmu = *reinterpret_cast<const f32x4*>(pmu + k);
+        rls = *reinterpret_cast<const f32x4*>(pls + k);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) rnz[i] = *reinterpret_cast<const f32x4*>(pnz + (size_t)i * F + k);
+    };
+    auto wload = [&](int s) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            rw[kb][0] = *reinterpret_cast<const f32x4*>(wrow + 32 * s + 16 * kb);
+            rw[kb][1] = *reinterpret_cast<const f32x4*>(wrow + 32 * s + 16 * kb + 4);
+        }
+    };
+    float sg[KV];
+    auto produce_begin = [&]() {
+#pragma unroll
+        for (int q = 0; q < KV; ++q) sg[q] = okb ? __expf(clamp_lstd(rls[q])) : 0.f;
+    };
+    auto produce_row = [&](int i, unsigned char* buf) {
+        u32x2 h, m, l;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x0 = okb ? fmaf(sg[2 * q], rnz[i][2 * q], rmu[2 * q]) : 0.f;
+            const float x1 = okb ? fmaf(sg[2 * q + 1], rnz[i][2 * q + 1], rmu[2 * q + 1]) : 0.f;
+            unsigned hh, mm, ll;
+            x3_split2(x0, x1, hh, mm, ll);
+            h[q] = hh; m[q] = mm; l[q] = ll;
+        }
+        unsigned char* p = buf + wofs[i];
+        *reinterpret_cast<u32x2*>(p) = h;
+        *reinterpret_cast<u32x2*>(p + NX_IMGB) = m;
+        *reinterpret_cast<u32x2*>(p + 2 * NX_IMGB) = l;
+    };
+
+    nq_f32x16 acc[5];
+#pragma unroll
+    for (int t5 = 0; t5 < 5; ++t5)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t5][r] = 0.f;
+
+    // (splitting W one step ahead, a quarter per odd fragment in the shadow of the previous step's MFMAs, measured slower: 28.8k vs 25.5k
+    // cycles for the eight steps)
+    auto step = [&](int s, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const unsigned aaddr = lds0 + (unsigned)((s & 1) * NX_BUFB);
+        unsigned char* const nxt = L + ((s + 1) & 1) * NX_BUFB;
+        u32x4 fa[2][3];
+        nq_fload<0, 0>(fa[0], aaddr);
+        bf16x8 Bh[2], Bm[2], Bl[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 bh, bm, bl;
+            unsigned h, m, l;
+            x3_split2(rw[kb][0][0], rw[kb][0][1], h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
+            x3_split2(rw[kb][0][2], rw[kb][0][3], h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
+            x3_split2(rw[kb][1][0], rw[kb][1][1], h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
+            x3_split2(rw[kb][1][2], rw[kb][1][3], h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
+            Bh[kb] = __builtin_bit_cast(bf16x8, bh); Bm[kb] = __builtin_bit_cast(bf16x8, bm); Bl[kb] = __builtin_bit_cast(bf16x8, bl);
+        }
+        if (MORE) { wload(s + 1); produce_begin(); }
+        // fragment J = (tile J / 2, k block J % 2); one noise row of the next step's images per two fragments
+#define NQ_FRAG(J)                                                                                                     \
+        {                                                                                                              \
+            if ((J) + 1 < 10) nq_fload<((J) + 1 < 10 ? ((J) + 1) / 2 : 0), ((J) + 1) % 2>(fa[((J) + 1) & 1], aaddr);   \
+            if (MORE && ((J) & 1) == 0) produce_row((J) >> 1, nxt);                                                    \
+            nx_claim<((J) + 1 < 10)>(fa[(J) & 1]);                                                                     \
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[(J) & 1][0]), Am = __builtin_bit_cast(bf16x8, fa[(J) & 1][1]), \
+                         Al = __builtin_bit_cast(bf16x8, fa[(J) & 1][2]);                                              \
+            nq_f32x16 c = acc[(J) / 2];                                                                                \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[(J) % 2], c, 0, 0, 0);                                  \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[(J) % 2], c, 0, 0, 0);                                  \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm[(J) % 2], c, 0, 0, 0);                                  \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh[(J) % 2], c, 0, 0, 0);                                  \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm[(J) % 2], c, 0, 0, 0);                                  \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[(J) % 2], c, 0, 0, 0);                                  \
+            acc[(J) / 2] = c;                                                                                          \
+        }
+        NQ_FRAG(0) NQ_FRAG(1) NQ_FRAG(2) NQ_FRAG(3) NQ_FRAG(4) NQ_FRAG(5) NQ_FRAG(6) NQ_FRAG(7) NQ_FRAG(8) NQ_FRAG(9)
+#undef NQ_FRAG
+        if (MORE) gload(min(s + 2, S - 1));
+        __syncthreads();
+    };
+
+    gload(0); wload(0);
+    produce_begin();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) produce_row(i, L);
+    gload(S > 1 ? 1 : 0);
+    __syncthreads();
+    NCT(1);
+    for (int s = 0; s + 1 < S; ++s) step(s, std::true_type{});
+    step(S - 1, std::false_type{});
+    NCT(2);
+
+    if (sig_dst) {
+        for (int s = 0; s < S; ++s) {
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(pls + 32 * s);
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < KV; ++q) o[q] = expf(clamp_lstd(ls[q]));
+            *reinterpret_cast<f32x4*>(sig_dst + 32 * s) = o;
+        }
+    }
+    if (!colok) return;
+    // slot sigma = 16 t5 + r of this lane's half: batch row b0 + 4 half + sigma / 20, noise row sigma % 20.  Walked per batch row (static
+    // register positions; the row / store guards are four uniform-ish branches, not eighty)
+    const float bj = t.bias[col];
+    const float invN = 1.0f / (float)N;
+#pragma unroll
+    for (int bl = 0; bl < 4; ++bl) {
+        const int b = b0 + 4 * half + bl;
+        float y[20];
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < 20; ++n) {
+            const int sig = 20 * bl + n;
+            y[n] = elu_fast(acc[sig >> 4][sig & 15] + bj);
+            sum += y[n];
+        }
+        if (b < t.B) {
+            t.Hm[(size_t)b * H + col] = sum * invN;
+            if (t.U) {
+                float* up = t.U + ((size_t)b * N) * H + col;
+#pragma unroll
+                for (int n = 0; n < 20; ++n) up[(size_t)n * H] = y[n];
+            }
+        }
+    }
+    NCT(3); NCT(5);
+}
+
 // ------------------------------------------------------------------------------------------------
 // dL/d(mean, log_std), both heads (actor step).
 // workgroup = 8 waves: waves 0-3 consume head 0, waves 4-7 head 1; wave (w&3) owns 16 feature columns;
@@ -1465,7 +1651,9 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     if (nb->engine == 1) {
         if ((F % 32) != 0 || g2 != 2) return -3;
         static const int wide = [] { const char* e = getenv("RLREP_NC_X3_WIDE"); return e ? atoi(e) : 1; }();
-        if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
+        static const int quad = [] { const char* e = getenv("RLREP_NC_X3_Q"); return e ? atoi(e) : 1; }();
+        if (nb->cols == 128 && quad) hipLaunchKernelGGL(nc_fwd_x3q_kernel, dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
+        else if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
         else if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<2>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
         else hipLaunchKernelGGL((nc_fwd_x3_kernel<1>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
         return (int)hipGetLastError();
@@ -1513,6 +1701,7 @@ extern "C" int rl_nc_init() {
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3w_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e != hipSuccess) return (int)e;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

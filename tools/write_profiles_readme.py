@@ -15,7 +15,7 @@ def row(k):
             f"{d.get('FETCH_SIZE', 0) / 1024:.1f} | {d.get('WRITE_SIZE', 0) / 1024:.1f} | {d.get('SQ_LDS_BANK_CONFLICT', 0):.0f} |")
 
 
-keys = [k for k in ('nc_fwd_x3w_kernel<8>', 'nc_fwd_x3_kernel<1>', 'nc_fwd_kernel<1>', 'nc_dw_x3_kernel', 'nc_dw_fin_kernel', 'nc_dw_kernel<false>', 'nc_dw_kernel<true>', 'nc_dw_kernel', 'nc_dx_x3_kernel', 'nc_dx_kernel<true>',
+keys = [k for k in ('nc_fwd_x3q_kernel', 'nc_fwd_x3w_kernel<8>', 'nc_fwd_x3_kernel<1>', 'nc_fwd_kernel<1>', 'nc_dw_x3_kernel', 'nc_dw_fin_kernel', 'nc_dw_kernel<false>', 'nc_dw_kernel<true>', 'nc_dw_kernel', 'nc_dx_x3_kernel', 'nc_dx_kernel<true>',
                     'gemm16_kernel<0, 0, 1, true, true>', 'gemm16_kernel<0, 1, 1, true, false>',
                     'gemm16_kernel<1, 1, 4, false, false>', 'adam_kernel', 'train_prologue_kernel') if k in pmc]
 txt = f'''# profiles, round 1
@@ -25,7 +25,7 @@ rocprofv3 output collected on one MI355X (gpurun box) with these commands (`cd /
 
 * `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_{tag}b -- python3 bench.py --steps 300 --warmup 30 --no-cpu`
   -> `{tag}_vlsac_b256_kernel_stats.csv` (workload vlsac_halfcheetah_f256_b256, hipGraph replay; 331 train() calls incl.
-  capture/warm-up, plus bench.py's roofline loop: 220 extra critic-stage `nc_fwd_x3w_kernel<8>` launches)
+  capture/warm-up, plus bench.py's roofline loop: 220 extra critic-stage `nc_fwd_x3q_kernel` launches)
 * three separate `--pmc` passes, `--kernel-trace` only (`tools/_pmc.sh`, eager launches, 25 train() calls each)
   -> `{tag}_pmc_summary.json` (per-kernel mean over dispatches of the per-dispatch sums)
 * un-profiled `python bench.py` on the same box -> `{tag}_bench.json`
@@ -49,7 +49,7 @@ roofline: `{json.dumps(b['roofline'])}`
 
 cpu_baseline: `{json.dumps(b['cpu_baseline'])}`
 
-The noise-critic first layer runs on the bf16 pipe as an exact three-way split (bf16x3, `csrc/x3.h`): `nc_fwd_x3w_kernel<8>` is the critic
+The noise-critic first layer runs on the bf16 pipe as an exact three-way split (bf16x3, `csrc/x3.h`): `nc_fwd_x3q_kernel` is the critic
 step's four-head launch (2.68 GFLOP; also bench.py's roofline loop, 220 launches), `nc_fwd_x3_kernel<1>` the actor step's two-head launch
 (1.34 GFLOP), `nc_dx_x3_kernel` the actor step's dL/d(mean, log_std), `nc_dw_x3_kernel` (+ `nc_dw_fin_kernel`, the fixed-order sum of its
 split-K slabs) the critic step's weight gradient (1.34 GFLOP).
