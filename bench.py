@@ -49,10 +49,10 @@ ALG_GFLOP = {'vlsac_halfcheetah_f256_b256': 10.59, 'sac_halfcheetah_b256': 0.582
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md); the bf16x3 tile executes 6 bf16 MFMA flops per algorithmic fp32 flop
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
-# HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r01_pmc_summary.json (nc_fwd_x3w_kernel<8>:
-# FETCH_SIZE 3251.0 KB raw, x2 for 16-byte reads on gfx950, + WRITE_SIZE 11520.0 KB): 18.5 MB against 11.0 MB algorithmic (10.5 MB of
+# HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r01_pmc_summary.json (nc_fwd_x3q_kernel:
+# FETCH_SIZE 3279.0 KB raw, x2 for 16-byte reads on gfx950, + WRITE_SIZE 11520.0 KB): 18.5 MB against 11.0 MB algorithmic (10.5 MB of
 # ELU outputs written + tables and weights read once; every XCD's L2 fetches its own copy of the 1 MB of weights)
-NC_FWD_TRAFFIC_BYTES = int((2 * 3251.0 + 11520.0) * 1024)
+NC_FWD_TRAFFIC_BYTES = int((2 * 3279.0 + 11520.0) * 1024)
 
 
 class Space:

@@ -740,6 +740,7 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
         }
         NQ_FRAG(0) NQ_FRAG(1) NQ_FRAG(2) NQ_FRAG(3) NQ_FRAG(4) NQ_FRAG(5) NQ_FRAG(6) NQ_FRAG(7) NQ_FRAG(8) NQ_FRAG(9)
 #undef NQ_FRAG
+        // (a sched_group_barrier pipeline {1 MFMA, 4-6 VALU} x 60 over this block changed nothing: 22.7-24.5 us against 22.7)
         if (MORE) gload(min(s + 2, S - 1));
         __syncthreads();
     };

@@ -61,11 +61,12 @@ split-K slabs) the critic step's weight gradient (1.34 GFLOP).
 |---|---|---|---|---|---|---|
 ''' + '\n'.join(row(k) for k in keys) + '''
 
-VALU_MFMA_BUSY / (launch time x 1024 SIMDs x clock) is the chip-wide matrix-pipe utilisation: 15.7 M busy cycles (983 040 bf16 MFMAs x 16)
-over 21.2 us x 1024 SIMDs x 2.1 GHz = 34 % for the four-head `nc_fwd_x3w_kernel<8>` launch -- the same product on fp32 MFMA kept its pipe
-60 % busy for 30.8 us.  The x3 kernels are bound by vector-instruction ISSUE, not by the matrix pipe: SQ_INSTS_VALU / SQ_INSTS_MFMA = 4.3
-(forward) and 5.9 (dX) with the bf16 MFMA holding the issue port for 8 of its 16 cycles (tools/exp/nc_timeline.py: 3.3k cycles per 32-deep
-step for 1.9k of matrix-pipe time).  `roofline.frac` prices the launch against 2500 / 6 = 417 TF (six bf16 MFMA flops per fp32 product).
+VALU_MFMA_BUSY / (launch time x 1024 SIMDs x clock) is the chip-wide matrix-pipe utilisation: 15.7 M busy cycles (491 520 bf16 MFMAs
+of 32 cycles) over 22.6 us x 1024 SIMDs x 2.0 GHz = 34 % for the four-head `nc_fwd_x3q_kernel` launch -- the same product on fp32 MFMA kept
+its pipe 60 % busy for 30.8 us.  The x3 kernels are bound by vector-instruction ISSUE and its scheduling, not by the matrix pipe:
+SQ_INSTS_VALU / SQ_INSTS_MFMA = 7.5 (x3q, 32x32x16), 6.1 (two-head forward, 16x16x32), 5.9 (dX), 9.2 (dW); tools/exp/nc_timeline.py
+puts a 32-deep step at 3.2k cycles for 1.9k of matrix-pipe time.  `roofline.frac` prices the launch against 2500 / 6 = 417 TF (six bf16
+MFMA flops per fp32 product).
 FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane reads) gives bench.py's `roofline.traffic` =
 2 x FETCH + WRITE = 18.5 MB per four-head launch against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs; each XCD's L2
 fetches its own copy of the 1 MB of weights).  `nc_dw_x3` / `nc_dx_x3` read U (10.5 MB) once with dword / 8-byte loads (uncalibrated /
