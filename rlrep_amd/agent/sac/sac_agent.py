@@ -642,7 +642,7 @@ class SACAgent(object):
             P['ev_ca'][k].record(s_ca)
         P['used'][k] = True
         self._pending = 2
-        return self.core.info(lazy_source=self._flushed_metrics)
+        return self.core.info(lazy_source=self._flushed_metrics, early=(self.FEATURE_KEYS, self._feature_metrics_of(P['ev_snap'][k])))
 
     # ---- data parallel + deferred critic / actor chain ---------------------------------------------------------------------------
     # The two launch chains of the pipelined mode, each cut into hipGraph segments at its gradient all-reduces (feature chain: 4,
@@ -729,6 +729,14 @@ class SACAgent(object):
     def _flushed_metrics(self):
         self.flush()
         return self.core.metrics_tensor().clone()
+
+    def _feature_metrics_of(self, ev_feature_done):
+        """Source of the feature-step losses of a pipelined train(): they are final once its feature chain has ended (the event), while its
+        critic / actor chain may still be running -- reading only those keys does not end the overlap with the next call."""
+        def fetch():
+            ev_feature_done.synchronize()
+            return self.core.metrics_tensor().clone()
+        return fetch
 
     def flush(self):
         """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""

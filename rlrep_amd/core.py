@@ -26,9 +26,13 @@ class LazyInfo(dict):
     Q14), each a device sync; here the metric slots are snapshotted on the device and only fetched when a
     value is actually read (main.py reads `info` once per 5000 steps)."""
 
-    def __init__(self, names, snapshot):
+    def __init__(self, names, snapshot, early=None):
+        """early = (keys, callable): a subset of the metrics that is final BEFORE the full snapshot is (pipelined train(): the feature
+        steps' losses are final when the feature chain ends, while the critic / actor chain is still running); reading only such keys
+        fetches them through `callable` and does not wait for the rest."""
         super().__init__()
         self._names, self._snap, self._done = names, snapshot, False
+        self._early_keys, self._early_snap, self._early_done = (frozenset(early[0]), early[1], False) if early else (frozenset(), None, False)
         for n in names:
             if n:
                 dict.__setitem__(self, n, None)
@@ -42,8 +46,19 @@ class LazyInfo(dict):
                     dict.__setitem__(self, n, float(vals[i]))
             self._done = True
 
+    def _fetch_early(self):
+        if not (self._done or self._early_done):
+            vals = self._early_snap().cpu().numpy()
+            for i, n in enumerate(self._names):
+                if n in self._early_keys:
+                    dict.__setitem__(self, n, float(vals[i]))
+            self._early_done = True
+
     def __getitem__(self, k):
-        self._fetch()
+        if k in self._early_keys and not self._done:
+            self._fetch_early()
+        else:
+            self._fetch()
         return dict.__getitem__(self, k)
 
     def get(self, k, d=None):
@@ -288,10 +303,10 @@ class HipCore:
             self._mt = self.workspace[off:off + 4 * METRIC_SLOTS].view(torch.float32)
         return self._mt
 
-    def info(self, keys=None, lazy_source=None):
+    def info(self, keys=None, lazy_source=None, early=None):
         snap = lazy_source if lazy_source is not None else self.metrics_tensor().clone()
         names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]
-        return LazyInfo(names, snap)
+        return LazyInfo(names, snap, early)
 
     def stages(self, program):
         n = lib.rlrep_stage_count(self.h, program)

@@ -493,3 +493,30 @@ def test_deferred_pipeline_sees_rows_added_between_calls():
         outs.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_pipelined_info_early_keys_match_sequential():
+    """The feature-step losses of a pipelined train() can be read as soon as its feature chain has ended (LazyInfo early keys), without
+    flushing the critic / actor chain; every value read that way, and the critic / actor values read afterwards from the same dict, equal
+    the sequential graph mode's."""
+    c = Case('vlsac_tiny')
+    seen = []
+    for pipe in (True, False):
+        kw = dict(c.kw)
+        if c.meta.get('patch_vae_hidden'):
+            kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+        cls = type(make_agent(c))
+        agent = cls(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, graph=True, pipeline=pipe,
+                    seed=5, **kw)
+        agent.core.load_state(c.init)
+        buf = make_buffer(c)
+        vals = []
+        for t in range(8):
+            info = agent.train(buf, c.B)
+            vals.append((info['kl_loss'], info['vae_loss']))            # early keys only: no flush in pipelined mode
+            if pipe and t < 7:
+                assert agent._pending, 'reading feature losses must not end the overlap'
+            if t % 3 == 2:
+                vals.append((info['q1_loss'], info['actor_loss'], info['kl_loss']))   # then the rest of the same dict
+        seen.append(vals)
+    assert seen[0] == seen[1]
