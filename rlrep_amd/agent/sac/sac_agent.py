@@ -724,7 +724,7 @@ class SACAgent(object):
         P['used'][k] = True
         P['prev'] = k
         self._pending = 3
-        return self.core.info(lazy_source=self._flushed_metrics)
+        return self.core.info(lazy_source=self._flushed_metrics, early=(self.FEATURE_KEYS, self._feature_metrics_of(P['ev_snap'][k])))
 
     def _flushed_metrics(self):
         self.flush()
