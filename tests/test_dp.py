@@ -304,3 +304,65 @@ def test_hip_dp_over_rccl_one_rank_equals_single_gpu():
         for k, v in out['single'][1].items():
             assert np.array_equal(v, out[mode][1][k]), f'{mode} != single GPU at {k}'
         assert out[mode][2] == out['single'][2]
+
+
+def _gpu_pipe_big_worker(rank, world, port, q, pipelined):
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
+    os.environ['RLREP_PIPELINE_DP'] = '1' if pipelined else '0'
+    try:
+        dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        torch.manual_seed(0)
+
+        class Sp:
+            low, high = -np.ones(6, np.float32), np.ones(6, np.float32)
+        agent = VLSACAgent(state_dim=17, action_dim=6, action_space=Sp(), max_batch=256, seed=41, hidden_dim=256, feature_dim=256,
+                           extra_feature_steps=3)
+        data = synth.replay(17, 6, 4096, seed=10 + rank)                 # every rank its own shard
+        buf = ReplayBuffer(17, 6, max_size=4096)
+        buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+        for t in range(30):
+            info = agent.train(buf, 256)
+            if t == 11:
+                float(info['kl_loss'])                                   # an early key: must not disturb the schedule
+        agent.flush()
+        torch.cuda.synchronize()
+        st = {k: v.numpy() for k, v in agent.core.state().items()}
+        q.put((rank, st, bool(agent._pipe is not None and agent._pipe.get('mode') == 3)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+
+
+@pytest.mark.gpu
+def test_hip_dp_pipelined_headline_dims():
+    """Two ranks (gloo, one GPU), BASELINE config-2 dimensions (the bf16x3 noise-critic kernels, split-K weight gradient, two-stream
+    schedule with graph segments between the six all-reduces), 30 train() calls on per-rank replay shards: replicas bit-identical, and
+    the pipelined schedule ends exactly where the sequential data-parallel one does."""
+    out = {}
+    for pipelined in (True, False):
+        world, port = 2, _free_port()
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_gpu_pipe_big_worker, args=(r, world, port, q, pipelined)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(world):
+            r = q.get(timeout=400)
+            assert isinstance(r[1], dict), r[1]
+            res[r[0]] = r
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert res[0][2] == pipelined
+        for k, v in res[0][1].items():
+            assert np.all(np.isfinite(v)), k
+            assert np.array_equal(v, res[1][1][k]), f'replicas diverged at {k} (pipelined={pipelined})'
+        out[pipelined] = res[0][1]
+    for k, v in out[True].items():
+        assert np.array_equal(v, out[False][k]), f'pipelined != sequential at {k}'
