@@ -67,7 +67,8 @@ its pipe 60 % busy for 30.8 us.  The x3 kernels are bound by vector-instruction 
 SQ_INSTS_VALU / SQ_INSTS_MFMA = 7.5 (x3q, 32x32x16), 6.1 (two-head forward, 16x16x32), 5.9 (dX), 9.2 (dW); tools/exp/nc_timeline.py
 puts a 32-deep step at 3.2k cycles for 1.9k of matrix-pipe time.  `roofline.frac` prices the launch against 2500 / 6 = 417 TF (six bf16
 MFMA flops per fp32 product).
-FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane reads) gives bench.py's `roofline.traffic` =
+WRITE_SIZE of the four-head forward, 11 520 KB, is exactly its stores (U 10 485 760 + Hm 1 048 576 + sigma 262 144 bytes): the counter is
+calibrated for this kernel's dword stores.  FETCH_SIZE is raw (KB as reported / 1024); the guide's gfx950 rule (x2 for 16-byte-per-lane reads) gives bench.py's `roofline.traffic` =
 2 x FETCH + WRITE = 18.5 MB per four-head launch against 11.0 MB algorithmic (10.5 MB of elu outputs U written + inputs; each XCD's L2
 fetches its own copy of the 1 MB of weights).  `nc_dw_x3` / `nc_dx_x3` read U (10.5 MB) once with dword / 8-byte loads (uncalibrated /
 half-counted access widths in FETCH_SIZE); the column tiles that share rows of U are placed on one XCD.
