@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# HIP maps streams onto a few hardware queues (4 by default) and streams that share one are serialised.  The pipelined train() uses two
+# streams (plus, with N > 1 ranks, one RCCL stream per process group): give the runtime enough queues, before it initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 import numpy as np
 import torch
 

@@ -166,6 +166,7 @@ class SACAgent(object):
         # critic / actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (vlsac; _train_graph_pipelined)
         self.use_pipeline = bool(int(os.environ.get('RLREP_PIPELINE', '1'))) and hip_kwargs.get('pipeline', True)
         self.use_pipeline_dp = bool(int(os.environ.get('RLREP_PIPELINE_DP', '1')))
+        self._pg_ca = None           # second process group (own communicator / stream) for the deferred chain's all-reduces; see _train_graph_dp_pipelined
         self._pipe = None
         self._pending = False
         self.core.before_read = self.flush
@@ -313,13 +314,13 @@ class SACAgent(object):
     def _feature_once(self, buffer, B, i, g):
         raise NotImplementedError
 
-    def _allreduce(self, group, with_tail=False):
+    def _allreduce(self, group, with_tail=False, pg=None):
         import torch.distributed as dist
         lay = self.core.layout
         o, n = lay.group_offset[group], lay.group_floats[group]
         end = lay.grad_floats if with_tail else o + n
         view = self.core.grads[o:end]
-        self._collective(lambda: dist.all_reduce(view))
+        self._collective(lambda: dist.all_reduce(view, group=pg))
 
     def _collective(self, fn):
         """Run a torch.distributed call now, or -- during segmented capture (data parallel + hipGraph) -- close the
@@ -548,7 +549,7 @@ class SACAgent(object):
         """ReplayBuffer hook: the caller's stream is about to overwrite ring rows / the size scalar that the feature chain of the
         pipelined train() in flight may still be sampling from on its own stream -- make the caller's stream wait for that chain."""
         P = self._pipe
-        if P is not None and self._pending in (2, 3) and P.get('last_f') is not None:
+        if P is not None and self._pending == 2 and P.get('last_f') is not None:
             torch.cuda.current_stream().wait_event(P['last_f'])
 
     def _train_graph_pipelined(self, buffer, B):
@@ -646,10 +647,11 @@ class SACAgent(object):
 
     # ---- data parallel + deferred critic / actor chain ---------------------------------------------------------------------------
     # The two launch chains of the pipelined mode, each cut into hipGraph segments at its gradient all-reduces (feature chain: 4,
-    # critic/actor chain: 2).  ONE process group, ONE fixed issue order per train() on every rank (no cross-rank ordering hazard); the
-    # critic/actor items of train(t) are issued INTERLEAVED with the feature items of train(t+1) in the order their gradients become
-    # ready (f0, critic, f1, actor, f2, f3), so the communicator's in-order queue does not hold a ready all-reduce behind an unready one.
-    _DP_ORDER = ('F', 'C', 'F', 'C', 'C', 'F', 'F', 'C', 'C', 'F', 'F', 'F', 'F', 'F')   # gF0 gC0 cF0 cC gC1 gF1 cF1 cA gC2 gF2 cF2 gF3 cF3 gF4
+    # critic/actor chain: 2).  Each chain has its OWN process group (communicator + RCCL stream): within a communicator the issue
+    # order is the program order of one chain, identical on every rank; the two communicators never wait for each other, so the
+    # feature chain's all-reduces of train(t+1) are not queued behind the critic / actor ones of train(t); and BOTH chains of a call are
+    # issued by that call -- flush() (reading a returned info dict, select_action, ...) only waits, it never issues a collective, so a
+    # rank that reads its metrics while the others do not cannot desynchronise the ranks.
 
     def _capture_segments(self, fn):
         first = torch.cuda.CUDAGraph()
@@ -665,6 +667,9 @@ class SACAgent(object):
         return segs
 
     def _train_graph_dp_pipelined(self, buffer, B):
+        if self._pg_ca is None:
+            import torch.distributed as dist
+            self._pg_ca = dist.new_group()             # collective: every rank reaches its first pipelined train() (same program)
         if getattr(buffer, 'before_device_write', 0) is None:
             buffer.before_device_write = self._order_buffer_writes
         buffer.flush()
@@ -690,40 +695,36 @@ class SACAgent(object):
                     fs.append(self._capture_segments(feature_chain))
 
                     def ca_chain(k=k):
-                        c.deferred_part(k, 0); self._allreduce(1); c.deferred_part(k, 1)
-                        c.deferred_part(k, 2); self._allreduce(2, True); c.deferred_part(k, 3)
+                        c.deferred_part(k, 0); self._allreduce(1, pg=self._pg_ca); c.deferred_part(k, 1)
+                        c.deferred_part(k, 2); self._allreduce(2, True, pg=self._pg_ca); c.deferred_part(k, 3)
                     cs.append(self._capture_segments(ca_chain))
             torch.cuda.current_stream().wait_stream(cap)
             torch.cuda.synchronize()
             s_ca, s_f = _concurrent_stream_pair(c)
             self._pipe = dict(key=key, mode=3, t=0, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
-                              ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False], prev=None)
+                              ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
         P = self._pipe
         k = P['t'] & 1
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
         cur = torch.cuda.current_stream()
         s_f.wait_stream(cur)
+        if not self._pending:
+            s_ca.wait_stream(cur)
         if P['used'][k]:
             s_f.wait_event(P['ev_ca'][k])                  # the pair that read this snapshot set last (train t-2)
-        F = list(P['fs'][k])
-        prev = P['prev']
-        C = list(P['cs'][prev]) if prev is not None else []
-        if C:
-            s_ca.wait_event(P['ev_snap'][prev])
-        order = list(self._DP_ORDER) if C and len(F) == 9 and len(C) == 5 else ['F'] * len(F) + ['C'] * len(C)
-        for chain in order:
-            kind, x = (F if chain == 'F' else C).pop(0)
-            with torch.cuda.stream(s_f if chain == 'F' else s_ca):
+        with torch.cuda.stream(s_f):
+            for kind, x in P['fs'][k]:
                 x.replay() if kind == 'graph' else x()
-        assert not F and not C
-        P['ev_snap'][k].record(s_f)
+            P['ev_snap'][k].record(s_f)
         P['last_f'] = P['ev_snap'][k]
-        if prev is not None:
-            P['ev_ca'][prev].record(s_ca)
+        with torch.cuda.stream(s_ca):
+            s_ca.wait_event(P['ev_snap'][k])
+            for kind, x in P['cs'][k]:
+                x.replay() if kind == 'graph' else x()
+            P['ev_ca'][k].record(s_ca)
         P['used'][k] = True
-        P['prev'] = k
-        self._pending = 3
+        self._pending = 2
         return self.core.info(lazy_source=self._flushed_metrics, early=(self.FEATURE_KEYS, self._feature_metrics_of(P['ev_snap'][k])))
 
     def _flushed_metrics(self):
@@ -740,20 +741,7 @@ class SACAgent(object):
 
     def flush(self):
         """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""
-        if self._pending == 3:                         # data parallel: the last train()'s critic / actor chain has not been issued yet
-            self._pending = False
-            P = self._pipe
-            prev, s_ca = P['prev'], P['s_ca']
-            s_ca.wait_event(P['ev_snap'][prev])
-            with torch.cuda.stream(s_ca):
-                for kind, x in P['cs'][prev]:
-                    x.replay() if kind == 'graph' else x()
-            P['ev_ca'][prev].record(s_ca)
-            P['prev'] = None
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(s_ca)
-            cur.wait_stream(P['s_f'])
-        elif self._pending == 2:                       # two-stream form: the pair is already in flight on its own stream
+        if self._pending == 2:                         # two-stream forms: the pair is already in flight on its own streams
             self._pending = False
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._pipe['s_ca'])

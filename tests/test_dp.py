@@ -215,6 +215,8 @@ def _gpu_pipe_worker(rank, world, port, q, pipelined):
         info = agent.train(buf, c.B)
         if t == 3:
             agent.select_action(np.zeros(c.S, np.float32))
+        if rank == 0 and t in (1, 4):
+            float(info['q1_loss'])         # ONE rank reads a critic metric (a flush): flush() issues no collective, the ranks stay in step
     last = float(info['q1_loss'])
     torch.cuda.synchronize()
     took = bool(agent._pipe is not None and agent._pipe.get('mode') == 3)
