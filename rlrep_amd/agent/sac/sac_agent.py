@@ -545,6 +545,15 @@ class SACAgent(object):
             self._feature_once(buffer, B, i, True)
         return self._pool['eps_crit'], self._pool['eps_act']
 
+    def _wait_set_free(self, P, k, s_f):
+        """Snapshot set k is about to be overwritten by the feature chain of this call: the critic / actor chain that read it last
+        (train t-2) must have finished.  Waited for on the HOST: a wait packet in the feature stream costs ~12 us of its critical path
+        (2 816 -> 2 917 train()/s); the host then runs at most two calls ahead of the device.  RLREP_HOST_REUSE_WAIT=0: stream wait."""
+        if os.environ.get('RLREP_HOST_REUSE_WAIT', '1') != '0':
+            P['ev_ca'][k].synchronize()
+        else:
+            s_f.wait_event(P['ev_ca'][k])
+
     def _order_buffer_writes(self):
         """ReplayBuffer hook: the caller's stream is about to overwrite ring rows / the size scalar that the feature chain of the
         pipelined train() in flight may still be sampling from on its own stream -- make the caller's stream wait for that chain."""
@@ -633,7 +642,7 @@ class SACAgent(object):
             s_ca.wait_stream(cur)
         with torch.cuda.stream(s_f):
             if P['used'][k]:
-                s_f.wait_event(P['ev_ca'][k])                  # the pair that read this set last (train t-2)
+                self._wait_set_free(P, k, s_f)
             P['fs'][k].replay()
             P['ev_snap'][k].record(s_f)
             P['last_f'] = P['ev_snap'][k]
@@ -712,7 +721,8 @@ class SACAgent(object):
         if not self._pending:
             s_ca.wait_stream(cur)
         if P['used'][k]:
-            s_f.wait_event(P['ev_ca'][k])                  # the pair that read this snapshot set last (train t-2)
+            s_f.wait_event(P['ev_ca'][k])                  # the pair that read this snapshot set last (train t-2); a stream wait here: the
+                                                           # host, which issues 14 items per call in this form, must keep its run-ahead
         with torch.cuda.stream(s_f):
             for kind, x in P['fs'][k]:
                 x.replay() if kind == 'graph' else x()
