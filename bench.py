@@ -257,9 +257,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        agent.train(buf, B)
-    agent.flush()
+    try:
+        for _ in range(args.warmup):
+            agent.train(buf, B)
+        agent.flush()
+    except Exception as e:          # noqa: BLE001 -- insurance for the N > 1 run nobody could rehearse on a one-GPU box
+        # the same program runs on every rank, so an exception of the pipelined data-parallel form is raised on all of them: fall back
+        # to the sequential data-parallel form (graph segments between collectives on one stream) and say so in the JSON line
+        if not (getattr(agent, '_dp', False) and getattr(agent, 'use_pipeline_dp', False)):
+            raise
+        sys.stderr.write(f'[bench rank {rank}] pipelined data-parallel train() failed ({type(e).__name__}: {e}); sequential form instead\n')
+        agent.use_pipeline_dp = False
+        agent._pipe, agent._pending, agent._graph = None, False, None
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            agent.train(buf, B)
+        agent.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
