@@ -218,15 +218,27 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=int(os.environ.get('RLREP_CPU_THREADS', 16)))
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--replicas', action='store_true',
+                    help='N > 1: N independent agents (own parameters, own replay, NO gradient all-reduce) instead of data-parallel training')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no HIP call, no
+        # torch.cuda query), the ranks are CHILD processes of torch.distributed.run and rank 0's JSON line is relayed as is.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
-                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    replicas = args.replicas and world > 1          # N independent B-sized agents, no collective: the literal "steps at batch=B" reading
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dist = None
     force_dp = world == 1 and os.environ.get('RLREP_FORCE_DP') == '1'    # rehearsal: DP step forms over a one-rank RCCL group
@@ -236,18 +248,24 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
     if world > 1 or force_dp:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('RLREP_DIST_BACKEND', 'nccl')      # 'gloo' lets two ranks share one GPU in tests
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
     if args.no_graph:
         os.environ['RLREP_GRAPH'] = '0'
 
     alg, S, A, B, kw = WORKLOADS[args.workload]
     torch.manual_seed(0)
+    if replicas:
+        # independent replicas: the agent must not see the process group (it would broadcast parameters and all-reduce gradients)
+        import rlrep_amd.agent.sac.sac_agent as _sa
+        _sa._world = lambda: (1, 0)
+        torch.manual_seed(rank)
     agent = make_agent(alg, S, A, B, kw)
     buf, data = synth_buffer(S, A, seed=rank)
 

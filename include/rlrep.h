@@ -181,6 +181,9 @@ int32_t rlrep_replay_sample(rlrep_agent* agent, int32_t slot, const float* ring_
 /* Philox4x32-10 fills: uniform indices in [0,hi) and N(0,1) noise (counter-based, replayable). */
 int32_t rlrep_fill_indices(int32_t* dst_dev, int64_t n, int32_t hi, uint64_t seed, uint64_t offset, void* stream);
 int32_t rlrep_fill_normal(float* dst_dev, int64_t n, float std, uint64_t seed, uint64_t offset, void* stream);
+/* The bare Philox4x32-10 bijection the fills are built on, for known-answer tests (Random123 kat_vectors):
+ * ctr_key_dev uint32[n][6] = (counter x4, key x2) -> out_dev uint32[n][4].  Not on any hot path. */
+int32_t rlrep_philox_raw(const uint32_t* ctr_key_dev, uint32_t* out_dev, int64_t n, void* stream);
 
 /* Graph-replay-safe variants: the Philox offset is `offset + *counter_dev` and the index range is `*hi_dev`,
  * both read on the device at execution time (rlrep_steps_dev() is the agent's train() counter). */
@@ -189,6 +192,10 @@ int32_t rlrep_fill_indices_dev(int32_t* dst_dev, int64_t n, const int32_t* hi_de
 int32_t rlrep_fill_normal_dev(float* dst_dev, int64_t n, float std, uint64_t seed, uint64_t offset,
                               const int32_t* counter_dev, void* stream);
 const int32_t* rlrep_steps_dev(rlrep_agent* agent);
+/* The four optimizer groups' device records: 14 32-bit words each -- {int32 step; float lr, beta1, beta2, eps, tau; 8 derived floats
+ * recomputed on every step}.  A checkpoint restores `step` only and keeps the constructor's hyper-parameters (rlrep_amd/agent/sac). */
+const void* rlrep_group_cfg_dev(rlrep_agent* agent);
+#define RLREP_GROUP_CFG_WORDS 14
 
 /* ---- launch-saving forms of the sampling calls (graph-replayed train()) -------------------------
  * rlrep_train_prologue == rlrep_begin_train + rlrep_fill_indices_dev(idx_pool) + rlrep_fill_normal_dev(eps_pool) +

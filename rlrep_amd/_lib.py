@@ -85,9 +85,11 @@ def _load():
         'rlrep_replay_sample': (i32, [vp, i32, vp, vp, i32, vp]),
         'rlrep_fill_indices': (i32, [vp, i64, i32, u64, u64, vp]),
         'rlrep_fill_normal': (i32, [vp, i64, f32, u64, u64, vp]),
+        'rlrep_philox_raw': (i32, [vp, vp, i64, vp]),
         'rlrep_fill_indices_dev': (i32, [vp, i64, vp, u64, u64, vp, vp]),
         'rlrep_fill_normal_dev': (i32, [vp, i64, f32, u64, u64, vp, vp]),
         'rlrep_steps_dev': (vp, [vp]),
+        'rlrep_group_cfg_dev': (vp, [vp]),
         'rlrep_feature_step': (i32, [vp, vp, vp, vp]),
         'rlrep_prefetch_policy': (i32, [vp, vp]),
         'rlrep_prefetch_policy_early': (i32, [vp, vp, vp]),

@@ -39,6 +39,7 @@ class CTRLSACAgent(SACAgent):
 
     def feature_step(self, batch):
         """ctrlsac_agent.py:213-251 (+ update_feature_target :253-255 fused into the optimizer launch)."""
+        self.flush()          # nothing of a pipelined train() may still be reading the slot / writing the feature parameters
         self._set_batch(batch)
         self.core.feature_step(None)
         return self.core.info(self.FEATURE_KEYS)

@@ -24,7 +24,7 @@ def _beta_cdf(x, a, b, n=200001):
                 continue
             u = np.linspace(0.0, xv ** aa, n)
             f = (1.0 - u ** (1.0 / aa)) ** (bb - 1.0) / aa
-            out[i] = np.trapz(f, u)
+            out[i] = np.sum((f[1:] + f[:-1]) * np.diff(u)) * 0.5          # trapezoid rule
         return out
     Bab = exp(lgamma(a) + lgamma(b) - lgamma(a + b))
     res = np.empty_like(x)
@@ -34,16 +34,29 @@ def _beta_cdf(x, a, b, n=200001):
     return res
 
 
-def generate_alphabars(a, b, num_alphas):
-    """diffsrsac_agent.py:178-203 (noise_alphabars only; noise_alphas is never used in training)."""
+def _raw_alphabars(a, b, num_alphas):
     x = np.linspace(0, 1, num_alphas)
     try:
         from scipy.stats import beta
         cdf = beta.cdf(x, a, b)
     except Exception:
         cdf = _beta_cdf(x, a, b)
-    raw = 1. - cdf
+    return 1. - cdf
+
+
+def generate_alphabars(a, b, num_alphas):
+    """diffsrsac_agent.py:178-203, the noise_alphabars half: 1 - BetaCDF(x; a, b) on a uniform grid, clipped to its second and
+    second-to-last values (so that neither alphabar = 1 nor alphabar = 0 is ever drawn)."""
+    raw = _raw_alphabars(a, b, num_alphas)
     return np.clip(raw, a_min=raw[-2], a_max=raw[1]).astype(np.float32)
+
+
+def generate_alphas(a, b, num_alphas, max_beta=0.99):
+    """The noise_alphas half (never read by training, diffsrsac_agent.py:150-153): per-step alpha_i = 1 - beta_i with
+    beta_i = min(1 - abar_{i+1} / abar_i, 0.99) taken on the UNCLIPPED schedule, the first beta repeated in front."""
+    raw = _raw_alphabars(a, b, num_alphas)
+    betas = np.minimum(1.0 - raw[1:] / raw[:-1], max_beta)
+    return (1.0 - np.concatenate([betas[:1], betas])).astype(np.float32)
 
 
 class DIFFSRSACAgent(SACAgent):
@@ -82,12 +95,18 @@ class DIFFSRSACAgent(SACAgent):
         ab = generate_alphabars(self._ab[0], self._ab[1], self.num_noises)
         self.core.view('noise_alphabars').reshape(-1).copy_(torch.from_numpy(ab).reshape(-1))
 
+    @staticmethod
+    def generate_alphabars_and_alphas(a, b, num_alphas):
+        """diffsrsac_agent.py:178-203: -> (alphabars float32[num_alphas], alphas float32[num_alphas]) as CPU tensors."""
+        return torch.from_numpy(generate_alphabars(a, b, num_alphas)), torch.from_numpy(generate_alphas(a, b, num_alphas))
+
     @property
     def noise_alphabars(self):
         return self.core.view('noise_alphabars').reshape(-1)
 
     def critic_feeder_feature_step(self, batch, noise_idx=None, eps=None):
         """diffsrsac_agent.py:271-318."""
+        self.flush()          # nothing of a pipelined train() may still be reading the slot / writing the feature parameters
         self._set_batch(batch)
         B = self._B
         if noise_idx is None:

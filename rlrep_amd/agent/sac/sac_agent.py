@@ -35,6 +35,21 @@ class ArenaModule(nn.Module):
                 mod = getattr(mod, p)
             mod.register_parameter(parts[-1], nn.Parameter(core.view(name), requires_grad=False))
 
+    def _quiesce(self):
+        # the parameters are raw arena views: a pipelined train() may still be writing them on its own streams
+        hook = getattr(self._core_ref[0], 'before_read', None)
+        if hook is not None:
+            hook()
+            torch.cuda.current_stream().synchronize()
+
+    def state_dict(self, *args, **kwargs):
+        self._quiesce()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._quiesce()
+        return super().load_state_dict(*args, **kwargs)
+
 
 _STREAM_PAIR = {}
 
@@ -165,7 +180,9 @@ class SACAgent(object):
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
         # critic / actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (vlsac; _train_graph_pipelined)
         self.use_pipeline = bool(int(os.environ.get('RLREP_PIPELINE', '1'))) and hip_kwargs.get('pipeline', True)
-        self.use_pipeline_dp = bool(int(os.environ.get('RLREP_PIPELINE_DP', '1')))
+        # two communicators in flight (one per chain): never met a second real rank on hardware, so it is opt-in (RLREP_PIPELINE_DP=1);
+        # the default N > 1 form is the sequential one (one communicator, program order identical on every rank)
+        self.use_pipeline_dp = bool(int(os.environ.get('RLREP_PIPELINE_DP', '0')))
         self._pg_ca = None           # second process group (own communicator / stream) for the deferred chain's all-reduces; see _train_graph_dp_pipelined
         self._pipe = None
         self._pending = False
@@ -279,7 +296,9 @@ class SACAgent(object):
         for k, dst in (('params', c.params), ('targets', c.targets), ('exp_avg', c.exp_avg), ('exp_avg_sq', c.exp_avg_sq),
                        ('alpha_state', c.alpha_state)):
             dst.copy_(snap[k])
-        c.device_state().copy_(snap['device_state'])
+        hyper = c.group_cfg()[:, 1:6].clone()          # lr, betas, eps, tau are THIS agent's constructor arguments, not the checkpoint's:
+        c.device_state().copy_(snap['device_state'])   # the device records come back with the checkpoint's step counters only
+        c.group_cfg()[:, 1:6].copy_(hyper)
         self.steps, self._ctr, self._seed = snap['steps'], snap['noise_ctr'], snap['seed']
         self._graph = None
         self._pipe, self._pending = None, False
@@ -497,7 +516,7 @@ class SACAgent(object):
         import torch.distributed as dist
         buffer.flush()
         buffer.size_dev()
-        key = (id(buffer), B)
+        key = self._graph_cache_key(buffer, B)
         if self._graph is None or self._graph_key != key:
             self._sample_into(buffer, B, 'warm', 0, False)
             idx_keys, eps_specs = self._plan(B)            # allocate the pools outside any capture (no launch: the train
@@ -514,10 +533,11 @@ class SACAgent(object):
                 try:
                     self._body(buffer, B, True)
                     segs, cur = self._seg
+                    self._seg = None
                     cur.capture_end()
                     segs.append(('graph', cur))
                 finally:
-                    self._seg = None
+                    self._abort_open_capture()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._graph, self._graph_key = segs, key
@@ -562,11 +582,10 @@ class SACAgent(object):
             torch.cuda.current_stream().wait_event(P['last_f'])
 
     def _train_graph_pipelined(self, buffer, B):
-        if getattr(buffer, 'before_device_write', 0) is None:
-            buffer.before_device_write = self._order_buffer_writes
+        self._hook_buffer(buffer)
         buffer.flush()
         buffer.size_dev()
-        key = (id(buffer), B)
+        key = self._graph_cache_key(buffer, B)
         c = self.core
         if self._pipe is None or self._pipe['key'] != key:
             self.flush()
@@ -669,21 +688,32 @@ class SACAgent(object):
         try:
             fn()
             segs, cur = self._seg
+            self._seg = None
             cur.capture_end()
             segs.append(('graph', cur))
         finally:
-            self._seg = None
+            self._abort_open_capture()
         return segs
+
+    def _abort_open_capture(self):
+        """An exception inside a segmented capture: end the open segment so that the stream leaves capture mode (the caller's
+        synchronize() would otherwise raise on a still-capturing stream), then forget the segments."""
+        if self._seg is not None:
+            _, cur = self._seg
+            self._seg = None
+            try:
+                cur.capture_end()
+            except Exception:
+                pass
 
     def _train_graph_dp_pipelined(self, buffer, B):
         if self._pg_ca is None:
             import torch.distributed as dist
             self._pg_ca = dist.new_group()             # collective: every rank reaches its first pipelined train() (same program)
-        if getattr(buffer, 'before_device_write', 0) is None:
-            buffer.before_device_write = self._order_buffer_writes
+        self._hook_buffer(buffer)
         buffer.flush()
         buffer.size_dev()
-        key = (id(buffer), B)
+        key = self._graph_cache_key(buffer, B)
         c = self.core
         if self._pipe is None or self._pipe['key'] != key:
             self.flush()
@@ -737,6 +767,18 @@ class SACAgent(object):
         self._pending = 2
         return self.core.info(lazy_source=self._flushed_metrics, early=(self.FEATURE_KEYS, self._feature_metrics_of(P['ev_snap'][k])))
 
+    @staticmethod
+    def _graph_cache_key(buffer, B):
+        """What a captured train() bakes in: the ring and size-scalar device addresses and the batch size (id(buffer) can be reused by
+        a new ReplayBuffer after the old one is collected)."""
+        return (buffer.ring.data_ptr(), buffer.size_dev().data_ptr(), int(buffer.ring.shape[0]), B)
+
+    def _hook_buffer(self, buffer):
+        hooks = getattr(buffer, 'before_device_write_hooks', None)
+        if hooks is not None and self._order_buffer_writes not in hooks:
+            hooks.append(self._order_buffer_writes)
+        self._held_buffer = buffer          # the cached graphs read its ring: keep it alive as long as they are
+
     def _flushed_metrics(self):
         self.flush()
         return self.core.metrics_tensor().clone()
@@ -763,7 +805,7 @@ class SACAgent(object):
     def _train_graph(self, buffer, B):
         buffer.flush()
         buffer.size_dev()
-        key = (id(buffer), B)
+        key = self._graph_cache_key(buffer, B)
         if self._graph is None or self._graph_key != key:
             # size the library's tables for B outside the capture (it re-uploads them with blocking copies
             # when the batch size changes), then capture the whole train() into one hipGraph

@@ -42,6 +42,7 @@ class SPEDERSACAgent(SACAgent):
     def feature_step(self, batch, s_random, a_random, s_prime_random):
         """spedersac_agent.py:181-219: the second batch's (s, a, s') are the "random" marginals."""
         import torch
+        self.flush()          # nothing of a pipelined train() may still be reading the slot / writing the feature parameters
         self._set_batch(batch, 0)
         z = torch.zeros(s_random.shape[0], 1, device=s_random.device)
         self.core.set_batch(1, s_random, a_random, z, s_prime_random, z)

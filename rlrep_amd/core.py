@@ -321,5 +321,11 @@ class HipCore:
         end = self._metrics_ptr - self.workspace.data_ptr() + 4 * METRIC_SLOTS
         return self.workspace[:end]
 
+    def group_cfg(self):
+        """float32[4, 14] view of the optimizer groups' device records (include/rlrep.h rlrep_group_cfg_dev): column 0 is the int32
+        step counter (bit pattern), columns 1..5 = lr, beta1, beta2, eps, tau."""
+        off = lib.rlrep_group_cfg_dev(self.h) - self.workspace.data_ptr()
+        return self.workspace[off:off + 4 * 14 * 4].view(torch.float32).view(4, 14)
+
     def launch_count(self):
         return lib.rlrep_last_launch_count(self.h)

@@ -102,6 +102,15 @@ __device__ __forceinline__ void philox_fill_body(const PhiloxFill& p, int block,
     }
 }
 __global__ __launch_bounds__(256) void philox_fill_kernel(PhiloxFill p) { philox_fill_body(p, blockIdx.x, gridDim.x); }
+// the bare bijection on caller-given (counter, key) pairs: known-answer tests only (rlrep_philox_raw)
+__global__ __launch_bounds__(256) void philox_raw_kernel(const uint32_t* __restrict__ ck, uint32_t* __restrict__ out, long long n) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    uint32_t c[4] = {ck[6 * e], ck[6 * e + 1], ck[6 * e + 2], ck[6 * e + 3]};
+    philox4x32_10(c, ck[6 * e + 4], ck[6 * e + 5]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) out[4 * e + s] = c[s];
+}
 
 __global__ __launch_bounds__(256) void train_prologue_kernel(TrainPrologue p) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
@@ -410,6 +419,10 @@ extern "C" int rl_launch_fill_slot(const SlotFill* p, hipStream_t st) {
 }
 extern "C" int rl_launch_philox(const PhiloxFill* p, hipStream_t st) {
     hipLaunchKernelGGL(philox_fill_kernel, dim3(grid_for((p->n + 3) / 4, 256, 2048)), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_philox_raw(const uint32_t* ck, uint32_t* out, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(philox_raw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ck, out, n);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st) {

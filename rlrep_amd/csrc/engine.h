@@ -32,6 +32,7 @@ int rl_nc_fwd_cols();
 void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols);
 int rl_launch_fill_slot(const SlotFill* p, hipStream_t st);
 int rl_launch_philox(const PhiloxFill* p, hipStream_t st);
+int rl_launch_philox_raw(const uint32_t* ck, uint32_t* out, long long n, hipStream_t st);
 int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st);
 int rl_launch_policy_bwd(const PolicyBwd* p, hipStream_t st);
 int rl_launch_vae_mid(const VaeMid* p, hipStream_t st);

@@ -901,7 +901,15 @@ int32_t rlrep_fill_normal_dev(float* dst, int64_t n, float std, uint64_t seed, u
     if (!dst) { rl_set_error("fill_normal_dev: bad argument"); return RLREP_ERR_ARG; }
     return philox(dst, nullptr, n, 0, std, 0, nullptr, seed, offset, counter_dev, stream);
 }
+int32_t rlrep_philox_raw(const uint32_t* ctr_key_dev, uint32_t* out_dev, int64_t n, void* stream) {
+    if (!ctr_key_dev || !out_dev || n <= 0 || n > (1ll << 30)) { rl_set_error("philox_raw: bad argument"); return RLREP_ERR_ARG; }
+    const int rc = rl_launch_philox_raw(ctr_key_dev, out_dev, n, (hipStream_t)stream);
+    if (rc) { rl_set_error("philox_raw: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
 const int32_t* rlrep_steps_dev(rlrep_agent* ag) { return ag ? ag->steps : nullptr; }
+static_assert(sizeof(GroupCfg) == 4 * RLREP_GROUP_CFG_WORDS, "include/rlrep.h documents the GroupCfg layout");
+const void* rlrep_group_cfg_dev(rlrep_agent* ag) { return ag ? ag->adam_step : nullptr; }
 
 static int run(rlrep_agent* ag, const Program& p, void* stream) {
     if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }

@@ -18,8 +18,9 @@ class GaussianPolicy(nn.Module):
         self.l1, self.l2 = nn.Linear(state_dim, hidden_dim), nn.Linear(hidden_dim, hidden_dim)
         self.mean_linear, self.log_std_linear = nn.Linear(hidden_dim, action_dim), nn.Linear(hidden_dim, action_dim)
         hi, lo = torch.as_tensor(action_space.high, dtype=torch.float32), torch.as_tensor(action_space.low, dtype=torch.float32)
-        self.register_buffer('action_scale', (hi - lo) / 2.)
-        self.register_buffer('action_bias', (hi + lo) / 2.)
+        # plain tensor attributes on the module-level `device`, NOT buffers (policy.py:33-36): they are absent from state_dict()
+        self.action_scale = ((hi - lo) / 2.).to(device)
+        self.action_bias = ((hi + lo) / 2.).to(device)
 
     def forward(self, state):
         h = F.relu(self.l2(F.relu(self.l1(state))))

@@ -33,8 +33,9 @@ class ReplayBuffer(object):
         self._size_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._size_pushed = -1
         self.device_epoch = 0        # bumped whenever this buffer enqueues device work on the caller's stream (a pipelined train() then orders itself after it)
-        self.before_device_write = None   # hook: called before the ring / size scalar is overwritten on the caller's stream (a pipelined
-                                          # train() may still be sampling from them on its own stream: the agent makes the caller's stream wait)
+        # hooks called before the ring / size scalar is overwritten on the caller's stream (a pipelined train() may still be sampling from
+        # them on its own stream: each agent that trains from this buffer appends one that makes the caller's stream wait)
+        self.before_device_write_hooks = []
 
     # ---- reference API ------------------------------------------------------------------------
     def add(self, state, action, next_state, reward, done):
@@ -56,14 +57,17 @@ class ReplayBuffer(object):
         self.ptr = (self.ptr + 1) % self.max_size
         self.size = min(self.size + 1, self.max_size)
 
+    def _before_device_write(self):
+        for h in self.before_device_write_hooks:
+            h()
+
     def flush(self):
         n = self._staged
         if n == 0:
             return
         a = self._stage_start
         first = min(n, self.max_size - a)
-        if self.before_device_write is not None:
-            self.before_device_write()
+        self._before_device_write()
         self.ring[a:a + first].copy_(self._stage[:first], non_blocking=True)
         if first < n:
             self.ring[:n - first].copy_(self._stage[first:n], non_blocking=True)
@@ -79,8 +83,7 @@ class ReplayBuffer(object):
         rows = np.concatenate([np.asarray(state, np.float32).reshape(n, -1), np.asarray(action, np.float32).reshape(n, -1),
                                np.asarray(next_state, np.float32).reshape(n, -1), np.asarray(reward, np.float32).reshape(n, 1),
                                np.asarray(done, np.float32).reshape(n, 1)], axis=1)
-        if self.before_device_write is not None:
-            self.before_device_write()
+        self._before_device_write()
         self.ring[:n].copy_(torch.from_numpy(rows))
         self.size, self.ptr, self._staged = n, n % self.max_size, 0
         self.device_epoch += 1
@@ -93,8 +96,7 @@ class ReplayBuffer(object):
     def restore(self, path):
         z = np.load(path)
         n = int(z['size'])
-        if self.before_device_write is not None:
-            self.before_device_write()
+        self._before_device_write()
         self.ring[:n].copy_(torch.from_numpy(z['ring']))
         self.ptr, self.size, self._staged = int(z['ptr']), n, 0
         self.device_epoch += 1
@@ -102,8 +104,7 @@ class ReplayBuffer(object):
     def size_dev(self):
         """int32[1] device scalar holding `size` (read by the graph-replayed index generator)."""
         if self._size_pushed != self.size:
-            if self.before_device_write is not None:
-                self.before_device_write()
+            self._before_device_write()
             self._size_dev.fill_(self.size)
             self._size_pushed = self.size
             self.device_epoch += 1

@@ -220,7 +220,7 @@ def load_synth_init(agent, alg, S_A, kw_shapes):
             agent.phi_target.load_state_dict(agent.phi.state_dict())
 
 
-def make(mods, name, alg, S, A, bound, B, T, kwargs, full, replay_n=256, patch_vae_hidden=None):
+def make(mods, name, alg, S, A, bound, B, T, kwargs, full, replay_n=256, patch_vae_hidden=None, keep_grads=True):
     import synth
     torch.set_num_threads(1)
     torch.manual_seed(0)
@@ -293,7 +293,7 @@ def make(mods, name, alg, S, A, bound, B, T, kwargs, full, replay_n=256, patch_v
                     out[f't{t}/eps/{i}'] = e
             for k, v in info.items():
                 out[f't{t}/info/{k}'] = np.float64(v.item() if torch.is_tensor(v) else v)
-            for (o, n, g) in grads_log:
+            for (o, n, g) in (grads_log if keep_grads else []):
                 out[f't{t}/grad/{o}/{n}'] = g if full else summary(g)
     finally:
         rec.close()
@@ -335,6 +335,13 @@ CASES = {
     'spedersac_ant512': ('spedersac', 111, 8, 1.0, 1024, 1, dict(SPED, phi_hidden_dim=512, mu_hidden_dim=512, critic_and_actor_hidden_dim=256, feature_dim=512, hidden_dim=256), False, 4096, None),
     'diffsrsac_tiny': ('diffsrsac', 5, 3, 1.0, 8, 3, dict(feature_dim=8, phi_hidden_dim=16, nabla_mu_hidden_dim=16, hidden_dim=16, extra_feature_steps=3), True, 64, None),
     'diffsrsac_hc': ('diffsrsac', 17, 6, 1.0, 256, 1, dict(hidden_dim=256, extra_feature_steps=3), False, 1024, None),
+    # BASELINE configs 3 and 5 at the dimensions main.py runs them with (main.py:90-91 ctrlsac F=2048 / H=1024; Humanoid-v3 S=376 A=17,
+    # batch 2048); summaries only (24 M / 50 M parameters)
+    'ctrlsac_hc2048': ('ctrlsac', 17, 6, 1.0, 256, 2, dict(hidden_dim=1024, feature_dim=2048, extra_feature_steps=3), False, 1024, None),
+    'diffsrsac_humanoid_b2048': ('diffsrsac', 376, 17, 0.4, 2048, 1, dict(hidden_dim=256, extra_feature_steps=3), False, 4096, None),
+    # 25 consecutive train() calls at the headline dimensions (SURVEY.md 7.4 / 8(c)(v) free-run loss trace): metrics of every call,
+    # final parameters and Adam state; per-step gradients are not stored
+    'vlsac_hc_free25': ('vlsac', 17, 6, 1.0, 256, 25, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3), False, 1024, None, False),
 }
 
 
@@ -346,4 +353,4 @@ if __name__ == '__main__':
     for name, c in CASES.items():
         if args.only and name not in args.only:
             continue
-        make(mods, name, *c[:7], c[7], c[8], c[9])
+        make(mods, name, *c[:7], c[7], c[8], c[9], *c[10:])

@@ -1,0 +1,237 @@
+"""The BENCHMARKED mode against the oracle, and the device random-number path against its restatement.
+
+`bench.py` times `agent.train(buffer, B)` in the default mode: hipGraph replay, sample indices and Gaussian noise drawn on the
+device by Philox4x32-10 from the device-resident train() counter, critic / actor chain of call t running beside the feature chain
+of call t+1.  The golden / oracle tests elsewhere drive `train_injected` with `graph=False`.  Here the default mode itself is
+checked: after every `train()` the draws it actually used are read back from the pools (`pool_idx`, `pool_eps`; diffsrsac's
+per-step `idx_n*` / `eps_pert*`), fed to the CPU oracle in the reference's draw order (reference draw sites
+utils/buffer.py:39-48, networks/vae.py:50-57, agent/sac/actor.py:47-60, agent/diffsrsac/diffsrsac_agent.py:276-283) and metrics
+and parameters must agree within 1e-4 (BASELINE.json north_star tolerance).  A wrong noise scale, an off-by-one index range or a
+gather that used other indices than the pool holds fails these tests.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fixture_io import Case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+class _Space:
+    def __init__(self, A, bound):
+        self.low, self.high = -bound * np.ones(A, np.float32), bound * np.ones(A, np.float32)
+
+
+def _cls(alg):
+    import importlib
+    name = {'sac': 'SACAgent', 'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent', 'spedersac': 'SPEDERSACAgent',
+            'diffsrsac': 'DIFFSRSACAgent'}[alg]
+    return getattr(importlib.import_module(f'rlrep_amd.agent.{alg}.{alg}_agent'), name)
+
+
+def _default_agent(c, **extra):
+    kw = dict(c.kw)
+    if c.meta.get('patch_vae_hidden'):
+        kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+    agent = _cls(c.alg)(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, seed=20240 + len(c.name),
+                        **kw, **extra)                        # no graph= / pipeline= argument: the defaults bench.py runs
+    agent.core.load_state(c.init)
+    return agent
+
+
+def _buffer(c):
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    buf = ReplayBuffer(c.S, c.A, max_size=c.meta['replay_n'])
+    r = c.replay
+    buf.load(r['state'], r['action'], r['next_state'], r['reward'], r['done'])
+    return buf
+
+
+def _read_back_draws(agent, B):
+    """(idx list, eps list) of the train() call that has just been flushed, in the oracle's consumption order."""
+    idx_keys, eps_specs = agent._plan(B)
+    ipool = agent._bufs['pool_idx'].cpu().numpy()
+    epool = agent._bufs['pool_eps'].cpu().numpy()
+    assert ipool.size == len(idx_keys) * B
+    idx = [ipool[q * B:(q + 1) * B].astype(np.int64) for q in range(len(idx_keys))]
+    eps, o = {}, 0
+    for k, sh in eps_specs:
+        n = int(np.prod(sh))
+        eps[k] = epool[o:o + n].reshape(sh).copy()
+        o += n
+    assert o == epool.size
+    nf = agent._feature_iters()
+    out = []
+    if agent.ALG == 'vlsac':
+        out += [eps[f'feat{i}'] for i in range(nf)]
+    if agent.ALG == 'diffsrsac':
+        for i in range(nf):
+            out += [agent._bufs[f'idx_n{i}'].cpu().numpy().astype(np.int64), agent._bufs[f'eps_pert{i}'].cpu().numpy().copy()]
+    out += [eps['crit'], eps['act']]
+    return idx, out
+
+
+def _check_against_oracle(c, calls, expect_pipeline):
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    torch.set_num_threads(4)
+    agent, buf = _default_agent(c), _buffer(c)
+    assert agent.use_graph, 'the default mode is graph replay'
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    n = c.meta['replay_n']
+    seen = []
+    for t in range(calls):
+        info = agent.train(buf, c.B)
+        agent.flush()
+        torch.cuda.synchronize()
+        idx, eps = _read_back_draws(agent, c.B)
+        for i in idx:
+            assert i.min() >= 0 and i.max() < n, (c.name, t, i.min(), i.max())
+        seen.append(np.concatenate([e.ravel() for e in eps if e.dtype == np.float32]))
+        oinfo = o.train([gather_batch(c.replay, i) for i in idx], [torch.as_tensor(e) for e in eps])
+        for k, v in oinfo.items():
+            assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (c.name, t, k, info[k], v)
+    if expect_pipeline:
+        assert agent._pipe is not None and agent._pipe.get('mode') != 1, f'{c.name} must take the two-stream pipelined path'
+    # fresh draws every call (the device counter advanced): no two calls saw the same noise
+    for a in range(len(seen)):
+        for b in range(a + 1, len(seen)):
+            assert not np.array_equal(seen[a], seen[b]), (c.name, a, b)
+    st, P = agent.core.state(), o.state()
+    worst = 0.0
+    for k in st:
+        if k in P and not k.endswith('noise') and k != 'noise_alphabars':
+            e = rel_l2(st[k].numpy(), P[k].numpy())
+            worst = max(worst, e)
+            assert e < 1e-4, (c.name, k, e)
+    return worst
+
+
+@pytest.mark.parametrize('alg,pipe', [('sac', False), ('vlsac', True), ('ctrlsac', True), ('spedersac', True), ('diffsrsac', False)])
+def test_default_mode_matches_oracle_tiny(alg, pipe):
+    worst = _check_against_oracle(Case(alg + '_tiny'), calls=4, expect_pipeline=pipe)
+    print(f'{alg}_tiny default mode vs oracle: worst param rel-L2 {worst:.2e}')
+
+
+def test_default_mode_matches_oracle_headline_dims():
+    """BASELINE config[1] (vlsac, HalfCheetah dims, F = H = 256, B = 256, 4 feature steps): exactly what bench.py times."""
+    worst = _check_against_oracle(Case('vlsac_hc'), calls=3, expect_pipeline=True)
+    print(f'vlsac_hc default mode vs oracle: worst param rel-L2 {worst:.2e}')
+
+
+def test_default_mode_sequential_graph_matches_oracle(monkeypatch):
+    """RLREP_PIPELINE=0: the one-graph sequential form of the same train()."""
+    monkeypatch.setenv('RLREP_PIPELINE', '0')
+    _check_against_oracle(Case('vlsac_tiny'), calls=3, expect_pipeline=False)
+
+
+# ---- the generator itself ------------------------------------------------------------------------------------------------------
+def test_philox_known_answers_on_device():
+    """Random123's published Philox4x32-10 vectors through the device function the fills are built on."""
+    import ctypes as C
+    from rlrep_amd._lib import lib, check
+    from oracle.philox import KAT, philox4x32_10
+    rs = np.random.RandomState(3)
+    extra = rs.randint(0, 2 ** 32, size=(64, 6), dtype=np.uint64)
+    ck = np.array([list(c) + list(k) for c, k, _ in KAT] + extra.tolist(), dtype=np.uint32)
+    want = np.array([list(e) for _, _, e in KAT], dtype=np.uint32)
+    d_in = torch.from_numpy(ck.view(np.int32)).cuda()
+    d_out = torch.zeros(len(ck), 4, dtype=torch.int32, device='cuda')
+    check(lib.rlrep_philox_raw(C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), len(ck),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'philox_raw')
+    got = d_out.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[:3], want), (got[:3], want)
+    assert np.array_equal(got[3:], philox4x32_10(ck[3:, :4], ck[3:, 4:]))
+
+
+def _core():
+    c = Case('sac_tiny')
+    from rlrep_amd.agent.sac.sac_agent import SACAgent
+    return SACAgent(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, 1.0), max_batch=c.B, **c.kw).core
+
+
+@pytest.mark.parametrize('n,hi,seed,offset', [(1, 7, 0, 0), (1023, 1000, 12345, (1 << 40) + 17), (4096, 65536, 2 ** 31 - 1, 5 << 20),
+                                              (100003, 1000000, 987654321, (1 << 40) + 123456)])
+def test_index_stream_is_bit_exact_and_in_range(n, hi, seed, offset):
+    from oracle import philox
+    core = _core()
+    t = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+    core.fill_indices(t, hi, seed, offset)
+    got = t.cpu().numpy()
+    assert got.min() >= 0 and got.max() < hi
+    assert np.array_equal(got, philox.indices(n, hi, seed, offset))
+
+
+def test_index_stream_is_uniform():
+    """chi-square of 2^20 draws over 1000 cells (999 degrees of freedom: mean 999, sd 44.7; bound = mean + 5 sd) and the
+    extreme cells 0 and hi - 1 are both reached (an off-by-one range would lose or overshoot one of them)."""
+    core = _core()
+    n, hi = 1 << 20, 1000
+    t = torch.empty(n, dtype=torch.int32, device='cuda')
+    core.fill_indices(t, hi, 424242, 9 << 20)
+    cnt = np.bincount(t.cpu().numpy(), minlength=hi).astype(np.float64)
+    assert cnt.size == hi and cnt[0] > 0 and cnt[-1] > 0
+    chi2 = ((cnt - n / hi) ** 2 / (n / hi)).sum()
+    assert chi2 < 999 + 5 * 44.7, chi2
+
+
+def test_device_counter_variant_reads_size_and_step_on_the_device():
+    """rlrep_fill_indices_dev: range from a device scalar, stream offset = offset + the agent's train() counter."""
+    from oracle import philox
+    c = Case('sac_tiny')
+    from rlrep_amd.agent.sac.sac_agent import SACAgent
+    agent = SACAgent(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, 1.0), max_batch=c.B, **c.kw)
+    core = agent.core
+    hi_dev = torch.full((1,), 777, dtype=torch.int32, device='cuda')
+    t = torch.empty(500, dtype=torch.int32, device='cuda')
+    for step in range(3):
+        core.fill_indices_dev(t, hi_dev, 99, 1 << 40)
+        assert np.array_equal(t.cpu().numpy(), philox.indices(500, 777, 99, (1 << 40) + step)), step
+        core.begin_train()                          # steps += 1 on the device
+
+
+@pytest.mark.parametrize('n,std,seed,offset', [(5, 1.0, 1, 0), (4099, 0.449, 77, 2 << 40), (1 << 16, 1.0, 31337, (2 << 40) + 9)])
+def test_normal_stream_matches_restatement(n, std, seed, offset):
+    """Box-Muller on the Philox words, element by element (float32 libm differences between device and host: <= 2e-6 absolute at
+    |x| <= 6)."""
+    from oracle import philox
+    core = _core()
+    t = torch.zeros(n, dtype=torch.float32, device='cuda')
+    core.fill_normal(t, std, seed, offset)
+    got, want = t.cpu().numpy(), philox.normals(n, std, seed, offset)
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(got - want)) <= 4e-6 * max(std, 1.0), np.max(np.abs(got - want))
+
+
+def test_normal_stream_moments():
+    """N(0, std^2) moments over 2^22 draws: mean 0 +- 5 sd/sqrt(n), variance, skewness 0, kurtosis 3, tail mass beyond 3 sigma."""
+    core = _core()
+    n = 1 << 22
+    for std in (1.0, 0.449):
+        t = torch.empty(n, dtype=torch.float32, device='cuda')
+        core.fill_normal(t, std, 2718281828, 3 << 40)
+        x = t.cpu().numpy().astype(np.float64) / std
+        assert abs(x.mean()) < 5 / np.sqrt(n)
+        assert abs(x.var() - 1.0) < 5 * np.sqrt(2.0 / n)
+        assert abs((x ** 3).mean()) < 5 * np.sqrt(15.0 / n)
+        assert abs((x ** 4).mean() - 3.0) < 5 * np.sqrt(96.0 / n)
+        tail = (np.abs(x) > 3).mean()
+        assert abs(tail - 0.0026998) < 5 * np.sqrt(0.0027 / n), tail
+        # consecutive elements (the cos / sin pair of one Box-Muller draw, and neighbours across blocks) are uncorrelated
+        assert abs(np.mean(x[:-1] * x[1:])) < 5 / np.sqrt(n)
+
+
+def test_train_pools_are_the_documented_streams():
+    """The pools a graph-replayed train() draws are exactly stream (seed, (1 << 40) + steps) for indices and (seed, (2 << 40) + steps)
+    for noise, steps = the value of the device train() counter AFTER this call's increment (train_prologue_kernel: step_add = 1)."""
+    from oracle import philox
+    c = Case('vlsac_tiny')
+    agent, buf = _default_agent(c), _buffer(c)
+    for call in range(1, 4):
+        agent.train(buf, c.B)
+        agent.flush()
+        torch.cuda.synchronize()
+        ip, ep = agent._bufs['pool_idx'].cpu().numpy(), agent._bufs['pool_eps'].cpu().numpy()
+        assert np.array_equal(ip, philox.indices(ip.size, c.meta['replay_n'], agent._seed, (1 << 40) + call))
+        assert np.max(np.abs(ep - philox.normals(ep.size, 1.0, agent._seed, (2 << 40) + call))) <= 4e-6

@@ -97,7 +97,7 @@ def test_hip_matches_reference_golden(name):
             continue
         err = _cmp(st[k].numpy(), v, c.full)
         worst['param'] = max(worst['param'], err)
-        assert err < 1e-4, (name, k, err)
+        assert err < (1e-4 if c.T <= 3 else 5e-4), (name, k, err)       # T = 25 free run: Adam amplifies rounding on near-zero gradient elements
         # Polyak'd copies move by tau * (a few Adam steps): compare the MOVEMENT, the absolute check above cannot see
         # a target update that never ran
         if c.full and 'target' in k and k in c.init:
@@ -105,7 +105,32 @@ def test_hip_matches_reference_golden(name):
             d_mine = st[k].numpy().astype(np.float64) - np.asarray(c.init[k], np.float64)
             if np.linalg.norm(d_ref) > 1e-9:
                 assert rel_l2(d_mine, d_ref) < 2e-2, (name, k, 'target movement', rel_l2(d_mine, d_ref))
-    print(f'{name}: worst info {worst["info"]:.2e} grad {worst["grad"]:.2e} param {worst["param"]:.2e}')
+    # Adam state after the last call (the fixtures' adam/<optimizer>/<name>/{m,v,step} summaries): moments of every tensor the
+    # reference's optimizers hold state for, the fp64 temperature moments, and the step counters of the optimizer groups
+    worst['adam'] = 0.0
+    steps_seen = {}
+    for key, ref in c.adam.items():
+        opt, pname, which = key.split('/')
+        if opt == 'log_alpha_optimizer':
+            mine = float(agent.core.alpha_state[{'m': 1, 'v': 2, 'step': 3}[which]].item())
+            want = float(ref) if which == 'step' else float(ref[1])          # summary()[1] = the sum = the scalar itself
+            assert abs(mine - want) <= 1e-4 * max(abs(want), 1e-12), (name, key, mine, want)
+            continue
+        if pname not in agent.core.descs or opt not in OPT_GROUP:
+            continue
+        if which == 'step':
+            steps_seen[OPT_GROUP[opt]] = int(ref)
+            continue
+        mine = agent.core.view(pname, 'exp_avg' if which == 'm' else 'exp_avg_sq').cpu().numpy()
+        if ref[0] < 1e-12:
+            continue
+        err = _cmp(mine, ref, False)
+        worst['adam'] = max(worst['adam'], err)
+        assert err < (1e-4 if which == 'm' else 2e-4) * (1 if c.T <= 3 else 5), (name, key, err)
+    cfg_steps = agent.core.group_cfg()[:, 0].contiguous().view(torch.int32).cpu().numpy()
+    for g, n in steps_seen.items():
+        assert int(cfg_steps[g]) == n, (name, 'optimizer group', g, int(cfg_steps[g]), n)
+    print(f'{name}: worst info {worst["info"]:.2e} grad {worst["grad"]:.2e} param {worst["param"]:.2e} adam {worst["adam"]:.2e}')
 
 
 @pytest.mark.parametrize('alg', ['sac', 'vlsac'])
