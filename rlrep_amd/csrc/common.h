@@ -94,6 +94,10 @@ struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; GemmT
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)
 // ------------------------------------------------------------------------------------------------
+// Transposed shadow copy of a weight matrix (rowprog.hip reads W^T so that a lane's 16-byte B fragment and its neighbours' are
+// contiguous): tensor at float offset `off` (n = rows * cols) of an arena, shadow [cols][rows] at sp; st = shadow of its Polyak target.
+struct ShadowEnt { long long off, n; int rows, cols; float* sp; float* st; };
+
 struct AdamTask {
     float* p; const float* g; float* m; float* v;
     long long n;
@@ -102,6 +106,7 @@ struct AdamTask {
     // optional Polyak of a sub-range [pol_off, pol_off+pol_n) of p into target
     float* target; long long pol_off, pol_n; float tau;
     const int* pol_steps; int pol_period;     // if pol_steps != nullptr: Polyak only when *pol_steps % pol_period == 0
+    const ShadowEnt* sh; int nsh;             // transposed shadows of this group's weight matrices, kept current by this launch (or null)
 };
 
 struct PolyakTask {

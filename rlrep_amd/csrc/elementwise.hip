@@ -112,11 +112,48 @@ __global__ __launch_bounds__(256) void philox_raw_kernel(const uint32_t* __restr
     for (int s = 0; s < 4; ++s) out[4 * e + s] = c[s];
 }
 
+// ------------------------------------------------------------------------------------------------
+// transposed weight shadows (ShadowEnt): block t of a shadow launch transposes one 32 x 32 tile through LDS
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int shadow_tiles(const ShadowEnt& e) { return ((e.rows + 31) / 32) * ((e.cols + 31) / 32); }
+__device__ __forceinline__ void shadow_tile_body(const ShadowEnt* __restrict__ sh, int nsh, const float* __restrict__ base, int tile, bool target) {
+    __shared__ float tl[32][33];
+    int ei = 0, t0 = 0;
+    for (int q = 0; q < nsh; ++q) { const int nt = shadow_tiles(sh[q]); if (tile < t0 + nt) { ei = q; break; } t0 += nt; if (q == nsh - 1) return; }
+    const ShadowEnt e = sh[ei];
+    float* dst = target ? e.st : e.sp;
+    if (!dst) return;
+    const int tc = (e.cols + 31) / 32, local = tile - t0;
+    const int r0 = (local / tc) * 32, c0 = (local % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 256 threads: 8 rows per pass
+    const float* src = base + e.off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tl[ty + 8 * k][tx] = (r < e.rows && c < e.cols) ? src[(size_t)r * e.cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < e.rows && c < e.cols) dst[(size_t)c * e.rows + r] = tl[tx][ty + 8 * k];
+    }
+}
+__global__ __launch_bounds__(256) void shadow_kernel(const ShadowEnt* __restrict__ sh, int nsh, const float* __restrict__ base, int target) {
+    shadow_tile_body(sh, nsh, base, blockIdx.x, target != 0);
+}
+extern "C" int rl_launch_shadow(const ShadowEnt* sh_dev, int nsh, int ntiles, const float* base, int target, hipStream_t st) {
+    if (ntiles <= 0 || nsh <= 0) return 0;
+    hipLaunchKernelGGL(shadow_kernel, dim3(ntiles), dim3(256), 0, st, sh_dev, nsh, base, target);
+    return (int)hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void train_prologue_kernel(TrainPrologue p) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const int bid = blockIdx.x;
     if (bid < p.nb_idx) philox_fill_body(p.idx, bid, p.nb_idx);
     else if (bid < p.nb_idx + p.nb_eps) philox_fill_body(p.eps, bid - p.nb_idx, p.nb_eps);
+    else if (bid >= p.nb_idx + p.nb_eps + p.nb_fill) shadow_tile_body(p.sh, p.nsh, p.sh_base, bid - p.nb_idx - p.nb_eps - p.nb_fill, false);
     else {
         IdxGen g; g.on = 1; g.seed = p.idx.seed; g.stream_id = p.idx.stream_id;
         g.off = p.idx.offset + (unsigned long long)(*p.idx.step_dev + p.idx.step_add);
@@ -356,11 +393,37 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
         }
         *reinterpret_cast<f32x4*>(t.p + i) = p4; *reinterpret_cast<f32x4*>(t.m + i) = m4; *reinterpret_cast<f32x4*>(t.v + i) = v4;
         if (pol) *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off)) = t4;
+        if (t.sh) {
+            // keep the transposed shadows of the weight matrices current (4 scattered 4-byte stores; tensors start on multiples of 4 floats,
+            // so the four elements belong to one tensor or to alignment padding)
+            for (int q = 0; q < t.nsh; ++q) {
+                const ShadowEnt e = t.sh[q];
+                if (i < e.off || i >= e.off + e.n) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const long long l = i + s - e.off;
+                    if (l >= e.n) break;
+                    const int r = (int)(l / e.cols), c = (int)(l - (long long)r * e.cols);
+                    e.sp[(size_t)c * e.rows + r] = p4[s];
+                    if (pol && e.st) e.st[(size_t)c * e.rows + r] = t4[s];
+                }
+                break;
+            }
+        }
     } else {
         for (int s = 0; s < 4 && i + s < t.n; ++s) {
             const long long e = i + s;
             float* tp = (pol_on && e >= t.pol_off && e < t.pol_off + t.pol_n) ? t.target + (e - t.pol_off) : nullptr;
             adam_elem(sc, t.g[e], t.p + e, t.m + e, t.v + e, tp);
+            for (int q = 0; t.sh && q < t.nsh; ++q) {
+                const ShadowEnt se = t.sh[q];
+                if (e < se.off || e >= se.off + se.n) continue;
+                const long long l = e - se.off;
+                const int r = (int)(l / se.cols), c = (int)(l - (long long)r * se.cols);
+                se.sp[(size_t)c * se.rows + r] = t.p[e];
+                if (tp && se.st) se.st[(size_t)c * se.rows + r] = *tp;
+                break;
+            }
         }
     }
 }
@@ -460,7 +523,7 @@ extern "C" int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st) {
     p->nb_idx = grid_for((p->idx.n + 3) / 4, 256, 2048);
     p->nb_eps = grid_for((p->eps.n + 3) / 4, 256, 2048);
     p->nb_fill = grid_for((long long)p->fill.B * (2 * p->fill.S + p->fill.A + 2), 256, 2048);
-    hipLaunchKernelGGL(train_prologue_kernel, dim3(p->nb_idx + p->nb_eps + p->nb_fill), dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(train_prologue_kernel, dim3(p->nb_idx + p->nb_eps + p->nb_fill + p->nb_tr), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {

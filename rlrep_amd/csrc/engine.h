@@ -10,6 +10,7 @@
 #include "../../include/rlrep.h"
 #include "common.h"
 #include "kparams.h"
+#include "rowprog.h"
 
 // kernel launchers (defined next to the kernels)
 extern "C" {
@@ -45,6 +46,7 @@ int rl_launch_polyak(const PolyakTask* t, hipStream_t st);
 int rl_launch_counter_inc(int* c, hipStream_t st);
 int rl_launch_copy(const float* src, float* dst, long long n, hipStream_t st);
 int rl_launch_copy_segs(const CopySegs* p, hipStream_t st);
+int rl_launch_shadow(const ShadowEnt* sh_dev, int nsh, int ntiles, const float* base, int target, hipStream_t st);
 }
 
 void rl_set_error(const char* fmt, ...);

@@ -305,10 +305,144 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     // actor buffers are needed by the feature program variant that carries the policy forwards
     ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
     ActorBufs ab_pi = alloc_actor(b, B, A, Ha);                                              // policy on s  (actor step)
+    // ---- the forward + dX chains of a feature step as ONE launch of row-block programs (rowprog.hip) -------------------------------
+    // Two workgroups per 16-row block: program E runs encoder -> sample / KL -> decoder -> decoder and encoder backward, program F runs
+    // f forward, publishes its heads to E (the KL term needs both Gaussians), receives dKL/d(f heads) and runs f's backward beside E's
+    // decoder passes.  `early`: two more programs run both policy forwards (what the first three launches of feat_bwd_h carry).
+    const int nrb = (B + RP_ROWS - 1) / RP_ROWS;
+    const int nblk_rp = nrb;
+    float* part_kl_rp = ws.f(nblk_rp); float* part_mse_rp = ws.f((size_t)2 * nblk_rp);
+    int* rp_flags = (int*)ws.alloc(sizeof(int) * 2 * nrb);
+    if (!b.dry && rp_flags && b.ws.ok()) (void)hipMemset(rp_flags, 0, sizeof(int) * 2 * nrb);
+    auto rp_feature = [&](RpAsm& A_, bool early) {
+        const bool pair = !getenv("RLREP_ROWPROG_SINGLE");
+        auto Wp = [&](const char* n) { return ag->P(n); };
+        const bool useT = ag->nsh[0] > 0;
+        // forward layer `name`: from the transposed shadow when the agent keeps one (wide layers), else from W itself
+        auto FW = [&](const RpBuf& x, int K, const std::string& name, const std::string& bias_name, int N, int act, const RpBuf* d, float* gout, int ldg) {
+            if (useT && N >= 64 && ag->shadow_of.count(name + ".weight")) A_.fwdT(x, K, ag->PT(name + ".weight"), ag->P(bias_name + ".bias"), N, act, d, gout, ldg);
+            else A_.fwd(x, K, ag->P(name + ".weight"), K, ag->P(bias_name + ".bias"), N, act, d, gout, ldg);
+        };
+        auto f_forward = [&](RpBuf& x, RpBuf& h1, RpBuf& h2) {
+            x = A_.buf(SA); h1 = A_.buf(Hv); h2 = A_.buf(Hv);
+            A_.load(s0.XF, SA, SA, x);
+            FW(x, SA, "f.l1", "f.l1", Hv, ACT_RELU, &h1, gf.H1, Hv);
+            FW(h1, Hv, "f.l2", "f.l2", Hv, ACT_RELU, &h2, gf.H2, Hv);
+        };
+        auto f_backward = [&](const RpBuf& g, const RpBuf* m2, const RpBuf* m1, const RpBuf& g2) {
+            A_.load(GFH, 2 * F, 2 * F, g);
+            A_.dx(g, 2 * F, Wp("f.mean_linear.weight"), Hv, Hv, ACT_RELU, m2, gf.H2, Hv, &g2, GH2f, Hv);
+            A_.dx(g2, Hv, Wp("f.l2.weight"), Hv, Hv, ACT_RELU, m1, gf.H1, Hv, nullptr, GH1f, Hv);
+        };
+        // ---- program E (and, unpaired, the whole step) ----
+        A_.begin();
+        RpBuf r0b = A_.buf(std::max(KE, S + 1)), r1 = A_.buf(std::max(Hv, F)), r2 = A_.buf(std::max(Hv, F)), rhh = A_.buf(2 * F),
+              rfh = A_.buf(std::max(2 * F, Hv)), r5 = A_.buf(std::max(F, Hv));
+        if (!pair) {
+            // f forward first, on the regions the encoder is about to use; its heads land where the KL op expects them
+            RpBuf x = RpAsm::at(r0b, SA), h1 = RpAsm::at(r1, Hv), h2 = RpAsm::at(r2, Hv), fh = RpAsm::at(rfh, 2 * F);
+            A_.load(s0.XF, SA, SA, x);
+            FW(x, SA, "f.l1", "f.l1", Hv, ACT_RELU, &h1, gf.H1, Hv);
+            FW(h1, Hv, "f.l2", "f.l2", Hv, ACT_RELU, &h2, gf.H2, Hv);
+            FW(h2, Hv, "f.mean_linear", "f.mean_linear", 2 * F, ACT_NONE, &fh, gf.HH, 2 * F);
+        }
+        {
+            RpBuf x = RpAsm::at(r0b, KE), h1 = RpAsm::at(r1, Hv), h2 = RpAsm::at(r2, Hv);
+            A_.load(s0.XE, KE, KE, x);
+            FW(x, KE, "encoder.l1", "encoder.l1", Hv, ACT_RELU, &h1, ge.H1, Hv);
+            FW(h1, Hv, "encoder.l2", "encoder.l2", Hv, ACT_RELU, &h2, ge.H2, Hv);
+            FW(h2, Hv, "encoder.mean_linear", "encoder.mean_linear", 2 * F, ACT_NONE, &rhh, ge.HH, 2 * F);
+        }
+        const RpBuf fh = RpAsm::at(rfh, 2 * F), z = RpAsm::at(r1, F), ez = RpAsm::at(r2, F);
+        if (pair) { A_.wait(0); A_.load(gf.HH, 2 * F, 2 * F, fh); }
+        {
+            RpOp o = RpAsm::blank(RP_VAE_MID);
+            o.src = rhh.off; o.lds = rhh.ld; o.src2 = fh.off; o.lds2 = fh.ld; o.N = F; o.dyn = 0; o.s0 = ag->inv_batch() / (float)F;
+            o.dst = z.off; o.ldd = z.ld; o.wpad = z.w; o.dst2 = ez.off; o.ldd2 = ez.ld;
+            o.gout = Z; o.ldg = F; o.gout2 = GFH; o.ldg2 = 2 * F; o.part = part_kl_rp; o.step = ag->adam_step + 0; o.flags = RPF_BUMP;
+            A_.ops.push_back(o);
+        }
+        if (pair) A_.signal(1);
+        // the f heads are dead: their region takes the decoder's hidden layer, then dz; z's region takes the encoder's dL/dh2
+        RpBuf d1 = RpAsm::at(rfh, Hv), dh = RpAsm::at(r0b, S + 1), gd1 = RpAsm::at(r5, Hv), dz = RpAsm::at(rfh, F), g2 = RpAsm::at(r1, Hv);
+        FW(z, F, "decoder.l1", "decoder.l1", Hv, ACT_RELU, &d1, D1, Hv);
+        A_.fwd(d1, Hv, Wp("decoder.state_linear.weight"), Hv, Wp("decoder.state_linear.bias"), S + 1, ACT_NONE, &dh, nullptr, 0);
+        {
+            RpOp o = RpAsm::blank(RP_MSE);
+            o.src = dh.off; o.lds = dh.ld; o.n0 = S; o.gin = s0.XE ? s0.XE + SA : nullptr; o.ldgin = KE; o.gin2 = s0.R;
+            o.s0 = ag->inv_batch() / (float)S; o.s1 = ag->inv_batch(); o.gout = GDH; o.ldg = S + 1; o.part = part_mse_rp;
+            A_.ops.push_back(o);
+        }
+        A_.dx(dh, S + 1, Wp("decoder.state_linear.weight"), Hv, Hv, ACT_RELU, &d1, nullptr, 0, &gd1, GD1, Hv);
+        A_.dx(gd1, Hv, Wp("decoder.l1.weight"), F, F, ACT_NONE, nullptr, nullptr, 0, &dz, nullptr, 0);
+        {
+            RpOp o = RpAsm::blank(RP_REPARAM);
+            o.src = dz.off; o.lds = dz.ld; o.src2 = ez.off; o.lds2 = ez.ld; o.dst = rhh.off; o.ldd = rhh.ld; o.N = F; o.gout = GEH; o.ldg = 2 * F;
+            A_.ops.push_back(o);
+        }
+        A_.dx(rhh, 2 * F, Wp("encoder.mean_linear.weight"), Hv, Hv, ACT_RELU, nullptr, ge.H2, Hv, &g2, GH2e, Hv);
+        A_.dx(g2, Hv, Wp("encoder.l2.weight"), Hv, Hv, ACT_RELU, nullptr, ge.H1, Hv, nullptr, GH1e, Hv);
+        if (!pair) {
+            RpBuf g = RpAsm::at(rfh, 2 * F), gg2 = RpAsm::at(r2, Hv);
+            f_backward(g, nullptr, nullptr, gg2);
+        }
+        A_.end(nrb);
+        if (pair) {
+            A_.begin();
+            RpBuf x, h1, h2;
+            f_forward(x, h1, h2);
+            FW(h2, Hv, "f.mean_linear", "f.mean_linear", 2 * F, ACT_NONE, nullptr, gf.HH, 2 * F);
+            A_.signal(0);
+            RpBuf g = A_.buf(2 * F), gg2 = A_.buf(Hv);
+            A_.wait(1);
+            f_backward(g, &h2, &h1, gg2);
+            A_.end(nrb);
+        }
+        if (early) {
+            for (int which = 0; which < 2; ++which) {
+                const ActorBufs& abx = which == 0 ? ab : ab_pi;
+                const float* X = which == 0 ? s0.XF2 : s0.XFpi;
+                A_.begin();
+                RpBuf x = A_.buf(S), a1 = A_.buf(Ha), a2 = A_.buf(Ha), ao = A_.buf(2 * A);
+                A_.load(X, SA, S, x);
+                A_.fwd(x, S, Wp("actor.trunk.0.weight"), S, Wp("actor.trunk.0.bias"), Ha, ACT_ELU, &a1, abx.A1, Ha);
+                A_.fwd(a1, Ha, Wp("actor.trunk.2.weight"), Ha, Wp("actor.trunk.2.bias"), Ha, ACT_ELU, &a2, abx.A2, Ha);
+                A_.fwd(a2, Ha, Wp("actor.trunk.4.weight"), Ha, Wp("actor.trunk.4.bias"), 2 * A, ACT_NONE, &ao, abx.AO, 2 * A);
+                RpOp o = RpAsm::blank(RP_POLICY);
+                o.src = ao.off; o.lds = ao.ld; o.n0 = A; o.dyn = which == 0 ? 1 : 2;
+                o.gout = const_cast<float*>(X) ? const_cast<float*>(X) + S : nullptr; o.ldg = SA; o.gout2 = abx.logp;
+                A_.ops.push_back(o);
+                A_.end(nrb);
+            }
+        }
+    };
+    // OPT-IN (RLREP_ROWPROG=1): measured on MI355X at the headline dimensions the fused launch takes 91-95 us against 44 us (stages timed
+    // alone) / ~57 us (in the dependent chain) for the nine launches it replaces -- one CU per 16-row block ingests every weight matrix
+    // (256 KB per 256 x 256 layer at ~50-65 GB/s per CU) and runs fp32 MFMA at 41-53 cycles per instruction: 5-6 us per layer and row
+    // block, i.e. a dependent launch.  DESIGN.md section 5.2 has the per-op timeline.
+    bool use_rp = rl_rowprog_enabled();
+    {
+        RpAsm probe; rp_feature(probe, true);
+        if (probe.lds_bytes() > RP_LDS_DYN_MAX || probe.ops.size() > 4096) use_rp = false;
+        for (auto& pr : probe.progs) if (pr.op_end - pr.op_begin > 40) use_rp = false;
+    }
     auto feature_program = [&](Program& p, bool early) {
         GemmTask te[3], tf[3];
         gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
         gauss_tasks(ag, false, "f", s0.XF, SA, SA, gf, tf);
+        if (use_rp) {
+            RpAsm A_; rp_feature(A_, early);
+            RpLaunch L; memset(&L, 0, sizeof(L));
+            L.ops = b.upload(A_.ops); L.flags = rp_flags; L.nprog = (int)A_.progs.size(); L.B = B; L.low_prio = 0;
+            L.lds_floats = A_.peak;
+            for (size_t q = 0; q < A_.progs.size(); ++q) L.prog[q] = A_.progs[q];
+            const int total = A_.blocks;
+            rlrep_agent* a = ag;
+            p.stages.push_back({[=](hipStream_t st) {
+                RpLaunch l2 = L; l2.dyn[0] = a->cur_eps; l2.dyn[1] = a->cur_eps3; l2.dyn[2] = a->cur_eps2;
+                return rl_launch_rowprog(&l2, total, st);
+            }, early ? "row programs: encoder | f | policy(s') | policy(s): forward + dX" : "row programs: encoder | f: forward + dX"});
+        } else
         if (early) {
             b.fwd_stage(p, {te[0], tf[0], actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "enc.l1 f.l1 actor.l1(s') actor.l1(s)");
             b.fwd_stage(p, {te[1], tf[1], actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi)}, "enc.l2 f.l2 actor.l2 x2");
@@ -319,6 +453,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
             b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
         }
+        if (!use_rp) {
         VaeMid vm; memset(&vm, 0, sizeof(vm));
         vm.EH = ge.HH; vm.FH = gf.HH; vm.Z = Z; vm.GEH = GEH; vm.GFH = GFH; vm.partial = part_kl;
         vm.B = B; vm.F = F; vm.nblk = nblk_kl; vm.scale = ag->inv_batch() / (float)F; vm.step = ag->adam_step + 0;
@@ -344,15 +479,16 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dx(GFH, 2 * F, B, 2 * F, Pw("f.mean_linear.weight"), Hv, GH2f, Hv, Hv, ACT_RELU, gf.H2, Hv)}, "heads dx");
         b.dx_stage(p, {Builder::dx(GH2e, Hv, B, Hv, Pw("encoder.l2.weight"), Hv, GH1e, Hv, Hv, ACT_RELU, ge.H1, Hv),
                        Builder::dx(GH2f, Hv, B, Hv, Pw("f.l2.weight"), Hv, GH1f, Hv, Hv, ACT_RELU, gf.H1, Hv)}, "l2 dx");
+        }
         {
             const LT& f0 = ag->L.get("f.l1.weight");
             const LT& fl = ag->L.get("f.log_std_linear.bias");
             b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
         }
         b.stash_fin({
-            Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
-            Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
-            Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
+            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
+            Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 0, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
+            Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 1, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
             Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
             Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)});
         b.dw_stage(p, {Builder::dw(GDH, S + 1, S + 1, D1, Hv, Hv, B, Gw("decoder.state_linear.weight"), Hv, Gw("decoder.state_linear.bias")),
@@ -371,9 +507,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     {
         // apply: Adam over (encoder, decoder, f) + Polyak f -> f_target (vlsac_agent.py:152-154, 240-242)
         const std::vector<FinTask> feat_fins = {
-            Builder::fin_sum(part_kl, nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
-            Builder::fin_sum(part_mse + 0, nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
-            Builder::fin_sum(part_mse + 1, nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
+            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
+            Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 0, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
+            Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 1, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
             Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
             Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)};
         const LT& f0 = ag->L.get("f.l1.weight");
@@ -680,7 +816,46 @@ static void static_state(rlrep_agent* ag) {
     const int S = ag->d.state_dim, A = ag->d.action_dim;
     ag->obs_in = ws.f((size_t)ag->d.max_batch * S);
     ag->act_out = ws.f((size_t)ag->d.max_batch * A);
+    // transposed weight shadows (see rlrep_agent::sh_dev): vlsac's feature group, read by the feature step's row programs
+    ag->shadow_of.clear();
+    for (int g = 0; g < 4; ++g) { ag->sh_dev[g] = nullptr; ag->nsh[g] = ag->sh_tiles[g] = 0; }
+    if (ag->d.alg == RLREP_ALG_VLSAC && rl_rowprog_enabled() && !getenv("RLREP_NO_SHADOWS")) {
+        std::vector<ShadowEnt> tab; std::vector<std::string> first;
+        const auto& T = ag->L.t;
+        for (size_t q = 0; q < T.size(); ++q) {
+            const LT& e = T[q];
+            if (e.arena != RLREP_ARENA_PARAM || e.group != 0 || e.cols <= 1 || e.name.find(".weight") == std::string::npos) continue;
+            // a glued pair (mean | log_std heads, state | reward heads: Layout::lin_pair) is two consecutive blocks [o1, in], [o2, in] = ONE
+            // [o1 + o2, in] matrix for the kernels: one shadow, reachable under the first tensor's name
+            if (!tab.empty() && q > 0 && T[q - 1].name.find(".weight") != std::string::npos && tab.back().off + tab.back().n == e.off && tab.back().cols == e.cols) {
+                tab.back().rows += e.rows; tab.back().n += (long long)e.rows * e.cols;
+                continue;
+            }
+            ShadowEnt se; memset(&se, 0, sizeof(se));
+            se.off = e.off; se.n = (long long)e.rows * e.cols; se.rows = e.rows; se.cols = e.cols;
+            tab.push_back(se); first.push_back(e.name);
+        }
+        int tiles = 0;
+        for (size_t k = 0; k < tab.size(); ++k) {
+            tab[k].sp = ws.f((size_t)tab[k].n);
+            ag->shadow_of[first[k]] = tab[k].sp;
+            tiles += ((tab[k].rows + 31) / 32) * ((tab[k].cols + 31) / 32);
+        }
+        ShadowEnt* dev = (ShadowEnt*)ws.alloc(tab.size() * sizeof(ShadowEnt));
+        if (!ws.dry && ws.ok() && !tab.empty()) (void)hipMemcpy(dev, tab.data(), tab.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice);
+        ag->sh_dev[0] = dev; ag->nsh[0] = (int)tab.size(); ag->sh_tiles[0] = tiles;
+    }
     ag->ws_static = ws.used;
+}
+
+// regenerate the shadows of group g from the parameters as they stand (a launch of its own: the eager entry points)
+static int refresh_shadows(rlrep_agent* ag, void* stream) {
+    for (int g = 0; g < 4; ++g) {
+        if (!ag->nsh[g]) continue;
+        const int rc = rl_launch_shadow(ag->sh_dev[g], ag->nsh[g], ag->sh_tiles[g], ag->a.param_dev, 0, (hipStream_t)stream);
+        if (rc) { rl_set_error("shadow refresh: hip error %d", rc); return RLREP_ERR_HIP; }
+    }
+    return 0;
 }
 
 // ================================================================================================
@@ -767,6 +942,7 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { rl_set_error("create: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
     if (rl_nc_init() != 0) { rl_set_error("create: cannot reserve LDS for the noise-critic kernels"); return RLREP_ERR_HIP; }
+    if (rl_rowprog_init() != 0) { rl_set_error("create: cannot reserve LDS for the row-program kernel"); return RLREP_ERR_HIP; }
     int rc = build_programs(ag.get(), dims->max_batch);
     if (rc != 0) return rc;
     *out = ag.release();
@@ -846,6 +1022,7 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
     tp.eps.seed = seed; tp.eps.offset = eps_offset; tp.eps.step_dev = ag->steps; tp.eps.step_add = 1;
     slot_fill_params(ag, 0, ring_dev, nullptr, tp.fill);
     tp.counter = ag->steps; tp.ticket = ag->steps + 1;
+    tp.sh = ag->sh_dev[0]; tp.nsh = ag->nsh[0]; tp.nb_tr = ag->sh_tiles[0]; tp.sh_base = ag->a.param_dev;
     rc = rl_launch_train_prologue(&tp, (hipStream_t)stream);
     if (rc) { rl_set_error("train_prologue: hip error %d", rc); return RLREP_ERR_HIP; }
     ag->slot[0].filled = true;
@@ -926,6 +1103,7 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (ag->d.alg == RLREP_ALG_DIFFSRSAC && (!eps || !idx)) { rl_set_error("diffsrsac feature step needs noise_idx[B] and eps[B,S]"); return RLREP_ERR_ARG; }
     if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
+    if (!ag->in_train && ag->has_shadows()) { const int rs = refresh_shadows(ag, stream); if (rs) return rs; }     // parameters may have been written by the caller
     ag->pi_ready = nullptr;                                       // f_target is about to change
     ag->early_ready_crit = ag->early_ready_act = nullptr;
     if (ag->early_crit && !ag->feat_bwd_h.stages.empty()) {
@@ -1019,6 +1197,7 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     if (!ag) return RLREP_ERR_ARG;
     int rc = rl_launch_counter_inc(ag->steps, (hipStream_t)stream);
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
+    if (ag->has_shadows() && (rc = refresh_shadows(ag, stream)) != 0) return rc;
     ag->in_train = true; ag->target_done = false;
     return 0;
 }

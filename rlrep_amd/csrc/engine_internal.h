@@ -52,6 +52,13 @@ struct rlrep_agent {
     std::vector<Exchange> feat_cuts;      // collectives inside the feature backward (world_size > 1 only)
     int last_launches = 0;
     size_t ws_static = 0;     // workspace bytes used by batch-independent state
+    // Transposed shadows of the weight matrices that row programs read in the forward direction (rowprog.hip): per optimizer group a device
+    // table + the shadow storage (workspace, batch independent).  Kept current by the group's Adam launch, regenerated from the
+    // parameters at the head of every train() (rlrep_train_prologue / rlrep_begin_train) and before an eager step outside a train().
+    const ShadowEnt* sh_dev[4] = {nullptr, nullptr, nullptr, nullptr}; int nsh[4] = {0, 0, 0, 0}, sh_tiles[4] = {0, 0, 0, 0};
+    std::map<std::string, float*> shadow_of;
+    float* PT(const std::string& n) const { auto it = shadow_of.find(n); return it == shadow_of.end() ? nullptr : it->second; }
+    bool has_shadows() const { return nsh[0] + nsh[1] + nsh[2] + nsh[3] > 0; }
 
     float* overridden(const std::string& n) const {
         if (!ov_base || n.compare(0, ov_prefix.size(), ov_prefix) != 0) return nullptr;
@@ -209,7 +216,7 @@ struct Builder {
     // step): the separate launch streams it with 16-byte lanes in 4.5 us, the 16 x 16 tile epilogue moves the same
     // bytes in 64-byte row segments and the weight-gradient launches grow by 3.8 / 2.6 / 2.2 / 1.7 us (feature /
     // critic / noise-critic / actor) -- 544 vs 533 us per train().  Opt-in with RLREP_FUSE_ADAM=1.
-    bool fused() const { return allow_fuse && ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev; }
+    bool fused() const { return allow_fuse && ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev && !ag->has_shadows(); }   // (the shadows are maintained by the Adam launch)
     std::vector<FinTask> pending_fin; bool fin_attached = false;
     // hand the finalisation tasks of the step to the NEXT weight-gradient stage (fused mode; ignored otherwise)
     void stash_fin(std::vector<FinTask> f) { pending_fin = fused() ? f : std::vector<FinTask>(); fin_attached = false; }
@@ -281,6 +288,7 @@ struct Builder {
         t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
         t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = pol_steps; t.pol_period = pol_period;
+        t.sh = ag->sh_dev[group]; t.nsh = ag->nsh[group];
         std::vector<AdamTask> tv{t};
         const AdamTask* dev = upload(tv);
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
@@ -315,6 +323,49 @@ struct Builder {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// row-block programs (rowprog.hip): host-side assembler
+// ------------------------------------------------------------------------------------------------
+static inline bool rl_rowprog_enabled() { const char* e = getenv("RLREP_ROWPROG"); return e && e[0] == '1'; }
+struct RpBuf { int off, ld, w; };            // LDS buffer: float offset, row stride, zero-padded width (multiple of 32)
+
+struct RpAsm {
+    std::vector<RpOp> ops; std::vector<RpProg> progs;
+    int top = 0, peak = 0, cur_begin = 0, blocks = 0;
+    static RpOp blank(int kind) { RpOp o; memset(&o, 0, sizeof(o)); o.kind = kind; o.dst = -1; o.dyn = -1; return o; }
+    // LDS regions are bump-allocated per program; `at` re-uses the storage of a dead buffer for a new shape
+    RpBuf buf(int cols) { RpBuf b; b.w = (cols + 31) & ~31; b.ld = b.w + 4; b.off = top; top += RP_ROWS * b.ld; if (top > peak) peak = top; return b; }
+    static RpBuf at(const RpBuf& dead, int cols) { RpBuf b; b.w = (cols + 31) & ~31; b.ld = b.w + 4; b.off = dead.off; if (b.ld > dead.ld) { fprintf(stderr, "rlrep: row-program buffer reuse does not fit\n"); abort(); } return b; }
+    void begin() { cur_begin = (int)ops.size(); top = 0; }
+    void end(int nblocks) { RpProg p; p.op_begin = cur_begin; p.op_end = (int)ops.size(); p.block_base = blocks; p.nblocks = nblocks; blocks += nblocks; progs.push_back(p); }
+    void load(const float* g, int ldg, int K, const RpBuf& d) {
+        RpOp o = blank(RP_LOAD); o.gin = g; o.ldgin = ldg; o.K = K; o.dst = d.off; o.ldd = d.ld; o.wpad = d.w; ops.push_back(o);
+    }
+    // Y = act(X W^T + b): W [N, K] row stride ldw
+    void fwd(const RpBuf& x, int K, const float* W, int ldw, const float* bias, int N, int act, const RpBuf* d, float* gout, int ldg) {
+        RpOp o = blank(RP_GEMM); o.src = x.off; o.lds = x.ld; o.K = K; o.N = N; o.W = W; o.ldw = ldw; o.bias = bias; o.act = act;
+        o.flags = bias ? RPF_BIAS : 0; if (d) { o.dst = d->off; o.ldd = d->ld; o.wpad = d->w; } o.gout = gout; o.ldg = ldg; ops.push_back(o);
+    }
+    // the same layer from the TRANSPOSED weight WT [K, N] (row stride N): the loader of the dX form, whose fragments are contiguous
+    void fwdT(const RpBuf& x, int K, const float* WT, const float* bias, int N, int act, const RpBuf* d, float* gout, int ldg) {
+        RpOp o = blank(RP_GEMM); o.src = x.off; o.lds = x.ld; o.K = K; o.N = N; o.W = WT; o.ldw = N; o.bias = bias; o.act = act;
+        o.flags = RPF_COL | (bias ? RPF_BIAS : 0); if (d) { o.dst = d->off; o.ldd = d->ld; o.wpad = d->w; } o.gout = gout; o.ldg = ldg; ops.push_back(o);
+    }
+    // dX = (G W) * act'(aux): W [K, N] row stride ldw (a column window of a wider matrix is W + offset with the full row stride)
+    void dx(const RpBuf& g, int K, const float* W, int ldw, int N, int act, const RpBuf* mask_lds, const float* mask_g, int ldmask,
+            const RpBuf* d, float* gout, int ldg) {
+        RpOp o = blank(RP_GEMM); o.src = g.off; o.lds = g.ld; o.K = K; o.N = N; o.W = W; o.ldw = ldw; o.act = act; o.flags = RPF_COL;
+        if (act != ACT_NONE && mask_lds) { o.flags |= RPF_MASK_LDS; o.src2 = mask_lds->off; o.lds2 = mask_lds->ld; }
+        else if (act != ACT_NONE && mask_g) { o.flags |= RPF_MASK_GLOBAL; o.gaux = mask_g; o.ldgaux = ldmask; }
+        else o.act = ACT_NONE;
+        if (d) { o.dst = d->off; o.ldd = d->ld; o.wpad = d->w; } o.gout = gout; o.ldg = ldg; ops.push_back(o);
+    }
+    void signal(int flag) { RpOp o = blank(RP_SIGNAL); o.flag = flag; ops.push_back(o); }
+    void wait(int flag) { RpOp o = blank(RP_WAIT); o.flag = flag; ops.push_back(o); }
+    void store(const RpBuf& s, int N, float* g, int ldg) { RpOp o = blank(RP_STORE); o.src = s.off; o.lds = s.ld; o.N = N; o.gout = g; o.ldg = ldg; ops.push_back(o); }
+    size_t lds_bytes() const { return (size_t)peak * sizeof(float); }
+};
 
 struct ActorBufs { float *A1, *A2, *AO, *logp, *dA, *Ghead, *GA2, *GA1; };
 

@@ -26,6 +26,8 @@ struct TrainPrologue {
     SlotFill fill;             // fill.idx == nullptr: row b uses element b of the `idx` stream
     int nb_idx, nb_eps, nb_fill;
     int* counter; int* ticket;
+    // transposed weight shadows regenerated from the parameters as they stand at the head of this train() (32 x 32 tiles, one per block)
+    const struct ShadowEnt* sh; int nsh, nb_tr; const float* sh_base;
 };
 
 // up to 10 float segments + one int copied by ONE launch (rlrep_defer_snapshot)

@@ -235,3 +235,43 @@ def test_train_pools_are_the_documented_streams():
         ip, ep = agent._bufs['pool_idx'].cpu().numpy(), agent._bufs['pool_eps'].cpu().numpy()
         assert np.array_equal(ip, philox.indices(ip.size, c.meta['replay_n'], agent._seed, (1 << 40) + call))
         assert np.max(np.abs(ep - philox.normals(ep.size, 1.0, agent._seed, (2 << 40) + call))) <= 4e-6
+
+
+# ---- the opt-in row-program form of the vlsac feature step (rowprog.hip) ---------------------------------------------------------
+@pytest.mark.parametrize('name,single', [('vlsac_tiny', False), ('vlsac_hc', False), ('vlsac_tiny', True)])
+def test_row_program_feature_step_matches_oracle(name, single, monkeypatch):
+    """RLREP_ROWPROG=1: forward + dX chains of a feature step as one launch of row-block programs (two workgroups per 16-row block that
+    hand the Gaussian heads / KL gradients to each other through flags; RLREP_ROWPROG_SINGLE=1: one workgroup per block, no hand-off),
+    reading the forward layers' weights from transposed shadows that the Adam launch keeps current -- in the default (graph, pipelined)
+    mode against the oracle on the read-back draws, like every other default-mode test."""
+    monkeypatch.setenv('RLREP_ROWPROG', '1')
+    if single:
+        monkeypatch.setenv('RLREP_ROWPROG_SINGLE', '1')
+    c = Case(name)
+    worst = _check_against_oracle(c, calls=3, expect_pipeline=True)
+    print(f'{name} row programs vs oracle: worst param rel-L2 {worst:.2e}')
+
+
+def test_row_program_shadows_follow_external_parameter_writes(monkeypatch):
+    """The transposed shadows are regenerated at the head of every train() and before an eager feature step: parameters overwritten by
+    the caller between calls (load_state / checkpoint load) are what the next step uses."""
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    monkeypatch.setenv('RLREP_ROWPROG', '1')
+    c = Case('vlsac_tiny')
+    agent, buf = _default_agent(c), _buffer(c)
+    agent.train(buf, c.B)
+    agent.flush()
+    agent.core.load_state(c.init)                                 # back to the fixture's parameters, behind the library's back
+    agent.core.exp_avg.zero_(); agent.core.exp_avg_sq.zero_()
+    agent.core.group_cfg()[:, 0] = 0                              # Adam step counters (int32 zero == float zero bit pattern)
+    agent.core.alpha_state[1:] = 0
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    rs = np.random.RandomState(3)
+    idx = rs.randint(0, c.meta['replay_n'], size=c.B)
+    eps = rs.standard_normal((c.B, c.kw['feature_dim'])).astype(np.float32)
+    batch = buf.gather(torch.as_tensor(idx, device='cuda'))
+    info = agent.feature_step(batch, eps=torch.as_tensor(eps, device='cuda'))
+    oinfo = o.feature_step(gather_batch(c.replay, idx), torch.as_tensor(eps))
+    for k, v in oinfo.items():
+        assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (k, info[k], v)
