@@ -77,8 +77,14 @@ typedef struct {
     int32_t num_noise;         /* vlsac critic noise rows (20) / diffsr num_noises (1000) */
     int32_t max_batch;         /* largest batch size this agent will be stepped with */
     int32_t rank;              /* data-parallel rank of this replica (0 when world_size == 1) */
-    int32_t reserved[2];
+    int32_t flags;             /* RLREP_FLAG_* */
+    int32_t reserved[1];
 } rlrep_dims;
+
+/* vlsac / ctrlsac / spedersac constructed with use_feature_target=False (vlsac_agent.py:113-114,176-179,214-219,257-258;
+ * ctrlsac_agent.py:167-168,185-186,268-273,340-346; spedersac_agent.py:150-151,306-307): no Polyak copy of the feature net; vlsac's critic
+ * and actor steps read the LIVE f, ctrlsac's critic step reads frozen_phi.  The target tensors stay in the layout and are never touched. */
+#define RLREP_FLAG_NO_FEATURE_TARGET 1
 
 /* Hyper-parameters (mirrors the reference constructors' scalar kwargs). */
 typedef struct {
@@ -95,7 +101,7 @@ typedef struct {
     int32_t learn_alpha;       /* auto_entropy_tuning */
     int32_t world_size;        /* data-parallel replicas: local losses are scaled by 1/(B*world_size) */
     float beta1, beta2, adam_eps;
-    float reserved[1];
+    float critic_reg_lambda;   /* diffsr critic_elu_layer_regularizer_lambda (diffsrsac_agent.py:62-90,215-227): enters q_loss_reg only */
 } rlrep_hyper;
 
 /* One named tensor inside an arena (what nn.Parameter views / state_dict() are built from). */

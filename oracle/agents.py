@@ -238,8 +238,12 @@ class OracleVLSAC(OracleSAC):
     """agent/vlsac/vlsac_agent.py:67-273."""
     alg = 'vlsac'
 
-    def __init__(self, S, A, params, lr=1e-4, feature_tau=0.001, extra_feature_steps=3, **kw):
+    def __init__(self, S, A, params, lr=1e-4, feature_tau=0.001, extra_feature_steps=3, use_feature_target=True, **kw):
         self.feature_tau, self.extra = feature_tau, extra_feature_steps
+        # vlsac_agent.py:113-114, 176-179, 214-219, 257-258: without a feature target the critic / actor steps read the LIVE f
+        # and there is no f_target (no Polyak either)
+        self.use_feature_target = bool(use_feature_target)
+        self.fnet = 'f_target' if self.use_feature_target else 'f'
         super().__init__(S, A, params, lr=lr, **kw)
 
     def _make_optimizers(self):
@@ -271,8 +275,9 @@ class OracleVLSAC(OracleSAC):
                 's_loss': s_loss.item(), 'r_loss': r_loss.item()}
 
     def update_feature_target(self):
-        """vlsac_agent.py:240-242."""
-        polyak(self.P, 'f', 'f_target', self.feature_tau)
+        """vlsac_agent.py:240-242 (called only with a feature target, :257-258)."""
+        if self.use_feature_target:
+            polyak(self.P, 'f', 'f_target', self.feature_tau)
 
     def critic_step(self, batch, eps_next):
         """vlsac_agent.py:201-237."""
@@ -280,8 +285,8 @@ class OracleVLSAC(OracleSAC):
         with torch.no_grad():
             mu, std = actor_mu_std(P, batch.next_state)
             a2, logp = squashed_rsample_logp(mu, std, eps_next)
-            mean, log_std = gauss_head(P, 'f_target', torch.cat([batch.state, batch.action], -1))
-            nmean, nlog_std = gauss_head(P, 'f_target', torch.cat([batch.next_state, a2], -1))
+            mean, log_std = gauss_head(P, self.fnet, torch.cat([batch.state, batch.action], -1))
+            nmean, nlog_std = gauss_head(P, self.fnet, torch.cat([batch.next_state, a2], -1))
             nq1, nq2 = vl_critic(P, 'critic_target', nmean, nlog_std)
             next_q = torch.min(nq1, nq2) - self.alpha * logp
             target_q = batch.reward + (1. - batch.done) * self.discount * next_q
@@ -292,7 +297,7 @@ class OracleVLSAC(OracleSAC):
                 'q1': q1.mean().item(), 'q2': q2.mean().item()}
 
     def _actor_q(self, obs, action):
-        mean, log_std = gauss_head(self.P, 'f_target', torch.cat([obs, action], -1))
+        mean, log_std = gauss_head(self.P, self.fnet, torch.cat([obs, action], -1))
         return vl_critic(self.P, 'critic', mean, log_std)
 
     def train(self, batches, noise):
@@ -317,8 +322,9 @@ class OracleCTRLSAC(OracleSAC):
     alg = 'ctrlsac'
     actor_lr_div = 3.0                                   # ctrlsac_agent.py:195-197
 
-    def __init__(self, S, A, params, lr=1e-4, feature_tau=0.005, extra_feature_steps=3, **kw):
+    def __init__(self, S, A, params, lr=1e-4, feature_tau=0.005, extra_feature_steps=3, use_feature_target=True, **kw):
         self.feature_tau, self.extra = feature_tau, extra_feature_steps
+        self.use_feature_target = bool(use_feature_target)      # ctrlsac_agent.py:167-168, 185-186, 268-273, 340-346
         super().__init__(S, A, params, lr=lr, **kw)
 
     def _make_optimizers(self):
@@ -344,8 +350,9 @@ class OracleCTRLSAC(OracleSAC):
         return {'total_loss': loss.item(), 'model_loss': model_loss.item(), 'r_loss': r_loss.item()}
 
     def update_feature_target(self):
-        """ctrlsac_agent.py:253-255."""
-        polyak(self.P, 'phi', 'phi_target', self.feature_tau)
+        """ctrlsac_agent.py:253-255 (called only with a feature target, :340-341)."""
+        if self.use_feature_target:
+            polyak(self.P, 'phi', 'phi_target', self.feature_tau)
 
     def sync_frozen(self):
         """ctrlsac_agent.py:344-346: BOTH frozen copies are loaded from `phi` (quirk Q8)."""
@@ -362,8 +369,9 @@ class OracleCTRLSAC(OracleSAC):
         with torch.no_grad():
             mu, std = actor_mu_std(P, batch.next_state)
             a2, logp = squashed_rsample_logp(mu, std, eps_next)
-            z = ctrl_phi(P, 'frozen_phi_target', batch.state, batch.action)
-            z2 = ctrl_phi(P, 'frozen_phi_target', batch.next_state, a2)
+            fz = 'frozen_phi_target' if self.use_feature_target else 'frozen_phi'
+            z = ctrl_phi(P, fz, batch.state, batch.action)
+            z2 = ctrl_phi(P, fz, batch.next_state, a2)
             nq1, nq2 = ctrl_critic(P, 'critic_target', z2)
             target_q = batch.reward + (1. - batch.done) * self.discount * (torch.min(nq1, nq2) - self.alpha * logp)
         q1, q2 = ctrl_critic(P, 'critic', z)
@@ -398,8 +406,9 @@ class OracleSPEDERSAC(OracleSAC):
     alg = 'spedersac'
 
     def __init__(self, S, A, params, phi_and_mu_lr=1e-5, critic_and_actor_lr=3e-4, feature_tau=0.005,
-                 extra_feature_steps=5, phi_hidden_depth=1, mu_hidden_depth=0, **kw):
+                 extra_feature_steps=5, phi_hidden_depth=1, mu_hidden_depth=0, use_feature_target=True, **kw):
         self.feature_tau, self.extra = feature_tau, extra_feature_steps
+        self.use_feature_target = bool(use_feature_target)      # spedersac_agent.py:150-151, 306-307 (phi_target is never read)
         self.feat_lr = phi_and_mu_lr
         self.phi_depth, self.mu_depth = phi_hidden_depth, mu_hidden_depth
         kw.pop('lr', None)
@@ -439,8 +448,9 @@ class OracleSPEDERSAC(OracleSAC):
         return {'total_loss': loss.item(), 'model_loss': model_loss.item(), 'r_loss': r_loss.item()}
 
     def update_feature_target(self):
-        """spedersac_agent.py:221-223."""
-        polyak(self.P, 'phi', 'phi_target', self.feature_tau)
+        """spedersac_agent.py:221-223 (called only with a feature target, :306-307)."""
+        if self.use_feature_target:
+            polyak(self.P, 'phi', 'phi_target', self.feature_tau)
 
     def critic_step(self, batch, eps_next):
         """spedersac_agent.py:225-257 (critic reads the LIVE phi under no_grad)."""
@@ -484,8 +494,9 @@ class OracleDIFFSRSAC(OracleSAC):
 
     def __init__(self, S, A, params, feature_dim=256, phi_and_nabla_mu_lr=0.003, critic_and_actor_lr=3e-4,
                  extra_feature_steps=3, sigma_scale_factor=0.449, phi_hidden_depth=1,
-                 nabla_mu_hidden_depth=1, **kw):
+                 nabla_mu_hidden_depth=1, critic_elu_layer_regularizer_lambda=0, **kw):
         self.extra = extra_feature_steps
+        self.reg_lambda = float(critic_elu_layer_regularizer_lambda)
         self.feat_lr = phi_and_nabla_mu_lr
         self.sigma = sigma_scale_factor
         self.F = feature_dim
@@ -529,18 +540,37 @@ class OracleDIFFSRSAC(OracleSAC):
         self.opt_phi.step(P, grads)
         return {'score_loss': loss.item()}
 
+    def _reg_terms(self, prefix, z):
+        """diffsrsac_agent.py:62-90: per head, x = l2(elu(l2(sin(l1 z)))) -- the SECOND linear layer applied once more to its own ELU
+        output -- and lambda * ( (sum_{i != j} (x_i . x_j)^2) / ((n - 1) n) - 2 mean_i |x_i|^2 / d + 1 / d )."""
+        P, lam = self.P, self.reg_lambda
+        total = 0.
+        for l1, l2 in (('.l1', '.l2'), ('.l4', '.l5')):
+            e = F.elu(_lin(P, prefix + l2, torch.sin(_lin(P, prefix + l1, z))))
+            x = _lin(P, prefix + l2, e)
+            n, d = x.shape
+            inprods = x @ x.T
+            norms = torch.diagonal(inprods)
+            part1 = (inprods.pow(2).sum() - norms.pow(2).sum()) / ((n - 1) * n)
+            total = total + lam * (part1 - 2. * norms.mean() / d + 1. / d)
+        return total
+
     def critic_step(self, batch, eps_next):
-        """diffsrsac_agent.py:205-239: the loss is evaluated but no parameter moves (quirk Q11);
-        reg terms are 0 (lambda=0, Q12) so q_loss_reg == q_loss_noreg; info['q2'] repeats q1 (Q13)."""
+        """diffsrsac_agent.py:205-239: the loss is evaluated but no parameter moves (quirk Q11); the regulariser of the target AND the
+        live critic enters q_loss_reg only (0 at the default lambda, Q12); info['q2'] repeats q1 (Q13)."""
         P = self.P
         with torch.no_grad():
             mu, std = actor_mu_std(P, batch.next_state)
             a2, logp = squashed_rsample_logp(mu, std, eps_next)
-            tq1, tq2 = rff_critic(P, 'critic_target', self.phi(batch.next_state, a2))
+            zn, zc = self.phi(batch.next_state, a2), self.phi(batch.state, batch.action)
+            tq1, tq2 = rff_critic(P, 'critic_target', zn)
             target_q = batch.reward + (1. - batch.done) * self.discount * (torch.min(tq1, tq2) - self.alpha.detach() * logp)
-            q1, q2 = rff_critic(P, 'critic', self.phi(batch.state, batch.action))
+            q1, q2 = rff_critic(P, 'critic', zc)
             loss = F.mse_loss(q1, target_q) + F.mse_loss(q2, target_q)
-        return {'q_loss_reg': loss.item(), 'q_loss_noreg': loss.item(), 'q1': q1.mean().item(), 'q2': q1.mean().item()}
+            reg = 0.
+            if self.reg_lambda != 0:
+                reg = self._reg_terms('critic_target', zn) + self._reg_terms('critic', zc)
+        return {'q_loss_reg': float(loss + reg), 'q_loss_noreg': loss.item(), 'q1': q1.mean().item(), 'q2': q1.mean().item()}
 
     def _actor_q(self, obs, action):
         return rff_critic(self.P, 'critic', self.phi(obs, action))
@@ -574,9 +604,13 @@ _CLASSES = {'sac': OracleSAC, 'vlsac': OracleVLSAC, 'ctrlsac': OracleCTRLSAC,
 def make_oracle(alg, S, A, params, **hp):
     """hp: the reference constructor's keyword arguments (unknown ones are ignored)."""
     hp = dict(hp)
-    for k in ('hidden_dim', 'alpha', 'use_feature_target', 'phi_hidden_dim', 'mu_hidden_dim',
+    if alg not in ('vlsac', 'ctrlsac', 'spedersac'):
+        hp.pop('use_feature_target', None)
+    if alg != 'diffsrsac':
+        hp.pop('critic_elu_layer_regularizer_lambda', None)
+    for k in ('hidden_dim', 'alpha', 'phi_hidden_dim', 'mu_hidden_dim',
               'critic_and_actor_hidden_dim', 'nabla_mu_hidden_dim', 'num_noises',
-              'critic_elu_layer_regularizer_lambda', 'DARL_noise_a', 'DARL_noise_b', 'action_space',
+              'DARL_noise_a', 'DARL_noise_b', 'action_space',
               'state_dim', 'action_dim'):
         hp.pop(k, None)
     if alg in ('sac', 'vlsac', 'ctrlsac'):

@@ -17,13 +17,14 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'rlrep.h')
 ALG = {'sac': 0, 'vlsac': 1, 'ctrlsac': 2, 'spedersac': 3, 'diffsrsac': 4}
 ARENA_PARAM, ARENA_TARGET = 0, 1
 GRAD_TAIL = 256
+FLAG_NO_FEATURE_TARGET = 1
 
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'alg', 'state_dim', 'action_dim', 'hidden_dim', 'actor_hidden_dim', 'feature_dim', 'vae_hidden_dim',
-        'phi_hidden_dim', 'phi_hidden_depth', 'mu_hidden_dim', 'mu_hidden_depth', 'num_noise', 'max_batch', 'rank')] + \
-        [('reserved', C.c_int32 * 2)]
+        'phi_hidden_dim', 'phi_hidden_depth', 'mu_hidden_dim', 'mu_hidden_depth', 'num_noise', 'max_batch', 'rank', 'flags')] + \
+        [('reserved', C.c_int32 * 1)]
 
 
 class Hyper(C.Structure):
@@ -32,7 +33,7 @@ class Hyper(C.Structure):
                 ('target_entropy', C.c_float), ('sigma_scale', C.c_float),
                 ('target_update_period', C.c_int32), ('extra_feature_steps', C.c_int32),
                 ('learn_alpha', C.c_int32), ('world_size', C.c_int32),
-                ('beta1', C.c_float), ('beta2', C.c_float), ('adam_eps', C.c_float), ('reserved', C.c_float * 1)]
+                ('beta1', C.c_float), ('beta2', C.c_float), ('adam_eps', C.c_float), ('critic_reg_lambda', C.c_float)]
 
 
 class TensorDesc(C.Structure):

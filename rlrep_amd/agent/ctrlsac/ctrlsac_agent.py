@@ -3,6 +3,7 @@
 feature_step = InfoNCE over the BxB score matrix phi(s,a).mu(s')^T (a GEMM, not the reference's [B,B,F]
 broadcast: quirk Q6) + 0.5*mse(theta(phi), r), Adam and Polyak phi->phi_target in one step program.
 """
+from rlrep_amd import _lib
 from rlrep_amd.agent.sac.sac_agent import SACAgent, device  # noqa: F401
 
 
@@ -15,17 +16,19 @@ class CTRLSACAgent(SACAgent):
     def __init__(self, state_dim, action_dim, action_space, lr=1e-4, discount=0.99, target_update_period=2,
                  tau=0.005, alpha=0.1, auto_entropy_tuning=True, hidden_dim=1024, feature_tau=0.005,
                  feature_dim=2048, use_feature_target=True, extra_feature_steps=1, **_hip):
-        if not use_feature_target:
-            raise NotImplementedError('use_feature_target=False is not built (main.py never sets it)')
         self._init_common(state_dim, action_dim, action_space, discount, target_update_period, tau, alpha,
                           auto_entropy_tuning)
         self.feature_dim, self.feature_tau = int(feature_dim), float(feature_tau)
-        self.use_feature_target = True
+        self.use_feature_target = bool(use_feature_target)
+        if not self.use_feature_target:
+            # ctrlsac_agent.py:167-168, 185-186: no phi_target / frozen_phi_target attributes; the critic step reads frozen_phi (:268-273)
+            self.MODULES = tuple(m for m in self.MODULES if m not in ('phi_target', 'frozen_phi_target'))
         self.extra_feature_steps = int(extra_feature_steps)
         # actor hidden is hard-coded to 256 (ctrlsac_agent.py:188-194); actor and alpha use lr/3 (:195-197)
         self._dims = dict(state_dim=state_dim, action_dim=action_dim, hidden_dim=hidden_dim, actor_hidden_dim=256,
                           feature_dim=feature_dim, phi_hidden_dim=hidden_dim, phi_hidden_depth=2,
-                          mu_hidden_dim=hidden_dim, mu_hidden_depth=2)
+                          mu_hidden_dim=hidden_dim, mu_hidden_depth=2,
+                          flags=0 if self.use_feature_target else _lib.FLAG_NO_FEATURE_TARGET)
         self._hyper = dict(lr_feature=lr, lr_critic=lr, lr_actor=lr / 3)
         self._finish_init(_hip)
 

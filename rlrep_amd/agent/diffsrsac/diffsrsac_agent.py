@@ -71,8 +71,6 @@ class DIFFSRSACAgent(SACAgent):
                  auto_entropy_tuning=True, hidden_dim=256, extra_feature_steps=3, num_noises=1000,
                  critic_elu_layer_regularizer_lambda=0, DARL_noise_a=0.3, DARL_noise_b=0.1,
                  sigma_scale_factor=0.449, **_hip):
-        if critic_elu_layer_regularizer_lambda != 0:
-            raise NotImplementedError('the ELU-layer regulariser is only built for lambda=0 (the reference default)')
         self._init_common(state_dim, action_dim, action_space, discount, target_update_period, tau, alpha,
                           auto_entropy_tuning)
         self.feature_dim = int(feature_dim)
@@ -84,7 +82,7 @@ class DIFFSRSACAgent(SACAgent):
                           feature_dim=feature_dim, phi_hidden_dim=phi_hidden_dim, phi_hidden_depth=phi_hidden_depth,
                           mu_hidden_dim=nabla_mu_hidden_dim, mu_hidden_depth=nabla_mu_hidden_depth, num_noise=num_noises)
         self._hyper = dict(lr_feature=phi_and_nabla_mu_lr, lr_critic=critic_and_actor_lr, lr_actor=critic_and_actor_lr,
-                           sigma_scale=sigma_scale_factor)
+                           sigma_scale=sigma_scale_factor, critic_reg_lambda=float(critic_elu_layer_regularizer_lambda))
         self._finish_init(_hip)
 
     def _init_parameters(self):

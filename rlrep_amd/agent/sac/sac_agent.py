@@ -147,7 +147,7 @@ class SACAgent(object):
         self.max_batch = int(hip_kwargs.get('max_batch', os.environ.get('RLREP_MAX_BATCH', 256)))
         self.world_size, self.rank = _world()
         dims = dict(feature_dim=0, vae_hidden_dim=0, phi_hidden_dim=0, phi_hidden_depth=0, mu_hidden_dim=0,
-                    mu_hidden_depth=0, num_noise=0, max_batch=self.max_batch)
+                    mu_hidden_depth=0, num_noise=0, max_batch=self.max_batch, flags=0)
         dims.update(self._dims)
         dims['rank'] = self.rank
         hyper = dict(discount=self.discount, tau=self.tau, feature_tau=float(self.feature_tau),

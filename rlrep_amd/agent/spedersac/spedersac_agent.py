@@ -3,6 +3,7 @@
 feature_step = spectral-decomposition loss in its O(B*F) form (quirk Q10) on two minibatches + reward head,
 Adam and Polyak phi->phi_target; critic = RFF critic sin/ELU on the LIVE phi.
 """
+from rlrep_amd import _lib
 from rlrep_amd.agent.sac.sac_agent import SACAgent, device  # noqa: F401
 
 
@@ -18,17 +19,18 @@ class SPEDERSACAgent(SACAgent):
                  discount=0.99, target_update_period=2, tau=0.005, alpha=0.1, auto_entropy_tuning=True,
                  hidden_dim=1024, feature_tau=0.005, feature_dim=2048, use_feature_target=True,
                  extra_feature_steps=1, **_hip):
-        if not use_feature_target:
-            raise NotImplementedError('use_feature_target=False is not built (main.py never sets it)')
         self._init_common(state_dim, action_dim, action_space, discount, target_update_period, tau, alpha,
                           auto_entropy_tuning)
         self.feature_dim, self.feature_tau = int(feature_dim), float(feature_tau)
-        self.use_feature_target = True
+        self.use_feature_target = bool(use_feature_target)
+        if not self.use_feature_target:
+            self.MODULES = tuple(m for m in self.MODULES if m != 'phi_target')       # spedersac_agent.py:150-151
         self.extra_feature_steps = int(extra_feature_steps)
         self._dims = dict(state_dim=state_dim, action_dim=action_dim, hidden_dim=critic_and_actor_hidden_dim,
                           actor_hidden_dim=critic_and_actor_hidden_dim, feature_dim=feature_dim,
                           phi_hidden_dim=max(phi_hidden_dim, 1), phi_hidden_depth=phi_hidden_depth,
-                          mu_hidden_dim=max(mu_hidden_dim, 1), mu_hidden_depth=mu_hidden_depth)
+                          mu_hidden_dim=max(mu_hidden_dim, 1), mu_hidden_depth=mu_hidden_depth,
+                          flags=0 if self.use_feature_target else _lib.FLAG_NO_FEATURE_TARGET)
         self._hyper = dict(lr_feature=phi_and_mu_lr, lr_critic=critic_and_actor_lr, lr_actor=critic_and_actor_lr)
         self._finish_init(_hip)
 

@@ -5,6 +5,7 @@
 extern "C" {
 int rl_launch_infonce(const InfoNce* p, hipStream_t st);
 int rl_launch_colsum(const ColSum* p, hipStream_t st);
+int rl_launch_reg_stats(const RegStats* p, hipStream_t st);
 int rl_launch_speder_rows(const SpederRows* p, hipStream_t st);
 int rl_launch_speder_grads(const SpederGrads* p, hipStream_t st);
 int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st);
@@ -254,7 +255,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         {
             const LT& q0 = ag->L.get("phi.l1.weight");
             const LT& ql = ag->L.get("phi.l3.bias");
-            b.set_polyak(Tw("phi_target.l1.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
+            if (!(ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET)) b.set_polyak(Tw("phi_target.l1.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
         }
         b.dw_stage(p, {Builder::dw(pf.GZ, F, F, pf.P2, Hp, Hp, B, Gw("phi.l3.weight"), Hp, Gw("phi.l3.bias")),
                        Builder::dw(GZM, F, F, M2, Hm, Hm, B, Gw("mu.l3.weight"), Hm, Gw("mu.l3.bias")),
@@ -267,13 +268,15 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         const LT& p0 = ag->L.get("phi.l1.weight");
         const LT& pl = ag->L.get("phi.l3.bias");
         float* m = ag->metrics;
-        b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("phi_target.l1.weight"), p0.off, pl.off + pl.rows - p0.off, ag->h.feature_tau,
+        // use_feature_target=False (ctrlsac_agent.py:340-346): no Polyak into phi_target, frozen_phi_target is not written
+        const bool nft = (ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET) != 0;
+        b.adam(ag->feat_apply, 0, ag->h.lr_feature, nft ? nullptr : Tw("phi_target.l1.weight"), p0.off, pl.off + pl.rows - p0.off, ag->h.feature_tau,
                {Builder::fin_sum(part_f + 0, nblk_f, 2, 1.0f / (float)B, m + M_FEAT_A),
                 Builder::fin_sum(part_f + 1, nblk_f, 2, 0.5f / (float)B, m + M_R_LOSS),
                 Builder::fin_combine(m + M_FEAT_A, 1.f, m + M_R_LOSS, 1.f, m + M_FEAT_TOTAL)}, "adam feature + polyak phi");
         // ctrlsac_agent.py:344-346: frozen_phi, frozen_phi_target <- phi (quirk Q8)
         const long long pn = pl.off + pl.rows - p0.off;
-        float* src = Pw("phi.l1.weight"); float* d1 = Tw("frozen_phi.l1.weight"); float* d2 = Tw("frozen_phi_target.l1.weight");
+        float* src = Pw("phi.l1.weight"); float* d1 = Tw("frozen_phi.l1.weight"); float* d2 = nft ? nullptr : Tw("frozen_phi_target.l1.weight");
         ag->sync_prog.stages.push_back({[=](hipStream_t st) { return rl_launch_copy2(src, d1, d2, pn, st); }, "frozen_phi* <- phi"});
     }
 
@@ -389,13 +392,50 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
                 critic_apply_folded(b, ag, "critic_target.l1.weight", critic_fins(ag, part_q, nblk));
             }
         } else if (emit_apply) {
-            // diffsrsac (quirk Q11): metrics only.  q_loss_reg == q_loss_noreg (lambda = 0, Q12); q2 := q1 (Q13)
+            // diffsrsac (quirk Q11): metrics only; q2 := q1 (Q13).  q_loss_noreg = mse1 + mse2; q_loss_reg adds the ELU-layer regulariser
+            // of BOTH nets' two heads (diffsrsac_agent.py:62-90, 215-227), which is lambda * (...) = 0 at the default lambda (Q12)
             const float ib = 1.0f / (float)B;
             float* m = ag->metrics;
-            b.finalize_only(papply, {Builder::fin_sum(part_q + 0, nblk, 4, ib, m + M_TMP0), Builder::fin_sum(part_q + 1, nblk, 4, ib, m + M_TMP1),
-                                               Builder::fin_combine(m + M_TMP0, 1.f, m + M_TMP1, 1.f, m + M_Q1_LOSS),
-                                               Builder::fin_copy(m + M_Q1_LOSS, m + M_Q2_LOSS),
-                                               Builder::fin_sum(part_q + 2, nblk, 4, ib, m + M_Q1), Builder::fin_copy(m + M_Q1, m + M_Q2)}, "critic metrics");
+            std::vector<FinTask> fins = {Builder::fin_sum(part_q + 0, nblk, 4, ib, m + M_TMP0), Builder::fin_sum(part_q + 1, nblk, 4, ib, m + M_TMP1),
+                                         Builder::fin_combine(m + M_TMP0, 1.f, m + M_TMP1, 1.f, m + M_Q2_LOSS),
+                                         Builder::fin_sum(part_q + 2, nblk, 4, ib, m + M_Q1), Builder::fin_copy(m + M_Q1, m + M_Q2)};
+            // (the regulariser's buffers are reserved whatever lambda is: rlrep_layout sizes the workspace from the dimensions alone)
+            float* XR = ws.f((size_t)4 * BH); float* CR = ws.f((size_t)4 * H * H);
+            RegStats rs; memset(&rs, 0, sizeof(rs));
+            rs.B = B; rs.H = H; rs.lambda = ag->h.critic_reg_lambda;
+            rs.nbc = (int)(((long long)H * H + 1023) / 1024); rs.nbr = (B + 3) / 4;
+            float* part_r = ws.f((size_t)4 * (rs.nbc + rs.nbr));
+            rs.partial = part_r;
+            {
+                // x = l2(E) once more on the ELU outputs (no activation), C = x^T x through the weight-gradient form, then the statistics.
+                // With lambda = 0 the stages are built into a scratch program and dropped: the builder's workspace reservations (split-K
+                // slabs) then stay a function of the dimensions alone
+                Program scratch;
+                const bool reg_on = ag->h.critic_reg_lambda != 0.f;
+                Program& pr = reg_on ? p : scratch;
+                std::vector<GemmTask> fw, gr;
+                for (int k = 0; k < 4; ++k) {
+                    const bool tgt = k < 2; const int head = k & 1;
+                    const RffBufs& r = tgt ? rt : rc;
+                    const std::string mname = tgt ? "critic_target" : "critic";
+                    auto w = [&](const char* nm) { return tgt ? ag->T(mname + nm) : ag->P(mname + nm); };
+                    float* xk = XR ? XR + (size_t)k * BH : nullptr; float* ck = CR ? CR + (size_t)k * H * H : nullptr;
+                    fw.push_back(Builder::fwd(r.E ? r.E + (size_t)head * BH : nullptr, H, B, H, w(head ? ".l5.weight" : ".l2.weight"), H, w(head ? ".l5.bias" : ".l2.bias"), H, xk, H, ACT_NONE));
+                    gr.push_back(Builder::dw(xk, H, H, xk, H, H, B, ck, H, nullptr));
+                    rs.X[k] = xk; rs.C[k] = ck;
+                }
+                b.fwd_stage(pr, fw, "critic regulariser: l2/l5 on the ELU outputs");
+                b.gemm(pr, LD_COL, LD_COL, gr, "critic regulariser: Gram matrices");
+                pr.stages.push_back({[=](hipStream_t st) { return rl_launch_reg_stats(&rs, st); }, "critic regulariser statistics"});
+                if (reg_on) {
+                    fins.push_back(Builder::fin_sum(part_r, 4 * (rs.nbc + rs.nbr), 1, 1.0f, m + M_TMP2));
+                    fins.push_back(Builder::fin_combine(m + M_Q2_LOSS, 1.f, m + M_TMP2, 1.f, m + M_Q1_LOSS));
+                } else {
+                    fins.push_back(Builder::fin_copy(m + M_Q2_LOSS, m + M_Q1_LOSS));
+                    fins.push_back(Builder::fin_copy(m + M_Q2_LOSS, m + M_Q1_LOSS));       // (same table size with and without the regulariser)
+                }
+            }
+            b.finalize_only(papply, fins, "critic metrics");
         }
     };
     auto actor_program = [&](Program& p) {
@@ -496,7 +536,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
             t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
             const LT& q0 = ag->L.get(phi.name(0) + ".weight");
             const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
-            b.set_polyak(ag->T("phi_target.trunk.0.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
+            if (!(ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET)) b.set_polyak(ag->T("phi_target.trunk.0.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
             b.dw_stage(p, t, "feature dW");
             b.clear_polyak();
         }
@@ -504,7 +544,8 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         const LT& pl = ag->L.get(phi.name(phi.depth) + ".bias");
         float* m = ag->metrics;
         const float ib = 1.0f / (float)B;
-        b.adam(ag->feat_apply, 0, ag->h.lr_feature, ag->T("phi_target.trunk.0.weight"), p0.off, pl.off + pl.rows - p0.off, ag->h.feature_tau,
+        // use_feature_target=False (spedersac_agent.py:306-307): no Polyak into the (never read) phi_target
+        b.adam(ag->feat_apply, 0, ag->h.lr_feature, (ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET) ? nullptr : ag->T("phi_target.trunk.0.weight"), p0.off, pl.off + pl.rows - p0.off, ag->h.feature_tau,
                {Builder::fin_sum(part_f + 0, nblk_f, 3, -2.0f * ib, m + M_TMP0), Builder::fin_sum(part_f + 1, nblk_f, 3, ib * ib, m + M_TMP1),
                 Builder::fin_combine(m + M_TMP0, 1.f, m + M_TMP1, 1.f, m + M_FEAT_A),
                 Builder::fin_sum(part_f + 2, nblk_f, 3, 0.5f * ib, m + M_R_LOSS),

@@ -287,6 +287,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     Slot& s0 = ag->slot[0];
     Workspace& ws = b.ws;
     b.allow_fuse = true;       // every parameter tensor of the three groups gets exactly one weight-gradient task below
+    // use_feature_target=False (vlsac_agent.py:176-179, 214-219, 257-258): critic and actor steps read the LIVE f, no Polyak into f_target
+    const bool nft = (ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET) != 0;
+    const std::string fnet = nft ? "f" : "f_target";
+    auto FT = [&](const char* n) { return nft ? ag->P(std::string("f.") + n) : ag->T(std::string("f_target.") + n); };
     auto Pw = [&](const char* n) { return ag->P(n); };
     auto Tw = [&](const char* n) { return ag->T(n); };
     auto Gw = [&](const char* n) { return ag->G(n); };
@@ -483,7 +487,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         {
             const LT& f0 = ag->L.get("f.l1.weight");
             const LT& fl = ag->L.get("f.log_std_linear.bias");
-            b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
+            if (!nft) b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
         }
         b.stash_fin({
             Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
@@ -515,7 +519,8 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         const LT& f0 = ag->L.get("f.l1.weight");
         const LT& flast = ag->L.get("f.log_std_linear.bias");
         const int64_t fn = flast.off + flast.rows - f0.off;
-        b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau, feat_fins, "adam feature + polyak f");
+        if (nft) b.adam(ag->feat_apply, 0, ag->h.lr_feature, nullptr, 0, 0, 0.f, feat_fins, "adam feature");
+        else b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau, feat_fins, "adam feature + polyak f");
     }
 
     // ---- critic / actor shared buffers ----
@@ -570,9 +575,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         Builder::fin_sum(part_q + 2, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1), Builder::fin_sum(part_q + 3, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2)};
     auto critic_program = [&](Program& p, int hoist) {      // 0: plain, 1: carries the actor step's forward half, 2: both policies ran already
         GemmTask tt[3], tn[3], tp[3];
-        gauss_tasks(ag, true, "f_target", s0.XF, SA, SA, gt, tt);
-        gauss_tasks(ag, true, "f_target", s0.XF2, SA, SA, gn, tn);
-        gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gp, tp);
+        gauss_tasks(ag, !nft, fnet, s0.XF, SA, SA, gt, tt);
+        gauss_tasks(ag, !nft, fnet, s0.XF2, SA, SA, gn, tn);
+        gauss_tasks(ag, !nft, fnet, s0.XFpi, SA, SA, gp, tp);
         if (hoist == 2) {
             b.fwd_stage(p, {tt[0], tn[0], tp[0]}, "ft.l1(s,a) ft.l1(s',a') ft.l1(s,a_pi)");
             b.fwd_stage(p, {tt[1], tn[1], tp[1]}, "ft.l2 x3");
@@ -663,7 +668,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     // ---- actor + temperature step (vlsac_agent.py:165-198) ----
     auto actor_program = [&](Program& p, int& resume) {
         GemmTask tt[3];
-        gauss_tasks(ag, true, "f_target", s0.XFpi, SA, SA, gp, tt);
+        gauss_tasks(ag, !nft, fnet, s0.XFpi, SA, SA, gp, tt);
         b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "actor.l1(s)");
         b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab_pi)}, "actor.l2");
         actor_head_stage(b, p, ag, ab_pi, s0.XFpi + S, SA, {}, "actor.head + policy");
@@ -692,10 +697,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 3) / 4) * t.tiles_k; t.tile_base = 0;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(&t, st); }, "noise critic dX -> (dmean, dlog_std)"});
         }
-        b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, Tw("f_target.mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gp.H2, Hv)}, "ft.heads dx");
-        b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, Tw("f_target.l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gp.H1, Hv)}, "ft.l2 dx");
+        b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, FT("mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gp.H2, Hv)}, "ft.heads dx");
+        b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, FT("l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gp.H1, Hv)}, "ft.l2 dx");
         b.stash_fin(actor_fins(ag, part_l, nblk));
-        actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, Tw("f_target.l1.weight") ? Tw("f_target.l1.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
+        actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, FT("l1.weight") ? FT("l1.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
     };
     actor_program(ag->actor_bwd, ag->actor_resume);
     actor_apply_program(b, ag, part_l, nblk);
@@ -703,9 +708,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
 
     // ---- deferred variants: the same critic / actor programs against a snapshot set (see rlrep_agent::dset) ----
     for (int set = 0; set < 2; ++set) {
-        const LT& f0 = ag->L.get("f_target.l1.weight");
-        const LT& fl = ag->L.get("f_target.log_std_linear.bias");
-        const Slot keep = defer_begin(b, ag, set, "f_target.", "f_target.l1.weight", ag->a.target_dev ? ag->a.target_dev + f0.off : nullptr,
+        const LT& f0 = ag->L.get(fnet + ".l1.weight");
+        const LT& fl = ag->L.get(fnet + ".log_std_linear.bias");
+        float* fbase = nft ? ag->a.param_dev : ag->a.target_dev;          // the snapshot is of whichever copy the two steps read
+        const Slot keep = defer_begin(b, ag, set, nft ? "f." : "f_target.", nft ? "f.l1.weight" : "f_target.l1.weight", fbase ? fbase + f0.off : nullptr,
                                       fl.off + fl.rows - f0.off);
         critic_program(ag->dset[set].critic_bwd, can_hoist ? 1 : 0);
         actor_program(ag->dset[set].actor_bwd, ag->dset[set].actor_resume);

@@ -190,6 +190,11 @@ struct SpederGrads {
     const float* phi; const float* mu; const float* c; const float* drhat; const float* phibar; const float* v;
     const float* theta_w; float* Gphi; float* Gmu; int B, F; float inv_batch;
 };
+// diffsrsac critic regulariser (diffsrsac_agent.py:62-75): per head x = l2(elu(l2(sin(l1 z)))) [B, H] and its Gram matrix C = x^T x [H, H]:
+//   reg = lambda * ( (sum C^2 - sum_i |x_i|^4) / ((B - 1) B)  -  2 mean_i |x_i|^2 / H  +  1 / H ),  sum C^2 = sum_ij (x_i . x_j)^2
+// every block writes its share of the sum over the four (net, head) pairs, already scaled, to partial[block]
+struct RegStats { const float* X[4]; const float* C[4]; int B, H, nbc, nbr; float lambda; float* partial; };
+
 struct DiffsrPerturb {
     const float* alphabars; const int* idx; const float* s2; int ld_s2; const float* eps;
     float* XN; float* TGT; int B, S; GroupCfg* step0; GroupCfg* step1;

@@ -267,6 +267,43 @@ __global__ __launch_bounds__(256) void copy2_kernel(const float* __restrict__ sr
 }
 
 // ------------------------------------------------------------------------------------------------
+// diffsrsac ELU-layer regulariser statistics (RegStats).  Blocks [0, 4 nbc): 1024 elements of one Gram matrix each; blocks
+// [4 nbc, 4 nbc + 4 nbr): four rows of one x each (one wave per row).  Deterministic: one partial per block, summed by the finaliser.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reg_stats_kernel(RegStats p) {
+    __shared__ float sh[4];
+    const int bid = blockIdx.x;
+    const float n = (float)p.B, d = (float)p.H;
+    const float a = 1.0f / ((n - 1.0f) * n);
+    float v = 0.f;
+    if (bid < 4 * p.nbc) {
+        const int k = bid / p.nbc, blk = bid - k * p.nbc;
+        const long long tot = (long long)p.H * p.H;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = (long long)blk * 1024 + u * 256 + threadIdx.x;
+            if (e < tot) { const float c = p.C[k][e]; v += c * c; }
+        }
+        v *= a;
+    } else {
+        const int rbid = bid - 4 * p.nbc;
+        const int k = rbid / p.nbr, blk = rbid - k * p.nbr;
+        const int row = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        float s = 0.f;
+        if (row < p.B) for (int c = lane; c < p.H; c += 64) { const float x = p.X[k][(size_t)row * p.H + c]; s += x * x; }
+        s = wave_sum(s);                                   // |x_row|^2
+        if (lane == 0 && row < p.B) v = -a * s * s - 2.0f * s / (n * d);
+        if (bid == 4 * p.nbc && threadIdx.x == 0) v += 4.0f / d;      // part3, once per (net, head)
+    }
+    const float r = block_sum_256(v, sh);
+    if (threadIdx.x == 0) p.partial[bid] = p.lambda * r;
+}
+extern "C" int rl_launch_reg_stats(const RegStats* p, hipStream_t st) {
+    hipLaunchKernelGGL(reg_stats_kernel, dim3(4 * (p->nbc + p->nbr)), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline int rows_blocks(int B) { int g = (B + 3) / 4; return g > 128 ? 128 : g; }
 
 extern "C" int rl_launch_infonce(const InfoNce* p, hipStream_t st) {

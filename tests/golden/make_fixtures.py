@@ -160,6 +160,8 @@ OPTS = {
 def named_state(agent, alg):
     out = {}
     for m in MODULES[alg]:
+        if not hasattr(agent, m):
+            continue                      # use_feature_target=False: no f_target / phi_target / frozen_phi_target attributes
         for k, v in getattr(agent, m).state_dict().items():
             out[f'{m}.{k}'] = v.detach().clone().numpy()
     out['log_alpha'] = agent.log_alpha.detach().clone().numpy()
@@ -175,6 +177,8 @@ def param_names(agent, alg):
     """id(param) -> '<module>.<name>' for every live parameter (+ log_alpha)."""
     names = {id(agent.log_alpha): 'log_alpha'}
     for m in MODULES[alg]:
+        if not hasattr(agent, m):
+            continue
         for k, p in getattr(agent, m).named_parameters():
             names[id(p)] = f'{m}.{k}'
     return names
@@ -341,6 +345,12 @@ CASES = {
     'diffsrsac_humanoid_b2048': ('diffsrsac', 376, 17, 0.4, 2048, 1, dict(hidden_dim=256, extra_feature_steps=3), False, 4096, None),
     # 25 consecutive train() calls at the headline dimensions (SURVEY.md 7.4 / 8(c)(v) free-run loss trace): metrics of every call,
     # final parameters and Adam state; per-step gradients are not stored
+    # use_feature_target=False (vlsac_agent.py:176-179,214-219; ctrlsac_agent.py:268-273,340-346; spedersac_agent.py:306-307)
+    'vlsac_tiny_noft': ('vlsac', 5, 3, 1.0, 8, 3, dict(hidden_dim=16, feature_dim=8, extra_feature_steps=3, use_feature_target=False), True, 64, 16),
+    'ctrlsac_tiny_noft': ('ctrlsac', 5, 3, 1.0, 8, 2, dict(hidden_dim=16, feature_dim=8, extra_feature_steps=3, use_feature_target=False), True, 64, None),
+    'spedersac_tiny_noft': ('spedersac', 5, 3, 1.0, 8, 2, dict(SPED, phi_hidden_dim=16, mu_hidden_dim=16, critic_and_actor_hidden_dim=16, feature_dim=8, hidden_dim=16, use_feature_target=False), True, 64, None),
+    # ELU-layer regulariser switched on (diffsrsac_agent.py:62-90,215-227): enters q_loss_reg only
+    'diffsrsac_tiny_reg': ('diffsrsac', 5, 3, 1.0, 8, 2, dict(feature_dim=8, phi_hidden_dim=16, nabla_mu_hidden_dim=16, hidden_dim=16, extra_feature_steps=3, critic_elu_layer_regularizer_lambda=0.25), True, 64, None),
     'vlsac_hc_free25': ('vlsac', 17, 6, 1.0, 256, 25, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3), False, 1024, None, False),
 }
 

@@ -275,3 +275,13 @@ def test_row_program_shadows_follow_external_parameter_writes(monkeypatch):
     oinfo = o.feature_step(gather_batch(c.replay, idx), torch.as_tensor(eps))
     for k, v in oinfo.items():
         assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (k, info[k], v)
+
+
+@pytest.mark.parametrize('name', ['vlsac_tiny_noft', 'ctrlsac_tiny_noft', 'spedersac_tiny_noft'])
+def test_default_mode_without_feature_target(name):
+    """use_feature_target=False in the default (graph, pipelined) mode: vlsac's deferred critic / actor chain then runs against a snapshot
+    of the LIVE f (vlsac_agent.py:176-179, 214-219), ctrlsac / spedersac drop the Polyak copies."""
+    c = Case(name)
+    assert c.kw.get('use_feature_target') is False
+    worst = _check_against_oracle(c, calls=4, expect_pipeline=True)
+    print(f'{name} default mode vs oracle: worst param rel-L2 {worst:.2e}')

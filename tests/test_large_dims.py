@@ -155,3 +155,10 @@ def test_vlsac_noise_critic_engines_agree(monkeypatch):
         outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})
     for k in outs[0]:
         assert rel_l2(outs[0][k], outs[1][k]) < 1e-5, k
+
+
+def test_diffsrsac_regulariser_at_config_dimensions():
+    """critic_elu_layer_regularizer_lambda != 0 (diffsrsac_agent.py:62-90, 215-227) at B = 1024, H = 256: the Gram matrices x^T x
+    [256 x 256] reduce over 1024 rows through the LDS-tiled weight-gradient engine (split-K slabs reserved whatever lambda is)."""
+    _run('diffsrsac', ('rlrep_amd.agent.diffsrsac.diffsrsac_agent', 'DIFFSRSACAgent'), 17, 6, 1024,
+         dict(hidden_dim=256, extra_feature_steps=0, critic_elu_layer_regularizer_lambda=0.5), trains=2)
