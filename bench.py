@@ -160,13 +160,24 @@ def big_gemm_roofline(agent, B, S, F, Hn, reps=20):
             'executed_bf16_tflops': round(6 * achieved, 1), 'vs_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
 
 
-def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
-    """The CPU oracle (a from-scratch port of the reference's PyTorch-CPU path, oracle/) on this box."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=9.0):
+    """The CPU oracle (a from-scratch port of the reference's PyTorch-CPU path, oracle/) on this box: an N-thread leg and a 1-thread
+    leg.  NOTE: the oracle deduplicates work the reference executes (second encoder pass, [B,B,F] broadcast, critic /
+    feature weight gradients in the actor step: 13.35 vs 10.59 GFLOP for vlsac), so the reference itself is slower than this number."""
     from oracle import make_oracle
     from oracle.agents import gather_batch
     from oracle.shapes import param_shapes
     import synth
-    torch.set_num_threads(threads)
     init = synth.init_like(param_shapes(alg, S, A, **kw))
     for k in list(init):
         for s_, d_ in (('critic', 'critic_target'), ('f', 'f_target'), ('phi', 'phi_target')):
@@ -175,38 +186,133 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=15.0):
     if alg == 'vlsac':
         init['critic_target.noise'] = init['critic.noise'].copy()
     init['log_alpha'] = np.log(np.float64(0.1))
-    o = make_oracle(alg, S, A, init, **kw)
     rs = np.random.RandomState(5)
     F = kw.get('feature_dim', 256)
     nf = kw.get('extra_feature_steps', 0) + 1 if alg != 'sac' else 0
     tens = {k: torch.from_numpy(v) for k, v in data.items()}
-    if alg == 'diffsrsac':
-        from rlrep_amd.agent.diffsrsac.diffsrsac_agent import generate_alphabars
-        o.P['noise_alphabars'] = torch.from_numpy(generate_alphabars(0.3, 0.1, 1000))
 
-    def one():
-        nb = o.n_batches()
-        idx = [rs.randint(0, REPLAY_N, size=B) for _ in range(nb)]
-        eps = []
-        if alg == 'vlsac':
-            eps = [torch.from_numpy(rs.standard_normal((B, F)).astype(np.float32)) for _ in range(nf)]
+    def leg(nthreads):
+        torch.set_num_threads(nthreads)
+        o = make_oracle(alg, S, A, init, **kw)
         if alg == 'diffsrsac':
-            for _ in range(nf):
-                eps += [torch.from_numpy(rs.randint(0, 1000, size=B)), torch.from_numpy((0.449 * rs.standard_normal((B, S))).astype(np.float32))]
-        eps += [torch.from_numpy(rs.standard_normal((B, A)).astype(np.float32)) for _ in range(2)]
-        o.train([gather_batch(tens, i) for i in idx], eps)
+            from rlrep_amd.agent.diffsrsac.diffsrsac_agent import generate_alphabars
+            o.P['noise_alphabars'] = torch.from_numpy(generate_alphabars(0.3, 0.1, 1000))
 
-    for _ in range(3):
-        one()
-    t0 = time.time()
-    n = 0
-    while n < 200 and (n < 2 or time.time() - t0 < budget_s):
-        one()
-        n += 1
-    dt = time.time() - t0
+        def one():
+            nb = o.n_batches()
+            idx = [rs.randint(0, REPLAY_N, size=B) for _ in range(nb)]
+            eps = []
+            if alg == 'vlsac':
+                eps = [torch.from_numpy(rs.standard_normal((B, F)).astype(np.float32)) for _ in range(nf)]
+            if alg == 'diffsrsac':
+                for _ in range(nf):
+                    eps += [torch.from_numpy(rs.randint(0, 1000, size=B)), torch.from_numpy((0.449 * rs.standard_normal((B, S))).astype(np.float32))]
+            eps += [torch.from_numpy(rs.standard_normal((B, A)).astype(np.float32)) for _ in range(2)]
+            o.train([gather_batch(tens, i) for i in idx], eps)
+        for _ in range(2):
+            one()
+        t0 = time.time()
+        n = 0
+        while n < 200 and (n < 2 or time.time() - t0 < budget_s):
+            one()
+            n += 1
+        return n, time.time() - t0
+
+    n, dt = leg(threads)
+    n1, dt1 = leg(1)
     return {'value': round(n / dt, 3), 'unit': 'train()/s', 'cores': threads, 'kind': 'port',
             'sample': f'{n} train() calls of the same workload on the CPU oracle (torch {torch.__version__} CPU, '
-                      f'{threads} threads of {os.cpu_count()} logical cores), {dt:.1f} s'}
+                      f'{threads} threads of {os.cpu_count()} logical cores), {dt:.1f} s',
+            'single_thread': {'value': round(n1 / dt1, 3), 'cores': 1, 'sample': f'{n1} train() calls, {dt1:.1f} s'},
+            'cpu_model': _cpu_model(),
+            'note': 'oracle = deduplicated restatement of the reference (10.59 vs 13.35 executed GFLOP per vlsac train()): the reference '
+                    'itself measured 10.3 train()/s on 8 cores of the build container (SURVEY.md section 6)'}
+
+
+# kernel families of the vlsac step programs, by stage name (include/rlrep.h rlrep_stage_name)
+def _family(name):
+    if name.startswith('noise critic'):
+        return 'noise critic (nc_*_x3 kernels, bf16x3 on the bf16 matrix pipe)'
+    if name.startswith('adam') or name.startswith('polyak'):
+        return 'optimizer (adam_kernel: Adam + Polyak + metrics + next-minibatch gather)'
+    if name.startswith('qhead') or name.startswith('vae_mid') or name.startswith('policy'):
+        return 'losses (qhead / vae_mid: elementwise + wave reductions)'
+    if name.startswith('row programs'):
+        return 'row programs (rowprog_kernel)'
+    return 'gemm16_kernel (16-row fp32-MFMA tile engine: every 256-wide layer forward / dX / dW)'
+
+
+# algorithmic flops of a gemm16 stage are not carried by its name; the family totals come from SURVEY.md Appendix F (per train())
+FAMILY_GFLOP = {'gemm16': 3.88, 'noise critic': 6.71}
+
+
+def stage_profile(agent, reps=40):
+    """Every stage of the sequential step programs timed ALONE (hipGraph of `reps` back-to-back launches, HIP events on the launch stream),
+    grouped into kernel families: launches per train(), us per train(), share, algorithmic TFLOP/s.  Standalone times are a LOWER bound of
+    what a launch costs inside the dependent chain (there its operands arrive cold from another XCD's L2: `critical_path_us`)."""
+    core = agent.core
+    nf = agent._feature_iters()
+    mult = {0: nf, 1: nf, 2: 1, 3: 1, 4: 1, 5: 1}
+    fam = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for prog in range(6):
+        for i, name in enumerate(core.stages(prog)):
+            for _ in range(3):
+                core.run_stage(prog, i)
+            torch.cuda.synchronize()
+            g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(reps):
+                    core.run_stage(prog, i)
+            g.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (3 * reps)
+            f = fam.setdefault(_family(name), {'launches_per_train': 0, 'us_per_train': 0.0})
+            f['launches_per_train'] += mult[prog]
+            f['us_per_train'] += us * mult[prog]
+    tot = sum(f['us_per_train'] for f in fam.values())
+    out = []
+    for k, f in sorted(fam.items(), key=lambda kv: -kv[1]['us_per_train']):
+        rec = {'family': k, 'launches_per_train': f['launches_per_train'], 'us_per_train': round(f['us_per_train'], 1),
+               'share_of_stage_time': round(f['us_per_train'] / tot, 3)}
+        for key, gf in FAMILY_GFLOP.items():
+            if k.startswith(key):
+                tf = gf * 1e9 / (f['us_per_train'] * 1e-6) / 1e12
+                peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if key == 'noise critic' else FP32_MFMA_PEAK_TFLOPS
+                rec.update({'algorithmic_gflop_per_train': gf, 'achieved': round(tf, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                            'frac': round(tf / peak, 4)})
+        out.append(rec)
+    return out
+
+
+def chain_times(agent, reps=60):
+    """The two launch chains of the pipelined train() replayed ALONE: the feature chain (critical path) and the critic + actor chain."""
+    P = getattr(agent, '_pipe', None)
+    if not P or 'fs' not in P:
+        return None
+    agent.flush()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {}
+    for key, graphs in (('feature_chain_us', P['fs']), ('critic_actor_chain_us', P['ca'])):
+        g = graphs[0]
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out[key] = round(e0.elapsed_time(e1) * 1e3 / reps, 1)
+    if 'launches' in P:
+        out['feature_chain_launches'], out['critic_actor_chain_launches'] = int(P['launches'][0]), int(P['launches'][1])
+    return out
 
 
 def main():
@@ -275,22 +381,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    try:
-        for _ in range(args.warmup):
-            agent.train(buf, B)
-        agent.flush()
-    except Exception as e:          # noqa: BLE001 -- insurance for the N > 1 run nobody could rehearse on a one-GPU box
-        # the same program runs on every rank, so an exception of the pipelined data-parallel form is raised on all of them: fall back
-        # to the sequential data-parallel form (graph segments between collectives on one stream) and say so in the JSON line
-        if not (getattr(agent, '_dp', False) and getattr(agent, 'use_pipeline_dp', False)):
-            raise
-        sys.stderr.write(f'[bench rank {rank}] pipelined data-parallel train() failed ({type(e).__name__}: {e}); sequential form instead\n')
-        agent.use_pipeline_dp = False
-        agent._pipe, agent._pending, agent._graph = None, False, None
-        torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            agent.train(buf, B)
-        agent.flush()
+    for _ in range(args.warmup):
+        agent.train(buf, B)
+    agent.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -314,19 +407,31 @@ def main():
     dt_sync = time.perf_counter() - t1
 
     if rank == 0:
-        value = world * args.steps / dt
+        updates = args.steps / dt                      # synchronized train() calls per second (each rank performs every one of them)
+        value = world * updates
+        mode = 'single' if world == 1 and not force_dp else ('replicas' if replicas else 'dp')
         out = {
-            'metric': 'gradient steps/sec (encoder+critic+actor) at batch=256',
+            'metric': f'gradient steps/sec (encoder+critic+actor) at batch={B}',
             'value': round(value, 2), 'unit': 'train()/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload, 'agent': alg, 'state_dim': S, 'action_dim': A, 'batch_per_gpu': B,
-                       'global_batch': B * world, 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
+                       'global_batch': B * world if mode == 'dp' else B, 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
-                       'parallelism': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)' if (world > 1 or force_dp) else 'single GPU',
+                       'parallelism': {'single': 'single GPU',
+                                       'dp': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)',
+                                       'replicas': f'{world} independent agents (own parameters and replay, no collective)'}[mode],
                        'hipgraph': (bool(agent.use_graph) if not agent._dp else ('segments between collectives' if agent.use_graph and agent.use_graph_dp else False)),
                        # critic + actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (same updates, same order)
                        'deferred_critic_actor_branch': bool(getattr(agent, '_pipe', None))},
+            # what `value` counts: with N > 1 data-parallel ranks every rank performs the same `global_updates_per_sec` train() calls, each
+            # on its own batch-B shard of a global batch N*B; value = N * global_updates_per_sec = samples_per_sec / B ("batch-B gradient
+            # steps" worth of samples).  --replicas runs N independent batch-B agents instead: value = their train() calls summed.
+            'value_definition': {'single': 'train() calls per second at batch B',
+                                 'dp': 'world_size x synchronized global updates per second (= samples_per_sec / B); one global update = batch B x world_size',
+                                 'replicas': 'sum over the independent replicas of their train() calls per second at batch B'}[mode],
+            'global_updates_per_sec': round(updates if mode != 'replicas' else value, 2),
+            'rccl_world_size': (dist.get_world_size() if dist is not None else 1),
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B, 1),
             'metrics_finite': bool(finite),
@@ -334,6 +439,13 @@ def main():
         }
         if alg == 'vlsac':
             out['roofline'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
+            if world == 1:
+                # the heaviest KERNEL is the roofline object above; the family with the largest TIME share is the tile engine, each with its own frac
+                out['chains'] = chain_times(agent)
+                out['kernel_families'] = stage_profile(agent)
+                if out['chains']:
+                    out['critical_path_us'] = out['chains']['feature_chain_us']
+                    out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)
         elif alg == 'diffsrsac':
             out['roofline'] = big_gemm_roofline(agent, B, S, 256, 512)
         # whole-train() view: algorithmic GFLOP per train() per GPU against the fp32 peak

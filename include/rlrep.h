@@ -335,6 +335,8 @@ int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t batch, int32_t feature_dim, int
 
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
+/* process-wide number of kernel launches the library has issued so far (a captured train()'s launch count = the difference around its capture) */
+int64_t rlrep_launch_counter(void);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,7 @@ def _load():
         'rlrep_nc_fwd_plan': (i32, [i32] * 4 + [P(i32)] * 3),
         'rlrep_metrics_dev': (vp, [vp]),
         'rlrep_last_launch_count': (i32, [vp]),
+        'rlrep_launch_counter': (i64, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it

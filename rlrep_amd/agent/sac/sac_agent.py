@@ -624,7 +624,9 @@ class SACAgent(object):
                 # two streams that were TIMED to be concurrent; train(t) uses snapshot set t & 1:
                 #   stream F : [feature steps(t) + snapshot(t -> set)]            after the critic/actor pair of t-2 (same set)
                 #   stream CA: [critic + actor(t) from set]                       after snapshot(t)
+                from rlrep_amd._lib import lib as _l
                 fs, ca = [], []
+                n0 = _l.rlrep_launch_counter()
                 for k in range(2):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
@@ -632,11 +634,13 @@ class SACAgent(object):
                         c.defer_snapshot(ec, ea, k)
                         c.end_train()
                     fs.append(g)
+                n1 = _l.rlrep_launch_counter()
                 for k in range(2):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
                         c.deferred_critic_actor(k)
                     ca.append(g)
+                P['launches'] = ((n1 - n0) // 2, (_l.rlrep_launch_counter() - n1) // 2)      # kernels in the feature / critic+actor graph
                 s_ca, s_f = _concurrent_stream_pair(c)
                 P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
                          ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
@@ -811,10 +815,13 @@ class SACAgent(object):
             # when the batch size changes), then capture the whole train() into one hipGraph
             self._sample_into(buffer, B, 'warm', 0, False)
             torch.cuda.synchronize()
+            from rlrep_amd._lib import lib as _l
             s = torch.cuda.Stream()
             g = torch.cuda.CUDAGraph()
+            n0 = _l.rlrep_launch_counter()
             with torch.cuda.graph(g, stream=s):
                 self._body(buffer, B, True)
             self._graph, self._graph_key = g, key
+            self._graph_launches = _l.rlrep_launch_counter() - n0
         self._graph.replay()
         return self.core.info()

@@ -125,6 +125,8 @@ struct Workspace {
 // ------------------------------------------------------------------------------------------------
 // programs
 // ------------------------------------------------------------------------------------------------
+// process-wide count of kernel launches issued by the library (rlrep_launch_counter: bench.py counts the launches a captured train() holds)
+extern long long g_rl_launches;
 struct Stage { std::function<int(hipStream_t)> run; const char* what; };
 
 struct Program {
@@ -133,6 +135,7 @@ struct Program {
         for (size_t q = first; q < stages.size(); ++q) {
             const Stage& s = stages[q];
             int rc = s.run(st);
+            ++g_rl_launches;
             if (rc != 0) { rl_set_error("stage '%s' failed: hip error %d", s.what, rc); return RLREP_ERR_HIP; }
         }
         return 0;

@@ -9,6 +9,7 @@
 #include <memory>
 
 static thread_local char g_err[512] = "";
+long long g_rl_launches = 0;
 void rl_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
@@ -858,7 +859,7 @@ static void static_state(rlrep_agent* ag) {
 static int refresh_shadows(rlrep_agent* ag, void* stream) {
     for (int g = 0; g < 4; ++g) {
         if (!ag->nsh[g]) continue;
-        const int rc = rl_launch_shadow(ag->sh_dev[g], ag->nsh[g], ag->sh_tiles[g], ag->a.param_dev, 0, (hipStream_t)stream);
+        const int rc = rl_launch_shadow(ag->sh_dev[g], ag->nsh[g], ag->sh_tiles[g], ag->a.param_dev, 0, (hipStream_t)stream); ++g_rl_launches;
         if (rc) { rl_set_error("shadow refresh: hip error %d", rc); return RLREP_ERR_HIP; }
     }
     return 0;
@@ -980,7 +981,7 @@ int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, vo
     p.B = ag->B; p.S = ag->d.state_dim; p.A = ag->d.action_dim;
     p.XE = s.XE; p.XF = s.XF; p.XF2 = s.XF2; p.XFpi = s.XFpi; p.R = s.R; p.D = s.D;
     s.filled = true;
-    rc = rl_launch_fill_slot(&p, (hipStream_t)stream);
+    rc = (++g_rl_launches, rl_launch_fill_slot(&p, (hipStream_t)stream));
     if (rc) { rl_set_error("fill_slot: hip error %d", rc); return RLREP_ERR_HIP; }
     return 0;
 }
@@ -1029,7 +1030,7 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
     slot_fill_params(ag, 0, ring_dev, nullptr, tp.fill);
     tp.counter = ag->steps; tp.ticket = ag->steps + 1;
     tp.sh = ag->sh_dev[0]; tp.nsh = ag->nsh[0]; tp.nb_tr = ag->sh_tiles[0]; tp.sh_base = ag->a.param_dev;
-    rc = rl_launch_train_prologue(&tp, (hipStream_t)stream);
+    rc = (++g_rl_launches, rl_launch_train_prologue(&tp, (hipStream_t)stream));
     if (rc) { rl_set_error("train_prologue: hip error %d", rc); return RLREP_ERR_HIP; }
     ag->slot[0].filled = true;
     ag->pf_done = true; ag->pf_ring = ring_dev; ag->pf_idx = idx_pool_dev;     // the first `batch` pool entries are in slot 0
@@ -1053,7 +1054,7 @@ int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev
     p.ring = ring_dev; p.idx = idx_dev; p.B = ag->B; p.S = ag->d.state_dim; p.A = ag->d.action_dim;
     p.XE = s.XE; p.XF = s.XF; p.XF2 = s.XF2; p.XFpi = s.XFpi; p.R = s.R; p.D = s.D;
     s.filled = true;
-    rc = rl_launch_fill_slot(&p, (hipStream_t)stream);
+    rc = (++g_rl_launches, rl_launch_fill_slot(&p, (hipStream_t)stream));
     if (rc) { rl_set_error("fill_slot: hip error %d", rc); return RLREP_ERR_HIP; }
     return 0;
 }
@@ -1064,7 +1065,7 @@ static int philox(float* df, int32_t* di, int64_t n, int kind, float std, int hi
     PhiloxFill p; memset(&p, 0, sizeof(p));
     p.dst_f = df; p.dst_i = di; p.n = n; p.kind = kind; p.std = std; p.hi = hi; p.hi_dev = hi_dev; p.seed = seed; p.offset = off;
     p.step_dev = step_dev; p.stream_id = 0;
-    int rc = rl_launch_philox(&p, (hipStream_t)stream);
+    int rc = (++g_rl_launches, rl_launch_philox(&p, (hipStream_t)stream));
     if (rc) { rl_set_error("philox: hip error %d", rc); return RLREP_ERR_HIP; }
     return 0;
 }
@@ -1201,7 +1202,7 @@ int32_t rlrep_update_target(rlrep_agent* ag, void* stream) {
 }
 int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     if (!ag) return RLREP_ERR_ARG;
-    int rc = rl_launch_counter_inc(ag->steps, (hipStream_t)stream);
+    int rc = (++g_rl_launches, rl_launch_counter_inc(ag->steps, (hipStream_t)stream));
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
     if (ag->has_shadows() && (rc = refresh_shadows(ag, stream)) != 0) return rc;
     ag->in_train = true; ag->target_done = false;
@@ -1223,7 +1224,7 @@ int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_crit
     }
     CopySegs cs = ag->dset[set].segs;
     cs.src[cs.n - 2] = eps_critic; cs.src[cs.n - 1] = eps_actor;
-    const int rc = rl_launch_copy_segs(&cs, (hipStream_t)stream);
+    const int rc = (++g_rl_launches, rl_launch_copy_segs(&cs, (hipStream_t)stream));
     if (rc) { rl_set_error("defer_snapshot: hip error %d", rc); return RLREP_ERR_HIP; }
     ag->dset[set].valid = true;
     return 0;
@@ -1271,7 +1272,7 @@ int32_t rlrep_feature_backward_part(rlrep_agent* ag, int32_t part, const float* 
     const int hi = part == ncut ? (int)ag->feat_bwd.stages.size() : ag->feat_cuts[part].after_stage + 1;
     if (part == 0) ag->last_launches = 0;
     for (int i = lo; i < hi; ++i) {
-        int rc = ag->feat_bwd.stages[i].run((hipStream_t)stream);
+        int rc = ag->feat_bwd.stages[i].run((hipStream_t)stream); ++g_rl_launches;
         if (rc) { rl_set_error("stage '%s' failed: hip error %d", ag->feat_bwd.stages[i].what, rc); return RLREP_ERR_HIP; }
     }
     ag->last_launches += hi - lo;
@@ -1336,7 +1337,7 @@ int32_t rlrep_run_stage(rlrep_agent* ag, int32_t program, int32_t stage, void* s
     Program* p = ag ? prog_of(ag, program) : nullptr;
     if (!p || stage < 0 || stage >= (int)p->stages.size()) { rl_set_error("run_stage: bad program/stage"); return RLREP_ERR_ARG; }
     if (!ag->slot[0].filled) { rl_set_error("run_stage before a full step"); return RLREP_ERR_STATE; }
-    int rc = p->stages[stage].run((hipStream_t)stream);
+    int rc = p->stages[stage].run((hipStream_t)stream); ++g_rl_launches;
     if (rc) { rl_set_error("stage '%s' failed: hip error %d", p->stages[stage].what, rc); return RLREP_ERR_HIP; }
     return 0;
 }
@@ -1410,6 +1411,7 @@ int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t B, int32_t F, int32_t H, int32_
 }
 
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
+int64_t rlrep_launch_counter(void) { return g_rl_launches; }
 int32_t rlrep_last_launch_count(rlrep_agent* ag) { return ag ? ag->last_launches : 0; }
 
 }  // extern "C"

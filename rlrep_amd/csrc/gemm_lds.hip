@@ -21,6 +21,7 @@
 // of ctrlsac) are split along K over `splits` workgroups per tile; partial tiles go to a slab and a finishing launch
 // adds them in split order (deterministic) and applies the epilogue.  No float atomics anywhere.
 #include "common.h"
+extern long long g_rl_launches;
 #include "kparams.h"
 
 #define GL_BK 32
@@ -566,6 +567,7 @@ extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, i
     if (rc != 0) return rc;
     if (fin_blocks > 0) {
         hipLaunchKernelGGL(gemm_lds_fin_kernel, dim3(fin_blocks), dim3(256), 0, st, *gb);
+        ++g_rl_launches;              // split-K: the stage is two kernels
         rc = (int)hipGetLastError();
     }
     return rc;

@@ -21,6 +21,7 @@
 // next step's operands into registers before issuing the current step's MFMAs.
 #include <type_traits>
 #include "common.h"
+extern long long g_rl_launches;
 #include "kparams.h"
 #include "x3.h"
 
@@ -1735,6 +1736,7 @@ extern "C" int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t
         hipLaunchKernelGGL(nc_dw_x3_kernel, dim3(total_tiles), dim3(512), 0, st, *nb);
         const size_t HF = (size_t)t0.H * t0.F;
         hipLaunchKernelGGL(nc_dw_fin_kernel, dim3((unsigned)((HF + 255) / 256), nb->ntasks), dim3(256), 0, st, *nb);
+        ++g_rl_launches;              // this stage is two kernels
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);          // 96 KB of staged per-batch-row tables
