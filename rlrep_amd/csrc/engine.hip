@@ -188,7 +188,8 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
     const int S = ag->d.state_dim, A = ag->d.action_dim, H = ag->d.hidden_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
     const int SA = S + A;
     Slot& s0 = ag->slot[0];
-    ActorBufs ab = alloc_actor(b, B, A, Ha);
+    ActorBufs ab = alloc_actor(b, B, A, Ha);               // policy on s' (critic step)
+    ActorBufs ab_pi = alloc_actor(b, B, A, Ha);            // policy on s  (actor step)
     float* E1t = b.ws.f((size_t)B * 2 * H);       // target first-layer activations [B, 2H] (Q1|Q2)
     float* E1c = b.ws.f((size_t)B * 2 * H);
     float* Et = b.ws.f((size_t)2 * B * H);        // second-layer activations, heads stacked [2][B,H]
@@ -203,11 +204,20 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
     auto Tw = [&](const char* n) { return ag->T(n); };
 
     // ---- critic step ----
-    {
-        Program& p = ag->critic_bwd;
-        b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab)}, "actor.l1(s')");
-        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {}, "actor.head + policy");
+    // hoist: the variant that also carries the forward half of the FOLLOWING actor step (policy on s): its three layers read nothing the
+    // critic update writes, and as extra tasks of launches that exist anyway they take three launches off train() (rlrep_prefetch_policy)
+    const bool can_hoist = policy_fusable(ag) && !getenv("RLREP_NO_HOIST");
+    auto critic_program = [&](Program& p, bool hoist, bool emit_apply) {
+        if (hoist) {
+            b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "actor.l1(s') actor.l1(s)");
+            b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi)}, "actor.l2 x2");
+            b.fwd_stage(p, {policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
+                        "actor.head x2 + policy");
+        } else {
+            b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab)}, "actor.l1(s')");
+            b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
+            actor_head_stage(b, p, ag, ab, s0.XF2 + S, SA, {}, "actor.head + policy");
+        }
         b.fwd_stage(p, {Builder::fwd(s0.XF2, SA, B, SA, Tw("critic_target.Q1.0.weight"), SA, Tw("critic_target.Q1.0.bias"), 2 * H, E1t, 2 * H, ACT_ELU),
                         Builder::fwd(s0.XF, SA, B, SA, Pw("critic.Q1.0.weight"), SA, Pw("critic.Q1.0.bias"), 2 * H, E1c, 2 * H, ACT_ELU)}, "Q l1");
         b.fwd_stage(p, {Builder::fwd(E1t, 2 * H, B, H, Tw("critic_target.Q1.2.weight"), H, Tw("critic_target.Q1.2.bias"), H, Et, H, ACT_ELU),
@@ -238,15 +248,20 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
                 Builder::fin_combine(ag->metrics + M_TMP0, 1.f, ag->metrics + M_TMP1, 1.f, ag->metrics + M_Q1_LOSS),
                 Builder::fin_sum(part_q + 2, nblk, 4, ib, ag->metrics + M_Q1),
                 Builder::fin_copy(ag->metrics + M_Q1, ag->metrics + M_Q2)};
-        b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, cfins, "adam critic");
-        critic_apply_folded(b, ag, "critic_target.Q1.0.weight", cfins);
-    }
+        if (emit_apply) {
+            b.adam(ag->critic_apply, 1, ag->h.lr_critic, nullptr, 0, 0, 0.f, cfins, "adam critic");
+            critic_apply_folded(b, ag, "critic_target.Q1.0.weight", cfins);
+        }
+    };
+    critic_program(ag->critic_bwd, false, true);
+    if (can_hoist) critic_program(ag->critic_bwd_h, true, false);
     // ---- actor step ----
     {
         Program& p = ag->actor_bwd;
-        b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab)}, "actor.l1(s)");
-        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab)}, "actor.l2");
-        actor_head_stage(b, p, ag, ab, s0.XFpi + S, SA, {}, "actor.head + policy");
+        b.fwd_stage(p, {actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "actor.l1(s)");
+        b.fwd_stage(p, {actor_l(ag, 1, nullptr, 0, ab_pi)}, "actor.l2");
+        actor_head_stage(b, p, ag, ab_pi, s0.XFpi + S, SA, {}, "actor.head + policy");
+        ag->actor_resume = (int)p.stages.size();              // everything above is what critic_bwd_h already did
         b.fwd_stage(p, {Builder::fwd(s0.XFpi, SA, B, SA, Pw("critic.Q1.0.weight"), SA, Pw("critic.Q1.0.bias"), 2 * H, E1c, 2 * H, ACT_ELU)}, "Q l1");
         b.fwd_stage(p, {Builder::fwd(E1c, 2 * H, B, H, Pw("critic.Q1.2.weight"), H, Pw("critic.Q1.2.bias"), H, Ec, H, ACT_ELU),
                         Builder::fwd(E1c + H, 2 * H, B, H, Pw("critic.Q2.2.weight"), H, Pw("critic.Q2.2.bias"), H, Ec + (size_t)B * H, H, ACT_ELU)}, "Q l2");
@@ -254,14 +269,14 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
         q.Ec[0] = Ec; q.Ec[1] = Ec + (size_t)B * H;
         q.wc[0] = Pw("critic.Q1.4.weight"); q.wc[1] = Pw("critic.Q2.4.weight");
         q.bc[0] = Pw("critic.Q1.4.bias"); q.bc[1] = Pw("critic.Q2.4.bias");
-        q.logp = ab.logp; q.alpha_state = ag->a.alpha_state_dev; q.inv_batch = ag->inv_batch(); q.target_entropy = ag->h.target_entropy;
+        q.logp = ab_pi.logp; q.alpha_state = ag->a.alpha_state_dev; q.inv_batch = ag->inv_batch(); q.target_entropy = ag->h.target_entropy;
         q.GE[0] = GE; q.GE[1] = GE + (size_t)B * H; q.partial_loss = part_l; q.partial_c = ag->Gtail();
         q.B = B; q.H = H; q.nblk = nblk; q.step = ag->adam_step + 2;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_actor(&q, st); }, "qhead actor"});
         b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.Q1.2.weight"), H, G1, 2 * H, H, ACT_ELU, E1c, 2 * H),
                        Builder::dx(GE + (size_t)B * H, H, B, H, Pw("critic.Q2.2.weight"), H, G1 + H, 2 * H, H, ACT_ELU, E1c + H, 2 * H)}, "Q l2 dx");
         // both heads at once: [G1_1 | G1_2] [B,2H] x [W_Q1.0 ; W_Q2.0][:, S:S+A]
-        actor_backward(b, p, ag, ab, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(G1, 2 * H, B, 2 * H, Pw("critic.Q1.0.weight") ? Pw("critic.Q1.0.weight") + S : nullptr, SA, ab.dA, A, A, ACT_NONE, nullptr, 0));
+        actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(G1, 2 * H, B, 2 * H, Pw("critic.Q1.0.weight") ? Pw("critic.Q1.0.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
         actor_apply_program(b, ag, part_l, nblk);
     }
     update_target_program(ag, "critic.Q1.0.weight", "critic_target.Q1.0.weight");
