@@ -324,6 +324,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=int(os.environ.get('RLREP_CPU_THREADS', 16)))
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the per-stage / per-chain timing loops (rocprofv3 and PMC runs)')
     ap.add_argument('--replicas', action='store_true',
                     help='N > 1: N independent agents (own parameters, own replay, NO gradient all-reduce) instead of data-parallel training')
     args = ap.parse_args()
@@ -439,7 +440,7 @@ def main():
         }
         if alg == 'vlsac':
             out['roofline'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
-            if world == 1:
+            if world == 1 and not args.no_profile:
                 # the heaviest KERNEL is the roofline object above; the family with the largest TIME share is the tile engine, each with its own frac
                 out['chains'] = chain_times(agent)
                 out['kernel_families'] = stage_profile(agent)
