@@ -45,6 +45,11 @@ enum Epi : int {
 // tile 0 stores A for the weight-gradient pass, ldout2 its row stride).  vlsac: dL/d(dec.l1 output) = (dL/d[s_hat|r_hat] [B,18]) W_heads
 // rides in the dec.l1 dX launch instead of being a launch of its own.
 #define FLAG_PRE 256
+// ... or, FORWARD form (FLAG_PRE | FLAG_PRE_FWD): the A operand is the previous layer's activation itself,
+//   A[i][k] = relu( sum_{j < K1} X[i][j] * Wt[j][k] + b1[k] ),   K1 <= 48,  Wt = the TRANSPOSED first-layer weight [K1][K] (a shadow kept by the
+// optimizer launch: rows of W1 itself would be 92-/160-byte-strided 4-byte reads), x2 = b1 (ldaux2 = 0).  vlsac: encoder.l1 / f.l1 ride in
+// the encoder.l2 / f.l2 launch.
+#define FLAG_PRE_FWD 512
 
 struct GroupCfg;
 struct GemmTask {

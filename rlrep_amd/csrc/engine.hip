@@ -469,8 +469,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             b.fwd_stage(p, {te[2], tf[2], policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
                         "enc.heads f.heads actor.head x2 + policy");
         } else {
-            b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
-            b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
+            // the first layers ride in the second layers' launch when their transposed shadows exist (one launch less per feature step)
+            const bool have_t = ag->shadow_of.count("encoder.l1.weight") && ag->shadow_of.count("f.l1.weight");
+            if (!have_t || !b.fwd_stage12(p, {{te[0], te[1], ag->PT("encoder.l1.weight")}, {tf[0], tf[1], ag->PT("f.l1.weight")}}, "enc.l1+l2 f.l1+l2")) {
+                b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
+                b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
+            }
             b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
         }
         if (!use_rp) {
@@ -841,12 +845,19 @@ static void static_state(rlrep_agent* ag) {
     // transposed weight shadows (see rlrep_agent::sh_dev): vlsac's feature group, read by the feature step's row programs
     ag->shadow_of.clear();
     for (int g = 0; g < 4; ++g) { ag->sh_dev[g] = nullptr; ag->nsh[g] = ag->sh_tiles[g] = 0; }
-    if (ag->d.alg == RLREP_ALG_VLSAC && rl_rowprog_enabled() && !getenv("RLREP_NO_SHADOWS")) {
+    // ... and, with RLREP_FUSE_L1=1, the two FIRST layers of its feature nets (K = 2S+A / S+A) for the variant in which they ride in the
+    // second layers' launch (Builder::fwd_stage12 reads W1 transposed).  OPT-IN: measured 11.2 us for the fused launch against 3.7 + 4.9 us
+    // for the pair (every one of the 512 tiles re-reads W1^T and X: twice the L2 traffic, three times the load instructions): 2 763 vs
+    // 2 865 train()/s.
+    const char* fl1 = getenv("RLREP_FUSE_L1");
+    const bool sh_all = rl_rowprog_enabled(), sh_l1 = fl1 && fl1[0] == '1';
+    if (ag->d.alg == RLREP_ALG_VLSAC && (sh_all || sh_l1) && !getenv("RLREP_NO_SHADOWS")) {
         std::vector<ShadowEnt> tab; std::vector<std::string> first;
         const auto& T = ag->L.t;
         for (size_t q = 0; q < T.size(); ++q) {
             const LT& e = T[q];
             if (e.arena != RLREP_ARENA_PARAM || e.group != 0 || e.cols <= 1 || e.name.find(".weight") == std::string::npos) continue;
+            if (!sh_all && e.name != "encoder.l1.weight" && e.name != "f.l1.weight") continue;
             // a glued pair (mean | log_std heads, state | reward heads: Layout::lin_pair) is two consecutive blocks [o1, in], [o2, in] = ONE
             // [o1 + o2, in] matrix for the kernels: one shadow, reachable under the first tensor's name
             if (!tab.empty() && q > 0 && T[q - 1].name.find(".weight") != std::string::npos && tab.back().off + tab.back().n == e.off && tab.back().cols == e.cols) {

@@ -261,6 +261,27 @@ struct Builder {
         t.x0 = d1.A; t.ldx0 = d1.lda; t.x1 = d1.B; t.ldx1 = d1.ldb; t.n0 = d1.K; t.x2 = d1.aux; t.ldaux2 = d1.ldaux; t.y0 = d1.C; t.ldout2 = d1.ldc;
         gemm_small(p, LD_ROW, LD_COL, {t}, w2);
     }
+    // Forward twin: layer pairs (first, second) where the FIRST has a short inner length (<= 48), ReLU and a transposed weight shadow `wt`
+    // ([K1][N1], kept by the optimizer launch): one launch in which every tile of the second layer recomputes its 16 rows of the first
+    // (gemm16.hip, FLAG_PRE | FLAG_PRE_FWD) and column tile 0 stores them for the backward pass.  False (nothing emitted) if a pair does not fit.
+    struct FwdPair { GemmTask first, second; const float* wt; };
+    bool fwd_stage12(Program& p, const std::vector<FwdPair>& pairs, const char* what) {
+        if (pairs.empty()) return false;
+        std::vector<GemmTask> tasks;
+        for (const FwdPair& fp : pairs) {
+            const GemmTask& d1 = fp.first; const GemmTask& d2 = fp.second;
+            const bool ok = (dry || fp.wt) && d1.epi == EPI_FWD && d1.act == ACT_RELU && d1.K <= 48 && d1.scale == 1.f && d2.epi == EPI_FWD &&
+                            d2.A == d1.C && d2.lda == d1.ldc && d2.K == d1.Cn && d2.R == d1.R && !d1.out2 &&
+                            ((d2.R + 15) / 16) * ((d2.Cn + 15) / 16) < 384 * 2;
+            if (!ok) return false;
+            GemmTask t = d2;
+            t.flags |= FLAG_PRE | FLAG_PRE_FWD;
+            t.x0 = d1.A; t.ldx0 = d1.lda; t.x1 = fp.wt; t.ldx1 = d1.Cn; t.n0 = d1.K; t.x2 = d1.bias; t.ldaux2 = 0; t.y0 = d1.C; t.ldout2 = d1.ldc;
+            tasks.push_back(t);
+        }
+        gemm_small(p, LD_ROW, LD_ROW, tasks, what);
+        return true;
+    }
     // weight-gradient stage; carries the fused optimizer (and the Polyak spec set by set_polyak) when fused()
     float* pol_target = nullptr; int64_t pol_off = 0, pol_n = 0; float pol_tau = 0.f;
     void set_polyak(float* target, int64_t off, int64_t n, float tau) { pol_target = target; pol_off = off; pol_n = n; pol_tau = tau; }

@@ -119,22 +119,22 @@ __device__ __forceinline__ void mac_group(const float* __restrict__ A, int lda, 
 // MLPs, whose weights are stored [k][j] with 92-byte rows, made every fragment load touch 16-23 cache lines and lost: DESIGN.md 5.0.)
 struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const float* M; int ldm; float* out; int ldo; };
 
-template <int LB, int NF, bool VB, int NU>
+template <int LB, int NF, bool VB, int NU, int NJ, bool FWD>
 __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
                                               int i, int kq, int kb, int K, bool store, f32x4 (&acc)[NF]) {
-    float xf[2][4], wf[NU][2][4], mk[NU][4], b[NU][NF][4];
+    float xf[NJ][4], wf[NU][NJ][4], mk[NU][4], b[NU][NF][4];
     const int K1 = ps.K1;
     const float* xrow = ps.X + (size_t)min(r0 + i, R - 1) * ps.ldx;
     const float* mrow = ps.M + (size_t)min(r0 + i, R - 1) * ps.ldm;
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc)
+    for (int jc = 0; jc < NJ; ++jc)
 #pragma unroll
         for (int m = 0; m < 4; ++m) xf[jc][m] = xrow[min(16 * jc + 4 * kq + m, K1 - 1)];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int kcol = min(kb + 64 * u + i, K - 1);
 #pragma unroll
-        for (int jc = 0; jc < 2; ++jc)
+        for (int jc = 0; jc < NJ; ++jc)
 #pragma unroll
             for (int m = 0; m < 4; ++m) wf[u][jc][m] = ps.Wt[(size_t)min(16 * jc + 4 * kq + m, K1 - 1) * ps.ldw + kcol];
 #pragma unroll
@@ -145,14 +145,14 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
     __builtin_amdgcn_sched_barrier(0);
     // zero what the clamped loads fetched beyond K1 (inner index); rows beyond R / k beyond K are masked when A is formed
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc)
+    for (int jc = 0; jc < NJ; ++jc)
 #pragma unroll
         for (int m = 0; m < 4; ++m) xf[jc][m] = (16 * jc + 4 * kq + m) < K1 ? xf[jc][m] : 0.f;
     f32x4 D[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) D[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jc = 0; jc < 2; ++jc) {
+    for (int jc = 0; jc < NJ; ++jc) {
         if (16 * jc >= K1) break;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -165,7 +165,8 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
         float a[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const float g = mk[u][m] > 0.f ? D[u][m] : 0.f;
+            // dX form: mk = saved ReLU output (mask); forward form: mk = the layer's bias
+            const float g = FWD ? fmaxf(D[u][m] + mk[u][m], 0.f) : (mk[u][m] > 0.f ? D[u][m] : 0.f);
             a[m] = (rok && (kb + 64 * u + 4 * kq + m) < K) ? g : 0.f;
         }
         if (store && rok) {
@@ -310,12 +311,15 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     if constexpr (PRE) {
         PreSrc ps; ps.X = t.x0; ps.ldx = t.ldx0; ps.Wt = t.x1; ps.ldw = t.ldx1; ps.K1 = n0; ps.M = t.x2; ps.ldm = t.ldaux2; ps.out = t.y0; ps.ldo = t.ldout2;
         const bool store = (tc == 0) && ps.out;
+        // forward form (LB = LD_ROW): K1 <= 48, bias + ReLU; dX form (LB = LD_COL): K1 <= 32, ReLU mask
+        constexpr int NJ = (LB == LD_ROW) ? 3 : 2;
+        constexpr bool FW = (LB == LD_ROW);
         for (int kb = w * 16; kb < K; kb += 256) {
             const int nu = (K - kb + 63) >> 6;
-            if (nu >= 4) mac_group_pre<LB, NF, VB, 4>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
-            else if (nu == 1) mac_group_pre<LB, NF, VB, 1>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
-            else if (nu == 2) mac_group_pre<LB, NF, VB, 2>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
-            else mac_group_pre<LB, NF, VB, 3>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            else mac_group_pre<LB, NF, VB, 3, NJ, FW>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
         }
     } else
     for (int kb = w * 16; kb < K; kb += 256) {
@@ -509,10 +513,21 @@ static bool all_vec(const GemmBatch& gb, bool opB) {
 extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
-    if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch (dX form): every task carries FLAG_PRE
-        for (int q = 0; q < gb->ntasks; ++q) if (!(gb->t[q].flags & FLAG_PRE)) return -3;
-        if (la != LD_ROW || lb != LD_COL || nf != 1) return -3;
-        hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+    if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch: every task carries FLAG_PRE (and agrees on the form)
+        const int fw = gb->t[0].flags & FLAG_PRE_FWD;
+        for (int q = 0; q < gb->ntasks; ++q) {
+            if (!(gb->t[q].flags & FLAG_PRE) || (gb->t[q].flags & FLAG_PRE_FWD) != fw) return -3;
+            if (gb->t[q].n0 > (fw ? 48 : 32)) return -3;
+        }
+        if (la != LD_ROW || nf != 1) return -3;
+        if (fw) {
+            if (lb != LD_ROW) return -3;
+            if (all_vec(*gb, true)) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, true, true>), g, dim3(256), 0, st, *gb);
+            else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+        } else {
+            if (lb != LD_COL) return -3;
+            hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+        }
         return (int)hipGetLastError();
     }
     if (la == LD_ROW && lb == LD_ROW) {

@@ -285,3 +285,15 @@ def test_default_mode_without_feature_target(name):
     assert c.kw.get('use_feature_target') is False
     worst = _check_against_oracle(c, calls=4, expect_pipeline=True)
     print(f'{name} default mode vs oracle: worst param rel-L2 {worst:.2e}')
+
+
+def test_fused_first_layers_match_oracle(monkeypatch):
+    """RLREP_FUSE_L1=1 (opt-in, measured slower): encoder.l1 / f.l1 recomputed inside the encoder.l2 / f.l2 launch from transposed weight
+    shadows (gemm16.hip FLAG_PRE_FWD); K1 = 13 and 8 at the tiny dimensions, 40 and 23 at the headline ones."""
+    monkeypatch.setenv('RLREP_FUSE_L1', '1')
+    for name in ('vlsac_tiny', 'vlsac_hc'):
+        c = Case(name)
+        agent = _default_agent(c)
+        assert any('enc.l1+l2' in n for n in agent.core.stages(0)), agent.core.stages(0)
+        del agent
+        _check_against_oracle(c, calls=3, expect_pipeline=True)
