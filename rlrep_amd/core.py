@@ -37,13 +37,18 @@ class LazyInfo(dict):
             if n:
                 dict.__setitem__(self, n, None)
 
+    # quirk Q14: the reference returns these two as 0-dim TENSORS (sac_agent.py:163-166: `alpha_loss` fp32, `alpha` = log_alpha.exp() fp64),
+    # everything else as Python floats
+    TENSOR_KEYS = {'alpha_loss': torch.float32, 'alpha': torch.float64}
+
     def _fetch(self):
         if not self._done:
             snap = self._snap() if callable(self._snap) else self._snap     # callable: fetched (and flushed) on first read
             vals = snap.cpu().numpy()
             for i, n in enumerate(self._names):
                 if n:
-                    dict.__setitem__(self, n, float(vals[i]))
+                    v = float(vals[i])
+                    dict.__setitem__(self, n, torch.tensor(v, dtype=self.TENSOR_KEYS[n]) if n in self.TENSOR_KEYS else v)
             self._done = True
 
     def _fetch_early(self):

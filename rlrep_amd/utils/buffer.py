@@ -15,8 +15,13 @@ Batch = collections.namedtuple('Batch', ['state', 'action', 'reward', 'next_stat
 
 
 class ReplayBuffer(object):
-    def __init__(self, state_dim, action_dim, max_size=int(1e6), device=None, stage_rows=4096):
+    def __init__(self, state_dim, action_dim, max_size=int(1e6), device=None, stage_rows=4096, shard=None):
+        """shard=(rank, world): this ring is one shard of a replay partitioned by transition index: every rank is
+        offered the same stream of transitions and keeps transition i iff i % world == rank, at slot i // world of its own ring (the
+        default, shard=None, keeps everything: each data-parallel rank then owns the transitions of its own environment)."""
         self.max_size = int(max_size)
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        self._offered = 0
         self.ptr = 0
         self.size = 0
         self.state_dim, self.action_dim = int(state_dim), int(action_dim)
@@ -39,6 +44,11 @@ class ReplayBuffer(object):
 
     # ---- reference API ------------------------------------------------------------------------
     def add(self, state, action, next_state, reward, done):
+        if self.shard is not None:
+            i = self._offered
+            self._offered += 1
+            if i % self.shard[1] != self.shard[0]:
+                return
         if self._staged == self._stage.shape[0]:
             self.flush()
         if self._copy_done is not None:

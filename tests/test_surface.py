@@ -182,3 +182,33 @@ def test_replay_ring_wraps_like_the_reference():
         b = rb.sample(4)
         assert tuple(b._fields) == ('state', 'action', 'reward', 'next_state', 'done')
         assert b.state.shape == (4, 2) and b.reward.shape == (4, 1) and b.state.dtype == torch.float32
+
+
+def test_replay_ring_round_robin_sharding():
+    """the replay partitioned by transition index -- W shards offered the same stream hold, together, exactly the single
+    ring's content (transition i at slot i // W of shard i % W), also across the wrap-around."""
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    W, cap, n = 3, 4, 17                      # 17 transitions into 3 shards of 4 slots (global capacity 12): the oldest 5 are overwritten
+    shards = [ReplayBuffer(2, 1, max_size=cap, device='cpu', shard=(r, W)) for r in range(W)]
+    for i in range(n):
+        for s in shards:
+            s.add(np.full(2, i, np.float32), np.full(1, i, np.float32), np.full(2, -i, np.float32), float(i), 0.0)
+    kept = set()
+    for r, s in enumerate(shards):
+        assert s.size == cap
+        vals = s.state[:, 0].astype(int).tolist()
+        for slot, v in enumerate(vals):
+            assert v % W == r and (v // W) % cap == slot, (r, slot, v)
+        kept.update(vals)
+    assert kept == set(range(n - W * cap, n))
+
+
+def test_info_dict_value_types_match_the_reference():
+    """sac_agent.py:154-166 (quirk Q14): `alpha_loss` and `alpha` are 0-dim tensors (fp32 / fp64), every other metric a Python float."""
+    from rlrep_amd.core import LazyInfo
+    names = ['q_loss', 'alpha_loss', 'alpha', '']
+    info = LazyInfo(names, torch.tensor([1.5, 0.25, 0.1, 9.0]))
+    assert isinstance(info['q_loss'], float)
+    assert torch.is_tensor(info['alpha_loss']) and info['alpha_loss'].dtype == torch.float32 and info['alpha_loss'].ndim == 0
+    assert torch.is_tensor(info['alpha']) and info['alpha'].dtype == torch.float64
+    assert abs(float(info['alpha']) - 0.1) < 1e-7 and set(info.keys()) == {'q_loss', 'alpha_loss', 'alpha'}
