@@ -53,7 +53,7 @@ ALG_GFLOP = {'vlsac_halfcheetah_f256_b256': 10.59, 'sac_halfcheetah_b256': 0.582
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md); the bf16x3 tile executes 6 bf16 MFMA flops per algorithmic fp32 flop
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
-# HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r01_pmc_summary.json (nc_fwd_x3q_kernel:
+# HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r02_pmc_summary.json (same in r01; nc_fwd_x3q_kernel:
 # FETCH_SIZE 3279.0 KB raw, x2 for 16-byte reads on gfx950, + WRITE_SIZE 11520.0 KB): 18.5 MB against 11.0 MB algorithmic (10.5 MB of
 # ELU outputs written + tables and weights read once; every XCD's L2 fetches its own copy of the 1 MB of weights)
 NC_FWD_TRAFFIC_BYTES = int((2 * 3279.0 + 11520.0) * 1024)
@@ -116,7 +116,7 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     kname = ('nc_fwd_x3q_kernel' if quad else 'nc_fwd_x3w_kernel<8>' if wide else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
     out = {'bound': 'mfma', 'kernel': kname + (' (critic step, 4 heads, bf16x3)' if x3 else ' (critic step, 4 heads)'),
            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-           # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_summary.json
+           # HBM-side bytes per launch from the PMC passes committed in profiles/r02_pmc_summary.json
            # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)
            'traffic': NC_FWD_TRAFFIC_BYTES, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
     if x3:
