@@ -331,7 +331,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     // decoder passes.  `early`: two more programs run both policy forwards (what the first three launches of feat_bwd_h carry).
     const int nrb = (B + RP_ROWS - 1) / RP_ROWS;
     const int nblk_rp = nrb;
-    float* part_kl_rp = ws.f(nblk_rp); float* part_mse_rp = ws.f((size_t)2 * nblk_rp);
+    float* part_kl_rp = ws.f((size_t)nblk_rp * 8); float* part_mse_rp = ws.f((size_t)2 * nblk_rp);       // (KL: one partial per workgroup, up to 8 members per row block)
     int* rp_flags = (int*)ws.alloc(sizeof(int) * 2 * nrb);
     if (!b.dry && rp_flags && b.ws.ok()) (void)hipMemset(rp_flags, 0, sizeof(int) * 2 * nrb);
     auto rp_feature = [&](RpAsm& A_, bool early) {
@@ -440,9 +440,104 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     // alone) / ~57 us (in the dependent chain) for the nine launches it replaces -- one CU per 16-row block ingests every weight matrix
     // (256 KB per 256 x 256 layer at ~50-65 GB/s per CU) and runs fp32 MFMA at 41-53 cycles per instruction: 5-6 us per layer and row
     // block, i.e. a dependent launch.  DESIGN.md section 5.2 has the per-op timeline.
+
+    // ---- cluster form (RLREP_ROWPROG=2): C workgroups per row block and chain, member m owns a column slice of every layer and the
+    // members complete each other's vectors through tagged 8-byte granules in global memory (RP_XCHG; tools/exp/cluster_hop.hip: 1.9-2.4 us
+    // per hop with 256 workgroups exchanging at once).  Masks come from the activations in global memory (each member wrote its own slice).
+    int CS = 0;                                   // cluster size: 0 = not applicable
+    for (int c : {8, 4, 2}) if (!CS && Hv % c == 0 && F % c == 0 && (long long)nrb * c * 2 <= 256 && 16 * (2 * F / c) <= RP_XSLOT && 16 * (Hv / c) <= RP_XSLOT) CS = c;
+    unsigned long long* xbuf = (unsigned long long*)ws.alloc(rl_rowprog_cluster() && CS ? (size_t)nrb * 2 * RP_MAX_HOPS * CS * RP_XSLOT * 8 : 8);
+    auto rp_feature_cluster = [&](RpAsm& A_) {
+        const int wh = Hv / CS, wf = F / CS;
+        auto Wp = [&](const std::string& n) { return ag->P(n); };
+        auto last = [&]() -> RpOp& { return A_.ops.back(); };
+        // forward slice of layer `name` (N_total outputs; this member: columns col_base + m*ws .. + ws) from the transposed shadow
+        auto fwdS = [&](const RpBuf& x, int K, const std::string& name, const std::string& bias_name, int Ntot, int col_base, int wsl, int act,
+                        const RpBuf& dfull, float* gout, int ldg) {
+            RpBuf d = dfull; d.off += col_base; d.w = wsl;
+            const float* WT = ag->PT(name + ".weight");
+            const float* bias = Wp(bias_name + ".bias");
+            A_.fwdT(x, K, WT ? WT + col_base : nullptr, bias ? bias + col_base : nullptr, wsl, act, &d, gout ? gout + col_base : nullptr, ldg);
+            RpOp& o = last(); o.ldw = Ntot; o.wpad = wsl; o.m_w = wsl; o.m_b = wsl; o.m_dst = wsl; o.m_g = wsl;
+        };
+        // dX slice: columns m*ws .. of (G W) masked by the activation in global memory
+        auto dxS = [&](const RpBuf& g, int K, const float* W, int ldw, int wsl, int act, const float* mask_g, int ldmask, const RpBuf* dfull, bool slice_dst,
+                       float* gout, int ldg) {
+            RpBuf d; if (dfull) { d = *dfull; d.w = wsl; }
+            A_.dx(g, K, W, ldw, wsl, act, nullptr, mask_g, ldmask, dfull ? &d : nullptr, gout, ldg);
+            RpOp& o = last(); o.wpad = wsl; o.m_w = wsl; o.m_g = wsl; o.m_gaux = wsl; o.m_dst = slice_dst ? 0 : wsl;
+        };
+        // ---------------- program E ----------------
+        A_.begin();
+        {
+            RpBuf bx = A_.buf(std::max(KE, S + 1)), bA = A_.buf(2 * F > Hv ? 2 * F : Hv), bB = A_.buf(2 * F > Hv ? 2 * F : Hv), bC = A_.buf(std::max(F, Hv));
+            RpBuf ezs = A_.buf(wf), dzs = A_.buf(wf);
+            A_.load(s0.XE, KE, KE, bx);
+            fwdS(bx, KE, "encoder.l1", "encoder.l1", Hv, 0, wh, ACT_RELU, bA, ge.H1, Hv);
+            A_.xop(RP_XCHG, bA, 0, wh, 1, 0);
+            fwdS(bA, Hv, "encoder.l2", "encoder.l2", Hv, 0, wh, ACT_RELU, bB, ge.H2, Hv);
+            A_.xop(RP_XCHG, bB, 1, wh, 1, 0);
+            fwdS(bB, Hv, "encoder.mean_linear", "encoder.mean_linear", 2 * F, 0, wf, ACT_NONE, bA, ge.HH, 2 * F);
+            fwdS(bB, Hv, "encoder.mean_linear", "encoder.mean_linear", 2 * F, F, wf, ACT_NONE, bA, ge.HH, 2 * F);
+            A_.xop(RP_GATHER, bB, 2, wf, 2, F, 2);                      // my slice of the f heads, from member m of the F cluster (its hop 2)
+            {
+                RpOp o = RpAsm::blank(RP_VAE_MID);
+                o.src = bA.off; o.lds = bA.ld; o.src2 = bB.off; o.lds2 = bB.ld; o.N = wf; o.K = F; o.wpad = wf; o.dyn = 0; o.s0 = ag->inv_batch() / (float)F;
+                o.dst = bC.off; o.ldd = bC.ld; o.dst2 = ezs.off; o.ldd2 = ezs.ld;
+                o.gout = Z; o.ldg = F; o.gout2 = GFH; o.ldg2 = 2 * F; o.part = part_kl_rp; o.step = ag->adam_step + 0; o.flags = RPF_BUMP | RPF_FH_INPLACE;
+                o.m_src = wf; o.m_s2 = wf; o.m_dst = wf; o.m_g = wf; o.m_g2 = wf; o.m_gin = wf;
+                A_.ops.push_back(o);
+            }
+            A_.xop(RP_PUBLISH, bB, 7, wf, 2, F);                        // dKL/d(f heads) for the F cluster
+            A_.xop(RP_XCHG, bC, 2, wf, 1, 0);                           // z
+            fwdS(bC, F, "decoder.l1", "decoder.l1", Hv, 0, wh, ACT_RELU, bB, D1, Hv);
+            A_.xop(RP_XCHG, bB, 3, wh, 1, 0);
+            RpBuf dh = RpAsm::at(bx, S + 1);
+            A_.fwd(bB, Hv, Wp("decoder.state_linear.weight"), Hv, Wp("decoder.state_linear.bias"), S + 1, ACT_NONE, &dh, nullptr, 0);   // every member, whole
+            {
+                RpOp o = RpAsm::blank(RP_MSE);
+                o.src = dh.off; o.lds = dh.ld; o.n0 = S; o.gin = s0.XE ? s0.XE + SA : nullptr; o.ldgin = KE; o.gin2 = s0.R;
+                o.s0 = ag->inv_batch() / (float)S; o.s1 = ag->inv_batch(); o.gout = GDH; o.ldg = S + 1; o.part = part_mse_rp;
+                A_.ops.push_back(o);
+            }
+            dxS(dh, S + 1, Wp("decoder.state_linear.weight"), Hv, wh, ACT_RELU, D1, Hv, &bC, false, GD1, Hv);
+            A_.xop(RP_XCHG, bC, 4, wh, 1, 0);
+            dxS(bC, Hv, Wp("decoder.l1.weight"), F, wf, ACT_NONE, nullptr, 0, &dzs, true, nullptr, 0);
+            {
+                RpOp o = RpAsm::blank(RP_REPARAM);
+                o.src = dzs.off; o.lds = dzs.ld; o.src2 = ezs.off; o.lds2 = ezs.ld; o.dst = bA.off; o.ldd = bA.ld; o.N = wf; o.K = F; o.gout = GEH; o.ldg = 2 * F;
+                o.m_dst = wf; o.m_g = wf;
+                A_.ops.push_back(o);
+            }
+            A_.xop(RP_XCHG, bA, 5, wf, 2, F);                           // dL/d(encoder heads), both halves
+            dxS(bA, 2 * F, Wp("encoder.mean_linear.weight"), Hv, wh, ACT_RELU, ge.H2, Hv, &bB, false, GH2e, Hv);
+            A_.xop(RP_XCHG, bB, 6, wh, 1, 0);
+            dxS(bB, Hv, Wp("encoder.l2.weight"), Hv, wh, ACT_RELU, ge.H1, Hv, nullptr, false, GH1e, Hv);
+        }
+        A_.end(nrb, CS, 0);
+        // ---------------- program F ----------------
+        A_.begin();
+        {
+            RpBuf bx = A_.buf(SA), bA = A_.buf(Hv), bB = A_.buf(Hv), bH = A_.buf(2 * F);
+            A_.load(s0.XF, SA, SA, bx);
+            fwdS(bx, SA, "f.l1", "f.l1", Hv, 0, wh, ACT_RELU, bA, gf.H1, Hv);
+            A_.xop(RP_XCHG, bA, 0, wh, 1, 0);
+            fwdS(bA, Hv, "f.l2", "f.l2", Hv, 0, wh, ACT_RELU, bB, gf.H2, Hv);
+            A_.xop(RP_XCHG, bB, 1, wh, 1, 0);
+            fwdS(bB, Hv, "f.mean_linear", "f.mean_linear", 2 * F, 0, wf, ACT_NONE, bH, gf.HH, 2 * F);
+            fwdS(bB, Hv, "f.mean_linear", "f.mean_linear", 2 * F, F, wf, ACT_NONE, bH, gf.HH, 2 * F);
+            A_.xop(RP_PUBLISH, bH, 2, wf, 2, F);                        // my slice of the heads, for member m of the E cluster
+            A_.xop(RP_GATHER, bH, 7, wf, 2, F, 1);                      // dKL/d(f heads): every E member's slice
+            dxS(bH, 2 * F, Wp("f.mean_linear.weight"), Hv, wh, ACT_RELU, gf.H2, Hv, &bA, false, GH2f, Hv);
+            A_.xop(RP_XCHG, bA, 3, wh, 1, 0);
+            dxS(bA, Hv, Wp("f.l2.weight"), Hv, wh, ACT_RELU, gf.H1, Hv, nullptr, false, GH1f, Hv);
+        }
+        A_.end(nrb, CS, 1);
+    };
     bool use_rp = rl_rowprog_enabled();
+    const bool use_cluster = rl_rowprog_cluster() && CS > 0 && ag->nsh[0] > 0;
     {
-        RpAsm probe; rp_feature(probe, true);
+        RpAsm probe; if (use_cluster) rp_feature_cluster(probe); else rp_feature(probe, true);
         if (probe.lds_bytes() > RP_LDS_DYN_MAX || probe.ops.size() > 4096) use_rp = false;
         for (auto& pr : probe.progs) if (pr.op_end - pr.op_begin > 40) use_rp = false;
     }
@@ -451,10 +546,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
         gauss_tasks(ag, false, "f", s0.XF, SA, SA, gf, tf);
         if (use_rp) {
-            RpAsm A_; rp_feature(A_, early);
+            RpAsm A_; if (use_cluster && !early) rp_feature_cluster(A_); else rp_feature(A_, early);
             RpLaunch L; memset(&L, 0, sizeof(L));
             L.ops = b.upload(A_.ops); L.flags = rp_flags; L.nprog = (int)A_.progs.size(); L.B = B; L.low_prio = 0;
-            L.lds_floats = A_.peak;
+            L.lds_floats = A_.peak; L.xbuf = xbuf; L.epoch = ag->rp_epoch;
             for (size_t q = 0; q < A_.progs.size(); ++q) L.prog[q] = A_.progs[q];
             const int total = A_.blocks;
             rlrep_agent* a = ag;
@@ -510,7 +605,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             if (!nft) b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
         }
         b.stash_fin({
-            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
+            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp * (use_cluster ? CS : 1) : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
             Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 0, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
             Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 1, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
             Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
@@ -531,11 +626,13 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     {
         // apply: Adam over (encoder, decoder, f) + Polyak f -> f_target (vlsac_agent.py:152-154, 240-242)
         const std::vector<FinTask> feat_fins = {
-            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
+            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp * (use_cluster ? CS : 1) : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
             Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 0, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
             Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 1, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
             Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
-            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)};
+            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL),
+            // the next row-program launch gets a fresh epoch for its exchange granules (harmless when none is used)
+            Builder::fin_inc(ag->rp_epoch)};
         const LT& f0 = ag->L.get("f.l1.weight");
         const LT& flast = ag->L.get("f.log_std_linear.bias");
         const int64_t fn = flast.off + flast.rows - f0.off;
@@ -842,6 +939,8 @@ static void static_state(rlrep_agent* ag) {
     const int S = ag->d.state_dim, A = ag->d.action_dim;
     ag->obs_in = ws.f((size_t)ag->d.max_batch * S);
     ag->act_out = ws.f((size_t)ag->d.max_batch * A);
+    ag->rp_epoch = (int*)ws.alloc(sizeof(int) * 4);
+    if (!ws.dry && ws.ok()) { const int one[4] = {1, 0, 0, 0}; (void)hipMemcpy(ag->rp_epoch, one, sizeof(one), hipMemcpyHostToDevice); }
     // transposed weight shadows (see rlrep_agent::sh_dev): vlsac's feature group, read by the feature step's row programs
     ag->shadow_of.clear();
     for (int g = 0; g < 4; ++g) { ag->sh_dev[g] = nullptr; ag->nsh[g] = ag->sh_tiles[g] = 0; }
@@ -1137,6 +1236,7 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
     if (!ag->in_train && ag->has_shadows()) { const int rs = refresh_shadows(ag, stream); if (rs) return rs; }     // parameters may have been written by the caller
+    if (!ag->in_train && rl_rowprog_cluster() && ag->rp_epoch) (void)(++g_rl_launches, rl_launch_counter_inc(ag->rp_epoch, (hipStream_t)stream));   // a fresh epoch whatever ran before
     ag->pi_ready = nullptr;                                       // f_target is about to change
     ag->early_ready_crit = ag->early_ready_act = nullptr;
     if (ag->early_crit && !ag->feat_bwd_h.stages.empty()) {

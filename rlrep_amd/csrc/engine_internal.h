@@ -59,6 +59,9 @@ struct rlrep_agent {
     std::map<std::string, float*> shadow_of;
     float* PT(const std::string& n) const { auto it = shadow_of.find(n); return it == shadow_of.end() ? nullptr : it->second; }
     bool has_shadows() const { return nsh[0] + nsh[1] + nsh[2] + nsh[3] > 0; }
+    // cluster row programs (RLREP_ROWPROG=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
+    // extra launch before an eager step outside a train())
+    int* rp_epoch = nullptr;
 
     float* overridden(const std::string& n) const {
         if (!ov_base || n.compare(0, ov_prefix.size(), ov_prefix) != 0) return nullptr;
@@ -339,6 +342,9 @@ struct Builder {
         f.kind = FIN_COMBINE; f.in_a = a; f.in_b = b; f.scale = sa; f.scale_b = sb; f.out = out;
         return f;
     }
+    static FinTask fin_inc(int* counter) {
+        FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_INC; f.out = reinterpret_cast<float*>(counter); return f;
+    }
     static FinTask fin_copy(const float* a, float* out) {
         FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_COPY; f.in_a = a; f.out = out; return f;
     }
@@ -348,7 +354,8 @@ struct Builder {
 // ------------------------------------------------------------------------------------------------
 // row-block programs (rowprog.hip): host-side assembler
 // ------------------------------------------------------------------------------------------------
-static inline bool rl_rowprog_enabled() { const char* e = getenv("RLREP_ROWPROG"); return e && e[0] == '1'; }
+static inline bool rl_rowprog_enabled() { const char* e = getenv("RLREP_ROWPROG"); return e && (e[0] == '1' || e[0] == '2'); }
+static inline bool rl_rowprog_cluster() { const char* e = getenv("RLREP_ROWPROG"); return e && e[0] == '2'; }
 struct RpBuf { int off, ld, w; };            // LDS buffer: float offset, row stride, zero-padded width (multiple of 32)
 
 struct RpAsm {
@@ -359,7 +366,14 @@ struct RpAsm {
     RpBuf buf(int cols) { RpBuf b; b.w = (cols + 31) & ~31; b.ld = b.w + 4; b.off = top; top += RP_ROWS * b.ld; if (top > peak) peak = top; return b; }
     static RpBuf at(const RpBuf& dead, int cols) { RpBuf b; b.w = (cols + 31) & ~31; b.ld = b.w + 4; b.off = dead.off; if (b.ld > dead.ld) { fprintf(stderr, "rlrep: row-program buffer reuse does not fit\n"); abort(); } return b; }
     void begin() { cur_begin = (int)ops.size(); top = 0; }
-    void end(int nblocks) { RpProg p; p.op_begin = cur_begin; p.op_end = (int)ops.size(); p.block_base = blocks; p.nblocks = nblocks; blocks += nblocks; progs.push_back(p); }
+    void end(int nblocks, int csize = 1, int ctype = 0) {
+        RpProg p; p.op_begin = cur_begin; p.op_end = (int)ops.size(); p.block_base = blocks; p.nblocks = nblocks * csize; p.csize = csize; p.ctype = ctype;
+        blocks += p.nblocks; progs.push_back(p);
+    }
+    // cluster programs: exchange ops on the full-width LDS vector `v`; slice = ws columns x np pieces (piece stride ps) per member
+    void xop(int kind, const RpBuf& v, int hop, int ws, int np, int ps, int mode = 0) {
+        RpOp o = blank(kind); o.src = v.off; o.lds = v.ld; o.N = ws; o.K = np; o.ldw = ps; o.flag = hop; o.n0 = mode; ops.push_back(o);
+    }
     void load(const float* g, int ldg, int K, const RpBuf& d) {
         RpOp o = blank(RP_LOAD); o.gin = g; o.ldgin = ldg; o.K = K; o.dst = d.off; o.ldd = d.ld; o.wpad = d.w; ops.push_back(o);
     }

@@ -76,7 +76,7 @@ struct QHeadActor {
     int ldE;                   // row stride of Ec/GE (0 -> H)
 };
 
-enum FinKind : int { FIN_SUM = 0, FIN_COMBINE = 1, FIN_ALPHA = 2, FIN_COPY = 3 };
+enum FinKind : int { FIN_SUM = 0, FIN_COMBINE = 1, FIN_ALPHA = 2, FIN_COPY = 3, FIN_INC = 4 };    // FIN_INC: *(int*)out += 1 (launch epoch of the cluster programs)
 
 struct FinTask {
     int kind;
@@ -100,6 +100,8 @@ __device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin,
             if (lane == 0) *f.out = s * f.scale;
         } else if (f.kind == FIN_COMBINE) {
             if (lane == 0) *f.out = f.scale * (*f.in_a) + f.scale_b * (*f.in_b);
+        } else if (f.kind == FIN_INC) {
+            if (lane == 0) *reinterpret_cast<int*>(f.out) += 1;
         } else if (f.kind == FIN_COPY) {
             if (lane == 0) *f.out = *f.in_a;
         } else if (f.kind == FIN_ALPHA) {

@@ -14,8 +14,10 @@ struct GroupCfg;
 #define RP_ROWS 16            // batch rows per workgroup (one MFMA row tile)
 #define RP_THREADS 512        // 8 waves: 4 column groups x 2 halves of the inner dimension (two waves per SIMD)
 #define RP_MAX_PROGS 8
+#define RP_XSLOT 1024            // granules per (cluster, hop, member) slot of the exchange buffer (16 rows x up to 64 columns)
+#define RP_MAX_HOPS 12
 #define RP_MAX_DYN 4
-#define RP_LDS_DYN_MAX (124 * 1024)   // dynamic LDS a program may use for its activation buffers (160 KB per CU minus the kernel's static 35 KB)
+#define RP_LDS_DYN_MAX (122 * 1024)   // dynamic LDS a program may use for its activation buffers (160 KB per CU minus the kernel's static 37 KB)
 
 enum RpKind : int {
     RP_END = 0,
@@ -27,7 +29,13 @@ enum RpKind : int {
     RP_SIGNAL = 6,      // publish this block's global stores to the partner workgroup (flag = 1)
     RP_WAIT = 7,        // wait for the partner's flag, acquire, reset it
     RP_STORE = 8,       // LDS src [16, N] -> global gout
-    RP_POLICY = 9       // tanh-Gaussian sampling + log-prob from the actor head output [mu | rho] (agent/sac/actor.py:76-91)
+    RP_POLICY = 9,      // tanh-Gaussian sampling + log-prob from the actor head output [mu | rho] (agent/sac/actor.py:76-91)
+    // ---- cluster programs: C workgroups per row block, member m owns a column slice of every layer --------------------------------
+    // LDS src [16, .] holds the full-width vector being assembled; member m owns columns { m*N + q*ldw + c : q < K pieces, c < N }.
+    // PUBLISH writes the own slice to exchange slot (cluster, hop = flag, member) as 8-byte granules {float, tag}; GATHER polls the
+    // other members' slots (n0 = 0: own cluster, all other members; 1: peer cluster, ALL members; 2: peer cluster, the same member only)
+    // and completes the LDS vector.  XCHG = PUBLISH + GATHER(0).
+    RP_PUBLISH = 10, RP_GATHER = 11, RP_XCHG = 12
 };
 
 #define RPF_COL 1          // RP_GEMM: B operand is W[k][col] (dX = G W); default W[col][k] (Y = X W^T)
@@ -35,6 +43,7 @@ enum RpKind : int {
 #define RPF_MASK_LDS 4     // multiply by act'(aux) with aux in LDS (src2, lds2)
 #define RPF_MASK_GLOBAL 8  // multiply by act'(aux) with aux in global memory (gaux, ldgaux)
 #define RPF_BUMP 16        // RP_VAE_MID: row block 0 bumps the optimizer group's step counter
+#define RPF_FH_INPLACE 32   // RP_VAE_MID: also overwrite src2 (the f heads) with dKL/d(f heads), for a following RP_PUBLISH
 
 struct RpOp {
     int kind, flags;
@@ -51,9 +60,12 @@ struct RpOp {
     int n0, dyn, flag, wpad;               // dyn: index of the per-call pointer (RpDyn) this op reads (-1: none); wpad: zeroed LDS width
     float s0, s1;
     float* part; GroupCfg* step;
+    // cluster programs: per-member increments (floats / LDS floats) added to W, bias, gout, gout2, gaux, gin and to the LDS offsets dst, src2
+    int m_w, m_b, m_g, m_g2, m_gaux, m_gin, m_dst, m_s2, m_src, m_dst2;
+    int pad0, pad1;
 };
 
-struct RpProg { int op_begin, op_end; int block_base, nblocks; };      // one program = one kind of workgroup; nblocks row blocks
+struct RpProg { int op_begin, op_end; int block_base, nblocks; int csize, ctype; };   // one kind of workgroup; nblocks = row blocks x csize members (csize 1: no cluster); ctype: which of the two clusters of a row block
 
 struct RpLaunch {
     const RpOp* ops;            // device table
@@ -61,6 +73,8 @@ struct RpLaunch {
     int nprog, B, low_prio, lds_floats;
     RpProg prog[RP_MAX_PROGS];
     const float* dyn[RP_MAX_DYN];          // per-call pointers (noise), patched at launch time
+    unsigned long long* xbuf;              // exchange buffer [row block][2 cluster types][RP_MAX_HOPS][csize][RP_XSLOT] granules
+    const int* epoch;                      // device counter that differs between any two launches whose granules could be confused
 };
 
 extern "C" int rl_launch_rowprog(const RpLaunch* L, int total_blocks, hipStream_t st);

@@ -153,8 +153,10 @@ __device__ __forceinline__ void rp_gemm(const RpOp& op, int r0, int B, RpShared&
         for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // epilogue operands of this thread's 16 outputs (half 0 only), fetched before the inner loop so that their latency hides
         // behind it (and so that no load sits between the epilogue's stores: the compiler cannot move a load above a store that may alias)
-        // (volatile asm loads: as plain loads hipcc sinks them below the loop and the barrier, next to their first use -- 1.7 us of exposed
-        // latency per layer, measured.  They are older than every load of the inner loop and are claimed by the explicit wait after it.)
+        // (left alone hipcc sinks these loads below the loop and the barrier, next to their first use -- 1.7 us of exposed latency per layer,
+        // measured -- hence the memory-clobbering asm behind them.  They are PLAIN loads on purpose: an asm load whose result is claimed by a
+        // later s_waitcnt leaves the compiler free to copy or reuse the destination register while the load is in flight, and a change of
+        // register allocation turned exactly that into run-to-run differences of the loss.)
         float mk[4][4], bv[4];
         const bool epi = kh == 0 && live;
 #pragma unroll
@@ -169,18 +171,18 @@ __device__ __forceinline__ void rp_gemm(const RpOp& op, int r0, int B, RpShared&
                 gcf_t p = gaux + (size_t)min(r0 + 4 * q + reg, B - 1) * op.ldgaux;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    gcf_t pe = p + min(COL ? c0 + 4 * j + u : c0 + 16 * u + j, N - 1);
-                    asm volatile("global_load_dword %0, %1, off" : "+v"(mk[u][reg]) : "v"(pe));
+                    mk[u][reg] = p[min(COL ? c0 + 4 * j + u : c0 + 16 * u + j, N - 1)];
                 }
             }
         }
         if (epi && (op.flags & RPF_BIAS)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                gcf_t pe = bias + min(COL ? c0 + 4 * j + u : c0 + 16 * u + j, N - 1);
-                asm volatile("global_load_dword %0, %1, off" : "+v"(bv[u]) : "v"(pe));
+                bv[u] = bias[min(COL ? c0 + 4 * j + u : c0 + 16 * u + j, N - 1)];
             }
         }
+        // pin the loads above the inner loop: nothing may move across an asm that clobbers memory
+        asm volatile("" ::: "memory");
         if (live && g_beg < g_end) {
             const int last = g_end - 1;
             if (!COL) {
@@ -225,6 +227,9 @@ __device__ __forceinline__ void rp_gemm(const RpOp& op, int r0, int B, RpShared&
                     RP_WAIT8(bC);
                     if (g + 2 < g_end) rp_mac_dx(*reinterpret_cast<const f32x4*>(a_base + 16 * (g + 2)), bC, acc);
                 }
+                // the clamped prefetches of the last iterations are still in flight and the compiler does not know it: their destination
+                // registers are dead to it from here on, so they must have landed before anything else is allocated there
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef RP_LD4
 #undef RP_WAIT8
             } else {
@@ -241,14 +246,7 @@ __device__ __forceinline__ void rp_gemm(const RpOp& op, int r0, int B, RpShared&
                 }
             }
         }
-        // claim the epilogue operands (the operand stream issued behind them has been consumed: they arrived long ago)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            asm volatile("" : "+v"(bv[u]));
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) asm volatile("" : "+v"(mk[u][reg]));
-        }
+        asm volatile("" ::: "memory");
         if (tim && threadIdx.x == 0) RP_STAMP(tim, 128 + oi, wall_clock64());
         if (kh >= 1 && live) {
 #pragma unroll
@@ -272,11 +270,24 @@ __device__ __forceinline__ void rp_gemm(const RpOp& op, int r0, int B, RpShared&
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float x = acc[u][reg];
-                    for (int part = 1; part < P; ++part) x += sh.red[(part - 1) * cpp + cg][u * 4 + reg][lane];      // fixed order
-                    v[reg][u] = x + (biased ? bv[u] : 0.f);
-                }
+                for (int u = 0; u < 4; ++u) v[reg][u] = acc[u][reg];
+            // the other parts' partial sums in fixed order: part-major, so that the 16 LDS reads of a part are in flight together (an
+            // element-major loop with a run-time part count serialises 16 x (P - 1) dependent LDS round trips: 3.7 us per layer at P = 8)
+            for (int part = 1; part < P; ++part) {
+                float t[4][4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[reg][u] = sh.red[(part - 1) * cpp + cg][u * 4 + reg][lane];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[reg][u] += t[reg][u];
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[reg][u] += biased ? bv[u] : 0.f;
             // ONE uniform branch per layer on (masked, activation), the 16 elements inside it (a switch per element is a ladder of ~80
             // scalar branches per layer)
 #define RP_EACH(expr) _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) _Pragma("unroll") for (int u = 0; u < 4; ++u) { const float x = v[reg][u]; const float m = mk[u][reg]; (void)m; v[reg][u] = (expr); }
@@ -370,8 +381,11 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
 #pragma unroll
     for (int p = 1; p < RP_MAX_PROGS; ++p) if (p < L.nprog && bid >= L.prog[p].block_base) pi = p;
     const RpProg pr = L.prog[pi];
-    const int rb = bid - pr.block_base;
+    const int cs = pr.csize > 1 ? pr.csize : 1;
+    const int local = bid - pr.block_base;
+    const int rb = local / cs, member = local - rb * cs;       // cluster programs: csize consecutive workgroups share a row block
     const int r0 = rb * RP_ROWS;
+    const unsigned epoch = L.epoch ? (unsigned)*(const RP_GAS int*)L.epoch : 0u;
     const int B = L.B;
     const int nrb = (B + RP_ROWS - 1) / RP_ROWS;
     const int nops = pr.op_end - pr.op_begin;
@@ -383,7 +397,18 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
     __syncthreads();
     const int tid = threadIdx.x;
     for (int oi = 0; oi < nops; ++oi) {
-        const RpOp op = rp_fetch(sh.ops, oi);
+        RpOp op = rp_fetch(sh.ops, oi);
+        if (member) {                           // this member's column slice of the layer: shifted operand / result pointers (uniform scalars)
+            // (null stays null: an absent result / operand must stay absent)
+            if (op.W) op.W += member * op.m_w;
+            if (op.bias) op.bias += member * op.m_b;
+            if (op.gout) op.gout += member * op.m_g;
+            if (op.gout2) op.gout2 += member * op.m_g2;
+            if (op.gaux) op.gaux += member * op.m_gaux;
+            if (op.gin) op.gin += member * op.m_gin;
+            if (op.dst >= 0) op.dst += member * op.m_dst;
+            op.src2 += member * op.m_s2; op.src += member * op.m_src; op.dst2 += member * op.m_dst2;
+        }
         if (tim && threadIdx.x == 0) { RP_STAMP(tim, oi, wall_clock64()); RP_STAMP(tim, 64 + oi, clock64()); }
         if (op.kind == RP_LOAD || (op.kind == RP_GEMM && (op.flags & RPF_MASK_GLOBAL))) rp_sync_global();
         switch (op.kind) {
@@ -410,8 +435,9 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
             // src = encoder heads [16, 2F] (mean | log_std), src2 = f heads (read only).  src <- (dKL/dmean1 | dKL/dlog_std1) in place,
             // dst <- z (zero up to its padded width: it is the decoder's K operand), dst2 <- eps * sigma1 * clamp-mask;
             // gout <- z, gout2 <- (dKL/dmean2 | dKL/dlog_std2); KL partial -> part[rb]
-            const int F = op.N, Fp = op.wpad;
-            gcf_t eps = G(L.dyn[op.dyn]);
+            // cluster member: N = the slice's width, K = F (offset of the log-std halves, row stride of the noise), all pointers pre-shifted
+            const int F = op.N, Fp = op.wpad, FO = op.K > 0 ? op.K : op.N;
+            gcf_t eps = G(L.dyn[op.dyn]) + member * op.m_gin;
             float k = 0.f;
             {
                 const int row = tid >> 5, l = tid & 31;
@@ -420,7 +446,7 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                 const float* fh = rp_buf + op.src2 + row * op.lds2;
                 float* zr = rp_buf + op.dst + row * op.ldd;
                 float* ezr = rp_buf + op.dst2 + row * op.ldd2;
-                gcf_t er = eps + (size_t)min(r0 + row, B - 1) * F;
+                gcf_t er = eps + (size_t)min(r0 + row, B - 1) * FO;
                 gf_t gz = G(op.gout) + (size_t)min(r0 + row, B - 1) * op.ldg;
                 gf_t g2 = G(op.gout2) + (size_t)min(r0 + row, B - 1) * op.ldg2;
                 const float sc = op.s0;                                  // 1 / (B_global * F)
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                         const int jj = j0 + 32 * i;
                         if (jj >= Fp) break;
                         if (jj >= F) { zr[jj] = 0.f; continue; }
-                        const float m1 = eh[jj], l1r = eh[F + jj], m2 = fh[jj], l2r = fh[F + jj];
+                        const float m1 = eh[jj], l1r = eh[FO + jj], m2 = fh[jj], l2r = fh[FO + jj];
                         const float l1 = clamp_lstd(l1r), l2 = clamp_lstd(l2r);
                         const float es = ev[i] * expf(l1);
                         const float z = m1 + es;
@@ -442,22 +468,24 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                         const float kk = l2 - l1 + 0.5f * (v1 + d * d) * iv2 - 0.5f;
                         const float dm1 = d * iv2 * sc;
                         eh[jj] = dm1;
-                        eh[F + jj] = (v1 * iv2 - 1.f) * sc * lstd_mask(l1r);
+                        eh[FO + jj] = (v1 * iv2 - 1.f) * sc * lstd_mask(l1r);
                         zr[jj] = z;
                         ezr[jj] = es * lstd_mask(l1r);
+                        const float gl2 = (1.f - (v1 + d * d) * iv2) * sc * lstd_mask(l2r);
+                        if (op.flags & RPF_FH_INPLACE) { float* fw = const_cast<float*>(fh); fw[jj] = -dm1; fw[FO + jj] = gl2; }
                         if (rok) {
                             k += kk;
                             gz[jj] = z;
                             g2[jj] = -dm1;
-                            g2[F + jj] = (1.f - (v1 + d * d) * iv2) * sc * lstd_mask(l2r);
+                            g2[FO + jj] = gl2;
                         }
                     }
                 }
             }
             const float s = rp_block_sum(k, sh.part);
             if (tid == 0) {
-                G(op.part)[rb] = s;
-                if ((op.flags & RPF_BUMP) && rb == 0 && op.step) bump_group(op.step);
+                G(op.part)[local] = s;
+                if ((op.flags & RPF_BUMP) && local == 0 && op.step) bump_group(op.step);
             }
         } break;
         case RP_MSE: {
@@ -472,27 +500,27 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                 const float d = *p - tgt;
                 const float g = d * (c < S ? op.s0 : op.s1);
                 *p = g;
-                if (r0 + row < B) {
+                if (r0 + row < B && member == 0) {          // (cluster: every member evaluates the heads, member 0 reports)
                     if (c < S) es += d * d; else er += d * d;
                     G(op.gout)[(size_t)(r0 + row) * op.ldg + c] = g;
                 }
             }
             const float a = rp_block_sum(es, sh.part);
             const float b = rp_block_sum(er, sh.part);
-            if (tid == 0) { G(op.part)[2 * rb] = a; G(op.part)[2 * rb + 1] = b; }
+            if (tid == 0 && member == 0) { G(op.part)[2 * rb] = a; G(op.part)[2 * rb + 1] = b; }
         } break;
         case RP_REPARAM: {
             // dst (dKL/dmean1 | dKL/dlog_std1) += (dz | dz * eps sigma mask);  src = dz [16, F], src2 = eps sigma mask [16, F]; gout <- dst
-            const int F = op.N, row = tid >> 5;
+            const int F = op.N, FO = op.K > 0 ? op.K : op.N, row = tid >> 5;
             const bool rok = r0 + row < B;
             float* g = rp_buf + op.dst + row * op.ldd;
             gf_t go = G(op.gout) + (size_t)min(r0 + row, B - 1) * op.ldg;
             for (int jj = tid & 31; jj < F; jj += 32) {
                 const float dz = rp_buf[op.src + row * op.lds + jj];
                 const float ez = rp_buf[op.src2 + row * op.lds2 + jj];
-                const float a = g[jj] + dz, b = g[F + jj] + dz * ez;
-                g[jj] = a; g[F + jj] = b;
-                if (rok) { go[jj] = a; go[F + jj] = b; }
+                const float a = g[jj] + dz, b = g[FO + jj] + dz * ez;
+                g[jj] = a; g[FO + jj] = b;
+                if (rok) { go[jj] = a; go[FO + jj] = b; }
             }
         } break;
         case RP_STORE: {
@@ -518,6 +546,53 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                     lp += -0.5f * e * e - l - 0.91893853320467274f - 2.f * (0.69314718055994531f - x - softplus_f(-2.f * x));
                 }
                 if (op.gout2) G(op.gout2)[r0 + tid] = lp;
+            }
+        } break;
+        case RP_PUBLISH: case RP_GATHER: case RP_XCHG: {
+            // slice geometry: width ws = N, pieces np = K (>= 1), piece stride ps = ldw; element e of a slice = (row, piece, c)
+            const int ws = op.N, np = op.K > 0 ? op.K : 1, ps = op.ldw, per_row = ws * np, ne = RP_ROWS * per_row;
+            const unsigned tag = epoch * 64u + (unsigned)op.flag;
+            RP_GAS unsigned long long* const xb = (RP_GAS unsigned long long*)L.xbuf;
+            auto slot = [&](int ctype, int mem) { return xb + ((((size_t)rb * 2 + ctype) * RP_MAX_HOPS + op.flag) * cs + mem) * RP_XSLOT; };
+            auto col_of = [&](int mem, int r) { const int qq = r / ws; return mem * ws + qq * ps + (r - qq * ws); };
+            if (op.kind != RP_GATHER) {
+                RP_GAS unsigned long long* mine = slot(pr.ctype, member);
+                for (int e = tid; e < ne; e += RP_THREADS) {
+                    const int row = e / per_row, r = e - row * per_row;
+                    const float v = rp_buf[op.src + row * op.lds + col_of(member, r)];
+                    __hip_atomic_store(mine + e, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (op.kind != RP_PUBLISH && op.n0 != 2) {
+                // the assembled vector is the next layer's inner operand: zero its padding up to the next multiple of 32 columns (the region
+                // may have held a wider vector before)
+                const int total = (np - 1) * ps + cs * ws, padw = ((total + 31) & ~31) - total;
+                for (int e = tid; e < RP_ROWS * padw; e += RP_THREADS) { const int row = e / padw; rp_buf[op.src + row * op.lds + total + (e - row * padw)] = 0.f; }
+            }
+            if (op.kind != RP_PUBLISH) {
+                const int from = op.n0 == 0 ? pr.ctype : (pr.ctype ^ 1);
+                // the granules this thread is responsible for: position e (and e + 512) of every source member
+                for (int e = tid; e < ne; e += RP_THREADS) {
+                    const int row = e / per_row, r = e - row * per_row;
+                    unsigned pending = 0;
+                    for (int o = 0; o < cs; ++o) {
+                        const bool want = op.n0 == 0 ? (o != member) : (op.n0 == 1 ? true : (o == member));
+                        if (want) pending |= 1u << o;
+                    }
+                    int spins = 0;
+                    while (pending && spins < (1 << 20)) {
+                        for (int o = 0; o < cs; ++o) {
+                            if (!(pending & (1u << o))) continue;
+                            const unsigned long long g = __hip_atomic_load(slot(from, o) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(g >> 32) == tag) {
+                                rp_buf[op.src + row * op.lds + col_of(o, r)] = __uint_as_float((unsigned)g);
+                                pending &= ~(1u << o);
+                            }
+                        }
+                        if (pending) __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                    }
+                }
             }
         } break;
         case RP_SIGNAL: {

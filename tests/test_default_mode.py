@@ -297,3 +297,14 @@ def test_fused_first_layers_match_oracle(monkeypatch):
         assert any('enc.l1+l2' in n for n in agent.core.stages(0)), agent.core.stages(0)
         del agent
         _check_against_oracle(c, calls=3, expect_pipeline=True)
+
+
+@pytest.mark.parametrize('name', ['vlsac_tiny', 'vlsac_hc'])
+def test_cluster_row_programs_match_oracle(name, monkeypatch):
+    """RLREP_ROWPROG=2: the cluster form -- C workgroups per row block and chain (4 at the tiny dimensions, 8 at the headline ones), each
+    owning a column slice of every layer, completing each other's activation vectors through tagged 8-byte granules (rowprog.hip
+    RP_XCHG / RP_PUBLISH / RP_GATHER) -- in the default mode against the oracle on the read-back draws."""
+    monkeypatch.setenv('RLREP_ROWPROG', '2')
+    c = Case(name)
+    worst = _check_against_oracle(c, calls=3, expect_pipeline=True)
+    print(f'{name} cluster row programs vs oracle: worst param rel-L2 {worst:.2e}')
