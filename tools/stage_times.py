@@ -15,21 +15,25 @@ for _ in range(200): agent.train(buf,B)
 e1.record(); torch.cuda.synchronize()
 print('train() GPU time per call (events, graph=%s): %.1f us'%(agent.use_graph, e0.elapsed_time(e1)*1e3/200))
 core=agent.core
+WARM=int(os.environ.get('STAGE_WARM','20'))      # replays of the 50-launch graph before timing (clock ramp)
+ONLY=os.environ.get('STAGE_ONLY')               # substring filter on the stage name
 names={0:'feature_bwd',1:'feature_apply',2:'critic_bwd',3:'critic_apply',4:'actor_bwd',5:'actor_apply',6:'update_target'}
 tot_all=0
 for p in range(7):
     st=core.stages(p); tot=0
     for i,n in enumerate(st):
+        if ONLY and ONLY not in n: continue
         for _ in range(10): core.run_stage(p,i)
         torch.cuda.synchronize()
         g=torch.cuda.CUDAGraph(); s=torch.cuda.Stream()
         with torch.cuda.graph(g, stream=s):
             for _ in range(50): core.run_stage(p,i)
-        g.replay(); torch.cuda.synchronize()
+        for _ in range(WARM): g.replay()
+        torch.cuda.synchronize()
         e0.record()
-        for _ in range(4): g.replay()
+        for _ in range(8): g.replay()
         e1.record(); torch.cuda.synchronize()
-        us=e0.elapsed_time(e1)*1e3/200
+        us=e0.elapsed_time(e1)*1e3/400
         tot+=us
         print(f'  {names[p]:14s} {i:2d} {us:7.2f} us  {n}')
     mult = 4 if p<2 else 1
