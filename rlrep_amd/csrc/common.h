@@ -101,7 +101,12 @@ struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; GemmT
 // ------------------------------------------------------------------------------------------------
 // Transposed shadow copy of a weight matrix (rowprog.hip reads W^T so that a lane's 16-byte B fragment and its neighbours' are
 // contiguous): tensor at float offset `off` (n = rows * cols) of an arena, shadow [cols][rows] at sp; st = shadow of its Polyak target.
-struct ShadowEnt { long long off, n; int rows, cols; float* sp; float* st; };
+//
+// kind 1 (noisecritic.hip): the bf16x3 images of a weight matrix [rows = H][cols = F], F % 32 == 0, in the order the noise critic's B
+// fragments are read: [F / 32 steps][3 images hi, mid, lo][H rows][4 groups of 8 consecutive k][8 bf16] -- 64 bytes per (step, image, row).
+// sp / st then point at those byte images (3 * rows * cols * 2 bytes each).  `src`, when set, is the tensor itself (the refresh launch of a
+// table whose entries live in different arenas: live and target critic); otherwise base + off as for kind 0.
+struct ShadowEnt { long long off, n; int rows, cols; float* sp; float* st; const float* src; int kind, pad; };
 
 struct AdamTask {
     float* p; const float* g; float* m; float* v;

@@ -3,6 +3,7 @@
 // deterministic per-block partial sums (no float atomics) that the optimizer launch finalises.
 #include "common.h"
 #include "kparams.h"
+#include "x3.h"
 
 // ------------------------------------------------------------------------------------------------
 // minibatch slot fill: replay-ring gather (idx) or five separate arrays (reference Batch fields)
@@ -126,7 +127,13 @@ __device__ __forceinline__ void shadow_tile_body(const ShadowEnt* __restrict__ s
     const int tc = (e.cols + 31) / 32, local = tile - t0;
     const int r0 = (local / tc) * 32, c0 = (local % tc) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 256 threads: 8 rows per pass
-    const float* src = base + e.off;
+    const float* src = e.src ? e.src : base + e.off;
+    if (e.kind == 1) {
+        // bf16x3 images: the tile is one 32-deep step of 32 rows; thread = (row, four consecutive k) -> 8 bytes of each image
+        const int r = r0 + (threadIdx.x >> 3), k4 = threadIdx.x & 7;
+        if (r < e.rows) x3_shadow_store(reinterpret_cast<unsigned char*>(dst), e.rows, r, c0 + 4 * k4, *reinterpret_cast<const f32x4*>(src + (size_t)r * e.cols + c0 + 4 * k4));
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + ty + 8 * k, c = c0 + tx;
@@ -399,6 +406,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
             for (int q = 0; q < t.nsh; ++q) {
                 const ShadowEnt e = t.sh[q];
                 if (i < e.off || i >= e.off + e.n) continue;
+                if (e.kind == 1) {
+                    // (cols % 32 == 0 and the tensor starts on a multiple of 4 floats: the four elements are four consecutive k of one row)
+                    const long long l = i - e.off;
+                    const int r = (int)(l / e.cols), c = (int)(l - (long long)r * e.cols);
+                    x3_shadow_store(reinterpret_cast<unsigned char*>(e.sp), e.rows, r, c, p4);
+                    if (pol && e.st) x3_shadow_store(reinterpret_cast<unsigned char*>(e.st), e.rows, r, c, t4);
+                    break;
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const long long l = i + s - e.off;
@@ -420,6 +435,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
                 if (e < se.off || e >= se.off + se.n) continue;
                 const long long l = e - se.off;
                 const int r = (int)(l / se.cols), c = (int)(l - (long long)r * se.cols);
+                if (se.kind == 1) {         // (unreachable for the shapes that get such a shadow: their arrays take the 16-byte path above)
+                    x3_shadow_store1(reinterpret_cast<unsigned char*>(se.sp), se.rows, r, c, t.p[e]);
+                    if (tp && se.st) x3_shadow_store1(reinterpret_cast<unsigned char*>(se.st), se.rows, r, c, *tp);
+                    break;
+                }
                 se.sp[(size_t)c * se.rows + r] = t.p[e];
                 if (tp && se.st) se.st[(size_t)c * se.rows + r] = *tp;
                 break;

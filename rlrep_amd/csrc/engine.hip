@@ -656,9 +656,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     const size_t BH = (size_t)B * H, BNH = (size_t)B * N * H;
     const float* noise = Tw("critic.noise");
 
-    auto nc_task = [&](const float* HH, const float* W, const float* bias, float* Hm, float* Ubuf) {
+    auto nc_task = [&](const float* HH, const float* W, const float* bias, float* Hm, float* Ubuf, const unsigned char* W3 = nullptr) {
         NcFwdTask t; memset(&t, 0, sizeof(t));
-        t.mean = HH; t.lstd = HH ? HH + F : nullptr; t.ld_ml = 2 * F; t.noise = noise; t.W = W; t.bias = bias; t.Hm = Hm; t.U = Ubuf;
+        t.mean = HH; t.lstd = HH ? HH + F : nullptr; t.ld_ml = 2 * F; t.noise = noise; t.W = W; t.W3 = W3; t.bias = bias; t.Hm = Hm; t.U = Ubuf;
         t.B = B; t.F = F; t.H = H; t.N = N;
         return t;
     };
@@ -716,12 +716,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             b.fwd_stage(p, {tn[2]}, "ft.heads");
         }
         {
-            NcFwdTask live1 = nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U);
+            NcFwdTask live1 = nc_task(gt.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U, ag->W3("critic.l1.weight"));
             live1.sigma_out = SIG;
-            nc_stage(p, {nc_task(gn.HH, Tw("critic_target.l1.weight"), Tw("critic_target.l1.bias"), HmT, nullptr),
-                         nc_task(gn.HH, Tw("critic_target.l4.weight"), Tw("critic_target.l4.bias"), HmT + BH, nullptr),
+            nc_stage(p, {nc_task(gn.HH, Tw("critic_target.l1.weight"), Tw("critic_target.l1.bias"), HmT, nullptr, ag->W3("critic_target.l1.weight")),
+                         nc_task(gn.HH, Tw("critic_target.l4.weight"), Tw("critic_target.l4.bias"), HmT + BH, nullptr, ag->W3("critic_target.l4.weight")),
                          live1,
-                         nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4 (target+live)");
+                         nc_task(gt.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH, ag->W3("critic.l4.weight"))}, "noise critic l1/l4 (target+live)");
         }
         b.fwd_stage(p, {Builder::fwd(HmT, H, B, H, Tw("critic_target.l2.weight"), H, Tw("critic_target.l2.bias"), H, Et, H, ACT_ELU),
                         Builder::fwd(HmT + BH, H, B, H, Tw("critic_target.l5.weight"), H, Tw("critic_target.l5.bias"), H, Et + BH, H, ACT_ELU),
@@ -793,8 +793,8 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         b.fwd_stage(p, {tt[1]}, "ft.l2");
         b.fwd_stage(p, {tt[2]}, "ft.heads");
         resume = (int)p.stages.size();                // everything above is what critic_bwd_h already did
-        nc_stage(p, {nc_task(gp.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U),
-                     nc_task(gp.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH)}, "noise critic l1/l4");
+        nc_stage(p, {nc_task(gp.HH, Pw("critic.l1.weight"), Pw("critic.l1.bias"), HmC, U, ag->W3("critic.l1.weight")),
+                     nc_task(gp.HH, Pw("critic.l4.weight"), Pw("critic.l4.bias"), HmC + BH, U + BNH, ag->W3("critic.l4.weight"))}, "noise critic l1/l4");
         b.fwd_stage(p, {Builder::fwd(HmC, H, B, H, Pw("critic.l2.weight"), H, Pw("critic.l2.bias"), H, Ec, H, ACT_ELU),
                         Builder::fwd(HmC + BH, H, B, H, Pw("critic.l5.weight"), H, Pw("critic.l5.bias"), H, Ec + BH, H, ACT_ELU)}, "critic l2/l5");
         QHeadActor q; memset(&q, 0, sizeof(q));
@@ -977,16 +977,57 @@ static void static_state(rlrep_agent* ag) {
         if (!ws.dry && ws.ok() && !tab.empty()) (void)hipMemcpy(dev, tab.data(), tab.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice);
         ag->sh_dev[0] = dev; ag->nsh[0] = (int)tab.size(); ag->sh_tiles[0] = tiles;
     }
+    // bf16x3 images of the noise critic's first layers (vlsac): see rlrep_agent::x3_refresh.  RLREP_NC_SHADOWS=0 turns them off (the
+    // kernels then split W themselves, as in round 1).
+    ag->x3_refresh = nullptr; ag->x3_n = ag->x3_tiles = 0; ag->x3_of.clear();
+    {
+        const char* e = getenv("RLREP_NC_SHADOWS");
+        const int F = ag->d.feature_dim, H = ag->d.hidden_dim;
+        if (ag->d.alg == RLREP_ALG_VLSAC && !(e && e[0] == '0') && F > 0 && (F % 32) == 0 && ag->L.index.count("critic.l1.weight") && ag->L.index.count("critic_target.l1.weight")) {
+            std::vector<ShadowEnt> all, live;
+            const char* names[4] = {"critic.l1.weight", "critic.l4.weight", "critic_target.l1.weight", "critic_target.l4.weight"};
+            for (int q = 0; q < 4; ++q) {
+                const LT& t = ag->L.get(names[q]);
+                ShadowEnt se; memset(&se, 0, sizeof(se));
+                se.off = t.off; se.n = (long long)t.rows * t.cols; se.rows = t.rows; se.cols = t.cols; se.kind = 1;
+                unsigned char* img = (unsigned char*)ws.alloc((size_t)3 * t.rows * t.cols * 2);
+                se.sp = reinterpret_cast<float*>(img);
+                se.src = q < 2 ? (ag->a.param_dev ? ag->a.param_dev + t.off : nullptr) : (ag->a.target_dev ? ag->a.target_dev + t.off : nullptr);
+                ag->x3_of[names[q]] = img;
+                all.push_back(se);
+                ag->x3_tiles += ((t.rows + 31) / 32) * ((t.cols + 31) / 32);
+                if (q < 2) { ShadowEnt lv = se; lv.src = nullptr; lv.off = t.off - ag->L.group_off[1]; live.push_back(lv); }     // (the Adam launch indexes from the group's start)
+                (void)H;
+            }
+            ShadowEnt* dev = (ShadowEnt*)ws.alloc(all.size() * sizeof(ShadowEnt));
+            ShadowEnt* dev_live = (ShadowEnt*)ws.alloc(live.size() * sizeof(ShadowEnt));
+            if (!ws.dry && ws.ok()) {
+                (void)hipMemcpy(dev, all.data(), all.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice);
+                (void)hipMemcpy(dev_live, live.data(), live.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice);
+            }
+            ag->x3_refresh = dev; ag->x3_n = (int)all.size();
+            // the critic group's Adam launch keeps the live images current (the actor step reads them right after the critic update)
+            ag->sh_dev[1] = dev_live; ag->nsh[1] = (int)live.size(); ag->sh_tiles[1] = 0;      // (no tiles: group 1 is refreshed through x3_refresh)
+        }
+    }
     ag->ws_static = ws.used;
 }
 
 // regenerate the shadows of group g from the parameters as they stand (a launch of its own: the eager entry points)
 static int refresh_shadows(rlrep_agent* ag, void* stream) {
     for (int g = 0; g < 4; ++g) {
-        if (!ag->nsh[g]) continue;
+        if (!ag->nsh[g] || !ag->sh_tiles[g]) continue;
         const int rc = rl_launch_shadow(ag->sh_dev[g], ag->nsh[g], ag->sh_tiles[g], ag->a.param_dev, 0, (hipStream_t)stream); ++g_rl_launches;
         if (rc) { rl_set_error("shadow refresh: hip error %d", rc); return RLREP_ERR_HIP; }
     }
+    return 0;
+}
+
+// regenerate the bf16x3 images of the noise critic's first layers, live and target, from the tensors as they stand (one launch)
+static int refresh_x3(rlrep_agent* ag, void* stream) {
+    if (!ag->x3_n) return 0;
+    const int rc = rl_launch_shadow(ag->x3_refresh, ag->x3_n, ag->x3_tiles, nullptr, 0, (hipStream_t)stream); ++g_rl_launches;
+    if (rc) { rl_set_error("x3 shadow refresh: hip error %d", rc); return RLREP_ERR_HIP; }
     return 0;
 }
 
@@ -1269,6 +1310,9 @@ int32_t rlrep_critic_backward(rlrep_agent* ag, const float* eps, void* stream) {
     if (!eps) { rl_set_error("critic step needs eps[B,A]"); return RLREP_ERR_ARG; }
     ag->cur_eps = eps; ag->last_launches = 0;
     ag->pi_ready = nullptr;
+    // the images of critic.l1 / l4 and of their targets, from the tensors as they are now: the target copies have no other writer, and a
+    // caller may have written any of them since the last step (the launch rides on the chain that has slack in the pipelined train())
+    { const int rs = refresh_x3(ag, stream); if (rs) return rs; }
     if (ag->early_ready_crit && ag->early_ready_crit == eps) {      // both policy forwards already ran (last feature step)
         const float* act_eps = ag->early_ready_act;
         ag->early_ready_crit = ag->early_ready_act = nullptr; ag->hoist_req = nullptr;
@@ -1301,6 +1345,7 @@ int32_t rlrep_actor_backward(rlrep_agent* ag, const float* eps, void* stream) {
     const size_t first = (ag->pi_ready && ag->pi_ready == eps) ? (size_t)ag->actor_resume : 0;
     ag->pi_ready = nullptr;
     if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    if (!ag->in_train) { const int rs = refresh_x3(ag, stream); if (rs) return rs; }        // (inside a train() the critic's Adam launch kept the live images current)
     ag->last_launches += (int)(ag->actor_bwd.stages.size() - first);
     return ag->actor_bwd.run((hipStream_t)stream, first);
 }
@@ -1364,7 +1409,11 @@ int32_t rlrep_deferred_part(rlrep_agent* ag, int32_t set, int32_t part, void* st
     const float* e_crit = D.eps; const float* e_act = D.eps + (size_t)ag->B * ag->d.action_dim;
     const float* keep1 = ag->cur_eps; const float* keep2 = ag->cur_eps2;
     int rc = 0;
-    if (part == -1 || part == 0) { ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0; rc = run(ag, D.critic_bwd, stream); }
+    if (part == -1 || part == 0) {
+        ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0;
+        rc = refresh_x3(ag, stream);                 // as in rlrep_critic_backward: on this, the chain with slack
+        if (!rc) rc = run(ag, D.critic_bwd, stream);
+    }
     if (!rc && (part == -1 || part == 1)) rc = run(ag, D.critic_apply, stream);
     if (!rc && (part == -1 || part == 2)) {
         ag->cur_eps = e_act;

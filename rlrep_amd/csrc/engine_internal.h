@@ -59,6 +59,12 @@ struct rlrep_agent {
     std::map<std::string, float*> shadow_of;
     float* PT(const std::string& n) const { auto it = shadow_of.find(n); return it == shadow_of.end() ? nullptr : it->second; }
     bool has_shadows() const { return nsh[0] + nsh[1] + nsh[2] + nsh[3] > 0; }
+    // bf16x3 images of the noise critic's first-layer weights (vlsac; ShadowEnt kind 1): live critic.l1 / l4 are kept current by the critic
+    // group's Adam launch (sh_dev[1]); ALL of x3_refresh (live and target, absolute sources) is regenerated by a launch at the head of the
+    // critic step, which is what serves the target copies and a caller who wrote parameters behind the library's back
+    const ShadowEnt* x3_refresh = nullptr; int x3_n = 0, x3_tiles = 0;
+    std::map<std::string, const unsigned char*> x3_of;
+    const unsigned char* W3(const std::string& n) const { auto it = x3_of.find(n); return it == x3_of.end() ? nullptr : it->second; }
     // cluster row programs (RLREP_ROWPROG=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
     // extra launch before an eager step outside a train())
     int* rp_epoch = nullptr;

@@ -136,6 +136,7 @@ struct NcFwdTask {
     const float* mean; const float* lstd; int ld_ml;
     const float* noise;              // [N, F]
     const float* W; const float* bias;   // [H, F], [H]
+    const unsigned char* W3;         // bf16x3 images of W (ShadowEnt kind 1; nullptr: the kernel splits W itself)
     float* Hm;                       // [B, H]
     float* U;                        // [B*N, H] elu outputs (nullptr: not stored)
     float* sigma_out;                // [B, F] exp(clamp(log_std)) (nullptr: not stored)

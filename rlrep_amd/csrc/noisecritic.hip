@@ -33,10 +33,6 @@ extern __shared__ __attribute__((aligned(16))) float nc_smem[];
 // Instrumented build (tools/exp/nc_timeline.py): thread 0 of every workgroup stamps the shader clock at entry, after the table
 // staging barrier, after the MFMA loop and at exit, plus the 100 MHz wall clock at entry / exit.
 __device__ unsigned long long g_nc_tim[6 * 4096];
-__device__ unsigned long long g_nc_blk[16 * 64];
-extern "C" int rl_nc_blocks_fetch(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_nc_blk), sizeof(unsigned long long) * n);
-}
 extern "C" int rl_nc_timing_fetch(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_nc_tim), sizeof(unsigned long long) * n);
 }
@@ -349,13 +345,24 @@ __global__ __launch_bounds__(512) void nc_fwd_x3_kernel(NcFwdBatch nb) {
     }
     const int aofs = m16 * NX_RSB + kq * 16;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)aofs;
-    struct WReg { f32x4 v[CG][2]; };
-    auto wload = [&](int s, WReg& r) {
-        const int k = 32 * min(s, S - 1);
+    // with bf16x3 images of W (NcFwdTask::W3): v[c][0..2] are the hi / mid / lo fragments themselves, 16 bytes each at
+    // ((3 s + image) H + col) 64 + kq 16; without: v[c][0..1] are eight fp32 values that cstep splits
+    struct WReg { f32x4 v[CG][3]; };
+    const bool w3 = t.W3 != nullptr;
+    const unsigned char* w3row[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) w3row[c] = w3 ? t.W3 + (size_t)min(col[c], H - 1) * 64 + kq * 16 : nullptr;
+    auto wload = [&](int s, WReg& r, auto w3_tag) {
+        const int sc = min(s, S - 1);
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            r.v[c][0] = *reinterpret_cast<const f32x4*>(wrow[c] + k);
-            r.v[c][1] = *reinterpret_cast<const f32x4*>(wrow[c] + k + 4);
+            if (decltype(w3_tag)::value) {
+#pragma unroll
+                for (int img = 0; img < 3; ++img) r.v[c][img] = *reinterpret_cast<const f32x4*>(w3row[c] + ((size_t)(3 * sc + img) * H) * 64);
+            } else {
+                r.v[c][0] = *reinterpret_cast<const f32x4*>(wrow[c] + 32 * sc);
+                r.v[c][1] = *reinterpret_cast<const f32x4*>(wrow[c] + 32 * sc + 4);
+            }
         }
     };
     f32x4 acc[CG][NFR];
@@ -365,14 +372,19 @@ __global__ __launch_bounds__(512) void nc_fwd_x3_kernel(NcFwdBatch nb) {
         for (int f = 0; f < NFR; ++f) acc[c][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     WReg wa, wb;                                            // W fragments of steps s and s + 1; refilled two steps ahead
-    wload(0, wa); wload(1, wb);
+    if (w3) { wload(0, wa, std::true_type{}); wload(1, wb, std::true_type{}); } else { wload(0, wa, std::false_type{}); wload(1, wb, std::false_type{}); }
     __syncthreads();
     NCT(1);
-    auto cstep = [&](int s, WReg& rw) {
+    auto cstep = [&](int s, WReg& rw, auto w3_tag) {
+        constexpr bool W3 = decltype(w3_tag)::value;
         const unsigned aaddr = lds0 + (unsigned)((s & 1) * NX_BUFB);
         u32x4 fa[2][3];
         nx_fload<0>(fa[0], aaddr);
         bf16x8 Bh[CG], Bm[CG], Bl[CG];
+        if (W3) {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) { Bh[c] = __builtin_bit_cast(bf16x8, rw.v[c][0]); Bm[c] = __builtin_bit_cast(bf16x8, rw.v[c][1]); Bl[c] = __builtin_bit_cast(bf16x8, rw.v[c][2]); }
+        } else
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             u32x4 bh, bm, bl;
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(512) void nc_fwd_x3_kernel(NcFwdBatch nb) {
             x3_split2(rw.v[c][1][2], rw.v[c][1][3], h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
             Bh[c] = __builtin_bit_cast(bf16x8, bh); Bm[c] = __builtin_bit_cast(bf16x8, bm); Bl[c] = __builtin_bit_cast(bf16x8, bl);
         }
-        wload(s + 2, rw);
+        wload(s + 2, rw, w3_tag);
 #define NX_FRAG(J)                                                                                                     \
         {                                                                                                              \
             if ((J) + 1 < NFR) nx_fload<((J) + 1 < NFR ? (J) + 1 : 0)>(fa[((J) + 1) & 1], aaddr);                      \
@@ -405,9 +417,16 @@ __global__ __launch_bounds__(512) void nc_fwd_x3_kernel(NcFwdBatch nb) {
 #undef NX_FRAG
         __syncthreads();
     };
-    for (int s = 0; s < S; s += 2) {
-        cstep(s, wa);
-        if (s + 1 < S) cstep(s + 1, wb);
+    if (w3) {
+        for (int s = 0; s < S; s += 2) {
+            cstep(s, wa, std::true_type{});
+            if (s + 1 < S) cstep(s + 1, wb, std::true_type{});
+        }
+    } else {
+        for (int s = 0; s < S; s += 2) {
+            cstep(s, wa, std::false_type{});
+            if (s + 1 < S) cstep(s + 1, wb, std::false_type{});
+        }
     }
     NCT(2);
 
@@ -641,23 +660,18 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     // ---- producer role: thread = (k chunk of 4, batch row, noise group of 5) ----
-    // lane -> batch row: bits 3, 5, 4 of the thread index are bits 0, 1, 2 of pb, so that each half-wave holds the batch rows {0,1,4,5} /
-    // {2,3,6,7}: their image rows start at four different multiples of 16 banks (row stride 80 B, eight lanes x 8 B per row) and a 64-lane
-    // ds_write_b64 is conflict-free.  (With pb = bits 3..5 in order the half-waves held rows whose starts coincided in pairs: SQ_LDS_BANK_CONFLICT
-    // counted 6 cycles per write.)
-    const int kc = tid & 7, pb = ((tid >> 3) & 1) | (((tid >> 5) & 1) << 1) | (((tid >> 4) & 1) << 2), ng = tid >> 6;
+    const int kc = tid & 7, pb = (tid >> 3) & 7, ng = tid >> 6;
     const bool okb = b0 + pb < t.B;
     const int bsrc = min(b0 + pb, t.B - 1);
     const float* const pmu = t.mean + (size_t)bsrc * t.ld_ml + kc * KV;
     const float* const pls = t.lstd + (size_t)bsrc * t.ld_ml + kc * KV;
     const float* const pnz = t.noise + (size_t)(5 * ng) * F + kc * KV;
-    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L;
-    unsigned waddr[5];                                      // LDS byte address of this thread's chunk in buffer 0, per noise row
+    int wofs[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int sig = (pb & 3) * 20 + 5 * ng + i, rem = sig & 15;
         const int lrow = 32 * (sig >> 4) + 8 * (rem >> 2) + 4 * (pb >> 2) + (rem & 3);
-        waddr[i] = lbase + (unsigned)(lrow * NX_RSB + kc * KV * 2);
+        wofs[i] = lrow * NX_RSB + kc * KV * 2;
     }
     float* const sig_dst = (t.sigma_out && th == 0 && ng == 0 && okb) ? t.sigma_out + (size_t)(b0 + pb) * F + kc * KV : nullptr;
 
@@ -666,72 +680,55 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
     const int col = n0 + 32 * w + c32;
     const bool colok = col < H;
     const float* const wrow = t.W + (size_t)min(col, H - 1) * F + 8 * half;
-    const unsigned lds0 = lbase + (unsigned)(c32 * NX_RSB + half * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)(c32 * NX_RSB + half * 16);
 
-    // Table registers in TWO named sets: step s builds the images of step s + 1 from one set while the loads of step s + 2 fill the other,
-    // issued at the start of the step, a whole step ahead of their first use.
-    struct TReg { f32x4 mu, ls, nz[5]; };
-    TReg tra, trb;
-    struct WReg { f32x4 v[2][2]; };                          // the fp32 W fragments of a step: [k block][half of its 8 values]
-    WReg wa, wb;
-    auto gload = [&](int s, TReg& r) {
-        const int k = 32 * min(s, S - 1);                      // past the end: re-read the last step (no branch), never used
-        r.mu = *reinterpret_cast<const f32x4*>(pmu + k);
-        r.ls = *reinterpret_cast<const f32x4*>(pls + k);
+    f32x4 rmu, rls, rnz[5];
+    f32x4 rw[2][2];
+    // with bf16x3 images of W (NcFwdTask::W3, kept by the optimizer launch): the three B fragments of a k block as they are multiplied,
+    // 16 bytes each at ((3 s + image) H + col) 64 + (2 kb + half) 16 -- no split in this kernel (88 of its ~260 VALU instructions per step)
+    u32x4 rb[2][3];
+    const unsigned char* const w3p = t.W3 ? t.W3 + (size_t)min(col, H - 1) * 64 + half * 16 : nullptr;
+    auto gload = [&](int s) {
+        const int k = 32 * s;
+        rmu = *reinterpret_cast<const f32x4*>(pmu + k);
+        rls = *reinterpret_cast<const f32x4*>(pls + k);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) r.nz[i] = *reinterpret_cast<const f32x4*>(pnz + (size_t)i * F + k);
+        for (int i = 0; i < 5; ++i) rnz[i] = *reinterpret_cast<const f32x4*>(pnz + (size_t)i * F + k);
     };
-    auto wload = [&](int s, WReg& r) {
-        const int k = 32 * min(s, S - 1);
+    auto wload = [&](int s, auto w3_tag) {
+        if (decltype(w3_tag)::value) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            r.v[kb][0] = *reinterpret_cast<const f32x4*>(wrow + k + 16 * kb);
-            r.v[kb][1] = *reinterpret_cast<const f32x4*>(wrow + k + 16 * kb + 4);
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int img = 0; img < 3; ++img) rb[kb][img] = *reinterpret_cast<const u32x4*>(w3p + ((size_t)(3 * s + img) * H) * 64 + kb * 32);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                rw[kb][0] = *reinterpret_cast<const f32x4*>(wrow + 32 * s + 16 * kb);
+                rw[kb][1] = *reinterpret_cast<const f32x4*>(wrow + 32 * s + 16 * kb + 4);
+            }
         }
     };
-    float sg[KV], mz[KV];
-    const float okf = okb ? 1.f : 0.f;
-    auto produce_begin = [&](const TReg& r) {
-        // a batch row beyond the batch builds zeros: sigma = mean = 0 (the noise is finite; its source row is a valid, clamped one).  By
-        // multiplication, not by a branch: control flow inside a step lets the IR-level sink pass carry the pure VALU work of the earlier
-        // blocks across it, to just before its first use in the next step -- out of the shadow of the MFMAs it was placed behind.
+    float sg[KV];
+    auto produce_begin = [&]() {
 #pragma unroll
-        for (int q = 0; q < KV; ++q) { sg[q] = __expf(clamp_lstd(r.ls[q])) * okf; mz[q] = r.mu[q] * okf; }
+        for (int q = 0; q < KV; ++q) sg[q] = okb ? __expf(clamp_lstd(rls[q])) : 0.f;
     };
-    // One noise row of the next step's images, in two halves: row_values (pure VALU: placed in the block of fragment MFMAs BEFORE the one that
-    // writes the row, so that it can hide in their shadow -- a matrix instruction of this shape leaves room for ~5 VALU instructions,
-    // tools/exp/mfma_valu.hip) and row_write.  The three 8-byte LDS writes are volatile asm like the fragment reads below: volatile asm
-    // statements keep their program order, so the number of LDS operations issued behind any fragment's reads is known exactly and the claims
-    // can leave all of them in flight.  (As compiler-generated stores they landed between a fragment's reads and the claim of the previous
-    // fragment, whose lgkmcnt(3) then waited for those reads as well: no prefetch on every second fragment, 450 cycles per step.)
-    struct RowV { u32x2 h, m, l; };
-    auto row_values = [&](const TReg& r, int i, RowV& o) {
+    auto produce_row = [&](int i, unsigned char* buf) {
+        u32x2 h, m, l;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float x0 = fmaf(sg[2 * q], r.nz[i][2 * q], mz[2 * q]);
-            const float x1 = fmaf(sg[2 * q + 1], r.nz[i][2 * q + 1], mz[2 * q + 1]);
+            const float x0 = okb ? fmaf(sg[2 * q], rnz[i][2 * q], rmu[2 * q]) : 0.f;
+            const float x1 = okb ? fmaf(sg[2 * q + 1], rnz[i][2 * q + 1], rmu[2 * q + 1]) : 0.f;
             unsigned hh, mm, ll;
             x3_split2(x0, x1, hh, mm, ll);
-            o.h[q] = hh; o.m[q] = mm; o.l[q] = ll;
+            h[q] = hh; m[q] = mm; l[q] = ll;
         }
+        unsigned char* p = buf + wofs[i];
+        *reinterpret_cast<u32x2*>(p) = h;
+        *reinterpret_cast<u32x2*>(p + NX_IMGB) = m;
+        *reinterpret_cast<u32x2*>(p + 2 * NX_IMGB) = l;
     };
-    // the values exist from here on (an empty volatile asm that takes them as operands: nothing volatile moves across it, so the work that
-    // produces them stays in the block it was written in)
-    auto row_pin = [&](RowV& o) { asm volatile("" : "+v"(o.h), "+v"(o.m), "+v"(o.l)); };
-    auto row_write = [&](const RowV& v, int i, unsigned bufoff) {
-        const unsigned p = waddr[i] + bufoff;
-        asm volatile("ds_write_b64 %0, %1" :: "v"(p), "v"(v.h));
-        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(p), "v"(v.m), "n"(NX_IMGB));
-        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(p), "v"(v.l), "n"(2 * NX_IMGB));
-    };
-    // the split W fragments of a step (both k blocks), and a quarter of the split (two of a k block's four element pairs)
-    struct BReg { u32x4 h[2], m[2], l[2]; };
-    auto wsplit_half = [&](const WReg& r, BReg& o, int kb, int hf) {
-        unsigned h, m, l;
-        x3_split2(r.v[kb][hf][0], r.v[kb][hf][1], h, m, l); o.h[kb][2 * hf] = h; o.m[kb][2 * hf] = m; o.l[kb][2 * hf] = l;
-        x3_split2(r.v[kb][hf][2], r.v[kb][hf][3], h, m, l); o.h[kb][2 * hf + 1] = h; o.m[kb][2 * hf + 1] = m; o.l[kb][2 * hf + 1] = l;
-    };
-    auto wsplit_pin = [&](BReg& o, int kb) { asm volatile("" : "+v"(o.h[kb]), "+v"(o.m[kb]), "+v"(o.l[kb])); };
 
     nq_f32x16 acc[5];
 #pragma unroll
@@ -739,70 +736,39 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t5][r] = 0.f;
 
-    // Fragment J = (row tile J / 2, k block J % 2) of a step lives in register set J % 5 and is read TWO fragments ahead of its use (ten
-    // fragments per step: the rotation closes over a step).  Order of the LDS operations of fragment J's block: [writes of noise row J / 2
-    // (J even, 3)] [reads of fragment J + 2 (3)] [claim J].  Issued behind the reads of fragment J, therefore: the writes of block J - 1,
-    // the reads of J + 1, the writes of block J, the reads of J + 2 -- 9 operations in the steady state, which the claim leaves in flight.
-    // Fragment 9: claim, BARRIER (every wave has read the last fragment of this buffer and has written its rows of the next), reads of
-    // fragments 0 and 1 of the next step, and only then the six MFMAs of fragment 9, which hide the barrier skew and that read latency.
-    //
-    // The VALU work of a step rides in the shadow of its MFMAs, a piece per block (all of it is independent of the block's own MFMAs):
-    //   block 0, 2, 4, 6 : a quarter of the split of the NEXT step's W fragments (loaded at the head of the PREVIOUS step) -> Bn
-    //   block 1, 3, 5, 7 : the values of noise row (J + 1) / 2 of the next step's images (written by block J + 1)
-    //   block 8          : sigma / mean of the step after next (its tables were loaded at the head of this step)
-    //   block 9          : the values of row 0 of the step after next (written by block 0 of the next step)
-    u32x4 fa[5][3];
-    RowV rv;
-#ifdef RL_TIMING_NC
-    // per-block shader-clock stamps of the last full step (s_memtime counts on lgkmcnt, out of order with LDS: the claims below only get
-    // stricter by it, never wrong)
-    unsigned long long blk[13];
-#pragma unroll
-    for (int q = 0; q < 13; ++q) blk[q] = 0;
-#define NCB(k) do { if (MORE2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(blk[k])); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define NCB(k) do {} while (0)
-#endif
-    // The LAST step of a regular workgroup (all 8 batch rows and 128 columns valid) also carries the epilogue of the row tiles that are final:
-    // tile t is complete after fragment 2t + 1, so blocks 2t + 2 and 2t + 3 take half of its 16 outputs each (bias, ELU, sum over the noise
-    // axis, the U store) in the shadow of their MFMAs -- the last step builds nothing, its VALU slots are free -- and only tile 4 is left for
-    // after the loop.  EPI: 0 none (generic epilogue below), 1 without U (target heads), 2 with U.
-    float hsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const float bj_epi = t.bias[min(col, H - 1)];
-    float* upb[4];
-#pragma unroll
-    for (int bl = 0; bl < 4; ++bl) upb[bl] = t.U ? t.U + ((size_t)min(b0 + 4 * half + bl, t.B - 1) * N) * H + min(col, H - 1) : nullptr;
-    auto tile_epi = [&](auto epi_tag, int t5, int hf) {
-        constexpr int EPI = decltype(epi_tag)::value;
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-            const int r = 8 * hf + r8, sig = 16 * t5 + r, bl = sig / 20, n = sig - 20 * bl;
-            const float y = elu_fast(acc[t5][r] + bj_epi);
-            hsum[bl] += y;
-            if (EPI == 2) upb[bl][(size_t)n * H] = y;
-        }
-    };
-    auto step = [&](int s, auto more_tag, auto more2_tag, auto buf_tag, auto epi_tag, TReg& cur, TReg& refill, BReg& Bc, BReg& Bn, WReg& wcur, WReg& wrefill) {
-        constexpr bool MORE = decltype(more_tag)::value;          // a step follows: build its images, split its W
-        constexpr bool MORE2 = decltype(more2_tag)::value;        // two steps follow: block 9 prepares row 0 of the step after next
-        constexpr int BUF = decltype(buf_tag)::value;
-        constexpr int EPI = decltype(epi_tag)::value;
-        static_assert(EPI == 0 || !MORE, "the overlapped epilogue belongs to the last step");
-        const unsigned aaddr = lds0 + (unsigned)(BUF * NX_BUFB), naddr = lds0 + (unsigned)((BUF ^ 1) * NX_BUFB);
-        constexpr unsigned nbuf = (unsigned)((BUF ^ 1) * NX_BUFB);
-        if (MORE2) {
-            gload(s + 2, refill); wload(s + 2, wrefill);                // two steps ahead of their use ...
-            asm volatile("" ::: "memory");                              // ... and pinned here: left alone, hipcc sinks the loads next to their first use
-        }
+    // (splitting W one step ahead, a quarter per odd fragment in the shadow of the previous step's MFMAs, measured slower: 28.8k vs 25.5k
+    // cycles for the eight steps)
+    auto step = [&](int s, auto more_tag, auto w3_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        constexpr bool W3 = decltype(w3_tag)::value;
+        const unsigned aaddr = lds0 + (unsigned)((s & 1) * NX_BUFB);
+        unsigned char* const nxt = L + ((s + 1) & 1) * NX_BUFB;
+        u32x4 fa[2][3];
+        nq_fload<0, 0>(fa[0], aaddr);
         bf16x8 Bh[2], Bm[2], Bl[2];
+        if (W3) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { Bh[kb] = __builtin_bit_cast(bf16x8, Bc.h[kb]); Bm[kb] = __builtin_bit_cast(bf16x8, Bc.m[kb]); Bl[kb] = __builtin_bit_cast(bf16x8, Bc.l[kb]); }
-#define NQ_W(J) ((MORE && (J) >= 0 && (J) <= 8 && ((J) & 1) == 0) ? 3 : 0)
-#define NQ_R(J) (((J) < 10) ? 3 : 0)
-#define NQ_MFMA(J)                                                                                                     \
+            for (int kb = 0; kb < 2; ++kb) { Bh[kb] = __builtin_bit_cast(bf16x8, rb[kb][0]); Bm[kb] = __builtin_bit_cast(bf16x8, rb[kb][1]); Bl[kb] = __builtin_bit_cast(bf16x8, rb[kb][2]); }
+        } else
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 bh, bm, bl;
+            unsigned h, m, l;
+            x3_split2(rw[kb][0][0], rw[kb][0][1], h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
+            x3_split2(rw[kb][0][2], rw[kb][0][3], h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
+            x3_split2(rw[kb][1][0], rw[kb][1][1], h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
+            x3_split2(rw[kb][1][2], rw[kb][1][3], h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
+            Bh[kb] = __builtin_bit_cast(bf16x8, bh); Bm[kb] = __builtin_bit_cast(bf16x8, bm); Bl[kb] = __builtin_bit_cast(bf16x8, bl);
+        }
+        if (MORE) { wload(s + 1, w3_tag); produce_begin(); }
+        // fragment J = (tile J / 2, k block J % 2); one noise row of the next step's images per two fragments
+#define NQ_FRAG(J)                                                                                                     \
         {                                                                                                              \
-            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[(J) % 5][0]), Am = __builtin_bit_cast(bf16x8, fa[(J) % 5][1]), \
-                         Al = __builtin_bit_cast(bf16x8, fa[(J) % 5][2]);                                              \
+            if ((J) + 1 < 10) nq_fload<((J) + 1 < 10 ? ((J) + 1) / 2 : 0), ((J) + 1) % 2>(fa[((J) + 1) & 1], aaddr);   \
+            if (MORE && ((J) & 1) == 0) produce_row((J) >> 1, nxt);                                                    \
+            nx_claim<((J) + 1 < 10)>(fa[(J) & 1]);                                                                     \
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fa[(J) & 1][0]), Am = __builtin_bit_cast(bf16x8, fa[(J) & 1][1]), \
+                         Al = __builtin_bit_cast(bf16x8, fa[(J) & 1][2]);                                              \
             nq_f32x16 c = acc[(J) / 2];                                                                                \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[(J) % 2], c, 0, 0, 0);                                  \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[(J) % 2], c, 0, 0, 0);                                  \
@@ -812,95 +778,29 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[(J) % 2], c, 0, 0, 0);                                  \
             acc[(J) / 2] = c;                                                                                          \
         }
-        // one MFMA, then up to four VALU instructions, six times: what hides in a 32-cycle matrix instruction of one wave (mfma_valu.hip)
-#define NQ_PIPE _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
-#define NQ_PIPE_EPI _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
-#define NQ_FRAG(J)                                                                                                     \
-        {                                                                                                              \
-            if (NQ_W(J)) row_write(rv, (J) >> 1, nbuf);                                                                \
-            if ((J) + 2 < 10) nq_fload<((J) + 2 < 10 ? ((J) + 2) / 2 : 0), ((J) + 2) % 2>(fa[((J) + 2) % 5], aaddr);   \
-            nx_claim_n<NQ_W((J) - 1) + NQ_R((J) + 1) + NQ_W(J) + NQ_R((J) + 2)>(fa[(J) % 5]);                          \
-            if (MORE && ((J) & 1) == 1 && (J) <= 7) row_values(cur, ((J) + 1) >> 1, rv);                               \
-            if (MORE && ((J) & 1) == 0 && (J) <= 6) wsplit_half(wcur, Bn, (J) >> 2, ((J) >> 1) & 1);                   \
-            if (MORE2 && (J) == 8) produce_begin(refill);                                                              \
-            if (EPI && (J) >= 2) tile_epi(epi_tag, ((J) - 2) >> 1, (J) & 1);                                           \
-            NQ_MFMA(J)                                                                                                 \
-            if (EPI && (J) >= 2) { NQ_PIPE_EPI }                                                                       \
-            if (MORE && ((J) & 1) == 1 && (J) <= 7) row_pin(rv);                                                       \
-            if (MORE && ((J) & 1) == 0 && (J) <= 6) wsplit_pin(Bn, (J) >> 2);                                          \
-            if (MORE2 && (J) == 8) asm volatile("" : "+v"(sg[0]), "+v"(sg[1]), "+v"(sg[2]), "+v"(sg[3]), "+v"(mz[0]), "+v"(mz[1]), "+v"(mz[2]), "+v"(mz[3])); \
-            if ((MORE && (J) <= 7) || (MORE2 && (J) == 8)) { NQ_PIPE }                                                 \
-            NCB((J) + 1);                                                                                              \
-        }
-        NCB(0);
-        NQ_FRAG(0) NQ_FRAG(1) NQ_FRAG(2) NQ_FRAG(3) NQ_FRAG(4) NQ_FRAG(5) NQ_FRAG(6) NQ_FRAG(7) NQ_FRAG(8)
-        {
-            nx_claim_n<0>(fa[9 % 5]);                           // (lgkmcnt(0): also this thread's writes of the next step's images)
-            NCB(11);
-#ifndef RL_NC_EXP_NOBAR
-            asm volatile("s_barrier" ::: "memory");
-#endif
-            NCB(12);
-            if (MORE) { nq_fload<0, 0>(fa[0], naddr); nq_fload<0, 1>(fa[1], naddr); }
-            if (MORE2) row_values(refill, 0, rv);
-            if (EPI) tile_epi(epi_tag, 3, 1);
-            NQ_MFMA(9)
-            if (EPI) { NQ_PIPE_EPI }
-            if (MORE2) { row_pin(rv); _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0); } }
-            NCB(10);
-        }
+        NQ_FRAG(0) NQ_FRAG(1) NQ_FRAG(2) NQ_FRAG(3) NQ_FRAG(4) NQ_FRAG(5) NQ_FRAG(6) NQ_FRAG(7) NQ_FRAG(8) NQ_FRAG(9)
 #undef NQ_FRAG
-#undef NQ_PIPE_EPI
-#undef NQ_PIPE
-#undef NQ_MFMA
-#undef NQ_R
-#undef NQ_W
+        // (a sched_group_barrier pipeline {1 MFMA, 4-6 VALU} x 60 over this block changed nothing: 22.7-24.5 us against 22.7)
+        if (MORE) gload(min(s + 2, S - 1));
+        __syncthreads();
     };
 
-    // prologue: images of step 0 from the first table set; W fragments of step 0 split; tables of step 1 in the second set, with its
-    // sigma / mean and the values of its row 0 ready for block 0 of step 0
-    BReg ba, bb;
-    gload(0, tra); wload(0, wa);
-    gload(1, trb); wload(1, wb);
-    produce_begin(tra);
+    gload(0);
+    if (w3p) wload(0, std::true_type{}); else wload(0, std::false_type{});
+    produce_begin();
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { row_values(tra, i, rv); row_write(rv, i, 0u); }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wsplit_half(wa, ba, q >> 1, q & 1);
-    if (S > 1) { produce_begin(trb); row_values(trb, 0, rv); }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    nq_fload<0, 0>(fa[0], lds0); nq_fload<0, 1>(fa[1], lds0);
+    for (int i = 0; i < 5; ++i) produce_row(i, L);
+    gload(S > 1 ? 1 : 0);
+    __syncthreads();
     NCT(1);
-    // step s reads buffer s & 1, builds from trb (s even) / tra (s odd) and refills the other set; split W fragments: ba (s even) / bb (s odd);
-    // fp32 W of step s + 1: wb (s even) / wa (s odd), the other set receives step s + 2
-    typedef std::integral_constant<int, 0> B0; typedef std::integral_constant<int, 1> B1;
-    typedef std::integral_constant<int, 0> E0; typedef std::integral_constant<int, 1> E1; typedef std::integral_constant<int, 2> E2;
-    typedef std::true_type T_; typedef std::false_type F_;
-    const bool regular = (b0 + 8 <= t.B) && (n0 + 128 <= H);
-    int epi_done = 0;
-    int s = 0;
-    for (; s + 3 <= S - 1; s += 2) {                           // both steps of the pair have two steps behind them
-        step(s, T_{}, T_{}, B0{}, E0{}, trb, tra, ba, bb, wb, wa);
-        step(s + 1, T_{}, T_{}, B1{}, E0{}, tra, trb, bb, ba, wa, wb);
+    if (w3p) {
+        for (int s = 0; s + 1 < S; ++s) step(s, std::true_type{}, std::true_type{});
+        step(S - 1, std::false_type{}, std::true_type{});
+    } else {
+        for (int s = 0; s + 1 < S; ++s) step(s, std::true_type{}, std::false_type{});
+        step(S - 1, std::false_type{}, std::false_type{});
     }
-    // the tail: 1, 2 or 3 steps left (s even)
-    if (S - s == 3) {
-        step(s, T_{}, T_{}, B0{}, E0{}, trb, tra, ba, bb, wb, wa); step(s + 1, T_{}, F_{}, B1{}, E0{}, tra, trb, bb, ba, wa, wb);
-        step(s + 2, F_{}, F_{}, B0{}, E0{}, trb, tra, ba, bb, wb, wa);
-    } else if (S - s == 2) {
-        step(s, T_{}, F_{}, B0{}, E0{}, trb, tra, ba, bb, wb, wa);
-        // (the usual shape: an even number of steps; the overlapped epilogue exists for this one)
-        if (!regular) step(s + 1, F_{}, F_{}, B1{}, E0{}, tra, trb, bb, ba, wa, wb);
-        else if (t.U) { step(s + 1, F_{}, F_{}, B1{}, E2{}, tra, trb, bb, ba, wa, wb); epi_done = 2; }
-        else { step(s + 1, F_{}, F_{}, B1{}, E1{}, tra, trb, bb, ba, wa, wb); epi_done = 1; }
-    } else step(s, F_{}, F_{}, B0{}, E0{}, trb, tra, ba, bb, wb, wa);
     NCT(2);
-#ifdef RL_TIMING_NC
-    if (lane == 0 && bid < 16) {
-#pragma unroll
-        for (int q = 0; q < 13; ++q) g_nc_blk[16 * (4 * bid + w) + q] = blk[q];
-    }
-#endif
 
     if (sig_dst) {
         for (int s = 0; s < S; ++s) {
@@ -911,19 +811,11 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
             *reinterpret_cast<f32x4*>(sig_dst + 32 * s) = o;
         }
     }
-    const float invN = 1.0f / (float)N;
-    if (epi_done) {
-        // tiles 0-3 went out with the last step: tile 4 and the means are left
-        if (epi_done == 2) { tile_epi(E2{}, 4, 0); tile_epi(E2{}, 4, 1); } else { tile_epi(E1{}, 4, 0); tile_epi(E1{}, 4, 1); }
-#pragma unroll
-        for (int bl = 0; bl < 4; ++bl) t.Hm[(size_t)(b0 + 4 * half + bl) * H + col] = hsum[bl] * invN;
-        NCT(3); NCT(5);
-        return;
-    }
     if (!colok) return;
     // slot sigma = 16 t5 + r of this lane's half: batch row b0 + 4 half + sigma / 20, noise row sigma % 20.  Walked per batch row (static
     // register positions; the row / store guards are four uniform-ish branches, not eighty)
     const float bj = t.bias[col];
+    const float invN = 1.0f / (float)N;
 #pragma unroll
     for (int bl = 0; bl < 4; ++bl) {
         const int b = b0 + 4 * half + bl;
@@ -937,13 +829,11 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
         }
         if (b < t.B) {
             t.Hm[(size_t)b * H + col] = sum * invN;
-#ifndef RL_NC_NOU
             if (t.U) {
                 float* up = t.U + ((size_t)b * N) * H + col;
 #pragma unroll
                 for (int n = 0; n < 20; ++n) up[(size_t)n * H] = y[n];
             }
-#endif
         }
     }
     NCT(3); NCT(5);

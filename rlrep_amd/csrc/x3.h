@@ -23,3 +23,25 @@ __device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsi
     lo = x3_pk(s0, s1);
 }
 
+
+// ---- bf16x3 weight shadows (ShadowEnt kind 1): [F / 32 steps][3 images][rows][4 groups of 8 k][8 bf16] --------------------------------
+__device__ __forceinline__ size_t x3_shadow_off(int rows, int img, int r, int c) {        // byte offset of element (r, c) in image img
+    return ((((size_t)(c >> 5) * 3 + img) * rows + r) * 4 + ((c >> 3) & 3)) * 16 + (size_t)(c & 7) * 2;
+}
+// four consecutive k (c % 4 == 0) of row r
+__device__ __forceinline__ void x3_shadow_store(unsigned char* dst, int rows, int r, int c, const f32x4& v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    x3_split2(v[0], v[1], h0, m0, l0);
+    x3_split2(v[2], v[3], h1, m1, l1);
+    const u32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
+    *reinterpret_cast<u32x2*>(dst + x3_shadow_off(rows, 0, r, c)) = h;
+    *reinterpret_cast<u32x2*>(dst + x3_shadow_off(rows, 1, r, c)) = m;
+    *reinterpret_cast<u32x2*>(dst + x3_shadow_off(rows, 2, r, c)) = l;
+}
+__device__ __forceinline__ void x3_shadow_store1(unsigned char* dst, int rows, int r, int c, float v) {
+    unsigned h, m, l;
+    x3_split2(v, 0.f, h, m, l);
+    *reinterpret_cast<unsigned short*>(dst + x3_shadow_off(rows, 0, r, c)) = (unsigned short)(h & 0xffffu);
+    *reinterpret_cast<unsigned short*>(dst + x3_shadow_off(rows, 1, r, c)) = (unsigned short)(m & 0xffffu);
+    *reinterpret_cast<unsigned short*>(dst + x3_shadow_off(rows, 2, r, c)) = (unsigned short)(l & 0xffffu);
+}

@@ -277,6 +277,40 @@ def test_row_program_shadows_follow_external_parameter_writes(monkeypatch):
         assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (k, info[k], v)
 
 
+def test_noise_critic_weight_images_follow_external_parameter_writes():
+    """vlsac at the headline dims runs its noise critic from bf16x3 images of critic.l1 / l4 and of their target copies (ShadowEnt kind 1).
+    The live images are kept by the critic group's Adam launch and ALL of them are regenerated at the head of every critic step: parameters
+    and targets overwritten by the caller between calls are what the next critic and actor steps use."""
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    c = Case('vlsac_hc')
+    agent, buf = _default_agent(c), _buffer(c)
+    agent.train(buf, c.B)
+    agent.flush()
+    agent.core.load_state(c.init)                                 # parameters AND targets back to the fixture's, behind the library's back
+    agent.core.exp_avg.zero_(); agent.core.exp_avg_sq.zero_()
+    agent.core.group_cfg()[:, 0] = 0
+    agent.core.alpha_state[1:] = 0
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    rs = np.random.RandomState(5)
+    idx = rs.randint(0, c.meta['replay_n'], size=c.B)
+    batch = buf.gather(torch.as_tensor(idx, device='cuda'))
+    obatch = gather_batch(c.replay, idx)
+    for step in ('critic_step', 'update_actor_and_alpha'):
+        eps = rs.standard_normal((c.B, c.A)).astype(np.float32)
+        info = getattr(agent, step)(batch, eps=torch.as_tensor(eps, device='cuda'))
+        oinfo = getattr(o, step)(obatch, torch.as_tensor(eps))
+        for k, v in oinfo.items():
+            assert abs(float(info[k]) - v) <= 1e-4 * max(abs(v), 1e-2), (step, k, float(info[k]), v)
+
+
+def test_noise_critic_without_weight_images(monkeypatch):
+    """RLREP_NC_SHADOWS=0: the round-1 form (every noise-critic workgroup splits its W fragments itself) stays available and correct."""
+    monkeypatch.setenv('RLREP_NC_SHADOWS', '0')
+    worst = _check_against_oracle(Case('vlsac_hc'), calls=3, expect_pipeline=True)
+    print(f'vlsac_hc without weight images vs oracle: worst param rel-L2 {worst:.2e}')
+
+
 @pytest.mark.parametrize('name', ['vlsac_tiny_noft', 'ctrlsac_tiny_noft', 'spedersac_tiny_noft'])
 def test_default_mode_without_feature_target(name):
     """use_feature_target=False in the default (graph, pipelined) mode: vlsac's deferred critic / actor chain then runs against a snapshot

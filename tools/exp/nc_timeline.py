@@ -45,19 +45,3 @@ for name, a, b in (('staging', 0, 1), ('mfma loop', 1, 2), ('epilogue', 2, 3), (
     print('%-10s cycles: median %8.0f  p10 %8.0f  p90 %8.0f' % (name, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 dur = (t[:, 5] - t[:, 4]) / 100.0
 print('per-workgroup wall duration: median %.2f us, min %.2f, max %.2f; implied clock %.0f MHz' % (np.median(dur), dur.min(), dur.max(), np.median((t[:, 3] - t[:, 0]) / dur)))
-
-if hasattr(_lib.lib, 'rl_nc_blocks_fetch'):
-    nb = 16 * 64
-    hb = (C.c_ulonglong * nb)()
-    _lib.lib.rl_nc_blocks_fetch.argtypes = [C.c_void_p, C.c_int]
-    if _lib.lib.rl_nc_blocks_fetch(hb, nb) == 0:
-        b = np.array(hb, dtype=np.float64).reshape(16, 4, 16)        # [workgroup][wave][stamp]
-        if b[:, :, 0].min() > 0:
-            print('nc_fwd_x3q, last full step, shader cycles (median over 16 workgroups), per wave:')
-            for wv in range(4):
-                x = b[:, wv, :]
-                d = np.diff(x[:, :10], axis=1)
-                print('  wave %d: blocks 0-8: ' % wv + ' '.join('%4.0f' % np.median(d[:, j]) for j in range(9)) +
-                      '   claim 9: %4.0f  barrier: %4.0f  after: %4.0f   step %.0f   start vs wave 0: %+.0f' % (
-                          np.median(x[:, 11] - x[:, 9]), np.median(x[:, 12] - x[:, 11]), np.median(x[:, 10] - x[:, 12]), np.median(x[:, 10] - x[:, 0]),
-                          np.median(x[:, 0] - b[:, 0, 0])))
