@@ -56,7 +56,7 @@ REPLAY_N = 65536
 # HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r02_pmc_summary.json (same in r01; nc_fwd_x3q_kernel:
 # FETCH_SIZE 3279.0 KB raw, x2 for 16-byte reads on gfx950, + WRITE_SIZE 11520.0 KB): 18.5 MB against 11.0 MB algorithmic (10.5 MB of
 # ELU outputs written + tables and weights read once; every XCD's L2 fetches its own copy of the 1 MB of weights)
-NC_FWD_TRAFFIC_BYTES = int((2 * 3279.0 + 11520.0) * 1024)
+NC_FWD_TRAFFIC_BYTES = int((2 * 4305.5 + 11520.0) * 1024)        # r02 with the bf16x3 weight images (3 x 2 bytes per weight instead of 4): r01 was 2 * 3279.0 + 11520.0
 
 
 class Space:

@@ -19,7 +19,10 @@ CSRC = os.path.join(ROOT, 'rlrep_amd', 'csrc')
 def _files_with_asm_loads():
     out = []
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith('.hip') and 'asm volatile("global_load' in open(os.path.join(CSRC, f)).read():
+        if not f.endswith('.hip'):
+            continue
+        src = open(os.path.join(CSRC, f)).read()
+        if 'asm volatile("global_load' in src or 'asm volatile("ds_read' in src:
             out.append(f)
     return out
 
@@ -62,3 +65,32 @@ def test_guard_follows_the_back_edge_of_a_loop():
         '\ts_endpgm', '.Lfunc_end0:'])
     bad = check_async_asm.scan(asm)
     assert [b[0] for b in bad] == [3], bad
+
+
+def test_guard_covers_lds_reads_claimed_by_lgkmcnt():
+    asm = '\n'.join([
+        'k:',
+        '\t;;#ASMSTART', '\tds_read_b128 v[4:7], v0 offset:0', '\t;;#ASMEND',
+        '\t;;#ASMSTART', '\tds_read_b128 v[8:11], v0 offset:64', '\t;;#ASMEND',
+        '\t;;#ASMSTART', '\ts_waitcnt lgkmcnt(1)', '\t;;#ASMEND',
+        '\tv_add_f32_e32 v12, v4, v5',           # claimed (the older read)
+        '\tv_add_f32_e32 v13, v8, v9',           # NOT claimed: one read may still be in flight
+        '\ts_waitcnt lgkmcnt(0)',
+        '\tv_add_f32_e32 v13, v8, v9',
+        '\ts_endpgm', '.Lfunc_end0:'])
+    bad = check_async_asm.scan(asm)
+    assert [b[0] for b in bad] == [12], bad
+
+
+def test_scalar_loads_in_flight_make_partial_lgkm_waits_claim_nothing():
+    asm = '\n'.join([
+        'k:',
+        '\t;;#ASMSTART', '\tds_read_b128 v[4:7], v0 offset:0', '\t;;#ASMEND',
+        '\ts_load_dwordx2 s[0:1], s[4:5], 0x0',
+        '\t;;#ASMSTART', '\tds_read_b128 v[8:11], v0 offset:64', '\t;;#ASMEND',
+        '\ts_waitcnt lgkmcnt(1)',                # the scalar load may be the one that returned
+        '\tv_add_f32_e32 v12, v4, v5',
+        '\ts_waitcnt lgkmcnt(0)',
+        '\ts_endpgm', '.Lfunc_end0:'])
+    bad = check_async_asm.scan(asm)
+    assert [b[0] for b in bad] == [10], bad

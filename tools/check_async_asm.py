@@ -2,7 +2,8 @@
 """Guard for the inline-asm prefetch loads of rowprog.hip.
 
 rp_gemm's dX inner loop issues its weight loads as `asm volatile("global_load_dwordx4 ...")` and claims them with explicit
-`s_waitcnt vmcnt(8)` (the compiler's own wait-count pass drains the prefetch at the loop head otherwise).  The compiler does
+`s_waitcnt vmcnt(8)` (the compiler's own wait-count pass drains the prefetch at the loop head otherwise).  The noise-critic
+kernels read their LDS fragments the same way (`asm volatile("ds_read_b128 ...")` claimed by `s_waitcnt lgkmcnt(n)`).  The compiler does
 not know that such a load is still in flight: it is free to copy, reuse or spill the destination registers before the wait.  This script
 compiles the file to gfx950 assembly and runs a forward data flow over each kernel's control-flow graph: on no path from an asm load to the
 s_waitcnt that claims it may another instruction name one of its destination registers.  (vmcnt returns in order, so `s_waitcnt vmcnt(n)` claims every load but the n youngest.)
@@ -62,39 +63,64 @@ def _blocks(lines):
     return blocks
 
 
-_LOAD = re.compile(r'^(global_load|buffer_load|flat_load|scratch_load|global_atomic\w*_rtn)')
+_VLOAD = re.compile(r'^(global_load|buffer_load|flat_load|scratch_load|global_atomic\w*_rtn)')
+_DS = re.compile(r'^ds_')
+_SMEM = re.compile(r'^(s_load|s_buffer_load|s_memtime|s_memrealtime|s_dcache)')
+
+
+def _dest(t):
+    m = re.match(r'\S+\s+v(?:\[(\d+):(\d+)\]|(\d+))', t)
+    if not m:
+        return set()
+    lo, hi = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
+    return set(range(lo, hi + 1))
 
 
 def _transfer(block, state, bad):
-    """state: the vector-memory loads in flight, oldest first, as a tuple of frozensets of the registers an ASM load will still write (empty
-    for the compiler's own loads, which it tracks itself).  Loads return in order, so `s_waitcnt vmcnt(n)` leaves the n youngest in flight.
-    Stores are ignored: they share the counter but may retire out of order with loads, so ignoring them is the conservative reading."""
-    q = list(state)
+    """state = (vm, lgkm): the operations in flight on the two counters, oldest first, each a frozenset of the registers an ASM load will
+    still write (empty for everything the compiler tracks itself).
+      vmcnt  : vector-memory loads return in order, so `s_waitcnt vmcnt(n)` leaves the n youngest in flight.  Stores share the counter
+               but may retire out of order with loads: ignoring them is the conservative reading.
+      lgkmcnt: LDS operations (reads AND writes) complete in order among themselves; scalar-memory operations share the counter and
+               return out of order, so while one is in flight only lgkmcnt(0) is taken to claim anything.
+    """
+    vm, lg = list(state[0]), list(state[1])
+    smem = state[2]
     for ln, t, inasm in block['ins']:
-        if t.startswith('s_waitcnt') and 'vmcnt' in t:
-            n = int(re.search(r'vmcnt\((\d+)\)', t).group(1))
-            q = q[len(q) - n:] if n else []
+        if t.startswith('s_waitcnt'):
+            m = re.search(r'vmcnt\((\d+)\)', t)
+            if m:
+                n = int(m.group(1))
+                vm = vm[len(vm) - n:] if n else []
+            m = re.search(r'lgkmcnt\((\d+)\)', t)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    lg, smem = [], 0
+                elif not smem:
+                    lg = lg[len(lg) - n:]
             continue
-        if _LOAD.match(t):
-            dest = set()
-            m = re.match(r'\S+\s+v(?:\[(\d+):(\d+)\]|(\d+))', t)
-            if inasm and m:
-                lo, hi = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
-                dest = set(range(lo, hi + 1))
-            # the address registers of this very instruction may not be in flight either
-            inflight = set().union(*q) if q else set()
-            hit = (_regs(t) - dest) & inflight if inasm else _regs(t) & inflight
+        inflight = (set().union(*vm) if vm else set()) | (set().union(*lg) if lg else set())
+        if _VLOAD.match(t) or _DS.match(t):
+            is_ds = bool(_DS.match(t))
+            dest = _dest(t) if (inasm and (not is_ds or 'read' in t)) else set()
+            hit = (_regs(t) - dest) & inflight
             if hit and bad is not None:
                 bad.add((ln, t, tuple(sorted(hit))))
-            q.append(frozenset(dest))
+            (lg if is_ds else vm).append(frozenset(dest))
             continue
-        if q:
-            hit = _regs(t) & set().union(*q)
+        if _SMEM.match(t):
+            smem = 1
+            continue
+        if inflight:
+            hit = _regs(t) & inflight
             if hit and bad is not None:
                 bad.add((ln, t, tuple(sorted(hit))))
-    while q and not q[0]:
-        q.pop(0)
-    return tuple(q[-64:])
+    while vm and not vm[0]:
+        vm.pop(0)
+    while lg and not lg[0]:
+        lg.pop(0)
+    return (tuple(vm[-64:]), tuple(lg[-64:]), smem if lg else 0)
 
 
 def scan(asm_text):
@@ -118,7 +144,7 @@ def scan(asm_text):
             if b['fall'] and k + 1 < len(blocks):
                 s_.append(k + 1)
             succ.append(s_)
-        seen, work = set(), [(0, ())]
+        seen, work = set(), [(0, ((), (), 0))]
         while work:
             k, st = work.pop()
             if (k, st) in seen:
