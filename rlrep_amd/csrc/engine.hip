@@ -320,7 +320,11 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     float* GEH = ws.f((size_t)B * 2 * F); float* GFH = ws.f((size_t)B * 2 * F);
     float* GH2e = ws.f((size_t)B * Hv); float* GH1e = ws.f((size_t)B * Hv);
     float* GH2f = ws.f((size_t)B * Hv); float* GH1f = ws.f((size_t)B * Hv);
-    const int nblk_kl = (int)(((long long)B * F + 255) / 256), nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
+    // the Gaussian heads of encoder and f and vae_mid as ONE launch (heads_vae_kernel: a 16 x 16 tile per workgroup, one KL partial each);
+    // RLREP_FUSE_VAEMID=0 keeps the heads launch + vae_mid_kernel (256 elements and one partial per block)
+    const bool fuse_vm = !(getenv("RLREP_FUSE_VAEMID") && getenv("RLREP_FUSE_VAEMID")[0] == '0');
+    const int tiles_vm = ((B + 15) / 16) * ((F + 15) / 16);
+    const int nblk_kl = fuse_vm ? tiles_vm : (int)(((long long)B * F + 255) / 256), nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
     float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse);
     // actor buffers are needed by the feature program variant that carries the policy forwards
     ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
@@ -561,8 +565,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         if (early) {
             b.fwd_stage(p, {te[0], tf[0], actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "enc.l1 f.l1 actor.l1(s') actor.l1(s)");
             b.fwd_stage(p, {te[1], tf[1], actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi)}, "enc.l2 f.l2 actor.l2 x2");
-            b.fwd_stage(p, {te[2], tf[2], policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
-                        "enc.heads f.heads actor.head x2 + policy");
+            if (!fuse_vm)
+                b.fwd_stage(p, {te[2], tf[2], policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
+                            "enc.heads f.heads actor.head x2 + policy");
         } else {
             // the first layers ride in the second layers' launch when their transposed shadows exist (one launch less per feature step)
             const bool have_t = ag->shadow_of.count("encoder.l1.weight") && ag->shadow_of.count("f.l1.weight");
@@ -570,14 +575,28 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                 b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
                 b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
             }
-            b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
+            if (!fuse_vm) b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
         }
         if (!use_rp) {
+        if (fuse_vm) {
+            HeadsVae hv; memset(&hv, 0, sizeof(hv));
+            hv.Ae = ge.H2; hv.Af = gf.H2; hv.lda = Hv; hv.We = Pw("encoder.mean_linear.weight"); hv.be = Pw("encoder.mean_linear.bias");
+            hv.Wf = Pw("f.mean_linear.weight"); hv.bf = Pw("f.mean_linear.bias");
+            hv.Z = Z; hv.EZ = EZ; hv.GEH = GEH; hv.GFH = GFH; hv.partial = part_kl; hv.EH = nullptr; hv.FH = nullptr;       // (nothing downstream of vae_mid reads the heads themselves)
+            hv.B = B; hv.F = F; hv.K = Hv; hv.tiles_c = (F + 15) / 16; hv.scale = ag->inv_batch() / (float)F; hv.step = ag->adam_step + 0;
+            p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = ag->cur_eps; return rl_launch_heads_vae(&q, st); }, "enc.heads f.heads + vae_mid"});
+        } else {
         VaeMid vm; memset(&vm, 0, sizeof(vm));
         vm.EH = ge.HH; vm.FH = gf.HH; vm.Z = Z; vm.GEH = GEH; vm.GFH = GFH; vm.partial = part_kl;
         vm.B = B; vm.F = F; vm.nblk = nblk_kl; vm.scale = ag->inv_batch() / (float)F; vm.step = ag->adam_step + 0;
         vm.EZ = EZ;
         p.stages.push_back({[=](hipStream_t st) { VaeMid q = vm; q.eps = ag->cur_eps; return rl_launch_vae_mid(&q, st); }, "vae_mid"});
+        }
+        if (early && fuse_vm)       // the two policy heads of the early variant ride with the next forward launch instead of the heads launch
+            b.fwd_stage(p, {Builder::fwd(Z, F, B, F, Pw("decoder.l1.weight"), F, Pw("decoder.l1.bias"), Hv, D1, Hv, ACT_RELU),
+                            policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
+                        "dec.l1 actor.head x2 + policy");
+        else
         b.fwd_stage(p, {Builder::fwd(Z, F, B, F, Pw("decoder.l1.weight"), F, Pw("decoder.l1.bias"), Hv, D1, Hv, ACT_RELU)}, "dec.l1");
         {
             // decoder heads with the 0.5*mse loss fused into the epilogue: the launch writes d loss / d[s_hat | r_hat]

@@ -53,6 +53,17 @@ struct VaeMid {
     int B, F, nblk; float scale; GroupCfg* step;
 };
 
+// the Gaussian heads of encoder and f AND vae_mid in one launch (elementwise.hip heads_vae_kernel): tile = 16 rows x 16 feature columns
+struct HeadsVae {
+    const float* Ae; const float* Af; int lda;            // encoder / f trunk outputs [B, K]
+    const float* We; const float* be;                     // encoder heads [2F, K] (mean rows, then log_std rows), bias [2F]
+    const float* Wf; const float* bf;
+    const float* eps;                                      // [B, F]
+    float* Z; float* EZ; float* GEH; float* GFH; float* partial;
+    float* EH; float* FH;                                  // the heads themselves [B, 2F] (nullable: nothing downstream reads them)
+    int B, F, K, tiles_c; float scale; GroupCfg* step;
+};
+
 struct VaeMse {
     const float* DH; const float* s2; int ld_s2; const float* r;
     float* GDH; float* partial; int B, S, nblk; float scale_s, scale_r;
