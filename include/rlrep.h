@@ -278,6 +278,13 @@ int32_t rlrep_feature_backward_part(rlrep_agent* agent, int32_t part, const floa
  * after deferred(t).  There are two sets, so with set = t & 1 a snapshot only waits for the pair of train(t-2). */
 int32_t rlrep_defer_supported(rlrep_agent* agent);          /* number of snapshot sets (2) or 0 */
 int32_t rlrep_defer_snapshot(rlrep_agent* agent, int32_t set, const float* eps_critic_dev, const float* eps_actor_dev, void* stream);
+/* Folded form: called BEFORE the last feature step of train(t), rlrep_defer_arm makes that step's optimizer launch (rlrep_feature_apply)
+ * write snapshot set `set` as well -- the minibatch slices, noise and step counter by extra blocks, the f_target block by the lanes that
+ * produce its new values -- and the rlrep_defer_snapshot that follows with the same arguments launches nothing (one dependent launch
+ * less on the chain that bounds vlsac's train(): agent/vlsac/vlsac_agent.py:245-273 has no counterpart, it is a scheduling device).
+ * The caller's ordering duties move accordingly: the set must be free when that LAST feature step is issued.  Returns 1 if armed, 0 if
+ * the agent / configuration has no folded form (then rlrep_defer_snapshot copies as before). */
+int32_t rlrep_defer_arm(rlrep_agent* agent, int32_t set, const float* eps_critic_dev, const float* eps_actor_dev);
 int32_t rlrep_deferred_critic_actor(rlrep_agent* agent, int32_t set, void* stream);
 /* The same in four parts for data-parallel callers (all-reduce of the critic / actor gradient slices after parts 0 and 2):
  * 0 critic backward, 1 critic apply (+ period-gated critic-target Polyak), 2 actor backward, 3 actor + temperature apply. */

@@ -111,6 +111,7 @@ def _load():
         'rlrep_feature_backward_part': (i32, [vp, i32, vp, vp, vp]),
         'rlrep_defer_supported': (i32, [vp]),
         'rlrep_defer_snapshot': (i32, [vp, i32, vp, vp, vp]),
+        'rlrep_defer_arm': (i32, [vp, i32, vp, vp]),
         'rlrep_deferred_critic_actor': (i32, [vp, i32, vp]),
         'rlrep_deferred_part': (i32, [vp, i32, i32, vp]),
         'rlrep_end_train': (i32, [vp]),

@@ -556,12 +556,16 @@ class SACAgent(object):
     # from 71 launches to max(48 feature, 25 critic+actor).  Every parameter sees exactly the updates, in exactly the order, of
     # the sequential train(); `flush()` (called by everything that looks at the critic / actor: select_action, checkpoints,
     # reading a returned info dict, the eager step methods) runs the one pending critic+actor pair.
-    def _feature_part(self, buffer, B):
+    def _feature_part(self, buffer, B, snap_set=None):
         self._pool = None
         self._next_key = {}
         self._fill_pools(buffer, B, True)           # rlrep_train_prologue: steps += 1, pools, first gather
         self._early_key = None                      # both policy forwards belong to the deferred branch
-        for i in range(self._feature_iters()):
+        n = self._feature_iters()
+        for i in range(n):
+            if snap_set is not None and i == n - 1:
+                # the snapshot for the deferred critic / actor chain rides in this last step's optimizer launch (rlrep_defer_arm)
+                self.core.defer_arm(self._pool['eps_crit'], self._pool['eps_act'], snap_set)
             self._feature_once(buffer, B, i, True)
         return self._pool['eps_crit'], self._pool['eps_act']
 
@@ -630,7 +634,7 @@ class SACAgent(object):
                 for k in range(2):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
-                        ec, ea = self._feature_part(buffer, B)
+                        ec, ea = self._feature_part(buffer, B, snap_set=k)
                         c.defer_snapshot(ec, ea, k)
                         c.end_train()
                     fs.append(g)

@@ -267,6 +267,11 @@ class HipCore:
     def defer_snapshot(self, eps_critic, eps_actor, set=0):
         check(lib.rlrep_defer_snapshot(self.h, int(set), _ptr(eps_critic), _ptr(eps_actor), _stream()), 'defer_snapshot')
 
+    def defer_arm(self, eps_critic, eps_actor, set=0):
+        """Before the LAST feature step of a train(): that step's optimizer launch also writes snapshot set `set` (rlrep_defer_arm);
+        the defer_snapshot that follows with the same arguments launches nothing.  False: no folded form for this agent."""
+        return lib.rlrep_defer_arm(self.h, int(set), _ptr(eps_critic), _ptr(eps_actor)) == 1
+
     def deferred_critic_actor(self, set=0):
         check(lib.rlrep_deferred_critic_actor(self.h, int(set), _stream()), 'deferred_critic_actor')
 

@@ -444,11 +444,26 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
 // fused multi-tensor Adam (+ Polyak of a sub-range) + metric finalisation + temperature update
 // torch/optim/adam.py::_single_tensor_adam operation order; SURVEY Appendix A.11/A.12
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void copy_segs_body(const CopySegs& p, int blk, int nblk) {
+    const long long total = p.end[p.n - 1];
+    for (long long e = (long long)blk * 256 + threadIdx.x; e < total; e += (long long)nblk * 256) {
+        int q = 0;
+#pragma unroll
+        for (int k = 0; k < COPY_MAX_SEGS - 1; ++k) if (k < p.n - 1 && e >= p.end[k]) q = k + 1;
+        const long long base = q ? p.end[q - 1] : 0;
+        p.dst[q][e - base] = p.src[q][e - base];
+    }
+    if (blk == 0 && threadIdx.x == 0 && p.isrc) *p.idst = *p.isrc;
+}
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
                                                    const PolyakTask* __restrict__ pol, int npol,
-                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks) {
+                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, AdamSnap snap, int snap_blocks) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const int bid = blockIdx.x;
+    if (bid > adam_blocks + fill_blocks) {       // the small segments of a folded snapshot (AdamSnap)
+        copy_segs_body(snap.segs, bid - adam_blocks - fill_blocks - 1, snap_blocks);
+        return;
+    }
     if (bid > adam_blocks) {
         // rlrep_prefetch_batch: the gather of the NEXT minibatch rides here (the step that owned the slot has finished
         // reading it: its weight-gradient launch precedes this one)
@@ -490,6 +505,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
         }
         *reinterpret_cast<f32x4*>(t.p + i) = p4; *reinterpret_cast<f32x4*>(t.m + i) = m4; *reinterpret_cast<f32x4*>(t.v + i) = v4;
         if (pol) *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off)) = t4;
+        if (snap.on && ti == 0 && i >= snap.off && i < snap.off + snap.n) {        // folded snapshot: the new values, as the deferred chain will read them
+            if (snap.which == 0) *reinterpret_cast<f32x4*>(snap.block + (i - snap.off)) = p4;
+            else *reinterpret_cast<f32x4*>(snap.block + (i - snap.off)) = pol ? t4 : *reinterpret_cast<const f32x4*>(t.target + (i - t.pol_off));
+        }
         if (t.sh) {
             // keep the transposed shadows of the weight matrices current (4 scattered 4-byte stores; tensors start on multiples of 4 floats,
             // so the four elements belong to one tensor or to alignment padding)
@@ -520,6 +539,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
             const long long e = i + s;
             float* tp = (pol_on && e >= t.pol_off && e < t.pol_off + t.pol_n) ? t.target + (e - t.pol_off) : nullptr;
             adam_elem(sc, t.g[e], t.p + e, t.m + e, t.v + e, tp);
+            if (snap.on && ti == 0 && e >= snap.off && e < snap.off + snap.n) snap.block[e - snap.off] = snap.which == 0 ? t.p[e] : t.target[e - t.pol_off];
             for (int q = 0; t.sh && q < t.nsh; ++q) {
                 const ShadowEnt se = t.sh[q];
                 if (e < se.off || e >= se.off + se.n) continue;
@@ -564,15 +584,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src
 // segments laid end to end: element e of the concatenation belongs to the first segment whose end > e
 __global__ __launch_bounds__(256) void copy_segs_kernel(CopySegs p) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
-    const long long total = p.end[p.n - 1];
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        int q = 0;
-#pragma unroll
-        for (int k = 0; k < COPY_MAX_SEGS - 1; ++k) if (k < p.n - 1 && e >= p.end[k]) q = k + 1;
-        const long long base = q ? p.end[q - 1] : 0;
-        p.dst[q][e - base] = p.src[q][e - base];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.isrc) *p.idst = *p.isrc;
+    copy_segs_body(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,11 +639,13 @@ extern "C" int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st) {
     hipLaunchKernelGGL(qhead_actor_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
-extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, hipStream_t st) {
+extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const AdamSnap* snap, hipStream_t st) {
     SlotFill none = SlotFill();
+    AdamSnap nosnap = AdamSnap();
     const int fb = sf ? grid_for((long long)sf->B * (2 * sf->S + sf->A + 2), 256, 2048) : 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb), dim3(256), 0, st, tasks, ntasks, adam_blocks,
-                       (const PolyakTask*)nullptr, 0, fin, nfin, sf ? *sf : none, fb);
+    const int sb = (snap && snap->on && snap->segs.n > 0) ? grid_for(snap->segs.end[snap->segs.n - 1], 256, 256) : 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + sb), dim3(256), 0, st, tasks, ntasks, adam_blocks,
+                       (const PolyakTask*)nullptr, 0, fin, nfin, sf ? *sf : none, fb, snap ? *snap : nosnap, sb);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st) {

@@ -849,6 +849,14 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         float* fbase = nft ? ag->a.param_dev : ag->a.target_dev;          // the snapshot is of whichever copy the two steps read
         const Slot keep = defer_begin(b, ag, set, nft ? "f." : "f_target.", nft ? "f.l1.weight" : "f_target.l1.weight", fbase ? fbase + f0.off : nullptr,
                                       fl.off + fl.rows - f0.off);
+        {
+            // the same block as the feature group's optimizer launch produces it (rlrep_defer_arm): the live f's range of the group, or the
+            // range its Polyak writes into f_target (both start at f.l1.weight's offset in the group)
+            rlrep_agent::DeferSet& D = ag->dset[set];
+            const LT& p0 = ag->L.get("f.l1.weight");
+            D.block_off = p0.off - ag->L.group_off[0]; D.block_n = fl.off + fl.rows - f0.off; D.block_which = nft ? 0 : 1;
+            if (getenv("RLREP_NO_FOLD_SNAPSHOT") || ag->h.world_size > 1 || b.fused()) D.block_which = -1;
+        }
         critic_program(ag->dset[set].critic_bwd, can_hoist ? 1 : 0);
         actor_program(ag->dset[set].actor_bwd, ag->dset[set].actor_resume);
         if (!can_hoist) ag->dset[set].actor_resume = 0;
@@ -1404,6 +1412,18 @@ int32_t rlrep_defer_supported(rlrep_agent* ag) {
     for (int k = 0; k < 2; ++k) if (!ag->dset[k].critic_bwd.stages.empty() && !ag->dset[k].actor_bwd.stages.empty()) ++n;
     return n == 2 ? 2 : 0;
 }
+// Arm the folded snapshot: the NEXT feature optimizer launch (rlrep_feature_apply) also writes snapshot set `set` -- the minibatch slices
+// and the two noise blocks by extra blocks, the f_target (or live f) block by the lanes that produce its new values -- and the
+// rlrep_defer_snapshot that follows with the same arguments launches nothing.  To be called before the LAST feature step of a train().
+// Returns 1 if armed, 0 if this agent / configuration has no folded form (the caller proceeds as before).
+int32_t rlrep_defer_arm(rlrep_agent* ag, int32_t set, const float* eps_critic, const float* eps_actor) {
+    if (!ag || set < 0 || set > 1) return 0;
+    ag->snap_armed = false; ag->snap_done = -1;
+    if (!eps_critic || !eps_actor || !rlrep_defer_supported(ag) || ag->dset[set].block_which < 0 || !ag->dset[set].block) return 0;
+    if (!ag->sync_prog.stages.empty()) return 0;
+    ag->snap_armed = true; ag->snap_set = set; ag->snap_ec = eps_critic; ag->snap_ea = eps_actor;
+    return 1;
+}
 int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_critic, const float* eps_actor, void* stream) {
     if (!ag || !eps_critic || !eps_actor || set < 0 || set > 1) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
     if (!rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
@@ -1412,6 +1432,12 @@ int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_crit
         const int rs = ag->sync_prog.run((hipStream_t)stream);
         if (rs) return rs;
     }
+    if (ag->snap_done == set && ag->snap_ec == eps_critic && ag->snap_ea == eps_actor) {      // the last feature optimizer launch already wrote this set
+        ag->snap_done = -1; ag->snap_armed = false;
+        ag->dset[set].valid = true;
+        return 0;
+    }
+    ag->snap_done = -1; ag->snap_armed = false;
     CopySegs cs = ag->dset[set].segs;
     cs.src[cs.n - 2] = eps_critic; cs.src[cs.n - 1] = eps_actor;
     const int rc = (++g_rl_launches, rl_launch_copy_segs(&cs, (hipStream_t)stream));

@@ -42,6 +42,7 @@ struct rlrep_agent {
     // pair of train(t) -- only for that of train(t-1), which is long finished.
     struct DeferSet {
         Slot slot; float* block = nullptr; float* eps = nullptr; int* steps = nullptr; CopySegs segs;
+        long long block_off = 0, block_n = 0; int block_which = -1;        // the block as the feature optimizer launch sees it (-1: no folded snapshot)
         Program critic_bwd, critic_apply, actor_bwd; int actor_resume = 0; bool valid = false;
     };
     DeferSet dset[2]; int dcur = 0;             // dcur: the set the programs under construction belong to
@@ -62,6 +63,8 @@ struct rlrep_agent {
     // bf16x3 images of the noise critic's first-layer weights (vlsac; ShadowEnt kind 1): live critic.l1 / l4 are kept current by the critic
     // group's Adam launch (sh_dev[1]); ALL of x3_refresh (live and target, absolute sources) is regenerated by a launch at the head of the
     // critic step, which is what serves the target copies and a caller who wrote parameters behind the library's back
+    // folded snapshot (rlrep_defer_arm): the next feature optimizer launch also writes snapshot set snap_set; snap_done = the set it wrote
+    bool snap_armed = false; int snap_set = -1, snap_done = -1; const float* snap_ec = nullptr; const float* snap_ea = nullptr;
     const ShadowEnt* x3_refresh = nullptr; int x3_n = 0, x3_tiles = 0;
     std::map<std::string, const unsigned char*> x3_of;
     const unsigned char* W3(const std::string& n) const { auto it = x3_of.find(n); return it == x3_of.end() ? nullptr : it->second; }
@@ -329,13 +332,29 @@ struct Builder {
             // a minibatch armed by rlrep_prefetch_batch is gathered by extra blocks of this launch
             const SlotFill* sf = a->pf_armed ? &a->pf_fill : nullptr;
             if (sf) { a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; a->early_ready_crit = a->early_ready_act = nullptr; }
-            return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, st);
+            // a snapshot armed by rlrep_defer_arm rides in the feature group's launch (never beside a minibatch gather: both touch slot 0)
+            AdamSnap sn; memset(&sn, 0, sizeof(sn));
+            if (group == 0 && a->snap_armed && !sf) {
+                const rlrep_agent::DeferSet& D = a->dset[a->snap_set];
+                const CopySegs& full = D.segs;
+                long long end = 0; int n = 0;
+                for (int q = 0; q < full.n; ++q) {
+                    const long long cnt = full.end[q] - (q ? full.end[q - 1] : 0);
+                    if (full.dst[q] == D.block) continue;                                   // the block is written by the optimizer's own lanes
+                    sn.segs.src[n] = q == full.n - 2 ? a->snap_ec : q == full.n - 1 ? a->snap_ea : full.src[q];
+                    sn.segs.dst[n] = full.dst[q]; end += cnt; sn.segs.end[n] = end; ++n;
+                }
+                sn.segs.n = n; sn.segs.isrc = full.isrc; sn.segs.idst = full.idst;
+                sn.block = D.block; sn.off = D.block_off; sn.n = D.block_n; sn.which = D.block_which; sn.on = 1;
+                a->snap_armed = false; a->snap_done = a->snap_set;
+            }
+            return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, sn.on ? &sn : nullptr, st);
         }, what});
     }
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, st); }, what});
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, nullptr, st); }, what});
     }
 
     static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {

@@ -33,6 +33,10 @@ struct TrainPrologue {
 // up to 10 float segments + one int copied by ONE launch (rlrep_defer_snapshot)
 #define COPY_MAX_SEGS 10
 struct CopySegs { int n; const float* src[COPY_MAX_SEGS]; float* dst[COPY_MAX_SEGS]; long long end[COPY_MAX_SEGS]; const int* isrc; int* idst; };
+// The deferred chain's snapshot folded into the LAST feature optimizer launch of a train() (rlrep_defer_arm): the small segments (minibatch
+// slices, policy noise, step counter) are copied by extra blocks; the block of parameters / targets the chain reads is written by the
+// optimizer's own lanes as they produce the new values ([off, off + n) of the task's range; which = 0: parameters, 1: Polyak target).
+struct AdamSnap { CopySegs segs; float* block; long long off, n; int which, on; };
 
 struct PolicyFwd {
     const float* O; const float* eps; int B, A;

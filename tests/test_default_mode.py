@@ -277,6 +277,24 @@ def test_row_program_shadows_follow_external_parameter_writes(monkeypatch):
         assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (k, info[k], v)
 
 
+def test_snapshot_rides_in_the_last_feature_optimizer_launch(monkeypatch):
+    """rlrep_defer_arm: the deferred chain's snapshot is written by the last feature step's optimizer launch (one dependent launch less on
+    the chain that bounds train()); RLREP_NO_FOLD_SNAPSHOT=1 keeps the separate copy launch.  Both forms against the oracle, and the
+    launch counts of the captured feature graph differ by exactly one."""
+    c = Case('vlsac_hc')
+    counts = {}
+    for fold in (True, False):
+        if not fold:
+            monkeypatch.setenv('RLREP_NO_FOLD_SNAPSHOT', '1')
+        agent, buf = _default_agent(c), _buffer(c)
+        agent.train(buf, c.B)
+        agent.flush()
+        counts[fold] = agent._pipe['launches'][0]
+        del agent
+        _check_against_oracle(c, calls=3, expect_pipeline=True)
+    assert counts[False] == counts[True] + 1, counts
+
+
 def test_noise_critic_weight_images_follow_external_parameter_writes():
     """vlsac at the headline dims runs its noise critic from bf16x3 images of critic.l1 / l4 and of their target copies (ShadowEnt kind 1).
     The live images are kept by the critic group's Adam launch and ALL of them are regenerated at the head of every critic step: parameters
