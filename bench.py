@@ -239,7 +239,7 @@ def _family(name):
         return 'losses (qhead / vae_mid: elementwise + wave reductions)'
     if name.startswith('row programs'):
         return 'row programs (rowprog_kernel)'
-    return 'gemm16_kernel (16-row fp32-MFMA tile engine: every 256-wide layer forward / dX / dW)'
+    return 'gemm16_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'
 
 
 # algorithmic flops of a gemm16 stage are not carried by its name; the family totals come from SURVEY.md Appendix F (per train())
