@@ -506,8 +506,12 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
         *reinterpret_cast<f32x4*>(t.p + i) = p4; *reinterpret_cast<f32x4*>(t.m + i) = m4; *reinterpret_cast<f32x4*>(t.v + i) = v4;
         if (pol) *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off)) = t4;
         if (snap.on && ti == 0 && i >= snap.off && i < snap.off + snap.n) {        // folded snapshot: the new values, as the deferred chain will read them
-            if (snap.which == 0) *reinterpret_cast<f32x4*>(snap.block + (i - snap.off)) = p4;
-            else *reinterpret_cast<f32x4*>(snap.block + (i - snap.off)) = pol ? t4 : *reinterpret_cast<const f32x4*>(t.target + (i - t.pol_off));
+            const f32x4 sv = snap.which == 0 ? p4 : (pol ? t4 : *reinterpret_cast<const f32x4*>(t.target + (i - t.pol_off)));
+            if (i + 4 <= snap.off + snap.n && !(snap.off & 3) && !(((uintptr_t)snap.block) & 15)) *reinterpret_cast<f32x4*>(snap.block + (i - snap.off)) = sv;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (i + q < snap.off + snap.n) snap.block[i + q - snap.off] = sv[q];      // (a range that does not end on a multiple of four)
+            }
         }
         if (t.sh) {
             // keep the transposed shadows of the weight matrices current (4 scattered 4-byte stores; tensors start on multiples of 4 floats,
