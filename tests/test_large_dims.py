@@ -35,7 +35,7 @@ def _retie(alg, P):
                     P[d + k[3:]] = P[k].copy()
 
 
-def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=()):
+def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=(), agent_kw=None):
     import importlib
     from oracle import make_oracle
     from oracle.agents import gather_batch
@@ -48,7 +48,7 @@ def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=())
     if alg == 'vlsac':
         init['critic.noise'] = np.random.RandomState(5).standard_normal(init['critic.noise'].shape).astype(np.float32)   # N(0,1) buffer
         init['critic_target.noise'] = init['critic.noise'].copy()                       # quirk Q3: same buffer in both copies
-    agent = cls(state_dim=S, action_dim=A, action_space=_Space(A), max_batch=B, graph=False, **kw)
+    agent = cls(state_dim=S, action_dim=A, action_space=_Space(A), max_batch=B, graph=False, **{k: v for k, v in kw.items() if k != 'vae_hidden'}, **(agent_kw or {}))
     if alg == 'diffsrsac':
         init['noise_alphabars'] = agent.core.state()['noise_alphabars'].numpy().copy()
     agent.core.load_state(init)
@@ -140,6 +140,15 @@ def test_vlsac_noise_critic_first_layer_on_bf16x3(S, A, B, F, H, monkeypatch):
     assert _lib.lib.rlrep_nc_fwd_plan(2, B, F, H, *[C.byref(o) for o in out]) == 0 and out[0].value == 1
     _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), S, A, B,
          dict(hidden_dim=H, feature_dim=F, extra_feature_steps=1), trains=2)
+
+
+@pytest.mark.parametrize('S,A,B,F,H,Hv', [(7, 2, 19, 24, 32, 40), (5, 3, 33, 40, 16, 24), (9, 2, 64, 16, 32, 72)])
+def test_vlsac_fused_heads_and_vae_mid_at_odd_shapes(S, A, B, F, H, Hv):
+    """heads_vae_kernel (the Gaussian heads of encoder / f fused with vae_mid; csrc/elementwise.hip) at shapes where nothing is a multiple
+    of its 16 x 16 tile or its 16-deep chunks: feature width 24 / 40 / 16, batch 19 / 33 / 64, VAE hidden width 40 / 24 / 72 -- against
+    the CPU oracle, two train() calls each."""
+    _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), S, A, B,
+         dict(hidden_dim=H, feature_dim=F, vae_hidden=Hv, extra_feature_steps=1), trains=2, agent_kw=dict(vae_hidden_dim=Hv))
 
 
 def test_vlsac_noise_critic_engines_agree(monkeypatch):
