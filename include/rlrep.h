@@ -340,6 +340,14 @@ int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t rows, int32_t cols, int3
 int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t batch, int32_t feature_dim, int32_t hidden_dim,
                           int32_t* engine, int32_t* rows, int32_t* cols);
 
+/* Chains (csrc/xchain.hip): consecutive row-local stages of a step program -- the forward and dX launches of the reference's
+ * feature_step / critic_step / update_actor_and_alpha (agent/vlsac/vlsac_agent.py:126-237 and siblings) -- run as ONE persistent launch
+ * whose workgroups synchronise per XCD.  The launch checks its own assumptions on the device: *status receives the error word
+ * (0 = clean; bit 0: a wait inside a chain timed out; bit 1: the workgroups of one group did not share an XCD, i.e. the hand-offs
+ * were not guaranteed to be seen).  SYNCHRONISES `stream`.  Returns RLREP_ERR_STATE (and sets the error text) when the word is not 0:
+ * results of the affected steps are invalid; RLREP_XCHAIN=0 selects one launch per stage. */
+int32_t rlrep_chain_status(rlrep_agent* agent, uint32_t* status, void* stream);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 /* process-wide number of kernel launches the library has issued so far (a captured train()'s launch count = the difference around its capture) */

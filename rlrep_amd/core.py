@@ -26,12 +26,13 @@ class LazyInfo(dict):
     Q14), each a device sync; here the metric slots are snapshotted on the device and only fetched when a
     value is actually read (main.py reads `info` once per 5000 steps)."""
 
-    def __init__(self, names, snapshot, early=None):
+    def __init__(self, names, snapshot, early=None, after=None):
         """early = (keys, callable): a subset of the metrics that is final BEFORE the full snapshot is (pipelined train(): the feature
         steps' losses are final when the feature chain ends, while the critic / actor chain is still running); reading only such keys
         fetches them through `callable` and does not wait for the rest."""
         super().__init__()
         self._names, self._snap, self._done = names, snapshot, False
+        self._after = after          # called once the values are on the host (HipCore.chain_check: the device-side checks of the chain launches)
         self._early_keys, self._early_snap, self._early_done = (frozenset(early[0]), early[1], False) if early else (frozenset(), None, False)
         for n in names:
             if n:
@@ -45,6 +46,8 @@ class LazyInfo(dict):
         if not self._done:
             snap = self._snap() if callable(self._snap) else self._snap     # callable: fetched (and flushed) on first read
             vals = snap.cpu().numpy()
+            if self._after is not None:
+                self._after()
             for i, n in enumerate(self._names):
                 if n:
                     v = float(vals[i])
@@ -171,7 +174,14 @@ class HipCore:
             self.before_read()             # e.g. the agent's flush() of a pending deferred critic / actor pair
         out = {k: self.view(k).detach().cpu().clone() for k in self.order}
         out['log_alpha'] = self.alpha_state[0].detach().cpu().clone()
+        self.chain_check()
         return out
+
+    def chain_check(self):
+        """Raise if a persistent chain launch (csrc/xchain.hip) failed its device-side checks since the agent was created: a wait that
+        timed out, or workgroups of one group on different XCDs.  Synchronises the current stream."""
+        w = C.c_uint32(0)
+        check(lib.rlrep_chain_status(self.h, C.byref(w), _stream()), 'chain_status')
 
     # ---- data ---------------------------------------------------------------------------------
     def set_batch(self, slot, state, action, reward, next_state, done):
@@ -316,7 +326,7 @@ class HipCore:
     def info(self, keys=None, lazy_source=None, early=None):
         snap = lazy_source if lazy_source is not None else self.metrics_tensor().clone()
         names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]
-        return LazyInfo(names, snap, early)
+        return LazyInfo(names, snap, early, after=self.chain_check)
 
     def stages(self, program):
         n = lib.rlrep_stage_count(self.h, program)

@@ -9,7 +9,7 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $EXTRA_FLAGS"
 pids=()
-for f in gemm16 gemm_lds noisecritic elementwise replearn rowprog engine agents2 $EXTRA_SRCS; do
+for f in gemm16 gemm_lds noisecritic elementwise replearn rowprog xchain engine agents2 $EXTRA_SRCS; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$OBJ/$f.o")" ] || [ "$HERE/../../include/rlrep.h" -nt "$OBJ/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)

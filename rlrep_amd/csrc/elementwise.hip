@@ -3,6 +3,7 @@
 // deterministic per-block partial sums (no float atomics) that the optimizer launch finalises.
 #include "common.h"
 #include "kparams.h"
+#include "heads_vae_tile.h"
 #include "x3.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -253,94 +254,14 @@ __global__ __launch_bounds__(256) void vae_mid_kernel(VaeMid p) {
     }
 }
 
-// The two Gaussian heads (encoder, f: [B, K] x [2F, K]^T each) and vae_mid in ONE launch: a workgroup owns 16 rows x 16 feature columns and
-// computes the four 16 x 16 products it needs for them -- encoder mean / log_std, f mean / log_std of those columns -- on
-// v_mfma_f32_16x16x4_f32 (exact fp32), wave w taking the 16-deep chunks w, w + 4, ... of the inner dimension; the four partial tiles
-// meet in LDS, and thread (row, column) then does what vae_mid_kernel does for its element.  One dependent launch less per feature step.
+// The two Gaussian heads (encoder, f) and vae_mid in ONE launch: one 16 x 16 tile per workgroup (heads_vae_tile.h).  One dependent launch
+// less per feature step than the heads launch + vae_mid_kernel.
 __global__ __launch_bounds__(256) void heads_vae_kernel(HeadsVae p) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     __shared__ float red[4][4][256];    // [wave][net * 2 + part][16 x 16]
     __shared__ float sh[4];
-    const int F = p.F, K = p.K, B = p.B;
     const int tr = blockIdx.x / p.tiles_c, tc = blockIdx.x - tr * p.tiles_c;
-    const int r0 = tr * 16, c0 = tc * 16;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = lane & 15, kq = lane >> 4;
-    const int arow = min(r0 + i, B - 1), wcol = min(c0 + i, F - 1);
-    const float* pa[2] = {p.Ae + (size_t)arow * p.lda, p.Af + (size_t)arow * p.lda};
-    const float* pw[2][2] = {{p.We + (size_t)wcol * K, p.We + (size_t)(F + wcol) * K}, {p.Wf + (size_t)wcol * K, p.Wf + (size_t)(F + wcol) * K}};
-    const bool vec = !(K & 3) && !(p.lda & 3) && !((((uintptr_t)p.Ae) | ((uintptr_t)p.Af) | ((uintptr_t)p.We) | ((uintptr_t)p.Wf)) & 15);
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) acc[n][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto ld = [&](const float* base, int k, float (&v)[4]) {
-        if (vec && k + 3 < K) { const f32x4 x = *reinterpret_cast<const f32x4*>(base + k); v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
-        else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) v[s] = (k + s < K) ? base[k + s] : 0.f;
-        }
-    };
-    // four 16-deep chunks (K = 256: all of this wave's share) are loaded before the first of them is multiplied: one exposed load latency
-    // per workgroup instead of one per chunk
-    for (int kb0 = 16 * w; kb0 < K; kb0 += 256) {
-        float a[4][2][4], b[4][2][2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = kb0 + 64 * c + 4 * kq;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) { ld(pa[n], k, a[c][n]); ld(pw[n][0], k, b[c][n][0]); ld(pw[n][1], k, b[c][n][1]); }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (kb0 + 64 * c >= K) break;
-            // (the four accumulators in turn: consecutive MFMAs are independent)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[n][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][n][s], b[c][n][q][s], acc[n][q], 0, 0, 0);
-        }
-    }
-    // C/D map: lane (i, kq) holds rows 4 kq + r, column i
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[w][n * 2 + q][(4 * kq + r) * 16 + i] = acc[n][q][r];
-    __syncthreads();
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-    const int bq = r0 + row, j = c0 + col;
-    float kl = 0.f;
-    if (bq < B && j < F) {
-        float h[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = ((red[0][q][threadIdx.x] + red[1][q][threadIdx.x]) + red[2][q][threadIdx.x]) + red[3][q][threadIdx.x];
-        const float m1 = h[0] + p.be[j], l1r = h[1] + p.be[F + j], m2 = h[2] + p.bf[j], l2r = h[3] + p.bf[F + j];
-        if (p.EH) { p.EH[(size_t)bq * 2 * F + j] = m1; p.EH[(size_t)bq * 2 * F + F + j] = l1r; }
-        if (p.FH) { p.FH[(size_t)bq * 2 * F + j] = m2; p.FH[(size_t)bq * 2 * F + F + j] = l2r; }
-        // ---- vae_mid (vlsac_agent.py:135-150), as vae_mid_kernel ----
-        const float l1 = clamp_lstd(l1r), l2 = clamp_lstd(l2r);
-        const float es = p.eps[(size_t)bq * F + j] * expf(l1);
-        p.Z[(size_t)bq * F + j] = m1 + es;
-        p.EZ[(size_t)bq * F + j] = es * lstd_mask(l1r);
-        const float v1 = expf(2.f * l1), iv2 = expf(-2.f * l2), d = m1 - m2;
-        kl = l2 - l1 + 0.5f * (v1 + d * d) * iv2 - 0.5f;
-        const float sc = p.scale;
-        const float dm1 = d * iv2 * sc;
-        p.GEH[(size_t)bq * 2 * F + j] = dm1;
-        p.GEH[(size_t)bq * 2 * F + F + j] = (v1 * iv2 - 1.f) * sc * lstd_mask(l1r);
-        p.GFH[(size_t)bq * 2 * F + j] = -dm1;
-        p.GFH[(size_t)bq * 2 * F + F + j] = (1.f - (v1 + d * d) * iv2) * sc * lstd_mask(l2r);
-    }
-    const float ssum = block_sum_256(kl, sh);
-    if (threadIdx.x == 0) {
-        p.partial[blockIdx.x] = ssum;
-        if (blockIdx.x == 0 && p.step) bump_group(p.step);
-    }
+    heads_vae_tile<false>(p, tr, tc, p.eps, red, sh);
 }
 
 __global__ __launch_bounds__(256) void vae_mse_kernel(VaeMse p) {

@@ -38,6 +38,7 @@ int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st);
 int rl_launch_policy_bwd(const PolicyBwd* p, hipStream_t st);
 int rl_launch_vae_mid(const VaeMid* p, hipStream_t st);
 int rl_launch_heads_vae(const HeadsVae* p, hipStream_t st);
+int rl_launch_xchain(const XcLaunch* L, hipStream_t st);
 int rl_launch_vae_mse(const VaeMse* p, hipStream_t st);
 int rl_launch_qhead_critic(const QHeadCritic* p, hipStream_t st);
 int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st);

@@ -562,7 +562,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                 return rl_launch_rowprog(&l2, total, st);
             }, early ? "row programs: encoder | f | policy(s') | policy(s): forward + dX" : "row programs: encoder | f: forward + dX"});
         } else
-        if (early) {
+        b.chain_begin(p);              // everything up to the weight gradients is row-local: ONE persistent launch (xchain.hip)
+        if (use_rp) {
+        } else if (early) {
             b.fwd_stage(p, {te[0], tf[0], actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "enc.l1 f.l1 actor.l1(s') actor.l1(s)");
             b.fwd_stage(p, {te[1], tf[1], actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi)}, "enc.l2 f.l2 actor.l2 x2");
             if (!fuse_vm)
@@ -584,8 +586,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             hv.Wf = Pw("f.mean_linear.weight"); hv.bf = Pw("f.mean_linear.bias");
             hv.Z = Z; hv.EZ = EZ; hv.GEH = GEH; hv.GFH = GFH; hv.partial = part_kl; hv.EH = nullptr; hv.FH = nullptr;       // (nothing downstream of vae_mid reads the heads themselves)
             hv.B = B; hv.F = F; hv.K = Hv; hv.tiles_c = (F + 15) / 16; hv.scale = ag->inv_batch() / (float)F; hv.step = ag->adam_step + 0;
-            p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = ag->cur_eps; return rl_launch_heads_vae(&q, st); }, "enc.heads f.heads + vae_mid"});
+            b.heads_vae_stage(p, hv, "enc.heads f.heads + vae_mid");
         } else {
+        b.chain_flush();
         VaeMid vm; memset(&vm, 0, sizeof(vm));
         vm.EH = ge.HH; vm.FH = gf.HH; vm.Z = Z; vm.GEH = GEH; vm.GFH = GFH; vm.partial = part_kl;
         vm.B = B; vm.F = F; vm.nblk = nblk_kl; vm.scale = ag->inv_batch() / (float)F; vm.step = ag->adam_step + 0;
@@ -618,6 +621,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         b.dx_stage(p, {Builder::dx(GH2e, Hv, B, Hv, Pw("encoder.l2.weight"), Hv, GH1e, Hv, Hv, ACT_RELU, ge.H1, Hv),
                        Builder::dx(GH2f, Hv, B, Hv, Pw("f.l2.weight"), Hv, GH1f, Hv, Hv, ACT_RELU, gf.H1, Hv)}, "l2 dx");
         }
+        b.chain_end();
         {
             const LT& f0 = ag->L.get("f.l1.weight");
             const LT& fl = ag->L.get("f.log_std_linear.bias");
@@ -967,6 +971,8 @@ static void static_state(rlrep_agent* ag) {
     ag->obs_in = ws.f((size_t)ag->d.max_batch * S);
     ag->act_out = ws.f((size_t)ag->d.max_batch * A);
     ag->rp_epoch = (int*)ws.alloc(sizeof(int) * 4);
+    ag->xc_err = (unsigned*)ws.alloc(256);
+    if (!ws.dry && ws.ok()) (void)hipMemset(ag->xc_err, 0, 256);
     if (!ws.dry && ws.ok()) { const int one[4] = {1, 0, 0, 0}; (void)hipMemcpy(ag->rp_epoch, one, sizeof(one), hipMemcpyHostToDevice); }
     // transposed weight shadows (see rlrep_agent::sh_dev): vlsac's feature group, read by the feature step's row programs
     ag->shadow_of.clear();
@@ -1627,6 +1633,21 @@ int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t B, int32_t F, int32_t H, int32_
     *engine = e;
     if (rows) *rows = 4 * g2;
     if (cols) *cols = c;
+    return 0;
+}
+
+int32_t rlrep_chain_status(rlrep_agent* ag, uint32_t* status, void* stream) {
+    if (!ag || !ag->xc_err) { rl_set_error("chain_status: bad argument"); return RLREP_ERR_ARG; }
+    unsigned w = 0;
+    hipError_t e = hipMemcpyAsync(&w, ag->xc_err, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { rl_set_error("chain_status: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    if (status) *status = w;
+    if (w) {
+        rl_set_error("a persistent chain launch failed its run-time checks (word %u:%s%s); results are invalid -- RLREP_XCHAIN=0 runs one launch per stage",
+                     w, (w & 1u) ? " wait timed out" : "", (w & 2u) ? " workgroups of a group on different XCDs" : "");
+        return RLREP_ERR_STATE;
+    }
     return 0;
 }
 

@@ -1,6 +1,7 @@
 // Internal definitions shared by engine.hip and agents2.hip (agent state, program builder).
 #pragma once
 #include "engine.h"
+#include <deque>
 
 struct Slot { float *XE, *XF, *XF2, *XFpi, *R, *D; bool filled = false; };
 
@@ -71,6 +72,9 @@ struct rlrep_agent {
     // cluster row programs (RLREP_ROWPROG=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
     // extra launch before an eager step outside a train())
     int* rp_epoch = nullptr;
+    // xchain.hip: error word of the persistent chain launches (rlrep_chain_status) and the names of their stages (owned here: Stage::what is a
+    // plain pointer)
+    unsigned* xc_err = nullptr; std::deque<std::string> stage_names;
 
     float* overridden(const std::string& n) const {
         if (!ov_base || n.compare(0, ov_prefix.size(), ov_prefix) != 0) return nullptr;
@@ -148,6 +152,7 @@ struct Builder {
             }
             small.push_back(t);
         }
+        if (!bigx3.empty() || !big128.empty() || !big64.empty()) chain_flush();
         if (!bigx3.empty()) gemm_lds_stage(p, la, lb, 129, bigx3, what);
         if (!big128.empty()) gemm_lds_stage(p, la, lb, 128, big128, what);
         if (!big64.empty()) gemm_lds_stage(p, la, lb, 64, big64, what);
@@ -171,6 +176,10 @@ struct Builder {
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm_lds(bt, la, lb, &gb, base, fin, st); }, what});
     }
     void gemm_small(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
+        if (chain_take(p, la, lb, tasks, what)) return;
+        gemm_small_launch(p, la, lb, tasks, what);
+    }
+    void gemm_small_launch(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
         // column fragments per workgroup: the widest tile that still leaves >= ~1.5 workgroups per CU; the
         // epilogues that need a whole row / per-tile partials in one fragment force NF = 1
         int nf = 1;
@@ -213,6 +222,106 @@ struct Builder {
             }, what});
         else
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, nf, &gb, total, st); }, what});
+    }
+
+    // ---- chains (xchain.hip) -----------------------------------------------------------------------
+    // Between chain_begin(p) and chain_end() consecutive ROW-LOCAL stages of program p (forward and dX stages of the 16-row tile engine, the
+    // fused heads + vae_mid stage) are not emitted as launches but collected as PHASES of one persistent launch, in which the workgroups of
+    // an XCD hand their tiles to each other through that XCD's L2 (kparams.h XcLaunch).  Anything else that reaches the program inside the
+    // bracket must go through chain_flush() first: gemm() does it for the LDS-tiled engines, the builders do it before a stage they push
+    // themselves.  A chain of one phase is emitted as the ordinary launch it would have been.
+    struct ChainPhase { XcPhase ph; std::vector<GemmTask> tasks; HeadsVae hv; const char* what; int la, lb; };
+    std::vector<ChainPhase> chain; Program* chain_prog = nullptr; int chain_R = -1;
+    // OPT-IN while it is slower than the launches it replaces beside the deferred chain: RLREP_XCHAIN=1
+    static bool chain_enabled() { const char* e = getenv("RLREP_XCHAIN"); return e && e[0] == '1'; }
+    static int chain_mpg() { const char* e = getenv("RLREP_XCHAIN_MPG"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }
+    bool chain_fits(int R) const { return chain_enabled() && R <= 512 && (chain_R < 0 || chain_R == R); }
+    void chain_begin(Program& p) { chain_flush(); chain_prog = &p; chain_R = -1; }
+    void chain_end() { chain_flush(); chain_prog = nullptr; }
+    static bool vec_ok(const std::vector<GemmTask>& tasks, bool opB, bool dry_) {
+        for (const GemmTask& t : tasks) {
+            const float* ptr = opB ? t.B : t.A; const int ld = opB ? t.ldb : t.lda;
+            if ((ld & 3) || (t.K & 3) || (!dry_ && (((uintptr_t)ptr) & 15))) return false;
+        }
+        return true;
+    }
+    bool chain_take(Program& p, int la, int lb, const std::vector<GemmTask>& tasks, const char* what) {
+        if (chain_prog != &p) return false;
+        bool ok = la == LD_ROW && !tasks.empty() && !fused();
+        for (const GemmTask& t : tasks) {
+            ok = ok && tasks.size() <= GEMM_MAX_TASKS && chain_fits(t.R) && t.R == tasks[0].R && !(t.flags & FLAG_PRE_FWD) && t.epi != EPI_DW && t.Cn <= 2048 && t.K <= 2048;
+            ok = ok && (((t.flags & FLAG_PRE) != 0) == ((tasks[0].flags & FLAG_PRE) != 0));
+        }
+        if (!ok) { chain_flush(); return false; }
+        ChainPhase c; memset(&c.ph, 0, sizeof(c.ph)); memset(&c.hv, 0, sizeof(c.hv));
+        c.ph.kind = XC_GEMM; c.ph.la = la; c.ph.lb = lb; c.ph.pre = (tasks[0].flags & FLAG_PRE) ? 1 : 0;
+        c.ph.vecA = vec_ok(tasks, false, dry) ? 1 : 0; c.ph.vecB = vec_ok(tasks, true, dry) ? 1 : 0;
+        c.tasks = tasks; c.what = what; c.la = la; c.lb = lb;
+        chain_R = tasks[0].R;
+        chain.push_back(c);
+        return true;
+    }
+    // the fused Gaussian heads + vae_mid stage (heads_vae_kernel) as a phase, or as its own launch outside a chain
+    void heads_vae_stage(Program& p, const HeadsVae& hv, const char* what) {
+        rlrep_agent* a = ag;
+        if (chain_prog == &p && chain_fits(hv.B) && !fused()) {
+            ChainPhase c; memset(&c.ph, 0, sizeof(c.ph));
+            c.ph.kind = XC_HEADS_VAE; c.ph.dyn = 0; c.hv = hv; c.what = what; c.la = c.lb = 0;
+            chain_R = hv.B;
+            chain.push_back(c);
+            return;
+        }
+        chain_flush();
+        p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = a->cur_eps; return rl_launch_heads_vae(&q, st); }, what});
+    }
+    void chain_flush() {
+        if (chain.empty()) return;
+        std::vector<ChainPhase> c; c.swap(chain);
+        Program& p = *chain_prog;
+        const int R = chain_R; chain_R = -1;
+        rlrep_agent* a = ag;
+        if (c.size() == 1) {            // nothing to chain: the launch it would have been
+            if (c[0].ph.kind == XC_GEMM) gemm_small_launch(p, c[0].la, c[0].lb, c[0].tasks, c[0].what);
+            else { const HeadsVae hv = c[0].hv; p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = a->cur_eps; return rl_launch_heads_vae(&q, st); }, c[0].what}); }
+            return;
+        }
+        const int rbg = (((R + 15) / 16) + XC_GROUPS - 1) / XC_GROUPS;      // 16-row blocks per group
+        std::vector<XcPhase> phs; std::vector<GemmTask> tasks; std::vector<HeadsVae> hvs;
+        std::string name = "chain:";
+        for (ChainPhase& cp : c) {
+            XcPhase ph = cp.ph;
+            if (ph.kind == XC_GEMM) {
+                ph.task0 = (int)tasks.size(); ph.ntasks = (int)cp.tasks.size();
+                int base = 0, q = 0;
+                ph.rbg = rbg; ph.R = R;
+                for (GemmTask t : cp.tasks) {
+                    t.tiles_c = (t.Cn + 15) / 16; t.ntiles = rbg * t.tiles_c; t.tile_base = base;
+                    ph.tb[q] = base; ph.tcs[q] = t.tiles_c; ++q;
+                    base += t.ntiles;
+                    tasks.push_back(t);
+                }
+                ph.tiles = base;
+            } else {
+                ph.aux = (int)hvs.size(); ph.tiles = rbg * cp.hv.tiles_c;
+                hvs.push_back(cp.hv);
+            }
+            phs.push_back(ph);
+            name += std::string(" [") + cp.what + "]";
+        }
+        if (hvs.empty()) { HeadsVae z; memset(&z, 0, sizeof(z)); hvs.push_back(z); }      // (identical allocations in the dry and the real pass)
+        XcLaunch L; memset(&L, 0, sizeof(L));
+        L.ntasks = (int)tasks.size(); L.nhv = (int)hvs.size();
+        if (tasks.empty()) tasks.push_back(base());
+        L.ph = upload(phs); L.nph = (int)phs.size(); L.tasks = upload(tasks); L.hv = upload(hvs);
+        L.flags = (unsigned*)ws.alloc(sizeof(unsigned) * XC_GROUPS * XC_FLAG_STRIDE);
+        if (!dry && ws.ok() && L.flags) (void)hipMemset(L.flags, 0, sizeof(unsigned) * XC_GROUPS * XC_FLAG_STRIDE);
+        L.err = a->xc_err; L.rbg = rbg; L.mpg = chain_mpg(); L.low_prio = low_prio ? 1 : 0;
+        a->stage_names.push_back(name);
+        const char* what = a->stage_names.back().c_str();
+        p.stages.push_back({[=](hipStream_t st) {
+            XcLaunch l = L; l.dyn[0] = a->cur_eps; l.dyn[1] = a->cur_eps2; l.dyn[2] = a->cur_eps3;
+            return rl_launch_xchain(&l, st);
+        }, what});
     }
     // ---- optimizer fusion (single-GPU path) ------------------------------------------------------
     // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch applies Adam (and

@@ -221,3 +221,34 @@ struct DiffsrScore {
     float* U; const float* PHI; const float* TGT; const float* alphabars; const int* idx;
     float* GPHI; float* partial; int B, F, S; float sigma, inv_batch;
 };
+
+// ------------------------------------------------------------------------------------------------
+// xchain.hip: several DEPENDENT row-local stages of a step program in ONE persistent launch, synchronised per XCD
+// ------------------------------------------------------------------------------------------------
+// The 8 * mpg workgroups form 8 groups (group = blockIdx.x % 8: one XCD under the round-robin dealing of workgroups, verified at run time
+// through HW_REG_XCC_ID); group g owns the 16-row blocks g * rbg .. of every task and walks the phases in order, its members handing their
+// tiles to each other through that XCD's L2 (plain stores, one flag per member, sc1 loads).  A phase = what used to be one launch.
+enum XcKind : int { XC_GEMM = 0, XC_HEADS_VAE = 1, XC_QHEAD_CRITIC = 2, XC_QHEAD_ACTOR = 3 };
+struct XcPhase {
+    int kind;
+    int task0, ntasks;             // XC_GEMM: tasks[task0 .. task0 + ntasks) of the launch's table; GemmTask::tile_base / ntiles = GROUP-LOCAL tile range
+    int la, lb, vecA, vecB, pre;   // operand layouts / access widths of the phase, as for a gemm16 launch
+    int tiles;                     // tiles (work items) per group
+    int aux;                       // XC_HEADS_VAE / XC_QHEAD_*: index into the launch's table of that kind
+    int dyn;                       // XC_HEADS_VAE: which dyn[] slot carries eps
+    int rbg, R;                    // XC_GEMM: 16-row blocks per group and row count of the phase's tasks
+    int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS];   // XC_GEMM: group-local first tile and column tiles of each task (the decode reads no task record)
+};
+#define XC_GROUPS 8
+#define XC_FLAG_STRIDE 64          // flags per group: one flag per member, up to 64 members (two 128-byte lines)
+struct XcLaunch {
+    const XcPhase* ph; int nph;
+    const GemmTask* tasks; const HeadsVae* hv; const QHeadCritic* qc; const QHeadActor* qa;
+    int ntasks, nhv, nqc, nqa;
+    unsigned* flags;               // [XC_GROUPS][XC_FLAG_STRIDE]: (phase counter << 4) | XCC id of the writer; never reset (monotonic, wrap-safe compare)
+    unsigned* err;                 // bit 0: a wait timed out; bit 1: members of one group ran on different XCDs (hand-offs not guaranteed)
+    int rbg;                       // 16-row blocks per group (of tasks with the launch's common row count)
+    int mpg;                       // members (workgroups) per group; grid = XC_GROUPS * mpg
+    const float* dyn[3];           // per-call noise pointers (FLAG_DYN_EPS / _EPS2 / _EPS3)
+    int low_prio;
+};

@@ -16,19 +16,35 @@ import check_async_asm  # noqa: E402
 CSRC = os.path.join(ROOT, 'rlrep_amd', 'csrc')
 
 
+def _source_with_local_includes(path, seen=None):
+    """The text of a .hip file plus that of the csrc headers it includes (the tile bodies live in headers shared by two kernels)."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return ''
+    seen.add(path)
+    src = open(path).read()
+    for inc in re.findall(r'#include "([\w./]+\.h)"', src):
+        src += _source_with_local_includes(os.path.join(CSRC, inc), seen)
+    return src
+
+
 def _files_with_asm_loads():
     out = []
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith('.hip'):
             continue
-        src = open(os.path.join(CSRC, f)).read()
+        src = _source_with_local_includes(os.path.join(CSRC, f))
         if 'asm volatile("global_load' in src or 'asm volatile("ds_read' in src:
             out.append(f)
     return out
 
 
 def test_guard_sees_the_files_it_is_meant_for():
-    assert {'rowprog.hip', 'gemm16.hip', 'noisecritic.hip'} <= set(_files_with_asm_loads())
+    # (gemm16_tile.h, shared by gemm16.hip and xchain.hip, no longer issues asm loads: its epilogue operands are plain loads pinned by a
+    # memory-clobbering asm since round 3 -- the guard flagged the asm form as soon as the tile body moved into a header)
+    assert {'rowprog.hip', 'noisecritic.hip'} <= set(_files_with_asm_loads())
+    assert not {'gemm16.hip', 'xchain.hip'} & set(_files_with_asm_loads())
 
 
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='hipcc not on PATH')
