@@ -70,6 +70,13 @@ struct GemmTask {
     float* out2;         // EPI_FWD+ACT_SIN: pre-activation; EPI_DW: bias gradient
     int ldout2;
     int ntiles;
+    // ---- the epilogue's operand SLOTS, precomputed on the host (rl_gemm16_plan) ---------------------------
+    // The epilogue kind only selects up to five slot descriptors -- base, row stride, column stride (1, or 0 if bit q of scs0 is set),
+    // offset, column window [slo, shi) -- and the kernel's operand loads are generic.  Deriving them in the kernel cost every tile a
+    // ladder of scalar branches with a dependent scalar-load round trip per case (x0, ldx0, aux3, F, ad_p ...: ~1 800 cycles between
+    // "workgroup starts" and "first operand load issued"); as part of the record they arrive with the hot block in one burst.
+    // spx2: bit q set = slot q's base is x2, which a launch whose table lives in device memory patches per call (FLAG_DYN_EPS*).
+    const float* sp[5]; int srs[5], sof[5], slo[5], shi[5]; int scs0, spx2;
     // ---- cold block: only the epilogue that needs a field reads it ---------------------------------
     const float* aux2;   // LD_NCX: log-std
     const float* aux3;   // EPI_DX_REPARAM: eps*exp(l)*mask;  LD_NCX: mean
@@ -90,11 +97,52 @@ struct GemmTask {
     float* slab; float* bslab;
 };
 
+// host side: fill the slots of a finished task record (every launcher of the 16-row tile engine calls it on its copy of the record)
+static inline void rl_gemm16_plan(GemmTask& t) {
+    for (int q = 0; q < 5; ++q) { t.sp[q] = nullptr; t.srs[q] = 0; t.sof[q] = 0; t.slo[q] = 0; t.shi[q] = t.Cn; }
+    t.scs0 = 0; t.spx2 = 0;
+    switch (t.epi) {
+    case EPI_FWD: t.sp[0] = t.bias; break;
+    case EPI_DX:
+        if (t.act != ACT_NONE) { t.sp[0] = t.aux; t.srs[0] = t.ldaux; }
+        if (t.flags & FLAG_ACCUM) { t.sp[1] = t.C; t.srs[1] = t.ldc; }
+        if (t.r1u) { t.sp[2] = t.r1u; t.srs[2] = 1; t.scs0 |= 4; t.sp[3] = t.r1v; }
+        break;
+    case EPI_FWD_MSE:
+        t.sp[0] = t.bias;
+        t.sp[1] = t.x0; t.srs[1] = t.ldx0; t.shi[1] = t.n0;
+        t.sp[2] = t.x1; t.srs[2] = 1; t.scs0 |= 4; t.slo[2] = t.n0;
+        break;
+    case EPI_FWD_POLICY:
+        t.sp[0] = t.bias;
+        t.sp[1] = t.x2; t.srs[1] = t.n0; t.shi[1] = t.n0; t.spx2 = 2;
+        break;
+    case EPI_DX_POLICYBWD:
+        t.sp[0] = t.x0; t.srs[0] = 2 * t.n0; t.sof[0] = t.n0;
+        t.sp[1] = t.x2; t.srs[1] = t.n0; t.spx2 = 2;
+        t.sp[2] = t.x1; t.srs[2] = t.ldx1;
+        break;
+    case EPI_DX_REPARAM:
+        t.sp[0] = t.aux3; t.srs[0] = t.ldaux3;
+        t.sp[1] = t.C; t.srs[1] = t.ldc;
+        t.sp[2] = t.C; t.srs[2] = t.ldc; t.sof[2] = t.F;
+        break;
+    default:   // EPI_DW
+        if (t.flags & FLAG_ACCUM) { t.sp[1] = t.C; t.srs[1] = t.ldc; }
+        if (t.ad_p) {      // optimizer fused in: the tile of the parameter, its Adam moments (and its Polyak target)
+            t.sp[0] = t.ad_p; t.sp[2] = t.ad_m; t.sp[3] = t.ad_v; t.sp[4] = t.ad_t;
+            t.srs[0] = t.srs[2] = t.srs[3] = t.srs[4] = t.ldc;
+        }
+    }
+}
+
 #define GEMM_MAX_TASKS 8
 struct FinTask;
 // passed by value (kernarg segment).  nfin > 0: the launch has one extra trailing workgroup that runs the step's metric
 // finalisation / temperature update (the optimizer itself then runs in the EPI_DW epilogues: GemmTask::ad_*)
-struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
+// tb / tcs: first tile and column tiles of each task, copied next to the header by the launcher so that a workgroup finds its task and its
+// tile coordinates from ONE burst of scalar loads (then the task record with a second one), instead of a round trip per dependent field
+struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; int pad_; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)

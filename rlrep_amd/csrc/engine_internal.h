@@ -297,6 +297,7 @@ struct Builder {
                 for (GemmTask t : cp.tasks) {
                     t.tiles_c = (t.Cn + 15) / 16; t.ntiles = rbg * t.tiles_c; t.tile_base = base;
                     ph.tb[q] = base; ph.tcs[q] = t.tiles_c; ++q;
+                    rl_gemm16_plan(t);
                     base += t.ntiles;
                     tasks.push_back(t);
                 }

@@ -63,18 +63,23 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     TIM(0);
     // latency-critical launch: win the issue arbitration against the waves of a noise-critic launch that may be running on the
     // other stream of the deferred pipeline (405.8 vs 429.7 us per train(); alone on the chip it changes nothing)
-    if (!gb.low_prio) __builtin_amdgcn_s_setprio(3);
+    // header + per-task tile ranges: one burst of scalar loads (unused entries of tb are INT_MAX)
+    const int nfin = gb.nfin, low_prio = gb.low_prio;
+    int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS];
+#pragma unroll
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) { tb[q] = gb.tb[q]; tcs[q] = gb.tcs[q]; }
+    if (!low_prio) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x;
-    if (gb.nfin > 0 && bid == (int)gridDim.x - 1) {      // trailing workgroup: metric finalisation / temperature update
-        if (threadIdx.x < 64) finalize_tasks(gb.fin, gb.nfin, threadIdx.x);
+    if (nfin > 0 && bid == (int)gridDim.x - 1) {      // trailing workgroup: metric finalisation / temperature update
+        if (threadIdx.x < 64) finalize_tasks(gb.fin, nfin, threadIdx.x);
         return;
     }
-    int ti = 0;
+    int ti = 0, base = tb[0], tiles_c = tcs[0];
 #pragma unroll
-    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= tb[q]) { ti = q; base = tb[q]; tiles_c = tcs[q]; }
     const GemmTask& t = gb.t[ti];
-    const int local = bid - t.tile_base;
-    const int tr = local / t.tiles_c, tc = local - tr * t.tiles_c;
+    const int local = bid - base;
+    const int tr = local / tiles_c, tc = local - tr * tiles_c;
 #ifdef RL_TIMING
     float* const pC = t.C; const int epi = t.epi;
     gemm16_tile<LA, LB, NF, VA, VB, PRE, false>(t, tr, tc, red, bsum, nullptr, tim_c);
@@ -105,8 +110,14 @@ static bool all_vec(const GemmBatch& gb, bool opB) {
     return true;
 }
 
-extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb, int total_tiles, hipStream_t st) {
+extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
+    // the epilogue operand slots travel in the record (common.h rl_gemm16_plan): filled here, on the launcher's copy, after the caller's
+    // per-call patches (noise pointers)
+    GemmBatch planned = *gb_in;
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) { planned.tb[q] = 0x7fffffff; planned.tcs[q] = 1; }
+    for (int q = 0; q < planned.ntasks; ++q) { rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c; }
+    const GemmBatch* const gb = &planned;
     dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
     if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch: every task carries FLAG_PRE (and agrees on the form)
         const int fw = gb->t[0].flags & FLAG_PRE_FWD;

@@ -11,6 +11,9 @@
 // C/D: col=l&15, row=4*(l>>4)+reg.  The inner index may be permuted freely as long as A and B agree, so each lane takes FOUR
 // CONSECUTIVE inner indices (one 16-byte load in the row-contiguous case) and feeds them to four successive MFMAs.
 #pragma once
+#ifndef RL_UNIFORM_W
+#define RL_UNIFORM_W 1
+#endif
 #include "common.h"
 #include "kparams.h"
 
@@ -177,110 +180,49 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // through a generic pointer hipcc reads every field with a vector load + s_waitcnt vmcnt(0), one L2 round trip each).
 #define RL_CONST_AS __attribute__((address_space(4)))
 
-// Everything a tile needs that is UNIFORM and known from its task record alone: the hot block of the record and the epilogue's operand
-// slots.  gemm16_prep fills it (scalar loads + scalar code only); a persistent caller runs it BEFORE it waits for the tile's inputs, so
-// that the record's two dependent L2 round trips (~1 800 cycles, xc_timeline "record" + "slots") hide behind the wait.
-struct G16Plan {
-    const float *pA, *pB, *pbias, *paux, *pr1u, *pr1v, *px2; float *pC, *pout2;
-    int lda, ldb, ldc, ldaux, ldout2, R, Cn, K, epi, act, flags, n0, local, r0, c0, tc;
-    float scale;
-    // The epilogue kind only selects up to five SLOT descriptors (base, row stride, column stride, offset, column window); the loads
-    // themselves are generic and branch-free (a lane outside its window reads the slot's base address and the value is discarded)
-    const float* sp[5]; int srs[5], scs[5], sof[5], slo[5], shi[5];
-};
-
-// The record fields the plan is made of, as raw values: gemm16_load only ISSUES the scalar loads (nothing uses a value), so a caller that
-// has something to wait for in between -- xchain's poll of its group's flags -- overlaps the record's L2 round trip with that wait;
-// gemm16_slots then derives the plan (scalar code only).
-struct G16Raw {
-    const float *A, *B, *bias, *aux, *r1u, *r1v, *x0, *x1, *x2, *aux3; float *C, *out2;
-    int lda, ldb, ldc, ldaux, ldout2, R, Cn, K, epi, act, flags, n0, tiles_c, ldx0, ldx1, ldaux3, F;
-    float scale;
-};
-template <class TaskT>
-__device__ __forceinline__ void gemm16_load(const TaskT& t, G16Raw& r) {
-    r.A = t.A; r.B = t.B; r.C = t.C; r.bias = t.bias; r.aux = t.aux; r.r1u = t.r1u; r.r1v = t.r1v;
-    r.lda = t.lda; r.ldb = t.ldb; r.ldc = t.ldc; r.ldaux = t.ldaux; r.R = t.R; r.Cn = t.Cn; r.K = t.K; r.tiles_c = t.tiles_c;
-    r.epi = t.epi; r.act = t.act; r.flags = t.flags; r.scale = t.scale; r.n0 = t.n0; r.out2 = t.out2; r.ldout2 = t.ldout2;
-    r.x0 = t.x0; r.x1 = t.x1; r.x2 = t.x2; r.aux3 = t.aux3; r.ldx0 = t.ldx0; r.ldx1 = t.ldx1; r.ldaux3 = t.ldaux3; r.F = t.F;
-}
-template <int NF, bool COH, class TaskT>
-__device__ __forceinline__ void gemm16_slots(const TaskT& t, const G16Raw& r, const int tr, const int tc, const float* const* dyn, G16Plan& P) {
-    P.pA = r.A; P.pB = r.B; P.pC = r.C; P.pbias = r.bias; P.paux = r.aux; P.pr1u = r.r1u; P.pr1v = r.r1v;
-    P.lda = r.lda; P.ldb = r.ldb; P.ldc = r.ldc; P.ldaux = r.ldaux;
-    P.R = r.R; P.Cn = r.Cn; P.K = r.K;
-    P.epi = r.epi; P.act = r.act; P.flags = r.flags; P.n0 = r.n0; P.scale = r.scale;
-    P.pout2 = r.out2; P.ldout2 = r.ldout2;
-    P.px2 = r.x2;
-    if (COH && dyn) P.px2 = (P.flags & FLAG_DYN_EPS) ? dyn[0] : (P.flags & FLAG_DYN_EPS2) ? dyn[1] : (P.flags & FLAG_DYN_EPS3) ? dyn[2] : P.px2;
-    P.local = tr * r.tiles_c + tc; P.tc = tc;
-    P.r0 = tr * 16; P.c0 = tc * 16 * NF;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) { P.sp[q] = nullptr; P.srs[q] = 0; P.scs[q] = 1; P.sof[q] = 0; P.slo[q] = 0; P.shi[q] = P.Cn; }
-    switch (P.epi) {
-    case EPI_FWD: P.sp[0] = P.pbias; break;
-    case EPI_DX:
-        if (P.act != ACT_NONE) { P.sp[0] = P.paux; P.srs[0] = P.ldaux; }
-        if (P.flags & FLAG_ACCUM) { P.sp[1] = P.pC; P.srs[1] = P.ldc; }
-        if (P.pr1u) { P.sp[2] = P.pr1u; P.srs[2] = 1; P.scs[2] = 0; P.sp[3] = P.pr1v; }
-        break;
-    case EPI_FWD_MSE:
-        P.sp[0] = P.pbias;
-        P.sp[1] = r.x0; P.srs[1] = r.ldx0; P.shi[1] = P.n0;
-        P.sp[2] = r.x1; P.srs[2] = 1; P.scs[2] = 0; P.slo[2] = P.n0;
-        break;
-    case EPI_FWD_POLICY:
-        P.sp[0] = P.pbias;
-        P.sp[1] = P.px2; P.srs[1] = P.n0; P.shi[1] = P.n0;
-        break;
-    case EPI_DX_POLICYBWD:
-        P.sp[0] = r.x0; P.srs[0] = 2 * P.n0; P.sof[0] = P.n0;
-        P.sp[1] = P.px2; P.srs[1] = P.n0;
-        P.sp[2] = r.x1; P.srs[2] = r.ldx1;
-        break;
-    case EPI_DX_REPARAM:
-        P.sp[0] = r.aux3; P.srs[0] = r.ldaux3;
-        P.sp[1] = P.pC; P.srs[1] = P.ldc;
-        P.sp[2] = P.pC; P.srs[2] = P.ldc; P.sof[2] = r.F;
-        break;
-    default:   // EPI_DW
-        if (P.flags & FLAG_ACCUM) { P.sp[1] = P.pC; P.srs[1] = P.ldc; }
-        if constexpr (!COH) {
-            if (t.ad_p) {      // optimizer fused in: the tile of the parameter, its Adam moments (and its Polyak target)
-                P.sp[0] = t.ad_p; P.sp[2] = t.ad_m; P.sp[3] = t.ad_v; P.sp[4] = t.ad_t;
-                P.srs[0] = P.srs[2] = P.srs[3] = P.srs[4] = P.ldc;
-            }
-        }
-    }
-}
-template <int NF, bool COH, class TaskT>
-__device__ __forceinline__ void gemm16_prep(const TaskT& t, const int tr, const int tc, const float* const* dyn, G16Plan& P) {
-    G16Raw r;
-    gemm16_load<TaskT>(t, r);
-    gemm16_slots<NF, COH, TaskT>(t, r, tr, tc, dyn, P);
-}
-
-// One output tile of task t (plan P from gemm16_prep).
+// One output tile (row tile tr, column tile tc) of task t.  `dyn`: the per-call noise pointers of a launch whose task table lives in
+// device memory (xchain: FLAG_DYN_EPS* select dyn[0..2] for the slots whose base is x2); nullptr where the caller patched t.x2 itself
+// before it planned the record (rl_gemm16_plan).
 template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask>
-__device__ __forceinline__ void gemm16_run(const TaskT& t, const G16Plan& P, float (&red)[4][NF][4][64], float (&bsum)[4][16] RL_TIM_PARAM) {
-    const float* const pA = P.pA; const float* const pB = P.pB; float* const pC = P.pC; const float* const pbias = P.pbias;
-    const int lda = P.lda, ldb = P.ldb, ldc = P.ldc;
-    const int R = P.R, Cn = P.Cn, K = P.K;
-    const int epi = P.epi, act = P.act, flags = P.flags, n0 = P.n0;
-    const float scale = P.scale;
-    float* const pout2 = P.pout2; const int ldout2 = P.ldout2;
-    const int local = P.local, tc = P.tc, r0 = P.r0, c0 = P.c0;
+__device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
+                                            const float* const* dyn RL_TIM_PARAM) {
+    // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
+    const float* const pA = t.A; const float* const pB = t.B; float* const pC = t.C; const float* const pbias = t.bias;
+    const int lda = t.lda, ldb = t.ldb, ldc = t.ldc;
+    const int R = t.R, Cn = t.Cn, K = t.K, tiles_c = t.tiles_c;
+    const int epi = t.epi, act = t.act, flags = t.flags, n0 = t.n0;
+    const float scale = t.scale;
+    float* const pout2 = t.out2; const int ldout2 = t.ldout2;
     const float* sp[5]; int srs[5], scs[5], sof[5], slo[5], shi[5];
+    const int scs0 = t.scs0, spx2 = t.spx2;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { sp[q] = P.sp[q]; srs[q] = P.srs[q]; scs[q] = P.scs[q]; sof[q] = P.sof[q]; slo[q] = P.slo[q]; shi[q] = P.shi[q]; }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = 0; q < 5; ++q) { sp[q] = t.sp[q]; srs[q] = t.srs[q]; sof[q] = t.sof[q]; slo[q] = t.slo[q]; shi[q] = t.shi[q]; scs[q] = (scs0 >> q) & 1 ? 0 : 1; }
+    if (COH && dyn && spx2) {
+        const float* const px2 = (flags & FLAG_DYN_EPS) ? dyn[0] : (flags & FLAG_DYN_EPS2) ? dyn[1] : (flags & FLAG_DYN_EPS3) ? dyn[2] : sp[1];
+        sp[1] = px2;               // (x2 is slot 1 wherever it is a slot)
+    }
+    // (materialise the whole record HERE: left to itself hipcc loads each slot field next to its first use, between the operand loads,
+    // with a scalar-load round trip in front of every one of them)
+    asm volatile("" :: "s"(pA), "s"(pB), "s"(pC), "s"(pbias), "s"(lda), "s"(ldb), "s"(ldc), "s"(R), "s"(Cn), "s"(K), "s"(epi), "s"(act), "s"(flags), "s"(n0), "s"(scale));
+    asm volatile("" :: "s"(sp[0]), "s"(sp[1]), "s"(sp[2]), "s"(sp[3]), "s"(sp[4]), "s"(srs[0]), "s"(srs[1]), "s"(srs[2]), "s"(srs[3]), "s"(srs[4]),
+                 "s"(sof[0]), "s"(sof[1]), "s"(sof[2]), "s"(sof[3]), "s"(sof[4]));
+    asm volatile("" :: "s"(slo[0]), "s"(slo[1]), "s"(slo[2]), "s"(slo[3]), "s"(slo[4]), "s"(shi[0]), "s"(shi[1]), "s"(shi[2]), "s"(shi[3]), "s"(shi[4]), "s"(scs0));
+    TIMB(1);
+    const int local = tr * tiles_c + tc;
+    const int r0 = tr * 16, c0 = tc * 16 * NF;
+    // (w is wave-uniform but a VGPR value to hipcc: without the readfirstlane the K loop and the `nu` dispatch below are exec-masked
+    // divergent control flow -- saveexec ladders, accumulator copies through VGPRs, conservative waits at every merge)
+    const int lane = threadIdx.x & 63, w = RL_UNIFORM_W ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     const int i = lane & 15, kq = lane >> 4;
 
     f32x4 acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    const bool want_bias = !COH && (epi == EPI_DW) && (flags & FLAG_BIASGRAD) && (tc == 0);
+    // (weight gradients are the k-major / k-major launches: every other instantiation drops the bias-gradient and fused-optimizer code,
+    // whose speculative record loads otherwise sit, round trip by round trip, in front of the operand loads)
+    constexpr bool DW = !COH && LA == LD_COL && LB == LD_COL;
+    const bool want_bias = DW && (epi == EPI_DW) && (flags & FLAG_BIASGRAD) && (tc == 0);
     TIMB(5);
     const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
     const int r = r0 + (ol >> 4) * 4 + oreg;
@@ -306,10 +248,11 @@ __device__ __forceinline__ void gemm16_run(const TaskT& t, const G16Plan& P, flo
 
     // fused optimizer: Adam scalars of the group, and (column-tile 0 only) the bias element this thread will update
     AdamScal adsc;
-    const bool fuse_opt = !COH && (epi == EPI_DW) && t.ad_p;
-    if constexpr (!COH) { if (fuse_opt) adsc = t.ad_grp->sc; }
+    bool fuse_opt = false;
+    if constexpr (DW) { fuse_opt = (epi == EPI_DW) && t.ad_p; if (fuse_opt) adsc = t.ad_grp->sc; }
     float bpv = 0.f, bmv = 0.f, bvv = 0.f, btv = 0.f;
-    const bool bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
+    bool bias_opt = false;
+    if constexpr (DW) bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
     if (bias_opt) {
         const int o = r0 + threadIdx.x;
         bpv = t.ad_pb[o]; bmv = t.ad_mb[o]; bvv = t.ad_vb[o];
@@ -490,18 +433,4 @@ __device__ __forceinline__ void gemm16_run(const TaskT& t, const G16Plan& P, flo
         } break;
         }
     }
-}
-
-// prep + run: one tile, record read at the point of use (gemm16_kernel: the record is in the kernel-argument segment)
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask>
-__device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
-                                            const float* const* dyn RL_TIM_PARAM) {
-    G16Plan P;
-    gemm16_prep<NF, COH, TaskT>(t, tr, tc, dyn, P);
-#ifdef RL_TIMING
-    TIMB(1);
-    gemm16_run<LA, LB, NF, VA, VB, PRE, COH, TaskT>(t, P, red, bsum, tim_c);
-#else
-    gemm16_run<LA, LB, NF, VA, VB, PRE, COH, TaskT>(t, P, red, bsum);
-#endif
 }

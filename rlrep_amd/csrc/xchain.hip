@@ -54,18 +54,17 @@ typedef RL_CONST_AS GemmTask XcTask;
 typedef RL_CONST_AS XcPhase XcPh;
 typedef RL_CONST_AS HeadsVae XcHv;
 
-// run one GEMM tile whose plan is ready (gemm16_prep ran before the wait)
 template <int LA, int LB, bool VA, bool VB, bool PRE>
-__device__ __forceinline__ void xc_gemm_run(const XcTask& t, const G16Plan& P, float* smem, float (&bsum)[4][16], unsigned long long* timc) {
+__device__ __forceinline__ void xc_gemm_tile(const XcTask& t, int tr, int tc, float* smem, float (&bsum)[4][16], const float* const* dyn, unsigned long long* timc) {
     auto& red = *reinterpret_cast<float (*)[4][1][4][64]>(smem);
 #ifdef RL_TIMING
-    gemm16_run<LA, LB, 1, VA, VB, PRE, true, XcTask>(t, P, red, bsum, timc);
+    gemm16_tile<LA, LB, 1, VA, VB, PRE, true, XcTask>(t, tr, tc, red, bsum, dyn, timc);
 #else
     (void)timc;
-    gemm16_run<LA, LB, 1, VA, VB, PRE, true, XcTask>(t, P, red, bsum);
+    gemm16_tile<LA, LB, 1, VA, VB, PRE, true, XcTask>(t, tr, tc, red, bsum, dyn);
 #endif
 }
-#define XC_RUN(...) xc_gemm_run<__VA_ARGS__>(t, P, smem, bsum, timp)
+#define XC_RUN(...) xc_gemm_tile<__VA_ARGS__>(t, tr, tc, smem, bsum, L.dyn, timp)
 
 // tile index of a GEMM phase -> (task, row tile, column tile); false: the tile lies beyond the task's rows
 __device__ __forceinline__ bool xc_decode(const XcPh& ph, const XcTask* tasks, int g, int tile, int& ti, int& tr, int& tc) {
@@ -103,16 +102,7 @@ __global__ __launch_bounds__(256) void xchain_kernel(XcLaunch L) {
         bool first_tile = true;
 #endif
         XCT(0);
-        // the first tile's record is static: decoded and read (scalar loads) BEFORE the wait for its inputs
         const XcTask* const tasks = (const XcTask*)L.tasks;
-        int ti0 = 0, tr0 = 0, tc0 = 0; bool live0 = false; G16Raw R0;
-#ifdef RL_TIMING_XC
-        if (threadIdx.x == 0) tcs[0] = clock64();
-#endif
-        if (ph.kind == XC_GEMM && m < ph.tiles) {
-            live0 = xc_decode(ph, tasks, g, m, ti0, tr0, tc0);
-            if (live0) gemm16_load<XcTask>(tasks[ti0], R0);            // (issued only: consumed by gemm16_slots after the wait)
-        }
         if (p > 0) {
             // every member of my group has finished phase p - 1
             if (w == 0 && !dead_s) {
@@ -135,16 +125,11 @@ __global__ __launch_bounds__(256) void xchain_kernel(XcLaunch L) {
             if (!first) __syncthreads();          // the reduction buffers of the previous tile are still being read
             if (ph.kind == XC_GEMM) {
                 int ti, tr, tc;
-                G16Plan P;
-                if (first) { ti = ti0; tr = tr0; tc = tc0; if (!live0) { first = false; continue; } gemm16_slots<1, true, XcTask>(tasks[ti], R0, tr, tc, L.dyn, P); }
-                else {
-                    if (!xc_decode(ph, tasks, g, tile, ti, tr, tc)) continue;
-                    gemm16_prep<1, true, XcTask>(tasks[ti], tr, tc, L.dyn, P);
-                }
+                if (!xc_decode(ph, tasks, g, tile, ti, tr, tc)) { first = false; continue; }
                 const XcTask& t = tasks[ti];
 #ifdef RL_TIMING_XC
                 unsigned long long* const timp = first_tile ? tcs : nullptr;
-                if (first_tile && threadIdx.x == 0) tcs[1] = clock64();
+                if (first_tile && threadIdx.x == 0) tcs[0] = clock64();
 #else
                 unsigned long long* const timp = nullptr;
 #endif
