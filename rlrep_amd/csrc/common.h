@@ -142,7 +142,8 @@ struct FinTask;
 // finalisation / temperature update (the optimizer itself then runs in the EPI_DW epilogues: GemmTask::ad_*)
 // tb / tcs: first tile and column tiles of each task, copied next to the header by the launcher so that a workgroup finds its task and its
 // tile coordinates from ONE burst of scalar loads (then the task record with a second one), instead of a round trip per dependent field
-struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; int pad_; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
+// total: tiles of the launch (the trailing finalisation workgroup, if any, is block `total`; reading gridDim costs a round trip of its own)
+struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; int total; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)

@@ -28,7 +28,7 @@
 // Instrumented build (tools/exp/gemm_timeline.py): thread 0 of every 8th workgroup records the 100 MHz wall clock at
 // entry and exit and the shader clock at entry, once its task record is in registers, after its MFMAs, after the
 // reduction barrier and at exit.  Slot = launch sequence number (bumped by workgroup 0 at exit) * 2048 + blockIdx.x.
-struct RlTimRec { unsigned long long w0, w4, c[5]; int grid, bid; unsigned tag, valid; };
+struct RlTimRec { unsigned long long w0, w4, c[8]; int grid, bid; unsigned tag, valid; };
 __device__ RlTimRec* g_tim = nullptr;
 __device__ unsigned g_tim_launch = 0, g_tim_cap = 0;
 extern "C" int rl_timing_buffer(void* buf, unsigned cap) {
@@ -43,7 +43,7 @@ extern "C" unsigned rl_timing_count() { unsigned n = 0; (void)hipMemcpyFromSymbo
 #define TIM(k) do { if (TIM_ON) tim_c[k] = clock64(); } while (0)
 #define TIM_FIN() do { if (threadIdx.x == 0 && g_tim) { if (TIM_ON) { tim_c[4] = clock64(); const unsigned long long w4 = wall_clock64(); \
     const unsigned slot = tim_lid * 2048u + blockIdx.x; \
-    if (slot < g_tim_cap) { RlTimRec r; r.w0 = tim_w0; r.w4 = w4; for (int q = 0; q < 5; ++q) r.c[q] = tim_c[q]; r.grid = gridDim.x; r.bid = blockIdx.x; \
+    if (slot < g_tim_cap) { RlTimRec r; r.w0 = tim_w0; r.w4 = w4; for (int q = 0; q < 8; ++q) r.c[q] = tim_c[q]; r.grid = gridDim.x; r.bid = blockIdx.x; \
     r.tag = (unsigned)(((uintptr_t)pC) >> 4) ^ ((unsigned)epi << 28); r.valid = 1; g_tim[slot] = r; } } \
     if (blockIdx.x == 0) atomicAdd(&g_tim_launch, 1u); } } while (0)
 #else
@@ -51,7 +51,7 @@ extern "C" unsigned rl_timing_count() { unsigned n = 0; (void)hipMemcpyFromSymbo
 #define TIM_FIN() do {} while (0)
 #endif
 
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false>
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false, int EPI_K = -1, int ACT_K = -1>
 __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
@@ -64,13 +64,15 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     // latency-critical launch: win the issue arbitration against the waves of a noise-critic launch that may be running on the
     // other stream of the deferred pipeline (405.8 vs 429.7 us per train(); alone on the chip it changes nothing)
     // header + per-task tile ranges: one burst of scalar loads (unused entries of tb are INT_MAX)
-    const int nfin = gb.nfin, low_prio = gb.low_prio;
+    const int nfin = gb.nfin, low_prio = gb.low_prio, total = gb.total;
     int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS];
 #pragma unroll
     for (int q = 0; q < GEMM_MAX_TASKS; ++q) { tb[q] = gb.tb[q]; tcs[q] = gb.tcs[q]; }
+    asm volatile("" :: "s"(nfin), "s"(low_prio), "s"(total), "s"(tb[0]), "s"(tb[1]), "s"(tb[2]), "s"(tb[3]), "s"(tb[4]), "s"(tb[5]), "s"(tb[6]), "s"(tb[7]),
+                 "s"(tcs[0]), "s"(tcs[1]), "s"(tcs[2]), "s"(tcs[3]), "s"(tcs[4]), "s"(tcs[5]), "s"(tcs[6]), "s"(tcs[7]));
     if (!low_prio) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x;
-    if (nfin > 0 && bid == (int)gridDim.x - 1) {      // trailing workgroup: metric finalisation / temperature update
+    if (nfin > 0 && bid == total) {      // trailing workgroup: metric finalisation / temperature update
         if (threadIdx.x < 64) finalize_tasks(gb.fin, nfin, threadIdx.x);
         return;
     }
@@ -82,9 +84,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     const int tr = local / tiles_c, tc = local - tr * tiles_c;
 #ifdef RL_TIMING
     float* const pC = t.C; const int epi = t.epi;
-    gemm16_tile<LA, LB, NF, VA, VB, PRE, false>(t, tr, tc, red, bsum, nullptr, tim_c);
+    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K>(t, tr, tc, red, bsum, nullptr, tim_c);
 #else
-    gemm16_tile<LA, LB, NF, VA, VB, PRE, false>(t, tr, tc, red, bsum, nullptr);
+    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K>(t, tr, tc, red, bsum, nullptr);
 #endif
     TIM_FIN();
 }
@@ -97,6 +99,22 @@ static void launch_nf(int nf, dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (nf == 1) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB>), g, dim3(256), 0, st, gb);
     else if (nf == 2) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 2, VA, VB>), g, dim3(256), 0, st, gb);
     else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 4, VA, VB>), g, dim3(256), 0, st, gb);
+}
+
+// NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
+// instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
+template <int LA, int LB, bool VA, bool VB>
+static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
+    if (getenv("RLREP_GEMM16_GENERIC")) return false;
+    const int epi = gb.t[0].epi, act = gb.t[0].act;
+    if (gb.nfin > 0 || (epi != EPI_FWD && epi != EPI_DX) || (act != ACT_NONE && act != ACT_RELU && act != ACT_ELU)) return false;
+    if ((LB == LD_ROW) != (epi == EPI_FWD)) return false;
+    for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].epi != epi || gb.t[q].act != act || (gb.t[q].flags & FLAG_PRE)) return false;
+    constexpr int E = LB == LD_ROW ? (int)EPI_FWD : (int)EPI_DX;
+    if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, E, ACT_NONE>), g, dim3(256), 0, st, gb);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, E, ACT_RELU>), g, dim3(256), 0, st, gb);
+    else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, E, ACT_ELU>), g, dim3(256), 0, st, gb);
+    return true;
 }
 
 // 16-byte operand loads are legal for a launch only if EVERY task of it has 4-float-aligned rows and inner length
@@ -117,6 +135,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     GemmBatch planned = *gb_in;
     for (int q = 0; q < GEMM_MAX_TASKS; ++q) { planned.tb[q] = 0x7fffffff; planned.tcs[q] = 1; }
     for (int q = 0; q < planned.ntasks; ++q) { rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c; }
+    planned.total = total_tiles;
     const GemmBatch* const gb = &planned;
     dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
     if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch: every task carries FLAG_PRE (and agrees on the form)
@@ -137,11 +156,11 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         return (int)hipGetLastError();
     }
     if (la == LD_ROW && lb == LD_ROW) {
-        if (all_vec(*gb, false) && all_vec(*gb, true)) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb);
-        else launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
+        if (all_vec(*gb, false) && all_vec(*gb, true)) { if (nf != 1 || !launch_spec<LD_ROW, LD_ROW, true, true>(g, st, *gb)) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb); }
+        else if (nf != 1 || !launch_spec<LD_ROW, LD_ROW, false, false>(g, st, *gb)) launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
     } else if (la == LD_ROW && lb == LD_COL) {
-        if (all_vec(*gb, false)) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb);
-        else launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
+        if (all_vec(*gb, false)) { if (nf != 1 || !launch_spec<LD_ROW, LD_COL, true, false>(g, st, *gb)) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
+        else if (nf != 1 || !launch_spec<LD_ROW, LD_COL, false, false>(g, st, *gb)) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
     } else if (la == LD_COL && lb == LD_COL) launch_nf<LD_COL, LD_COL, false, false>(nf, g, st, *gb);
     else return -1;
     return (int)hipGetLastError();

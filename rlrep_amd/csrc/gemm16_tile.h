@@ -183,14 +183,18 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // One output tile (row tile tr, column tile tc) of task t.  `dyn`: the per-call noise pointers of a launch whose task table lives in
 // device memory (xchain: FLAG_DYN_EPS* select dyn[0..2] for the slots whose base is x2); nullptr where the caller patched t.x2 itself
 // before it planned the record (rl_gemm16_plan).
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask>
+// EPI_K / ACT_K: the epilogue kind / activation as COMPILE-TIME constants (-1: read from the record).  A launch whose tasks all share a
+// plain forward or dX epilogue runs an instantiation that contains nothing else: the generic body is ~2 900 instructions, and its
+// epilogue walks a ladder of far scalar branches through cold code (instruction-cache misses: 1 200 - 2 800 cycles between "reduction
+// barrier passed" and "tile stored" in tools/exp/gemm_timeline.py, for five VALU instructions and a store).
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
                                             const float* const* dyn RL_TIM_PARAM) {
     // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
     const float* const pA = t.A; const float* const pB = t.B; float* const pC = t.C; const float* const pbias = t.bias;
     const int lda = t.lda, ldb = t.ldb, ldc = t.ldc;
     const int R = t.R, Cn = t.Cn, K = t.K, tiles_c = t.tiles_c;
-    const int epi = t.epi, act = t.act, flags = t.flags, n0 = t.n0;
+    const int epi = EPI_K >= 0 ? EPI_K : t.epi, act = ACT_K >= 0 ? ACT_K : t.act, flags = t.flags, n0 = t.n0;
     const float scale = t.scale;
     float* const pout2 = t.out2; const int ldout2 = t.ldout2;
     const float* sp[5]; int srs[5], scs[5], sof[5], slo[5], shi[5];

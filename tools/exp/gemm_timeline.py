@@ -19,7 +19,7 @@ buf, _ = bench.synth_buffer(S, A, 0)
 for _ in range(20): agent.train(buf, B)
 torch.cuda.synchronize()
 NL = 80; CAP = NL * 2048
-tb = torch.zeros(CAP * 9, dtype=torch.int64, device='cuda')          # RlTimRec is 72 bytes
+tb = torch.zeros(CAP * 12, dtype=torch.int64, device='cuda')          # RlTimRec is 96 bytes
 assert raw.rl_timing_buffer(C.c_void_p(tb.data_ptr()), CAP) == 0
 for _ in range(3): agent.train(buf, B)
 torch.cuda.synchronize()
@@ -30,19 +30,20 @@ e0.record(); agent.train(buf, B); e1.record()
 torch.cuda.synchronize()
 print('this train(): %.1f us by events' % (e0.elapsed_time(e1) * 1e3))
 nl = raw.rl_timing_count()
-rec = tb.cpu().numpy().reshape(CAP, 9)
+rec = tb.cpu().numpy().reshape(CAP, 12)
 print(f'{nl} gemm16 launches; wall times in us (100 MHz clock), phases in shader cycles / 2200 = us')
-print(' #   WGs  gap_prev  ramp   span  | median per sampled WG: record  loads+mfma  reduce  epilogue   life (max)')
+print(' #   WGs  gap_prev  ramp   span  | median per sampled WG (cycles): find task  record  slot loads issued  operands+mfma  reduce  epilogue |  life us (max)')
 prev = None; tot = 0.0
 for k in range(nl):
-    r = rec[k * 2048:(k + 1) * 2048]; r = r[(r[:, 8] >> 32) == 1]
+    r = rec[k * 2048:(k + 1) * 2048]; r = r[(r[:, 11] >> 32) == 1]
     if not len(r): continue
-    w0, w4, c = r[:, 0], r[:, 1], r[:, 2:7]
-    grid = int(r[0, 7] & 0xffffffff)
+    w0, w4 = r[:, 0], r[:, 1]
+    c = np.stack([r[:, 2], r[:, 3], r[:, 7], r[:, 8], r[:, 4], r[:, 5], r[:, 6]], axis=1)     # entry, record (1), (5), slot loads issued (6), mfma done (2), reduced (3), exit (4)
+    grid = int(r[0, 10] & 0xffffffff)
     gap = (w0.min() - prev) / 100 if prev is not None else 0.0
-    ph = np.median(np.diff(c, axis=1), axis=0) / 2200.0
-    life = (c[:, 4] - c[:, 0]) / 2200.0
-    print(f"{k:3d} {grid:5d}  {gap:7.2f} {(w0.max()-w0.min())/100:6.2f} {(w4.max()-w0.min())/100:6.2f}  |  {ph[0]:6.2f} {ph[1]:9.2f} {ph[2]:8.2f} {ph[3]:8.2f}   {np.median(life):6.2f} ({life.max():.2f})")
+    d = np.diff(c, axis=1); ph = np.median(d, axis=0); ph = np.array([ph[0], ph[1] + 0, ph[2], ph[3], ph[4], ph[5]])
+    life = (c[:, 6] - c[:, 0]) / 2200.0
+    print(f"{k:3d} {grid:5d}  {gap:7.2f} {(w0.max()-w0.min())/100:6.2f} {(w4.max()-w0.min())/100:6.2f}  |  {ph[0]:8.0f} {ph[1]:8.0f} {ph[2]:8.0f} {ph[3]:10.0f} {ph[4]:8.0f} {ph[5]:8.0f}  | {np.median(life):6.2f} ({life.max():.2f})")
     tot += (w4.max() - w0.min()) / 100
     prev = w4.max()
 print('sum of gemm16 kernel spans %.1f us' % tot)
