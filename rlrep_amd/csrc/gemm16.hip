@@ -161,7 +161,15 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     } else if (la == LD_ROW && lb == LD_COL) {
         if (all_vec(*gb, false)) { if (nf != 1 || !launch_spec<LD_ROW, LD_COL, true, false>(g, st, *gb)) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
         else if (nf != 1 || !launch_spec<LD_ROW, LD_COL, false, false>(g, st, *gb)) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
-    } else if (la == LD_COL && lb == LD_COL) launch_nf<LD_COL, LD_COL, false, false>(nf, g, st, *gb);
+    } else if (la == LD_COL && lb == LD_COL) {
+        // weight gradients with nothing to accumulate into and no fused optimizer: the instantiation without slot loads / optimizer code
+        bool plain = gb->nfin == 0 && !getenv("RLREP_GEMM16_GENERIC");
+        for (int q = 0; q < gb->ntasks; ++q) plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM) && !gb->t[q].ad_p;
+        if (plain && nf == 4) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 4, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, *gb);
+        else if (plain && nf == 2) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 2, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, *gb);
+        else if (plain && nf == 1) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 1, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, *gb);
+        else launch_nf<LD_COL, LD_COL, false, false>(nf, g, st, *gb);
+    }
     else return -1;
     return (int)hipGetLastError();
 }

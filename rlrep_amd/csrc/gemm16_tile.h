@@ -16,6 +16,7 @@
 #endif
 #include "common.h"
 #include "kparams.h"
+#include <type_traits>
 
 typedef unsigned rl_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -237,26 +238,36 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // register while the load is in flight -- tools/check_async_asm.py caught exactly that when this body moved into a header.)
     // ... and UNCONDITIONAL: a slot the epilogue does not use reads one word of operand A instead (discarded below).  An `if (slot in use)`
     // around the loads is a control-flow diamond, and hipcc drains vmcnt at every merge point: five exposed L2 round trips per tile.
+    // Slots that an instantiation with its epilogue compiled in can never use are not loaded at all: forward: slot 0 (bias); dX: 0-3 (saved
+    // activation, accumulate-into, rank-1 pair); weight gradient: none (its accumulate / fused-optimizer forms run the generic kernel).
     float ev[5][NF];
+    auto slot = [&](auto qtag) {
+        constexpr int q = decltype(qtag)::value;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const bool used = sp[q] != nullptr;
-        const float* const spq = used ? sp[q] : pA;
+        for (int f = 0; f < NF; ++f) ev[q][f] = 0.f;
+        constexpr bool possible = EPI_K < 0 || (EPI_K == EPI_FWD && q == 0) || (EPI_K == EPI_DX && q < 4);
+        if constexpr (possible) {
+            const bool used = sp[q] != nullptr;
+            const float* const spq = used ? sp[q] : pA;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const int c = c0 + 16 * f + (ol & 15);
-            const bool ok = used && (r < R) && (c >= slo[q]) && (c < shi[q]);
-            ev[q][f] = rl_ld<COH>(spq, ok ? (size_t)r * srs[q] + (size_t)(c * scs[q] + sof[q]) : (size_t)0);
+            for (int f = 0; f < NF; ++f) {
+                const int c = c0 + 16 * f + (ol & 15);
+                const bool ok = used && (r < R) && (c >= slo[q]) && (c < shi[q]);
+                ev[q][f] = rl_ld<COH>(spq, ok ? (size_t)r * srs[q] + (size_t)(c * scs[q] + sof[q]) : (size_t)0);
+            }
         }
-    }
+    };
+    slot(std::integral_constant<int, 0>()); slot(std::integral_constant<int, 1>()); slot(std::integral_constant<int, 2>());
+    slot(std::integral_constant<int, 3>()); slot(std::integral_constant<int, 4>());
 
     // fused optimizer: Adam scalars of the group, and (column-tile 0 only) the bias element this thread will update
     AdamScal adsc;
     bool fuse_opt = false;
-    if constexpr (DW) { fuse_opt = (epi == EPI_DW) && t.ad_p; if (fuse_opt) adsc = t.ad_grp->sc; }
+    constexpr bool DWOPT = DW && EPI_K < 0;        // (the plain weight-gradient instantiation carries no optimizer code)
+    if constexpr (DWOPT) { fuse_opt = (epi == EPI_DW) && t.ad_p; if (fuse_opt) adsc = t.ad_grp->sc; }
     float bpv = 0.f, bmv = 0.f, bvv = 0.f, btv = 0.f;
     bool bias_opt = false;
-    if constexpr (DW) bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
+    if constexpr (DWOPT) bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
     if (bias_opt) {
         const int o = r0 + threadIdx.x;
         bpv = t.ad_pb[o]; bmv = t.ad_mb[o]; bvv = t.ad_vb[o];
