@@ -103,18 +103,31 @@ static void launch_nf(int nf, dim3 g, hipStream_t st, const GemmBatch& gb) {
 
 // NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
 // instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
-template <int LA, int LB, bool VA, bool VB>
+template <int LA, int LB, int NF, bool VA, bool VB>
 static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (getenv("RLREP_GEMM16_GENERIC")) return false;
     const int epi = gb.t[0].epi, act = gb.t[0].act;
-    if (gb.nfin > 0 || (epi != EPI_FWD && epi != EPI_DX) || (act != ACT_NONE && act != ACT_RELU && act != ACT_ELU)) return false;
-    if ((LB == LD_ROW) != (epi == EPI_FWD)) return false;
+    if (gb.nfin > 0) return false;
     for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].epi != epi || gb.t[q].act != act || (gb.t[q].flags & FLAG_PRE)) return false;
-    constexpr int E = LB == LD_ROW ? (int)EPI_FWD : (int)EPI_DX;
-    if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, E, ACT_NONE>), g, dim3(256), 0, st, gb);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, E, ACT_RELU>), g, dim3(256), 0, st, gb);
-    else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, E, ACT_ELU>), g, dim3(256), 0, st, gb);
-    return true;
+    if (LB == LD_ROW && epi == EPI_FWD) {
+        if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, gb);
+        else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, gb);
+        else if (act == ACT_ELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_ELU>), g, dim3(256), 0, st, gb);
+        else return false;
+        return true;
+    }
+    if (LB == LD_COL && epi == EPI_DX) {
+        if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, gb);
+        else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_RELU>), g, dim3(256), 0, st, gb);
+        else if (act == ACT_ELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, gb);
+        else return false;
+        return true;
+    }
+    if (NF == 1 && LB == LD_ROW && epi == EPI_FWD_MSE) {       // vlsac decoder heads + mse
+        hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, EPI_FWD_MSE, ACT_NONE>), g, dim3(256), 0, st, gb);
+        return true;
+    }
+    return false;
 }
 
 // 16-byte operand loads are legal for a launch only if EVERY task of it has 4-float-aligned rows and inner length
@@ -151,16 +164,20 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
             else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, false, true>), g, dim3(256), 0, st, *gb);
         } else {
             if (lb != LD_COL) return -3;
-            hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+            bool rep = !getenv("RLREP_GEMM16_GENERIC"), plain = rep;
+            for (int q = 0; q < gb->ntasks; ++q) { rep = rep && gb->t[q].epi == EPI_DX_REPARAM; plain = plain && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_NONE; }
+            if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, *gb);
+            else if (plain) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, *gb);
+            else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, *gb);
         }
         return (int)hipGetLastError();
     }
     if (la == LD_ROW && lb == LD_ROW) {
-        if (all_vec(*gb, false) && all_vec(*gb, true)) { if (nf != 1 || !launch_spec<LD_ROW, LD_ROW, true, true>(g, st, *gb)) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb); }
-        else if (nf != 1 || !launch_spec<LD_ROW, LD_ROW, false, false>(g, st, *gb)) launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
+        if (all_vec(*gb, false) && all_vec(*gb, true)) { if (!(nf == 1 && launch_spec<LD_ROW, LD_ROW, 1, true, true>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_ROW, 2, true, true>(g, st, *gb))) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb); }
+        else if (!(nf == 1 && launch_spec<LD_ROW, LD_ROW, 1, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
     } else if (la == LD_ROW && lb == LD_COL) {
-        if (all_vec(*gb, false)) { if (nf != 1 || !launch_spec<LD_ROW, LD_COL, true, false>(g, st, *gb)) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
-        else if (nf != 1 || !launch_spec<LD_ROW, LD_COL, false, false>(g, st, *gb)) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
+        if (all_vec(*gb, false)) { if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, true, false>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_COL, 2, true, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
+        else if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
     } else if (la == LD_COL && lb == LD_COL) {
         // weight gradients with nothing to accumulate into and no fused optimizer: the instantiation without slot loads / optimizer code
         bool plain = gb->nfin == 0 && !getenv("RLREP_GEMM16_GENERIC");

@@ -245,7 +245,8 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         constexpr int q = decltype(qtag)::value;
 #pragma unroll
         for (int f = 0; f < NF; ++f) ev[q][f] = 0.f;
-        constexpr bool possible = EPI_K < 0 || (EPI_K == EPI_FWD && q == 0) || (EPI_K == EPI_DX && q < 4);
+        constexpr bool possible = EPI_K < 0 || (EPI_K == EPI_FWD && q == 0) || (EPI_K == EPI_DX && q < 4) ||
+                                  ((EPI_K == EPI_FWD_MSE || EPI_K == EPI_DX_REPARAM || EPI_K == EPI_DX_POLICYBWD) && q < 3) || (EPI_K == EPI_FWD_POLICY && q < 2);
         if constexpr (possible) {
             const bool used = sp[q] != nullptr;
             const float* const spq = used ? sp[q] : pA;
