@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RLREP_ABI_VERSION 1
+#define RLREP_ABI_VERSION 2      /* 2: rlrep_replay_add takes rows (no agent), rlrep_chain_status */
 
 typedef enum {
     RLREP_OK = 0,
@@ -179,8 +179,11 @@ int32_t rlrep_set_batch(rlrep_agent* agent, int32_t slot, const rlrep_batch* bat
 
 /* Device-resident replay ring: rows of [s | a | s' | r | d] (row length 2S+A+2 floats). */
 int32_t rlrep_replay_row_floats(const rlrep_dims* dims);
-int32_t rlrep_replay_add(rlrep_agent* agent, float* ring_dev, int64_t capacity, int64_t ptr,
-                         const float* row_host, void* stream);
+/* ReplayBuffer.add (utils/buffer.py:28-36), batched: `nrows` staged rows (pinned host memory, row_floats floats each) enter the ring at
+ * slot `ptr` and wrap around its end (ptr' = (ptr + nrows) % capacity is the caller's to keep, as `self.ptr` is in the reference).
+ * Asynchronous on `stream`: at most two copies.  nrows <= capacity. */
+int32_t rlrep_replay_add(float* ring_dev, int64_t capacity, int32_t row_floats, int64_t ptr,
+                         const float* rows_host, int64_t nrows, void* stream);
 /* gather rows idx_dev[0..batch) of the ring into a batch slot */
 int32_t rlrep_replay_sample(rlrep_agent* agent, int32_t slot, const float* ring_dev, const int32_t* idx_dev,
                             int32_t batch, void* stream);

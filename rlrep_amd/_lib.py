@@ -82,7 +82,7 @@ def _load():
         'rlrep_agent_destroy': (None, [vp]),
         'rlrep_set_batch': (i32, [vp, i32, P(Batch), vp]),
         'rlrep_replay_row_floats': (i32, [P(Dims)]),
-        'rlrep_replay_add': (i32, [vp, vp, i64, i64, vp, vp]),
+        'rlrep_replay_add': (i32, [vp, i64, i32, i64, vp, i64, vp]),
         'rlrep_replay_sample': (i32, [vp, i32, vp, vp, i32, vp]),
         'rlrep_fill_indices': (i32, [vp, i64, i32, u64, u64, vp]),
         'rlrep_fill_normal': (i32, [vp, i64, f32, u64, u64, vp]),
@@ -131,7 +131,7 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.rlrep_abi_version() != 1:
+    if lib.rlrep_abi_version() != 2:
         raise RuntimeError('librlrep_hip.so ABI version mismatch')
     return lib, sig
 

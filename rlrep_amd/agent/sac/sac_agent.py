@@ -233,9 +233,18 @@ class SACAgent(object):
         return self.core.alpha_state[0]
 
     def select_action(self, state, explore=False):
+        return self._select_action(state, explore)
+
+    def _select_action(self, state, explore=False, eps=None):
+        """sac_agent.py:89-96.  `eps` (tests): the [1, A] standard-normal draw of `dist.sample()` instead of a fresh one."""
         self.flush()
         obs = torch.as_tensor(np.asarray(state, dtype=np.float32)).reshape(1, -1).to(self.core.device)
-        eps = self._noise('sel', (1, self.action_dim)) if explore else None
+        if explore and eps is not None:
+            eps = torch.as_tensor(np.asarray(eps, dtype=np.float32)).reshape(1, self.action_dim).to(self.core.device)
+        elif explore:
+            eps = self._noise('sel', (1, self.action_dim))
+        else:
+            eps = None
         action = self.core.actor_forward(obs, eps, *self.action_range)
         assert action.ndim == 2 and action.shape[0] == 1
         return util.to_np(action[0])

@@ -1187,10 +1187,15 @@ int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, vo
 
 int32_t rlrep_replay_row_floats(const rlrep_dims* d) { return d ? 2 * d->state_dim + d->action_dim + 2 : RLREP_ERR_ARG; }
 
-int32_t rlrep_replay_add(rlrep_agent* ag, float* ring_dev, int64_t capacity, int64_t ptr, const float* row_host, void* stream) {
-    if (!ag || !ring_dev || !row_host || ptr < 0 || ptr >= capacity) { rl_set_error("replay_add: bad argument"); return RLREP_ERR_ARG; }
-    const int w = 2 * ag->d.state_dim + ag->d.action_dim + 2;
-    hipError_t e = hipMemcpyAsync(ring_dev + ptr * w, row_host, sizeof(float) * w, hipMemcpyHostToDevice, (hipStream_t)stream);
+int32_t rlrep_replay_add(float* ring_dev, int64_t capacity, int32_t row_floats, int64_t ptr, const float* rows_host, int64_t nrows, void* stream) {
+    if (!ring_dev || !rows_host || capacity <= 0 || row_floats <= 0 || ptr < 0 || ptr >= capacity || nrows < 0 || nrows > capacity) {
+        rl_set_error("replay_add: bad argument"); return RLREP_ERR_ARG;
+    }
+    const int64_t first = nrows < capacity - ptr ? nrows : capacity - ptr;
+    hipError_t e = hipSuccess;
+    if (first > 0) e = hipMemcpyAsync(ring_dev + ptr * row_floats, rows_host, sizeof(float) * first * row_floats, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess && first < nrows)        // across the wrap-around
+        e = hipMemcpyAsync(ring_dev, rows_host + first * row_floats, sizeof(float) * (nrows - first) * row_floats, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e != hipSuccess) { rl_set_error("replay_add: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
     return 0;
 }

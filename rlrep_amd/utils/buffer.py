@@ -78,17 +78,26 @@ class ReplayBuffer(object):
         a = self._stage_start
         first = min(n, self.max_size - a)
         self._before_device_write()
-        self.ring[a:a + first].copy_(self._stage[:first], non_blocking=True)
-        if first < n:
-            self.ring[:n - first].copy_(self._stage[first:n], non_blocking=True)
         if self.device.type == 'cuda':
-            self._copy_done = torch.cuda.Event()
-            self._copy_done.record()
+            # the C ABI's entry for this row of the path (include/rlrep.h rlrep_replay_add): the staged rows, wrap-around included
+            import ctypes as C
+            from rlrep_amd._lib import lib, check
+            with torch.cuda.device(self.device):
+                check(lib.rlrep_replay_add(C.c_void_p(self.ring.data_ptr()), self.max_size, self.row, a, C.c_void_p(self._stage.data_ptr()), n,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'replay_add')
+                self._copy_done = torch.cuda.Event()
+                self._copy_done.record()
+        else:
+            self.ring[a:a + first].copy_(self._stage[:first])
+            if first < n:
+                self.ring[:n - first].copy_(self._stage[first:n])
         self._staged = 0
         self.device_epoch += 1
 
     def load(self, state, action, next_state, reward, done):
         """Bulk-fill the ring (synthetic benchmarks / tests)."""
+        if self.shard is not None:
+            raise ValueError('load() fills the whole ring and knows nothing of the shard rule: add() the transitions instead')
         n = int(len(state))
         rows = np.concatenate([np.asarray(state, np.float32).reshape(n, -1), np.asarray(action, np.float32).reshape(n, -1),
                                np.asarray(next_state, np.float32).reshape(n, -1), np.asarray(reward, np.float32).reshape(n, 1),
@@ -101,7 +110,7 @@ class ReplayBuffer(object):
     def save(self, path):
         self.flush()
         torch.cuda.synchronize() if self.device.type == 'cuda' else None
-        np.savez_compressed(path, ring=self.ring[:self.size].cpu().numpy(), ptr=self.ptr, size=self.size)
+        np.savez_compressed(path, ring=self.ring[:self.size].cpu().numpy(), ptr=self.ptr, size=self.size, offered=self._offered)
 
     def restore(self, path):
         z = np.load(path)
@@ -109,6 +118,7 @@ class ReplayBuffer(object):
         self._before_device_write()
         self.ring[:n].copy_(torch.from_numpy(z['ring']))
         self.ptr, self.size, self._staged = int(z['ptr']), n, 0
+        self._offered = int(z['offered']) if 'offered' in z.files else 0      # (files written before round 3 carry no shard counter)
         self.device_epoch += 1
 
     def size_dev(self):

@@ -1,0 +1,125 @@
+"""Parity cross-terms that earlier rounds left open ("What's missing" 1, 6, 7 and "What's weak" 9):
+
+* the BENCHMARKED mode (hipGraph replay, device Philox draws, two-stream pipeline where the agent has one) against the oracle at the
+  dimensions BASELINE.json's configs 3 - 5 name -- the large-layer engines (gemm_lds, bf16x3) under graph capture, which the golden
+  tests only run eagerly with injected noise;
+* `ReplayBuffer.add` on the DEVICE ring against the reference's wrap-around table (utils/buffer.py:28-36) and the round-robin shard rule;
+* `select_action(explore=True)` with injected noise against the oracle's tanh-Gaussian sample (agent/sac/sac_agent.py:89-96,
+  agent/sac/actor.py:47-60);
+* vlsac `feature_step` followed by `update_feature_target()` -- the reference's call order (agent/vlsac/vlsac_agent.py:252-258) -- against
+  the oracle, and the documented deviation for a caller that skips the second call.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fixture_io import Case, rel_l2
+from test_default_mode import _check_against_oracle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize('name,calls,pipe', [('ctrlsac_hc256', 2, True), ('ctrlsac_hc2048', 2, True), ('spedersac_ant512', 2, True),
+                                             ('diffsrsac_hc', 2, False), ('diffsrsac_humanoid_b2048', 1, False)])
+def test_default_mode_matches_oracle_at_config_dims(name, calls, pipe):
+    """What `bench.py --workload ...` times for BASELINE configs 3 - 5: graph replay + device draws (+ pipeline), read back and fed to the oracle."""
+    worst = _check_against_oracle(Case(name), calls=calls, expect_pipeline=pipe)
+    print(f'{name} default mode vs oracle: worst param rel-L2 {worst:.2e}')
+
+
+# ---- replay ingestion on the device ring ------------------------------------------------------------------
+def test_device_ring_wraps_like_the_reference():
+    """utils/buffer.py:28-36 on `device='cuda'`: 8 adds into a ring of 5 -> ptr 3, size 5, rows 5, 6, 7 overwrite slots 0, 1, 2; pinned
+    staging flushed mid-way and across the wrap.  The table was captured from the reference (tests/golden/make_surface.py)."""
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    import test_surface
+    Z, m = test_surface.Z, test_surface.META['ring']
+    for stage_rows in (4096, 3, 1):
+        rb = ReplayBuffer(2, 1, max_size=m['max_size'], device='cuda', stage_rows=stage_rows)
+        for i in range(m['adds']):
+            rb.add(np.full(2, i, np.float32), np.full(1, 10 + i, np.float32), np.full(2, 100 + i, np.float32), float(i), float(i % 2))
+        assert (rb.ptr, rb.size, rb.max_size) == (m['ptr'], m['size'], m['max_size'])
+        for k in ('state', 'action', 'next_state', 'reward', 'done'):
+            got = getattr(rb, k)
+            got = got.cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+            assert np.array_equal(got.reshape(Z[f'ring/{k}'].shape), Z[f'ring/{k}']), (stage_rows, k)
+        b = rb.sample(4)
+        assert tuple(b._fields) == ('state', 'action', 'reward', 'next_state', 'done')
+        assert b.state.is_cuda and b.state.shape == (4, 2) and b.reward.shape == (4, 1) and b.state.dtype == torch.float32
+
+
+def test_device_ring_round_robin_sharding():
+    """transition i -> shard i % W, slot i // W, on the device ring and across the wrap-around."""
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    W, cap, n = 3, 4, 17
+    shards = [ReplayBuffer(2, 1, max_size=cap, device='cuda', shard=(r, W), stage_rows=2) for r in range(W)]
+    for i in range(n):
+        for s in shards:
+            s.add(np.full(2, i, np.float32), np.full(1, i, np.float32), np.full(2, -i, np.float32), float(i), 0.0)
+    kept = set()
+    for r, s in enumerate(shards):
+        assert s.size == cap
+        st = s.state
+        vals = (st.cpu().numpy() if torch.is_tensor(st) else np.asarray(st))[:, 0].astype(int).tolist()
+        for slot, v in enumerate(vals):
+            assert v % W == r and (v // W) % cap == slot, (r, slot, v)
+        kept.update(vals)
+    assert kept == set(range(n - W * cap, n))
+
+
+# ---- select_action(explore=True) -------------------------------------------------------------------------------------------------
+def test_select_action_explore_matches_oracle_sample():
+    """sac_agent.py:89-96 with `explore=True`: action = tanh(mu + eps * std), clamped -- the oracle's squashed_rsample_logp on the same eps."""
+    from oracle.agents import actor_mu_std, squashed_rsample_logp
+    from test_hip_parity import make_agent
+    c = Case('vlsac_tiny')
+    agent = make_agent(c)
+    P = {k: torch.as_tensor(v) for k, v in c.init.items()}
+    rs = np.random.RandomState(3)
+    for _ in range(4):
+        s = rs.standard_normal(c.S).astype(np.float32)
+        e = rs.standard_normal((1, c.A)).astype(np.float32)
+        a = agent._select_action(s, True, eps=e)
+        mu, std = actor_mu_std(P, torch.as_tensor(s)[None])
+        want, _ = squashed_rsample_logp(mu, std, torch.as_tensor(e))
+        assert a.shape == (c.A,)
+        assert np.allclose(a, want[0].numpy(), atol=1e-5), (a, want)
+
+
+# ---- feature_step + update_feature_target in the reference's order ---------------------------------------------------------------
+def test_feature_step_then_update_feature_target_matches_oracle():
+    """vlsac_agent.py:252-258: `feature_step(batch)` then `update_feature_target()` per feature iteration.  Here the Polyak f -> f_target is
+    fused into feature_step's optimizer launch and `update_feature_target()` is a no-op, so the pair equals the oracle's pair; the
+    test also pins the documented deviation: f_target has ALREADY moved after feature_step alone."""
+    from oracle import make_oracle
+    from oracle.agents import gather_batch
+    from test_hip_parity import make_agent
+    c = Case('vlsac_tiny')
+    agent = make_agent(c)
+    o = make_oracle(c.alg, c.S, c.A, c.init, **c.kw)
+    rs = np.random.RandomState(9)
+    F = c.kw['feature_dim']
+    ft0 = {k: v.clone() for k, v in agent.core.state().items() if k.startswith('f_target.')}
+    for it in range(3):
+        idx = rs.randint(0, c.meta['replay_n'], size=c.B)
+        eps = rs.standard_normal((c.B, F)).astype(np.float32)
+        ob = gather_batch(c.replay, idx)
+        from rlrep_amd.utils.buffer import Batch
+        dev = agent.core.device
+        hb = Batch(*(torch.as_tensor(np.asarray(getattr(ob, f))).to(dev) for f in ('state', 'action', 'reward', 'next_state', 'done')))
+        info = agent.feature_step(hb, eps=torch.as_tensor(eps).to(dev))
+        if it == 0:
+            moved = any(not torch.equal(v, agent.core.state()[k]) for k, v in ft0.items())
+            assert moved, 'documented deviation: the Polyak update rides in feature_step'
+        agent.update_feature_target()
+        oinfo = o.feature_step(ob, torch.as_tensor(eps))
+        o.update_feature_target()
+        for k, v in oinfo.items():
+            assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (it, k, info[k], v)
+    st, P = agent.core.state(), o.state()
+    for k in st:
+        if k in P and (k.startswith('f.') or k.startswith('f_target.') or k.startswith('encoder.') or k.startswith('decoder.')):
+            assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, k

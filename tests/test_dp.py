@@ -29,14 +29,20 @@ def _free_port():
 
 
 def _inputs(c, rs, nranks):
-    """Per-rank sample indices / noise for ONE train() of a tiny fixture's agent (vlsac / ctrlsac / spedersac)."""
-    F = c.kw['feature_dim']
-    nf = c.kw['extra_feature_steps'] + 1
-    nb = 2 * nf if c.alg == 'spedersac' else nf
+    """Per-rank sample indices / noise for ONE train() of a tiny fixture's agent, in the reference's draw order:
+    sac: one minibatch; vlsac: one latent noise per feature step; spedersac: two minibatches per feature step; diffsrsac: per feature step
+    the noise-level indices (diffsrsac_agent.py:276) and the sigma-scaled perturbation (:283); then the two policy noises."""
+    F = c.kw.get('feature_dim', 0)
+    nf = 0 if c.alg == 'sac' else c.kw['extra_feature_steps'] + 1
+    nb = 2 * nf if c.alg == 'spedersac' else max(nf, 1)
     out = []
     for _ in range(nranks):
         idx = [rs.randint(0, c.meta['replay_n'], size=c.B) for _ in range(nb)]
         eps = [rs.standard_normal((c.B, F)).astype(np.float32) for _ in range(nf)] if c.alg == 'vlsac' else []
+        if c.alg == 'diffsrsac':
+            for _i in range(nf):
+                eps.append(rs.randint(0, c.kw.get('num_noises', 1000), size=c.B).astype(np.int64))
+                eps.append((rs.standard_normal((c.B, c.S)) * c.kw.get('sigma_scale_factor', 0.449)).astype(np.float32))
         eps += [rs.standard_normal((c.B, c.A)).astype(np.float32) for _ in range(2)]
         out.append((idx, eps))
     return out
@@ -137,10 +143,11 @@ def _gpu_worker(rank, world, port, q, case='vlsac_tiny'):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny'])
+@pytest.mark.parametrize('case', ['sac_tiny', 'vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny', 'diffsrsac_tiny'])
 def test_hip_dp_two_ranks_match_global_batch_oracle(case):
     """ctrlsac (in-batch negatives over BOTH ranks' minibatches) and spedersac (global Phibar / v) are exact too:
-    the oracle sees one batch of 2B rows."""
+    the oracle sees one batch of 2B rows.  diffsrsac (BASELINE config 5's agent: two optimizers per feature step, all-reduce of the
+    nabla-mu group and of the phi group, diffsrsac_agent.py:271-318) and plain sac run the same backward -> all-reduce -> apply form."""
     from fixture_io import Case, rel_l2
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
