@@ -53,11 +53,6 @@ ALG_GFLOP = {'vlsac_halfcheetah_f256_b256': 10.59, 'sac_halfcheetah_b256': 0.582
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense (MI355X_MICROARCH.md); the bf16x3 tile executes 6 bf16 MFMA flops per algorithmic fp32 flop
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 REPLAY_N = 65536
-# HBM-side bytes per launch of the four-head noise-critic forward from the PMC passes in profiles/r02_pmc_summary.json (same in r01; nc_fwd_x3q_kernel:
-# FETCH_SIZE 3279.0 KB raw, x2 for 16-byte reads on gfx950, + WRITE_SIZE 11520.0 KB): 18.5 MB against 11.0 MB algorithmic (10.5 MB of
-# ELU outputs written + tables and weights read once; every XCD's L2 fetches its own copy of the 1 MB of weights)
-NC_FWD_TRAFFIC_BYTES = int((2 * 4305.5 + 11520.0) * 1024)        # r02 with the bf16x3 weight images (3 x 2 bytes per weight instead of 4): r01 was 2 * 3279.0 + 11520.0
-
 
 class Space:
     def __init__(self, A):
@@ -116,9 +111,9 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     kname = ('nc_fwd_x3q_kernel' if quad else 'nc_fwd_x3w_kernel<8>' if wide else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
     out = {'bound': 'mfma', 'kernel': kname + (' (critic step, 4 heads, bf16x3)' if x3 else ' (critic step, 4 heads)'),
            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-           # HBM-side bytes per launch from the PMC passes committed in profiles/r02_pmc_summary.json
-           # (FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE; measured offline, not in this run)
-           'traffic': NC_FWD_TRAFFIC_BYTES, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
+           # (traffic is not measured inside a timed run: the PMC passes -- FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE -- are
+           #  committed under profiles/ and quoted in DESIGN.md)
+           'traffic': None, 'us_per_launch': round(us, 2), 'flop_per_launch': flops}
     if x3:
         out['note'] = 'achieved = algorithmic fp32 flops / time; peak = dense bf16 MFMA peak (2500 TF) / 6 executed flops per product'
         out['executed_bf16_tflops'] = round(6 * achieved, 1)
@@ -315,6 +310,32 @@ def chain_times(agent, reps=60):
     return out
 
 
+def _start_clock_probe():
+    """rocm-smi in a child process, sampling the clocks while the caller keeps the GPU busy (it never touches HIP itself)."""
+    import shutil
+    import subprocess
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(exe):
+        return None
+    try:
+        return subprocess.Popen([exe, '--showclocks', '--json'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError:
+        return None
+
+
+def _read_clock_probe(p):
+    if p is None:
+        return None
+    try:
+        out, _ = p.communicate(timeout=30)
+        d = json.loads(out)
+        card = d.get('card0') or next(iter(d.values()))
+        pick = {k: v for k, v in card.items() if 'sclk' in k.lower() or 'mclk' in k.lower() or 'fclk' in k.lower()}
+        return {'source': 'rocm-smi --showclocks, sampled while the median repeats ran', **pick}
+    except Exception as e:           # the probe must never fail the benchmark
+        return {'source': 'rocm-smi --showclocks', 'error': str(e)[:80]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -325,6 +346,9 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-stage / per-chain timing loops (rocprofv3 and PMC runs)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1 data-parallel: weak = every rank its own batch B (global batch N*B); strong = the global batch stays B, each rank samples B/N '
+                         '(SURVEY.md 8e; BASELINE configs 4 and 5 name a total batch on 4 / 8 GPUs)')
     ap.add_argument('--replicas', action='store_true',
                     help='N > 1: N independent agents (own parameters, own replay, NO gradient all-reduce) instead of data-parallel training')
     args = ap.parse_args()
@@ -367,6 +391,12 @@ def main():
         os.environ['RLREP_GRAPH'] = '0'
 
     alg, S, A, B, kw = WORKLOADS[args.workload]
+    strong = args.scaling == 'strong' and world > 1 and not replicas
+    B_global = B
+    if strong:
+        if B % world:
+            raise SystemExit(f'--scaling strong: batch {B} is not a multiple of {world} ranks')
+        B = B // world              # per-rank minibatch; the loss kernels scale by 1 / (B * world) = 1 / B_global
     torch.manual_seed(0)
     if replicas:
         # independent replicas: the agent must not see the process group (it would broadcast parameters and all-reduce gradients)
@@ -382,7 +412,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # untimed: the W warm-up steps the caller asked for, and at least ~0.15 s of train() calls on top (graph instantiation, the two-stream
+    # pipeline's probe, the clock ramp: with the driver's W = 5 the 20-step window otherwise sits 6 % below the steady state)
+    extra = max(0, (300 if alg in ('vlsac', 'sac', 'ctrlsac') and B <= 256 else 10) - args.warmup)
+    for _ in range(args.warmup + extra):
         agent.train(buf, B)
     agent.flush()
     barrier()
@@ -396,8 +429,28 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # median of 5 repeats.  The --steps window above is what `value` reports (the driver's contract: EXACTLY K steps); a short
+    # window (the driver's 20 steps = 7 ms) is noisy by construction, so the same loop is also timed as 5 repeats of `rep_len` calls and the
+    # median reported beside it.  The shader clock is sampled by rocm-smi WHILE those repeats run.
+    rep_len = 500 if dt / args.steps < 2e-3 else max(20, min(args.steps, 100))
+    smi = _start_clock_probe() if rank == 0 else None
+    rep_rates = []
+    for _ in range(5):
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(rep_len):
+            agent.train(buf, B)
+        agent.flush()
+        barrier()
+        dr = time.perf_counter() - tr
+        if dist is not None:
+            tt = torch.tensor([dr], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dr = float(tt.item())
+        rep_rates.append((1 if strong else world) * rep_len / dr)
+    clocks = _read_clock_probe(smi) if rank == 0 else None
     info = agent.train(buf, B)
-    finite = all(np.isfinite(v) for v in info.values())
+    finite = all(np.isfinite(float(v)) for v in info.values())
     # the same loop with the metric dict READ after every train() (a device sync per call, as the reference's .item()s do)
     n_sync = min(args.steps, 300)
     barrier()
@@ -409,15 +462,15 @@ def main():
 
     if rank == 0:
         updates = args.steps / dt                      # synchronized train() calls per second (each rank performs every one of them)
-        value = world * updates
+        value = updates if strong else world * updates       # strong scaling: one synchronized update IS one batch-B_global gradient step
         mode = 'single' if world == 1 and not force_dp else ('replicas' if replicas else 'dp')
         out = {
-            'metric': f'gradient steps/sec (encoder+critic+actor) at batch={B}',
-            'value': round(value, 2), 'unit': 'train()/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'metric': f'gradient steps/sec (encoder+critic+actor) at batch={B_global}',
+            'value': round(value, 2), 'unit': 'train()/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_extra_untimed': extra,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload, 'agent': alg, 'state_dim': S, 'action_dim': A, 'batch_per_gpu': B,
-                       'global_batch': B * world if mode == 'dp' else B, 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
+                       'global_batch': (B_global if strong else B * world) if mode == 'dp' else B, 'scaling': 'strong' if strong else 'weak', 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
                        'parallelism': {'single': 'single GPU',
                                        'dp': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)',
@@ -429,21 +482,40 @@ def main():
             # on its own batch-B shard of a global batch N*B; value = N * global_updates_per_sec = samples_per_sec / B ("batch-B gradient
             # steps" worth of samples).  --replicas runs N independent batch-B agents instead: value = their train() calls summed.
             'value_definition': {'single': 'train() calls per second at batch B',
-                                 'dp': 'world_size x synchronized global updates per second (= samples_per_sec / B); one global update = batch B x world_size',
+                                 'dp': ('synchronized global updates per second; one global update = the batch B split over world_size ranks' if strong else
+                                        'world_size x synchronized global updates per second (= samples_per_sec / B); one global update = batch B x world_size'),
                                  'replicas': 'sum over the independent replicas of their train() calls per second at batch B'}[mode],
             'global_updates_per_sec': round(updates if mode != 'replicas' else value, 2),
             'rccl_world_size': (dist.get_world_size() if dist is not None else 1),
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
-            'samples_per_sec': round(value * B, 1),
+            'samples_per_sec': round(value * B_global if strong else value * B, 1),
             'metrics_finite': bool(finite),
-            'value_with_per_step_metric_fetch': round(world * n_sync / dt_sync, 2),
+            'value_with_per_step_metric_fetch': round((1 if strong else world) * n_sync / dt_sync, 2),
+            # median of 5 repeats of `rep_len` calls each (same loop, same barriers): the low-noise companion of the --steps window
+            'value_median_500' if rep_len == 500 else 'value_median_repeats': round(float(np.median(rep_rates)), 2),
+            'repeats': {'n': 5, 'calls_each': rep_len, 'values': [round(v, 1) for v in rep_rates]},
+            'clocks': clocks,
         }
         if alg == 'vlsac':
-            out['roofline'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
+            heaviest = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
+            out['roofline_heaviest_kernel'] = heaviest
+            out['roofline'] = heaviest
             if world == 1 and not args.no_profile:
-                # the heaviest KERNEL is the roofline object above; the family with the largest TIME share is the tile engine, each with its own frac
+                # `roofline` describes the RUN: the kernel family with the largest share of GPU time (the 16-row tile engine: every 256-wide
+                # layer), its algorithmic flops over the time its launches take, against the fp32 MFMA peak.  The
+                # heaviest single kernel (noise-critic forward) is `roofline_heaviest_kernel`.
                 out['chains'] = chain_times(agent)
-                out['kernel_families'] = stage_profile(agent)
+                fams = stage_profile(agent)
+                out['kernel_families'] = fams
+                top = fams[0]
+                if 'frac' in top:
+                    out['roofline'] = {'bound': 'mfma', 'kernel': top['family'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': 'TFLOP/s',
+                                       'frac': top['frac'], 'traffic': None, 'us_per_train': top['us_per_train'],
+                                       'launches_per_train': top['launches_per_train'], 'share_of_gpu_time': top['share_of_stage_time'],
+                                       'algorithmic_gflop_per_train': top['algorithmic_gflop_per_train'],
+                                       'note': 'achieved = algorithmic flops of the family per train() / the time its launches take (each stage timed '
+                                               'as 40 back-to-back launches with HIP events on the launch stream); traffic: PMC passes in profiles/ '
+                                               '(not collected inside a timed run)'}
                 if out['chains']:
                     out['critical_path_us'] = out['chains']['feature_chain_us']
                     out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)

@@ -169,7 +169,13 @@ class SACAgent(object):
         self._bufs = {}
         self._graph = None
         self._seg = None
+        self._seg_capture_colls = False
+        self._n_captured_colls = 0
         self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
+        # sequential data-parallel form on the RCCL backend: the gradient all-reduces are CAPTURED into the hipGraph of train() (one graph
+        # instead of 7 segments + 6 eager calls of ~14 us of host time each).  One stream, one communicator: the collectives of a replay
+        # are issued in program order, identical on every rank.  RLREP_DP_CAPTURE=0 (and every non-RCCL backend) keeps the segments.
+        self.capture_collectives = bool(int(os.environ.get('RLREP_DP_CAPTURE', '1')))
         # backward -> all-reduce -> apply form of every optimizer step.  RLREP_FORCE_DP=1 takes it with a one-rank process group too
         # (sac / vlsac: rehearses the RCCL stream / graph-segment machinery on a single GPU; tests/test_dp.py)
         self._dp = self.world_size > 1 or (self.ALG in ('sac', 'vlsac') and bool(int(os.environ.get('RLREP_FORCE_DP', '0'))))
@@ -354,6 +360,10 @@ class SACAgent(object):
         """Run a torch.distributed call now, or -- during segmented capture (data parallel + hipGraph) -- close the
         graph segment recorded so far, remember the collective as an eager step and open the next segment.
         No RCCL call is ever captured."""
+        if self._seg is not None and self._seg_capture_colls:
+            fn()                                    # recorded into the open graph (ProcessGroupNCCL under stream capture)
+            self._n_captured_colls += 1
+            return
         if self._seg is not None:
             segs, cur = self._seg
             cur.capture_end()
@@ -534,6 +544,13 @@ class SACAgent(object):
             torch.cuda.synchronize()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
+            self._seg_capture_colls = self.capture_collectives and dist.is_initialized() and dist.get_backend() == 'nccl'
+            self._n_captured_colls = 0
+            if self._seg_capture_colls:
+                # the communicator must exist before the capture begins (its lazy creation allocates: not permitted while capturing);
+                # every rank builds its graph at the same train() call, so this is a matched collective
+                dist.all_reduce(torch.zeros(1, device=self.core.device))
+                torch.cuda.synchronize()
             with torch.cuda.stream(s):
                 first = torch.cuda.CUDAGraph()
                 # thread-local capture mode: the process group's watchdog thread may query events while we capture

@@ -259,13 +259,15 @@ def test_hip_dp_pipelined_equals_sequential_dp():
 
 
 def _gpu_rccl_worker(port, q, mode):
-    """mode: 'single' (no process group), 'dp' (sequential DP over a one-rank RCCL group), 'dp_pipe' (pipelined DP, same group)."""
+    """mode: 'single' (no process group), 'dp' (sequential DP over a one-rank RCCL group, all-reduces captured into the graph), 'dp_seg'
+    (the same with graph segments around eager all-reduces), 'dp_pipe' (pipelined DP, same group)."""
     from fixture_io import Case
     from test_hip_parity import make_agent, make_buffer
     try:
         if mode != 'single':
             os.environ['RLREP_FORCE_DP'] = '1'
             os.environ['RLREP_PIPELINE_DP'] = '1' if mode == 'dp_pipe' else '0'
+            os.environ['RLREP_DP_CAPTURE'] = '0' if mode == 'dp_seg' else '1'
             torch.cuda.set_device(0)
             dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
         c = Case('vlsac_tiny')
@@ -281,7 +283,9 @@ def _gpu_rccl_worker(port, q, mode):
         form = 'pipe' if agent._pipe is not None else 'graph'
         if mode == 'dp_pipe':
             assert agent._pipe['mode'] == 3
-        if mode == 'dp':
+        if mode == 'dp':          # the six all-reduces of a vlsac train() are inside ONE captured graph
+            assert sum(1 for k, _ in agent._graph if k == 'coll') == 0 and len(agent._graph) == 1 and agent._n_captured_colls == 6
+        if mode == 'dp_seg':      # RLREP_DP_CAPTURE=0: graph segments around eager collectives
             assert sum(1 for k, _ in agent._graph if k == 'coll') == 6
         st = {k: v.numpy() for k, v in agent.core.state().items()}
         q.put((mode, st, last, form))
@@ -300,7 +304,7 @@ def test_hip_dp_over_rccl_one_rank_equals_single_gpu():
     capture, and the two issuing streams sharing one communicator."""
     out = {}
     ctx = mp.get_context('spawn')
-    for mode in ('single', 'dp', 'dp_pipe'):
+    for mode in ('single', 'dp', 'dp_seg', 'dp_pipe'):
         q = ctx.Queue()
         p = ctx.Process(target=_gpu_rccl_worker, args=(_free_port(), q, mode))
         p.start()
@@ -309,7 +313,7 @@ def test_hip_dp_over_rccl_one_rank_equals_single_gpu():
         assert isinstance(res[1], dict), res[1]
         assert p.exitcode == 0
         out[mode] = res
-    for mode in ('dp', 'dp_pipe'):
+    for mode in ('dp', 'dp_seg', 'dp_pipe'):
         for k, v in out['single'][1].items():
             assert np.array_equal(v, out[mode][1][k]), f'{mode} != single GPU at {k}'
         assert out[mode][2] == out['single'][2]
