@@ -755,6 +755,11 @@ class SACAgent(object):
             idx_keys, eps_specs = self._plan(B)
             self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
             self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
+            import torch.distributed as dist
+            self._seg_capture_colls = self.capture_collectives and dist.is_initialized() and dist.get_backend() == 'nccl'
+            if self._seg_capture_colls:          # both communicators exist before the captures begin (see _train_graph_dp)
+                dist.all_reduce(torch.zeros(1, device=c.device))
+                dist.all_reduce(torch.zeros(1, device=c.device), group=self._pg_ca)
             torch.cuda.synchronize()
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
