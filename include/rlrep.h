@@ -351,6 +351,10 @@ int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t batch, int32_t feature_dim, int
  * results of the affected steps are invalid; RLREP_XCHAIN=0 selects one launch per stage. */
 int32_t rlrep_chain_status(rlrep_agent* agent, uint32_t* status, void* stream);
 
+/* bit 0: this library was built with RLREP_BUILD_EXPERIMENTS=1 (the opt-in engines that were measured and not adopted: RLREP_ROWPROG,
+ * RLREP_XCHAIN, RLREP_FUSE_L1, superseded noise-critic forward kernels).  0: they are not compiled in and their switches are ignored. */
+int32_t rlrep_build_flags(void);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 /* process-wide number of kernel launches the library has issued so far (a captured train()'s launch count = the difference around its capture) */

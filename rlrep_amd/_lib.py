@@ -124,6 +124,7 @@ def _load():
         'rlrep_gemm_plan': (i32, [i32] * 8 + [P(i32)] * 5),
         'rlrep_nc_fwd_plan': (i32, [i32] * 4 + [P(i32)] * 3),
         'rlrep_chain_status': (i32, [vp, P(C.c_uint32), vp]),
+        'rlrep_build_flags': (i32, []),
         'rlrep_metrics_dev': (vp, [vp]),
         'rlrep_last_launch_count': (i32, [vp]),
         'rlrep_launch_counter': (i64, []),
@@ -137,6 +138,11 @@ def _load():
 
 
 lib, SIGNATURES = _load()
+
+
+def has_experiments():
+    """True if the loaded library carries the opt-in engines (built with RLREP_BUILD_EXPERIMENTS=1)."""
+    return bool(lib.rlrep_build_flags() & 1)
 
 
 def check(rc, what=''):

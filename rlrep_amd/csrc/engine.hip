@@ -543,6 +543,11 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     {
         RpAsm probe; if (use_cluster) rp_feature_cluster(probe); else rp_feature(probe, true);
         if (probe.lds_bytes() > RP_LDS_DYN_MAX || probe.ops.size() > 4096) use_rp = false;
+        // the paired programs wait for each other inside the launch: every workgroup of it must be resident at once (256 CUs, as many
+        // workgroups per CU as their LDS allows, at most 2 of these 512-thread ones) -- otherwise waiters could hold the chip while their
+        // partners are never scheduled
+        const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u) / std::max<size_t>(probe.lds_bytes(), 1))));
+        if (probe.blocks > 256 * per_cu) use_rp = false;
         for (auto& pr : probe.progs) if (pr.op_end - pr.op_begin > 40) use_rp = false;
     }
     auto feature_program = [&](Program& p, bool early) {
@@ -553,7 +558,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             RpAsm A_; if (use_cluster && !early) rp_feature_cluster(A_); else rp_feature(A_, early);
             RpLaunch L; memset(&L, 0, sizeof(L));
             L.ops = b.upload(A_.ops); L.flags = rp_flags; L.nprog = (int)A_.progs.size(); L.B = B; L.low_prio = 0;
-            L.lds_floats = A_.peak; L.xbuf = xbuf; L.epoch = ag->rp_epoch;
+            L.lds_floats = A_.peak; L.xbuf = xbuf; L.epoch = ag->rp_epoch; L.err = ag->xc_err;
             for (size_t q = 0; q < A_.progs.size(); ++q) L.prog[q] = A_.progs[q];
             const int total = A_.blocks;
             rlrep_agent* a = ag;
@@ -982,7 +987,11 @@ static void static_state(rlrep_agent* ag) {
     // for the pair (every one of the 512 tiles re-reads W1^T and X: twice the L2 traffic, three times the load instructions): 2 763 vs
     // 2 865 train()/s.
     const char* fl1 = getenv("RLREP_FUSE_L1");
+#ifdef RL_EXPERIMENTS
     const bool sh_all = rl_rowprog_enabled(), sh_l1 = fl1 && fl1[0] == '1';
+#else
+    const bool sh_all = false, sh_l1 = false; (void)fl1;       // (the fused-first-layers launch is an experiments-build kernel)
+#endif
     if (ag->d.alg == RLREP_ALG_VLSAC && (sh_all || sh_l1) && !getenv("RLREP_NO_SHADOWS")) {
         std::vector<ShadowEnt> tab; std::vector<std::string> first;
         const auto& T = ag->L.t;
@@ -1315,7 +1324,7 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
     if (!ag->in_train && ag->has_shadows()) { const int rs = refresh_shadows(ag, stream); if (rs) return rs; }     // parameters may have been written by the caller
-    if (!ag->in_train && rl_rowprog_cluster() && ag->rp_epoch) (void)(++g_rl_launches, rl_launch_counter_inc(ag->rp_epoch, (hipStream_t)stream));   // a fresh epoch whatever ran before
+    if (!ag->in_train && rl_rowprog_enabled() && ag->rp_epoch) (void)(++g_rl_launches, rl_launch_counter_inc(ag->rp_epoch, (hipStream_t)stream));   // a fresh epoch whatever ran before
     ag->pi_ready = nullptr;                                       // f_target is about to change
     ag->early_ready_crit = ag->early_ready_act = nullptr;
     if (ag->early_crit && !ag->feat_bwd_h.stages.empty()) {
@@ -1650,10 +1659,18 @@ int32_t rlrep_chain_status(rlrep_agent* ag, uint32_t* status, void* stream) {
     if (status) *status = w;
     if (w) {
         rl_set_error("a persistent chain launch failed its run-time checks (word %u:%s%s); results are invalid -- RLREP_XCHAIN=0 runs one launch per stage",
-                     w, (w & 1u) ? " wait timed out" : "", (w & 2u) ? " workgroups of a group on different XCDs" : "");
+                     w, (w & 5u) ? " wait timed out" : "", (w & 2u) ? " workgroups of a group on different XCDs" : "");
         return RLREP_ERR_STATE;
     }
     return 0;
+}
+
+int32_t rlrep_build_flags(void) {
+#ifdef RL_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }

@@ -233,7 +233,11 @@ struct Builder {
     struct ChainPhase { XcPhase ph; std::vector<GemmTask> tasks; HeadsVae hv; const char* what; int la, lb; };
     std::vector<ChainPhase> chain; Program* chain_prog = nullptr; int chain_R = -1;
     // OPT-IN while it is slower than the launches it replaces beside the deferred chain: RLREP_XCHAIN=1
+#ifdef RL_EXPERIMENTS
     static bool chain_enabled() { const char* e = getenv("RLREP_XCHAIN"); return e && e[0] == '1'; }
+#else
+    static bool chain_enabled() { return false; }
+#endif
     static int chain_mpg() { const char* e = getenv("RLREP_XCHAIN_MPG"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }
     bool chain_fits(int R) const { return chain_enabled() && R <= 512 && (chain_R < 0 || chain_R == R); }
     void chain_begin(Program& p) { chain_flush(); chain_prog = &p; chain_R = -1; }
@@ -489,8 +493,14 @@ struct Builder {
 // ------------------------------------------------------------------------------------------------
 // row-block programs (rowprog.hip): host-side assembler
 // ------------------------------------------------------------------------------------------------
+// (opt-in engines: compiled into the experiments library only, rlrep_amd/csrc/build.sh)
+#ifdef RL_EXPERIMENTS
 static inline bool rl_rowprog_enabled() { const char* e = getenv("RLREP_ROWPROG"); return e && (e[0] == '1' || e[0] == '2'); }
 static inline bool rl_rowprog_cluster() { const char* e = getenv("RLREP_ROWPROG"); return e && e[0] == '2'; }
+#else
+static inline bool rl_rowprog_enabled() { return false; }
+static inline bool rl_rowprog_cluster() { return false; }
+#endif
 struct RpBuf { int off, ld, w; };            // LDS buffer: float offset, row stride, zero-padded width (multiple of 32)
 
 struct RpAsm {

@@ -51,8 +51,13 @@ extern "C" unsigned rl_timing_count() { unsigned n = 0; (void)hipMemcpyFromSymbo
 #define TIM_FIN() do {} while (0)
 #endif
 
+// The launch header travels TWICE: inside the batch (gemm_lds shares the struct) and as 14 leading scalar arguments -- flags, tile count,
+// the eight tasks' first tiles, their column-tile counts packed two to a word -- which the hardware PRELOADS into SGPRs at wave launch
+// (build.sh compiles this file with -mllvm -amdgpu-kernarg-preload-count=14): a workgroup knows its task and tile without a single load,
+// and its first scalar-load round trip is the task record itself.
 template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false, int EPI_K = -1, int ACT_K = -1>
-__global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6, int tb7,
+                                                     unsigned tc01, unsigned tc23, unsigned tc45, unsigned tc67, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
 
@@ -63,13 +68,11 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
     TIM(0);
     // latency-critical launch: win the issue arbitration against the waves of a noise-critic launch that may be running on the
     // other stream of the deferred pipeline (405.8 vs 429.7 us per train(); alone on the chip it changes nothing)
-    // header + per-task tile ranges: one burst of scalar loads (unused entries of tb are INT_MAX)
-    const int nfin = gb.nfin, low_prio = gb.low_prio, total = gb.total;
-    int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS];
-#pragma unroll
-    for (int q = 0; q < GEMM_MAX_TASKS; ++q) { tb[q] = gb.tb[q]; tcs[q] = gb.tcs[q]; }
-    asm volatile("" :: "s"(nfin), "s"(low_prio), "s"(total), "s"(tb[0]), "s"(tb[1]), "s"(tb[2]), "s"(tb[3]), "s"(tb[4]), "s"(tb[5]), "s"(tb[6]), "s"(tb[7]),
-                 "s"(tcs[0]), "s"(tcs[1]), "s"(tcs[2]), "s"(tcs[3]), "s"(tcs[4]), "s"(tcs[5]), "s"(tcs[6]), "s"(tcs[7]));
+    // header + per-task tile ranges (unused entries of tb are INT_MAX): preloaded kernel arguments
+    const int low_prio = hdr & 1, nfin = hdr >> 1;
+    const int tb[GEMM_MAX_TASKS] = {tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7};
+    const int tcs[GEMM_MAX_TASKS] = {(int)(tc01 & 0xffffu), (int)(tc01 >> 16), (int)(tc23 & 0xffffu), (int)(tc23 >> 16),
+                                     (int)(tc45 & 0xffffu), (int)(tc45 >> 16), (int)(tc67 & 0xffffu), (int)(tc67 >> 16)};
     if (!low_prio) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x;
     if (nfin > 0 && bid == total) {      // trailing workgroup: metric finalisation / temperature update
@@ -94,11 +97,15 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmBatch gb) {
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
+// the 14 preloaded header scalars of a planned batch, then the batch
+#define G16_ARGS(B) ((B).low_prio ? 1 : 0) | ((B).nfin << 1), (B).total, (B).tb[0], (B).tb[1], (B).tb[2], (B).tb[3], (B).tb[4], (B).tb[5], (B).tb[6], (B).tb[7], \
+    (unsigned)((B).tcs[0] | ((B).tcs[1] << 16)), (unsigned)((B).tcs[2] | ((B).tcs[3] << 16)), (unsigned)((B).tcs[4] | ((B).tcs[5] << 16)), (unsigned)((B).tcs[6] | ((B).tcs[7] << 16)), (B)
+
 template <int LA, int LB, bool VA, bool VB>
 static void launch_nf(int nf, dim3 g, hipStream_t st, const GemmBatch& gb) {
-    if (nf == 1) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB>), g, dim3(256), 0, st, gb);
-    else if (nf == 2) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 2, VA, VB>), g, dim3(256), 0, st, gb);
-    else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 4, VA, VB>), g, dim3(256), 0, st, gb);
+    if (nf == 1) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB>), g, dim3(256), 0, st, G16_ARGS(gb));
+    else if (nf == 2) hipLaunchKernelGGL((gemm16_kernel<LA, LB, 2, VA, VB>), g, dim3(256), 0, st, G16_ARGS(gb));
+    else hipLaunchKernelGGL((gemm16_kernel<LA, LB, 4, VA, VB>), g, dim3(256), 0, st, G16_ARGS(gb));
 }
 
 // NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
@@ -110,21 +117,21 @@ static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (gb.nfin > 0) return false;
     for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].epi != epi || gb.t[q].act != act || (gb.t[q].flags & FLAG_PRE)) return false;
     if (LB == LD_ROW && epi == EPI_FWD) {
-        if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, gb);
-        else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, gb);
-        else if (act == ACT_ELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_ELU>), g, dim3(256), 0, st, gb);
+        if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
+        else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, G16_ARGS(gb));
+        else if (act == ACT_ELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(gb));
         else return false;
         return true;
     }
     if (LB == LD_COL && epi == EPI_DX) {
-        if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, gb);
-        else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_RELU>), g, dim3(256), 0, st, gb);
-        else if (act == ACT_ELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, gb);
+        if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
+        else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_RELU>), g, dim3(256), 0, st, G16_ARGS(gb));
+        else if (act == ACT_ELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(gb));
         else return false;
         return true;
     }
     if (NF == 1 && LB == LD_ROW && epi == EPI_FWD_MSE) {       // vlsac decoder heads + mse
-        hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, EPI_FWD_MSE, ACT_NONE>), g, dim3(256), 0, st, gb);
+        hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, EPI_FWD_MSE, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
         return true;
     }
     return false;
@@ -159,16 +166,20 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         }
         if (la != LD_ROW || nf != 1) return -3;
         if (fw) {
+#ifndef RL_EXPERIMENTS
+            return -3;                                   // first layers fused into the second: measured slower, experiments build only
+#else
             if (lb != LD_ROW) return -3;
-            if (all_vec(*gb, true)) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, true, true>), g, dim3(256), 0, st, *gb);
-            else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+            if (all_vec(*gb, true)) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, true, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_ROW, 1, false, false, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
+#endif
         } else {
             if (lb != LD_COL) return -3;
             bool rep = !getenv("RLREP_GEMM16_GENERIC"), plain = rep;
             for (int q = 0; q < gb->ntasks; ++q) { rep = rep && gb->t[q].epi == EPI_DX_REPARAM; plain = plain && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_NONE; }
-            if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, *gb);
-            else if (plain) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, *gb);
-            else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, *gb);
+            if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else if (plain) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
         }
         return (int)hipGetLastError();
     }
@@ -182,9 +193,9 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         // weight gradients with nothing to accumulate into and no fused optimizer: the instantiation without slot loads / optimizer code
         bool plain = gb->nfin == 0 && !getenv("RLREP_GEMM16_GENERIC");
         for (int q = 0; q < gb->ntasks; ++q) plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM) && !gb->t[q].ad_p;
-        if (plain && nf == 4) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 4, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, *gb);
-        else if (plain && nf == 2) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 2, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, *gb);
-        else if (plain && nf == 1) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 1, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, *gb);
+        if (plain && nf == 4) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 4, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+        else if (plain && nf == 2) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 2, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+        else if (plain && nf == 1) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 1, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
         else launch_nf<LD_COL, LD_COL, false, false>(nf, g, st, *gb);
     }
     else return -1;

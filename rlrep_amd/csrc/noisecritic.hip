@@ -1699,9 +1699,14 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
         if ((F % 32) != 0 || g2 != 2) return -3;
         static const int wide = [] { const char* e = getenv("RLREP_NC_X3_WIDE"); return e ? atoi(e) : 1; }();
         static const int quad = [] { const char* e = getenv("RLREP_NC_X3_Q"); return e ? atoi(e) : 1; }();
+#ifdef RL_EXPERIMENTS
         if (nb->cols == 128 && quad) hipLaunchKernelGGL(nc_fwd_x3q_kernel, dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
-        else if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
-        else if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<2>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
+        else if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);     // superseded by x3q
+        else if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<2>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);             // superseded by x3q
+#else
+        (void)wide; (void)quad;
+        if (nb->cols == 128) hipLaunchKernelGGL(nc_fwd_x3q_kernel, dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
+#endif
         else hipLaunchKernelGGL((nc_fwd_x3_kernel<1>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
         return (int)hipGetLastError();
     }
@@ -1746,8 +1751,11 @@ extern "C" int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st) {
 // one-time setup (agent creation, never inside a stream capture): nc_dw needs more dynamic LDS than the 64 KB default
 extern "C" int rl_nc_init() {
     const size_t lds = (size_t)NCDW_BB * (NCDW_TLD + 16) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+    hipError_t e = hipSuccess;
+#ifdef RL_EXPERIMENTS
+    e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3w_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
+#endif
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nc_fwd_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NX_BUFB);
     if (e != hipSuccess) return (int)e;

@@ -74,7 +74,8 @@ struct RpLaunch {
     RpProg prog[RP_MAX_PROGS];
     const float* dyn[RP_MAX_DYN];          // per-call pointers (noise), patched at launch time
     unsigned long long* xbuf;              // exchange buffer [row block][2 cluster types][RP_MAX_HOPS][csize][RP_XSLOT] granules
-    const int* epoch;                      // device counter that differs between any two launches whose granules could be confused
+    const int* epoch;                      // device counter that differs between any two launches whose granules / flags could be confused
+    unsigned* err;                         // error word (rlrep_chain_status bit 2): a wait of this launch timed out
 };
 
 extern "C" int rl_launch_rowprog(const RpLaunch* L, int total_blocks, hipStream_t st);

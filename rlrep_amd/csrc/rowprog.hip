@@ -386,6 +386,7 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
     const int rb = local / cs, member = local - rb * cs;       // cluster programs: csize consecutive workgroups share a row block
     const int r0 = rb * RP_ROWS;
     const unsigned epoch = L.epoch ? (unsigned)*(const RP_GAS int*)L.epoch : 0u;
+    int rp_dead = 0;            // a wait of this thread timed out: stop waiting (the launch drains; the error word says the results are void)
     const int B = L.B;
     const int nrb = (B + RP_ROWS - 1) / RP_ROWS;
     const int nops = pr.op_end - pr.op_begin;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                         if (want) pending |= 1u << o;
                     }
                     int spins = 0;
-                    while (pending && spins < (1 << 20)) {
+                    while (pending && spins < (1 << 20) && !rp_dead) {
                         for (int o = 0; o < cs; ++o) {
                             if (!(pending & (1u << o))) continue;
                             const unsigned long long g = __hip_atomic_load(slot(from, o) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -592,6 +593,9 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                         if (pending) __builtin_amdgcn_s_sleep(1);
                         ++spins;
                     }
+                    // a granule that never arrived: raise the error word (rlrep_chain_status) and stop waiting in this launch, so that it
+                    // drains; what was assembled from stale slots is reported, not used silently
+                    if (pending && !rp_dead) { if (L.err) atomicOr(L.err, 4u); rp_dead = 1; }
                 }
             }
         } break;
@@ -601,7 +605,8 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(L.flags + op.flag * nrb + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the flag carries the launch epoch: a signal that comes after its waiter gave up cannot be mistaken for the next launch's
+                __hip_atomic_store(L.flags + op.flag * nrb + rb, (int)(epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } break;
         case RP_WAIT: {
@@ -609,10 +614,11 @@ __global__ __launch_bounds__(RP_THREADS) void rowprog_kernel(RpLaunch L) {
                 int* f = L.flags + op.flag * nrb + rb;
                 // bounded: the partner workgroup of this launch is co-resident or will be (the grid is far smaller than the chip)
                 long long spins = 0;
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1ll << 26)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+                const int want = (int)(epoch + 1u);
+                while (!rp_dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && spins < (1ll << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+                if (!rp_dead && spins >= (1ll << 22)) { if (L.err) atomicOr(L.err, 4u); rp_dead = 1; }      // partner never signalled: report, stop waiting
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } break;
         default: break;

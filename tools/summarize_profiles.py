@@ -11,7 +11,8 @@ Inputs (written on the GPU box by the commands quoted in profiles/<tag>_README.m
 import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-G = os.path.join(ROOT, 'gpurun_out'); P = os.path.join(ROOT, 'profiles')
+G = os.path.join(ROOT, 'gpurun_out'); P = os.environ.get('RLREP_PROFILES_OUT') or os.path.join(ROOT, 'profiles')
+os.makedirs(P, exist_ok=True)
 
 
 def short(name):
@@ -79,15 +80,17 @@ for sub in ('pmc_gemm', 'pmc_gemm2'):
     for k, cs in acc.items():
         for c, per in cs.items():
             gp.setdefault(k, {})[c] = round(sum(per.values()) / len(per), 1)
-json.dump(gp, open(os.path.join(P, f'{tag}_pmc_gemm_4096.json'), 'w'), indent=1, sort_keys=True)
+if gp:
+    json.dump(gp, open(os.path.join(P, f'{tag}_pmc_gemm_4096.json'), 'w'), indent=1, sort_keys=True)
 if os.path.exists(os.path.join(G, 'bench_gemm.log')):
     keep = [l for l in open(os.path.join(G, 'bench_gemm.log')).read().splitlines() if ' GF |' in l]
     open(os.path.join(P, f'{tag}_gemm_engines.txt'), 'w').write('\n'.join(keep) + '\n')
-json.dump(extra, open(os.path.join(P, f'{tag}_large_workloads_top_kernels.json'), 'w'), indent=1)
+if extra:
+    json.dump(extra, open(os.path.join(P, f'{tag}_large_workloads_top_kernels.json'), 'w'), indent=1)
 
 print('\n'.join(table))
 b = json.loads(bench)
-print('\nbench:', b['value'], b['unit'], b['ms_per_step'], 'ms;', 'roofline', json.dumps(b['roofline']))
+print('\nbench:', b['value'], b['unit'], b['ms_per_step'], 'ms;', 'roofline', json.dumps(b.get('roofline')))
 for k in ('nc_fwd_kernel<1>', 'nc_dw_kernel', 'nc_dx_kernel<true>'):
     if k in pmc:
         print(k, {c: pmc[k].get(c) for c in ('SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'FETCH_SIZE', 'WRITE_SIZE', 'SQ_LDS_BANK_CONFLICT')})
