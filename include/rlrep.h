@@ -324,7 +324,9 @@ int32_t rlrep_run_stage(rlrep_agent* agent, int32_t program, int32_t stage, void
  *        3 dW:      acc, flags & 1: C += ..., flags & 2: out2[r] = sum_k opA(r,k) (bias gradient)
  *   engine: 0 = 16-row tile engine (gemm16), 1 = LDS-tiled engine (gemm_lds), 2 = its 128-wide tile on the bf16 pipe
  *   (bf16x3: three-way operand split, six MFMAs, fp32 accuracy); bt (0 auto, 64, 128) and splits
- *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats).
+ *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats) and, behind them, one arrival
+ *   counter per 64 x 64 output tile: with room for those the tile that stores the last split combines the slabs itself (flags & 8:
+ *   the separate finishing launch of rounds 1-2 instead).
  * Returns 0, or RLREP_ERR_ARG when the engine cannot run the shape (alignment rules in gemm_lds.hip). */
 int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, int32_t lda, const float* b_dev, int32_t ldb,
                    float* c_dev, int32_t ldc, int32_t rows, int32_t cols, int32_t inner, int32_t epi, int32_t act, int32_t flags,

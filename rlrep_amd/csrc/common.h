@@ -95,6 +95,9 @@ struct GemmTask {
     // bslab [splits][R]; the finishing launch adds them in split order) -- zero for gemm16 launches
     int splits, kchunk, fin_base;
     float* slab; float* bslab;
+    // arrival counters, one per output tile (tickets != nullptr): the workgroup that stores the LAST split of a tile adds the slabs in split
+    // order and runs the epilogue inside the tile kernel -- no finishing launch (gemm_lds.hip)
+    int* tickets;
 };
 
 // host side: fill the slots of a finished task record (every launcher of the 16-row tile engine calls it on its copy of the record)

@@ -1614,6 +1614,12 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
             if (!wsp || ws_floats < (int64_t)psp * R * (((Cn + 3) & ~3) + 1)) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
             t.slab = wsp; t.bslab = wsp + (size_t)psp * R * ((Cn + 3) & ~3); t.fin_base = 0;
             fin = (int)(((long long)R * ((Cn + 3) / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
+            // the in-kernel last-arriver combine (flags & 8: the finishing launch instead) when the workspace has room for its counters
+            const int64_t used = (int64_t)psp * R * (((Cn + 3) & ~3) + 1), ntk = (int64_t)((R + 63) / 64) * ((Cn + 63) / 64);
+            if (engine == 1 && !(flags & 8) && ws_floats >= used + ntk) {
+                t.tickets = reinterpret_cast<int*>(wsp + used);
+                if (hipMemsetAsync(t.tickets, 0, sizeof(int) * ntk, (hipStream_t)stream) != hipSuccess) { rl_set_error("gemm: cannot clear the arrival counters"); return RLREP_ERR_HIP; }
+            }
         }
         t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;

@@ -144,9 +144,18 @@ struct Builder {
                 // (the bias-gradient flag depends on a pointer that is null in the dry pass: reserve for every dW task)
                 float* slab = sp > 1 ? ws.f((size_t)sp * t.R * ((t.Cn + 3) & ~3)) : nullptr;
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
+                // arrival counters of the in-kernel split-K combine (at most one per 64 x 64 output tile), zeroed once: the last arriver
+                // of a tile leaves its counter at zero.  MEASURED (MI355X) and NOT the default: the tile that draws the last ticket reads
+                // splits x 16 KB through one CU while the finishing launch spreads the same bytes over the chip -- ctrlsac at main.py's
+                // dimensions 718 vs 756 train()/s, spedersac (Ant, F = 512) 880 vs 933 (the guide's splitk-seam row says the same: +6 %).
+                // RLREP_SPLITK_INKERNEL=1 selects it (bit-identical results: tests/test_gemm_engines.py).
+                int* tickets = sp > 1 ? (int*)ws.alloc(sizeof(int) * (size_t)((t.R + 63) / 64) * ((t.Cn + 63) / 64)) : nullptr;
+                if (tickets && !dry && ws.ok()) (void)hipMemset(tickets, 0, sizeof(int) * (size_t)((t.R + 63) / 64) * ((t.Cn + 63) / 64));
+                if (!getenv("RLREP_SPLITK_INKERNEL")) tickets = nullptr;
                 // ... pointer alignment can only add scalar-access flags (and take bf16x3 away)
                 const int code = rl_gemm_lds_route(&t, la, lb, dry ? 0 : rl_gemm_lds_ptr_flags(&t), &sp, &kc, &fl);
                 t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab; t.flags |= fl;
+                t.tickets = (sp > 1 && code != 129) ? tickets : nullptr;
                 (code == 129 ? bigx3 : code == 128 ? big128 : big64).push_back(t);
                 continue;
             }

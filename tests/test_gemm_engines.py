@@ -45,7 +45,7 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0):
+def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0, fin_launch=False):
     """mode: 'fwd' (A [R,K], B [Cn,K]), 'dx' (A [R,K], B [K,Cn]), 'dw' (A [K,R], B [K,Cn]).  Returns (got, want, extra)."""
     from rlrep_amd import _lib
     rs = np.random.RandomState(seed)
@@ -60,7 +60,7 @@ def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, s
     dA, dB, dC = _dev(A), _dev(Bm), _dev(C0)
     bias_v = aux = out2 = None
     epi = {'fwd': 0, 'dx': 1, 'dw': 3}[mode]
-    flags = 1 if accum else 0
+    flags = (1 if accum else 0) | (8 if fin_launch else 0)      # 8: split-K finished by the separate launch instead of the last arriver
     extra_want = None
     if mode == 'fwd':
         bias_v = rs.standard_normal(Cn).astype(np.float32) if bias else None
@@ -80,7 +80,7 @@ def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, s
     d_bias = _dev(bias_v) if bias_v is not None else None
     d_aux = _dev(aux) if aux is not None else None
     # split-K slabs: splits * R * (Cn + 1) floats; the automatic plan never exceeds ~256 tiles' worth beyond the output
-    ws_floats = splits * R * (Cn + 5) if splits else min(32 * R * (Cn + 5), 10_000_000 + 2 * (R + 128) * (Cn + 133))
+    ws_floats = (splits * R * (Cn + 5) + 4096) if splits else min(32 * R * (Cn + 5), 10_000_000 + 2 * (R + 128) * (Cn + 133))
     ws = torch.zeros(max(1, ws_floats), device='cuda')
     rc = _lib.lib.rlrep_gemm(engine, la, lb, _ptr(dA), dA.shape[1], _ptr(dB), dB.shape[1], _ptr(dC), Cn, R, Cn, K, epi, ACT[act], flags,
                              _ptr(d_bias), _ptr(d_aux), Cn, _ptr(out2), bt, splits, _ptr(ws), ws.numel(),
@@ -124,11 +124,16 @@ def test_lds_engine_ragged_edges(mode, bt):
 
 
 @pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+@pytest.mark.parametrize('fin_launch', [False, True])
 @pytest.mark.parametrize('splits', [2, 3, 7])
-def test_lds_engine_split_k(mode, splits):
+def test_lds_engine_split_k(mode, splits, fin_launch):
     """split-K slabs + finishing launch, including a last split shorter than the others and K not a multiple of 32"""
-    check(1, mode, 128, 192, 708, bt=64, splits=splits, seed=5, accum=(mode != 'fwd'))
-    check(1, mode, 200, 128, 1024, bt=128, splits=splits, seed=6)
+    check(1, mode, 128, 192, 708, bt=64, splits=splits, seed=5, accum=(mode != 'fwd'), fin_launch=fin_launch)
+    check(1, mode, 200, 128, 1024, bt=128, splits=splits, seed=6, fin_launch=fin_launch)
+    if not fin_launch:          # the in-kernel combine adds the slabs in split order whoever arrives last: bit-identical to the finishing launch
+        a, _, _ = run_gemm(1, mode, 200, 128, 1024, bt=64, splits=splits, seed=6)
+        b, _, _ = run_gemm(1, mode, 200, 128, 1024, bt=64, splits=splits, seed=6, fin_launch=True)
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize('act', ['relu', 'elu', 'sin', 'tanh'])
