@@ -201,10 +201,10 @@ int32_t rlrep_fill_indices_dev(int32_t* dst_dev, int64_t n, const int32_t* hi_de
 int32_t rlrep_fill_normal_dev(float* dst_dev, int64_t n, float std, uint64_t seed, uint64_t offset,
                               const int32_t* counter_dev, void* stream);
 const int32_t* rlrep_steps_dev(rlrep_agent* agent);
-/* The four optimizer groups' device records: 14 32-bit words each -- {int32 step; float lr, beta1, beta2, eps, tau; 8 derived floats
- * recomputed on every step}.  A checkpoint restores `step` only and keeps the constructor's hyper-parameters (rlrep_amd/agent/sac). */
+/* The four optimizer groups' device records: 22 32-bit words each -- {int32 step; float lr, beta1, beta2, eps, tau; 8 derived floats
+ * recomputed on every step; 8 words of running beta^step powers (double) with the (step, betas) they belong to}.  A checkpoint restores `step` only and keeps the constructor's hyper-parameters (rlrep_amd/agent/sac). */
 const void* rlrep_group_cfg_dev(rlrep_agent* agent);
-#define RLREP_GROUP_CFG_WORDS 14
+#define RLREP_GROUP_CFG_WORDS 22
 
 /* ---- launch-saving forms of the sampling calls (graph-replayed train()) -------------------------
  * rlrep_train_prologue == rlrep_begin_train + rlrep_fill_indices_dev(idx_pool) + rlrep_fill_normal_dev(eps_pool) +

@@ -342,10 +342,10 @@ class HipCore:
         return self.workspace[:end]
 
     def group_cfg(self):
-        """float32[4, 14] view of the optimizer groups' device records (include/rlrep.h rlrep_group_cfg_dev): column 0 is the int32
+        """float32[4, 22] view of the optimizer groups' device records (include/rlrep.h rlrep_group_cfg_dev): column 0 is the int32
         step counter (bit pattern), columns 1..5 = lr, beta1, beta2, eps, tau."""
         off = lib.rlrep_group_cfg_dev(self.h) - self.workspace.data_ptr()
-        return self.workspace[off:off + 4 * 14 * 4].view(torch.float32).view(4, 14)
+        return self.workspace[off:off + 4 * 22 * 4].view(torch.float32).view(4, 22)
 
     def launch_count(self):
         return lib.rlrep_last_launch_count(self.h)

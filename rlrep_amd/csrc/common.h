@@ -225,12 +225,28 @@ __device__ __forceinline__ void adam_elem(const AdamScal& a, float g, float* p, 
 }
 
 // Per-optimizer-group device state: hyper-parameters (written once at create), the Adam step counter and the
-// bias-correction scalars of the CURRENT step.  The loss kernel of a step program bumps it (one thread, one
-// double-precision pow) so that the optimizer epilogues only read eight floats.
-struct GroupCfg { int step; float lr, b1, b2, eps, tau; AdamScal sc; };
+// bias-correction scalars of the CURRENT step.  The loss kernel of a step program bumps it (one thread) so that the
+// optimizer epilogues only read eight floats.
+// b1p / b2p = beta^step in double precision, advanced by ONE multiplication per step: the two double-precision pow() calls this
+// replaced ran in a single thread of a launch on the critical chain (heads_vae / qhead: its block 0 ended ~1 us after the others).
+// They are trusted only while (pstep, pb1, pb2) say they belong to the current (step, beta1, beta2) -- a caller that rewrites the record
+// (checkpoint restore, a test that zeroes the step) falls back to pow() once.
+struct GroupCfg { int step; float lr, b1, b2, eps, tau; AdamScal sc; int pstep; float pb1, pb2; int pad_; double b1p, b2p; };
 __device__ __forceinline__ void bump_group(GroupCfg* g) {
-    g->step += 1;
-    g->sc = adam_scalars(g->lr, g->b1, g->b2, g->eps, g->tau, g->step);
+    const int step = g->step + 1;
+    const float b1 = g->b1, b2 = g->b2;
+    double p1, p2;
+    if (g->pstep == step - 1 && g->pb1 == b1 && g->pb2 == b2 && step > 1) { p1 = g->b1p * (double)b1; p2 = g->b2p * (double)b2; }
+    else { p1 = pow((double)b1, (double)step); p2 = pow((double)b2, (double)step); }
+    g->step = step; g->pstep = step; g->pb1 = b1; g->pb2 = b2; g->b1p = p1; g->b2p = p2;
+    AdamScal a;
+    const double bc1 = 1.0 - p1, bc2 = 1.0 - p2;
+    a.nss = (float)(-((double)g->lr / bc1));
+    a.bc2s = (float)sqrt(bc2);
+    a.w1 = (float)(1.0 - (double)b1);
+    a.w2 = (float)(1.0 - (double)b2);
+    a.b2 = b2; a.eps = g->eps; a.tau = g->tau; a.omt = (float)(1.0 - (double)g->tau);
+    g->sc = a;
 }
 
 // block-wide sum for 256-thread blocks; result valid in thread 0
