@@ -278,8 +278,10 @@ int32_t rlrep_feature_backward_part(rlrep_agent* agent, int32_t part, const floa
  * per parameter as the sequential entry points (tests/test_hip_parity.py::test_deferred_pipeline_is_equivalent); the caller
  * must order: snapshot(t) into set s after feature steps(t) AND after the deferred pair that last used set s; deferred(t) after
  * snapshot(t) and after deferred(t-1); anything that reads the critic / actor (select_action, checkpoints, metrics of those steps)
- * after deferred(t).  There are two sets, so with set = t & 1 a snapshot only waits for the pair of train(t-2). */
-int32_t rlrep_defer_supported(rlrep_agent* agent);          /* number of snapshot sets (2) or 0 */
+ * after deferred(t).  There are rlrep_defer_supported()
+ * sets (3), so with set = t % 3 a snapshot only waits for the pair of train(t-3): the DEVICE needs two, the third keeps a HOST that waits for
+ * that older pair before launching the next feature chain a full call ahead of the device. */
+int32_t rlrep_defer_supported(rlrep_agent* agent);          /* number of snapshot sets (3) or 0 */
 int32_t rlrep_defer_snapshot(rlrep_agent* agent, int32_t set, const float* eps_critic_dev, const float* eps_actor_dev, void* stream);
 /* Folded form: called BEFORE the last feature step of train(t), rlrep_defer_arm makes that step's optimizer launch (rlrep_feature_apply)
  * write snapshot set `set` as well -- the minibatch slices, noise and step counter by extra blocks, the f_target block by the lanes that

@@ -597,8 +597,10 @@ class SACAgent(object):
 
     def _wait_set_free(self, P, k, s_f):
         """Snapshot set k is about to be overwritten by the feature chain of this call: the critic / actor chain that read it last
-        (train t-2) must have finished.  Waited for on the HOST: a wait packet in the feature stream costs ~12 us of its critical path
-        (2 816 -> 2 917 train()/s); the host then runs at most two calls ahead of the device.  RLREP_HOST_REUSE_WAIT=0: stream wait."""
+        (train t-nset) must have finished.  Waited for on the HOST: a wait packet in the feature stream costs ~12 us of its critical path
+        (2 816 -> 2 917 train()/s); the host then runs at most nset calls ahead of the device.  With nset = 2 that wait ends about one
+        graph-launch latency before the running feature chain does and the feature queue idles between calls; the third set
+        (RLREP_DEFER_SETS, default 3) removes it.  RLREP_HOST_REUSE_WAIT=0: stream wait."""
         if os.environ.get('RLREP_HOST_REUSE_WAIT', '1') != '0':
             P['ev_ca'][k].synchronize()
         else:
@@ -651,13 +653,14 @@ class SACAgent(object):
                     c.deferred_critic_actor(0)
                 P.update(first=first, steady=steady, tail=tail)
             else:
-                # two streams that were TIMED to be concurrent; train(t) uses snapshot set t & 1:
+                # two streams that were TIMED to be concurrent; train(t) uses snapshot set t % nset:
                 #   stream F : [feature steps(t) + snapshot(t -> set)]            after the critic/actor pair of t-2 (same set)
                 #   stream CA: [critic + actor(t) from set]                       after snapshot(t)
                 from rlrep_amd._lib import lib as _l
                 fs, ca = [], []
                 n0 = _l.rlrep_launch_counter()
-                for k in range(2):
+                nset = min(c.defer_supported(), max(2, int(os.environ.get('RLREP_DEFER_SETS', '3'))))
+                for k in range(nset):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
                         ec, ea = self._feature_part(buffer, B, snap_set=k)
@@ -665,22 +668,22 @@ class SACAgent(object):
                         c.end_train()
                     fs.append(g)
                 n1 = _l.rlrep_launch_counter()
-                for k in range(2):
+                for k in range(nset):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
                         c.deferred_critic_actor(k)
                     ca.append(g)
-                P['launches'] = ((n1 - n0) // 2, (_l.rlrep_launch_counter() - n1) // 2)      # kernels in the feature / critic+actor graph
+                P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
                 s_ca, s_f = _concurrent_stream_pair(c)
-                P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
-                         ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
+                P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, nset=nset, ev_snap=[torch.cuda.Event() for _ in range(nset)],
+                         ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
             self._pipe = P
         P = self._pipe
         if P['mode'] == 1:
             (P['steady'] if self._pending else P['first']).replay()
             self._pending = True
             return self.core.info(lazy_source=self._flushed_metrics)
-        k = P['t'] & 1
+        k = P['t'] % P['nset']
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
         cur = torch.cuda.current_stream()
@@ -779,10 +782,10 @@ class SACAgent(object):
             torch.cuda.current_stream().wait_stream(cap)
             torch.cuda.synchronize()
             s_ca, s_f = _concurrent_stream_pair(c)
-            self._pipe = dict(key=key, mode=3, t=0, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
+            self._pipe = dict(key=key, mode=3, t=0, nset=2, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
                               ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
         P = self._pipe
-        k = P['t'] & 1
+        k = P['t'] % P['nset']
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
         cur = torch.cuda.current_stream()

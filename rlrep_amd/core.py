@@ -272,7 +272,8 @@ class HipCore:
 
     # ---- deferred critic / actor steps (include/rlrep.h: the feature steps of train(t+1) may run beside them) --------
     def defer_supported(self):
-        return lib.rlrep_defer_supported(self.h) == 2
+        """Number of snapshot sets the deferred critic / actor chain may rotate over (0: not built for this agent)."""
+        return int(lib.rlrep_defer_supported(self.h))
 
     def defer_snapshot(self, eps_critic, eps_actor, set=0):
         check(lib.rlrep_defer_snapshot(self.h, int(set), _ptr(eps_critic), _ptr(eps_actor), _stream()), 'defer_snapshot')

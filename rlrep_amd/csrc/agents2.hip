@@ -330,7 +330,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
     if (ag->h.world_size <= 1) {
         const LT& q0 = ag->L.get("phi.l1.weight");
         const LT& ql = ag->L.get("phi.l3.bias");
-        for (int set = 0; set < 2; ++set) {
+        for (int set = 0; set < rlrep_agent::NSETS; ++set) {
             const Slot keep = defer_begin(b, ag, set, "phi.", "phi.l1.weight", Pw("phi.l1.weight"), ql.off + ql.rows - q0.off);
             critic_program(ag->dset[set].critic_bwd);
             actor_program(ag->dset[set].actor_bwd);
@@ -467,7 +467,7 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
         const LT& q0 = ag->L.get(phi.name(0) + ".weight");
         const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
         const std::string pre = phi.prefix + ".", first = phi.name(0) + ".weight";
-        for (int set = 0; set < 2; ++set) {
+        for (int set = 0; set < rlrep_agent::NSETS; ++set) {
             const Slot keep = defer_begin(b, ag, set, pre.c_str(), first.c_str(), ag->P(first), ql.off + ql.rows - q0.off);
             Program unused;
             critic_program(ag->dset[set].critic_bwd, unused, false);

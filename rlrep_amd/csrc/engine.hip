@@ -852,7 +852,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
 
     // ---- deferred variants: the same critic / actor programs against a snapshot set (see rlrep_agent::dset) ----
-    for (int set = 0; set < 2; ++set) {
+    for (int set = 0; set < rlrep_agent::NSETS; ++set) {
         const LT& f0 = ag->L.get(fnet + ".l1.weight");
         const LT& fl = ag->L.get(fnet + ".log_std_linear.bias");
         float* fbase = nft ? ag->a.param_dev : ag->a.target_dev;          // the snapshot is of whichever copy the two steps read
@@ -912,8 +912,9 @@ void defer_end(Builder& b, rlrep_agent* ag, int set, const Slot& keep, const std
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2, &ag->dset[0].critic_bwd, &ag->dset[0].critic_apply, &ag->dset[0].actor_bwd, &ag->dset[1].critic_bwd, &ag->dset[1].critic_apply, &ag->dset[1].actor_bwd})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2})
         p->stages.clear();
+    for (auto& D : ag->dset) for (Program* p : {&D.critic_bwd, &D.critic_apply, &D.actor_bwd}) p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
     ag->pf_armed = ag->pf_done = false;
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
@@ -1429,15 +1430,15 @@ int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
 int32_t rlrep_defer_supported(rlrep_agent* ag) {
     if (!ag) return 0;
     int n = 0;
-    for (int k = 0; k < 2; ++k) if (!ag->dset[k].critic_bwd.stages.empty() && !ag->dset[k].actor_bwd.stages.empty()) ++n;
-    return n == 2 ? 2 : 0;
+    for (int k = 0; k < rlrep_agent::NSETS; ++k) if (!ag->dset[k].critic_bwd.stages.empty() && !ag->dset[k].actor_bwd.stages.empty()) ++n;
+    return n == rlrep_agent::NSETS ? n : 0;
 }
 // Arm the folded snapshot: the NEXT feature optimizer launch (rlrep_feature_apply) also writes snapshot set `set` -- the minibatch slices
 // and the two noise blocks by extra blocks, the f_target (or live f) block by the lanes that produce its new values -- and the
 // rlrep_defer_snapshot that follows with the same arguments launches nothing.  To be called before the LAST feature step of a train().
 // Returns 1 if armed, 0 if this agent / configuration has no folded form (the caller proceeds as before).
 int32_t rlrep_defer_arm(rlrep_agent* ag, int32_t set, const float* eps_critic, const float* eps_actor) {
-    if (!ag || set < 0 || set > 1) return 0;
+    if (!ag || set < 0 || set >= rlrep_agent::NSETS) return 0;
     ag->snap_armed = false; ag->snap_done = -1;
     if (!eps_critic || !eps_actor || !rlrep_defer_supported(ag) || ag->dset[set].block_which < 0 || !ag->dset[set].block) return 0;
     if (!ag->sync_prog.stages.empty()) return 0;
@@ -1445,7 +1446,7 @@ int32_t rlrep_defer_arm(rlrep_agent* ag, int32_t set, const float* eps_critic, c
     return 1;
 }
 int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_critic, const float* eps_actor, void* stream) {
-    if (!ag || !eps_critic || !eps_actor || set < 0 || set > 1) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
+    if (!ag || !eps_critic || !eps_actor || set < 0 || set >= rlrep_agent::NSETS) { rl_set_error("defer_snapshot: bad argument"); return RLREP_ERR_ARG; }
     if (!rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
     if (!ag->slot[0].filled) { rl_set_error("defer_snapshot before set_batch / replay_sample"); return RLREP_ERR_STATE; }
     if (!ag->sync_prog.stages.empty()) {          // ctrlsac: frozen_phi, frozen_phi_target <- phi (ctrlsac_agent.py:344-346) belongs to the end of the feature steps
@@ -1468,7 +1469,7 @@ int32_t rlrep_defer_snapshot(rlrep_agent* ag, int32_t set, const float* eps_crit
 // part: 0 critic backward, 1 critic apply (+ period-gated critic-target Polyak), 2 actor backward, 3 actor + temperature apply; -1 all.
 // Data parallel callers all-reduce the critic / actor gradient slices between 0 and 1 and between 2 and 3.
 int32_t rlrep_deferred_part(rlrep_agent* ag, int32_t set, int32_t part, void* stream) {
-    if (!ag || set < 0 || set > 1 || part < -1 || part > 3 || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
+    if (!ag || set < 0 || set >= rlrep_agent::NSETS || part < -1 || part > 3 || !rlrep_defer_supported(ag)) { rl_set_error("deferred critic/actor steps are not built for this agent"); return RLREP_ERR_STATE; }
     rlrep_agent::DeferSet& D = ag->dset[set];
     if (!D.valid) { rl_set_error("deferred critic/actor steps before rlrep_defer_snapshot of this set"); return RLREP_ERR_STATE; }
     const float* e_crit = D.eps; const float* e_act = D.eps + (size_t)ag->B * ag->d.action_dim;

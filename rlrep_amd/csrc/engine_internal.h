@@ -39,14 +39,17 @@ struct rlrep_agent {
     // run [critic, actor of t] and [feature steps of t+1] as two concurrent branches.  rlrep_defer_snapshot takes the snapshot
     // (one launch) after the last feature step; rlrep_deferred_critic_actor runs the two steps against it.  Same arithmetic,
     // same order of updates per parameter; only the overlap changes.
-    // TWO snapshot sets (ping-pong): train(t) uses set t & 1, so the snapshot of train(t+1) never has to wait for the critic / actor
-    // pair of train(t) -- only for that of train(t-1), which is long finished.
+    // SEVERAL snapshot sets (round robin): train(t) uses set t % NSETS, so the snapshot of train(t+1) never has to wait for the critic /
+    // actor pair of train(t) -- only for that of train(t+1-NSETS).  Two sets are enough for the DEVICE; the third is for the HOST, which waits
+    // for that older pair before it may launch the next feature chain: with two sets that wait ends ~one graph-launch latency before the
+    // running feature chain does, and the feature queue idles between two train() calls (tools/exp/trace_gaps.py).
     struct DeferSet {
         Slot slot; float* block = nullptr; float* eps = nullptr; int* steps = nullptr; CopySegs segs;
         long long block_off = 0, block_n = 0; int block_which = -1;        // the block as the feature optimizer launch sees it (-1: no folded snapshot)
         Program critic_bwd, critic_apply, actor_bwd; int actor_resume = 0; bool valid = false;
     };
-    DeferSet dset[2]; int dcur = 0;             // dcur: the set the programs under construction belong to
+    static constexpr int NSETS = 3;             // rlrep_defer_supported() reports it; a caller rotating over all of them only ever waits for the pair of train(t-3)
+    DeferSet dset[NSETS]; int dcur = 0;             // dcur: the set the programs under construction belong to
     // while the deferred programs are built, tensors named ov_prefix* resolve into the snapshot block ov_base (same internal layout
     // as the block that starts at ov_first): vlsac f_target.*, ctrlsac phi.*, spedersac phi.trunk.*
     const float* ov_base = nullptr; std::string ov_prefix, ov_first;
