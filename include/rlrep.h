@@ -359,6 +359,11 @@ int32_t rlrep_chain_status(rlrep_agent* agent, uint32_t* status, void* stream);
  * RLREP_XCHAIN, RLREP_FUSE_L1, superseded noise-critic forward kernels).  0: they are not compiled in and their switches are ignored. */
 int32_t rlrep_build_flags(void);
 
+/* Diagnostics: one single-thread launch on `stream` that appends (100 MHz device wall clock << 8 | tag) to a ring of `cap` 64-bit words
+ * after a running counter in ring[0] (ring: cap + 1 words of device memory, zeroed by the caller).  Captured between the launches of a
+ * train() graph it dates the chains on the DEVICE (tools/exp/chain_stamps.py); it is not part of any step. */
+int32_t rlrep_debug_stamp(int64_t* ring_dev, int32_t cap, int32_t tag, void* stream);
+
 /* Number of kernel launches the last step program issued (for the latency model in DESIGN.md). */
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 /* process-wide number of kernel launches the library has issued so far (a captured train()'s launch count = the difference around its capture) */

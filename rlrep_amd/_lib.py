@@ -125,6 +125,7 @@ def _load():
         'rlrep_nc_fwd_plan': (i32, [i32] * 4 + [P(i32)] * 3),
         'rlrep_chain_status': (i32, [vp, P(C.c_uint32), vp]),
         'rlrep_build_flags': (i32, []),
+        'rlrep_debug_stamp': (i32, [vp, i32, i32, vp]),
         'rlrep_metrics_dev': (vp, [vp]),
         'rlrep_last_launch_count': (i32, [vp]),
         'rlrep_launch_counter': (i64, []),

@@ -595,6 +595,15 @@ class SACAgent(object):
             self._feature_once(buffer, B, i, True)
         return self._pool['eps_crit'], self._pool['eps_act']
 
+    def _stamp(self, tag):
+        """RLREP_STAMP=1 (diagnostics, tools/exp/chain_stamps.py): a one-thread launch that dates this point of the chain on the device."""
+        if os.environ.get('RLREP_STAMP', '0') != '1':
+            return
+        from rlrep_amd._lib import lib as _l, check as _check
+        if getattr(self, '_stamp_ring', None) is None:
+            self._stamp_ring = torch.zeros(1 + 8192, dtype=torch.int64, device=self.core.device)
+        _check(_l.rlrep_debug_stamp(self._stamp_ring.data_ptr(), 8192, int(tag), torch.cuda.current_stream().cuda_stream), 'debug_stamp')
+
     def _wait_set_free(self, P, k, s_f):
         """Snapshot set k is about to be overwritten by the feature chain of this call: the critic / actor chain that read it last
         (train t-nset) must have finished.  Waited for on the HOST: a wait packet in the feature stream costs ~12 us of its critical path
@@ -663,15 +672,19 @@ class SACAgent(object):
                 for k in range(nset):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
+                        self._stamp(1)
                         ec, ea = self._feature_part(buffer, B, snap_set=k)
                         c.defer_snapshot(ec, ea, k)
                         c.end_train()
+                        self._stamp(2)
                     fs.append(g)
                 n1 = _l.rlrep_launch_counter()
                 for k in range(nset):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s1):
+                        self._stamp(3)
                         c.deferred_critic_actor(k)
+                        self._stamp(4)
                     ca.append(g)
                 P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
                 s_ca, s_f = _concurrent_stream_pair(c)

@@ -1672,6 +1672,18 @@ int32_t rlrep_chain_status(rlrep_agent* ag, uint32_t* status, void* stream) {
     return 0;
 }
 
+__global__ void debug_stamp_kernel(long long* ring, int cap, int tag) {
+    const unsigned long long i = atomicAdd((unsigned long long*)ring, 1ull);
+    ring[1 + (long long)(i % (unsigned long long)cap)] = (long long)((wall_clock64() << 8) | (unsigned long long)(tag & 255));
+}
+int32_t rlrep_debug_stamp(int64_t* ring, int32_t cap, int32_t tag, void* stream) {
+    if (!ring || cap <= 0) { rl_set_error("debug_stamp: bad argument"); return RLREP_ERR_ARG; }
+    hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)ring, (int)cap, (int)tag);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("debug_stamp: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    return 0;
+}
+
 int32_t rlrep_build_flags(void) {
 #ifdef RL_EXPERIMENTS
     return 1;
