@@ -359,6 +359,16 @@ int32_t rlrep_chain_status(rlrep_agent* agent, uint32_t* status, void* stream);
  * RLREP_XCHAIN, RLREP_FUSE_L1, superseded noise-critic forward kernels).  0: they are not compiled in and their switches are ignored. */
 int32_t rlrep_build_flags(void);
 
+/* Metric history.  While on (rlrep_history(agent, 1)), the LAST optimizer launch of every train() -- the actor's, reference
+ * agent/sac/sac_agent.py:157-166 -- also appends the 16 metric slots to a device ring of *records records of *record_floats floats: record
+ * n % *records holds the metrics of the n-th such launch since the agent was created and n itself (int32 bit pattern) in word *tag_word; *seq is
+ * the device counter n.  The reference returns the metrics of a train() as host floats (a device sync per value); a caller
+ * that replays train() as a hipGraph reads record n when -- and if -- somebody looks at the returned dict, instead of paying a snapshot
+ * launch per call.  A record is overwritten *records calls later: the tag says whether it still is the one asked for.  The switch is read
+ * when a step is LAUNCHED (or captured), not on the device.  Not kept by the fused-optimizer variant (RLREP_FUSE_ADAM). */
+int32_t rlrep_history(rlrep_agent* agent, int32_t on);
+int32_t rlrep_history_dev(rlrep_agent* agent, const float** ring, const int32_t** seq, int32_t* records, int32_t* record_floats, int32_t* tag_word);
+
 /* Diagnostics: one single-thread launch on `stream` that appends (100 MHz device wall clock << 8 | tag) to a ring of `cap` 64-bit words
  * after a running counter in ring[0] (ring: cap + 1 words of device memory, zeroed by the caller).  Captured between the launches of a
  * train() graph it dates the chains on the DEVICE (tools/exp/chain_stamps.py); it is not part of any step. */

@@ -126,6 +126,8 @@ def _load():
         'rlrep_chain_status': (i32, [vp, P(C.c_uint32), vp]),
         'rlrep_build_flags': (i32, []),
         'rlrep_debug_stamp': (i32, [vp, i32, i32, vp]),
+        'rlrep_history': (i32, [vp, i32]),
+        'rlrep_history_dev': (i32, [vp, P(vp), P(vp), P(i32), P(i32), P(i32)]),
         'rlrep_metrics_dev': (vp, [vp]),
         'rlrep_last_launch_count': (i32, [vp]),
         'rlrep_launch_counter': (i64, []),

@@ -551,6 +551,8 @@ class SACAgent(object):
                 # every rank builds its graph at the same train() call, so this is a matched collective
                 dist.all_reduce(torch.zeros(1, device=self.core.device))
                 torch.cuda.synchronize()
+            self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')      # see _train_graph
+            self.core.history(self._hist)
             with torch.cuda.stream(s):
                 first = torch.cuda.CUDAGraph()
                 # thread-local capture mode: the process group's watchdog thread may query events while we capture
@@ -563,15 +565,21 @@ class SACAgent(object):
                     cur.capture_end()
                     segs.append(('graph', cur))
                 finally:
+                    self.core.history(False)
                     self._abort_open_capture()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._graph, self._graph_key = segs, key
+            self._hist_n = self.core.history_seq() if self._hist else 0
         for kind, x in self._graph:
             if kind == 'graph':
                 x.replay()
             else:
                 x()
+        if self._hist:
+            n = self._hist_n
+            self._hist_n += 1
+            return self.core.info(lazy_source=self.core.history_source(n))
         return self.core.info()
 
     # ---- pipelined graph mode ---------------------------------------------------------------------------------------
@@ -870,9 +878,21 @@ class SACAgent(object):
             s = torch.cuda.Stream()
             g = torch.cuda.CUDAGraph()
             n0 = _l.rlrep_launch_counter()
-            with torch.cuda.graph(g, stream=s):
-                self._body(buffer, B, True)
+            # the call's metrics are filed in the library's history ring by the last launch of the graph (rlrep_history) and fetched when the
+            # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_INFO_HISTORY=0: a clone per call.
+            self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')
+            self.core.history(self._hist)
+            try:
+                with torch.cuda.graph(g, stream=s):
+                    self._body(buffer, B, True)
+            finally:
+                self.core.history(False)
             self._graph, self._graph_key = g, key
             self._graph_launches = _l.rlrep_launch_counter() - n0
+            self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
         self._graph.replay()
+        if self._hist:
+            n = self._hist_n
+            self._hist_n += 1
+            return self.core.info(lazy_source=self.core.history_source(n))
         return self.core.info()

@@ -324,6 +324,38 @@ class HipCore:
             self._mt = self.workspace[off:off + 4 * METRIC_SLOTS].view(torch.float32)
         return self._mt
 
+    # ---- metric history (include/rlrep.h rlrep_history): the metrics of whole-train() graph replays, read when somebody looks --------
+    def history(self, on):
+        check(lib.rlrep_history(self.h, 1 if on else 0), 'history')
+
+    def _history_views(self):
+        if not hasattr(self, '_hist'):
+            ring, seq = C.c_void_p(), C.c_void_p()
+            n, rec, tag = C.c_int32(), C.c_int32(), C.c_int32()
+            check(lib.rlrep_history_dev(self.h, C.byref(ring), C.byref(seq), C.byref(n), C.byref(rec), C.byref(tag)), 'history_dev')
+            base = self.workspace.data_ptr()
+            r = self.workspace[ring.value - base:ring.value - base + 4 * n.value * rec.value].view(torch.float32).view(n.value, rec.value)
+            q = self.workspace[seq.value - base:seq.value - base + 4].view(torch.int32)
+            self._hist = (r, q, n.value, tag.value)
+        return self._hist
+
+    def history_seq(self):
+        """Number of records filed so far (SYNCHRONISES the current stream)."""
+        return int(self._history_views()[1].item())
+
+    def history_source(self, n):
+        """LazyInfo source for the metrics of the n-th filed train(): fetched from the ring on first read."""
+        ring, _, cap, tag = self._history_views()
+
+        def fetch():
+            rec = ring[n % cap].cpu()
+            got = int(rec.view(torch.int32)[tag])
+            if got != n:
+                raise RuntimeError(f'the metrics of this train() call (record {n}) have been overwritten: the history ring holds the last {cap} '
+                                   f'calls (found record {got}); read a returned info dict within {cap} train() calls')
+            return rec[:METRIC_SLOTS]
+        return fetch
+
     def info(self, keys=None, lazy_source=None, early=None):
         snap = lazy_source if lazy_source is not None else self.metrics_tensor().clone()
         names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]

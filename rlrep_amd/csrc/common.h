@@ -50,6 +50,9 @@ enum Epi : int {
 // optimizer launch: rows of W1 itself would be 92-/160-byte-strided 4-byte reads), x2 = b1 (ldaux2 = 0).  vlsac: encoder.l1 / f.l1 ride in
 // the encoder.l2 / f.l2 launch.
 #define FLAG_PRE_FWD 512
+// dX form only: the fused short product's mask is ELU'(M) = (M > 0 ? 1 : M + 1) instead of ReLU'(M) -- the actor head's dX (K1 = 2A) riding in
+// the dX launch of the actor's second layer (agent/sac/actor.py:31-45 backward)
+#define FLAG_PRE_ELU 1024
 
 struct GroupCfg;
 struct GemmTask {

@@ -145,8 +145,9 @@ void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab
         pb.alpha_state = ag->a.alpha_state_dev; pb.inv_batch = ag->inv_batch(); pb.G = ab.Ghead; pb.B = B; pb.A = A;
         p.stages.push_back({[=](hipStream_t st) { PolicyBwd q = pb; q.eps = ag->cur_eps; return rl_launch_policy_bwd(&q, st); }, "policy_bwd"});
     }
-    b.dx_stage(p, {Builder::dx(ab.Ghead, 2 * A, B, 2 * A, ag->P("actor.trunk.4.weight"), Ha, ab.GA2, Ha, Ha, ACT_ELU, ab.A2, Ha)}, "actor.head dx");
-    b.dx_stage(p, {Builder::dx(ab.GA2, Ha, B, Ha, ag->P("actor.trunk.2.weight"), Ha, ab.GA1, Ha, Ha, ACT_ELU, ab.A1, Ha)}, "actor.l2 dx");
+    // the head's dX (inner length 2A <= 32) is recomputed by every tile of the second layer's dX launch (FLAG_PRE | FLAG_PRE_ELU): one launch less
+    b.dx_stage12(p, Builder::dx(ab.Ghead, 2 * A, B, 2 * A, ag->P("actor.trunk.4.weight"), Ha, ab.GA2, Ha, Ha, ACT_ELU, ab.A2, Ha),
+                 Builder::dx(ab.GA2, Ha, B, Ha, ag->P("actor.trunk.2.weight"), Ha, ab.GA1, Ha, Ha, ACT_ELU, ab.A1, Ha), "actor.head dx", "actor.head dx + actor.l2 dx");
     b.dw_stage(p, {Builder::dw(ab.Ghead, 2 * A, 2 * A, ab.A2, Ha, Ha, B, ag->G("actor.trunk.4.weight"), Ha, ag->G("actor.trunk.4.bias")),
                    Builder::dw(ab.GA2, Ha, Ha, ab.A1, Ha, Ha, B, ag->G("actor.trunk.2.weight"), Ha, ag->G("actor.trunk.2.bias")),
                    Builder::dw(ab.GA1, Ha, Ha, X, ldx, S, B, ag->G("actor.trunk.0.weight"), S, ag->G("actor.trunk.0.bias"))},
@@ -158,7 +159,8 @@ std::vector<FinTask> actor_fins(rlrep_agent* ag, const float* partial_loss, int 
     fa.kind = FIN_ALPHA; fa.partials = ag->Gtail(); fa.count = nblk; fa.stride = 1; fa.scale = ag->inv_batch();
     fa.out = ag->metrics + M_ALPHA_LOSS; fa.out2 = ag->metrics + M_ALPHA; fa.alpha_state = ag->a.alpha_state_dev;
     fa.lr = ag->h.lr_actor; fa.beta1 = ag->h.beta1; fa.beta2 = ag->h.beta2; fa.eps = ag->h.adam_eps; fa.learn = ag->h.learn_alpha;
-    return {Builder::fin_sum(partial_loss, nblk, 1, 1.0f / (float)ag->B, ag->metrics + M_ACTOR_LOSS), fa};
+    // the actor's optimizer launch is the last one of a train(): it also files the call's metrics in the history ring (rlrep_history)
+    return {Builder::fin_sum(partial_loss, nblk, 1, 1.0f / (float)ag->B, ag->metrics + M_ACTOR_LOSS), fa, Builder::fin_history(ag)};
 }
 void actor_apply_program(Builder& b, rlrep_agent* ag, const float* partial_loss, int nblk) {
     b.adam(ag->actor_apply, 2, ag->h.lr_actor, nullptr, 0, 0, 0.f, actor_fins(ag, partial_loss, nblk), "adam actor + alpha");
@@ -977,6 +979,9 @@ static void static_state(rlrep_agent* ag) {
     ag->obs_in = ws.f((size_t)ag->d.max_batch * S);
     ag->act_out = ws.f((size_t)ag->d.max_batch * A);
     ag->rp_epoch = (int*)ws.alloc(sizeof(int) * 4);
+    ag->hist = ws.f((size_t)RL_HIST_N * RL_HIST_REC);
+    ag->hist_seq = (int*)ws.alloc(sizeof(int) * 4);
+    if (!ws.dry && ws.ok()) { (void)hipMemset(ag->hist, 0xff, sizeof(float) * RL_HIST_N * RL_HIST_REC); (void)hipMemset(ag->hist_seq, 0, sizeof(int) * 4); }
     ag->xc_err = (unsigned*)ws.alloc(256);
     if (!ws.dry && ws.ok()) (void)hipMemset(ag->xc_err, 0, 256);
     if (!ws.dry && ws.ok()) { const int one[4] = {1, 0, 0, 0}; (void)hipMemcpy(ag->rp_epoch, one, sizeof(one), hipMemcpyHostToDevice); }
@@ -1681,6 +1686,21 @@ int32_t rlrep_debug_stamp(int64_t* ring, int32_t cap, int32_t tag, void* stream)
     hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)ring, (int)cap, (int)tag);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("debug_stamp: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+int32_t rlrep_history(rlrep_agent* ag, int32_t on) {
+    if (!ag) { rl_set_error("history: bad argument"); return RLREP_ERR_ARG; }
+    ag->hist_on = on != 0;
+    return 0;
+}
+int32_t rlrep_history_dev(rlrep_agent* ag, const float** ring, const int32_t** seq, int32_t* records, int32_t* record_floats, int32_t* tag_word) {
+    if (!ag || !ag->hist) { rl_set_error("history_dev: bad argument"); return RLREP_ERR_ARG; }
+    if (ring) *ring = ag->hist;
+    if (seq) *seq = ag->hist_seq;
+    if (records) *records = RL_HIST_N;
+    if (record_floats) *record_floats = RL_HIST_REC;
+    if (tag_word) *tag_word = RL_HIST_TAG;
     return 0;
 }
 

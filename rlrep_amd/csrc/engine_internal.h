@@ -75,6 +75,7 @@ struct rlrep_agent {
     // cluster row programs (RLREP_ROWPROG=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
     // extra launch before an eager step outside a train())
     int* rp_epoch = nullptr;
+    float* hist = nullptr; int* hist_seq = nullptr; bool hist_on = false;      // metric history ring (kparams.h FIN_HISTORY, rlrep_history)
     // xchain.hip: error word of the persistent chain launches (rlrep_chain_status) and the names of their stages (owned here: Stage::what is a
     // plain pointer)
     unsigned* xc_err = nullptr; std::deque<std::string> stage_names;
@@ -357,7 +358,7 @@ struct Builder {
     bool fused() const { return allow_fuse && ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev && !ag->has_shadows(); }   // (the shadows are maintained by the Adam launch)
     std::vector<FinTask> pending_fin; bool fin_attached = false;
     // hand the finalisation tasks of the step to the NEXT weight-gradient stage (fused mode; ignored otherwise)
-    void stash_fin(std::vector<FinTask> f) { pending_fin = fused() ? f : std::vector<FinTask>(); fin_attached = false; }
+    void stash_fin(std::vector<FinTask> f) { if (!f.empty() && f.back().kind == FIN_HISTORY) f.pop_back(); pending_fin = fused() ? f : std::vector<FinTask>(); fin_attached = false; }
     float lr_of(int g) const { return g == 1 ? ag->h.lr_critic : g == 2 ? ag->h.lr_actor : ag->h.lr_feature; }
     int group_of(int64_t off) const {
         for (int g = 0; g < 4; ++g) if (ag->L.group_n[g] > 0 && off >= ag->L.group_off[g] && off < ag->L.group_off[g] + ag->L.group_n[g]) return g;
@@ -387,15 +388,15 @@ struct Builder {
 
     void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
     void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
-    // Two consecutive dX stages of which the FIRST has a short inner length (<= 32) and a ReLU mask: one launch in which every tile of
+    // Two consecutive dX stages of which the FIRST has a short inner length (<= 32) and a ReLU or ELU mask: one launch in which every tile of
     // the second recomputes its 16 rows of the first (gemm16.hip, FLAG_PRE).  Falls back to the two stages when the pair does not fit.
     void dx_stage12(Program& p, GemmTask d1, GemmTask d2, const char* w1, const char* w2) {
-        const bool ok = !getenv("RLREP_NO_FUSE_DX") && d1.epi == EPI_DX && d1.act == ACT_RELU && !(d1.flags & FLAG_ACCUM) && !d1.r1u && d1.K <= 32 &&
+        const bool ok = !getenv("RLREP_NO_FUSE_DX") && d1.epi == EPI_DX && (d1.act == ACT_RELU || d1.act == ACT_ELU) && !(d1.flags & FLAG_ACCUM) && !d1.r1u && d1.K <= 32 &&
                         d1.scale == 1.f && d2.A == d1.C && d2.lda == d1.ldc && d2.K == d1.Cn && d2.R == d1.R &&
                         (d2.epi == EPI_DX || d2.epi == EPI_DX_REPARAM) && ((d2.R + 15) / 16) * ((d2.Cn + 15) / 16) < 384 * 2;
         if (!ok) { dx_stage(p, {d1}, w1); dx_stage(p, {d2}, w2); return; }
         GemmTask t = d2;
-        t.flags |= FLAG_PRE;
+        t.flags |= FLAG_PRE | (d1.act == ACT_ELU ? FLAG_PRE_ELU : 0);
         t.x0 = d1.A; t.ldx0 = d1.lda; t.x1 = d1.B; t.ldx1 = d1.ldb; t.n0 = d1.K; t.x2 = d1.aux; t.ldaux2 = d1.ldaux; t.y0 = d1.C; t.ldout2 = d1.ldc;
         gemm_small(p, LD_ROW, LD_COL, {t}, w2);
     }
@@ -451,7 +452,8 @@ struct Builder {
         std::vector<AdamTask> tv{t};
         const AdamTask* dev = upload(tv);
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
-        const int nfin = (int)fin.size();
+        const int nfin_all = (int)fin.size();
+        const bool hist_last = !fin.empty() && fin.back().kind == FIN_HISTORY;        // run only while rlrep_history is on
         const int blocks = (int)((t.n + 1023) / 1024);
         rlrep_agent* a = ag;
         p.stages.push_back({[=](hipStream_t st) {
@@ -474,10 +476,13 @@ struct Builder {
                 sn.block = D.block; sn.off = D.block_off; sn.n = D.block_n; sn.which = D.block_which; sn.on = 1;
                 a->snap_armed = false; a->snap_done = a->snap_set;
             }
+            const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
             return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, sn.on ? &sn : nullptr, st);
         }, what});
     }
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
+        if (!fin.empty() && fin.back().kind == FIN_HISTORY) fin.pop_back();        // (the history ring is kept by the separate optimizer launch only)
+        if (fin.empty()) return;
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, nullptr, st); }, what});
@@ -495,6 +500,11 @@ struct Builder {
     }
     static FinTask fin_inc(int* counter) {
         FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_INC; f.out = reinterpret_cast<float*>(counter); return f;
+    }
+    static FinTask fin_history(const rlrep_agent* a) {
+        FinTask f; memset(&f, 0, sizeof(f));
+        f.kind = FIN_HISTORY; f.in_a = a->metrics; f.stride = RL_HIST_TAG; f.out = a->hist; f.count = RL_HIST_N; f.partials = reinterpret_cast<const float*>(a->hist_seq);
+        return f;
     }
     static FinTask fin_copy(const float* a, float* out) {
         FinTask f; memset(&f, 0, sizeof(f)); f.kind = FIN_COPY; f.in_a = a; f.out = out; return f;

@@ -175,9 +175,13 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
 #endif
         } else {
             if (lb != LD_COL) return -3;
-            bool rep = !getenv("RLREP_GEMM16_GENERIC"), plain = rep;
-            for (int q = 0; q < gb->ntasks; ++q) { rep = rep && gb->t[q].epi == EPI_DX_REPARAM; plain = plain && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_NONE; }
-            if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            bool rep = !getenv("RLREP_GEMM16_GENERIC"), plain = rep, elu = rep;
+            for (int q = 0; q < gb->ntasks; ++q) {
+                rep = rep && gb->t[q].epi == EPI_DX_REPARAM; plain = plain && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_NONE;
+                elu = elu && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_ELU;
+            }
+            if (elu) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
             else if (plain) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
             else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
         }

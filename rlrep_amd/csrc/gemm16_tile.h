@@ -105,7 +105,7 @@ struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const
 
 template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false>
 __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
-                                              int i, int kq, int kb, int K, bool store, f32x4 (&acc)[NF]) {
+                                              int i, int kq, int kb, int K, bool store, bool elu, f32x4 (&acc)[NF]) {
     float xf[NJ][4], wf[NU][NJ][4], mk[NU][4], b[NU][NF][4];
     const int K1 = ps.K1;
     const size_t xrow = (size_t)min(r0 + i, R - 1) * ps.ldx;
@@ -150,8 +150,8 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
         float a[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            // dX form: mk = saved ReLU output (mask); forward form: mk = the layer's bias
-            const float g = FWD ? fmaxf(D[u][m] + mk[u][m], 0.f) : (mk[u][m] > 0.f ? D[u][m] : 0.f);
+            // dX form: mk = saved ReLU / ELU output (mask; `elu` is uniform over the launch: FLAG_PRE_ELU); forward form: mk = the layer's bias
+            const float g = FWD ? fmaxf(D[u][m] + mk[u][m], 0.f) : (mk[u][m] > 0.f ? D[u][m] : (elu ? D[u][m] * (mk[u][m] + 1.f) : 0.f));
             a[m] = (rok && (kb + 64 * u + 4 * kq + m) < K) ? g : 0.f;
         }
         if (store && rok) {
@@ -281,15 +281,16 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     if constexpr (PRE) {
         PreSrc ps; ps.X = t.x0; ps.ldx = t.ldx0; ps.Wt = t.x1; ps.ldw = t.ldx1; ps.K1 = n0; ps.M = t.x2; ps.ldm = t.ldaux2; ps.out = t.y0; ps.ldo = t.ldout2;
         const bool store = (tc == 0) && ps.out;
+        const bool pre_elu = (flags & FLAG_PRE_ELU) != 0;
         // forward form (LB = LD_ROW): K1 <= 48, bias + ReLU; dX form (LB = LD_COL): K1 <= 32, ReLU mask
         constexpr int NJ = (LB == LD_ROW) ? 3 : 2;
         constexpr bool FW = (LB == LD_ROW);
         for (int kb = w * 16; kb < K; kb += 256) {
             const int nu = (K - kb + 63) >> 6;
-            if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
-            else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
-            else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
-            else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, acc);
+            if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
+            else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
+            else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
+            else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
         }
     } else
     for (int kb = w * 16; kb < K; kb += 256) {

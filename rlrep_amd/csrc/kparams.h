@@ -91,7 +91,14 @@ struct QHeadActor {
     int ldE;                   // row stride of Ec/GE (0 -> H)
 };
 
-enum FinKind : int { FIN_SUM = 0, FIN_COMBINE = 1, FIN_ALPHA = 2, FIN_COPY = 3, FIN_INC = 4 };    // FIN_INC: *(int*)out += 1 (launch epoch of the cluster programs)
+enum FinKind : int { FIN_SUM = 0, FIN_COMBINE = 1, FIN_ALPHA = 2, FIN_COPY = 3, FIN_INC = 4, FIN_HISTORY = 5 };    // FIN_INC: *(int*)out += 1 (launch epoch of the cluster programs)
+// FIN_HISTORY (last task of the LAST optimizer launch of a train(), run only while rlrep_history is on): the metric slots in_a[0 .. stride) are
+// appended to the ring `out` of `count` records of RL_HIST_REC floats, record = sequence number % count, the number itself (bit pattern) in
+// word [RL_HIST_TAG]; the sequence counter is *(int*)partials.  A caller that replays whole-train() graphs reads the metrics of call n from
+// record n % count, long after the call, without a snapshot launch per call.
+#define RL_HIST_REC 20
+#define RL_HIST_TAG 16
+#define RL_HIST_N 1024
 
 struct FinTask {
     int kind;
@@ -141,6 +148,15 @@ __device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin,
                 }
                 *f.out2 = (float)exp(st[0]);          // info['alpha'] is read after the optimizer step
             }
+        } else if (f.kind == FIN_HISTORY) {
+            // the slots were written by earlier launches and by lane 0 of this wave just above: order those stores, then read past the L1
+            __threadfence();
+            int* seq = reinterpret_cast<int*>(const_cast<float*>(f.partials));
+            const int n = *seq;
+            float* rec = f.out + (size_t)(n % f.count) * RL_HIST_REC;
+            if (lane < f.stride) rec[lane] = __hip_atomic_load(f.in_a + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == RL_HIST_TAG) reinterpret_cast<int*>(rec)[RL_HIST_TAG] = n;
+            if (lane == 0) *seq = n + 1;
         }
     }
 }

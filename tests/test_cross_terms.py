@@ -123,3 +123,30 @@ def test_feature_step_then_update_feature_target_matches_oracle():
     for k in st:
         if k in P and (k.startswith('f.') or k.startswith('f_target.') or k.startswith('encoder.') or k.startswith('decoder.')):
             assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, k
+
+
+# ---- the returned info dict of a whole-train() graph replay: filed on the device, fetched when read ------------------------------
+def test_info_of_graph_replays_is_per_call_and_expires_loudly(monkeypatch):
+    """sac_agent.py:157-166 returns the metrics of THAT call.  The one-graph train() files them in the library's history ring (rlrep_history)
+    and the dict fetches its record on first read: dicts read late and out of order equal, bit for bit, what a twin agent that snapshots
+    per call (RLREP_INFO_HISTORY=0) returned, and a dict whose record has been overwritten raises instead of reporting a later call."""
+    from test_default_mode import _default_agent, _buffer
+    c = Case('sac_tiny')
+    a, buf, n = _default_agent(c), _buffer(c), 6
+    monkeypatch.setenv('RLREP_INFO_HISTORY', '0')          # (read when the graph is captured: at the first train())
+    b = _default_agent(c)
+    ib = [dict(b.train(buf, c.B).items()) for _ in range(n)]
+    monkeypatch.delenv('RLREP_INFO_HISTORY')
+    ia = [a.train(buf, c.B) for _ in range(n)]
+    assert a._hist and not b._hist
+    for t in (4, 0, 5, 2, 1, 3):
+        for k, v in ib[t].items():
+            assert float(ia[t][k]) == float(v), (t, k, ia[t][k], v)
+    assert len({float(ib[t]['q_loss']) for t in range(n)}) > 1, 'the calls must differ for the test to mean anything'
+    stale = a.train(buf, c.B)
+    cap = a.core._history_views()[2]
+    for _ in range(cap):
+        last = a.train(buf, c.B)
+    assert np.isfinite(float(last['actor_loss']))
+    with pytest.raises(RuntimeError, match='overwritten'):
+        stale['actor_loss']
