@@ -5,6 +5,8 @@
 librlrep_hip.so (rlrep_amd/csrc).  Subclasses (vlsac, ctrlsac, spedersac, diffsrsac) only describe their
 dimensions, hyper-parameters, feature-step noise and parameter initialisation.
 """
+import contextlib
+import gc
 import os
 import zlib
 import numpy as np
@@ -15,6 +17,22 @@ from rlrep_amd.core import HipCore
 from rlrep_amd.utils import util
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """Around every hipGraph capture: collect now, then keep the cyclic collector off until the captures are done.  A collection that
+    fires INSIDE a capture can finalise an agent of an earlier life (HipCore.__del__: device synchronise + hipFree) or a CUDAGraph --
+    calls that are not permitted while a stream of the process is capturing; the process then dies in the runtime (seen as a bare
+    `Aborted` with "Garbage-collecting" on top of the Python stack, depending on nothing but the allocation count)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class ArenaModule(nn.Module):
@@ -537,40 +555,41 @@ class SACAgent(object):
         buffer.size_dev()
         key = self._graph_cache_key(buffer, B)
         if self._graph is None or self._graph_key != key:
-            self._sample_into(buffer, B, 'warm', 0, False)
-            idx_keys, eps_specs = self._plan(B)            # allocate the pools outside any capture (no launch: the train
-            self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)   # prologue would count a step and draw from the generator)
-            self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
-            torch.cuda.synchronize()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            self._seg_capture_colls = self.capture_collectives and dist.is_initialized() and dist.get_backend() == 'nccl'
-            self._n_captured_colls = 0
-            if self._seg_capture_colls:
-                # the communicator must exist before the capture begins (its lazy creation allocates: not permitted while capturing);
-                # every rank builds its graph at the same train() call, so this is a matched collective
-                dist.all_reduce(torch.zeros(1, device=self.core.device))
+            with _no_gc():          # (a cyclic-GC pass inside a capture may run destructors that touch the device: see _no_gc)
+                self._sample_into(buffer, B, 'warm', 0, False)
+                idx_keys, eps_specs = self._plan(B)            # allocate the pools outside any capture (no launch: the train
+                self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)   # prologue would count a step and draw from the generator)
+                self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
                 torch.cuda.synchronize()
-            self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')      # see _train_graph
-            self.core.history(self._hist)
-            with torch.cuda.stream(s):
-                first = torch.cuda.CUDAGraph()
-                # thread-local capture mode: the process group's watchdog thread may query events while we capture
-                first.capture_begin(capture_error_mode='thread_local')
-                self._seg = ([], first)
-                try:
-                    self._body(buffer, B, True)
-                    segs, cur = self._seg
-                    self._seg = None
-                    cur.capture_end()
-                    segs.append(('graph', cur))
-                finally:
-                    self.core.history(False)
-                    self._abort_open_capture()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            self._graph, self._graph_key = segs, key
-            self._hist_n = self.core.history_seq() if self._hist else 0
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                self._seg_capture_colls = self.capture_collectives and dist.is_initialized() and dist.get_backend() == 'nccl'
+                self._n_captured_colls = 0
+                if self._seg_capture_colls:
+                    # the communicator must exist before the capture begins (its lazy creation allocates: not permitted while capturing);
+                    # every rank builds its graph at the same train() call, so this is a matched collective
+                    dist.all_reduce(torch.zeros(1, device=self.core.device))
+                    torch.cuda.synchronize()
+                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')      # see _train_graph
+                self.core.history(self._hist)
+                with torch.cuda.stream(s):
+                    first = torch.cuda.CUDAGraph()
+                    # thread-local capture mode: the process group's watchdog thread may query events while we capture
+                    first.capture_begin(capture_error_mode='thread_local')
+                    self._seg = ([], first)
+                    try:
+                        self._body(buffer, B, True)
+                        segs, cur = self._seg
+                        self._seg = None
+                        cur.capture_end()
+                        segs.append(('graph', cur))
+                    finally:
+                        self.core.history(False)
+                        self._abort_open_capture()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self._graph, self._graph_key = segs, key
+                self._hist_n = self.core.history_seq() if self._hist else 0
         for kind, x in self._graph:
             if kind == 'graph':
                 x.replay()
@@ -637,68 +656,69 @@ class SACAgent(object):
         key = self._graph_cache_key(buffer, B)
         c = self.core
         if self._pipe is None or self._pipe['key'] != key:
-            self.flush()
-            self._sample_into(buffer, B, 'warm', 0, False)      # sizes the library's tables for B outside any capture
-            idx_keys, eps_specs = self._plan(B)
-            self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
-            self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
-            torch.cuda.synchronize()
-            mode = int(os.environ.get('RLREP_PIPELINE', '2'))
-            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-            P = dict(key=key, mode=mode, t=0)
-            if mode == 1:
-                # one graph per train(): the two branches inside it (snapshot set 0 only).  In-graph branches cost ~2.6 us per launch
-                # pair on this runtime (tools/exp/twochains.hip); kept as the single-stream form.
-                first, steady, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(first, stream=s1):
-                    ec, ea = self._feature_part(buffer, B)
-                    c.defer_snapshot(ec, ea, 0)
-                    c.end_train()
-                with torch.cuda.graph(steady, stream=s1):
-                    fork = torch.cuda.Event()
-                    fork.record()
-                    s2.wait_event(fork)
-                    c.deferred_critic_actor(0)                      # branch 1 (s1): critic + actor of the previous train()
-                    with torch.cuda.stream(s2):                      # branch 2 (s2): this train()'s feature steps
+            with _no_gc():          # (a cyclic-GC pass inside a capture may run destructors that touch the device: see _no_gc)
+                self.flush()
+                self._sample_into(buffer, B, 'warm', 0, False)      # sizes the library's tables for B outside any capture
+                idx_keys, eps_specs = self._plan(B)
+                self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
+                self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
+                torch.cuda.synchronize()
+                mode = int(os.environ.get('RLREP_PIPELINE', '2'))
+                s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+                P = dict(key=key, mode=mode, t=0)
+                if mode == 1:
+                    # one graph per train(): the two branches inside it (snapshot set 0 only).  In-graph branches cost ~2.6 us per launch
+                    # pair on this runtime (tools/exp/twochains.hip); kept as the single-stream form.
+                    first, steady, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(first, stream=s1):
                         ec, ea = self._feature_part(buffer, B)
-                        join = torch.cuda.Event()
-                        join.record()
-                    torch.cuda.current_stream().wait_event(join)
-                    c.defer_snapshot(ec, ea, 0)
-                    c.end_train()
-                with torch.cuda.graph(tail, stream=s1):
-                    c.deferred_critic_actor(0)
-                P.update(first=first, steady=steady, tail=tail)
-            else:
-                # two streams that were TIMED to be concurrent; train(t) uses snapshot set t % nset:
-                #   stream F : [feature steps(t) + snapshot(t -> set)]            after the critic/actor pair of t-2 (same set)
-                #   stream CA: [critic + actor(t) from set]                       after snapshot(t)
-                from rlrep_amd._lib import lib as _l
-                fs, ca = [], []
-                n0 = _l.rlrep_launch_counter()
-                nset = min(c.defer_supported(), max(2, int(os.environ.get('RLREP_DEFER_SETS', '3'))))
-                for k in range(nset):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s1):
-                        self._stamp(1)
-                        ec, ea = self._feature_part(buffer, B, snap_set=k)
-                        c.defer_snapshot(ec, ea, k)
+                        c.defer_snapshot(ec, ea, 0)
                         c.end_train()
-                        self._stamp(2)
-                    fs.append(g)
-                n1 = _l.rlrep_launch_counter()
-                for k in range(nset):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s1):
-                        self._stamp(3)
-                        c.deferred_critic_actor(k)
-                        self._stamp(4)
-                    ca.append(g)
-                P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
-                s_ca, s_f = _concurrent_stream_pair(c)
-                P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, nset=nset, ev_snap=[torch.cuda.Event() for _ in range(nset)],
-                         ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
-            self._pipe = P
+                    with torch.cuda.graph(steady, stream=s1):
+                        fork = torch.cuda.Event()
+                        fork.record()
+                        s2.wait_event(fork)
+                        c.deferred_critic_actor(0)                      # branch 1 (s1): critic + actor of the previous train()
+                        with torch.cuda.stream(s2):                      # branch 2 (s2): this train()'s feature steps
+                            ec, ea = self._feature_part(buffer, B)
+                            join = torch.cuda.Event()
+                            join.record()
+                        torch.cuda.current_stream().wait_event(join)
+                        c.defer_snapshot(ec, ea, 0)
+                        c.end_train()
+                    with torch.cuda.graph(tail, stream=s1):
+                        c.deferred_critic_actor(0)
+                    P.update(first=first, steady=steady, tail=tail)
+                else:
+                    # two streams that were TIMED to be concurrent; train(t) uses snapshot set t % nset:
+                    #   stream F : [feature steps(t) + snapshot(t -> set)]            after the critic/actor pair of t-2 (same set)
+                    #   stream CA: [critic + actor(t) from set]                       after snapshot(t)
+                    from rlrep_amd._lib import lib as _l
+                    fs, ca = [], []
+                    n0 = _l.rlrep_launch_counter()
+                    nset = min(c.defer_supported(), max(2, int(os.environ.get('RLREP_DEFER_SETS', '3'))))
+                    for k in range(nset):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=s1):
+                            self._stamp(1)
+                            ec, ea = self._feature_part(buffer, B, snap_set=k)
+                            c.defer_snapshot(ec, ea, k)
+                            c.end_train()
+                            self._stamp(2)
+                        fs.append(g)
+                    n1 = _l.rlrep_launch_counter()
+                    for k in range(nset):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=s1):
+                            self._stamp(3)
+                            c.deferred_critic_actor(k)
+                            self._stamp(4)
+                        ca.append(g)
+                    P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
+                    s_ca, s_f = _concurrent_stream_pair(c)
+                    P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, nset=nset, ev_snap=[torch.cuda.Event() for _ in range(nset)],
+                             ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
+                self._pipe = P
         P = self._pipe
         if P['mode'] == 1:
             (P['steady'] if self._pending else P['first']).replay()
@@ -774,37 +794,38 @@ class SACAgent(object):
         key = self._graph_cache_key(buffer, B)
         c = self.core
         if self._pipe is None or self._pipe['key'] != key:
-            self.flush()
-            self._sample_into(buffer, B, 'warm', 0, False)
-            idx_keys, eps_specs = self._plan(B)
-            self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
-            self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
-            import torch.distributed as dist
-            self._seg_capture_colls = self.capture_collectives and dist.is_initialized() and dist.get_backend() == 'nccl'
-            if self._seg_capture_colls:          # both communicators exist before the captures begin (see _train_graph_dp)
-                dist.all_reduce(torch.zeros(1, device=c.device))
-                dist.all_reduce(torch.zeros(1, device=c.device), group=self._pg_ca)
-            torch.cuda.synchronize()
-            cap = torch.cuda.Stream()
-            cap.wait_stream(torch.cuda.current_stream())
-            fs, cs = [], []
-            with torch.cuda.stream(cap):
-                for k in range(2):
-                    def feature_chain(k=k):
-                        ec, ea = self._feature_part(buffer, B)
-                        c.defer_snapshot(ec, ea, k)
-                        c.end_train()
-                    fs.append(self._capture_segments(feature_chain))
+            with _no_gc():          # (a cyclic-GC pass inside a capture may run destructors that touch the device: see _no_gc)
+                self.flush()
+                self._sample_into(buffer, B, 'warm', 0, False)
+                idx_keys, eps_specs = self._plan(B)
+                self._buf('pool_idx', (len(idx_keys) * B,), torch.int32)
+                self._buf('pool_eps', (sum(int(np.prod(sh)) for _, sh in eps_specs),))
+                import torch.distributed as dist
+                self._seg_capture_colls = self.capture_collectives and dist.is_initialized() and dist.get_backend() == 'nccl'
+                if self._seg_capture_colls:          # both communicators exist before the captures begin (see _train_graph_dp)
+                    dist.all_reduce(torch.zeros(1, device=c.device))
+                    dist.all_reduce(torch.zeros(1, device=c.device), group=self._pg_ca)
+                torch.cuda.synchronize()
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                fs, cs = [], []
+                with torch.cuda.stream(cap):
+                    for k in range(2):
+                        def feature_chain(k=k):
+                            ec, ea = self._feature_part(buffer, B)
+                            c.defer_snapshot(ec, ea, k)
+                            c.end_train()
+                        fs.append(self._capture_segments(feature_chain))
 
-                    def ca_chain(k=k):
-                        c.deferred_part(k, 0); self._allreduce(1, pg=self._pg_ca); c.deferred_part(k, 1)
-                        c.deferred_part(k, 2); self._allreduce(2, True, pg=self._pg_ca); c.deferred_part(k, 3)
-                    cs.append(self._capture_segments(ca_chain))
-            torch.cuda.current_stream().wait_stream(cap)
-            torch.cuda.synchronize()
-            s_ca, s_f = _concurrent_stream_pair(c)
-            self._pipe = dict(key=key, mode=3, t=0, nset=2, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
-                              ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
+                        def ca_chain(k=k):
+                            c.deferred_part(k, 0); self._allreduce(1, pg=self._pg_ca); c.deferred_part(k, 1)
+                            c.deferred_part(k, 2); self._allreduce(2, True, pg=self._pg_ca); c.deferred_part(k, 3)
+                        cs.append(self._capture_segments(ca_chain))
+                torch.cuda.current_stream().wait_stream(cap)
+                torch.cuda.synchronize()
+                s_ca, s_f = _concurrent_stream_pair(c)
+                self._pipe = dict(key=key, mode=3, t=0, nset=2, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
+                                  ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
         P = self._pipe
         k = P['t'] % P['nset']
         P['t'] += 1
@@ -870,26 +891,27 @@ class SACAgent(object):
         buffer.size_dev()
         key = self._graph_cache_key(buffer, B)
         if self._graph is None or self._graph_key != key:
-            # size the library's tables for B outside the capture (it re-uploads them with blocking copies
-            # when the batch size changes), then capture the whole train() into one hipGraph
-            self._sample_into(buffer, B, 'warm', 0, False)
-            torch.cuda.synchronize()
-            from rlrep_amd._lib import lib as _l
-            s = torch.cuda.Stream()
-            g = torch.cuda.CUDAGraph()
-            n0 = _l.rlrep_launch_counter()
-            # the call's metrics are filed in the library's history ring by the last launch of the graph (rlrep_history) and fetched when the
-            # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_INFO_HISTORY=0: a clone per call.
-            self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')
-            self.core.history(self._hist)
-            try:
-                with torch.cuda.graph(g, stream=s):
-                    self._body(buffer, B, True)
-            finally:
-                self.core.history(False)
-            self._graph, self._graph_key = g, key
-            self._graph_launches = _l.rlrep_launch_counter() - n0
-            self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
+            with _no_gc():          # (a cyclic-GC pass inside a capture may run destructors that touch the device: see _no_gc)
+                # size the library's tables for B outside the capture (it re-uploads them with blocking copies
+                # when the batch size changes), then capture the whole train() into one hipGraph
+                self._sample_into(buffer, B, 'warm', 0, False)
+                torch.cuda.synchronize()
+                from rlrep_amd._lib import lib as _l
+                s = torch.cuda.Stream()
+                g = torch.cuda.CUDAGraph()
+                n0 = _l.rlrep_launch_counter()
+                # the call's metrics are filed in the library's history ring by the last launch of the graph (rlrep_history) and fetched when the
+                # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_INFO_HISTORY=0: a clone per call.
+                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')
+                self.core.history(self._hist)
+                try:
+                    with torch.cuda.graph(g, stream=s):
+                        self._body(buffer, B, True)
+                finally:
+                    self.core.history(False)
+                self._graph, self._graph_key = g, key
+                self._graph_launches = _l.rlrep_launch_counter() - n0
+                self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
         self._graph.replay()
         if self._hist:
             n = self._hist_n

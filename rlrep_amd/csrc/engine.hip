@@ -1007,12 +1007,14 @@ static void static_state(rlrep_agent* ag) {
             if (!sh_all && e.name != "encoder.l1.weight" && e.name != "f.l1.weight") continue;
             // a glued pair (mean | log_std heads, state | reward heads: Layout::lin_pair) is two consecutive blocks [o1, in], [o2, in] = ONE
             // [o1 + o2, in] matrix for the kernels: one shadow, reachable under the first tensor's name
-            if (!tab.empty() && q > 0 && T[q - 1].name.find(".weight") != std::string::npos && tab.back().off + tab.back().n == e.off && tab.back().cols == e.cols) {
+            if (!tab.empty() && q > 0 && T[q - 1].name.find(".weight") != std::string::npos && tab.back().off + tab.back().n == e.off - ag->L.group_off[0] && tab.back().cols == e.cols) {
                 tab.back().rows += e.rows; tab.back().n += (long long)e.rows * e.cols;
                 continue;
             }
             ShadowEnt se; memset(&se, 0, sizeof(se));
-            se.off = e.off; se.n = (long long)e.rows * e.cols; se.rows = e.rows; se.cols = e.cols;
+            // offsets RELATIVE to the group's start: the group's Adam launch indexes its arena slice from 0, and the refresh launches are
+            // given param_dev + group_off[0] as their base (one table serves both, wherever the group sits in the arena)
+            se.off = e.off - ag->L.group_off[0]; se.n = (long long)e.rows * e.cols; se.rows = e.rows; se.cols = e.cols;
             tab.push_back(se); first.push_back(e.name);
         }
         int tiles = 0;
@@ -1065,7 +1067,7 @@ static void static_state(rlrep_agent* ag) {
 static int refresh_shadows(rlrep_agent* ag, void* stream) {
     for (int g = 0; g < 4; ++g) {
         if (!ag->nsh[g] || !ag->sh_tiles[g]) continue;
-        const int rc = rl_launch_shadow(ag->sh_dev[g], ag->nsh[g], ag->sh_tiles[g], ag->a.param_dev, 0, (hipStream_t)stream); ++g_rl_launches;
+        const int rc = rl_launch_shadow(ag->sh_dev[g], ag->nsh[g], ag->sh_tiles[g], ag->a.param_dev + ag->L.group_off[g], 0, (hipStream_t)stream); ++g_rl_launches;
         if (rc) { rl_set_error("shadow refresh: hip error %d", rc); return RLREP_ERR_HIP; }
     }
     return 0;
@@ -1166,6 +1168,9 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
     if (rl_rowprog_init() != 0) { rl_set_error("create: cannot reserve LDS for the row-program kernel"); return RLREP_ERR_HIP; }
     int rc = build_programs(ag.get(), dims->max_batch);
     if (rc != 0) return rc;
+    if (getenv("RLREP_FUSE_ADAM") && ag->has_shadows())        // a comparison run must not measure the other path without notice
+        fprintf(stderr, "rlrep: RLREP_FUSE_ADAM is ignored for this agent: its optimizer launch keeps the bf16x3 weight images of the noise critic "
+                        "(set RLREP_NC_SHADOWS=0 as well to compare the fused-optimizer form)\n");
     *out = ag.release();
     return 0;
 }
@@ -1248,7 +1253,7 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
     tp.eps.seed = seed; tp.eps.offset = eps_offset; tp.eps.step_dev = ag->steps; tp.eps.step_add = 1;
     slot_fill_params(ag, 0, ring_dev, nullptr, tp.fill);
     tp.counter = ag->steps; tp.ticket = ag->steps + 1;
-    tp.sh = ag->sh_dev[0]; tp.nsh = ag->nsh[0]; tp.nb_tr = ag->sh_tiles[0]; tp.sh_base = ag->a.param_dev;
+    tp.sh = ag->sh_dev[0]; tp.nsh = ag->nsh[0]; tp.nb_tr = ag->sh_tiles[0]; tp.sh_base = ag->a.param_dev + ag->L.group_off[0];
     rc = (++g_rl_launches, rl_launch_train_prologue(&tp, (hipStream_t)stream));
     if (rc) { rl_set_error("train_prologue: hip error %d", rc); return RLREP_ERR_HIP; }
     ag->slot[0].filled = true;
