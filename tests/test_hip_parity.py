@@ -261,7 +261,7 @@ def _run_vs_oracle(c, trains=2, seed=5):
         info = agent.train_injected(buf, c.B, idx, eps)
         oinfo = o.train([gather_batch(c.replay, i) for i in idx], [torch.as_tensor(e) for e in eps])
         for k, v in oinfo.items():
-            assert np.isfinite(info[k]), (k, info[k])
+            assert np.isfinite(float(info[k])), (k, info[k])
             assert abs(info[k] - v) <= 2e-4 * max(abs(v), 1e-2), (c.alg, t, k, info[k], v)
     st, P = agent.core.state(), o.state()
     for k in st:

@@ -77,7 +77,7 @@ def _run(alg, cls_path, S, A, B, kw, trains=1, replay_n=4096, expect_kernels=(),
         info = agent.train_injected(buf, B, idx, eps)
         oinfo = o.train([gather_batch(tens, i) for i in idx], [torch.as_tensor(e) for e in eps])
         for k, v in oinfo.items():
-            assert np.isfinite(info[k]), (alg, k)
+            assert np.isfinite(float(info[k])), (alg, k)
             assert abs(info[k] - v) <= 1e-4 * max(abs(v), 1e-2), (alg, t, k, info[k], v)
     st, P = agent.core.state(), o.state()
     worst = 0.0
