@@ -264,6 +264,9 @@ int32_t rlrep_actor_apply(rlrep_agent* agent, void* stream);
  * rlrep_feature_exchange_count()+1 parts; after part k the caller performs exchange k on a library buffer:
  *   kind 1: all-gather  -- every rank contributes `count` floats at ptr + local_off (in place, rank-major)
  *   kind 2: all-reduce SUM of `count` floats at ptr.
+ *   kind 3: `count` floats at ptr = the gradient arena at float offset local_off are FINAL (diffsrsac: the nabla-mu head's weight + bias
+ *           gradient, 99 % of that group's bytes, taken first): their all-reduce SUM may be issued now, asynchronously, and has to be complete --
+ *           like that of the rest of the group, which the caller reduces after the last part -- before rlrep_feature_apply.
  * With world_size == 1 there are no exchanges and rlrep_feature_backward runs everything. */
 int32_t rlrep_feature_exchange_count(rlrep_agent* agent);
 int32_t rlrep_feature_exchange(rlrep_agent* agent, int32_t k, int32_t* kind, float** ptr_dev, int64_t* count, int64_t* local_off);

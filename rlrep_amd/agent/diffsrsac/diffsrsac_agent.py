@@ -136,8 +136,10 @@ class DIFFSRSACAgent(SACAgent):
         else:
             nidx = self._indices(f'n{i}', B, self.num_noises)
         eps = self._eps(f'pert{i}', (B, self.state_dim), g, std=self.sigma_scale_factor)
-        if self.world_size > 1:
-            c.feature_backward(eps, nidx); self._allreduce(3); self._allreduce(0); c.feature_apply()
+        if self._dp:
+            # the nabla-mu head's gradient slice (99 % of group 3) is all-reduced from INSIDE the backward, as soon as its dW launch is done
+            # (exchange kind 3, csrc/agents2.hip build_diffsrsac); the rest of group 3 and group 0 follow the backward
+            self._feature_backward_dp(eps, nidx); self._allreduce_rest(3); self._allreduce(0); c.feature_apply()
         else:
             c.feature_step(eps, nidx)
 

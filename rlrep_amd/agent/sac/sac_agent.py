@@ -188,6 +188,7 @@ class SACAgent(object):
         self._graph = None
         self._seg = None
         self._seg_capture_colls = False
+        self._early_works, self._early_slices = [], []       # async gradient all-reduces issued inside a backward (exchange kind 3)
         self._n_captured_colls = 0
         self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
         # sequential data-parallel form on the RCCL backend: the gradient all-reduces are CAPTURED into the hipGraph of train() (one graph
@@ -196,7 +197,7 @@ class SACAgent(object):
         self.capture_collectives = bool(int(os.environ.get('RLREP_DP_CAPTURE', '1')))
         # backward -> all-reduce -> apply form of every optimizer step.  RLREP_FORCE_DP=1 takes it with a one-rank process group too
         # (sac / vlsac: rehearses the RCCL stream / graph-segment machinery on a single GPU; tests/test_dp.py)
-        self._dp = self.world_size > 1 or (self.ALG in ('sac', 'vlsac') and bool(int(os.environ.get('RLREP_FORCE_DP', '0'))))
+        self._dp = self.world_size > 1 or (self.ALG in ('sac', 'vlsac', 'diffsrsac') and bool(int(os.environ.get('RLREP_FORCE_DP', '0'))))
         self._inject = None
         self._pool = None
         self._next_key = {}
@@ -407,8 +408,35 @@ class SACAgent(object):
                     views = [buf[r * count:(r + 1) * count] for r in range(self.world_size)]
                     local = views[self.rank]
                     self._collective(lambda views=views, local=local: dist.all_gather(views, local))
+                elif kind == 3:
+                    # a slice of the gradient arena that is already final (diffsrsac: the nabla-mu head, 99 % of the bytes): its all-reduce is
+                    # ISSUED here and travels under the rest of the backward; _wait_early_reduces() joins it before the optimizer launch
+                    self._early_slices.append((off, off + count))
+                    self._collective(lambda buf=buf: self._early_works.append(dist.all_reduce(buf, async_op=True)))
                 else:
                     self._collective(lambda buf=buf: dist.all_reduce(buf))
+
+    def _wait_early_reduces(self):
+        def join():
+            for w in self._early_works:
+                w.wait()
+            self._early_works.clear()
+        self._collective(join)
+
+    def _allreduce_rest(self, group):
+        """All-reduce what the early (kind 3) exchanges of this backward left of `group`'s gradient slice, then join them."""
+        import torch.distributed as dist
+        lay = self.core.layout
+        lo, hi = lay.group_offset[group], lay.group_offset[group] + lay.group_floats[group]
+        done = sorted(s for s in self._early_slices if s[0] >= lo and s[1] <= hi)
+        self._early_slices = [s for s in self._early_slices if not (s[0] >= lo and s[1] <= hi)]
+        cur = lo
+        for a, b in done + [(hi, hi)]:
+            if a > cur:
+                view = self.core.grads[cur:a]
+                self._collective(lambda view=view: dist.all_reduce(view))
+            cur = max(cur, b)
+        self._wait_early_reduces()
 
     # ---- pooled noise: ALL sample indices and ALL standard-normal noise of one train() come from two
     # Philox launches into two contiguous buffers (instead of one launch per tensor) ---------------------

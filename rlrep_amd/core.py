@@ -224,6 +224,8 @@ class HipCore:
         """-> (kind, float32 tensor view of the library buffer, per-rank count, local offset)"""
         kind, ptr, count, off = C.c_int32(), C.c_void_p(), C.c_int64(), C.c_int64()
         check(lib.rlrep_feature_exchange(self.h, k, C.byref(kind), C.byref(ptr), C.byref(count), C.byref(off)), 'feature_exchange')
+        if kind.value == 3:          # a finished slice of the gradient arena (local offset = its offset in the arena)
+            return 3, self.grads[off.value:off.value + count.value], count.value, off.value
         total = count.value * (self.hyper.world_size if kind.value == 1 else 1)
         o = (ptr.value - self.workspace.data_ptr())
         buf = self.workspace[o:o + 4 * total].view(torch.float32)

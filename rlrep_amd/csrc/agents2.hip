@@ -592,6 +592,18 @@ void build_diffsrsac(Builder& b, rlrep_agent* ag) {
         ds.U = nf.act[nm.depth]; ds.PHI = pf.act[phi.depth]; ds.TGT = TGT; ds.alphabars = alphabars; ds.GPHI = pf.g[phi.depth]; ds.partial = part_f;
         ds.B = B; ds.F = F; ds.S = S; ds.sigma = ag->h.sigma_scale; ds.inv_batch = ag->inv_batch();
         p.stages.push_back({[=](hipStream_t st) { DiffsrScore q = ds; q.idx = ag->cur_idx; return rl_launch_diffsr_score(&q, st); }, "score matching loss"});
+        // Data parallel: the nabla-mu HEAD holds 99 % of the feature gradients (F*S x H: 197 MB at Humanoid dims) and its weight gradient needs
+        // only dU (just written) and the last hidden activation -- so it is taken FIRST, and exchange 3 tells the caller that the slice
+        // [head.weight .. end of group 3] of the gradient arena is complete: its all-reduce can travel while the head's dX (202 GFLOP), the
+        // rest of the backward and the small weight gradients run ("198 MB => RCCL, overlapped with backward").  The caller
+        // reduces the remainder of the group after the backward.  RLREP_NO_BUCKET_DP: one all-reduce after the whole backward, as before.
+        const bool head_first = (ag->h.world_size > 1 || getenv("RLREP_FORCE_DP")) && nm.depth >= 1 && !getenv("RLREP_NO_BUCKET_DP");      // (RLREP_FORCE_DP: the one-rank RCCL rehearsal)
+        if (head_first) {
+            b.dw_stage(p, {mlp_dw(ag, nm, nf, nm.depth, XN, S + 1)}, "nabla-mu head dW");
+            const LT& hw = ag->L.get(nm.name(nm.depth) + ".weight");
+            const int64_t end = ag->L.group_off[3] + ag->L.group_n[3];
+            ag->feat_cuts.push_back({(int)p.stages.size() - 1, 3, ag->a.grad_dev ? ag->a.grad_dev + hw.off : nullptr, end - hw.off, hw.off});
+        }
         for (int l = std::max(phi.depth, nm.depth); l >= 1; --l) {
             std::vector<GemmTask> t;
             if (l <= phi.depth) t.push_back(mlp_dx(ag, phi, pf, l));
@@ -601,7 +613,7 @@ void build_diffsrsac(Builder& b, rlrep_agent* ag) {
         {
             std::vector<GemmTask> t;
             for (int l = 0; l <= phi.depth; ++l) t.push_back(mlp_dw(ag, phi, pf, l, s0.XF, SA));
-            for (int l = 0; l <= nm.depth; ++l) t.push_back(mlp_dw(ag, nm, nf, l, XN, S + 1));
+            for (int l = 0; l <= nm.depth; ++l) if (!(head_first && l == nm.depth)) t.push_back(mlp_dw(ag, nm, nf, l, XN, S + 1));
             b.dw_stage(p, t, "feature dW");
         }
         // diffsrsac_agent.py:313-314: nablamu_net_optimizer.step(); phi_optimizer.step()

@@ -86,6 +86,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     const int local = bid - base;
     const int tr = local / tiles_c, tc = local - tr * tiles_c;
 #ifdef RL_TIMING
+    asm volatile("" :: "s"(tr), "s"(tc), "s"(ti));
+    TIM(7);                       // task and tile known (preloaded scalars only): what follows is the record's scalar-load round trip
     float* const pC = t.C; const int epi = t.epi;
     gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K>(t, tr, tc, red, bsum, nullptr, tim_c);
 #else

@@ -119,6 +119,66 @@ def test_dp_gradient_sum_identity_gloo():
         assert err < 1e-5, (rank, err)
 
 
+def _early_worker(rank, world, port, q):
+    """Host logic of the early (exchange kind 3) gradient all-reduce: SACAgent._feature_backward_dp / _allreduce_rest on a stub core."""
+    from rlrep_amd.agent.sac.sac_agent import SACAgent
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+
+    class Lay:
+        group_offset, group_floats, grad_floats = [0, 100, 0, 40], [40, 0, 0, 60], 100
+
+    class Core:
+        layout = Lay()
+
+        def __init__(self):
+            self.grads = torch.full((100,), float(rank + 1))
+            self.parts = []
+
+        def feature_exchange_count(self):
+            return 1
+
+        def feature_exchange(self, k):                    # group 3 = [40, 100): its tail [70, 100) is final after part 0
+            return 3, self.grads[70:100], 30, 70
+
+        def feature_backward_part(self, k, eps, idx):
+            self.parts.append(k)
+            if k == 1:
+                self.grads[40:70] += 10.0                 # the rest of the backward still writes the remainder of the group ...
+                assert self.grads[70].item() in (float(rank + 1), 3.0)     # ... while the early slice is untouched or already summed
+
+    a = SACAgent.__new__(SACAgent)
+    a.core, a.world_size, a.rank = Core(), world, rank
+    a._seg, a._seg_capture_colls, a._n_captured_colls = None, False, 0
+    a._early_works, a._early_slices = [], []
+    a._feature_backward_dp(None, None)
+    assert a.core.parts == [0, 1] and a._early_slices == [(70, 100)] and len(a._early_works) == 1
+    a._allreduce_rest(3)
+    a._allreduce(0)
+    assert not a._early_works and not a._early_slices
+    g = a.core.grads
+    ok = bool((g[0:40] == 3.0).all() and (g[40:70] == 23.0).all() and (g[70:100] == 3.0).all())      # every element summed exactly once
+    q.put((rank, ok, g[[0, 40, 69, 70, 99]].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_early_slice_allreduce_covers_every_gradient_once_gloo():
+    """diffsrsac's head-first gradient exchange (csrc/agents2.hip, exchange kind 3): the early slice is reduced asynchronously from inside the
+    backward, the remainder of the group after it -- two gloo ranks on the CPU, every gradient element summed exactly once."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_early_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, sample in res:
+        assert ok, (rank, sample)
+
+
 # ------------------------------------------------------------------------------------------------
 # GPU: the HIP train() with world_size 2
 # ------------------------------------------------------------------------------------------------
@@ -258,7 +318,7 @@ def test_hip_dp_pipelined_equals_sequential_dp():
     assert out[True][3] == out[False][3]
 
 
-def _gpu_rccl_worker(port, q, mode):
+def _gpu_rccl_worker(port, q, mode, case='vlsac_tiny'):
     """mode: 'single' (no process group), 'dp' (sequential DP over a one-rank RCCL group, all-reduces captured into the graph), 'dp_seg'
     (the same with graph segments around eager all-reduces), 'dp_pipe' (pipelined DP, same group)."""
     from fixture_io import Case
@@ -270,7 +330,7 @@ def _gpu_rccl_worker(port, q, mode):
             os.environ['RLREP_DP_CAPTURE'] = '0' if mode == 'dp_seg' else '1'
             torch.cuda.set_device(0)
             dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
-        c = Case('vlsac_tiny')
+        c = Case(case)
         agent = make_agent(c, seed=17)
         agent.use_graph = True
         buf = make_buffer(c)
@@ -278,15 +338,21 @@ def _gpu_rccl_worker(port, q, mode):
             info = agent.train(buf, c.B)
             if t == 4:
                 agent.select_action(np.zeros(c.S, np.float32))
-        last = float(info['q1_loss'])
+        last = float(info['q1_loss' if 'q1_loss' in info else 'actor_loss'])
         torch.cuda.synchronize()
         form = 'pipe' if agent._pipe is not None else 'graph'
         if mode == 'dp_pipe':
             assert agent._pipe['mode'] == 3
-        if mode == 'dp':          # the six all-reduces of a vlsac train() are inside ONE captured graph
+        if mode == 'dp' and case == 'vlsac_tiny':          # the six all-reduces of a vlsac train() are inside ONE captured graph
             assert sum(1 for k, _ in agent._graph if k == 'coll') == 0 and len(agent._graph) == 1 and agent._n_captured_colls == 6
-        if mode == 'dp_seg':      # RLREP_DP_CAPTURE=0: graph segments around eager collectives
+        if mode == 'dp_seg' and case == 'vlsac_tiny':      # RLREP_DP_CAPTURE=0: graph segments around eager collectives
             assert sum(1 for k, _ in agent._graph if k == 'coll') == 6
+        if mode != 'single' and case.startswith('diffsrsac'):
+            # the nabla-mu head's gradient slice is reduced from inside the backward (exchange kind 3), asynchronously
+            assert agent.core.feature_exchange_count() == 1 and agent.core.feature_exchange(0)[0] == 3
+            assert not agent._early_works and not agent._early_slices
+            if mode == 'dp':
+                assert len(agent._graph) == 1 and agent._n_captured_colls > 0
         st = {k: v.numpy() for k, v in agent.core.state().items()}
         q.put((mode, st, last, form))
         if mode != 'single':
@@ -294,6 +360,28 @@ def _gpu_rccl_worker(port, q, mode):
     except Exception:
         import traceback
         q.put((mode, traceback.format_exc(), None, None))
+
+
+@pytest.mark.gpu
+def test_hip_dp_diffsrsac_early_head_allreduce_over_rccl_one_rank():
+    """diffsrsac under data parallelism takes the nabla-mu head's weight gradient FIRST and all-reduces that slice (99 % of the group's bytes)
+    asynchronously while the rest of the backward runs (csrc/agents2.hip build_diffsrsac, exchange kind 3).  Over a one-rank RCCL
+    group (the all-reduce is the identity) both the captured and the segmented form must end in exactly the single-GPU state."""
+    out = {}
+    ctx = mp.get_context('spawn')
+    for mode in ('single', 'dp', 'dp_seg'):
+        q = ctx.Queue()
+        p = ctx.Process(target=_gpu_rccl_worker, args=(_free_port(), q, mode, 'diffsrsac_tiny'))
+        p.start()
+        res = q.get(timeout=280)
+        p.join(timeout=120)
+        assert isinstance(res[1], dict), res[1]
+        assert p.exitcode == 0
+        out[mode] = res
+    for mode in ('dp', 'dp_seg'):
+        for k, v in out['single'][1].items():
+            assert np.array_equal(v, out[mode][1][k]), f'{mode} != single GPU at {k}'
+        assert out[mode][2] == out['single'][2]
 
 
 @pytest.mark.gpu

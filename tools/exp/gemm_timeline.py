@@ -32,7 +32,7 @@ print('this train(): %.1f us by events' % (e0.elapsed_time(e1) * 1e3))
 nl = raw.rl_timing_count()
 rec = tb.cpu().numpy().reshape(CAP, 12)
 print(f'{nl} gemm16 launches; wall times in us (100 MHz clock), phases in shader cycles / 2200 = us')
-print(' #   WGs  gap_prev  ramp   span  | median per sampled WG (cycles): find task  record  slot loads issued  operands+mfma  reduce  epilogue |  life us (max)')
+print(' #   WGs  gap_prev  ramp   span  | median per sampled WG (cycles): [task known]  find task+record  -  slot loads issued  operands+mfma  reduce  epilogue |  life us (max)')
 prev = None; tot = 0.0
 for k in range(nl):
     r = rec[k * 2048:(k + 1) * 2048]; r = r[(r[:, 11] >> 32) == 1]
@@ -43,7 +43,8 @@ for k in range(nl):
     gap = (w0.min() - prev) / 100 if prev is not None else 0.0
     d = np.diff(c, axis=1); ph = np.median(d, axis=0); ph = np.array([ph[0], ph[1] + 0, ph[2], ph[3], ph[4], ph[5]])
     life = (c[:, 6] - c[:, 0]) / 2200.0
-    print(f"{k:3d} {grid:5d}  {gap:7.2f} {(w0.max()-w0.min())/100:6.2f} {(w4.max()-w0.min())/100:6.2f}  |  {ph[0]:8.0f} {ph[1]:8.0f} {ph[2]:8.0f} {ph[3]:10.0f} {ph[4]:8.0f} {ph[5]:8.0f}  | {np.median(life):6.2f} ({life.max():.2f})")
+    known = np.median(r[:, 9] - r[:, 2])                  # c[7] - c[0]: entry -> task and tile known (no loads)
+    print(f"{k:3d} {grid:5d}  {gap:7.2f} {(w0.max()-w0.min())/100:6.2f} {(w4.max()-w0.min())/100:6.2f}  |  [{known:6.0f}] {ph[0]:8.0f} {ph[1]:8.0f} {ph[2]:8.0f} {ph[3]:10.0f} {ph[4]:8.0f} {ph[5]:8.0f}  | {np.median(life):6.2f} ({life.max():.2f})")
     tot += (w4.max() - w0.min()) / 100
     prev = w4.max()
 print('sum of gemm16 kernel spans %.1f us' % tot)
