@@ -218,6 +218,9 @@ int32_t rlrep_train_prologue(rlrep_agent* agent, const float* ring_dev, const in
                              float* eps_pool_dev, int64_t n_eps, uint64_t seed, uint64_t idx_offset, uint64_t eps_offset,
                              int32_t batch, void* stream);
 int32_t rlrep_prefetch_batch(rlrep_agent* agent, const float* ring_dev, const int32_t* idx_dev, int32_t batch);
+/* the same for minibatch slot `slot` (1: spedersac's second, "random" minibatch, agent/spedersac/spedersac_agent.py:181-186): both gathers of the
+ * next feature step ride in this step's optimizer launch */
+int32_t rlrep_prefetch_batch_slot(rlrep_agent* agent, int32_t slot, const float* ring_dev, const int32_t* idx_dev, int32_t batch);
 
 /* ---- step programs ------------------------------------------------------------------------ */
 /* eps pointers: caller-provided standard-normal noise (parity runs inject the oracle's tensors).

@@ -95,6 +95,7 @@ def _load():
         'rlrep_prefetch_policy': (i32, [vp, vp]),
         'rlrep_prefetch_policy_early': (i32, [vp, vp, vp]),
         'rlrep_prefetch_batch': (i32, [vp, vp, vp, i32]),
+        'rlrep_prefetch_batch_slot': (i32, [vp, i32, vp, vp, i32]),
         'rlrep_train_prologue': (i32, [vp, vp, vp, vp, i64, vp, i64, u64, u64, u64, i32, vp]),
         'rlrep_critic_step': (i32, [vp, vp, vp]),
         'rlrep_actor_alpha_step': (i32, [vp, vp, vp]),

@@ -465,7 +465,7 @@ class SACAgent(object):
             self._pool['idx_' + k] = ipool[q * B:(q + 1) * B]
         # slot-0 batches in the order they are consumed: after gathering one, the next is armed to ride in the
         # step's optimizer launch (rlrep_prefetch_batch)
-        self._next_key = dict(zip(idx_keys, idx_keys[1:])) if (g and self.PREFETCH_CHAIN) else {}
+        self._next_key = self._prefetch_chain(idx_keys) if g else {}
         o = 0
         for k, sh in eps_specs:
             n = int(np.prod(sh))
@@ -475,12 +475,16 @@ class SACAgent(object):
         self._early_key = idx_keys[-1] if (g and self.PREFETCH_CHAIN and self._feature_iters() > 0
                                            and 'eps_crit' in self._pool and 'eps_act' in self._pool) else None
 
+    def _prefetch_chain(self, idx_keys):
+        """key -> the key whose gather (same slot) rides in the optimizer launch of the step that consumes `key`."""
+        return dict(zip(idx_keys, idx_keys[1:])) if self.PREFETCH_CHAIN else {}
+
     def _sample_into(self, buffer, B, key, slot=0, g=False):
         if self._inject is None and self._pool is not None and ('idx_' + key) in self._pool:
             self.core.sample(slot, buffer.ring, self._pool['idx_' + key], B)
-            nxt = self._next_key.get(key) if slot == 0 else None
+            nxt = self._next_key.get(key)
             if nxt is not None:
-                self.core.prefetch_batch(buffer.ring, self._pool['idx_' + nxt], B)
+                self.core.prefetch_batch(buffer.ring, self._pool['idx_' + nxt], B, slot)
             if slot == 0 and key == self._early_key:
                 # this is the minibatch the critic and actor steps will reuse: both policy forwards ride in its feature step
                 self.core.prefetch_policy_early(self._pool['eps_crit'], self._pool['eps_act'])

@@ -63,6 +63,13 @@ class SPEDERSACAgent(SACAgent):
             keys += [f'f{i}a', f'f{i}b']
         return keys, [('crit', (B, self.action_dim)), ('act', (B, self.action_dim))]
 
+    def _prefetch_chain(self, idx_keys):
+        # two chains, one per slot: f{i}a -> f{i+1}a (slot 0), f{i}b -> f{i+1}b (slot 1): both gathers of the next feature step ride in this
+        # step's optimizer launch (rlrep_prefetch_batch_slot); the critic / actor steps reuse the last pair
+        a = [k for k in idx_keys if k.endswith('a')]
+        b = [k for k in idx_keys if k.endswith('b')]
+        return {**dict(zip(a, a[1:])), **dict(zip(b, b[1:]))}
+
     def _feature_once(self, buffer, B, i, g):
         c = self.core
         self._sample_into(buffer, B, f'f{i}a', 0, g)

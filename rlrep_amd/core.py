@@ -194,9 +194,9 @@ class HipCore:
     def sample(self, slot, ring, idx, batch):
         check(lib.rlrep_replay_sample(self.h, slot, _ptr(ring), _ptr(idx), int(batch), _stream()), 'replay_sample')
 
-    def prefetch_batch(self, ring, idx, batch):
-        """Arm the gather of the next minibatch (slot 0) to ride in the next optimizer launch."""
-        rc = lib.rlrep_prefetch_batch(self.h, _ptr(ring), _ptr(idx), int(batch))
+    def prefetch_batch(self, ring, idx, batch, slot=0):
+        """Arm the gather of the next minibatch of `slot` to ride in the next optimizer launch."""
+        rc = lib.rlrep_prefetch_batch_slot(self.h, int(slot), _ptr(ring), _ptr(idx), int(batch))
         if rc < 0:
             check(rc, 'prefetch_batch')
         return rc == 1

@@ -391,11 +391,16 @@ __device__ __forceinline__ void copy_segs_body(const CopySegs& p, int blk, int n
 }
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
                                                    const PolyakTask* __restrict__ pol, int npol,
-                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, AdamSnap snap, int snap_blocks) {
+                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, SlotFill sf2, int fill2_blocks, AdamSnap snap, int snap_blocks) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const int bid = blockIdx.x;
-    if (bid > adam_blocks + fill_blocks) {       // the small segments of a folded snapshot (AdamSnap)
-        copy_segs_body(snap.segs, bid - adam_blocks - fill_blocks - 1, snap_blocks);
+    if (bid > adam_blocks + fill_blocks + fill2_blocks) {       // the small segments of a folded snapshot (AdamSnap)
+        copy_segs_body(snap.segs, bid - adam_blocks - fill_blocks - fill2_blocks - 1, snap_blocks);
+        return;
+    }
+    if (bid > adam_blocks + fill_blocks) {       // rlrep_prefetch_batch_slot(1): spedersac's second minibatch rides here too
+        IdxGen none; none.on = 0;
+        fill_slot_body(sf2, none, bid - adam_blocks - fill_blocks - 1, fill2_blocks);
         return;
     }
     if (bid > adam_blocks) {
@@ -578,13 +583,14 @@ extern "C" int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st) {
     hipLaunchKernelGGL(qhead_actor_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
-extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const AdamSnap* snap, hipStream_t st) {
+extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const SlotFill* sf2, const AdamSnap* snap, hipStream_t st) {
     SlotFill none = SlotFill();
     AdamSnap nosnap = AdamSnap();
     const int fb = sf ? grid_for((long long)sf->B * (2 * sf->S + sf->A + 2), 256, 2048) : 0;
+    const int fb2 = sf2 ? grid_for((long long)sf2->B * (2 * sf2->S + sf2->A + 2), 256, 2048) : 0;
     const int sb = (snap && snap->on && snap->segs.n > 0) ? grid_for(snap->segs.end[snap->segs.n - 1], 256, 256) : 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + sb), dim3(256), 0, st, tasks, ntasks, adam_blocks,
-                       (const PolyakTask*)nullptr, 0, fin, nfin, sf ? *sf : none, fb, snap ? *snap : nosnap, sb);
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, tasks, ntasks, adam_blocks,
+                       (const PolyakTask*)nullptr, 0, fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st) {

@@ -918,7 +918,7 @@ static int build_programs(rlrep_agent* ag, int B) {
         p->stages.clear();
     for (auto& D : ag->dset) for (Program* p : {&D.critic_bwd, &D.critic_apply, &D.actor_bwd}) p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
-    ag->pf_armed = ag->pf_done = false;
+    ag->pf_armed = ag->pf_done = false; ag->pf2_armed = ag->pf2_done = false;
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     ag->feat_cuts.clear();
     Builder b(ag);
@@ -1189,7 +1189,7 @@ static int ensure_batch(rlrep_agent* ag, int B) {
 
 int32_t rlrep_set_batch(rlrep_agent* ag, int32_t slot, const rlrep_batch* bt, void* stream) {
     if (!ag || !bt || slot < 0 || slot > 1 || (slot == 1 && ag->d.alg != RLREP_ALG_SPEDERSAC)) { rl_set_error("set_batch: bad argument"); return RLREP_ERR_ARG; }
-    if (slot == 0) { ag->pf_done = false; ag->pf_armed = false; }
+    if (slot == 0) { ag->pf_done = false; ag->pf_armed = false; } else { ag->pf2_done = false; ag->pf2_armed = false; }
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, bt->batch);
@@ -1236,13 +1236,23 @@ int32_t rlrep_prefetch_batch(rlrep_agent* ag, const float* ring_dev, const int32
     return 1;
 }
 
+int32_t rlrep_prefetch_batch_slot(rlrep_agent* ag, int32_t slot, const float* ring_dev, const int32_t* idx_dev, int32_t batch) {
+    if (slot == 0) return rlrep_prefetch_batch(ag, ring_dev, idx_dev, batch);
+    if (!ag || !ring_dev || !idx_dev || slot != 1 || ag->d.alg != RLREP_ALG_SPEDERSAC) { rl_set_error("prefetch_batch_slot: bad argument"); return RLREP_ERR_ARG; }
+    ag->pf2_armed = false;
+    if (batch != ag->B || getenv("RLREP_NO_PREFETCH_BATCH")) return 0;
+    slot_fill_params(ag, 1, ring_dev, idx_dev, ag->pf2_fill);
+    ag->pf2_ring = ring_dev; ag->pf2_idx = idx_dev; ag->pf2_armed = true;
+    return 1;
+}
+
 int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32_t* size_dev, int32_t* idx_pool_dev, int64_t n_idx,
                              float* eps_pool_dev, int64_t n_eps, uint64_t seed, uint64_t idx_offset, uint64_t eps_offset,
                              int32_t batch, void* stream) {
     if (!ag || !ring_dev || !size_dev || !idx_pool_dev || !eps_pool_dev || n_idx < batch || n_eps <= 0 || batch <= 0) {
         rl_set_error("train_prologue: bad argument"); return RLREP_ERR_ARG;
     }
-    ag->pi_ready = nullptr; ag->hoist_req = nullptr; ag->pf_armed = false; ag->pf_done = false;
+    ag->pi_ready = nullptr; ag->hoist_req = nullptr; ag->pf_armed = false; ag->pf_done = false; ag->pf2_armed = false; ag->pf2_done = false;
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;
@@ -1268,7 +1278,11 @@ int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev
         ag->pf_done = false;                                   // this very gather already ran (train prologue / optimizer launch)
         return 0;
     }
-    if (slot == 0) ag->pf_done = false;
+    if (slot == 1 && ag->pf2_done && ring_dev == ag->pf2_ring && idx_dev == ag->pf2_idx && batch == ag->B && ag->slot[1].filled) {
+        ag->pf2_done = false;                                  // gathered by the previous optimizer launch (rlrep_prefetch_batch_slot)
+        return 0;
+    }
+    if (slot == 0) ag->pf_done = false; else ag->pf2_done = false;
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);

@@ -26,6 +26,8 @@ struct rlrep_agent {
     // rlrep_prefetch_batch: slot-0 gather that the next optimizer launch performs; pf_done: the matching
     // rlrep_replay_sample(slot 0, pf_ring, pf_idx, B) is then a no-op
     SlotFill pf_fill; bool pf_armed = false, pf_done = false; const float* pf_ring = nullptr; const int* pf_idx = nullptr;
+    // the same for slot 1 (spedersac's second, "random" minibatch: rlrep_prefetch_batch_slot)
+    SlotFill pf2_fill; bool pf2_armed = false, pf2_done = false; const float* pf2_ring = nullptr; const int* pf2_idx = nullptr;
     int* ticket = nullptr;
     const float* cur_eps2 = nullptr; const float* hoist_req = nullptr; const float* pi_ready = nullptr;
     // One step further: when the critic / actor steps reuse the LAST feature step's minibatch (vlsac), BOTH policy
@@ -460,6 +462,8 @@ struct Builder {
             // a minibatch armed by rlrep_prefetch_batch is gathered by extra blocks of this launch
             const SlotFill* sf = a->pf_armed ? &a->pf_fill : nullptr;
             if (sf) { a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; a->early_ready_crit = a->early_ready_act = nullptr; }
+            const SlotFill* sf2 = a->pf2_armed ? &a->pf2_fill : nullptr;
+            if (sf2) { a->pf2_armed = false; a->pf2_done = true; a->slot[1].filled = true; }
             // a snapshot armed by rlrep_defer_arm rides in the feature group's launch (never beside a minibatch gather: both touch slot 0)
             AdamSnap sn; memset(&sn, 0, sizeof(sn));
             if (group == 0 && a->snap_armed && !sf) {
@@ -477,7 +481,7 @@ struct Builder {
                 a->snap_armed = false; a->snap_done = a->snap_set;
             }
             const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
-            return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, sn.on ? &sn : nullptr, st);
+            return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, st);
         }, what});
     }
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
@@ -485,7 +489,7 @@ struct Builder {
         if (fin.empty()) return;
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, nullptr, st); }, what});
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, nullptr, nullptr, st); }, what});
     }
 
     static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {

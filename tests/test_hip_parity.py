@@ -351,7 +351,7 @@ def test_graph_prologue_and_batch_prefetch_are_equivalent(name):
                 core.fill_indices_dev(ipool, size_dev, seed, ioff)
                 core.fill_normal_dev(epool, 1.0, seed, eoff)
             core.train_prologue = prologue
-            core.prefetch_batch = lambda ring, idx, B: False
+            core.prefetch_batch = lambda ring, idx, B, slot=0: False
             core.prefetch_policy_early = lambda e1, e2: False
         infos = [agent.train(buf, c.B) for _ in range(4)]
         torch.cuda.synchronize()
