@@ -239,14 +239,17 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         {
             GemmTask t = Builder::dx(Sx, WB, B, WB, ZMall, F, pf.GZ, F, F, ACT_NONE, nullptr, 0);
             t.r1u = DRH; t.r1v = Pw("theta.l.weight");
-            b.dx_stage(p, {t}, "dphi = dS mu' + drhat theta");
-        }
-        {
-            GemmTask t = Builder::base();     // dmu'[j,f] = (sum_i dS[i,j] phi[i,f]) * (1 - mu'^2)
-            t.A = Sx; t.lda = WB; t.B = pf.Z; t.ldb = F; t.C = GZMall; t.ldc = F; t.R = WB; t.Cn = F; t.K = B;
-            t.epi = EPI_DX; t.act = ACT_TANH; t.aux = ZMall; t.ldaux = F;
-            b.gemm(p, LD_COL, LD_COL, {t}, "dmu'_all = dS^T phi");
-            if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, GZMall, (int64_t)WB * F, 0});
+            GemmTask u = Builder::base();     // dmu'[j,f] = (sum_i dS[i,j] phi[i,f]) * (1 - mu'^2)
+            u.A = Sx; u.lda = WB; u.B = pf.Z; u.ldb = F; u.C = GZMall; u.ldc = F; u.R = WB; u.Cn = F; u.K = B;
+            u.epi = EPI_DX; u.act = ACT_TANH; u.aux = ZMall; u.ldaux = F;
+            if (Wd > 1) {          // data parallel: the all-reduce of dmu'_all sits right behind its own stage
+                b.dx_stage(p, {t}, "dphi = dS mu' + drhat theta");
+                b.gemm(p, LD_COL, LD_COL, {u}, "dmu'_all = dS^T phi");
+                ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, GZMall, (int64_t)WB * F, 0});
+            } else {
+                // both products consume the InfoNCE gradient dS and nothing of each other: ONE launch of two tile forms (gemm16_duo_kernel)
+                b.gemm_duo(p, {t}, {u}, "dphi = dS mu' + drhat theta", "dmu'_all = dS^T phi", "dphi = dS mu' + drhat theta | dmu'_all = dS^T phi");
+            }
         }
         b.dx_stage(p, {Builder::dx(pf.GZ, F, B, F, Pw("phi.l3.weight"), Hp, pf.G2, Hp, Hp, ACT_ELU, pf.P2, Hp),
                        Builder::dx(GZM, F, B, F, Pw("mu.l3.weight"), Hm, GM2, Hm, Hm, ACT_ELU, M2, Hm)}, "l3 dx");

@@ -239,6 +239,28 @@ struct Builder {
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, nf, &gb, total, st); }, what});
     }
 
+    // Two INDEPENDENT stages of different tile forms -- d1: row-major x k-major products (the dX form), d2: k-major x k-major ones (the
+    // weight-gradient form) -- as ONE launch (gemm16_duo_kernel): a dependent launch less.  Falls back to the two stages (d1 first) when a
+    // task is routed to the LDS-tiled engines, carries a fused short product, or the table does not fit.  RLREP_NO_DUO: always the two stages.
+    bool routes_small(const GemmTask& t, int la, int lb) { int sp = 1, kc = 0, fl = 0; GemmTask c = t; return fused() || !rl_gemm_lds_route(&c, la, lb, 0, &sp, &kc, &fl); }
+    void gemm_duo(Program& p, std::vector<GemmTask> d1, std::vector<GemmTask> d2, const char* w1, const char* w2, const char* what) {
+        bool ok = !getenv("RLREP_NO_DUO") && !chain_prog && !d1.empty() && !d2.empty() && d1.size() + d2.size() <= GEMM_MAX_TASKS && !(fused() && !pending_fin.empty());
+        for (auto& t : d1) ok = ok && routes_small(t, LD_ROW, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3));
+        for (auto& t : d2) ok = ok && routes_small(t, LD_COL, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3)) && !t.ad_p;
+        if (!ok) { gemm(p, LD_ROW, LD_COL, d1, w1); gemm(p, LD_COL, LD_COL, d2, w2); return; }
+        auto count4 = [&]() { long long n = 0; for (auto& t : d2) n += (long long)((t.R + 15) / 16) * ((t.Cn + 63) / 64); return n; };
+        const int nf2 = count4() >= 192 ? 4 : 1;
+        int base_tile = 0;
+        for (auto& t : d1) { t.tiles_c = (t.Cn + 15) / 16; t.ntiles = ((t.R + 15) / 16) * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles; }
+        for (auto& t : d2) { t.tiles_c = (t.Cn + 16 * nf2 - 1) / (16 * nf2); t.ntiles = ((t.R + 15) / 16) * t.tiles_c; t.tile_base = base_tile; base_tile += t.ntiles; }
+        GemmBatch gb; memset(&gb, 0, sizeof(gb));
+        gb.ntasks = (int)(d1.size() + d2.size()); gb.low_prio = low_prio ? 1 : 0;
+        for (size_t q = 0; q < d1.size(); ++q) gb.t[q] = d1[q];
+        for (size_t q = 0; q < d2.size(); ++q) gb.t[d1.size() + q] = d2[q];
+        const int total = base_tile, split = (int)d1.size();
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16_duo(split, nf2, &gb, total, st); }, what});
+    }
+
     // ---- chains (xchain.hip) -----------------------------------------------------------------------
     // Between chain_begin(p) and chain_end() consecutive ROW-LOCAL stages of program p (forward and dX stages of the 16-row tile engine, the
     // fused heads + vae_mid stage) are not emitted as launches but collected as PHASES of one persistent launch, in which the workgroups of

@@ -96,6 +96,39 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     TIM_FIN();
 }
 
+// TWO tile forms in one launch ("duo"): tasks [0, split) are row-major x k-major products (the dX form, NF = 1), tasks [split, ntasks) k-major
+// x k-major ones (the weight-gradient form, NF = NF2); a workgroup runs the body of the form its task belongs to.  For INDEPENDENT stages of
+// different forms that the step program would otherwise launch one after the other (ctrlsac: d(phi) = dS mu' and d(mu') = dS^T phi both
+// consume the InfoNCE gradient dS): one dependent launch less.  Generic epilogues; no finalisation workgroup.  hdr = low_prio | split << 4.
+template <bool VA1, int NF2>
+__global__ __launch_bounds__(256) void gemm16_duo_kernel(int hdr, int total, int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6, int tb7,
+                                                         unsigned tc01, unsigned tc23, unsigned tc45, unsigned tc67, GemmBatch gb) {
+    __shared__ float red[4][NF2][4][64];
+    __shared__ float bsum[4][16];
+    const int low_prio = hdr & 1, split = hdr >> 4;
+    const int tb[GEMM_MAX_TASKS] = {tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7};
+    const int tcs[GEMM_MAX_TASKS] = {(int)(tc01 & 0xffffu), (int)(tc01 >> 16), (int)(tc23 & 0xffffu), (int)(tc23 >> 16),
+                                     (int)(tc45 & 0xffffu), (int)(tc45 >> 16), (int)(tc67 & 0xffffu), (int)(tc67 >> 16)};
+    if (!low_prio) __builtin_amdgcn_s_setprio(3);
+    const int bid = blockIdx.x;
+    int ti = 0, base = tb[0], tiles_c = tcs[0];
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= tb[q]) { ti = q; base = tb[q]; tiles_c = tcs[q]; }
+    const GemmTask& t = gb.t[ti];
+    const int local = bid - base;
+    const int tr = local / tiles_c, tc = local - tr * tiles_c;
+    (void)total;
+#ifdef RL_TIMING
+    unsigned long long* const tim_none = nullptr;
+#define DUO_TIM , tim_none
+#else
+#define DUO_TIM
+#endif
+    if (ti < split) gemm16_tile<LD_ROW, LD_COL, 1, VA1, false, false, false, GemmTask, -1, -1>(t, tr, tc, reinterpret_cast<float (&)[4][1][4][64]>(red), bsum, nullptr DUO_TIM);
+    else gemm16_tile<LD_COL, LD_COL, NF2, false, false, false, false, GemmTask, -1, -1>(t, tr, tc, red, bsum, nullptr DUO_TIM);
+#undef DUO_TIM
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
@@ -205,5 +238,27 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         else launch_nf<LD_COL, LD_COL, false, false>(nf, g, st, *gb);
     }
     else return -1;
+    return (int)hipGetLastError();
+}
+
+// tasks [0, split): LD_ROW x LD_COL at NF = 1; tasks [split, ntasks): LD_COL x LD_COL at NF = nf2 (1 or 4); tile bases / column-tile counts set by the caller
+extern "C" int rl_launch_gemm16_duo(int split, int nf2, const GemmBatch* gb_in, int total_tiles, hipStream_t st) {
+    if (total_tiles <= 0) return 0;
+    if (split <= 0 || split >= gb_in->ntasks || gb_in->nfin > 0 || (nf2 != 1 && nf2 != 4)) return -4;
+    GemmBatch planned = *gb_in;
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) { planned.tb[q] = 0x7fffffff; planned.tcs[q] = 1; }
+    for (int q = 0; q < planned.ntasks; ++q) { rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c; if (planned.t[q].flags & FLAG_PRE) return -4; }
+    planned.total = total_tiles;
+    bool va = true;
+    for (int q = 0; q < split; ++q) { const GemmTask& t = planned.t[q]; if ((t.lda & 3) || (t.K & 3) || (((uintptr_t)t.A) & 15)) va = false; }
+    const int hdr = (planned.low_prio ? 1 : 0) | (split << 4);
+    dim3 g(total_tiles);
+#define DUO_ARGS hdr, planned.total, planned.tb[0], planned.tb[1], planned.tb[2], planned.tb[3], planned.tb[4], planned.tb[5], planned.tb[6], planned.tb[7], \
+    (unsigned)(planned.tcs[0] | (planned.tcs[1] << 16)), (unsigned)(planned.tcs[2] | (planned.tcs[3] << 16)), (unsigned)(planned.tcs[4] | (planned.tcs[5] << 16)), (unsigned)(planned.tcs[6] | (planned.tcs[7] << 16)), planned
+    if (va && nf2 == 1) hipLaunchKernelGGL((gemm16_duo_kernel<true, 1>), g, dim3(256), 0, st, DUO_ARGS);
+    else if (va) hipLaunchKernelGGL((gemm16_duo_kernel<true, 4>), g, dim3(256), 0, st, DUO_ARGS);
+    else if (nf2 == 1) hipLaunchKernelGGL((gemm16_duo_kernel<false, 1>), g, dim3(256), 0, st, DUO_ARGS);
+    else hipLaunchKernelGGL((gemm16_duo_kernel<false, 4>), g, dim3(256), 0, st, DUO_ARGS);
+#undef DUO_ARGS
     return (int)hipGetLastError();
 }
