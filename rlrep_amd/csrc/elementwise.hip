@@ -389,9 +389,15 @@ __device__ __forceinline__ void copy_segs_body(const CopySegs& p, int blk, int n
     }
     if (blk == 0 && threadIdx.x == 0 && p.isrc) *p.idst = *p.isrc;
 }
-__global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ tasks, int ntasks, int adam_blocks,
-                                                   const PolyakTask* __restrict__ pol, int npol,
+// The ONE optimizer task of the launch travels twice: as the by-value record `t` and -- its four arena pointers, the group record, the Polyak
+// target, the element count and the block count -- as 14 leading scalar arguments that the hardware PRELOADS into SGPRs at wave launch
+// (build.sh compiles this file with -mllvm -amdgpu-kernarg-preload-count=14): an optimizer block issues its four 16-byte loads and the load of the
+// group's scalars with its first instructions, instead of after three dependent round trips (task table -> record -> group record).
+// hdr = adam_blocks | vec_ok << 30 (vec_ok: every arena pointer 16-byte aligned and the Polyak sub-range on multiples of four floats).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
+                                                   const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, AdamTask t,
                                                    const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, SlotFill sf2, int fill2_blocks, AdamSnap snap, int snap_blocks) {
+    const int adam_blocks = hdr & 0x3fffffff;
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
     const int bid = blockIdx.x;
     if (bid > adam_blocks + fill_blocks + fill2_blocks) {       // the small segments of a folded snapshot (AdamSnap)
@@ -415,38 +421,33 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
         if (threadIdx.x < 64) finalize_tasks(fin, nfin, threadIdx.x);
         return;
     }
-    // locate task
-    // (reading the task record through the constant address space in one scalar burst was measured: no gain, 3 365 vs 3 385 train()/s)
-    int ti = 0; long long base_blk = 0;
-    for (int q = 0; q < ntasks; ++q) {
-        const long long nb = (tasks[q].n + 1023) / 1024;
-        if (bid < base_blk + nb) { ti = q; break; }
-        base_blk += nb;
-    }
-    const AdamTask& t = tasks[ti];
-    const AdamScal sc = t.grp->sc;
-    const bool pol_on = t.target && (!t.pol_steps || ((*t.pol_steps) % t.pol_period) == 0);
-    // 16 bytes per lane per array: group offsets/sizes and the Polyak sub-range are multiples of 4 floats (arena layout)
-    const long long i = ((long long)(bid - base_blk) * 256 + threadIdx.x) * 4;
-    if (i >= t.n) return;
-    const bool vec = (i + 4 <= t.n) && ((t.pol_off & 3) == 0) && ((t.pol_n & 3) == 0) &&
-                     (((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v) | ((uintptr_t)t.target)) & 15) == 0);
+    // (the arena pointers and the group record are preloaded arguments: these loads go out before the record `t` has arrived)
+    const long long i = ((long long)bid * 256 + threadIdx.x) * 4;
+    if (i >= an) return;
+    const AdamScal sc = agrp->sc;
+    const bool vec = (i + 4 <= an) && ((hdr >> 30) & 1);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, p4 = g, m4 = g, v4 = g;
     if (vec) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
-        f32x4 p4 = *reinterpret_cast<f32x4*>(t.p + i), m4 = *reinterpret_cast<f32x4*>(t.m + i), v4 = *reinterpret_cast<f32x4*>(t.v + i);
+        g = *reinterpret_cast<const f32x4*>(agr + i);
+        p4 = *reinterpret_cast<f32x4*>(ap + i); m4 = *reinterpret_cast<f32x4*>(am + i); v4 = *reinterpret_cast<f32x4*>(av + i);
+    }
+    asm volatile("" ::: "memory");      // (pin: the loads above stay ahead of the reads of the record below)
+    const int ti = 0;
+    const bool pol_on = atarget && (!t.pol_steps || ((*t.pol_steps) % t.pol_period) == 0);
+    if (vec) {
         const bool pol = pol_on && i >= t.pol_off && i < t.pol_off + t.pol_n;
         f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-        if (pol) t4 = *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off));
+        if (pol) t4 = *reinterpret_cast<f32x4*>(atarget + (i - t.pol_off));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float pp = p4[s], mm = m4[s], vv = v4[s], tt = t4[s];
             adam_elem(sc, g[s], &pp, &mm, &vv, pol ? &tt : nullptr);
             p4[s] = pp; m4[s] = mm; v4[s] = vv; t4[s] = tt;
         }
-        *reinterpret_cast<f32x4*>(t.p + i) = p4; *reinterpret_cast<f32x4*>(t.m + i) = m4; *reinterpret_cast<f32x4*>(t.v + i) = v4;
-        if (pol) *reinterpret_cast<f32x4*>(t.target + (i - t.pol_off)) = t4;
+        *reinterpret_cast<f32x4*>(ap + i) = p4; *reinterpret_cast<f32x4*>(am + i) = m4; *reinterpret_cast<f32x4*>(av + i) = v4;
+        if (pol) *reinterpret_cast<f32x4*>(atarget + (i - t.pol_off)) = t4;
         if (snap.on && ti == 0 && i >= snap.off && i < snap.off + snap.n) {        // folded snapshot: the new values, as the deferred chain will read them
-            const f32x4 sv = snap.which == 0 ? p4 : (pol ? t4 : *reinterpret_cast<const f32x4*>(t.target + (i - t.pol_off)));
+            const f32x4 sv = snap.which == 0 ? p4 : (pol ? t4 : *reinterpret_cast<const f32x4*>(atarget + (i - t.pol_off)));
             if (i + 4 <= snap.off + snap.n && !(snap.off & 3) && !(((uintptr_t)snap.block) & 15)) *reinterpret_cast<f32x4*>(snap.block + (i - snap.off)) = sv;
             else {
 #pragma unroll
@@ -479,22 +480,22 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTask* __restrict__ 
             }
         }
     } else {
-        for (int s = 0; s < 4 && i + s < t.n; ++s) {
+        for (int s = 0; s < 4 && i + s < an; ++s) {
             const long long e = i + s;
-            float* tp = (pol_on && e >= t.pol_off && e < t.pol_off + t.pol_n) ? t.target + (e - t.pol_off) : nullptr;
-            adam_elem(sc, t.g[e], t.p + e, t.m + e, t.v + e, tp);
-            if (snap.on && ti == 0 && e >= snap.off && e < snap.off + snap.n) snap.block[e - snap.off] = snap.which == 0 ? t.p[e] : t.target[e - t.pol_off];
+            float* tp = (pol_on && e >= t.pol_off && e < t.pol_off + t.pol_n) ? atarget + (e - t.pol_off) : nullptr;
+            adam_elem(sc, agr[e], ap + e, am + e, av + e, tp);
+            if (snap.on && ti == 0 && e >= snap.off && e < snap.off + snap.n) snap.block[e - snap.off] = snap.which == 0 ? ap[e] : atarget[e - t.pol_off];
             for (int q = 0; t.sh && q < t.nsh; ++q) {
                 const ShadowEnt se = t.sh[q];
                 if (e < se.off || e >= se.off + se.n) continue;
                 const long long l = e - se.off;
                 const int r = (int)(l / se.cols), c = (int)(l - (long long)r * se.cols);
                 if (se.kind == 1) {         // (unreachable for the shapes that get such a shadow: their arrays take the 16-byte path above)
-                    x3_shadow_store1(reinterpret_cast<unsigned char*>(se.sp), se.rows, r, c, t.p[e]);
+                    x3_shadow_store1(reinterpret_cast<unsigned char*>(se.sp), se.rows, r, c, ap[e]);
                     if (tp && se.st) x3_shadow_store1(reinterpret_cast<unsigned char*>(se.st), se.rows, r, c, *tp);
                     break;
                 }
-                se.sp[(size_t)c * se.rows + r] = t.p[e];
+                se.sp[(size_t)c * se.rows + r] = ap[e];
                 if (tp && se.st) se.st[(size_t)c * se.rows + r] = *tp;
                 break;
             }
@@ -583,14 +584,20 @@ extern "C" int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st) {
     hipLaunchKernelGGL(qhead_actor_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
-extern "C" int rl_launch_adam(const AdamTask* tasks, int ntasks, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const SlotFill* sf2, const AdamSnap* snap, hipStream_t st) {
+extern "C" int rl_launch_adam(const AdamTask* task, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const SlotFill* sf2, const AdamSnap* snap, hipStream_t st) {
     SlotFill none = SlotFill();
     AdamSnap nosnap = AdamSnap();
+    AdamTask t = AdamTask();
+    if (task && adam_blocks > 0) t = *task; else adam_blocks = 0;
+    if (t.n >= (1ll << 31) || adam_blocks >= (1 << 30)) return -5;
     const int fb = sf ? grid_for((long long)sf->B * (2 * sf->S + sf->A + 2), 256, 2048) : 0;
     const int fb2 = sf2 ? grid_for((long long)sf2->B * (2 * sf2->S + sf2->A + 2), 256, 2048) : 0;
     const int sb = (snap && snap->on && snap->segs.n > 0) ? grid_for(snap->segs.end[snap->segs.n - 1], 256, 256) : 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, tasks, ntasks, adam_blocks,
-                       (const PolyakTask*)nullptr, 0, fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb);
+    const bool vec_ok = ((t.pol_off & 3) == 0) && ((t.pol_n & 3) == 0) &&
+                        (((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v) | ((uintptr_t)t.target)) & 15) == 0);
+    const int hdr = adam_blocks | (vec_ok ? (1 << 30) : 0);
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, t,
+                       fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st) {

@@ -473,8 +473,6 @@ struct Builder {
         t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = pol_steps; t.pol_period = pol_period;
         t.sh = ag->sh_dev[group]; t.nsh = ag->nsh[group];
-        std::vector<AdamTask> tv{t};
-        const AdamTask* dev = upload(tv);
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
         const int nfin_all = (int)fin.size();
         const bool hist_last = !fin.empty() && fin.back().kind == FIN_HISTORY;        // run only while rlrep_history is on
@@ -503,7 +501,7 @@ struct Builder {
                 a->snap_armed = false; a->snap_done = a->snap_set;
             }
             const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
-            return rl_launch_adam(dev, 1, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, st);
+            return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, st);
         }, what});
     }
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
@@ -511,7 +509,7 @@ struct Builder {
         if (fin.empty()) return;
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, 0, fdev, nfin, nullptr, nullptr, nullptr, st); }, what});
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, fdev, nfin, nullptr, nullptr, nullptr, st); }, what});
     }
 
     static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {
