@@ -310,17 +310,50 @@ def chain_times(agent, reps=60):
     return out
 
 
-def _start_clock_probe():
-    """rocm-smi in a child process, sampling the clocks while the caller keeps the GPU busy (it never touches HIP itself)."""
+_PROBE_CODE = r"""
+import json, os, subprocess, sys
+line = sys.stdin.readline()                       # parked until the benchmark asks (or goes away: EOF)
+if line.strip() == 'go':
+    exe = sys.argv[1]
+    try:
+        # (run the script with this interpreter: its `#!/usr/bin/env python3` line would be two more exec hops)
+        out = subprocess.run([sys.executable, exe, '--showclocks', '--json'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=25).stdout
+    except Exception as e:
+        out = json.dumps({'error': str(e)[:80]})
+    sys.stdout.write(out)
+"""
+
+
+def _spawn_clock_probe(under_profiler):
+    """A parked helper process that will run rocm-smi when asked.  It is started FIRST THING, before this process has made any HIP call: a
+    process that has initialised the GPU must not fork + exec another program on this pool (and under rocprofv3 the profiler's preloaded
+    library has initialised it before main() runs: no probe at all then).  The helper itself never touches HIP."""
     import shutil
     import subprocess
+    if under_profiler:
+        return None
     exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    exe = os.path.realpath(exe)
     if not os.path.exists(exe):
         return None
     try:
-        return subprocess.Popen([exe, '--showclocks', '--json'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        with open(exe, 'rb') as f:
+            if b'python' not in f.readline():
+                return None
+        return subprocess.Popen([sys.executable, '-c', _PROBE_CODE, exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     except OSError:
         return None
+
+
+def _start_clock_probe(p):
+    """Tell the parked helper to sample the clocks now (while the caller keeps the GPU busy)."""
+    if p is None:
+        return None
+    try:
+        p.stdin.write('go\n'); p.stdin.flush()
+    except Exception:
+        return None
+    return p
 
 
 def _read_clock_probe(p):
@@ -352,6 +385,8 @@ def main():
     ap.add_argument('--replicas', action='store_true',
                     help='N > 1: N independent agents (own parameters, own replay, NO gradient all-reduce) instead of data-parallel training')
     args = ap.parse_args()
+    under_profiler = args.no_profile or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+    clock_helper = _spawn_clock_probe(under_profiler) if (args.gpus == 1 and int(os.environ.get('RANK', 0)) == 0) else None
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no HIP call, no
@@ -433,7 +468,7 @@ def main():
     # window (the driver's 20 steps = 7 ms) is noisy by construction, so the same loop is also timed as 5 repeats of `rep_len` calls and the
     # median reported beside it.  The shader clock is sampled by rocm-smi WHILE those repeats run.
     rep_len = 500 if dt / args.steps < 2e-3 else max(20, min(args.steps, 100))
-    smi = _start_clock_probe() if rank == 0 else None
+    smi = _start_clock_probe(clock_helper) if rank == 0 else None
     rep_rates = []
     for _ in range(5):
         barrier()
@@ -475,7 +510,9 @@ def main():
                        'parallelism': {'single': 'single GPU',
                                        'dp': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)',
                                        'replicas': f'{world} independent agents (own parameters and replay, no collective)'}[mode],
-                       'hipgraph': (bool(agent.use_graph) if not agent._dp else ('segments between collectives' if agent.use_graph and agent.use_graph_dp else False)),
+                       'hipgraph': (bool(agent.use_graph) if not agent._dp else
+                                    (('collectives captured into the graph(s)' if getattr(agent, '_seg_capture_colls', False) else 'segments between eager collectives')
+                                     if agent.use_graph and agent.use_graph_dp else False)),
                        # critic + actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (same updates, same order)
                        'deferred_critic_actor_branch': bool(getattr(agent, '_pipe', None))},
             # what `value` counts: with N > 1 data-parallel ranks every rank performs the same `global_updates_per_sec` train() calls, each
