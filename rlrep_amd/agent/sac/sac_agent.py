@@ -911,9 +911,18 @@ class SACAgent(object):
         """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""
         if self._pending == 2:                         # two-stream forms: the pair is already in flight on its own streams
             self._pending = False
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(self._pipe['s_ca'])
-            cur.wait_stream(self._pipe['s_f'])
+            P = self._pipe
+            if os.environ.get('RLREP_FLUSH_STREAM_WAIT') == '1':
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(P['s_ca'])
+                cur.wait_stream(P['s_f'])
+            else:
+                # Waited for on the HOST (every caller of flush() is about to read results anyway).  A stream-level wait here -- a barrier
+                # packet parked in the caller's hardware queue until both chains are done -- slows the launches still queued on the two
+                # chains' queues by ~12 % for as long as it is parked (tools/exp/window_stamps.py: the last two feature chains of a window
+                # 283 -> 315-335 us, the last critic / actor chain 193 -> 227 us; the same effect that made the set-reuse wait a host wait).
+                # The critic / actor chain of the last call is the last thing in flight: its feature chain ended before it started.
+                P['ev_ca'][(P['t'] - 1) % P['nset']].synchronize()
         elif self._pending:
             self._pending = False
             self._pipe['tail'].replay()
