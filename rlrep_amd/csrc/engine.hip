@@ -1166,6 +1166,7 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
     if (e != hipSuccess) { rl_set_error("create: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
     if (rl_nc_init() != 0) { rl_set_error("create: cannot reserve LDS for the noise-critic kernels"); return RLREP_ERR_HIP; }
     if (rl_rowprog_init() != 0) { rl_set_error("create: cannot reserve LDS for the row-program kernel"); return RLREP_ERR_HIP; }
+    if (rl_replearn_init() != 0) { rl_set_error("create: cannot reserve LDS for the score-matching kernel"); return RLREP_ERR_HIP; }
     int rc = build_programs(ag.get(), dims->max_batch);
     if (rc != 0) return rc;
     if (getenv("RLREP_FUSE_ADAM") && ag->has_shadows())        // a comparison run must not measure the other path without notice

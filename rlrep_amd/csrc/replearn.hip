@@ -258,6 +258,91 @@ __global__ __launch_bounds__(256) void diffsr_score_vec_kernel(DiffsrScore p) {
     }
 }
 
+// ONE pass over U (the default where it applies: S % 4 == 0, F <= 256): the two kernels above read every U[b] twice -- 385 KB per sample at
+// Humanoid dims, 788 MB per launch, far more than the L2s hold between the passes: 2.36 GB of HBM traffic for 1.58 GB of algorithmic bytes
+// (U read once, dU written once).  Here a workgroup takes its sample's block through LDS in column chunks of CH floats: all F rows of the
+// chunk are read once ([F][CH] floats of LDS, eight 16-byte loads in flight per lane), the chunk's scores are reduced over the row groups in
+// fixed order, and the second phase (dU = phi_z dscore_s out, dphi_z += sum_s dscore_s U[z,s]) reads the chunk back from LDS.  dphi
+// accumulates over the chunks in order in registers: no partial buffers, no atomics.
+// CH: floats per column chunk (32 / 64 / 128): LDS = F * CH * 4 bytes per workgroup decides how many workgroups share a CU
+template <int CH>
+__global__ __launch_bounds__(256) void diffsr_score_lds_kernel(DiffsrScore p) {
+    constexpr int LPR = CH / 4;                 // lanes per row
+    constexpr int NRG = 256 / LPR;              // row groups
+    constexpr int MAXK = 256 / NRG;             // rows per thread (F <= 256)
+    extern __shared__ float sm[];               // [F][CH] chunk of U | [NRG][CH] partial scores | [CH] dscore
+    __shared__ float shl[4];
+    const int b = blockIdx.x, S = p.S, F = p.F;
+    float* U = p.U + (size_t)b * F * S;
+    const float* phi = p.PHI + (size_t)b * F;
+    float* Uc = sm;
+    float* part = sm + (size_t)F * CH;
+    float* dsc = part + NRG * CH;
+    const int tid = threadIdx.x, rg = tid / LPR, c4 = (tid % LPR) * 4;
+    const float ab = p.alphabars[p.idx[b]];
+    const float coef = (1.0f - ab) * p.sigma;
+    float l = 0.f;
+    float gacc[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) gacc[k] = 0.f;
+    for (int cb = 0; cb < S; cb += CH) {
+        const int cw = min(CH, S - cb);
+        const bool okc = c4 < cw;
+        const int cc = okc ? c4 : 0;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        // phase 1: rows rg, rg + NRG, ... of the chunk: global -> LDS, score partial of this row group
+#pragma unroll
+        for (int k0 = 0; k0 < MAXK; k0 += 8) {
+            f32x4 u[8]; float pz[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = rg + NRG * (k0 + q), rr = min(r, F - 1);
+                u[q] = *reinterpret_cast<const f32x4*>(U + (size_t)rr * S + cb + cc);
+                pz[q] = r < F ? phi[rr] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = rg + NRG * (k0 + q);
+                if (r < F) *reinterpret_cast<f32x4*>(Uc + (size_t)r * CH + c4) = u[q];
+                a += pz[q] * u[q];
+            }
+        }
+        *reinterpret_cast<f32x4*>(part + rg * CH + c4) = okc ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (tid < cw) {
+            float score = part[tid];
+#pragma unroll 8
+            for (int g = 1; g < NRG; ++g) score += part[g * CH + tid];
+            const float diff = p.TGT[(size_t)b * S + cb + tid] - coef * score;
+            l += diff * diff;
+            dsc[tid] = -2.f * coef * diff * p.inv_batch;
+        }
+        __syncthreads();
+        const f32x4 d4 = okc ? *reinterpret_cast<const f32x4*>(dsc + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        // phase 2 from LDS: dU out, dphi partial of this chunk (the LPR lanes of a row group hold one row)
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            const int r = rg + NRG * k;
+            if (r < F) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(Uc + (size_t)r * CH + c4);
+                const f32x4 t = d4 * u;
+                float sdot = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+                for (int o = LPR / 2; o >= 1; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+                gacc[k] += sdot;
+                if (okc) *reinterpret_cast<f32x4*>(U + (size_t)r * S + cb + c4) = phi[r] * d4;
+            }
+        }
+        __syncthreads();
+    }
+    if ((tid % LPR) == 0) {
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) { const int r = rg + NRG * k; if (r < F) p.GPHI[(size_t)b * F + r] = gacc[k]; }
+    }
+    const float lb = block_sum_256(l, shl);
+    if (threadIdx.x == 0) p.partial[b] = lb;
+}
+
 __global__ __launch_bounds__(256) void copy2_kernel(const float* __restrict__ src, float* __restrict__ d1, float* __restrict__ d2, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float v = src[i];
@@ -330,8 +415,25 @@ extern "C" int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st) 
     hipLaunchKernelGGL(diffsr_perturb_kernel, dim3(g), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
+template <int CH> static size_t ds_lds(int F) { return ((size_t)F * CH + (size_t)(1024 / CH) * CH + CH) * sizeof(float); }
+extern "C" int rl_replearn_init() {
+    hipError_t e = hipFuncSetAttribute((const void*)diffsr_score_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds<128>(256));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)diffsr_score_lds_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds<64>(256));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)diffsr_score_lds_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_lds<32>(256));
+    return (int)e;
+}
 extern "C" int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st) {
-    if ((p->S & 3) == 0 && p->S <= 512 && ((((uintptr_t)p->U) & 15) == 0))
+    // one pass through LDS where it applies; column chunks of 64 floats (64 KB of LDS at F = 256: two workgroups per CU, whose load and store
+    // phases overlap) measured best at Humanoid dims: 380 us against 393 (32), 514 (128: one workgroup per CU) and 462 for the two-pass kernel.
+    // RLREP_SCORE_CH = 32 / 64 / 128 selects the chunk, 0 the two-pass kernels.
+    const char* e = getenv("RLREP_SCORE_CH");
+    const int ch = e ? atoi(e) : 64;
+    if (ch && (p->S & 3) == 0 && p->F <= 256 && ((((uintptr_t)p->U) & 15) == 0)) {
+        if (ch == 128) hipLaunchKernelGGL(diffsr_score_lds_kernel<128>, dim3(p->B), dim3(256), ds_lds<128>(p->F), st, *p);
+        else if (ch == 64) hipLaunchKernelGGL(diffsr_score_lds_kernel<64>, dim3(p->B), dim3(256), ds_lds<64>(p->F), st, *p);
+        else hipLaunchKernelGGL(diffsr_score_lds_kernel<32>, dim3(p->B), dim3(256), ds_lds<32>(p->F), st, *p);
+    }
+    else if ((p->S & 3) == 0 && p->S <= 512 && ((((uintptr_t)p->U) & 15) == 0))
         hipLaunchKernelGGL(diffsr_score_vec_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);
     else
         hipLaunchKernelGGL(diffsr_score_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);
