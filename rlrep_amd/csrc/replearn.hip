@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256) void diffsr_score_vec_kernel(DiffsrScore p) {
 // (U read once, dU written once).  Here a workgroup takes its sample's block through LDS in column chunks of CH floats: all F rows of the
 // chunk are read once ([F][CH] floats of LDS, eight 16-byte loads in flight per lane), the chunk's scores are reduced over the row groups in
 // fixed order, and the second phase (dU = phi_z dscore_s out, dphi_z += sum_s dscore_s U[z,s]) reads the chunk back from LDS.  dphi
-// accumulates over the chunks in order in registers: no partial buffers, no atomics.
+// accumulates over the chunks in order in registers: no partial buffers, no atomics.  (Issuing the NEXT chunk's loads before the second phase --
+// a register-held software pipeline -- was measured: 396 us against 367: the live registers cost the overlap between the two co-resident
+// workgroups more than the overlap inside one wins.)
 // CH: floats per column chunk (32 / 64 / 128): LDS = F * CH * 4 bytes per workgroup decides how many workgroups share a CU
 template <int CH>
 __global__ __launch_bounds__(256) void diffsr_score_lds_kernel(DiffsrScore p) {
@@ -291,17 +293,18 @@ __global__ __launch_bounds__(256) void diffsr_score_lds_kernel(DiffsrScore p) {
         const int cc = okc ? c4 : 0;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         // phase 1: rows rg, rg + NRG, ... of the chunk: global -> LDS, score partial of this row group
+        constexpr int GRP = MAXK < 16 ? MAXK : 16;       // 16-byte loads in flight per lane (16 against 8: 380 -> 367 us)
 #pragma unroll
-        for (int k0 = 0; k0 < MAXK; k0 += 8) {
-            f32x4 u[8]; float pz[8];
+        for (int k0 = 0; k0 < MAXK; k0 += GRP) {
+            f32x4 u[GRP]; float pz[GRP];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < GRP; ++q) {
                 const int r = rg + NRG * (k0 + q), rr = min(r, F - 1);
                 u[q] = *reinterpret_cast<const f32x4*>(U + (size_t)rr * S + cb + cc);
                 pz[q] = r < F ? phi[rr] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < GRP; ++q) {
                 const int r = rg + NRG * (k0 + q);
                 if (r < F) *reinterpret_cast<f32x4*>(Uc + (size_t)r * CH + c4) = u[q];
                 a += pz[q] * u[q];
