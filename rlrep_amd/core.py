@@ -180,6 +180,8 @@ class HipCore:
     def chain_check(self):
         """Raise if a persistent chain launch (csrc/xchain.hip) failed its device-side checks since the agent was created: a wait that
         timed out, or workgroups of one group on different XCDs.  Synchronises the current stream."""
+        if not _lib.has_experiments():          # only the experimental engines (row programs, chain kernel) ever set the word
+            return
         w = C.c_uint32(0)
         check(lib.rlrep_chain_status(self.h, C.byref(w), _stream()), 'chain_status')
 
