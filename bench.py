@@ -494,6 +494,21 @@ def main():
         float(agent.train(buf, B)[next(iter(info))])
     barrier()
     dt_sync = time.perf_counter() - t1
+    # ... and with a ReplayBuffer.add() before every train() (main.py:137-144's call pattern without the env step: the staged row and the size
+    # scalar travel to the device ring inside the timed loop)
+    n_add = min(args.steps, 500)
+    zs, za = np.zeros(S, np.float32), np.zeros(A, np.float32)
+    for _ in range(20):
+        buf.add(zs, za, zs, 0.0, 0.0); agent.train(buf, B)
+    agent.flush()
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(n_add):
+        buf.add(zs, za, zs, 0.0, 0.0)
+        agent.train(buf, B)
+    agent.flush()
+    barrier()
+    dt_add = time.perf_counter() - t2
 
     if rank == 0:
         updates = args.steps / dt                      # synchronized train() calls per second (each rank performs every one of them)
@@ -528,6 +543,7 @@ def main():
             'samples_per_sec': round(value * B_global if strong else value * B, 1),
             'metrics_finite': bool(finite),
             'value_with_per_step_metric_fetch': round((1 if strong else world) * n_sync / dt_sync, 2),
+            'value_with_replay_add_per_call': round((1 if strong else world) * n_add / dt_add, 2),
             # median of 5 repeats of `rep_len` calls each (same loop, same barriers): the low-noise companion of the --steps window
             'value_median_500' if rep_len == 500 else 'value_median_repeats': round(float(np.median(rep_rates)), 2),
             'repeats': {'n': 5, 'calls_each': rep_len, 'values': [round(v, 1) for v in rep_rates]},

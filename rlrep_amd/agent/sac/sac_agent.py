@@ -679,12 +679,28 @@ class SACAgent(object):
         pipelined train() in flight may still be sampling from on its own stream -- make the caller's stream wait for that chain."""
         P = self._pipe
         if P is not None and self._pending == 2 and P.get('last_f') is not None:
+            if P.get('s_f') is not None and torch.cuda.current_stream() == P['s_f']:
+                return                      # the write is issued ON the feature stream: ordered behind the chain by the stream itself
             torch.cuda.current_stream().wait_event(P['last_f'])
 
     def _train_graph_pipelined(self, buffer, B):
         self._hook_buffer(buffer)
-        buffer.flush()
-        buffer.size_dev()
+        P0 = self._pipe
+        if P0 is not None and P0.get('mode') == 2 and self._pending == 2 and os.environ.get('RLREP_RING_WRITES_ON_CALLER') != '1':
+            # rows staged by add() since the last call and the size scalar are written ON THE FEATURE STREAM: behind the chain that may
+            # still be sampling from the ring, in front of the one this call launches -- ordered by the stream, no cross-stream wait.  (On the
+            # caller's stream the write had to wait for the chain in flight: a barrier packet parked in the caller's queue for most of every
+            # period, which taxes both chains' launches -- DESIGN.md 5.4; add() + train() in a loop: 2 650 -> 3 360 train()/s, tools/exp/add_train_loop.py.)
+            e0 = getattr(buffer, 'device_epoch', None)
+            with torch.cuda.stream(P0['s_f']):
+                buffer.flush()
+                buffer.size_dev()
+            cur_id = torch.cuda.current_stream().cuda_stream
+            if e0 is not None and P0.get('seen') == (e0, cur_id):
+                P0['seen'] = (buffer.device_epoch, cur_id)        # our own writes need no wait for the caller's stream
+        else:
+            buffer.flush()
+            buffer.size_dev()
         key = self._graph_cache_key(buffer, B)
         c = self.core
         if self._pipe is None or self._pipe['key'] != key:
