@@ -783,8 +783,8 @@ class SACAgent(object):
         if not self._pending or seen[0] is None or P.get('seen') != seen:
             s_f.wait_stream(cur)
             P['seen'] = seen
-        if not self._pending:
-            s_ca.wait_stream(cur)
+        # (the critic / actor stream needs no wait of its own for the caller's stream: its chain starts behind the snapshot event, which the
+        #  feature stream records after a chain that has just been ordered behind the caller's stream)
         with torch.cuda.stream(s_f):
             if P['used'][k]:
                 self._wait_set_free(P, k, s_f)
