@@ -857,8 +857,12 @@ class SACAgent(object):
                 cap = torch.cuda.Stream()
                 cap.wait_stream(torch.cuda.current_stream())
                 fs, cs = [], []
+                # captured collectives: a call is 2 + 2 graph launches, the host has time to wait for the set's last reader itself (no wait parked
+                # in the feature queue) and three snapshot sets keep it a call ahead; segments around eager collectives: 14 items
+                # per call, two sets and a stream wait as before
+                nset = 3 if (self._seg_capture_colls and c.defer_supported() >= 3 and os.environ.get('RLREP_DP_PIPE_SETS', '3') == '3') else 2
                 with torch.cuda.stream(cap):
-                    for k in range(2):
+                    for k in range(nset):
                         def feature_chain(k=k):
                             ec, ea = self._feature_part(buffer, B)
                             c.defer_snapshot(ec, ea, k)
@@ -872,8 +876,8 @@ class SACAgent(object):
                 torch.cuda.current_stream().wait_stream(cap)
                 torch.cuda.synchronize()
                 s_ca, s_f = _concurrent_stream_pair(c)
-                self._pipe = dict(key=key, mode=3, t=0, nset=2, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f, ev_snap=[torch.cuda.Event(), torch.cuda.Event()],
-                                  ev_ca=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
+                self._pipe = dict(key=key, mode=3, t=0, nset=nset, host_wait=nset == 3, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f,
+                                  ev_snap=[torch.cuda.Event() for _ in range(nset)], ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
         P = self._pipe
         k = P['t'] % P['nset']
         P['t'] += 1
@@ -883,7 +887,10 @@ class SACAgent(object):
         if not self._pending:
             s_ca.wait_stream(cur)
         if P['used'][k]:
-            s_f.wait_event(P['ev_ca'][k])                  # the pair that read this snapshot set last (train t-2); a stream wait here: the
+            if P.get('host_wait'):
+                P['ev_ca'][k].synchronize()                # (train t-3: long done)
+            else:
+                s_f.wait_event(P['ev_ca'][k])              # the pair that read this snapshot set last (train t-2); a stream wait here: the
                                                            # host, which issues 14 items per call in this form, must keep its run-ahead
         with torch.cuda.stream(s_f):
             for kind, x in P['fs'][k]:
