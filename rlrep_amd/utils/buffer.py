@@ -135,8 +135,15 @@ class ReplayBuffer(object):
         ind = torch.from_numpy(np.random.randint(0, self.size, size=batch_size)).to(self.device)
         return self.gather(ind)
 
+    def _order_reads(self):
+        """A reader on the caller's stream: the last flush may have been issued on ANOTHER stream (a pipelined train() writes the staged rows on its
+        feature stream, sac_agent.py) -- wait for it there."""
+        if self._copy_done is not None and self.device.type == 'cuda':
+            torch.cuda.current_stream().wait_event(self._copy_done)
+
     def gather(self, ind):
         S, A = self.state_dim, self.action_dim
+        self._order_reads()
         rows = self.ring[ind.long()]
         return Batch(state=rows[:, :S].contiguous(), action=rows[:, S:S + A].contiguous(),
                      reward=rows[:, 2 * S + A:2 * S + A + 1].contiguous(),
@@ -146,6 +153,7 @@ class ReplayBuffer(object):
     # public array attributes of the reference, materialised on demand (read-only copies)
     def _col(self, a, b):
         self.flush()
+        self._order_reads()
         return self.ring[:, a:b].cpu().numpy().astype(np.float64)
 
     @property

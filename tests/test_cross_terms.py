@@ -150,3 +150,22 @@ def test_info_of_graph_replays_is_per_call_and_expires_loudly(monkeypatch):
     assert np.isfinite(float(last['actor_loss']))
     with pytest.raises(RuntimeError, match='overwritten'):
         stale['actor_loss']
+
+
+def test_rows_flushed_on_the_feature_stream_are_visible_to_readers_on_the_callers_stream():
+    """A pipelined train() writes the rows staged by add() on ITS feature stream (behind the chain that may still sample from the ring).  A reader
+    on the caller's stream right after the call -- ReplayBuffer.gather / the public array views, utils/buffer.py:39-48 -- must still see them."""
+    from test_default_mode import _default_agent, _buffer
+    c = Case('vlsac_tiny')
+    agent, buf = _default_agent(c), _buffer(c)
+    for _ in range(3):
+        agent.train(buf, c.B)                      # pipeline in flight
+    assert agent._pipe is not None and agent._pending == 2
+    for i in range(5):
+        slot = buf.ptr
+        s = np.full(c.S, 1000.0 + i, np.float32)
+        buf.add(s, np.full(c.A, -float(i), np.float32), s + 0.5, float(i), 0.0)
+        agent.train(buf, c.B)                      # flushes the staged row on the feature stream
+        got = buf.gather(torch.tensor([slot], device=buf.ring.device))
+        assert float(got.state[0, 0]) == 1000.0 + i and float(got.reward[0, 0]) == float(i), (i, got.state[0, :2], got.reward)
+    assert buf.state[buf.ptr - 1 if buf.ptr else buf.max_size - 1, 0] == 1004.0
