@@ -73,6 +73,7 @@ class ReplayBuffer(object):
 
     def flush(self):
         n = self._staged
+        self._order_reads()          # (whoever samples after this call, on this stream, sees a flush another stream may still be performing)
         if n == 0:
             return
         a = self._stage_start
