@@ -509,6 +509,22 @@ def main():
     agent.flush()
     barrier()
     dt_add = time.perf_counter() - t2
+    # ... and main.py:126-144's whole iteration without the environment step: select_action (needs the finished actor: a device sync), add, train
+    n_loop = min(args.steps, 300) if world == 1 else 0
+    dt_loop = None
+    if n_loop:
+        for _ in range(10):
+            act = agent.select_action(zs, explore=True); buf.add(zs, act, zs, 0.0, 0.0); agent.train(buf, B)
+        agent.flush()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(n_loop):
+            act = agent.select_action(zs, explore=True)
+            buf.add(zs, act, zs, 0.0, 0.0)
+            agent.train(buf, B)
+        agent.flush()
+        barrier()
+        dt_loop = time.perf_counter() - t3
 
     if rank == 0:
         updates = args.steps / dt                      # synchronized train() calls per second (each rank performs every one of them)
@@ -544,6 +560,7 @@ def main():
             'metrics_finite': bool(finite),
             'value_with_per_step_metric_fetch': round((1 if strong else world) * n_sync / dt_sync, 2),
             'value_with_replay_add_per_call': round((1 if strong else world) * n_add / dt_add, 2),
+            'main_loop_iterations_per_sec': (round(n_loop / dt_loop, 2) if dt_loop else None),        # select_action + add + train, no environment
             # median of 5 repeats of `rep_len` calls each (same loop, same barriers): the low-noise companion of the --steps window
             'value_median_500' if rep_len == 500 else 'value_median_repeats': round(float(np.median(rep_rates)), 2),
             'repeats': {'n': 5, 'calls_each': rep_len, 'values': [round(v, 1) for v in rep_rates]},

@@ -205,6 +205,13 @@ class SACAgent(object):
         self.use_graph = bool(int(os.environ.get('RLREP_GRAPH', '1'))) and hip_kwargs.get('graph', True)
         # critic / actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (vlsac; _train_graph_pipelined)
         self.use_pipeline = bool(int(os.environ.get('RLREP_PIPELINE', '1'))) and hip_kwargs.get('pipeline', True)
+        # The two-chain schedule pays when train() calls follow each other; a caller that LOOKS at the critic / actor between two calls -- main.py's
+        # loop: select_action before every train() -- ends the overlap each time, and what is left of the schedule is its cost (snapshot, event
+        # hand-off between the streams: 466 us per call against 431 us for the one-graph sequential train(); tools/exp/rl_loop.py: 1 600 vs 1 880
+        # iterations/s).  Both forms perform identical updates (tests), so train() picks per call: three calls in a row whose pair was waited
+        # for before the next call -> the sequential graph; two calls in a row with nothing looked at in between -> back to the two chains.
+        self._adaptive = bool(int(os.environ.get('RLREP_ADAPTIVE_PIPELINE', '1'))) and hip_kwargs.get('adaptive', 'pipeline' not in hip_kwargs)      # (an explicit pipeline= argument pins the form)
+        self._looked, self._n_looked, self._n_b2b = False, 0, 0
         # two communicators in flight (one per chain): never met a second real rank on hardware, so it is opt-in (RLREP_PIPELINE_DP=1);
         # the default N > 1 form is the sequential one (one communicator, program order identical on every rank)
         self.use_pipeline_dp = bool(int(os.environ.get('RLREP_PIPELINE_DP', '0')))
@@ -263,16 +270,27 @@ class SACAgent(object):
     def _select_action(self, state, explore=False, eps=None):
         """sac_agent.py:89-96.  `eps` (tests): the [1, A] standard-normal draw of `dist.sample()` instead of a fresh one."""
         self.flush()
-        obs = torch.as_tensor(np.asarray(state, dtype=np.float32)).reshape(1, -1).to(self.core.device)
+        # one observation in, one action out, once per environment step: pinned host buffers and fixed device buffers (a pageable tensor costs a
+        # staging copy and a synchronisation in each direction, and an allocation: tools/exp/rl_loop.py)
+        sel = getattr(self, '_sel', None)
+        if sel is None:
+            dev = self.core.device
+            sel = self._sel = dict(obs_pin=torch.empty(1, self.state_dim, dtype=torch.float32).pin_memory(),
+                                   act_pin=torch.empty(1, self.action_dim, dtype=torch.float32).pin_memory(),
+                                   obs=torch.empty(1, self.state_dim, dtype=torch.float32, device=dev),
+                                   out=torch.empty(1, self.action_dim, dtype=torch.float32, device=dev))
+        sel['obs_pin'].numpy()[0, :] = np.asarray(state, dtype=np.float32).reshape(-1)
+        sel['obs'].copy_(sel['obs_pin'], non_blocking=True)
         if explore and eps is not None:
             eps = torch.as_tensor(np.asarray(eps, dtype=np.float32)).reshape(1, self.action_dim).to(self.core.device)
         elif explore:
             eps = self._noise('sel', (1, self.action_dim))
         else:
             eps = None
-        action = self.core.actor_forward(obs, eps, *self.action_range)
-        assert action.ndim == 2 and action.shape[0] == 1
-        return util.to_np(action[0])
+        self.core.actor_forward(sel['obs'], eps, *self.action_range, out=sel['out'])
+        sel['act_pin'].copy_(sel['out'], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return sel['act_pin'].numpy()[0].copy()
 
     def update_target(self):
         self.flush()
@@ -297,7 +315,13 @@ class SACAgent(object):
         self.steps += 1
         if self.use_graph and not self._dp:
             if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
-                return self._train_graph_pipelined(buffer, batch_size)
+                if self._prefer_sequential():
+                    self.flush()
+                    out = self._train_graph(buffer, batch_size)
+                else:
+                    out = self._train_graph_pipelined(buffer, batch_size)
+                self._looked = False             # (flush() calls made by the call itself do not count)
+                return out
             return self._train_graph(buffer, batch_size)
         if self.use_graph and self.use_graph_dp:
             if self.use_pipeline and self.use_pipeline_dp and self._feature_iters() > 0 and self.ALG == 'vlsac' and self.core.defer_supported():
@@ -930,8 +954,22 @@ class SACAgent(object):
             return self.core.metrics_tensor().clone()
         return fetch
 
+    def _prefer_sequential(self):
+        """Per-call choice between the two-chain and the one-graph form of train() (see __init__): has the caller been waiting for the critic /
+        actor pair between the calls?"""
+        if not self._adaptive or int(os.environ.get('RLREP_PIPELINE', '2')) == 1:
+            return False
+        if self._looked:
+            self._n_looked, self._n_b2b = min(self._n_looked + 1, 8), 0
+        else:
+            self._n_b2b += 1
+            if self._n_b2b >= 2:
+                self._n_looked = 0
+        return self._n_looked >= 3
+
     def flush(self):
         """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""
+        self._looked = True
         if self._pending == 2:                         # two-stream forms: the pair is already in flight on its own streams
             self._pending = False
             P = self._pipe

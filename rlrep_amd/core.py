@@ -299,9 +299,10 @@ class HipCore:
     def sync_frozen(self):
         check(lib.rlrep_sync_frozen(self.h, _stream()), 'sync_frozen')
 
-    def actor_forward(self, obs, eps, lo, hi):
+    def actor_forward(self, obs, eps, lo, hi, out=None):
         n = int(obs.shape[0])
-        out = torch.empty(n, self.dims.action_dim, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(n, self.dims.action_dim, dtype=torch.float32, device=self.device)
         check(lib.rlrep_actor_forward(self.h, _ptr(obs), n, _ptr(eps), float(lo), float(hi), _ptr(out), _stream()), 'actor_forward')
         return out
 

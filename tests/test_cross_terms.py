@@ -169,3 +169,34 @@ def test_rows_flushed_on_the_feature_stream_are_visible_to_readers_on_the_caller
         got = buf.gather(torch.tensor([slot], device=buf.ring.device))
         assert float(got.state[0, 0]) == 1000.0 + i and float(got.reward[0, 0]) == float(i), (i, got.state[0, :2], got.reward)
     assert buf.state[buf.ptr - 1 if buf.ptr else buf.max_size - 1, 0] == 1004.0
+
+
+@pytest.mark.parametrize('name', ['vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny'])
+def test_adaptive_choice_of_the_train_form_changes_nothing(name):
+    """train() picks, per call, the two-chain or the one-graph form from how the caller has been calling it (main.py's loop looks at the actor
+    before every train(): sequential; a training loop does not: two chains).  A call pattern that crosses over several times ends in exactly the state
+    of an agent pinned to the sequential form, and the choice is the one the pattern should produce."""
+    from test_default_mode import _default_agent, _buffer
+    c = Case(name)
+    outs, forms = [], []
+    for adaptive in (True, False):
+        agent = _default_agent(c, adaptive=adaptive, **({} if adaptive else {'pipeline': False}))
+        buf = _buffer(c)
+        s = np.zeros(c.S, np.float32)
+        seq = []
+        for t in range(26):
+            look = (4 <= t < 12) or t >= 20                     # back to back, then main.py's pattern, then back to back, then main.py's again
+            if look:
+                agent.select_action(s)
+            n0 = getattr(agent, '_hist_n', 0) if getattr(agent, '_graph', None) is not None else 0
+            agent.train(buf, c.B)
+            seq.append(getattr(agent, '_graph', None) is not None and getattr(agent, '_hist_n', 0) == n0 + 1)
+        agent.flush()
+        torch.cuda.synchronize()
+        outs.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
+        forms.append(seq)
+    for k, v in outs[1].items():
+        assert np.array_equal(outs[0][k], v), (name, k)
+    took_sequential = forms[0]
+    assert not any(took_sequential[:6]) and all(took_sequential[8:12]), took_sequential          # switches after three looked-at calls ...
+    assert not any(took_sequential[14:20]) and all(took_sequential[24:]), took_sequential       # ... and back after two back-to-back ones

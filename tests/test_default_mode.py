@@ -41,6 +41,7 @@ def _default_agent(c, **extra):
     kw = dict(c.kw)
     if c.meta.get('patch_vae_hidden'):
         kw['vae_hidden_dim'] = c.meta['patch_vae_hidden']
+    extra.setdefault('adaptive', False)       # these tests flush after every call to read the draws back: keep them on the form a train() loop runs
     agent = _cls(c.alg)(state_dim=c.S, action_dim=c.A, action_space=_Space(c.A, c.meta['bound']), max_batch=c.B, seed=20240 + len(c.name),
                         **kw, **extra)                        # no graph= / pipeline= argument: the defaults bench.py runs
     agent.core.load_state(c.init)
