@@ -136,6 +136,7 @@ class SACAgent(object):
     FEATURE_KEYS = ()
     CRITIC_KEYS = ('q_loss', 'q1', 'q2')
     ACTOR_KEYS = ('actor_loss', 'alpha_loss', 'alpha')
+    CHECKPOINT_FORMAT = 'rlrep-ckpt-2'        # 2: GroupCfg grew to 22 words (running Adam powers); bump with the device-record layout
 
     def __init__(self, state_dim, action_dim, action_space, lr=3e-4, discount=0.99, target_update_period=2,
                  tau=0.005, alpha=0.1, auto_entropy_tuning=True, hidden_dim=1024, **_hip):
@@ -190,11 +191,16 @@ class SACAgent(object):
         self._seg_capture_colls = False
         self._early_works, self._early_slices = [], []       # async gradient all-reduces issued inside a backward (exchange kind 3)
         self._n_captured_colls = 0
+        self._fresh_dp_graph = False
         self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
-        # sequential data-parallel form on the RCCL backend: the gradient all-reduces are CAPTURED into the hipGraph of train() (one graph
-        # instead of 7 segments + 6 eager calls of ~14 us of host time each).  One stream, one communicator: the collectives of a replay
-        # are issued in program order, identical on every rank.  RLREP_DP_CAPTURE=0 (and every non-RCCL backend) keeps the segments.
-        self.capture_collectives = bool(int(os.environ.get('RLREP_DP_CAPTURE', '1')))
+        # sequential data-parallel form on the RCCL backend: the gradient all-reduces may be CAPTURED into the hipGraph of train() (one graph
+        # instead of 7 segments + 6 eager calls of ~14 us of host time each; one stream, one communicator: the collectives of a replay
+        # are issued in program order, identical on every rank).  That form has only ever run over a ONE-rank RCCL group (the only RCCL
+        # configuration a one-GPU box allows), where an all-reduce moves nothing between devices -- so it is the default only there.
+        # With world_size > 1 the default is the form that two real ranks have run (gloo, tests/test_dp.py): graph segments around
+        # eager all-reduces.  RLREP_DP_CAPTURE=1 (bench.py --dp-form captured) opts in; a failure while building or first replaying the
+        # captured graph raises with that switch named (no silent fallback: every rank must take the same form).
+        self.capture_collectives = bool(int(os.environ.get('RLREP_DP_CAPTURE', '1' if self.world_size == 1 else '0')))
         # backward -> all-reduce -> apply form of every optimizer step.  RLREP_FORCE_DP=1 takes it with a one-rank process group too
         # (sac / vlsac: rehearses the RCCL stream / graph-segment machinery on a single GPU; tests/test_dp.py)
         self._dp = self.world_size > 1 or (self.ALG in ('sac', 'vlsac', 'diffsrsac') and bool(int(os.environ.get('RLREP_FORCE_DP', '0'))))
@@ -336,8 +342,7 @@ class SACAgent(object):
         c = self.core
         self.flush()
         torch.cuda.synchronize()
-        steps_dev = None
-        return {'alg': self.ALG, 'params': c.params.cpu(), 'targets': c.targets.cpu(), 'exp_avg': c.exp_avg.cpu(),
+        return {'format': self.CHECKPOINT_FORMAT, 'device_state_bytes': int(c.device_state().numel()), 'alg': self.ALG, 'params': c.params.cpu(), 'targets': c.targets.cpu(), 'exp_avg': c.exp_avg.cpu(),
                 'exp_avg_sq': c.exp_avg_sq.cpu(), 'alpha_state': c.alpha_state.cpu(), 'device_state': c.device_state().cpu(),
                 'steps': self.steps, 'noise_ctr': self._ctr, 'seed': self._seed, 'layout': list(c.order)}
 
@@ -351,6 +356,13 @@ class SACAgent(object):
         c = self.core
         if snap['alg'] != self.ALG or snap['layout'] != list(c.order) or snap['params'].numel() != c.params.numel():
             raise RuntimeError('checkpoint does not match this agent (algorithm / dimensions differ)')
+        # the device records (step counters, per-group optimizer scalars, metric slots) are copied back byte for byte: their layout is the
+        # library's (include/rlrep.h RLREP_GROUP_CFG_WORDS) and changes with it -- a checkpoint of another format is refused by name, not
+        # by an opaque copy_ shape error
+        fmt, nbytes = snap.get('format'), snap.get('device_state_bytes', snap['device_state'].numel())
+        if fmt != self.CHECKPOINT_FORMAT or int(nbytes) != int(c.device_state().numel()) or snap['device_state'].numel() != c.device_state().numel():
+            raise RuntimeError(f'checkpoint does not match this library: format {fmt!r} with {int(nbytes)} bytes of device records, this build '
+                               f'writes format {self.CHECKPOINT_FORMAT!r} with {int(c.device_state().numel())} (saved by another version of rlrep_amd)')
         for k, dst in (('params', c.params), ('targets', c.targets), ('exp_avg', c.exp_avg), ('exp_avg_sq', c.exp_avg_sq),
                        ('alpha_state', c.alpha_state)):
             dst.copy_(snap[k])
@@ -400,9 +412,10 @@ class SACAgent(object):
         self._collective(lambda: dist.all_reduce(view, group=pg))
 
     def _collective(self, fn):
-        """Run a torch.distributed call now, or -- during segmented capture (data parallel + hipGraph) -- close the
-        graph segment recorded so far, remember the collective as an eager step and open the next segment.
-        No RCCL call is ever captured."""
+        """Run a torch.distributed call now, or -- while a data-parallel train() is being captured -- either record it into the open
+        hipGraph (RCCL backend with RLREP_DP_CAPTURE=1: ProcessGroupNCCL under stream capture) or close the graph segment recorded so
+        far, remember the collective as an eager step between two segments and open the next segment (the default with world_size > 1,
+        and the only form on gloo)."""
         if self._seg is not None and self._seg_capture_colls:
             fn()                                    # recorded into the open graph (ProcessGroupNCCL under stream capture)
             self._n_captured_colls += 1
@@ -580,6 +593,31 @@ class SACAgent(object):
     def _critic_trains(self):
         return True
 
+    def _history_info(self):
+        """The info dict of a whole-train() graph replay: record n of the library's metric history ring, fetched when read.  Reading it
+        counts as LOOKING at the critic / actor for the adaptive choice of the train() form (a caller who reads every dict and never calls
+        select_action would otherwise oscillate between the forms: in the two-chain form a read flushes and marks the look, here it did
+        not).  Before the ring can wrap, the unread dicts still alive are resolved from one host copy of it."""
+        n = self._hist_n
+        self._hist_n += 1
+        half = max(1, self.core.history_capacity() // 2)
+        if n % half == half - 1:
+            self.core.history_resolve()
+        return self.core.info(lazy_source=self.core.history_source(n), on_read=self._mark_looked)
+
+    def _mark_looked(self):
+        self._looked = True
+
+    def _raise_capture_hint(self, e):
+        """A data-parallel train() failed while its hipGraph was built or first replayed.  With the collectives CAPTURED into the graph
+        (RLREP_DP_CAPTURE=1 on the RCCL backend) say how to get the segmented form instead -- every rank has to make the same choice, so
+        there is no per-rank fallback, and a process that has touched the GPU is never re-executed: the launcher sets the switch."""
+        if self._seg_capture_colls:
+            raise RuntimeError('data-parallel train(): building / replaying the hipGraph with CAPTURED RCCL all-reduces failed '
+                               f'({type(e).__name__}: {e}).  Re-launch with RLREP_DP_CAPTURE=0 (bench.py --dp-form segments): hipGraph '
+                               'segments around eager all-reduces, the form the multi-rank tests run.') from e
+        raise e
+
     def _between_feature_and_critic(self):
         pass
 
@@ -628,33 +666,41 @@ class SACAgent(object):
                     torch.cuda.synchronize()
                 self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')      # see _train_graph
                 self.core.history(self._hist)
-                with torch.cuda.stream(s):
-                    first = torch.cuda.CUDAGraph()
-                    # thread-local capture mode: the process group's watchdog thread may query events while we capture
-                    first.capture_begin(capture_error_mode='thread_local')
-                    self._seg = ([], first)
-                    try:
-                        self._body(buffer, B, True)
-                        segs, cur = self._seg
-                        self._seg = None
-                        cur.capture_end()
-                        segs.append(('graph', cur))
-                    finally:
-                        self.core.history(False)
-                        self._abort_open_capture()
-                torch.cuda.current_stream().wait_stream(s)
-                torch.cuda.synchronize()
+                try:
+                    with torch.cuda.stream(s):
+                        first = torch.cuda.CUDAGraph()
+                        # thread-local capture mode: the process group's watchdog thread may query events while we capture
+                        first.capture_begin(capture_error_mode='thread_local')
+                        self._seg = ([], first)
+                        try:
+                            self._body(buffer, B, True)
+                            segs, cur = self._seg
+                            self._seg = None
+                            cur.capture_end()
+                            segs.append(('graph', cur))
+                        finally:
+                            self.core.history(False)
+                            self._abort_open_capture()
+                    torch.cuda.current_stream().wait_stream(s)
+                    torch.cuda.synchronize()
+                except Exception as e:
+                    self._raise_capture_hint(e)
                 self._graph, self._graph_key = segs, key
                 self._hist_n = self.core.history_seq() if self._hist else 0
-        for kind, x in self._graph:
-            if kind == 'graph':
-                x.replay()
-            else:
-                x()
+                self._fresh_dp_graph = True
+        try:
+            for kind, x in self._graph:
+                if kind == 'graph':
+                    x.replay()
+                else:
+                    x()
+            if self._fresh_dp_graph:                  # the first replay of a newly built graph is checked to the end (once per capture)
+                self._fresh_dp_graph = False
+                torch.cuda.synchronize()
+        except Exception as e:
+            self._raise_capture_hint(e)
         if self._hist:
-            n = self._hist_n
-            self._hist_n += 1
-            return self.core.info(lazy_source=self.core.history_source(n))
+            return self._history_info()
         return self.core.info()
 
     # ---- pipelined graph mode ---------------------------------------------------------------------------------------
@@ -1016,7 +1062,5 @@ class SACAgent(object):
                 self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
         self._graph.replay()
         if self._hist:
-            n = self._hist_n
-            self._hist_n += 1
-            return self.core.info(lazy_source=self.core.history_source(n))
+            return self._history_info()
         return self.core.info()

@@ -4,6 +4,7 @@ torch is used for what the C ABI asks the caller to provide -- device memory (ar
 and index buffers), the current HIP stream -- and nothing else: no torch op runs on the update path.
 """
 import ctypes as C
+import weakref
 import numpy as np
 import torch
 
@@ -26,13 +27,14 @@ class LazyInfo(dict):
     Q14), each a device sync; here the metric slots are snapshotted on the device and only fetched when a
     value is actually read (main.py reads `info` once per 5000 steps)."""
 
-    def __init__(self, names, snapshot, early=None, after=None):
+    def __init__(self, names, snapshot, early=None, after=None, on_read=None):
         """early = (keys, callable): a subset of the metrics that is final BEFORE the full snapshot is (pipelined train(): the feature
         steps' losses are final when the feature chain ends, while the critic / actor chain is still running); reading only such keys
         fetches them through `callable` and does not wait for the rest."""
         super().__init__()
         self._names, self._snap, self._done = names, snapshot, False
         self._after = after          # called once the values are on the host (HipCore.chain_check: the device-side checks of the chain launches)
+        self._on_read = on_read      # called when the CALLER reads the dict for the first time (not when the library resolves it early)
         self._early_keys, self._early_snap, self._early_done = (frozenset(early[0]), early[1], False) if early else (frozenset(), None, False)
         for n in names:
             if n:
@@ -42,11 +44,18 @@ class LazyInfo(dict):
     # everything else as Python floats
     TENSOR_KEYS = {'alpha_loss': torch.float32, 'alpha': torch.float64}
 
-    def _fetch(self):
+    def _fetch(self, host_ring=None):
+        """host_ring: a host copy of the metric history ring (HipCore.history_resolve: the library resolves unread dicts before the ring
+        wraps); None: the caller is reading."""
         if not self._done:
-            snap = self._snap() if callable(self._snap) else self._snap     # callable: fetched (and flushed) on first read
+            if host_ring is None and self._on_read is not None:
+                self._on_read()
+            if host_ring is not None:
+                snap = self._snap(host_ring)
+            else:
+                snap = self._snap() if callable(self._snap) else self._snap     # callable: fetched (and flushed) on first read
             vals = snap.cpu().numpy()
-            if self._after is not None:
+            if self._after is not None and host_ring is None:
                 self._after()
             for i, n in enumerate(self._names):
                 if n:
@@ -352,19 +361,41 @@ class HipCore:
         """LazyInfo source for the metrics of the n-th filed train(): fetched from the ring on first read."""
         ring, _, cap, tag = self._history_views()
 
-        def fetch():
-            rec = ring[n % cap].cpu()
+        def fetch(host_ring=None):
+            rec = (host_ring if host_ring is not None else ring)[n % cap].cpu()
             got = int(rec.view(torch.int32)[tag])
             if got != n:
                 raise RuntimeError(f'the metrics of this train() call (record {n}) have been overwritten: the history ring holds the last {cap} '
                                    f'calls (found record {got}); read a returned info dict within {cap} train() calls')
             return rec[:METRIC_SLOTS]
+        fetch.history_record = n
         return fetch
 
-    def info(self, keys=None, lazy_source=None, early=None):
+    def history_capacity(self):
+        return self._history_views()[2]
+
+    def history_resolve(self):
+        """Resolve every returned-but-unread info dict that is backed by the history ring: ONE copy of the ring to the host, then each live
+        dict takes its record.  The agent calls this every capacity / 2 replays, so a dict a caller keeps (per-episode / per-epoch logging)
+        stays valid forever, like the reference's plain floats -- at the price of one device synchronisation per 512 train() calls, and
+        only while unread dicts are alive."""
+        live = [li for li in list(getattr(self, '_hist_unread', ())) if not li._done]
+        self._hist_unread = weakref.WeakSet()
+        if not live:
+            return
+        host = self._history_views()[0].cpu()
+        for li in live:
+            li._fetch(host)
+
+    def info(self, keys=None, lazy_source=None, early=None, on_read=None):
         snap = lazy_source if lazy_source is not None else self.metrics_tensor().clone()
         names = self.metric_names if keys is None else [n if n in keys else '' for n in self.metric_names]
-        return LazyInfo(names, snap, early, after=self.chain_check)
+        li = LazyInfo(names, snap, early, after=self.chain_check, on_read=on_read)
+        if getattr(lazy_source, 'history_record', None) is not None:
+            if not hasattr(self, '_hist_unread'):
+                self._hist_unread = weakref.WeakSet()
+            self._hist_unread.add(li)
+        return li
 
     def stages(self, program):
         n = lib.rlrep_stage_count(self.h, program)

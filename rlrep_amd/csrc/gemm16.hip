@@ -189,7 +189,10 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     // per-call patches (noise pointers)
     GemmBatch planned = *gb_in;
     for (int q = 0; q < GEMM_MAX_TASKS; ++q) { planned.tb[q] = 0x7fffffff; planned.tcs[q] = 1; }
-    for (int q = 0; q < planned.ntasks; ++q) { rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c; }
+    for (int q = 0; q < planned.ntasks; ++q) {
+        rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c;
+        if (planned.t[q].tiles_c <= 0 || planned.t[q].tiles_c > 0xffff) return -3;       // the preloaded header packs column-tile counts two to a word
+    }
     planned.total = total_tiles;
     const GemmBatch* const gb = &planned;
     dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
@@ -247,7 +250,11 @@ extern "C" int rl_launch_gemm16_duo(int split, int nf2, const GemmBatch* gb_in, 
     if (split <= 0 || split >= gb_in->ntasks || gb_in->nfin > 0 || (nf2 != 1 && nf2 != 4)) return -4;
     GemmBatch planned = *gb_in;
     for (int q = 0; q < GEMM_MAX_TASKS; ++q) { planned.tb[q] = 0x7fffffff; planned.tcs[q] = 1; }
-    for (int q = 0; q < planned.ntasks; ++q) { rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c; if (planned.t[q].flags & FLAG_PRE) return -4; }
+    for (int q = 0; q < planned.ntasks; ++q) {
+        rl_gemm16_plan(planned.t[q]); planned.tb[q] = planned.t[q].tile_base; planned.tcs[q] = planned.t[q].tiles_c;
+        if (planned.t[q].flags & FLAG_PRE) return -4;
+        if (planned.t[q].tiles_c <= 0 || planned.t[q].tiles_c > 0xffff) return -3;
+    }
     planned.total = total_tiles;
     bool va = true;
     for (int q = 0; q < split; ++q) { const GemmTask& t = planned.t[q]; if ((t.lda & 3) || (t.K & 3) || (((uintptr_t)t.A) & 15)) va = false; }

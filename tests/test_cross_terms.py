@@ -126,10 +126,12 @@ def test_feature_step_then_update_feature_target_matches_oracle():
 
 
 # ---- the returned info dict of a whole-train() graph replay: filed on the device, fetched when read ------------------------------
-def test_info_of_graph_replays_is_per_call_and_expires_loudly(monkeypatch):
-    """sac_agent.py:157-166 returns the metrics of THAT call.  The one-graph train() files them in the library's history ring (rlrep_history)
-    and the dict fetches its record on first read: dicts read late and out of order equal, bit for bit, what a twin agent that snapshots
-    per call (RLREP_INFO_HISTORY=0) returned, and a dict whose record has been overwritten raises instead of reporting a later call."""
+def test_info_of_graph_replays_is_per_call_and_outlives_the_ring(monkeypatch):
+    """sac_agent.py:157-166 returns the metrics of THAT call as plain floats that stay valid forever.  The one-graph train() files them in the
+    library's history ring (rlrep_history) and the dict fetches its record on first read: dicts read late and out of order equal, bit for bit,
+    what a twin agent that snapshots per call (RLREP_INFO_HISTORY=0) returned; a dict the caller KEEPS unread while the ring wraps (per-epoch
+    logging) is resolved by the library before its record is overwritten (HipCore.history_resolve, every capacity / 2 calls) and still holds
+    its own call's values; the raw source of an overwritten record raises instead of reporting a later call."""
     from test_default_mode import _default_agent, _buffer
     c = Case('sac_tiny')
     a, buf, n = _default_agent(c), _buffer(c), 6
@@ -139,17 +141,34 @@ def test_info_of_graph_replays_is_per_call_and_expires_loudly(monkeypatch):
     monkeypatch.delenv('RLREP_INFO_HISTORY')
     ia = [a.train(buf, c.B) for _ in range(n)]
     assert a._hist and not b._hist
-    for t in (4, 0, 5, 2, 1, 3):
+    for t in (4, 0, 5, 2):
         for k, v in ib[t].items():
             assert float(ia[t][k]) == float(v), (t, k, ia[t][k], v)
     assert len({float(ib[t]['q_loss']) for t in range(n)}) > 1, 'the calls must differ for the test to mean anything'
-    stale = a.train(buf, c.B)
-    cap = a.core._history_views()[2]
-    for _ in range(cap):
+    cap = a.core.history_capacity()
+    raw_stale = a.core.history_source(1)              # the bare ring source of call 1: nothing resolves it
+    for _ in range(cap + 8):
         last = a.train(buf, c.B)
     assert np.isfinite(float(last['actor_loss']))
+    for t in (1, 3):                                   # kept unread across a full wrap of the ring
+        for k, v in ib[t].items():
+            assert float(ia[t][k]) == float(v), (t, k, ia[t][k], v)
     with pytest.raises(RuntimeError, match='overwritten'):
-        stale['actor_loss']
+        raw_stale()
+
+
+def test_reading_every_info_dict_settles_on_the_sequential_form():
+    """a caller that reads the returned dict after every train() and never calls select_action must not oscillate between the
+    two forms of train(): a read of a history-backed dict counts as a look, as a read of a two-chain dict (which flushes) does."""
+    from test_default_mode import _default_agent, _buffer
+    c = Case('vlsac_tiny')
+    agent, buf = _default_agent(c, adaptive=True), _buffer(c)
+    forms = []
+    for _ in range(14):
+        info = agent.train(buf, c.B)
+        forms.append('P' if agent._pending == 2 else 'S')
+        float(info['q1_loss'])
+    assert forms[:3] == ['P', 'P', 'P'] and set(forms[4:]) == {'S'}, forms
 
 
 def test_rows_flushed_on_the_feature_stream_are_visible_to_readers_on_the_callers_stream():

@@ -401,24 +401,27 @@ def test_deferred_pipeline_is_equivalent(name):
         assert abs(ia[k] - ib[k]) <= 1e-6 * max(abs(ib[k]), 1e-2), (k, ia[k], ib[k])
 
 
-@pytest.mark.parametrize('alg,S,A,B,kw', [
-    ('vlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
-    ('ctrlsac', 17, 6, 256, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
-])
-def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw, monkeypatch):
-    """400 pipelined train() calls at the BASELINE dimensions (two streams, two snapshot sets, device Philox) end in exactly the
-    parameters, moments and targets of 400 sequential ones: any missing dependency between the two launch chains would show here
-    (tools/exp/pipe_soak.py runs the same check for 2000 calls: 0.0 difference for vlsac, ctrlsac and spedersac).
-    RLREP_NC_DW_FULL=1: both forms on the SAME noise-critic dW kernel -- the deferred chain's default is the 128-VGPR build of it,
-    whose results differ from the 233-VGPR build in the last bit (test_lean_noise_critic_dw_matches_full below)."""
+@pytest.mark.parametrize('alg,S,A,B,calls,kw', [
+    ('vlsac', 17, 6, 256, 400, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
+    ('ctrlsac', 17, 6, 256, 400, dict(hidden_dim=256, feature_dim=256, extra_feature_steps=3)),
+    # the configurations whose default-mode oracle check flushes after every call (so the two chains never overlap
+    # while being compared) get the overlap covered here, at their BASELINE dimensions (fewer calls: 17 / 4 ms of GPU time per pair)
+    ('ctrlsac', 17, 6, 256, 120, dict(hidden_dim=1024, feature_dim=2048, extra_feature_steps=3)),
+    ('spedersac', 111, 8, 1024, 120, dict(phi_and_mu_lr=1e-5, phi_hidden_dim=512, phi_hidden_depth=1, mu_hidden_dim=512, mu_hidden_depth=0,
+                                          critic_and_actor_lr=3e-4, critic_and_actor_hidden_dim=256, feature_dim=512, hidden_dim=256,
+                                          extra_feature_steps=5)),
+], ids=['vlsac_hc', 'ctrlsac_hc256', 'ctrlsac_hc2048', 'spedersac_ant512'])
+def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, calls, kw, monkeypatch):
+    """Pipelined train() calls at the BASELINE dimensions (two streams, three snapshot sets, device Philox) end in exactly the
+    parameters, moments and targets of as many sequential ones: any missing dependency between the two launch chains would show here
+    (tools/exp/pipe_soak.py runs the same check for thousands of calls: 0.0 difference for vlsac, ctrlsac and spedersac)."""
     import importlib
-    monkeypatch.setenv('RLREP_NC_DW_FULL', '1')
-    # ... and on the same POLICY-FORWARD kernels: the sequential form would otherwise run both policy forwards inside the last feature
-    # step's row-program launch, the pipelined form inside the critic step's tile launches (different summation order, last-bit differences)
+    # both forms on the same POLICY-FORWARD kernels: the sequential form would otherwise run both policy forwards inside the last feature
+    # step's launches, the pipelined form inside the critic step's tile launches (different summation order, last-bit differences)
     monkeypatch.setenv('RLREP_NO_EARLY_POLICY', '1')
     import synth
     from rlrep_amd.utils.buffer import ReplayBuffer
-    name = {'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent'}[alg]
+    name = {'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent', 'spedersac': 'SPEDERSACAgent'}[alg]
     cls = getattr(importlib.import_module(f'rlrep_amd.agent.{alg}.{alg}_agent'), name)
     data = synth.replay(S, A, 8192, seed=0)
     outs = []
@@ -427,12 +430,16 @@ def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, kw, monkeypatch):
         agent = cls(state_dim=S, action_dim=A, action_space=_Space(A, 1.0), max_batch=B, pipeline=pipe, seed=99, **kw)
         buf = ReplayBuffer(S, A, max_size=8192)
         buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
-        for i in range(400):
+        for i in range(calls):
             agent.train(buf, B)
-            if i == 250:
+            if i == (calls * 5) // 8:
                 agent.select_action(np.zeros(S, np.float32))
+        if pipe:
+            assert agent._pipe is not None and agent._pipe.get('mode') == 2, 'the pipelined agent must have taken the two-stream form'
         outs.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
         outs[-1]['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy()
+        del agent, buf
+        torch.cuda.synchronize()
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
 

@@ -52,3 +52,9 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
         assert torch.equal(sa[k], sb[k]), k
     for k in ia.keys():
         assert ia[k] == ib[k], k
+    # a checkpoint of another format / with device records of another size is refused by name, not by a copy_ shape error
+    snap = a.state_snapshot()
+    for bad in (dict(snap, format='rlrep-ckpt-1'), dict(snap, device_state=snap['device_state'][:-8], device_state_bytes=snap['device_state'].numel() - 8),
+                {k: v for k, v in snap.items() if k != 'format'}):
+        with pytest.raises(RuntimeError, match='does not match this library'):
+            b.load(bad)
