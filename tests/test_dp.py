@@ -203,7 +203,11 @@ def _gpu_worker(rank, world, port, q, case='vlsac_tiny'):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['sac_tiny', 'vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny', 'diffsrsac_tiny'])
+@pytest.mark.parametrize('case', ['sac_tiny', 'vlsac_tiny', 'ctrlsac_tiny', 'spedersac_tiny', 'diffsrsac_tiny',
+                                  # the two agents BASELINE shards (configs 4 and 5), at config dimensions: spedersac Ant F = 512 with B = 1024 per
+                                  # rank (the LDS-tiled engine, split-K, the Phibar / v exchange at full width) and diffsrsac at HalfCheetah dims
+                                  # (the bf16x3 head, the early all-reduce of the head's gradient slice)
+                                  'spedersac_ant512', 'diffsrsac_hc'])
 def test_hip_dp_two_ranks_match_global_batch_oracle(case):
     """ctrlsac (in-batch negatives over BOTH ranks' minibatches) and spedersac (global Phibar / v) are exact too:
     the oracle sees one batch of 2B rows.  diffsrsac (BASELINE config 5's agent: two optimizers per feature step, all-reduce of the
