@@ -103,12 +103,10 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     _lib.lib.rlrep_nc_fwd_plan(4, B, F, H, *[C.byref(o) for o in plan])
     x3 = plan[0].value == 1
     # bf16x3 engine: six bf16 MFMA flops are executed per algorithmic fp32 flop, so the ceiling for ALGORITHMIC flops is the dense
-    # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NC_X3=0) it is the fp32 MFMA peak
+    # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NO_X3) it is the fp32 MFMA peak
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-    # the launcher's choice for a 128-wide tile (noisecritic.hip rl_launch_nc_fwd): 32x32x16 one-role kernel, else the 16x16x32 one-role one
-    quad = plan[2].value == 128 and os.environ.get('RLREP_NC_X3_Q', '1') != '0'
-    wide = plan[2].value == 128 and os.environ.get('RLREP_NC_X3_WIDE', '1') != '0'
-    kname = ('nc_fwd_x3q_kernel' if quad else 'nc_fwd_x3w_kernel<8>' if wide else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
+    # the launcher's choice (noisecritic.hip rl_launch_nc_fwd): the 32x32x16 one-role kernel for a 128-wide tile
+    kname = ('nc_fwd_x3q_kernel' if plan[2].value == 128 else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'
     out = {'bound': 'mfma', 'kernel': kname + (' (critic step, 4 heads, bf16x3)' if x3 else ' (critic step, 4 heads)'),
            'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
            # (traffic is not measured inside a timed run: the PMC passes -- FETCH_SIZE x2 for wide reads on gfx950 + WRITE_SIZE -- are
@@ -165,10 +163,12 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=9.0):
-    """The CPU oracle (a from-scratch port of the reference's PyTorch-CPU path, oracle/) on this box: an N-thread leg and a 1-thread
-    leg.  NOTE: the oracle deduplicates work the reference executes (second encoder pass, [B,B,F] broadcast, critic /
-    feature weight gradients in the actor step: 13.35 vs 10.59 GFLOP for vlsac), so the reference itself is slower than this number."""
+def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=6.0):
+    """The CPU oracle (a from-scratch port of the reference's PyTorch-CPU path, oracle/) on this box's host cores, same workload, same
+    loop: a SWEEP over torch thread counts -- 1, 16, 64 and os.cpu_count() (SURVEY.md 8d names the last and 1), plus `--cpu-threads` --
+    each a bounded sample; `value` is the best leg, `cores` its thread count, `sweep` every leg.  NOTE: the oracle deduplicates work the
+    reference executes (second encoder pass, [B,B,F] broadcast, critic / feature weight gradients in the actor step: 13.35 vs 10.59 GFLOP
+    for vlsac), so the reference itself is slower than this number."""
     from oracle import make_oracle
     from oracle.agents import gather_batch
     from oracle.shapes import param_shapes
@@ -186,7 +186,7 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=9.0):
     nf = kw.get('extra_feature_steps', 0) + 1 if alg != 'sac' else 0
     tens = {k: torch.from_numpy(v) for k, v in data.items()}
 
-    def leg(nthreads):
+    def leg(nthreads, budget):
         torch.set_num_threads(nthreads)
         o = make_oracle(alg, S, A, init, **kw)
         if alg == 'diffsrsac':
@@ -204,55 +204,84 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=9.0):
                     eps += [torch.from_numpy(rs.randint(0, 1000, size=B)), torch.from_numpy((0.449 * rs.standard_normal((B, S))).astype(np.float32))]
             eps += [torch.from_numpy(rs.standard_normal((B, A)).astype(np.float32)) for _ in range(2)]
             o.train([gather_batch(tens, i) for i in idx], eps)
-        for _ in range(2):
+        tw = time.time()
+        one()                                           # warm-up (allocator, thread pool)
+        slow = time.time() - tw > 1.0                   # (Humanoid: seconds per call -- one warm-up and at least one timed call per leg)
+        if not slow:
             one()
         t0 = time.time()
         n = 0
-        while n < 200 and (n < 2 or time.time() - t0 < budget_s):
+        while n < 200 and (n < (1 if slow else 2) or time.time() - t0 < budget):
             one()
             n += 1
         return n, time.time() - t0
 
-    n, dt = leg(threads)
-    n1, dt1 = leg(1)
-    return {'value': round(n / dt, 3), 'unit': 'train()/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} train() calls of the same workload on the CPU oracle (torch {torch.__version__} CPU, '
-                      f'{threads} threads of {os.cpu_count()} logical cores), {dt:.1f} s',
-            'single_thread': {'value': round(n1 / dt1, 3), 'cores': 1, 'sample': f'{n1} train() calls, {dt1:.1f} s'},
+    ncpu = os.cpu_count() or 1
+    counts = sorted({c for c in (1, 16, 64, ncpu, threads) if 1 <= c <= ncpu})
+    sweep = []
+    for c in counts:
+        # (measured on the 2 x 64-core box, profiles/r04_cpu_sweep_all_threads.json: with every logical core as a torch thread ONE vlsac
+        # train() takes 130 s -- 0.008 /s against 23 /s on 16 threads -- oversubscribed intra-op pools on matrices this small.  A leg whose
+        # predecessor already fell below half of the best rate is recorded as skipped instead of burning minutes of the run.)
+        best_so_far = max((r['value'] for r in sweep if 'value' in r), default=0.0)
+        if c > 16 and sweep and sweep[-1].get('value', 0.0) < 0.5 * best_so_far and os.environ.get('RLREP_CPU_SWEEP_ALL') != '1':
+            sweep.append({'threads': c, 'skipped': f"{sweep[-1]['threads']} threads already ran at {sweep[-1]['value']} /s against {best_so_far} /s best: more threads are slower"})
+            continue
+        n, dt = leg(c, budget_s)
+        sweep.append({'threads': c, 'value': round(n / dt, 3), 'calls': n, 'seconds': round(dt, 1)})
+    best = max((r for r in sweep if 'value' in r), key=lambda r: r['value'])
+    one_thr = next(r for r in sweep if r['threads'] == 1)
+    return {'value': best['value'], 'unit': 'train()/s', 'cores': best['threads'], 'kind': 'port',
+            'sample': f"{best['calls']} train() calls of the same workload on the CPU oracle (torch {torch.__version__} CPU, "
+                      f"{best['threads']} threads of {ncpu} logical cores: the best leg of the sweep), {best['seconds']} s",
+            'sweep': sweep,
+            'single_thread': {'value': one_thr['value'], 'cores': 1, 'sample': f"{one_thr['calls']} train() calls, {one_thr['seconds']} s"},
             'cpu_model': _cpu_model(),
             'note': 'oracle = deduplicated restatement of the reference (10.59 vs 13.35 executed GFLOP per vlsac train()): the reference '
                     'itself measured 10.3 train()/s on 8 cores of the build container (SURVEY.md section 6)'}
 
 
-# kernel families of the vlsac step programs, by stage name (include/rlrep.h rlrep_stage_name)
-def _family(name):
-    if name.startswith('noise critic'):
-        return 'noise critic (nc_*_x3 kernels, bf16x3 on the bf16 matrix pipe)'
-    if name.startswith('adam') or name.startswith('polyak'):
-        return 'optimizer (adam_kernel: Adam + Polyak + metrics + next-minibatch gather)'
-    if name.startswith('qhead') or name.startswith('vae_mid') or name.startswith('policy'):
-        return 'losses (qhead / vae_mid: elementwise + wave reductions)'
-    if name.startswith('row programs'):
-        return 'row programs (rowprog_kernel)'
-    return 'gemm16_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'
-
-
-# algorithmic flops of a gemm16 stage are not carried by its name; the family totals come from SURVEY.md Appendix F (per train())
-FAMILY_GFLOP = {'gemm16': 3.88, 'noise critic': 6.71}
+# Kernel families of the step programs, by the engine id the library reports per stage (include/rlrep.h rlrep_stage_info):
+# name -> (engine ids, bound, peak, unit, regex over rocprofv3 kernel names: which rows of profiles/*_kernel_stats.csv / *_pmc_*.json belong to it)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 measured)
+FAMILIES = {
+    'gemm16': ((1, 2), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm16_kernel|gemm16_duo_kernel|heads_vae_kernel)',
+               'gemm16_kernel + gemm16_duo_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'),
+    'gemm_lds64': ((3,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm_lds_kernel<64|gemm_lds_fin_kernel)',
+                   'gemm_lds_kernel<64,...> + gemm_lds_fin_kernel (64-wide LDS tiles on fp32 MFMA, split-K slabs + finishing blocks)'),
+    'gemm_lds128': ((4,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^gemm_lds_kernel<128', 'gemm_lds_kernel<128,...> (128-wide LDS tiles on fp32 MFMA)'),
+    'gemm_x3': ((5,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^gemm_x3_kernel',
+                'gemm_x3_kernel (128-wide tiles on the bf16 pipe, exact 3-way split: peak = dense bf16 peak / 6 executed flops per product)'),
+    'noise_critic': ((6,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^nc_', 'nc_fwd / nc_dx / nc_dw kernels (vlsac noise critic, bf16x3: peak = dense bf16 peak / 6)'),
+    'optimizer': ((7,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^adam_kernel', 'adam_kernel (Adam + Polyak + metrics + riders: 28 B per parameter + 12 B per target element)'),
+    'score': ((8,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^diffsr_score', 'diffsr_score kernels (one pass over the [B, F*S] tensor)'),
+    'other': ((0,), None, None, None, r'.*', 'losses, gathers, copies (elementwise + wave reductions)'),
+}
+_ENGINE_FAMILY = {e: k for k, v in FAMILIES.items() for e in v[0]}
 
 
 def stage_profile(agent, reps=40):
     """Every stage of the sequential step programs timed ALONE (hipGraph of `reps` back-to-back launches, HIP events on the launch stream),
-    grouped into kernel families: launches per train(), us per train(), share, algorithmic TFLOP/s.  Standalone times are a LOWER bound of
-    what a launch costs inside the dependent chain (there its operands arrive cold from another XCD's L2: `critical_path_us`)."""
+    grouped into kernel families by the engine the library reports for the stage (rlrep_stage_info), with the library's own count of the
+    stage's algorithmic flops / bytes: launches per train(), us per train(), share, achieved rate against the family's peak.  Standalone
+    times are a LOWER bound of what a launch costs inside the dependent chain (there its operands arrive cold from another XCD's L2)."""
+    import ctypes as C
+    from rlrep_amd._lib import lib, check
     core = agent.core
     nf = agent._feature_iters()
-    mult = {0: nf, 1: nf, 2: 1, 3: 1, 4: 1, 5: 1}
+    mult = {0: nf, 1: nf, 2: 1, 3: 1, 4: 1, 5: 1, 6: 1}
+    slow = agent.max_batch >= 2048
+    if slow:
+        reps = 4
     fam = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for prog in range(6):
+    for prog in range(7):
+        if mult[prog] == 0:
+            continue
         for i, name in enumerate(core.stages(prog)):
-            for _ in range(3):
+            eng, fl, by = C.c_int32(), C.c_double(), C.c_double()
+            check(lib.rlrep_stage_info(core.h, prog, i, C.byref(eng), C.byref(fl), C.byref(by)), 'stage_info')
+            for _ in range(1 if slow else 3):
                 core.run_stage(prog, i)
             torch.cuda.synchronize()
             g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
@@ -261,28 +290,96 @@ def stage_profile(agent, reps=40):
                     core.run_stage(prog, i)
             g.replay()
             torch.cuda.synchronize()
+            nrep = 2 if slow else 3
             e0.record()
-            for _ in range(3):
+            for _ in range(nrep):
                 g.replay()
             e1.record()
             torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / (3 * reps)
-            f = fam.setdefault(_family(name), {'launches_per_train': 0, 'us_per_train': 0.0})
+            us = e0.elapsed_time(e1) * 1e3 / (nrep * reps)
+            f = fam.setdefault(_ENGINE_FAMILY.get(eng.value, 'other'), {'launches_per_train': 0, 'us_per_train': 0.0, 'gflop': 0.0, 'mbytes': 0.0, 'stages': []})
             f['launches_per_train'] += mult[prog]
             f['us_per_train'] += us * mult[prog]
+            f['gflop'] += fl.value * mult[prog] / 1e9
+            f['mbytes'] += by.value * mult[prog] / 1e6
+            f['stages'].append([name, mult[prog], round(us, 2)])
     tot = sum(f['us_per_train'] for f in fam.values())
     out = []
     for k, f in sorted(fam.items(), key=lambda kv: -kv[1]['us_per_train']):
-        rec = {'family': k, 'launches_per_train': f['launches_per_train'], 'us_per_train': round(f['us_per_train'], 1),
-               'share_of_stage_time': round(f['us_per_train'] / tot, 3)}
-        for key, gf in FAMILY_GFLOP.items():
-            if k.startswith(key):
-                tf = gf * 1e9 / (f['us_per_train'] * 1e-6) / 1e12
-                peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if key == 'noise critic' else FP32_MFMA_PEAK_TFLOPS
-                rec.update({'algorithmic_gflop_per_train': gf, 'achieved': round(tf, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                            'frac': round(tf / peak, 4)})
+        _, bound, peak, unit, rx, desc = FAMILIES[k]
+        rec = {'family': k, 'kernels': desc, 'kernel_regex': rx, 'launches_per_train': f['launches_per_train'], 'us_per_train': round(f['us_per_train'], 1),
+               'us_per_launch': round(f['us_per_train'] / max(f['launches_per_train'], 1), 2),
+               'share_of_stage_time': round(f['us_per_train'] / tot, 3),
+               'algorithmic_gflop_per_train': round(f['gflop'], 4), 'algorithmic_mbytes_per_train': round(f['mbytes'], 3)}
+        if bound == 'mfma' and f['gflop'] > 0:
+            tf = f['gflop'] * 1e9 / (f['us_per_train'] * 1e-6) / 1e12
+            rec.update({'bound': 'mfma', 'achieved': round(tf, 2), 'peak': round(peak, 1), 'unit': unit, 'frac': round(tf / peak, 4)})
+        elif bound == 'hbm' and f['mbytes'] > 0:
+            gbs = f['mbytes'] * 1e6 / (f['us_per_train'] * 1e-6) / 1e9
+            rec.update({'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': round(peak, 1), 'unit': unit, 'frac': round(gbs / peak, 4)})
+        rec['stages'] = f['stages']
         out.append(rec)
     return out
+
+
+def pmc_traffic(path, fam):
+    """HBM-side traffic of a kernel family from a committed PMC summary (tools/summarize_profiles.py: per kernel the mean over dispatches of
+    the per-dispatch sums of FETCH_SIZE / WRITE_SIZE, in KB, collected in SEPARATE --pmc passes).  Corrected as MI355X_MICROARCH.md (HBM /
+    rocprofv3) prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide read -> x2; WRITE_SIZE is exact.  Infinity-Cache
+    hits are counted (these are L2-miss bytes, an upper bound of HBM bytes).  -> bytes per launch (dispatch-weighted mean over the family's
+    kernels), per train() and the ratio to the family's algorithmic bytes."""
+    import re
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    rx = re.compile(fam['kernel_regex'])
+    nd, tot = 0, 0.0
+    per_kernel = {}
+    for k, v in d.items():
+        if k.startswith('__') or not rx.search(k) or 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
+            continue
+        b = (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0
+        n = int(v.get('dispatches', 1))
+        nd += n
+        tot += b * n
+        per_kernel[k] = round(b)
+    if not nd:
+        return None
+    per_launch = tot / nd
+    per_train = per_launch * fam['launches_per_train']
+    alg = fam['algorithmic_mbytes_per_train'] * 1e6
+    return {'bytes_per_launch': round(per_launch), 'bytes_per_train': round(per_train), 'algorithmic_bytes_per_train': round(alg),
+            'ratio_to_algorithmic': round(per_train / alg, 2) if alg > 0 else None,
+            'source': os.path.relpath(path, ROOT), 'correction': '(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B, per dispatch; separate --pmc passes; Infinity-Cache hits counted',
+            'dispatches': nd}
+
+
+def find_pmc_json(workload, explicit=None):
+    """profiles/rNN_pmc_<workload>.json of the latest round that has one (rNN_pmc_summary.json = the headline workload)."""
+    import glob
+    if explicit:
+        return explicit if os.path.exists(explicit) else None
+    c = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_{workload}.json')))
+    if not c and workload == 'vlsac_halfcheetah_f256_b256':
+        c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
+    return c[-1] if c else None
+
+
+def family_roofline(fam, pmc_path):
+    """The `roofline` object of the bench line for one kernel family of stage_profile()."""
+    r = {'bound': fam.get('bound'), 'kernel': fam['kernels'], 'family': fam['family'], 'achieved': fam.get('achieved'), 'peak': fam.get('peak'),
+         'unit': fam.get('unit'), 'frac': fam.get('frac'), 'traffic': None, 'us_per_launch': fam['us_per_launch'], 'us_per_train': fam['us_per_train'],
+         'launches_per_train': fam['launches_per_train'], 'share_of_gpu_time': fam['share_of_stage_time'],
+         'algorithmic_gflop_per_train': fam['algorithmic_gflop_per_train'], 'algorithmic_mbytes_per_train': fam['algorithmic_mbytes_per_train'],
+         'note': 'achieved = algorithmic flops (bytes) of the family per train(), as the library counts them per stage (rlrep_stage_info), / the time its '
+                 'launches take (each stage timed alone as back-to-back launches inside this run, HIP events on the launch stream); traffic = '
+                 'bytes per launch from the committed PMC summary (not collectable inside a timed run)'}
+    tr = pmc_traffic(pmc_path, fam) if pmc_path else None
+    if tr:
+        r['traffic'] = tr['bytes_per_launch']
+        r['traffic_detail'] = tr
+    return r
 
 
 def chain_times(agent, reps=60):
@@ -384,7 +481,13 @@ def main():
                          '(SURVEY.md 8e; BASELINE configs 4 and 5 name a total batch on 4 / 8 GPUs)')
     ap.add_argument('--replicas', action='store_true',
                     help='N > 1: N independent agents (own parameters, own replay, NO gradient all-reduce) instead of data-parallel training')
+    ap.add_argument('--dp-form', choices=['segments', 'captured'], default=None,
+                    help='N > 1 on RCCL: hipGraph segments around eager all-reduces (default: the form the two-rank tests run) or the all-reduces '
+                         'captured into the train() graph (RLREP_DP_CAPTURE=1; rehearsed with one rank only).  Read before any GPU call.')
+    ap.add_argument('--pmc-json', default=None, help='PMC summary to take roofline.traffic from (default: the latest profiles/r*_pmc_<workload>.json)')
     args = ap.parse_args()
+    if args.dp_form is not None:
+        os.environ['RLREP_DP_CAPTURE'] = '1' if args.dp_form == 'captured' else '0'
     under_profiler = args.no_profile or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
     clock_helper = _spawn_clock_probe(under_profiler) if (args.gpus == 1 and int(os.environ.get('RANK', 0)) == 0) else None
 
@@ -526,6 +629,33 @@ def main():
         barrier()
         dt_loop = time.perf_counter() - t3
 
+    # N > 1 self-checks: are the replicas still bit-identical after everything above, and what do the gradient
+    # all-reduces of one train() cost when nothing else runs
+    replicas_identical, allreduce_us = None, None
+    if dist is not None and not replicas:
+        agent.flush()
+        torch.cuda.synchronize()
+        # checksum of the parameter / target arenas and the fp64 temperature state: wrap-around int64 sum of the bit patterns
+        chk = torch.stack([agent.core.params.view(torch.int32).to(torch.int64).sum(), agent.core.targets.view(torch.int32).to(torch.int64).sum(),
+                           agent.core.alpha_state.view(torch.int64).sum()]).to(torch.float64)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replicas_identical = bool((hi == lo).all().item())
+        colls = [x for kind, x in (agent._graph or []) if kind == 'coll'] if isinstance(getattr(agent, '_graph', None), list) else []
+        if colls:
+            for fn in colls:
+                fn()
+            barrier()
+            tc = time.perf_counter()
+            nrep = 10
+            for _ in range(nrep):
+                for fn in colls:
+                    fn()
+            barrier()
+            allreduce_us = (time.perf_counter() - tc) / nrep * 1e6
+            agent.core.grads.zero_()            # (the repeated sums are garbage; the next backward rewrites every gradient anyway)
+
     if rank == 0:
         updates = args.steps / dt                      # synchronized train() calls per second (each rank performs every one of them)
         value = updates if strong else world * updates       # strong scaling: one synchronized update IS one batch-B_global gradient step
@@ -555,6 +685,10 @@ def main():
                                  'replicas': 'sum over the independent replicas of their train() calls per second at batch B'}[mode],
             'global_updates_per_sec': round(updates if mode != 'replicas' else value, 2),
             'rccl_world_size': (dist.get_world_size() if dist is not None else 1),
+            # N > 1: parameter / target / temperature checksums equal on every rank after the run (max == min over ranks); the gradient
+            # all-reduces of ONE train() issued back to back with nothing else running (segments form only: in the captured form they are graph nodes)
+            'replicas_identical': replicas_identical,
+            'allreduce_us_per_train': (round(allreduce_us, 1) if allreduce_us is not None else None),
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B_global if strong else value * B, 1),
             'metrics_finite': bool(finite),
@@ -566,31 +700,29 @@ def main():
             'repeats': {'n': 5, 'calls_each': rep_len, 'values': [round(v, 1) for v in rep_rates]},
             'clocks': clocks,
         }
+        # `roofline` describes the RUN: the kernel family with the largest share of GPU time -- its algorithmic flops (bytes), counted by the
+        # library per stage, over the time its launches take inside this run, against the peak that bounds it; `traffic` from the committed
+        # PMC summary of this workload.  Every family is listed in `kernel_families`.
+        pmc_path = find_pmc_json(args.workload, args.pmc_json)
+        if world == 1 and not args.no_profile:
+            fams = stage_profile(agent)
+            out['kernel_families'] = [{k: v for k, v in f.items() if k != 'stages'} for f in fams]
+            out['stage_times_us'] = {f['family']: f['stages'] for f in fams}
+            priced = [f for f in fams if 'frac' in f]
+            if priced:
+                out['roofline'] = family_roofline(priced[0], pmc_path)
+            out['chains'] = chain_times(agent)
+            if out['chains']:
+                out['critical_path_us'] = out['chains']['feature_chain_us']
+                out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)
+            elif getattr(agent, '_graph_launches', None):
+                out['launches_per_train'] = int(agent._graph_launches)
         if alg == 'vlsac':
-            heaviest = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
-            out['roofline_heaviest_kernel'] = heaviest
-            out['roofline'] = heaviest
-            if world == 1 and not args.no_profile:
-                # `roofline` describes the RUN: the kernel family with the largest share of GPU time (the 16-row tile engine: every 256-wide
-                # layer), its algorithmic flops over the time its launches take, against the fp32 MFMA peak.  The
-                # heaviest single kernel (noise-critic forward) is `roofline_heaviest_kernel`.
-                out['chains'] = chain_times(agent)
-                fams = stage_profile(agent)
-                out['kernel_families'] = fams
-                top = fams[0]
-                if 'frac' in top:
-                    out['roofline'] = {'bound': 'mfma', 'kernel': top['family'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': 'TFLOP/s',
-                                       'frac': top['frac'], 'traffic': None, 'us_per_train': top['us_per_train'],
-                                       'launches_per_train': top['launches_per_train'], 'share_of_gpu_time': top['share_of_stage_time'],
-                                       'algorithmic_gflop_per_train': top['algorithmic_gflop_per_train'],
-                                       'note': 'achieved = algorithmic flops of the family per train() / the time its launches take (each stage timed '
-                                               'as 40 back-to-back launches with HIP events on the launch stream); traffic: PMC passes in profiles/ '
-                                               '(not collected inside a timed run)'}
-                if out['chains']:
-                    out['critical_path_us'] = out['chains']['feature_chain_us']
-                    out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)
+            out['roofline_heaviest_kernel'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
+            out.setdefault('roofline', out['roofline_heaviest_kernel'])
         elif alg == 'diffsrsac':
-            out['roofline'] = big_gemm_roofline(agent, B, S, 256, 512)
+            out['roofline_heaviest_kernel'] = big_gemm_roofline(agent, B, S, 256, 512)
+            out.setdefault('roofline', out['roofline_heaviest_kernel'])
         # whole-train() view: algorithmic GFLOP per train() per GPU against the fp32 peak
         gf = ALG_GFLOP.get(args.workload)
         if gf:

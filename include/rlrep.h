@@ -319,9 +319,31 @@ const float* rlrep_metrics_dev(rlrep_agent* agent);
 /* Profiling hook: launch stage `stage` of step program `program` once (0 feature_bwd, 1 feature_apply,
  * 2 critic_bwd, 3 critic_apply, 4 actor_bwd, 5 actor_apply, 6 update_target); its inputs are whatever the
  * previous full step left in the workspace.  rlrep_stage_count/_name enumerate the stages. */
+/* vlsac noise-critic weight images (bf16x3 shadows of critic.l1 / l4 and their targets; no reference counterpart: nn.Linear has no such
+ * copies).  Default: every critic step regenerates them with one launch.  Between rlrep_images_managed(agent, 1) and (agent, 0) the step
+ * entry points skip that launch (inside a rlrep_begin_train .. rlrep_update_target bracket the critic group's optimizer launch keeps live and
+ * target images current) and the caller runs rlrep_refresh_images after anything else wrote critic / critic_target.  images_managed returns
+ * 1 if the agent keeps images, 0 if there is nothing to manage. */
+int32_t rlrep_images_managed(rlrep_agent* agent, int32_t on);
+int32_t rlrep_refresh_images(rlrep_agent* agent, void* stream);
+
 int32_t rlrep_stage_count(rlrep_agent* agent, int32_t program);
 const char* rlrep_stage_name(rlrep_agent* agent, int32_t program, int32_t stage);
 int32_t rlrep_run_stage(rlrep_agent* agent, int32_t program, int32_t stage, void* stream);
+/* What a stage launches (bench.py groups the stages of a train() into kernel families with it, and prices them): the kernel family
+ * (RLREP_ENGINE_*), the ALGORITHMIC flops of its products (2 * rows * columns * inner length per product; 0 for non-GEMM stages) and the
+ * algorithmic bytes (every operand and result of a product once, 4 bytes per element; optimizer stages: 28 bytes per parameter + 12 per
+ * Polyak-averaged target element).  No reference counterpart (the reference has no kernels of its own). */
+#define RLREP_ENGINE_OTHER 0        /* elementwise / loss / gather / copy kernels */
+#define RLREP_ENGINE_GEMM16 1       /* gemm16_kernel / gemm16_duo_kernel: the 16-row fp32-MFMA tile engine */
+#define RLREP_ENGINE_HEADS_VAE 2    /* heads_vae_kernel (vlsac: both Gaussian heads + sample / KL on a 16 x 16 tile) */
+#define RLREP_ENGINE_LDS64 3        /* gemm_lds_kernel<64,...> (+ its split-K finishing blocks) */
+#define RLREP_ENGINE_LDS128 4       /* gemm_lds_kernel<128,...> on fp32 MFMA */
+#define RLREP_ENGINE_X3 5           /* gemm_x3_kernel: the 128-wide tile on the bf16 pipe, exact three-way split */
+#define RLREP_ENGINE_NOISE_CRITIC 6 /* nc_fwd / nc_dx / nc_dw kernels (vlsac noise critic, bf16x3) */
+#define RLREP_ENGINE_OPTIMIZER 7    /* adam_kernel (Adam + Polyak + metric finalisation + riders) */
+#define RLREP_ENGINE_SCORE 8        /* diffsr score kernels (HBM-bound pass over [B, F*S]) */
+int32_t rlrep_stage_info(rlrep_agent* agent, int32_t program, int32_t stage, int32_t* engine, double* flops, double* bytes);
 
 /* Unit-test hook: ONE product on the path's GEMM engines with caller buffers (tests/test_gemm_engines.py checks both
  * engines against NumPy on every operand layout, epilogue, ragged edge and split-K plan).
@@ -332,9 +354,8 @@ int32_t rlrep_run_stage(rlrep_agent* agent, int32_t program, int32_t stage, void
  *        3 dW:      acc, flags & 1: C += ..., flags & 2: out2[r] = sum_k opA(r,k) (bias gradient)
  *   engine: 0 = 16-row tile engine (gemm16), 1 = LDS-tiled engine (gemm_lds), 2 = its 128-wide tile on the bf16 pipe
  *   (bf16x3: three-way operand split, six MFMAs, fp32 accuracy); bt (0 auto, 64, 128) and splits
- *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats) and, behind them, one arrival
- *   counter per 64 x 64 output tile: with room for those the tile that stores the last split combines the slabs itself (flags & 8:
- *   the separate finishing launch of rounds 1-2 instead).
+ *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats), which a finishing launch adds
+ *   in split order.
  * Returns 0, or RLREP_ERR_ARG when the engine cannot run the shape (alignment rules in gemm_lds.hip). */
 int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, int32_t lda, const float* b_dev, int32_t ldb,
                    float* c_dev, int32_t ldc, int32_t rows, int32_t cols, int32_t inner, int32_t epi, int32_t act, int32_t flags,

@@ -118,9 +118,12 @@ def _load():
         'rlrep_end_train': (i32, [vp]),
         'rlrep_sync_frozen': (i32, [vp, vp]),
         'rlrep_actor_forward': (i32, [vp, vp, i32, vp, f32, f32, vp, vp]),
+        'rlrep_images_managed': (i32, [vp, i32]),
+        'rlrep_refresh_images': (i32, [vp, vp]),
         'rlrep_stage_count': (i32, [vp, i32]),
         'rlrep_stage_name': (C.c_char_p, [vp, i32, i32]),
         'rlrep_run_stage': (i32, [vp, i32, i32, vp]),
+        'rlrep_stage_info': (i32, [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         'rlrep_gemm': (i32, [i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, i64, vp]),
         'rlrep_gemm_plan': (i32, [i32] * 8 + [P(i32)] * 5),
         'rlrep_nc_fwd_plan': (i32, [i32] * 4 + [P(i32)] * 3),

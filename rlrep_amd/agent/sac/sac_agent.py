@@ -225,6 +225,11 @@ class SACAgent(object):
         self._pipe = None
         self._pending = False
         self.core.before_read = self.flush
+        # weight images of the noise critic (vlsac): captured single-GPU train() graphs leave their upkeep to the optimizer launches and to
+        # _sync_images() (one launch less per train(): DESIGN.md 5.5)
+        self._img_on = False               # some captured graph relies on managed images
+        self._img_dirty = True
+        self._img_seen = None
 
     # parameter initialisation (values only; layout is the library's)
     def _orth(self, name, gain=1.0):
@@ -300,10 +305,12 @@ class SACAgent(object):
 
     def update_target(self):
         self.flush()
+        self._img_dirty = True
         self.core.update_target()
 
     def critic_step(self, batch, eps=None):
         self.flush()
+        self._img_dirty = True
         self._set_batch(batch)
         self.core.critic_step(self._noise('crit', (self._B, self.action_dim)) if eps is None else eps)
         return self.core.info(self.CRITIC_KEYS)
@@ -370,6 +377,7 @@ class SACAgent(object):
         c.device_state().copy_(snap['device_state'])   # the device records come back with the checkpoint's step counters only
         c.group_cfg()[:, 1:6].copy_(hyper)
         self.steps, self._ctr, self._seed = snap['steps'], snap['noise_ctr'], snap['seed']
+        self._img_dirty = True
         self._graph = None
         self._pipe, self._pending = None, False
         torch.cuda.synchronize()
@@ -593,6 +601,28 @@ class SACAgent(object):
     def _critic_trains(self):
         return True
 
+    @contextlib.contextmanager
+    def _managed_images(self):
+        """Around the capture of a single-GPU train() graph: the critic steps recorded inside do not carry the image-refresh launch."""
+        on = self.core.images_managed(True)
+        self._img_on = self._img_on or on
+        try:
+            yield
+        finally:
+            self.core.images_managed(False)
+
+    def _sync_images(self):
+        """Before replaying graphs that were captured with managed images: if anything but such a graph may have written critic /
+        critic_target since the images were last known to be current -- an eager step method, a checkpoint load, any torch write into the
+        arenas (version counters) -- regenerate them now (one eager launch; never in the steady state of a train() loop)."""
+        if not self._img_on:
+            return
+        v = self.core.arena_versions()
+        if self._img_dirty or v != self._img_seen:
+            self.flush()
+            self.core.refresh_images()
+            self._img_dirty, self._img_seen = False, v
+
     def _history_info(self):
         """The info dict of a whole-train() graph replay: record n of the library's metric history ring, fetched when read.  Reading it
         counts as LOOKING at the critic / actor for the adaptive choice of the train() form (a caller who reads every dict and never calls
@@ -628,6 +658,7 @@ class SACAgent(object):
         self.steps += 1
         self.flush()
         buffer.flush()
+        self._img_dirty = True
         self._inject = dict(idx=list(idx), eps=list(eps))
         try:
             self._body(buffer, batch_size, False)
@@ -638,6 +669,7 @@ class SACAgent(object):
     def _train_eager(self, buffer, B):
         self.flush()
         buffer.flush()
+        self._img_dirty = True
         self._body(buffer, B, False)
         return self.core.info()
 
@@ -664,7 +696,7 @@ class SACAgent(object):
                     # every rank builds its graph at the same train() call, so this is a matched collective
                     dist.all_reduce(torch.zeros(1, device=self.core.device))
                     torch.cuda.synchronize()
-                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')      # see _train_graph
+                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0'      # see _train_graph
                 self.core.history(self._hist)
                 try:
                     with torch.cuda.stream(s):
@@ -738,11 +770,8 @@ class SACAgent(object):
         (train t-nset) must have finished.  Waited for on the HOST: a wait packet in the feature stream costs ~12 us of its critical path
         (2 816 -> 2 917 train()/s); the host then runs at most nset calls ahead of the device.  With nset = 2 that wait ends about one
         graph-launch latency before the running feature chain does and the feature queue idles between calls; the third set
-        (RLREP_DEFER_SETS, default 3) removes it.  RLREP_HOST_REUSE_WAIT=0: stream wait."""
-        if os.environ.get('RLREP_HOST_REUSE_WAIT', '1') != '0':
-            P['ev_ca'][k].synchronize()
-        else:
-            s_f.wait_event(P['ev_ca'][k])
+        (RLREP_DEFER_SETS, default 3) removes it."""
+        P['ev_ca'][k].synchronize()
 
     def _order_buffer_writes(self):
         """ReplayBuffer hook: the caller's stream is about to overwrite ring rows / the size scalar that the feature chain of the
@@ -756,7 +785,7 @@ class SACAgent(object):
     def _train_graph_pipelined(self, buffer, B):
         self._hook_buffer(buffer)
         P0 = self._pipe
-        if P0 is not None and P0.get('mode') == 2 and self._pending == 2 and os.environ.get('RLREP_RING_WRITES_ON_CALLER') != '1':
+        if P0 is not None and P0.get('mode') == 2 and self._pending == 2:
             # rows staged by add() since the last call and the size scalar are written ON THE FEATURE STREAM: behind the chain that may
             # still be sampling from the ring, in front of the one this call launches -- ordered by the stream, no cross-stream wait.  (On the
             # caller's stream the write had to wait for the chain in flight: a barrier packet parked in the caller's queue for most of every
@@ -774,7 +803,7 @@ class SACAgent(object):
         key = self._graph_cache_key(buffer, B)
         c = self.core
         if self._pipe is None or self._pipe['key'] != key:
-            with _no_gc():          # (a cyclic-GC pass inside a capture may run destructors that touch the device: see _no_gc)
+            with _no_gc(), self._managed_images():          # (a cyclic-GC pass inside a capture may run destructors that touch the device: see _no_gc)
                 self.flush()
                 self._sample_into(buffer, B, 'warm', 0, False)      # sizes the library's tables for B outside any capture
                 idx_keys, eps_specs = self._plan(B)
@@ -838,6 +867,7 @@ class SACAgent(object):
                              ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
                 self._pipe = P
         P = self._pipe
+        self._sync_images()
         if P['mode'] == 1:
             (P['steady'] if self._pending else P['first']).replay()
             self._pending = True
@@ -930,7 +960,7 @@ class SACAgent(object):
                 # captured collectives: a call is 2 + 2 graph launches, the host has time to wait for the set's last reader itself (no wait parked
                 # in the feature queue) and three snapshot sets keep it a call ahead; segments around eager collectives: 14 items
                 # per call, two sets and a stream wait as before
-                nset = 3 if (self._seg_capture_colls and c.defer_supported() >= 3 and os.environ.get('RLREP_DP_PIPE_SETS', '3') == '3') else 2
+                nset = 3 if (self._seg_capture_colls and c.defer_supported() >= 3) else 2
                 with torch.cuda.stream(cap):
                     for k in range(nset):
                         def feature_chain(k=k):
@@ -1019,17 +1049,12 @@ class SACAgent(object):
         if self._pending == 2:                         # two-stream forms: the pair is already in flight on its own streams
             self._pending = False
             P = self._pipe
-            if os.environ.get('RLREP_FLUSH_STREAM_WAIT') == '1':
-                cur = torch.cuda.current_stream()
-                cur.wait_stream(P['s_ca'])
-                cur.wait_stream(P['s_f'])
-            else:
-                # Waited for on the HOST (every caller of flush() is about to read results anyway).  A stream-level wait here -- a barrier
-                # packet parked in the caller's hardware queue until both chains are done -- slows the launches still queued on the two
-                # chains' queues by ~12 % for as long as it is parked (tools/exp/window_stamps.py: the last two feature chains of a window
-                # 283 -> 315-335 us, the last critic / actor chain 193 -> 227 us; the same effect that made the set-reuse wait a host wait).
-                # The critic / actor chain of the last call is the last thing in flight: its feature chain ended before it started.
-                P['ev_ca'][(P['t'] - 1) % P['nset']].synchronize()
+            # Waited for on the HOST (every caller of flush() is about to read results anyway).  A stream-level wait here -- a barrier
+            # packet parked in the caller's hardware queue until both chains are done -- slows the launches still queued on the two
+            # chains' queues by ~12 % for as long as it is parked (tools/exp/window_stamps.py: the last two feature chains of a window
+            # 283 -> 315-335 us, the last critic / actor chain 193 -> 227 us; the same effect that made the set-reuse wait a host wait).
+            # The critic / actor chain of the last call is the last thing in flight: its feature chain ended before it started.
+            P['ev_ca'][(P['t'] - 1) % P['nset']].synchronize()
         elif self._pending:
             self._pending = False
             self._pipe['tail'].replay()
@@ -1050,16 +1075,17 @@ class SACAgent(object):
                 n0 = _l.rlrep_launch_counter()
                 # the call's metrics are filed in the library's history ring by the last launch of the graph (rlrep_history) and fetched when the
                 # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_INFO_HISTORY=0: a clone per call.
-                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0' and not os.environ.get('RLREP_FUSE_ADAM')
+                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0'
                 self.core.history(self._hist)
                 try:
-                    with torch.cuda.graph(g, stream=s):
+                    with self._managed_images(), torch.cuda.graph(g, stream=s):
                         self._body(buffer, B, True)
                 finally:
                     self.core.history(False)
                 self._graph, self._graph_key = g, key
                 self._graph_launches = _l.rlrep_launch_counter() - n0
                 self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
+        self._sync_images()
         self._graph.replay()
         if self._hist:
             return self._history_info()

@@ -305,6 +305,23 @@ class HipCore:
     def end_train(self):
         check(lib.rlrep_end_train(self.h), 'end_train')
 
+    # ---- weight images of the vlsac noise critic (include/rlrep.h rlrep_images_managed) -----------------------------------------
+    def images_managed(self, on):
+        """While on, the step entry points do not launch the image refresh at the head of a critic step (captured train() graphs then
+        carry one launch less; the caller refreshes after foreign writes).  True if this agent keeps images at all."""
+        rc = lib.rlrep_images_managed(self.h, 1 if on else 0)
+        if rc < 0:
+            check(rc, 'images_managed')
+        return rc == 1
+
+    def refresh_images(self):
+        check(lib.rlrep_refresh_images(self.h, _stream()), 'refresh_images')
+
+    def arena_versions(self):
+        """torch's in-place version counters of the parameter / target arenas: every torch write through ANY view of them (load_state_dict,
+        `.data.copy_`, an optimizer of the caller's) bumps one; the library's own kernels, which write through raw pointers, do not."""
+        return (self.params._version, self.targets._version)
+
     def sync_frozen(self):
         check(lib.rlrep_sync_frozen(self.h, _stream()), 'sync_frozen')
 
@@ -379,8 +396,8 @@ class HipCore:
         dict takes its record.  The agent calls this every capacity / 2 replays, so a dict a caller keeps (per-episode / per-epoch logging)
         stays valid forever, like the reference's plain floats -- at the price of one device synchronisation per 512 train() calls, and
         only while unread dicts are alive."""
-        live = [li for li in list(getattr(self, '_hist_unread', ())) if not li._done]
-        self._hist_unread = weakref.WeakSet()
+        live = [li for li in (r() for r in getattr(self, '_hist_unread', ())) if li is not None and not li._done]
+        self._hist_unread = []
         if not live:
             return
         host = self._history_views()[0].cpu()
@@ -393,8 +410,8 @@ class HipCore:
         li = LazyInfo(names, snap, early, after=self.chain_check, on_read=on_read)
         if getattr(lazy_source, 'history_record', None) is not None:
             if not hasattr(self, '_hist_unread'):
-                self._hist_unread = weakref.WeakSet()
-            self._hist_unread.add(li)
+                self._hist_unread = []
+            self._hist_unread.append(weakref.ref(li))        # (a dict subclass is unhashable: no WeakSet)
         return li
 
     def stages(self, program):

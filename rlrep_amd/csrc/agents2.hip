@@ -255,11 +255,6 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dx(GZM, F, B, F, Pw("mu.l3.weight"), Hm, GM2, Hm, Hm, ACT_ELU, M2, Hm)}, "l3 dx");
         b.dx_stage(p, {Builder::dx(pf.G2, Hp, B, Hp, Pw("phi.l2.weight"), Hp, pf.G1, Hp, Hp, ACT_ELU, pf.P1, Hp),
                        Builder::dx(GM2, Hm, B, Hm, Pw("mu.l2.weight"), Hm, GM1, Hm, Hm, ACT_ELU, M1, Hm)}, "l2 dx");
-        {
-            const LT& q0 = ag->L.get("phi.l1.weight");
-            const LT& ql = ag->L.get("phi.l3.bias");
-            if (!(ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET)) b.set_polyak(Tw("phi_target.l1.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
-        }
         b.dw_stage(p, {Builder::dw(pf.GZ, F, F, pf.P2, Hp, Hp, B, Gw("phi.l3.weight"), Hp, Gw("phi.l3.bias")),
                        Builder::dw(GZM, F, F, M2, Hm, Hm, B, Gw("mu.l3.weight"), Hm, Gw("mu.l3.bias")),
                        Builder::dw(pf.G2, Hp, Hp, pf.P1, Hp, Hp, B, Gw("phi.l2.weight"), Hp, Gw("phi.l2.bias")),
@@ -267,7 +262,6 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(pf.G1, Hp, Hp, s0.XF, SA, SA, B, Gw("phi.l1.weight"), SA, Gw("phi.l1.bias")),
                        Builder::dw(GM1, Hm, Hm, s2, KE, S, B, Gw("mu.l1.weight"), S, Gw("mu.l1.bias")),
                        Builder::dw(DRH, 1, 1, pf.Z, F, F, B, Gw("theta.l.weight"), F, Gw("theta.l.bias"))}, "feature dW");
-        b.clear_polyak();
         const LT& p0 = ag->L.get("phi.l1.weight");
         const LT& pl = ag->L.get("phi.l3.bias");
         float* m = ag->metrics;
@@ -537,11 +531,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
             for (int l = 0; l <= phi.depth; ++l) t.push_back(mlp_dw(ag, phi, pf, l, X2, SA));
             for (int l = 0; l <= mu.depth; ++l) t.push_back(mlp_dw(ag, mu, mf, l, S2, KE));
             t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
-            const LT& q0 = ag->L.get(phi.name(0) + ".weight");
-            const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
-            if (!(ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET)) b.set_polyak(ag->T("phi_target.trunk.0.weight"), q0.off, ql.off + ql.rows - q0.off, ag->h.feature_tau);
             b.dw_stage(p, t, "feature dW");
-            b.clear_polyak();
         }
         const LT& p0 = ag->L.get(phi.name(0) + ".weight");
         const LT& pl = ag->L.get(phi.name(phi.depth) + ".bias");
@@ -595,6 +585,7 @@ void build_diffsrsac(Builder& b, rlrep_agent* ag) {
         ds.U = nf.act[nm.depth]; ds.PHI = pf.act[phi.depth]; ds.TGT = TGT; ds.alphabars = alphabars; ds.GPHI = pf.g[phi.depth]; ds.partial = part_f;
         ds.B = B; ds.F = F; ds.S = S; ds.sigma = ag->h.sigma_scale; ds.inv_batch = ag->inv_batch();
         p.stages.push_back({[=](hipStream_t st) { DiffsrScore q = ds; q.idx = ag->cur_idx; return rl_launch_diffsr_score(&q, st); }, "score matching loss"});
+        Builder::tag(p, RLREP_ENGINE_SCORE, 4.0 * (double)B * (double)F * (double)S, 8.0 * (double)B * (double)F * (double)S);      // U once in, dU once out
         // Data parallel: the nabla-mu HEAD holds 99 % of the feature gradients (F*S x H: 197 MB at Humanoid dims) and its weight gradient needs
         // only dU (just written) and the last hidden activation -- so it is taken FIRST, and exchange 3 tells the caller that the slice
         // [head.weight .. end of group 3] of the gradient arena is complete: its all-reduce can travel while the head's dX (202 GFLOP), the

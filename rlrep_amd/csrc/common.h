@@ -76,7 +76,7 @@ struct GemmTask {
     // ---- the epilogue's operand SLOTS, precomputed on the host (rl_gemm16_plan) ---------------------------
     // The epilogue kind only selects up to five slot descriptors -- base, row stride, column stride (1, or 0 if bit q of scs0 is set),
     // offset, column window [slo, shi) -- and the kernel's operand loads are generic.  Deriving them in the kernel cost every tile a
-    // ladder of scalar branches with a dependent scalar-load round trip per case (x0, ldx0, aux3, F, ad_p ...: ~1 800 cycles between
+    // ladder of scalar branches with a dependent scalar-load round trip per case (x0, ldx0, aux3, F ...: ~1 800 cycles between
     // "workgroup starts" and "first operand load issued"); as part of the record they arrive with the hot block in one burst.
     // spx2: bit q set = slot q's base is x2, which a launch whose table lives in device memory patches per call (FLAG_DYN_EPS*).
     const float* sp[5]; int srs[5], sof[5], slo[5], shi[5]; int scs0, spx2;
@@ -86,11 +86,6 @@ struct GemmTask {
     int ldaux2, ldaux3;
     int ncN;             // noise rows (20) for LD_NCG/LD_NCX
     int F;               // EPI_DX_REPARAM: column offset of the log-std half
-    // EPI_DW with the optimizer fused in (single-GPU path): Adam on the tile's own weights (and bias), plus
-    // Polyak into the target copy.  All pointers are bases of tensors laid out like C / out2.
-    float* ad_p; float* ad_m; float* ad_v; float* ad_t;          // weight: param, exp_avg, exp_avg_sq, target (or null)
-    float* ad_pb; float* ad_mb; float* ad_vb; float* ad_tb;      // bias
-    const GroupCfg* ad_grp;
     // generic operands of the fused loss / policy epilogues
     const float* x0; const float* x1; const float* x2; float* y0; float* y1; const double* dptr;
     int ldx0, ldx1; float s0, s1;
@@ -98,9 +93,6 @@ struct GemmTask {
     // bslab [splits][R]; the finishing launch adds them in split order) -- zero for gemm16 launches
     int splits, kchunk, fin_base;
     float* slab; float* bslab;
-    // arrival counters, one per output tile (tickets != nullptr): the workgroup that stores the LAST split of a tile adds the slabs in split
-    // order and runs the epilogue inside the tile kernel -- no finishing launch (gemm_lds.hip)
-    int* tickets;
 };
 
 // host side: fill the slots of a finished task record (every launcher of the 16-row tile engine calls it on its copy of the record)
@@ -135,21 +127,15 @@ static inline void rl_gemm16_plan(GemmTask& t) {
         break;
     default:   // EPI_DW
         if (t.flags & FLAG_ACCUM) { t.sp[1] = t.C; t.srs[1] = t.ldc; }
-        if (t.ad_p) {      // optimizer fused in: the tile of the parameter, its Adam moments (and its Polyak target)
-            t.sp[0] = t.ad_p; t.sp[2] = t.ad_m; t.sp[3] = t.ad_v; t.sp[4] = t.ad_t;
-            t.srs[0] = t.srs[2] = t.srs[3] = t.srs[4] = t.ldc;
-        }
     }
 }
 
 #define GEMM_MAX_TASKS 8
-struct FinTask;
-// passed by value (kernarg segment).  nfin > 0: the launch has one extra trailing workgroup that runs the step's metric
-// finalisation / temperature update (the optimizer itself then runs in the EPI_DW epilogues: GemmTask::ad_*)
+// passed by value (kernarg segment).
 // tb / tcs: first tile and column tiles of each task, copied next to the header by the launcher so that a workgroup finds its task and its
 // tile coordinates from ONE burst of scalar loads (then the task record with a second one), instead of a round trip per dependent field
-// total: tiles of the launch (the trailing finalisation workgroup, if any, is block `total`; reading gridDim costs a round trip of its own)
-struct GemmBatch { int ntasks; int nfin; const FinTask* fin; int low_prio; int total; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
+// total: tiles of the launch
+struct GemmBatch { int ntasks; int low_prio; int total; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)
@@ -172,6 +158,12 @@ struct AdamTask {
     float* target; long long pol_off, pol_n; float tau;
     const int* pol_steps; int pol_period;     // if pol_steps != nullptr: Polyak only when *pol_steps % pol_period == 0
     const ShadowEnt* sh; int nsh;             // transposed shadows of this group's weight matrices, kept current by this launch (or null)
+    // Gradients that arrive as split-K PARTIALS (the vlsac noise critic's dW on bf16x3: noisecritic.hip nc_dw_x3_kernel): for elements
+    // [off, off + n) of the group the gradient is the sum, in split order, of slab[(q * splits + sp) * per + r] (q = l / per, r = l % per,
+    // l = element - off) -- the finishing launch those partials used to need rides here, and the sum is filed in the gradient arena too.
+    // per % 4 == 0, off % 4 == 0, 16-byte aligned slabs (the builder only folds then).  nslab = 0: plain gradients.
+    struct Slab { long long off, n, per; const float* slab; int splits, pad; } slabs[2];
+    int nslab, pad_;
 };
 
 struct PolyakTask {

@@ -434,6 +434,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const
     asm volatile("" ::: "memory");      // (pin: the loads above stay ahead of the reads of the record below)
     const int ti = 0;
     const bool pol_on = atarget && (!t.pol_steps || ((*t.pol_steps) % t.pol_period) == 0);
+    if (vec && t.nslab) {
+        // split-K partial gradients finished here (AdamTask::Slab): all partials in flight together, summed in split order (the order of
+        // the finishing launch this replaces: bit-identical), the sum filed in the gradient arena for whoever reads gradients
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q >= t.nslab || i < t.slabs[q].off || i >= t.slabs[q].off + t.slabs[q].n) continue;
+            const long long l = i - t.slabs[q].off, task = l / t.slabs[q].per, r = l - task * t.slabs[q].per;
+            const float* s0 = t.slabs[q].slab + (size_t)task * t.slabs[q].splits * t.slabs[q].per + r;
+            f32x4 part[16];
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp) part[sp] = *reinterpret_cast<const f32x4*>(s0 + (size_t)min(sp, t.slabs[q].splits - 1) * t.slabs[q].per);
+            g = part[0];
+#pragma unroll
+            for (int sp = 1; sp < 16; ++sp) if (sp < t.slabs[q].splits) g += part[sp];
+            *reinterpret_cast<f32x4*>(const_cast<float*>(agr) + i) = g;
+        }
+    }
     if (vec) {
         const bool pol = pol_on && i >= t.pol_off && i < t.pol_off + t.pol_n;
         f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
@@ -595,6 +612,8 @@ extern "C" int rl_launch_adam(const AdamTask* task, int adam_blocks, const FinTa
     const int sb = (snap && snap->on && snap->segs.n > 0) ? grid_for(snap->segs.end[snap->segs.n - 1], 256, 256) : 0;
     const bool vec_ok = ((t.pol_off & 3) == 0) && ((t.pol_n & 3) == 0) &&
                         (((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v) | ((uintptr_t)t.target)) & 15) == 0);
+    if (t.nslab > 0 && (!vec_ok || (t.n & 3))) return -6;          // (the builder folds split-K partials in only for groups on the 16-byte path)
+    for (int q = 0; q < t.nslab; ++q) if (t.slabs[q].splits < 1 || t.slabs[q].splits > 16) return -6;
     const int hdr = adam_blocks | (vec_ok ? (1 << 30) : 0);
     hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, t,
                        fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb);

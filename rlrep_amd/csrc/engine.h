@@ -27,7 +27,7 @@ int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t 
 int rl_launch_nc_dx(const NcDxTask* t, hipStream_t st);
 int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t st);
 int rl_nc_init();
-int rl_nc_dw_engine(int fused_optimizer);
+int rl_nc_dw_engine();
 int rl_nc_dw_splits(int B, int F, int H, int ntasks);
 int rl_nc_fwd_cols();
 void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols);
@@ -131,7 +131,9 @@ struct Workspace {
 // ------------------------------------------------------------------------------------------------
 // process-wide count of kernel launches issued by the library (rlrep_launch_counter: bench.py counts the launches a captured train() holds)
 extern long long g_rl_launches;
-struct Stage { std::function<int(hipStream_t)> run; const char* what; };
+// engine / flops / bytes: what rlrep_stage_info reports (include/rlrep.h RLREP_ENGINE_*: which kernel family the stage launches, the
+// ALGORITHMIC flops (2 * MAC) of its products and the bytes of their operands and results, each counted once)
+struct Stage { std::function<int(hipStream_t)> run; const char* what; int engine = 0; double flops = 0.0, bytes = 0.0; };
 
 struct Program {
     std::vector<Stage> stages;

@@ -304,7 +304,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     const int SA = S + A, KE = 2 * S + A;
     Slot& s0 = ag->slot[0];
     Workspace& ws = b.ws;
-    b.allow_fuse = true;       // every parameter tensor of the three groups gets exactly one weight-gradient task below
     // use_feature_target=False (vlsac_agent.py:176-179, 214-219, 257-258): critic and actor steps read the LIVE f, no Polyak into f_target
     const bool nft = (ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET) != 0;
     const std::string fnet = nft ? "f" : "f_target";
@@ -322,11 +321,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     float* GEH = ws.f((size_t)B * 2 * F); float* GFH = ws.f((size_t)B * 2 * F);
     float* GH2e = ws.f((size_t)B * Hv); float* GH1e = ws.f((size_t)B * Hv);
     float* GH2f = ws.f((size_t)B * Hv); float* GH1f = ws.f((size_t)B * Hv);
-    // the Gaussian heads of encoder and f and vae_mid as ONE launch (heads_vae_kernel: a 16 x 16 tile per workgroup, one KL partial each);
-    // RLREP_FUSE_VAEMID=0 keeps the heads launch + vae_mid_kernel (256 elements and one partial per block)
-    const bool fuse_vm = !(getenv("RLREP_FUSE_VAEMID") && getenv("RLREP_FUSE_VAEMID")[0] == '0');
+    // the Gaussian heads of encoder and f and vae_mid as ONE launch (heads_vae_kernel: a 16 x 16 tile per workgroup, one KL partial each;
+    // +3 % against the heads launch + an elementwise vae_mid launch, which is gone)
     const int tiles_vm = ((B + 15) / 16) * ((F + 15) / 16);
-    const int nblk_kl = fuse_vm ? tiles_vm : (int)(((long long)B * F + 255) / 256), nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
+    const int nblk_kl = tiles_vm, nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
     float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse);
     // actor buffers are needed by the feature program variant that carries the policy forwards
     ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
@@ -574,9 +572,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         } else if (early) {
             b.fwd_stage(p, {te[0], tf[0], actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "enc.l1 f.l1 actor.l1(s') actor.l1(s)");
             b.fwd_stage(p, {te[1], tf[1], actor_l(ag, 1, nullptr, 0, ab), actor_l(ag, 1, nullptr, 0, ab_pi)}, "enc.l2 f.l2 actor.l2 x2");
-            if (!fuse_vm)
-                b.fwd_stage(p, {te[2], tf[2], policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
-                            "enc.heads f.heads actor.head x2 + policy");
         } else {
             // the first layers ride in the second layers' launch when their transposed shadows exist (one launch less per feature step)
             const bool have_t = ag->shadow_of.count("encoder.l1.weight") && ag->shadow_of.count("f.l1.weight");
@@ -584,25 +579,17 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                 b.fwd_stage(p, {te[0], tf[0]}, "enc.l1 f.l1");
                 b.fwd_stage(p, {te[1], tf[1]}, "enc.l2 f.l2");
             }
-            if (!fuse_vm) b.fwd_stage(p, {te[2], tf[2]}, "enc.heads f.heads");
         }
         if (!use_rp) {
-        if (fuse_vm) {
+        {
             HeadsVae hv; memset(&hv, 0, sizeof(hv));
             hv.Ae = ge.H2; hv.Af = gf.H2; hv.lda = Hv; hv.We = Pw("encoder.mean_linear.weight"); hv.be = Pw("encoder.mean_linear.bias");
             hv.Wf = Pw("f.mean_linear.weight"); hv.bf = Pw("f.mean_linear.bias");
             hv.Z = Z; hv.EZ = EZ; hv.GEH = GEH; hv.GFH = GFH; hv.partial = part_kl; hv.EH = nullptr; hv.FH = nullptr;       // (nothing downstream of vae_mid reads the heads themselves)
             hv.B = B; hv.F = F; hv.K = Hv; hv.tiles_c = (F + 15) / 16; hv.scale = ag->inv_batch() / (float)F; hv.step = ag->adam_step + 0;
             b.heads_vae_stage(p, hv, "enc.heads f.heads + vae_mid");
-        } else {
-        b.chain_flush();
-        VaeMid vm; memset(&vm, 0, sizeof(vm));
-        vm.EH = ge.HH; vm.FH = gf.HH; vm.Z = Z; vm.GEH = GEH; vm.GFH = GFH; vm.partial = part_kl;
-        vm.B = B; vm.F = F; vm.nblk = nblk_kl; vm.scale = ag->inv_batch() / (float)F; vm.step = ag->adam_step + 0;
-        vm.EZ = EZ;
-        p.stages.push_back({[=](hipStream_t st) { VaeMid q = vm; q.eps = ag->cur_eps; return rl_launch_vae_mid(&q, st); }, "vae_mid"});
         }
-        if (early && fuse_vm)       // the two policy heads of the early variant ride with the next forward launch instead of the heads launch
+        if (early)                  // the two policy heads of the early variant ride with the next forward launch instead of the heads launch
             b.fwd_stage(p, {Builder::fwd(Z, F, B, F, Pw("decoder.l1.weight"), F, Pw("decoder.l1.bias"), Hv, D1, Hv, ACT_RELU),
                             policy_head_task(ag, ab, s0.XF2 + S, SA, FLAG_DYN_EPS3), policy_head_task(ag, ab_pi, s0.XFpi + S, SA, FLAG_DYN_EPS2)},
                         "dec.l1 actor.head x2 + policy");
@@ -629,17 +616,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dx(GH2f, Hv, B, Hv, Pw("f.l2.weight"), Hv, GH1f, Hv, Hv, ACT_RELU, gf.H1, Hv)}, "l2 dx");
         }
         b.chain_end();
-        {
-            const LT& f0 = ag->L.get("f.l1.weight");
-            const LT& fl = ag->L.get("f.log_std_linear.bias");
-            if (!nft) b.set_polyak(Tw("f_target.l1.weight"), f0.off, fl.off + fl.rows - f0.off, ag->h.feature_tau);
-        }
-        b.stash_fin({
-            Builder::fin_sum(use_rp ? part_kl_rp : part_kl, use_rp ? nblk_rp * (use_cluster ? CS : 1) : nblk_kl, 1, 1.0f / ((float)B * F), ag->metrics + M_KL),
-            Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 0, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / ((float)B * S), ag->metrics + M_S_LOSS),
-            Builder::fin_sum((use_rp ? part_mse_rp : part_mse) + 1, use_rp ? nblk_rp : nblk_mse, 2, 0.5f / (float)B, ag->metrics + M_R_LOSS),
-            Builder::fin_combine(ag->metrics + M_R_LOSS, 1.f, ag->metrics + M_S_LOSS, 1.f, ag->metrics + M_FEAT_A),
-            Builder::fin_combine(ag->metrics + M_FEAT_A, 1.f, ag->metrics + M_KL, 1.f, ag->metrics + M_FEAT_TOTAL)});
         b.dw_stage(p, {Builder::dw(GDH, S + 1, S + 1, D1, Hv, Hv, B, Gw("decoder.state_linear.weight"), Hv, Gw("decoder.state_linear.bias")),
                        Builder::dw(GD1, Hv, Hv, Z, F, F, B, Gw("decoder.l1.weight"), F, Gw("decoder.l1.bias")),
                        Builder::dw(GEH, 2 * F, 2 * F, ge.H2, Hv, Hv, B, Gw("encoder.mean_linear.weight"), Hv, Gw("encoder.mean_linear.bias")),
@@ -648,7 +624,6 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(GH2f, Hv, Hv, gf.H1, Hv, Hv, B, Gw("f.l2.weight"), Hv, Gw("f.l2.bias")),
                        Builder::dw(GH1e, Hv, Hv, s0.XE, KE, KE, B, Gw("encoder.l1.weight"), KE, Gw("encoder.l1.bias")),
                        Builder::dw(GH1f, Hv, Hv, s0.XF, SA, SA, B, Gw("f.l1.weight"), SA, Gw("f.l1.bias"))}, "feature dW");
-        b.clear_polyak();
     };
     feature_program(ag->feat_bwd, false);
     const bool can_hoist = policy_fusable(ag) && !getenv("RLREP_NO_HOIST");
@@ -711,6 +686,11 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         }
         const int total = base_tile;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_fwd(&nb, total, g2, st); }, what});
+        {   // per head: [B*N, F] x [F, H]; reads mean / log_std / W, writes the noise-row mean (and U where the head keeps it)
+            double by = 0.0;
+            for (auto& t : tasks) by += 4.0 * (2.0 * (double)B * F + (double)F * H + (double)B * H + (t.U ? (double)B * N * H : 0.0));
+            Builder::tag(p, RLREP_ENGINE_NOISE_CRITIC, (double)tasks.size() * 2.0 * (double)B * N * F * H, by);
+        }
     };
 
     // ---- critic step (vlsac_agent.py:201-237) ----
@@ -720,6 +700,20 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     const std::vector<FinTask> cfins = {
         Builder::fin_sum(part_q + 0, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1_LOSS), Builder::fin_sum(part_q + 1, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2_LOSS),
         Builder::fin_sum(part_q + 2, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q1), Builder::fin_sum(part_q + 3, nblk, 4, 1.0f / (float)B, ag->metrics + M_Q2)};
+    // split-K slabs of the noise critic's weight gradient (bf16x3 form): ONE set for every variant of the critic program (no two of them are
+    // ever in flight together), summed by the critic group's optimizer launch when there is no all-reduce between the two (AdamTask::Slab)
+    const int ncdw_splits = rl_nc_dw_splits(B, F, H, 2);
+    float* const ncdw_slab = ws.f((size_t)2 * ncdw_splits * H * F);
+    float* const ncdw_bslab = ws.f((size_t)2 * ncdw_splits * H);
+    const bool ncdw_in_adam = rl_nc_dw_engine() == 1 && ag->h.world_size <= 1 && ((H * F) & 3) == 0 && (H & 3) == 0 && ncdw_splits <= 16 && !getenv("RLREP_NO_FOLD_NCDW");
+    if (ncdw_in_adam) {
+        const LT& w1 = ag->L.get("critic.l1.weight"); const LT& b1 = ag->L.get("critic.l1.bias");
+        AdamTask::Slab sw; memset(&sw, 0, sizeof(sw));
+        sw.off = w1.off - ag->L.group_off[1]; sw.n = 2ll * H * F; sw.per = (long long)H * F; sw.slab = ncdw_slab; sw.splits = ncdw_splits;
+        AdamTask::Slab sb = sw;
+        sb.off = b1.off - ag->L.group_off[1]; sb.n = 2ll * H; sb.per = H; sb.slab = ncdw_bslab;
+        b.group_slabs[1] = {sw, sb};
+    }
     auto critic_program = [&](Program& p, int hoist) {      // 0: plain, 1: carries the actor step's forward half, 2: both policies ran already
         GemmTask tt[3], tn[3], tp[3];
         gauss_tasks(ag, !nft, fnet, s0.XF, SA, SA, gt, tt);
@@ -768,34 +762,26 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_qhead_critic(&q, st); }, "qhead critic"});
         b.dx_stage(p, {Builder::dx(GE, H, B, H, Pw("critic.l2.weight"), H, GHm, H, H, ACT_NONE, nullptr, 0),
                        Builder::dx(GE + BH, H, B, H, Pw("critic.l5.weight"), H, GHm + BH, H, H, ACT_NONE, nullptr, 0)}, "critic l2/l5 dx");
-        b.stash_fin(cfins);
         b.dw_stage(p, {Builder::dw(dq, 1, 1, Ec, H, H, 2 * B, Gw("critic.l3.weight"), H, Gw("critic.l3.bias")),     // shared l3: heads stacked
                        Builder::dw(GE, H, H, HmC, H, H, B, Gw("critic.l2.weight"), H, Gw("critic.l2.bias")),
                        Builder::dw(GE + BH, H, H, HmC + BH, H, H, B, Gw("critic.l5.weight"), H, Gw("critic.l5.bias"))}, "critic dW l3 l2 l5");
         {
             NcDwBatch nb; memset(&nb, 0, sizeof(nb));
             nb.ntasks = 2;
-            nb.lean = ((b.low_prio || getenv("RLREP_NC_DW_LEAN")) && !getenv("RLREP_NC_DW_FULL")) ? 1 : 0;     // deferred chain: leave registers for the feature chain's launches
+            nb.lean = b.low_prio ? 1 : 0;     // deferred chain (fp32 kernel only): leave registers for the feature chain's launches
             int base_tile = 0;
             auto ncdw = [&](int q, float* Ubuf, float* GH, float* gW, float* gb) {
                 NcDwTask& t = nb.t[q];
                 t.U = Ubuf; t.GH = GH; t.ldgh = H; t.mean = gt.HH; t.sigma = SIG; t.ld_ml = 2 * F;
                 t.noise = noise; t.gW = gW; t.gb = gb; t.B = B; t.F = F; t.H = H; t.N = N;
                 t.tiles_k = (F + 31) / 32; t.ntiles = ((H + 15) / 16) * t.tiles_k; t.tile_base = base_tile; base_tile += t.ntiles;
-                if (b.fused() && gW) {
-                    const int64_t ow = gW - ag->a.grad_dev, ob = gb - ag->a.grad_dev;
-                    t.ad_p = ag->a.param_dev + ow; t.ad_m = ag->a.exp_avg_dev + ow; t.ad_v = ag->a.exp_avg_sq_dev + ow;
-                    t.ad_pb = ag->a.param_dev + ob; t.ad_mb = ag->a.exp_avg_dev + ob; t.ad_vb = ag->a.exp_avg_sq_dev + ob;
-                    t.ad_grp = ag->adam_step + 1;
-                }
             };
             ncdw(0, U, GHm, Gw("critic.l1.weight"), Gw("critic.l1.bias"));
             ncdw(1, U + BNH, GHm + BH, Gw("critic.l4.weight"), Gw("critic.l4.bias"));
             // bf16x3 split-K form: 64 x 64 tiles x splits, partial tiles in workspace slabs (reserved in the dry pass as well)
-            nb.splits = rl_nc_dw_splits(B, F, H, 2);
-            nb.slab = ws.f((size_t)2 * nb.splits * H * F);
-            nb.bslab = ws.f((size_t)2 * nb.splits * H);
-            nb.engine = rl_nc_dw_engine(b.fused() ? 1 : 0);
+            nb.splits = ncdw_splits; nb.slab = ncdw_slab; nb.bslab = ncdw_bslab;
+            nb.engine = rl_nc_dw_engine();
+            nb.fin_in_adam = ncdw_in_adam ? 1 : 0;
             if (nb.engine == 1) {
                 base_tile = 0;
                 for (int q = 0; q < 2; ++q) {
@@ -804,6 +790,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             }
             const int total = base_tile;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dw(&nb, total, st); }, "noise critic dW l1/l4"});
+            Builder::tag(p, RLREP_ENGINE_NOISE_CRITIC, 2.0 * 2.0 * (double)B * N * F * H, 2.0 * 4.0 * ((double)B * N * H + (double)B * H + 2.0 * (double)B * F + (double)F * H));
         }
     };
     critic_program(ag->critic_bwd, 0);
@@ -843,10 +830,10 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             t.B = B; t.F = F; t.H = H; t.N = N; t.nheads = 2;
             t.tiles_k = (F + 63) / 64; t.ntiles = ((B + 3) / 4) * t.tiles_k; t.tile_base = 0;
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_nc_dx(&t, st); }, "noise critic dX -> (dmean, dlog_std)"});
+            Builder::tag(p, RLREP_ENGINE_NOISE_CRITIC, 2.0 * 2.0 * (double)B * N * F * H, 4.0 * (2.0 * ((double)B * N * H + (double)B * H + (double)F * H) + 3.0 * (double)B * F));
         }
         b.dx_stage(p, {Builder::dx(GTH, 2 * F, B, 2 * F, FT("mean_linear.weight"), Hv, GT2, Hv, Hv, ACT_RELU, gp.H2, Hv)}, "ft.heads dx");
         b.dx_stage(p, {Builder::dx(GT2, Hv, B, Hv, FT("l2.weight"), Hv, GT1, Hv, Hv, ACT_RELU, gp.H1, Hv)}, "ft.l2 dx");
-        b.stash_fin(actor_fins(ag, part_l, nblk));
         actor_backward(b, p, ag, ab_pi, s0.XFpi, SA, s0.XFpi + S, SA, Builder::dx(GT1, Hv, B, Hv, FT("l1.weight") ? FT("l1.weight") + S : nullptr, SA, ab_pi.dA, A, A, ACT_NONE, nullptr, 0));
     };
     actor_program(ag->actor_bwd, ag->actor_resume);
@@ -866,7 +853,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             rlrep_agent::DeferSet& D = ag->dset[set];
             const LT& p0 = ag->L.get("f.l1.weight");
             D.block_off = p0.off - ag->L.group_off[0]; D.block_n = fl.off + fl.rows - f0.off; D.block_which = nft ? 0 : 1;
-            if (getenv("RLREP_NO_FOLD_SNAPSHOT") || ag->h.world_size > 1 || b.fused()) D.block_which = -1;
+            if (getenv("RLREP_NO_FOLD_SNAPSHOT") || ag->h.world_size > 1) D.block_which = -1;
         }
         critic_program(ag->dset[set].critic_bwd, can_hoist ? 1 : 0);
         actor_program(ag->dset[set].actor_bwd, ag->dset[set].actor_resume);
@@ -1027,13 +1014,12 @@ static void static_state(rlrep_agent* ag) {
         if (!ws.dry && ws.ok() && !tab.empty()) (void)hipMemcpy(dev, tab.data(), tab.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice);
         ag->sh_dev[0] = dev; ag->nsh[0] = (int)tab.size(); ag->sh_tiles[0] = tiles;
     }
-    // bf16x3 images of the noise critic's first layers (vlsac): see rlrep_agent::x3_refresh.  RLREP_NC_SHADOWS=0 turns them off (the
-    // kernels then split W themselves, as in round 1).
+    // bf16x3 images of the noise critic's first layers (vlsac): see rlrep_agent::x3_refresh.  (Where the shape rules them out -- F not a
+    // multiple of 32 -- the kernels split W themselves, as in round 1.)
     ag->x3_refresh = nullptr; ag->x3_n = ag->x3_tiles = 0; ag->x3_of.clear();
     {
-        const char* e = getenv("RLREP_NC_SHADOWS");
         const int F = ag->d.feature_dim, H = ag->d.hidden_dim;
-        if (ag->d.alg == RLREP_ALG_VLSAC && !(e && e[0] == '0') && F > 0 && (F % 32) == 0 && ag->L.index.count("critic.l1.weight") && ag->L.index.count("critic_target.l1.weight")) {
+        if (ag->d.alg == RLREP_ALG_VLSAC && !getenv("RLREP_NO_X3") && F > 0 && (F % 32) == 0 && ag->L.index.count("critic.l1.weight") && ag->L.index.count("critic_target.l1.weight")) {
             std::vector<ShadowEnt> all, live;
             const char* names[4] = {"critic.l1.weight", "critic.l4.weight", "critic_target.l1.weight", "critic_target.l4.weight"};
             for (int q = 0; q < 4; ++q) {
@@ -1049,6 +1035,8 @@ static void static_state(rlrep_agent* ag) {
                 if (q < 2) { ShadowEnt lv = se; lv.src = nullptr; lv.off = t.off - ag->L.group_off[1]; live.push_back(lv); }     // (the Adam launch indexes from the group's start)
                 (void)H;
             }
+            // the critic's Adam launch carries the critic -> critic_target Polyak inside a train(): its lanes then keep the TARGET images current too
+            for (size_t q = 0; q < live.size(); ++q) live[q].st = all[q + 2].sp;
             ShadowEnt* dev = (ShadowEnt*)ws.alloc(all.size() * sizeof(ShadowEnt));
             ShadowEnt* dev_live = (ShadowEnt*)ws.alloc(live.size() * sizeof(ShadowEnt));
             if (!ws.dry && ws.ok()) {
@@ -1169,9 +1157,6 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
     if (rl_replearn_init() != 0) { rl_set_error("create: cannot reserve LDS for the score-matching kernel"); return RLREP_ERR_HIP; }
     int rc = build_programs(ag.get(), dims->max_batch);
     if (rc != 0) return rc;
-    if (getenv("RLREP_FUSE_ADAM") && ag->has_shadows())        // a comparison run must not measure the other path without notice
-        fprintf(stderr, "rlrep: RLREP_FUSE_ADAM is ignored for this agent: its optimizer launch keeps the bf16x3 weight images of the noise critic "
-                        "(set RLREP_NC_SHADOWS=0 as well to compare the fused-optimizer form)\n");
     *out = ag.release();
     return 0;
 }
@@ -1385,7 +1370,7 @@ int32_t rlrep_critic_backward(rlrep_agent* ag, const float* eps, void* stream) {
     ag->pi_ready = nullptr;
     // the images of critic.l1 / l4 and of their targets, from the tensors as they are now: the target copies have no other writer, and a
     // caller may have written any of them since the last step (the launch rides on the chain that has slack in the pipelined train())
-    { const int rs = refresh_x3(ag, stream); if (rs) return rs; }
+    if (!ag->images_managed) { const int rs = refresh_x3(ag, stream); if (rs) return rs; }
     if (ag->early_ready_crit && ag->early_ready_crit == eps) {      // both policy forwards already ran (last feature step)
         const float* act_eps = ag->early_ready_act;
         ag->early_ready_crit = ag->early_ready_act = nullptr; ag->hoist_req = nullptr;
@@ -1418,7 +1403,7 @@ int32_t rlrep_actor_backward(rlrep_agent* ag, const float* eps, void* stream) {
     const size_t first = (ag->pi_ready && ag->pi_ready == eps) ? (size_t)ag->actor_resume : 0;
     ag->pi_ready = nullptr;
     if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
-    if (!ag->in_train) { const int rs = refresh_x3(ag, stream); if (rs) return rs; }        // (inside a train() the critic's Adam launch kept the live images current)
+    if (!ag->in_train && !ag->images_managed) { const int rs = refresh_x3(ag, stream); if (rs) return rs; }        // (inside a train() the critic's Adam launch kept the live images current)
     ag->last_launches += (int)(ag->actor_bwd.stages.size() - first);
     return ag->actor_bwd.run((hipStream_t)stream, first);
 }
@@ -1502,7 +1487,7 @@ int32_t rlrep_deferred_part(rlrep_agent* ag, int32_t set, int32_t part, void* st
     int rc = 0;
     if (part == -1 || part == 0) {
         ag->cur_eps = e_crit; ag->cur_eps2 = e_act; ag->last_launches = 0;
-        rc = refresh_x3(ag, stream);                 // as in rlrep_critic_backward: on this, the chain with slack
+        if (!ag->images_managed) rc = refresh_x3(ag, stream);                 // as in rlrep_critic_backward
         if (!rc) rc = run(ag, D.critic_bwd, stream);
     }
     if (!rc && (part == -1 || part == 1)) rc = run(ag, D.critic_apply, stream);
@@ -1516,6 +1501,22 @@ int32_t rlrep_deferred_part(rlrep_agent* ag, int32_t set, int32_t part, void* st
     return rc;
 }
 int32_t rlrep_deferred_critic_actor(rlrep_agent* ag, int32_t set, void* stream) { return rlrep_deferred_part(ag, set, -1, stream); }
+// Weight images of the vlsac noise critic (bf16x3).  By default every critic step regenerates them from the tensors with a launch
+// of its own (a caller may have written parameters; the target copies have no other writer outside a train()).  A caller that replays
+// captured train() graphs can take that launch off the chain: between rlrep_images_managed(agent, 1) and (agent, 0) the step entry points do
+// NOT launch it -- inside a train() bracket the critic group's optimizer launch keeps the live AND (with the folded Polyak) the target images
+// current -- and the caller runs rlrep_refresh_images itself whenever anything else may have written critic / critic_target (an eager step
+// method, rlrep_update_target outside a bracket, a torch write into the arenas).  Returns 1 if the agent keeps such images (else 0: nothing to manage).
+int32_t rlrep_images_managed(rlrep_agent* ag, int32_t on) {
+    if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
+    if (!ag->x3_n || ag->critic_apply_f.stages.empty()) { ag->images_managed = false; return 0; }
+    ag->images_managed = on != 0;
+    return 1;
+}
+int32_t rlrep_refresh_images(rlrep_agent* ag, void* stream) {
+    if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
+    return refresh_x3(ag, stream);
+}
 int32_t rlrep_end_train(rlrep_agent* ag) {
     if (!ag) return RLREP_ERR_ARG;
     ag->in_train = ag->target_done = false;
@@ -1599,6 +1600,15 @@ const char* rlrep_stage_name(rlrep_agent* ag, int32_t program, int32_t stage) {
     if (!p || stage < 0 || stage >= (int)p->stages.size()) return nullptr;
     return p->stages[stage].what;
 }
+int32_t rlrep_stage_info(rlrep_agent* ag, int32_t program, int32_t stage, int32_t* engine, double* flops, double* bytes) {
+    Program* p = ag ? prog_of(ag, program) : nullptr;
+    if (!p || stage < 0 || stage >= (int)p->stages.size()) { rl_set_error("stage_info: bad program/stage"); return RLREP_ERR_ARG; }
+    const Stage& s = p->stages[stage];
+    if (engine) *engine = s.engine;
+    if (flops) *flops = s.flops;
+    if (bytes) *bytes = s.bytes;
+    return 0;
+}
 int32_t rlrep_run_stage(rlrep_agent* ag, int32_t program, int32_t stage, void* stream) {
     Program* p = ag ? prog_of(ag, program) : nullptr;
     if (!p || stage < 0 || stage >= (int)p->stages.size()) { rl_set_error("run_stage: bad program/stage"); return RLREP_ERR_ARG; }
@@ -1640,12 +1650,6 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
             if (!wsp || ws_floats < (int64_t)psp * R * (((Cn + 3) & ~3) + 1)) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
             t.slab = wsp; t.bslab = wsp + (size_t)psp * R * ((Cn + 3) & ~3); t.fin_base = 0;
             fin = (int)(((long long)R * ((Cn + 3) / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
-            // the in-kernel last-arriver combine (flags & 8: the finishing launch instead) when the workspace has room for its counters
-            const int64_t used = (int64_t)psp * R * (((Cn + 3) & ~3) + 1), ntk = (int64_t)((R + 63) / 64) * ((Cn + 63) / 64);
-            if (engine == 1 && !(flags & 8) && ws_floats >= used + ntk) {
-                t.tickets = reinterpret_cast<int*>(wsp + used);
-                if (hipMemsetAsync(t.tickets, 0, sizeof(int) * ntk, (hipStream_t)stream) != hipSuccess) { rl_set_error("gemm: cannot clear the arrival counters"); return RLREP_ERR_HIP; }
-            }
         }
         t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;

@@ -72,6 +72,7 @@ struct rlrep_agent {
     // folded snapshot (rlrep_defer_arm): the next feature optimizer launch also writes snapshot set snap_set; snap_done = the set it wrote
     bool snap_armed = false; int snap_set = -1, snap_done = -1; const float* snap_ec = nullptr; const float* snap_ea = nullptr;
     const ShadowEnt* x3_refresh = nullptr; int x3_n = 0, x3_tiles = 0;
+    bool images_managed = false;          // rlrep_images_managed: the step entry points leave the refresh launch to the caller
     std::map<std::string, const unsigned char*> x3_of;
     const unsigned char* W3(const std::string& n) const { auto it = x3_of.find(n); return it == x3_of.end() ? nullptr : it->second; }
     // cluster row programs (RLREP_ROWPROG=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
@@ -110,6 +111,18 @@ struct Builder {
     }
     Mat mat(int rows, int cols) { return Mat{ws.f((size_t)rows * cols), rows, cols, cols}; }
 
+    // what rlrep_stage_info reports for the stage pushed last: kernel family, algorithmic flops and bytes of its products
+    static void tag(Program& p, int engine, double flops, double bytes) { Stage& s = p.stages.back(); s.engine = engine; s.flops = flops; s.bytes = bytes; }
+    static void tag_gemms(Program& p, int engine, const std::vector<GemmTask>& tasks) {
+        double fl = 0.0, by = 0.0;
+        for (const GemmTask& t : tasks) {
+            fl += 2.0 * (double)t.R * (double)t.Cn * (double)t.K;
+            by += 4.0 * ((double)t.R * t.K + (double)t.Cn * t.K + (double)t.R * t.Cn);
+            if (t.flags & FLAG_PRE) { fl += 2.0 * (double)t.R * (double)t.K * (double)t.n0; by += 4.0 * ((double)t.R * t.n0 + (double)t.n0 * t.K); }    // the fused short product
+        }
+        tag(p, engine, fl, by);
+    }
+
     // ---- GEMM task constructors -------------------------------------------------------------
     static GemmTask base() { GemmTask t; memset(&t, 0, sizeof(t)); t.scale = 1.f; return t; }
     // Y[B,N] = act(X[B,K] W[N,K]^T + b)
@@ -146,22 +159,13 @@ struct Builder {
         for (auto& t : tasks) {
             int sp = 1, kc = 0, fl = 0;
             // dimensions decide the engine and the slab reservation (identical in the dry and the real pass) ...
-            if (!fused() && rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl)) {
+            if (rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl)) {
                 // (the bias-gradient flag depends on a pointer that is null in the dry pass: reserve for every dW task)
                 float* slab = sp > 1 ? ws.f((size_t)sp * t.R * ((t.Cn + 3) & ~3)) : nullptr;
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
-                // arrival counters of the in-kernel split-K combine (at most one per 64 x 64 output tile), zeroed once: the last arriver
-                // of a tile leaves its counter at zero.  MEASURED (MI355X) and NOT the default: the tile that draws the last ticket reads
-                // splits x 16 KB through one CU while the finishing launch spreads the same bytes over the chip -- ctrlsac at main.py's
-                // dimensions 718 vs 756 train()/s, spedersac (Ant, F = 512) 880 vs 933 (the guide's splitk-seam row says the same: +6 %).
-                // RLREP_SPLITK_INKERNEL=1 selects it (bit-identical results: tests/test_gemm_engines.py).
-                int* tickets = sp > 1 ? (int*)ws.alloc(sizeof(int) * (size_t)((t.R + 63) / 64) * ((t.Cn + 63) / 64)) : nullptr;
-                if (tickets && !dry && ws.ok()) (void)hipMemset(tickets, 0, sizeof(int) * (size_t)((t.R + 63) / 64) * ((t.Cn + 63) / 64));
-                if (!getenv("RLREP_SPLITK_INKERNEL")) tickets = nullptr;
                 // ... pointer alignment can only add scalar-access flags (and take bf16x3 away)
                 const int code = rl_gemm_lds_route(&t, la, lb, dry ? 0 : rl_gemm_lds_ptr_flags(&t), &sp, &kc, &fl);
                 t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab; t.flags |= fl;
-                t.tickets = (sp > 1 && code != 129) ? tickets : nullptr;
                 (code == 129 ? bigx3 : code == 128 ? big128 : big64).push_back(t);
                 continue;
             }
@@ -189,6 +193,7 @@ struct Builder {
         gb.ntasks = (int)tasks.size();
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm_lds(bt, la, lb, &gb, base, fin, st); }, what});
+        tag_gemms(p, bt == 129 ? RLREP_ENGINE_X3 : bt == 128 ? RLREP_ENGINE_LDS128 : RLREP_ENGINE_LDS64, tasks);
     }
     void gemm_small(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
         if (chain_take(p, la, lb, tasks, what)) return;
@@ -199,11 +204,10 @@ struct Builder {
         // epilogues that need a whole row / per-tile partials in one fragment force NF = 1
         int nf = 1;
         {
-            bool force1 = getenv("RLREP_NF1") != nullptr;
+            bool force1 = false;
             for (auto& t : tasks) force1 = force1 || t.epi == EPI_FWD_POLICY || t.epi == EPI_FWD_MSE || t.epi == EPI_DX_REPARAM;
             auto count = [&](int f) { long long n = 0; for (auto& t : tasks) n += (long long)((t.R + 15) / 16) * ((t.Cn + 16 * f - 1) / (16 * f)); return n; };
             if (!force1) { if (count(2) >= 384) nf = 2; if (count(4) >= 384) nf = 4; }
-            if (getenv("RLREP_NF")) nf = atoi(getenv("RLREP_NF")), nf = force1 ? 1 : nf;
             if (!tasks.empty() && (tasks[0].flags & FLAG_PRE)) nf = 1;
         }
         int base_tile = 0;
@@ -216,10 +220,6 @@ struct Builder {
         GemmBatch gb; memset(&gb, 0, sizeof(gb));
         gb.ntasks = (int)tasks.size();
         gb.low_prio = low_prio ? 1 : 0;
-        if (la == LD_COL && lb == LD_COL && fused() && !pending_fin.empty()) {
-            gb.fin = upload(pending_fin); gb.nfin = (int)pending_fin.size();
-            pending_fin.clear(); fin_attached = true;
-        }
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         const int total = base_tile;
         bool dyn = false;
@@ -237,16 +237,17 @@ struct Builder {
             }, what});
         else
             p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16(la, lb, nf, &gb, total, st); }, what});
+        tag_gemms(p, RLREP_ENGINE_GEMM16, tasks);
     }
 
     // Two INDEPENDENT stages of different tile forms -- d1: row-major x k-major products (the dX form), d2: k-major x k-major ones (the
     // weight-gradient form) -- as ONE launch (gemm16_duo_kernel): a dependent launch less.  Falls back to the two stages (d1 first) when a
     // task is routed to the LDS-tiled engines, carries a fused short product, or the table does not fit.  RLREP_NO_DUO: always the two stages.
-    bool routes_small(const GemmTask& t, int la, int lb) { int sp = 1, kc = 0, fl = 0; GemmTask c = t; return fused() || !rl_gemm_lds_route(&c, la, lb, 0, &sp, &kc, &fl); }
+    bool routes_small(const GemmTask& t, int la, int lb) { int sp = 1, kc = 0, fl = 0; GemmTask c = t; return !rl_gemm_lds_route(&c, la, lb, 0, &sp, &kc, &fl); }
     void gemm_duo(Program& p, std::vector<GemmTask> d1, std::vector<GemmTask> d2, const char* w1, const char* w2, const char* what) {
-        bool ok = !getenv("RLREP_NO_DUO") && !chain_prog && !d1.empty() && !d2.empty() && d1.size() + d2.size() <= GEMM_MAX_TASKS && !(fused() && !pending_fin.empty());
+        bool ok = !getenv("RLREP_NO_DUO") && !chain_prog && !d1.empty() && !d2.empty() && d1.size() + d2.size() <= GEMM_MAX_TASKS;
         for (auto& t : d1) ok = ok && routes_small(t, LD_ROW, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3));
-        for (auto& t : d2) ok = ok && routes_small(t, LD_COL, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3)) && !t.ad_p;
+        for (auto& t : d2) ok = ok && routes_small(t, LD_COL, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3));
         if (!ok) { gemm(p, LD_ROW, LD_COL, d1, w1); gemm(p, LD_COL, LD_COL, d2, w2); return; }
         auto count4 = [&]() { long long n = 0; for (auto& t : d2) n += (long long)((t.R + 15) / 16) * ((t.Cn + 63) / 64); return n; };
         const int nf2 = count4() >= 192 ? 4 : 1;
@@ -259,6 +260,7 @@ struct Builder {
         for (size_t q = 0; q < d2.size(); ++q) gb.t[d1.size() + q] = d2[q];
         const int total = base_tile, split = (int)d1.size();
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm16_duo(split, nf2, &gb, total, st); }, what});
+        { std::vector<GemmTask> both = d1; both.insert(both.end(), d2.begin(), d2.end()); tag_gemms(p, RLREP_ENGINE_GEMM16, both); }
     }
 
     // ---- chains (xchain.hip) -----------------------------------------------------------------------
@@ -288,7 +290,7 @@ struct Builder {
     }
     bool chain_take(Program& p, int la, int lb, const std::vector<GemmTask>& tasks, const char* what) {
         if (chain_prog != &p) return false;
-        bool ok = la == LD_ROW && !tasks.empty() && !fused();
+        bool ok = la == LD_ROW && !tasks.empty();
         for (const GemmTask& t : tasks) {
             ok = ok && tasks.size() <= GEMM_MAX_TASKS && chain_fits(t.R) && t.R == tasks[0].R && !(t.flags & FLAG_PRE_FWD) && t.epi != EPI_DW && t.Cn <= 2048 && t.K <= 2048;
             ok = ok && (((t.flags & FLAG_PRE) != 0) == ((tasks[0].flags & FLAG_PRE) != 0));
@@ -305,7 +307,7 @@ struct Builder {
     // the fused Gaussian heads + vae_mid stage (heads_vae_kernel) as a phase, or as its own launch outside a chain
     void heads_vae_stage(Program& p, const HeadsVae& hv, const char* what) {
         rlrep_agent* a = ag;
-        if (chain_prog == &p && chain_fits(hv.B) && !fused()) {
+        if (chain_prog == &p && chain_fits(hv.B)) {
             ChainPhase c; memset(&c.ph, 0, sizeof(c.ph));
             c.ph.kind = XC_HEADS_VAE; c.ph.dyn = 0; c.hv = hv; c.what = what; c.la = c.lb = 0;
             chain_R = hv.B;
@@ -314,6 +316,12 @@ struct Builder {
         }
         chain_flush();
         p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = a->cur_eps; return rl_launch_heads_vae(&q, st); }, what});
+        tag_heads_vae(p, hv);
+    }
+    // two [B, K] x [2F, K]^T head products; operands: both activations, both weight pairs; results: z, eps*sigma, two head gradients
+    static void tag_heads_vae(Program& p, const HeadsVae& hv) {
+        tag(p, RLREP_ENGINE_HEADS_VAE, 2.0 * 2.0 * (double)hv.B * (2.0 * hv.F) * (double)hv.K,
+            4.0 * (2.0 * (double)hv.B * hv.K + 2.0 * (2.0 * hv.F) * hv.K + (double)hv.B * hv.F * 7.0));
     }
     void chain_flush() {
         if (chain.empty()) return;
@@ -323,7 +331,7 @@ struct Builder {
         rlrep_agent* a = ag;
         if (c.size() == 1) {            // nothing to chain: the launch it would have been
             if (c[0].ph.kind == XC_GEMM) gemm_small_launch(p, c[0].la, c[0].lb, c[0].tasks, c[0].what);
-            else { const HeadsVae hv = c[0].hv; p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = a->cur_eps; return rl_launch_heads_vae(&q, st); }, c[0].what}); }
+            else { const HeadsVae hv = c[0].hv; p.stages.push_back({[=](hipStream_t st) { HeadsVae q = hv; q.eps = a->cur_eps; return rl_launch_heads_vae(&q, st); }, c[0].what}); tag_heads_vae(p, hv); }
             return;
         }
         const int rbg = (((R + 15) / 16) + XC_GROUPS - 1) / XC_GROUPS;      // 16-row blocks per group
@@ -365,50 +373,8 @@ struct Builder {
             return rl_launch_xchain(&l, st);
         }, what});
     }
-    // ---- optimizer fusion (single-GPU path) ------------------------------------------------------
-    // With one replica there is no all-reduce between backward and Adam, so the weight-gradient launch applies Adam (and
-    // the Polyak of the target copy) to its own tile in the epilogue, and the step's metric finalisation / temperature
-    // update rides in the same launch as one extra workgroup: the separate optimizer launch (~4.5 us + ~1.7 us of
-    // launch boundary at B = 256, six per vlsac train()) disappears.  The parameter / moment tiles are prefetched with
-    // the other epilogue operands before the inner loop, so the weight-gradient launch itself barely grows.  (A first
-    // version read p/m/v after the reduction and still needed a finalise launch: 624 vs 608 us per train(), slower.)
-    // A step program opts in (allow_fuse) only if every parameter tensor receives exactly ONE weight-gradient task.
     bool low_prio = false;        // set while the deferred critic / actor programs are built: their chain has slack next to the feature chain
-    bool allow_fuse = false;
-    // MEASURED (MI355X, vlsac B = 256): still a loss.  Adam is bandwidth work (28 bytes per parameter, ~17 MB per feature
-    // step): the separate launch streams it with 16-byte lanes in 4.5 us, the 16 x 16 tile epilogue moves the same
-    // bytes in 64-byte row segments and the weight-gradient launches grow by 3.8 / 2.6 / 2.2 / 1.7 us (feature /
-    // critic / noise-critic / actor) -- 544 vs 533 us per train().  Opt-in with RLREP_FUSE_ADAM=1.
-    bool fused() const { return allow_fuse && ag->h.world_size <= 1 && getenv("RLREP_FUSE_ADAM") && ag->a.grad_dev && !ag->has_shadows(); }   // (the shadows are maintained by the Adam launch)
-    std::vector<FinTask> pending_fin; bool fin_attached = false;
-    // hand the finalisation tasks of the step to the NEXT weight-gradient stage (fused mode; ignored otherwise)
-    void stash_fin(std::vector<FinTask> f) { if (!f.empty() && f.back().kind == FIN_HISTORY) f.pop_back(); pending_fin = fused() ? f : std::vector<FinTask>(); fin_attached = false; }
     float lr_of(int g) const { return g == 1 ? ag->h.lr_critic : g == 2 ? ag->h.lr_actor : ag->h.lr_feature; }
-    int group_of(int64_t off) const {
-        for (int g = 0; g < 4; ++g) if (ag->L.group_n[g] > 0 && off >= ag->L.group_off[g] && off < ag->L.group_off[g] + ag->L.group_n[g]) return g;
-        return -1;
-    }
-    void attach_adam(std::vector<GemmTask>& tasks, float* target = nullptr, int64_t pol_off = 0, int64_t pol_n = 0, float tau = 0.f) {
-        if (!fused()) return;
-        for (auto& t : tasks) {
-            if (t.epi != EPI_DW || !t.C) continue;
-            const int64_t off = t.C - ag->a.grad_dev;
-            const int g = group_of(off);
-            if (g < 0) continue;
-            t.ad_p = ag->a.param_dev + off; t.ad_m = ag->a.exp_avg_dev + off; t.ad_v = ag->a.exp_avg_sq_dev + off;
-            t.ad_t = (target && off >= pol_off && off < pol_off + pol_n) ? target + (off - pol_off) : nullptr;
-            if (t.out2) {
-                const int64_t ob = t.out2 - ag->a.grad_dev;
-                t.ad_pb = ag->a.param_dev + ob; t.ad_mb = ag->a.exp_avg_dev + ob; t.ad_vb = ag->a.exp_avg_sq_dev + ob;
-                t.ad_tb = (target && ob >= pol_off && ob < pol_off + pol_n) ? target + (ob - pol_off) : nullptr;
-            }
-            t.ad_grp = ag->adam_step + g;
-        }
-    }
-    void dw_stage_opt(Program& p, std::vector<GemmTask> t, const char* w, float* target = nullptr, int64_t pol_off = 0, int64_t pol_n = 0, float tau = 0.f) {
-        attach_adam(t, target, pol_off, pol_n, tau);
-        gemm(p, LD_COL, LD_COL, t, w);
-    }
 
     void fwd_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_ROW, t, w); }
     void dx_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_ROW, LD_COL, t, w); }
@@ -445,22 +411,13 @@ struct Builder {
         gemm_small(p, LD_ROW, LD_ROW, tasks, what);
         return true;
     }
-    // weight-gradient stage; carries the fused optimizer (and the Polyak spec set by set_polyak) when fused()
-    float* pol_target = nullptr; int64_t pol_off = 0, pol_n = 0; float pol_tau = 0.f;
-    void set_polyak(float* target, int64_t off, int64_t n, float tau) { pol_target = target; pol_off = off; pol_n = n; pol_tau = tau; }
-    void clear_polyak() { pol_target = nullptr; pol_off = pol_n = 0; pol_tau = 0.f; }
-    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) {
-        attach_adam(t, pol_target, pol_off, pol_n, pol_tau);
-        gemm(p, LD_COL, LD_COL, t, w);
-    }
+    // weight-gradient stage
+    void dw_stage(Program& p, std::vector<GemmTask> t, const char* w) { gemm(p, LD_COL, LD_COL, t, w); }
 
+    // split-K partial gradients that the group's optimizer launches finish themselves (AdamTask::Slab; set by the agent's builder)
+    std::vector<AdamTask::Slab> group_slabs[4];
     void adam(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau,
               std::vector<FinTask> fin, const char* what, const int* pol_steps = nullptr, int pol_period = 1) {
-        if (fused()) {          // Adam ran in the dW epilogues; the finalisation rode along unless nobody stashed it
-            if (!fin.empty() && !fin_attached) finalize_only(p, fin, what);
-            fin_attached = false;
-            return;
-        }
         const auto& L = ag->L;
         AdamTask t; memset(&t, 0, sizeof(t));
         const int64_t off = L.group_off[group];
@@ -473,6 +430,8 @@ struct Builder {
         t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = pol_steps; t.pol_period = pol_period;
         t.sh = ag->sh_dev[group]; t.nsh = ag->nsh[group];
+        t.nslab = (int)std::min<size_t>(group_slabs[group].size(), 2);
+        for (int q = 0; q < t.nslab; ++q) t.slabs[q] = group_slabs[group][q];
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
         const int nfin_all = (int)fin.size();
         const bool hist_last = !fin.empty() && fin.back().kind == FIN_HISTORY;        // run only while rlrep_history is on
@@ -503,9 +462,11 @@ struct Builder {
             const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
             return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, st);
         }, what});
+        tag(p, RLREP_ENGINE_OPTIMIZER, 0.0, 28.0 * (double)t.n + 12.0 * (double)(target ? pol_n : 0));     // read p, g, m, v; write p, m, v (+ target: read, read source, write)
     }
+    // metric finalisation without an optimizer (diffsrsac's critic step: quirk Q11, its optimizer is a no-op)
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {
-        if (!fin.empty() && fin.back().kind == FIN_HISTORY) fin.pop_back();        // (the history ring is kept by the separate optimizer launch only)
+        if (!fin.empty() && fin.back().kind == FIN_HISTORY) fin.pop_back();        // (the history ring is kept by the optimizer launches only)
         if (fin.empty()) return;
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();

@@ -8,7 +8,7 @@
 // k-ordered fma chain, same peak as the VALU but one VGPR per operand.  The four partial tiles are
 // summed through LDS in fixed wave order (bitwise reproducible), after which each thread owns NF output
 // elements and applies the fused epilogue (bias+activation, activation derivative, reparameterisation
-// backward, weight/bias gradient (+Adam), mse loss, tanh-Gaussian policy forward/backward).
+// backward, weight/bias gradient, mse loss, tanh-Gaussian policy forward/backward).
 // NF (column fragments per workgroup) is chosen per launch so that a launch stays within about two
 // workgroups per CU: wide layers (N = 512) and the 8-task weight-gradient launch use NF = 2 or 4.
 //
@@ -69,16 +69,13 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     // latency-critical launch: win the issue arbitration against the waves of a noise-critic launch that may be running on the
     // other stream of the deferred pipeline (405.8 vs 429.7 us per train(); alone on the chip it changes nothing)
     // header + per-task tile ranges (unused entries of tb are INT_MAX): preloaded kernel arguments
-    const int low_prio = hdr & 1, nfin = hdr >> 1;
+    const int low_prio = hdr & 1;
     const int tb[GEMM_MAX_TASKS] = {tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7};
     const int tcs[GEMM_MAX_TASKS] = {(int)(tc01 & 0xffffu), (int)(tc01 >> 16), (int)(tc23 & 0xffffu), (int)(tc23 >> 16),
                                      (int)(tc45 & 0xffffu), (int)(tc45 >> 16), (int)(tc67 & 0xffffu), (int)(tc67 >> 16)};
     if (!low_prio) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x;
-    if (nfin > 0 && bid == total) {      // trailing workgroup: metric finalisation / temperature update
-        if (threadIdx.x < 64) finalize_tasks(gb.fin, nfin, threadIdx.x);
-        return;
-    }
+    (void)total;
     int ti = 0, base = tb[0], tiles_c = tcs[0];
 #pragma unroll
     for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= tb[q]) { ti = q; base = tb[q]; tiles_c = tcs[q]; }
@@ -99,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
 // TWO tile forms in one launch ("duo"): tasks [0, split) are row-major x k-major products (the dX form, NF = 1), tasks [split, ntasks) k-major
 // x k-major ones (the weight-gradient form, NF = NF2); a workgroup runs the body of the form its task belongs to.  For INDEPENDENT stages of
 // different forms that the step program would otherwise launch one after the other (ctrlsac: d(phi) = dS mu' and d(mu') = dS^T phi both
-// consume the InfoNCE gradient dS): one dependent launch less.  Generic epilogues; no finalisation workgroup.  hdr = low_prio | split << 4.
+// consume the InfoNCE gradient dS): one dependent launch less.  Generic epilogues.  hdr = low_prio | split << 4.
 template <bool VA1, int NF2>
 __global__ __launch_bounds__(256) void gemm16_duo_kernel(int hdr, int total, int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6, int tb7,
                                                          unsigned tc01, unsigned tc23, unsigned tc45, unsigned tc67, GemmBatch gb) {
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm16_duo_kernel(int hdr, int total, int
 // host launcher
 // ------------------------------------------------------------------------------------------------
 // the 14 preloaded header scalars of a planned batch, then the batch
-#define G16_ARGS(B) ((B).low_prio ? 1 : 0) | ((B).nfin << 1), (B).total, (B).tb[0], (B).tb[1], (B).tb[2], (B).tb[3], (B).tb[4], (B).tb[5], (B).tb[6], (B).tb[7], \
+#define G16_ARGS(B) ((B).low_prio ? 1 : 0), (B).total, (B).tb[0], (B).tb[1], (B).tb[2], (B).tb[3], (B).tb[4], (B).tb[5], (B).tb[6], (B).tb[7], \
     (unsigned)((B).tcs[0] | ((B).tcs[1] << 16)), (unsigned)((B).tcs[2] | ((B).tcs[3] << 16)), (unsigned)((B).tcs[4] | ((B).tcs[5] << 16)), (unsigned)((B).tcs[6] | ((B).tcs[7] << 16)), (B)
 
 template <int LA, int LB, bool VA, bool VB>
@@ -149,7 +146,6 @@ template <int LA, int LB, int NF, bool VA, bool VB>
 static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (getenv("RLREP_GEMM16_GENERIC")) return false;
     const int epi = gb.t[0].epi, act = gb.t[0].act;
-    if (gb.nfin > 0) return false;
     for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].epi != epi || gb.t[q].act != act || (gb.t[q].flags & FLAG_PRE)) return false;
     if (LB == LD_ROW && epi == EPI_FWD) {
         if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
@@ -195,7 +191,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     }
     planned.total = total_tiles;
     const GemmBatch* const gb = &planned;
-    dim3 g(total_tiles + (gb->nfin > 0 ? 1 : 0));
+    dim3 g(total_tiles);
     if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch: every task carries FLAG_PRE (and agrees on the form)
         const int fw = gb->t[0].flags & FLAG_PRE_FWD;
         for (int q = 0; q < gb->ntasks; ++q) {
@@ -232,9 +228,9 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         if (all_vec(*gb, false)) { if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, true, false>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_COL, 2, true, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
         else if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
     } else if (la == LD_COL && lb == LD_COL) {
-        // weight gradients with nothing to accumulate into and no fused optimizer: the instantiation without slot loads / optimizer code
-        bool plain = gb->nfin == 0 && !getenv("RLREP_GEMM16_GENERIC");
-        for (int q = 0; q < gb->ntasks; ++q) plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM) && !gb->t[q].ad_p;
+        // weight gradients with nothing to accumulate into: the instantiation without slot loads
+        bool plain = !getenv("RLREP_GEMM16_GENERIC");
+        for (int q = 0; q < gb->ntasks; ++q) plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM);
         if (plain && nf == 4) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 4, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
         else if (plain && nf == 2) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 2, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
         else if (plain && nf == 1) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 1, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
@@ -247,7 +243,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
 // tasks [0, split): LD_ROW x LD_COL at NF = 1; tasks [split, ntasks): LD_COL x LD_COL at NF = nf2 (1 or 4); tile bases / column-tile counts set by the caller
 extern "C" int rl_launch_gemm16_duo(int split, int nf2, const GemmBatch* gb_in, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    if (split <= 0 || split >= gb_in->ntasks || gb_in->nfin > 0 || (nf2 != 1 && nf2 != 4)) return -4;
+    if (split <= 0 || split >= gb_in->ntasks || (nf2 != 1 && nf2 != 4)) return -4;
     GemmBatch planned = *gb_in;
     for (int q = 0; q < GEMM_MAX_TASKS; ++q) { planned.tb[q] = 0x7fffffff; planned.tcs[q] = 1; }
     for (int q = 0; q < planned.ntasks; ++q) {

@@ -224,8 +224,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    // (weight gradients are the k-major / k-major launches: every other instantiation drops the bias-gradient and fused-optimizer code,
-    // whose speculative record loads otherwise sit, round trip by round trip, in front of the operand loads)
+    // (weight gradients are the k-major / k-major launches: every other instantiation drops the bias-gradient code)
     constexpr bool DW = !COH && LA == LD_COL && LB == LD_COL;
     const bool want_bias = DW && (epi == EPI_DW) && (flags & FLAG_BIASGRAD) && (tc == 0);
     TIMB(5);
@@ -239,7 +238,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // ... and UNCONDITIONAL: a slot the epilogue does not use reads one word of operand A instead (discarded below).  An `if (slot in use)`
     // around the loads is a control-flow diamond, and hipcc drains vmcnt at every merge point: five exposed L2 round trips per tile.
     // Slots that an instantiation with its epilogue compiled in can never use are not loaded at all: forward: slot 0 (bias); dX: 0-3 (saved
-    // activation, accumulate-into, rank-1 pair); weight gradient: none (its accumulate / fused-optimizer forms run the generic kernel).
+    // activation, accumulate-into, rank-1 pair); weight gradient: none (its accumulate form runs the generic kernel).
     float ev[5][NF];
     auto slot = [&](auto qtag) {
         constexpr int q = decltype(qtag)::value;
@@ -261,19 +260,6 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     slot(std::integral_constant<int, 0>()); slot(std::integral_constant<int, 1>()); slot(std::integral_constant<int, 2>());
     slot(std::integral_constant<int, 3>()); slot(std::integral_constant<int, 4>());
 
-    // fused optimizer: Adam scalars of the group, and (column-tile 0 only) the bias element this thread will update
-    AdamScal adsc;
-    bool fuse_opt = false;
-    constexpr bool DWOPT = DW && EPI_K < 0;        // (the plain weight-gradient instantiation carries no optimizer code)
-    if constexpr (DWOPT) { fuse_opt = (epi == EPI_DW) && t.ad_p; if (fuse_opt) adsc = t.ad_grp->sc; }
-    float bpv = 0.f, bmv = 0.f, bvv = 0.f, btv = 0.f;
-    bool bias_opt = false;
-    if constexpr (DWOPT) bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
-    if (bias_opt) {
-        const int o = r0 + threadIdx.x;
-        bpv = t.ad_pb[o]; bmv = t.ad_mb[o]; bvv = t.ad_vb[o];
-        if (t.ad_tb) btv = t.ad_tb[o];
-    }
     asm volatile("" ::: "memory");      // the pin (see above)
     TIMB(6);
 
@@ -334,11 +320,6 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         const int q = threadIdx.x;
         const float gbv = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
         pout2[r0 + q] = gbv;
-        if (bias_opt) {
-            adam_elem(adsc, gbv, &bpv, &bmv, &bvv, t.ad_tb ? &btv : nullptr);
-            t.ad_pb[r0 + q] = bpv; t.ad_mb[r0 + q] = bmv; t.ad_vb[r0 + q] = bvv;
-            if (t.ad_tb) t.ad_tb[r0 + q] = btv;
-        }
     }
 
     if (epi == EPI_FWD_MSE) {
@@ -437,17 +418,9 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
             cp[t.F] = cold2[f] + v * e0[f];
             break;
         case EPI_DW:
-        default: {
-            const float g = cold[f] + v;
-            *cp = g;
-            if (fuse_opt) {      // e0 / cold2 / cold3 / cold4 = parameter, exp_avg, exp_avg_sq, Polyak target (prefetched)
-                const size_t o = (size_t)r * ldc + c;
-                float pv = e0[f], mv = cold2[f], vv = cold3[f], tv = cold4[f];
-                adam_elem(adsc, g, &pv, &mv, &vv, t.ad_t ? &tv : nullptr);
-                t.ad_p[o] = pv; t.ad_m[o] = mv; t.ad_v[o] = vv;
-                if (t.ad_t) t.ad_t[o] = tv;
-            }
-        } break;
+        default:
+            *cp = cold[f] + v;
+            break;
         }
     }
 }

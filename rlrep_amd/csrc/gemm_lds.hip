@@ -114,20 +114,6 @@ __device__ __forceinline__ void gl_frag(const float* __restrict__ S, int wbase, 
 // ---- epilogue of four consecutive output columns (shared by the main kernel and the split-K finisher) -----------
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-// split-K hand-off inside one launch (MI355X guide, visibility: every byte handed to another workgroup is stored write-through and
-// read with sc1 loads; the storing waves drain, ONE lane adds to the tile's counter, the last arriver reads): sc1 accesses through a raw
-// buffer descriptor over the slab
-typedef unsigned gl_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gl_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x27000); }
-__device__ __forceinline__ void st4_wt(__amdgpu_buffer_rsrc_t r, size_t idx, f32x4 v) {
-    const gl_u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, (unsigned)(idx * 4), 0, 16);
-}
-__device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t r, size_t idx) {
-    const gl_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(idx * 4), 0, 16);
-    return (f32x4){__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
-}
-
 // one output element (outputs whose row stride / width / pointers rule out 16-byte accesses)
 __device__ __forceinline__ void gl_epilogue1(const GemmTask& t, int r, int c, float v) {
     v *= t.scale;
@@ -292,9 +278,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
         __syncthreads();
     }
 
-    const bool inkernel = splits > 1 && t.tickets != nullptr;          // last-arriver combine (no finishing launch)
     const size_t C4w = (size_t)((Cn + 3) & ~3);
-    const __amdgpu_buffer_rsrc_t rslab = gl_rsrc(t.slab), rbslab = gl_rsrc(t.bslab);
     // bias gradient (EPI_DW): row sums of operand A, taken from the fragments the column-0 waves of column-tile 0 consumed
     const bool has_bias = LA == LD_COL && t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && tc == 0;
     if (has_bias && wc == 0) {
@@ -305,8 +289,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
             s += __shfl_xor(s, 32, 64);
             const int r = r0 + wr * WT + a * 16 + lane;
             if (lane < 16 && r < R) {
-                if (inkernel) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), rbslab, (unsigned)(((size_t)split * R + r) * 4), 0, 16);
-                else if (splits > 1) t.bslab[(size_t)split * R + r] = s;
+                if (splits > 1) t.bslab[(size_t)split * R + r] = s;
                 else t.out2[r] = s;
             }
         }
@@ -327,42 +310,8 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
         const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * (WT + 4) + cc);
         const int r = r0 + wr * WT + rr, c = c0 + wc * WT + cc;
         if (r < R && c < Cn) {
-            if (inkernel) st4_wt(rslab, ((size_t)split * R + r) * C4w + c, v);
-            else if (splits > 1) st4(t.slab + ((size_t)split * R + r) * C4w + c, v);
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * C4w + c, v);       // partial tile: the finishing blocks add the slabs in split order
             else gl_epilogue4(t, r, c, v);
-        }
-    }
-    if (!inkernel) return;
-
-    // ---- last-arriver combine: every wave has drained its write-through stores; one lane takes the tile's ticket; the workgroup that
-    // draws the last one adds the slabs in SPLIT ORDER (bit-reproducible, whoever arrives last) and runs the epilogue ----
-    __shared__ int last_s;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int* const tk = t.tickets + (tc * tiles_r + tr);
-        const int got = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = got == splits - 1;
-        if (last_s) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // ready for the next launch
-    }
-    __syncthreads();
-    if (!last_s) return;
-    constexpr int V4 = BT / 4;                                  // 16-byte segments per tile row
-    for (int e = threadIdx.x; e < BT * V4; e += 256) {
-        const int rr = e / V4, cc = (e - rr * V4) * 4;
-        const int r = r0 + rr, c = c0 + cc;
-        if (r >= R || c >= Cn) continue;
-        f32x4 v = ld4_sc1(rslab, (size_t)r * C4w + c);
-        for (int s = 1; s < splits; ++s) v += ld4_sc1(rslab, ((size_t)s * R + r) * C4w + c);
-        gl_epilogue4(t, r, c, v);
-    }
-    if (has_bias) {
-        for (int rr = threadIdx.x; rr < BT; rr += 256) {
-            const int r = r0 + rr;
-            if (r >= R) continue;
-            float s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbslab, (unsigned)((size_t)r * 4), 0, 16));
-            for (int q = 1; q < splits; ++q) s += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbslab, (unsigned)(((size_t)q * R + r) * 4), 0, 16));
-            t.out2[r] = s;
         }
     }
 }
@@ -618,9 +567,7 @@ extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, i
     int rc = bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb)
            : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb);
     if (rc != 0) return rc;
-    bool all_inkernel = bt != 129;                    // every split task carries arrival counters: its tile kernel finished the job itself
-    for (int q = 0; q < gb->ntasks; ++q) if (gb->t[q].splits > 1 && !gb->t[q].tickets) all_inkernel = false;
-    if (fin_blocks > 0 && !all_inkernel) {
+    if (fin_blocks > 0) {
         hipLaunchKernelGGL(gemm_lds_fin_kernel, dim3(fin_blocks), dim3(256), 0, st, *gb);
         ++g_rl_launches;              // split-K: the stage is two kernels
         rc = (int)hipGetLastError();
@@ -640,7 +587,6 @@ extern "C" int rl_gemm_lds_dim_flags(const GemmTask* t, int la, int lb) {
 }
 extern "C" int rl_gemm_lds_align_ok(const GemmTask* t, int la, int lb) {
     if (t->epi != EPI_FWD && t->epi != EPI_DX && t->epi != EPI_DW) return 0;
-    if (t->ad_p) return 0;
     (void)la; (void)lb;
     return 1;
 }

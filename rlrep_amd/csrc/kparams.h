@@ -185,13 +185,11 @@ struct NcDwTask {
     float* gW; float* gb;                           // [H, F], [H]
     int B, F, H, N;
     int tiles_k, tile_base, ntiles;
-    // optimizer fused into the epilogue (single-GPU path); null ad_p: gradients only
-    float* ad_p; float* ad_m; float* ad_v; float* ad_pb; float* ad_mb; float* ad_vb;
-    const GroupCfg* ad_grp;
 };
 // lean: the 128-VGPR build of the fp32 kernel (launch beside the feature chain).  engine 1 = bf16x3 split-K form: `splits` row ranges
 // per 64 x 64 output tile, partial tiles in slab [task][split][H][F], bias partials in bslab [task][split][H], summed by a finishing launch
-struct NcDwBatch { int ntasks; int lean; int engine; int splits; float* slab; float* bslab; NcDwTask t[2]; };
+// fin_in_adam: the partials are summed by the critic group's optimizer launch (AdamTask::Slab) instead of nc_dw_fin_kernel
+struct NcDwBatch { int ntasks; int lean; int engine; int splits; float* slab; float* bslab; int fin_in_adam; int pad_; NcDwTask t[2]; };
 
 struct NcDxTask {
     const float* GH[2]; int ldgh;    // dL/dHm per head [B, H]

@@ -1273,8 +1273,6 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 2) void nc_dw_kernel(NcDwBatch nb) 
     const float invN = 1.0f / (float)(4 * NC_NF);
     const bool want_bias = (tk == 0);
 
-    AdamScal adsc;
-    if (t.ad_p) { adsc = t.ad_grp->sc; adsc.tau = 0.f; }
     for (int e = tid; e < 4 * NC_NF * 32; e += 512) {
         const int n = e >> 5, c = e & 31;
         nz_s[n * NZLD + c] = t.noise[(size_t)n * F + min(k0 + c, F - 1)];      // columns past F are never stored
@@ -1437,7 +1435,6 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 2) void nc_dw_kernel(NcDwBatch nb) 
         if (row < H && colk < F) {
             const size_t o = (size_t)row * F + colk;
             t.gW[o] = v;
-            if (t.ad_p) adam_elem(adsc, v, t.ad_p + o, t.ad_m + o, t.ad_v + o, nullptr);
         }
     }
     if (want_bias && threadIdx.x < 16 && j0 + (int)threadIdx.x < H) {
@@ -1445,7 +1442,6 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 2) void nc_dw_kernel(NcDwBatch nb) 
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) v += bsum[ww][threadIdx.x];
         t.gb[j0 + threadIdx.x] = v;
-        if (t.ad_pb) { const int o = j0 + threadIdx.x; adam_elem(adsc, v, t.ad_pb + o, t.ad_mb + o, t.ad_vb + o, nullptr); }
     }
 }
 
@@ -1663,16 +1659,12 @@ __global__ __launch_bounds__(256) void nc_dw_fin_kernel(NcDwBatch nb) {
 
 // ------------------------------------------------------------------------------------------------
 // hidden units per nc_fwd workgroup (64 or 128); the builder sizes tiles_h with it
-extern "C" int rl_nc_fwd_cols() {
-    static const int v = [] { const char* e = getenv("RLREP_NC_COLS"); const int x = e ? atoi(e) : 128; return x == 64 ? 64 : 128; }();
-    return v;
-}
+extern "C" int rl_nc_fwd_cols() { return 128; }
 // Tiling of one nc_fwd launch: engine (0 fp32 MFMA, 1 bf16x3), batch-row groups per workgroup (g2, 4 rows each) and hidden
-// units per workgroup.  bf16x3 needs 32-deep K steps and 16-byte rows everywhere; RLREP_NC_X3=0 (or RLREP_NO_X3) keeps fp32.
+// units per workgroup.  bf16x3 needs 32-deep K steps and 16-byte rows everywhere; RLREP_NO_X3 keeps fp32 (tests: both engines).
 extern "C" void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols) {
     const int B = tasks[0].B, F = tasks[0].F, H = tasks[0].H;
-    const char* ex = getenv("RLREP_NC_X3");                 // read per plan (agent construction), so a test can flip it
-    const bool want_x3 = (ex ? atoi(ex) != 0 : true) && !getenv("RLREP_NO_X3");
+    const bool want_x3 = !getenv("RLREP_NO_X3");             // read per plan (agent construction), so a test can flip it
     bool x3 = want_x3 && (F % 32) == 0 && F >= 64;
     for (int q = 0; q < ntasks; ++q) {
         const NcFwdTask& t = tasks[q];
@@ -1682,14 +1674,12 @@ extern "C" void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, 
     if (x3) {
         *engine = 1; *g2 = 2;
         const long long wg128 = (long long)ntasks * ((B + 7) / 8) * ((H + 127) / 128);
-        const char* e = getenv("RLREP_NC_X3_COLS");
-        *cols = e ? (atoi(e) == 64 ? 64 : 128) : (wg128 >= 256 ? 128 : 64);
+        *cols = wg128 >= 256 ? 128 : 64;
         return;
     }
     *engine = 0;
     *cols = rl_nc_fwd_cols();
     *g2 = ((long long)ntasks * ((B + 3) / 4) * ((H + 63) / 64) <= 2048) ? 1 : 2;
-    if (getenv("RLREP_NC_G2")) *g2 = atoi(getenv("RLREP_NC_G2"));
 }
 extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, hipStream_t st) {
     if (total_tiles <= 0) return 0;
@@ -1697,14 +1687,14 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     const int F = nb->t[0].F, N = nb->t[0].N;
     if (nb->engine == 1) {
         if ((F % 32) != 0 || g2 != 2) return -3;
+#ifdef RL_EXPERIMENTS
+        // (the superseded two-role / 16x16x32 forms of the 128-wide tile: experiments library only)
         static const int wide = [] { const char* e = getenv("RLREP_NC_X3_WIDE"); return e ? atoi(e) : 1; }();
         static const int quad = [] { const char* e = getenv("RLREP_NC_X3_Q"); return e ? atoi(e) : 1; }();
-#ifdef RL_EXPERIMENTS
         if (nb->cols == 128 && quad) hipLaunchKernelGGL(nc_fwd_x3q_kernel, dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
         else if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);     // superseded by x3q
         else if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<2>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);             // superseded by x3q
 #else
-        (void)wide; (void)quad;
         if (nb->cols == 128) hipLaunchKernelGGL(nc_fwd_x3q_kernel, dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
 #endif
         else hipLaunchKernelGGL((nc_fwd_x3_kernel<1>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);
@@ -1725,10 +1715,9 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     return (int)hipGetLastError();
 }
 
-// engine of the dX launch: 1 = bf16x3 (H % 32 == 0, even row strides, 8-byte aligned U / GH; RLREP_NC_X3=0 keeps fp32 MFMA)
+// engine of the dX launch: 1 = bf16x3 (H % 32 == 0, even row strides, 8-byte aligned U / GH; RLREP_NO_X3 keeps fp32 MFMA)
 extern "C" int rl_nc_dx_engine(const NcDxTask* t) {
-    const char* ex = getenv("RLREP_NC_X3");
-    if ((ex && atoi(ex) == 0) || getenv("RLREP_NO_X3")) return 0;
+    if (getenv("RLREP_NO_X3")) return 0;
     if (t->N != 4 * NC_NF || (t->H % 32) != 0 || (t->ldgh & 1) || t->nheads < 1 || t->nheads > 2 || t->tiles_k != (t->F + 63) / 64) return 0;
     for (int h = 0; h < t->nheads; ++h) if (((((uintptr_t)t->U[h]) | ((uintptr_t)t->GH[h])) & 7) != 0) return 0;
     return 1;
@@ -1764,17 +1753,11 @@ extern "C" int rl_nc_init() {
     return (int)hipFuncSetAttribute((const void*)nc_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-// engine of the dW launch: 1 = bf16x3 split-K (needs slabs from the caller and no fused optimizer; RLREP_NC_X3=0 / RLREP_NC_DW_X3=0 keep fp32)
-extern "C" int rl_nc_dw_engine(int fused_optimizer) {
-    const char* ex = getenv("RLREP_NC_X3");
-    const char* ed = getenv("RLREP_NC_DW_X3");
-    if ((ex && atoi(ex) == 0) || (ed && atoi(ed) == 0) || getenv("RLREP_NO_X3") || fused_optimizer) return 0;
-    return 1;
-}
+// engine of the dW launch: 1 = bf16x3 split-K (needs slabs from the caller; RLREP_NO_X3 keeps fp32)
+extern "C" int rl_nc_dw_engine() { return getenv("RLREP_NO_X3") ? 0 : 1; }
 extern "C" int rl_nc_dw_splits(int B, int F, int H, int ntasks) {
     const int tiles = ((H + 63) / 64) * ((F + 63) / 64) * ntasks;
-    const char* e = getenv("RLREP_NC_DW_SPLITS");
-    int sp = e ? atoi(e) : (256 + tiles - 1) / tiles;                 // about one workgroup per CU
+    int sp = (256 + tiles - 1) / tiles;                               // about one workgroup per CU
     sp = sp < 1 ? 1 : sp > 16 ? 16 : sp;
     const int maxsp = (B + 7) / 8;                                    // at least 8 batch rows (five 32-deep steps) per split
     return sp > maxsp ? (maxsp < 1 ? 1 : maxsp) : sp;
@@ -1787,6 +1770,7 @@ extern "C" int rl_launch_nc_dw(const NcDwBatch* nb, int total_tiles, hipStream_t
         const NcDwTask& t0 = nb->t[0];
         for (int q = 1; q < nb->ntasks; ++q) if (nb->t[q].H != t0.H || nb->t[q].F != t0.F || nb->t[q].B != t0.B) return -3;
         hipLaunchKernelGGL(nc_dw_x3_kernel, dim3(total_tiles), dim3(512), 0, st, *nb);
+        if (nb->fin_in_adam) return (int)hipGetLastError();      // the critic group's optimizer launch adds the slabs (AdamTask::Slab)
         const size_t HF = (size_t)t0.H * t0.F;
         hipLaunchKernelGGL(nc_dw_fin_kernel, dim3((unsigned)((HF + 255) / 256), nb->ntasks), dim3(256), 0, st, *nb);
         ++g_rl_launches;              // this stage is two kernels

@@ -332,13 +332,6 @@ def test_noise_critic_weight_images_follow_external_parameter_writes():
             assert abs(float(info[k]) - v) <= 1e-4 * max(abs(v), 1e-2), (step, k, float(info[k]), v)
 
 
-def test_noise_critic_without_weight_images(monkeypatch):
-    """RLREP_NC_SHADOWS=0: the round-1 form (every noise-critic workgroup splits its W fragments itself) stays available and correct."""
-    monkeypatch.setenv('RLREP_NC_SHADOWS', '0')
-    worst = _check_against_oracle(Case('vlsac_hc'), calls=3, expect_pipeline=True)
-    print(f'vlsac_hc without weight images vs oracle: worst param rel-L2 {worst:.2e}')
-
-
 @pytest.mark.parametrize('name', ['vlsac_tiny_noft', 'ctrlsac_tiny_noft', 'spedersac_tiny_noft'])
 def test_default_mode_without_feature_target(name):
     """use_feature_target=False in the default (graph, pipelined) mode: vlsac's deferred critic / actor chain then runs against a snapshot

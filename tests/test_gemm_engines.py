@@ -45,7 +45,7 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0, fin_launch=False):
+def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0):
     """mode: 'fwd' (A [R,K], B [Cn,K]), 'dx' (A [R,K], B [K,Cn]), 'dw' (A [K,R], B [K,Cn]).  Returns (got, want, extra)."""
     from rlrep_amd import _lib
     rs = np.random.RandomState(seed)
@@ -60,7 +60,7 @@ def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, s
     dA, dB, dC = _dev(A), _dev(Bm), _dev(C0)
     bias_v = aux = out2 = None
     epi = {'fwd': 0, 'dx': 1, 'dw': 3}[mode]
-    flags = (1 if accum else 0) | (8 if fin_launch else 0)      # 8: split-K finished by the separate launch instead of the last arriver
+    flags = 1 if accum else 0
     extra_want = None
     if mode == 'fwd':
         bias_v = rs.standard_normal(Cn).astype(np.float32) if bias else None
@@ -124,16 +124,14 @@ def test_lds_engine_ragged_edges(mode, bt):
 
 
 @pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
-@pytest.mark.parametrize('fin_launch', [False, True])
 @pytest.mark.parametrize('splits', [2, 3, 7])
-def test_lds_engine_split_k(mode, splits, fin_launch):
-    """split-K slabs + finishing launch, including a last split shorter than the others and K not a multiple of 32"""
-    check(1, mode, 128, 192, 708, bt=64, splits=splits, seed=5, accum=(mode != 'fwd'), fin_launch=fin_launch)
-    check(1, mode, 200, 128, 1024, bt=128, splits=splits, seed=6, fin_launch=fin_launch)
-    if not fin_launch:          # the in-kernel combine adds the slabs in split order whoever arrives last: bit-identical to the finishing launch
-        a, _, _ = run_gemm(1, mode, 200, 128, 1024, bt=64, splits=splits, seed=6)
-        b, _, _ = run_gemm(1, mode, 200, 128, 1024, bt=64, splits=splits, seed=6, fin_launch=True)
-        assert np.array_equal(a, b)
+def test_lds_engine_split_k(mode, splits):
+    """split-K slabs + finishing launch (slabs added in split order), including a last split shorter than the others and K not a multiple of 32"""
+    check(1, mode, 128, 192, 708, bt=64, splits=splits, seed=5, accum=(mode != 'fwd'))
+    check(1, mode, 200, 128, 1024, bt=128, splits=splits, seed=6)
+    a, _, _ = run_gemm(1, mode, 200, 128, 1024, bt=64, splits=splits, seed=6)
+    b, _, _ = run_gemm(1, mode, 200, 128, 1024, bt=64, splits=splits, seed=6)
+    assert np.array_equal(a, b), 'fixed summation order: reruns are bit-identical'
 
 
 @pytest.mark.parametrize('act', ['relu', 'elu', 'sin', 'tanh'])

@@ -444,10 +444,10 @@ def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, calls, kw, monkey
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-def test_lean_noise_critic_dw_matches_full():
-    """The deferred chain's register-capped noise-critic dW kernel (nc_dw_kernel<true>, 128 VGPRs so that feature-chain launches can
-    start beside it) against the full build the sequential form uses: 40 train() calls at the headline dimensions, parameters within
-    1e-6 relative (measured 5e-9: last-bit rounding, same summation order)."""
+def test_pipelined_and_sequential_default_forms_agree():
+    """The two default forms as they ship (the pipelined one runs both policy forwards inside the critic step's tile launches, the
+    sequential one inside the last feature step's: different summation order): 40 train() calls at the headline dimensions, parameters
+    within 1e-6 relative (measured 5e-9: last-bit rounding)."""
     import synth
     from rlrep_amd.utils.buffer import ReplayBuffer
     from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent

@@ -135,7 +135,7 @@ def test_vlsac_noise_critic_first_layer_on_bf16x3(S, A, B, F, H, monkeypatch):
     over 8 ranges."""
     import ctypes as C
     from rlrep_amd import _lib
-    monkeypatch.delenv('RLREP_NC_X3', raising=False)
+    monkeypatch.delenv('RLREP_NO_X3', raising=False)
     out = [C.c_int32() for _ in range(3)]
     assert _lib.lib.rlrep_nc_fwd_plan(2, B, F, H, *[C.byref(o) for o in out]) == 0 and out[0].value == 1
     _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), S, A, B,
@@ -152,13 +152,13 @@ def test_vlsac_fused_heads_and_vae_mid_at_odd_shapes(S, A, B, F, H, Hv):
 
 
 def test_vlsac_noise_critic_engines_agree(monkeypatch):
-    """RLREP_NC_X3=0 keeps the first layer on fp32 MFMA: the same two train() calls end within fp32 rounding of the bf16x3 run."""
+    """RLREP_NO_X3 keeps the first layer on fp32 MFMA: the same two train() calls end within fp32 rounding of the bf16x3 run."""
     outs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv('RLREP_NC_X3', '0')
+            monkeypatch.setenv('RLREP_NO_X3', '1')
         else:
-            monkeypatch.delenv('RLREP_NC_X3', raising=False)
+            monkeypatch.delenv('RLREP_NO_X3', raising=False)
         a = _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), 17, 6, 128,
                  dict(hidden_dim=128, feature_dim=128, extra_feature_steps=0), trains=2)
         outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})
