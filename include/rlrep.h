@@ -327,6 +327,14 @@ const float* rlrep_metrics_dev(rlrep_agent* agent);
 int32_t rlrep_images_managed(rlrep_agent* agent, int32_t on);
 int32_t rlrep_refresh_images(rlrep_agent* agent, void* stream);
 
+/* Chained feature steps (vlsac, one GPU; no reference counterpart: a launch-saving form of `for _ in range(extra_feature_steps + 1):
+ * feature_step(...)`, vlsac_agent.py:250-256).  Called after rlrep_prefetch_batch has armed the NEXT step's minibatch and before this step's
+ * rlrep_feature_step: this step's weight-gradient launch then applies the optimizer to the two first layers in its epilogues, and its optimizer
+ * launch skips them and carries the next step's first launch (encoder.l1 / f.l1, rows read from the ring through the index pool) as leading
+ * tiles; the next rlrep_feature_backward starts at its second launch.  Same arithmetic in the same order per parameter.  1: armed, 0: not
+ * available (nothing changes).  The next call on the agent's feature path must be that next step (plain, no rlrep_prefetch_policy_early). */
+int32_t rlrep_feature_chain_next(rlrep_agent* agent);
+
 int32_t rlrep_stage_count(rlrep_agent* agent, int32_t program);
 const char* rlrep_stage_name(rlrep_agent* agent, int32_t program, int32_t stage);
 int32_t rlrep_run_stage(rlrep_agent* agent, int32_t program, int32_t stage, void* stream);

@@ -120,6 +120,7 @@ def _load():
         'rlrep_actor_forward': (i32, [vp, vp, i32, vp, f32, f32, vp, vp]),
         'rlrep_images_managed': (i32, [vp, i32]),
         'rlrep_refresh_images': (i32, [vp, vp]),
+        'rlrep_feature_chain_next': (i32, [vp]),
         'rlrep_stage_count': (i32, [vp, i32]),
         'rlrep_stage_name': (C.c_char_p, [vp, i32, i32]),
         'rlrep_run_stage': (i32, [vp, i32, i32, vp]),

@@ -529,7 +529,11 @@ class SACAgent(object):
             self.core.sample(slot, buffer.ring, self._pool['idx_' + key], B)
             nxt = self._next_key.get(key)
             if nxt is not None:
-                self.core.prefetch_batch(buffer.ring, self._pool['idx_' + nxt], B, slot)
+                armed = self.core.prefetch_batch(buffer.ring, self._pool['idx_' + nxt], B, slot)
+                # the feature step that consumes `nxt` follows this one directly: chain them (one launch less per pair; the library
+                # declines where it has no such form) -- unless that next step is the one that carries the policy forwards
+                if armed and slot == 0 and not self._dp and self._feature_iters() > 0 and nxt != self._early_key_for(key):
+                    self.core.feature_chain_next()
             if slot == 0 and key == self._early_key:
                 # this is the minibatch the critic and actor steps will reuse: both policy forwards ride in its feature step
                 self.core.prefetch_policy_early(self._pool['eps_crit'], self._pool['eps_act'])
@@ -543,6 +547,11 @@ class SACAgent(object):
         else:
             idx = self._indices(key, B, buffer.size)
         self.core.sample(slot, buffer.ring, idx, B)
+
+    def _early_key_for(self, key):
+        """The key of the minibatch whose feature step will carry both policy forwards (rlrep_prefetch_policy_early), as far as it is
+        known while `key` is being sampled: _fill_pools() has fixed it for this train()."""
+        return self._early_key
 
     def _graph_off(self, key):
         # distinct Philox streams per noise tensor inside one train(): offset = (hash << 32) + device step counter
@@ -604,7 +613,11 @@ class SACAgent(object):
     @contextlib.contextmanager
     def _managed_images(self):
         """Around the capture of a single-GPU train() graph: the critic steps recorded inside do not carry the image-refresh launch."""
-        on = self.core.images_managed(True)
+        # OPT-IN (RLREP_MANAGED_IMAGES=1).  Measured on MI355X, three alternations in one call (profiles/r04_ab_chain_cuts.txt): the launch it
+        # takes off the critic / actor chain is worth +0.3 % in the sequential form and COSTS 2.9 % in the two-chain form (3 510 -> 3 380
+        # train()/s): the chains are balanced, and the critic / actor chain starting 5 us earlier shifts its chip-filling noise-critic launches
+        # onto other feature-chain launches.  The default keeps the refresh launch at the head of every critic step.
+        on = os.environ.get('RLREP_MANAGED_IMAGES') == '1' and self.core.images_managed(True)
         self._img_on = self._img_on or on
         try:
             yield

@@ -212,6 +212,14 @@ class HipCore:
             check(rc, 'prefetch_batch')
         return rc == 1
 
+    def feature_chain_next(self):
+        """The next feature step follows this one directly on the minibatch just armed by prefetch_batch: chain the two
+        (include/rlrep.h rlrep_feature_chain_next).  False: no such form for this agent."""
+        rc = lib.rlrep_feature_chain_next(self.h)
+        if rc < 0:
+            check(rc, 'feature_chain_next')
+        return rc == 1
+
     def train_prologue(self, ring, size_dev, idx_pool, eps_pool, seed, idx_offset, eps_offset, batch):
         """begin_train + index pool + noise pool + gather of the first minibatch, one launch."""
         check(lib.rlrep_train_prologue(self.h, _ptr(ring), _ptr(size_dev), _ptr(idx_pool), idx_pool.numel(), _ptr(eps_pool),

@@ -26,7 +26,8 @@ enum Epi : int {
     EPI_DW = 3,         // C = acc (weight gradient), bias gradient = column sums of operand A
     EPI_FWD_MSE = 4,    // vlsac decoder heads: C <- d(0.5 mse)/d(pred) vs targets x0 (cols < n0) / x1 (col n0); partial sums -> y0
     EPI_FWD_POLICY = 5, // actor head (2A <= 16): C <- raw [mu|rho]; y0 <- tanh(mu + eps*sigma); y1 <- log pi   (agent/sac/actor.py:76-91)
-    EPI_DX_POLICYBWD = 6 // acc = dL/da: y0 <- dL/d[mu|rho]; no C store
+    EPI_DX_POLICYBWD = 6, // acc = dL/da: y0 <- dL/d[mu|rho]; no C store
+    EPI_DWA = 7          // COMPILE-TIME kind only (tasks carry EPI_DW): weight-gradient launch some of whose tasks run the optimizer (FLAG_ADAM)
 };
 
 #define FLAG_ACCUM 1       // C += value instead of C = value
@@ -53,6 +54,10 @@ enum Epi : int {
 // dX form only: the fused short product's mask is ELU'(M) = (M > 0 ? 1 : M + 1) instead of ReLU'(M) -- the actor head's dX (K1 = 2A) riding in
 // the dX launch of the actor's second layer (agent/sac/actor.py:31-45 backward)
 #define FLAG_PRE_ELU 1024
+// EPI_DW only: the optimizer runs in this task's epilogue (Adam on the tile's own weights and, column tile 0, bias; Polyak into the target
+// copy where ad_t / ad_tb are set) -- the FIRST layers of the vlsac feature nets, whose updated weights the next feature step's first launch
+// needs, so that the rest of the group's optimizer work can share a launch with that first layer.  GemmTask::ad_*.
+#define FLAG_ADAM 2048
 
 struct GroupCfg;
 struct GemmTask {
@@ -68,6 +73,7 @@ struct GemmTask {
     int R, Cn, K;        // output R x Cn, inner length K
     int tiles_c, tile_base;
     int epi, act, flags;
+    const int* gidx;     // row gather (gemm16 forward launches riding in an optimizer launch): operand-A row i is A[gidx[i] * lda + k] (null: row i)
     float scale;         // multiplies acc before the epilogue (1.0 default)
     int n0;              // fused loss / policy epilogues: column split (S or A)
     float* out2;         // EPI_FWD+ACT_SIN: pre-activation; EPI_DW: bias gradient
@@ -86,6 +92,10 @@ struct GemmTask {
     int ldaux2, ldaux3;
     int ncN;             // noise rows (20) for LD_NCG/LD_NCX
     int F;               // EPI_DX_REPARAM: column offset of the log-std half
+    // EPI_DW + FLAG_ADAM: Adam on the tile's own weights (and bias), plus Polyak into the target copy.  Bases of tensors laid out like C / out2.
+    float* ad_p; float* ad_m; float* ad_v; float* ad_t;          // weight: param, exp_avg, exp_avg_sq, target (or null)
+    float* ad_pb; float* ad_mb; float* ad_vb; float* ad_tb;      // bias
+    const GroupCfg* ad_grp;
     // generic operands of the fused loss / policy epilogues
     const float* x0; const float* x1; const float* x2; float* y0; float* y1; const double* dptr;
     int ldx0, ldx1; float s0, s1;
@@ -127,6 +137,10 @@ static inline void rl_gemm16_plan(GemmTask& t) {
         break;
     default:   // EPI_DW
         if (t.flags & FLAG_ACCUM) { t.sp[1] = t.C; t.srs[1] = t.ldc; }
+        if ((t.flags & FLAG_ADAM) && t.ad_p) {      // optimizer in the epilogue: the tile of the parameter, its Adam moments (and its Polyak target)
+            t.sp[0] = t.ad_p; t.sp[2] = t.ad_m; t.sp[3] = t.ad_v; t.sp[4] = t.ad_t;
+            t.srs[0] = t.srs[2] = t.srs[3] = t.srs[4] = t.ldc;
+        }
     }
 }
 
@@ -163,7 +177,9 @@ struct AdamTask {
     // l = element - off) -- the finishing launch those partials used to need rides here, and the sum is filed in the gradient arena too.
     // per % 4 == 0, off % 4 == 0, 16-byte aligned slabs (the builder only folds then).  nslab = 0: plain gradients.
     struct Slab { long long off, n, per; const float* slab; int splits, pad; } slabs[2];
-    int nslab, pad_;
+    int nslab;
+    // ranges of the group that this launch leaves alone (their optimizer ran in the weight-gradient epilogues: FLAG_ADAM); multiples of 4 floats
+    int nskip; long long skip_off[2], skip_n[2];
 };
 
 struct PolyakTask {
@@ -209,14 +225,16 @@ __device__ __forceinline__ AdamScal adam_scalars(float lr, float b1, float b2, f
     return a;
 }
 __device__ __forceinline__ void adam_elem(const AdamScal& a, float g, float* p, float* m, float* v, float* target) {
+    // every operation PINNED (explicit fma / mul / add / div / sqrt, round to nearest): this function is inlined into the optimizer launch
+    // and into weight-gradient epilogues (FLAG_ADAM), and the two must agree bit for bit whatever the compiler would contract where
     float mm = *m, vv = *v, pv = *p;
-    mm = mm + a.w1 * (g - mm);
-    vv = vv * a.b2;
-    vv = vv + (a.w2 * g) * g;
-    const float denom = sqrtf(vv) / a.bc2s + a.eps;
-    pv = pv + a.nss * (mm / denom);
+    mm = __fmaf_rn(a.w1, __fsub_rn(g, mm), mm);
+    vv = __fmul_rn(vv, a.b2);
+    vv = __fmaf_rn(__fmul_rn(a.w2, g), g, vv);
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), a.bc2s), a.eps);
+    pv = __fmaf_rn(a.nss, __fdiv_rn(mm, denom), pv);
     *m = mm; *v = vv; *p = pv;
-    if (target) *target = a.tau * pv + a.omt * (*target);
+    if (target) *target = __fmaf_rn(a.tau, pv, __fmul_rn(a.omt, *target));
 }
 
 // Per-optimizer-group device state: hyper-parameters (written once at create), the Adam step counter and the

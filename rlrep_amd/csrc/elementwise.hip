@@ -394,12 +394,12 @@ __device__ __forceinline__ void copy_segs_body(const CopySegs& p, int blk, int n
 // (build.sh compiles this file with -mllvm -amdgpu-kernarg-preload-count=14): an optimizer block issues its four 16-byte loads and the load of the
 // group's scalars with its first instructions, instead of after three dependent round trips (task table -> record -> group record).
 // hdr = adam_blocks | vec_ok << 30 (vec_ok: every arena pointer 16-byte aligned and the Polyak sub-range on multiples of four floats).
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
-                                                   const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, AdamTask t,
-                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, SlotFill sf2, int fill2_blocks, AdamSnap snap, int snap_blocks) {
+// (the body of an optimizer block; `bid` = block index within the optimizer part of the launch)
+__device__ __forceinline__ void adam_block(const int bid, float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
+                                           const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, const AdamTask& t,
+                                           const FinTask* __restrict__ fin, int nfin, const SlotFill& sf, int fill_blocks, const SlotFill& sf2, int fill2_blocks,
+                                           const AdamSnap& snap, int snap_blocks) {
     const int adam_blocks = hdr & 0x3fffffff;
-    __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
-    const int bid = blockIdx.x;
     if (bid > adam_blocks + fill_blocks + fill2_blocks) {       // the small segments of a folded snapshot (AdamSnap)
         copy_segs_body(snap.segs, bid - adam_blocks - fill_blocks - fill2_blocks - 1, snap_blocks);
         return;
@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const
     }
     asm volatile("" ::: "memory");      // (pin: the loads above stay ahead of the reads of the record below)
     const int ti = 0;
+    // ranges whose optimizer ran in the weight-gradient epilogues (FLAG_ADAM): nothing to do here
+    if (t.nskip > 0 && i >= t.skip_off[0] && i < t.skip_off[0] + t.skip_n[0]) return;
+    if (t.nskip > 1 && i >= t.skip_off[1] && i < t.skip_off[1] + t.skip_n[1]) return;
     const bool pol_on = atarget && (!t.pol_steps || ((*t.pol_steps) % t.pol_period) == 0);
     if (vec && t.nslab) {
         // split-K partial gradients finished here (AdamTask::Slab): all partials in flight together, summed in split order (the order of
@@ -518,6 +521,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
+                                                   const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, AdamTask t,
+                                                   const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, SlotFill sf2, int fill2_blocks, AdamSnap snap, int snap_blocks) {
+    __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
+    adam_block(blockIdx.x, ap, agr, am, av, agrp, atarget, an, hdr, t, fin, nfin, sf, fill_blocks, sf2, fill2_blocks, snap, snap_blocks);
+}
+
+// The optimizer launch of feature step k AND the first launch of feature step k + 1: blocks [0, gtiles) are 16 x 16 tiles of the
+// next step's first layers (encoder.l1 / f.l1: their weights were already updated in step k's weight-gradient epilogues, FLAG_ADAM, and
+// their input rows come straight from the replay ring through the index pool -- the minibatch slot itself is being gathered by the fill
+// blocks of this very launch); the blocks behind them are an ordinary optimizer launch that skips those two layers (AdamTask::skip_*).
+// The two parts share nothing: one dependent launch less per feature step.
+__global__ __launch_bounds__(256) void adam_l1_kernel(float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
+                                                      const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, int gtiles, int tb1, int tcs0, int tcs1,
+                                                      AdamTask t, const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, GemmTask g0, GemmTask g1) {
+    __shared__ float red[4][1][4][64];
+    __shared__ float bsum[4][16];
+    __builtin_amdgcn_s_setprio(3);
+    const int bid = blockIdx.x;
+    if (bid < gtiles) {
+        const bool second = bid >= tb1;
+        const GemmTask& gt = second ? g1 : g0;
+        const int local = second ? bid - tb1 : bid, tiles_c = second ? tcs1 : tcs0;
+        const int tr = local / tiles_c, tc = local - tr * tiles_c;
+#ifdef RL_TIMING
+        gemm16_tile<LD_ROW, LD_ROW, 1, false, false, false, false, GemmTask, EPI_FWD, ACT_RELU, true>(gt, tr, tc, red, bsum, nullptr, nullptr);
+#else
+        gemm16_tile<LD_ROW, LD_ROW, 1, false, false, false, false, GemmTask, EPI_FWD, ACT_RELU, true>(gt, tr, tc, red, bsum, nullptr);
+#endif
+        return;
+    }
+    SlotFill none2 = SlotFill(); AdamSnap nosnap = AdamSnap();
+    adam_block(bid - gtiles, ap, agr, am, av, agrp, atarget, an, hdr, t, fin, nfin, sf, fill_blocks, none2, 0, nosnap, 0);
 }
 
 __global__ __launch_bounds__(256) void polyak_kernel(PolyakTask t) {
@@ -617,6 +655,31 @@ extern "C" int rl_launch_adam(const AdamTask* task, int adam_blocks, const FinTa
     const int hdr = adam_blocks | (vec_ok ? (1 << 30) : 0);
     hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, t,
                        fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb);
+    return (int)hipGetLastError();
+}
+// optimizer launch of one group + the two first-layer tasks of the NEXT feature step as leading tiles (adam_l1_kernel); sf: the gather of that
+// step's minibatch (must be armed: the tiles read the same ring rows through sf->idx)
+extern "C" int rl_launch_adam_l1(const AdamTask* task, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const GemmTask* g0, const GemmTask* g1, hipStream_t st) {
+    if (!task || adam_blocks <= 0 || !sf || !sf->ring || !sf->idx || !g0 || !g1) return -7;
+    AdamTask t = *task;
+    if (t.n >= (1ll << 31) || adam_blocks >= (1 << 30)) return -5;
+    const int fb = grid_for((long long)sf->B * (2 * sf->S + sf->A + 2), 256, 2048);
+    const bool vec_ok = ((t.pol_off & 3) == 0) && ((t.pol_n & 3) == 0) &&
+                        (((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v) | ((uintptr_t)t.target)) & 15) == 0);
+    if (!vec_ok || (t.n & 3) || t.nslab) return -6;            // (skip ranges are honoured on the 16-byte path)
+    GemmTask a = *g0, b = *g1;
+    const int row_w = 2 * sf->S + sf->A + 2;
+    for (GemmTask* q : {&a, &b}) {
+        if (q->epi != EPI_FWD || q->act != ACT_RELU || q->K > row_w || q->R != sf->B) return -7;
+        q->A = sf->ring; q->lda = row_w; q->gidx = sf->idx;
+        q->tiles_c = (q->Cn + 15) / 16; q->ntiles = ((q->R + 15) / 16) * q->tiles_c;
+        rl_gemm16_plan(*q);
+    }
+    a.tile_base = 0; b.tile_base = a.ntiles;
+    const int gtiles = a.ntiles + b.ntiles;
+    const int hdr = adam_blocks | (1 << 30);
+    hipLaunchKernelGGL(adam_l1_kernel, dim3(gtiles + adam_blocks + 1 + fb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, gtiles, b.tile_base,
+                       a.tiles_c, b.tiles_c, t, fin, nfin, *sf, fb, a, b);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st) {

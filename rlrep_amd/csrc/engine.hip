@@ -550,7 +550,18 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         if (probe.blocks > 256 * per_cu) use_rp = false;
         for (auto& pr : probe.progs) if (pr.op_end - pr.op_begin > 40) use_rp = false;
     }
-    auto feature_program = [&](Program& p, bool early) {
+    auto with_adam = [&](GemmTask t, bool on, float* tw, float* tb) {
+        if (!on || !ag->a.grad_dev || !t.C) return t;
+        const int64_t ow = t.C - ag->a.grad_dev, ob = t.out2 - ag->a.grad_dev;
+        t.flags |= FLAG_ADAM;
+        t.ad_p = ag->a.param_dev + ow; t.ad_m = ag->a.exp_avg_dev + ow; t.ad_v = ag->a.exp_avg_sq_dev + ow; t.ad_t = tw;
+        t.ad_pb = ag->a.param_dev + ob; t.ad_mb = ag->a.exp_avg_dev + ob; t.ad_vb = ag->a.exp_avg_sq_dev + ob; t.ad_tb = tb;
+        t.ad_grp = ag->adam_step + 0;
+        return t;
+    };
+    // fuse_l1: the weight-gradient tasks of encoder.l1 / f.l1 run their optimizer (and f.l1's Polyak into f_target.l1) in the epilogue
+    // (FLAG_ADAM): the variant whose optimizer launch carries the next step's first layers (rlrep_feature_chain_next)
+    auto feature_program = [&](Program& p, bool early, bool fuse_l1 = false) {
         GemmTask te[3], tf[3];
         gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
         gauss_tasks(ag, false, "f", s0.XF, SA, SA, gf, tf);
@@ -622,8 +633,9 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                        Builder::dw(GFH, 2 * F, 2 * F, gf.H2, Hv, Hv, B, Gw("f.mean_linear.weight"), Hv, Gw("f.mean_linear.bias")),
                        Builder::dw(GH2e, Hv, Hv, ge.H1, Hv, Hv, B, Gw("encoder.l2.weight"), Hv, Gw("encoder.l2.bias")),
                        Builder::dw(GH2f, Hv, Hv, gf.H1, Hv, Hv, B, Gw("f.l2.weight"), Hv, Gw("f.l2.bias")),
-                       Builder::dw(GH1e, Hv, Hv, s0.XE, KE, KE, B, Gw("encoder.l1.weight"), KE, Gw("encoder.l1.bias")),
-                       Builder::dw(GH1f, Hv, Hv, s0.XF, SA, SA, B, Gw("f.l1.weight"), SA, Gw("f.l1.bias"))}, "feature dW");
+                       with_adam(Builder::dw(GH1e, Hv, Hv, s0.XE, KE, KE, B, Gw("encoder.l1.weight"), KE, Gw("encoder.l1.bias")), fuse_l1, nullptr, nullptr),
+                       with_adam(Builder::dw(GH1f, Hv, Hv, s0.XF, SA, SA, B, Gw("f.l1.weight"), SA, Gw("f.l1.bias")), fuse_l1,
+                                 nft ? nullptr : Tw("f_target.l1.weight"), nft ? nullptr : Tw("f_target.l1.bias"))}, fuse_l1 ? "feature dW (+ adam l1)" : "feature dW");
     };
     feature_program(ag->feat_bwd, false);
     const bool can_hoist = policy_fusable(ag) && !getenv("RLREP_NO_HOIST");
@@ -643,6 +655,19 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         const int64_t fn = flast.off + flast.rows - f0.off;
         if (nft) b.adam(ag->feat_apply, 0, ag->h.lr_feature, nullptr, 0, 0, 0.f, feat_fins, "adam feature");
         else b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau, feat_fins, "adam feature + polyak f");
+        // chained form (rlrep_feature_chain_next): first layers' optimizer in the weight-gradient epilogues, the rest + the NEXT step's first layers in one launch
+        if (!use_rp && !Builder::chain_enabled() && ag->h.world_size <= 1 && ag->nsh[0] == 0 && !getenv("RLREP_NO_CHAIN_NEXT")) {
+            feature_program(ag->feat_bwd_m, false, true);
+            GemmTask te[3], tf[3];
+            gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
+            gauss_tasks(ag, false, "f", s0.XF, SA, SA, gf, tf);
+            const LT& ew = ag->L.get("encoder.l1.weight"); const LT& eb = ag->L.get("encoder.l1.bias");
+            const LT& fw = ag->L.get("f.l1.weight"); const LT& fb = ag->L.get("f.l1.bias");
+            const int64_t g0 = ag->L.group_off[0];
+            b.adam_l1(ag->feat_apply_m, 0, ag->h.lr_feature, nft ? nullptr : Tw("f_target.l1.weight"), f0.off, nft ? 0 : fn, nft ? 0.f : ag->h.feature_tau, feat_fins,
+                      ew.off - g0, eb.off + eb.rows - ew.off, fw.off - g0, fb.off + fb.rows - fw.off, te[0], tf[0],
+                      "adam feature (- l1) + polyak f | next enc.l1 f.l1");
+        }
     }
 
     // ---- critic / actor shared buffers ----
@@ -901,11 +926,12 @@ void defer_end(Builder& b, rlrep_agent* ag, int set, const Slot& keep, const std
 static int build_programs(rlrep_agent* ag, int B) {
     ag->B = B;
     ag->ws.used = ag->ws_static;
-    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2})
+    for (Program* p : {&ag->feat_bwd, &ag->feat_apply, &ag->critic_bwd, &ag->critic_apply, &ag->actor_bwd, &ag->actor_apply, &ag->upd_target, &ag->infer, &ag->sync_prog, &ag->critic_bwd_h, &ag->critic_apply_f, &ag->feat_bwd_h, &ag->critic_bwd_h2, &ag->feat_bwd_m, &ag->feat_apply_m})
         p->stages.clear();
     for (auto& D : ag->dset) for (Program* p : {&D.critic_bwd, &D.critic_apply, &D.actor_bwd}) p->stages.clear();
     ag->infer_n = 0; ag->actor_resume = 0; ag->pi_ready = ag->hoist_req = nullptr; ag->in_train = ag->target_done = false;
     ag->pf_armed = ag->pf_done = false; ag->pf2_armed = ag->pf2_done = false;
+    ag->chain_next = ag->chain_bwd_done = ag->l1_done = false;
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     ag->feat_cuts.clear();
     Builder b(ag);
@@ -1239,6 +1265,7 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
         rl_set_error("train_prologue: bad argument"); return RLREP_ERR_ARG;
     }
     ag->pi_ready = nullptr; ag->hoist_req = nullptr; ag->pf_armed = false; ag->pf_done = false; ag->pf2_armed = false; ag->pf2_done = false;
+    ag->chain_next = ag->chain_bwd_done = ag->l1_done = false;
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;
@@ -1268,7 +1295,7 @@ int32_t rlrep_replay_sample(rlrep_agent* ag, int32_t slot, const float* ring_dev
         ag->pf2_done = false;                                  // gathered by the previous optimizer launch (rlrep_prefetch_batch_slot)
         return 0;
     }
-    if (slot == 0) ag->pf_done = false; else ag->pf2_done = false;
+    if (slot == 0) { ag->pf_done = false; ag->l1_done = false; ag->chain_next = false; } else ag->pf2_done = false;
     ag->pi_ready = nullptr; ag->hoist_req = nullptr;           // a new batch invalidates any prefetched policy forward
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);
@@ -1338,7 +1365,12 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (!ag->in_train && rl_rowprog_enabled() && ag->rp_epoch) (void)(++g_rl_launches, rl_launch_counter_inc(ag->rp_epoch, (hipStream_t)stream));   // a fresh epoch whatever ran before
     ag->pi_ready = nullptr;                                       // f_target is about to change
     ag->early_ready_crit = ag->early_ready_act = nullptr;
+    // chained feature steps: the previous step's optimizer launch already ran this step's first stage (encoder.l1 / f.l1)
+    const size_t first = ag->l1_done ? 1 : 0;
+    const bool chain = ag->chain_next;
+    ag->l1_done = false; ag->chain_next = false; ag->chain_bwd_done = false;
     if (ag->early_crit && !ag->feat_bwd_h.stages.empty()) {
+        if (first || chain) { rl_set_error("feature step: rlrep_feature_chain_next cannot be combined with rlrep_prefetch_policy_early"); return RLREP_ERR_STATE; }
         ag->cur_eps3 = ag->early_crit; ag->cur_eps2 = ag->early_act;
         ag->early_crit = ag->early_act = nullptr;
         const int rc = run(ag, ag->feat_bwd_h, stream);
@@ -1346,9 +1378,33 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
         return rc;
     }
     ag->early_crit = ag->early_act = nullptr;
-    return run(ag, ag->feat_bwd, stream);
+    if (!ag->slot[0].filled) { rl_set_error("step before set_batch / replay_sample"); return RLREP_ERR_STATE; }
+    const Program& p = chain ? ag->feat_bwd_m : ag->feat_bwd;
+    ag->last_launches += (int)(p.stages.size() - first);
+    const int rc = p.run((hipStream_t)stream, first);
+    if (rc == 0 && chain) ag->chain_bwd_done = true;
+    return rc;
 }
-int32_t rlrep_feature_apply(rlrep_agent* ag, void* stream) { STEP_PROLOGUE(true) return run(ag, ag->feat_apply, stream); }
+int32_t rlrep_feature_apply(rlrep_agent* ag, void* stream) {
+    STEP_PROLOGUE(true)
+    if (ag->chain_bwd_done) {          // the first layers' optimizer already ran (weight-gradient epilogues): the launch that skips them and runs the next step's head
+        ag->chain_bwd_done = false;
+        const int rc = run(ag, ag->feat_apply_m, stream);
+        if (rc == 0) ag->l1_done = true;
+        return rc;
+    }
+    return run(ag, ag->feat_apply, stream);
+}
+// The NEXT feature step will follow this one directly, on the minibatch armed by rlrep_prefetch_batch: chain them (rlrep_agent::feat_bwd_m).
+// Call between rlrep_prefetch_batch and this step's rlrep_feature_backward / rlrep_feature_step.  1: armed; 0: not available for this agent
+// (the step then runs as usual).  The caller must indeed run that next step next, with plain rlrep_feature_backward (no early policy).
+int32_t rlrep_feature_chain_next(rlrep_agent* ag) {
+    if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
+    ag->chain_next = false;
+    if (ag->feat_bwd_m.stages.empty() || ag->feat_apply_m.stages.empty() || !ag->pf_armed || ag->snap_armed) return 0;
+    ag->chain_next = true;
+    return 1;
+}
 int32_t rlrep_prefetch_policy_early(rlrep_agent* ag, const float* eps_critic, const float* eps_actor) {
     if (!ag) { rl_set_error("null agent"); return RLREP_ERR_ARG; }
     ag->early_crit = ag->early_act = nullptr;

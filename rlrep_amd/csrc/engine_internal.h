@@ -34,6 +34,11 @@ struct rlrep_agent {
     // forwards (on s' for the critic step, on s for the actor step) ride in that feature step's first three launches
     // (feat_bwd_h) and the critic step starts with all three f_target forwards in the same launches (critic_bwd_h2).
     Program feat_bwd_h, critic_bwd_h2;
+    // CHAINED feature steps (rlrep_feature_chain_next; vlsac, single GPU): when the next feature step follows directly on the minibatch armed by
+    // rlrep_prefetch_batch, this step's weight-gradient launch runs the optimizer of the two FIRST layers in its epilogues (feat_bwd_m: the
+    // plain program with FLAG_ADAM on those tasks), and its optimizer launch (feat_apply_m) skips them and carries the next step's first
+    // launch -- encoder.l1 / f.l1 on rows read straight from the ring -- as leading tiles; the next step then starts at its second stage.
+    Program feat_bwd_m, feat_apply_m; bool chain_next = false, chain_bwd_done = false, l1_done = false;
     const float* cur_eps3 = nullptr; const float* early_crit = nullptr; const float* early_act = nullptr;   // armed request
     const float* early_ready_crit = nullptr; const float* early_ready_act = nullptr;                        // done by feat_bwd_h
     // DEFERRED critic / actor steps (vlsac): the feature steps of train(t+1) read nothing the critic and actor steps of train(t)
@@ -463,6 +468,35 @@ struct Builder {
             return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, st);
         }, what});
         tag(p, RLREP_ENGINE_OPTIMIZER, 0.0, 28.0 * (double)t.n + 12.0 * (double)(target ? pol_n : 0));     // read p, g, m, v; write p, m, v (+ target: read, read source, write)
+    }
+    // optimizer launch of `group` that skips [skip0, skip0 + n0) and [skip1, skip1 + n1) (group-relative; their Adam ran in the weight-gradient
+    // epilogues) and carries the next step's two first-layer tasks as leading tiles (elementwise.hip adam_l1_kernel)
+    void adam_l1(Program& p, int group, float lr, float* target, int64_t pol_off, int64_t pol_n, float tau, std::vector<FinTask> fin,
+                 int64_t skip0, int64_t n0, int64_t skip1, int64_t n1, GemmTask g0, GemmTask g1, const char* what) {
+        const auto& L = ag->L;
+        AdamTask t; memset(&t, 0, sizeof(t));
+        const int64_t off = L.group_off[group];
+        t.p = ag->a.param_dev ? ag->a.param_dev + off : nullptr;
+        t.g = ag->a.grad_dev ? ag->a.grad_dev + off : nullptr;
+        t.m = ag->a.exp_avg_dev ? ag->a.exp_avg_dev + off : nullptr;
+        t.v = ag->a.exp_avg_sq_dev ? ag->a.exp_avg_sq_dev + off : nullptr;
+        t.n = L.group_n[group];
+        t.lr = lr; t.beta1 = ag->h.beta1; t.beta2 = ag->h.beta2; t.eps = ag->h.adam_eps;
+        t.grp = ag->adam_step + group;
+        t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = nullptr; t.pol_period = 1;
+        t.nskip = 2; t.skip_off[0] = skip0; t.skip_n[0] = n0; t.skip_off[1] = skip1; t.skip_n[1] = n1;
+        if (!fin.empty() && fin.back().kind == FIN_HISTORY) fin.pop_back();
+        const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
+        const int nfin = (int)fin.size();
+        const int blocks = (int)((t.n + 1023) / 1024);
+        rlrep_agent* a = ag;
+        p.stages.push_back({[=](hipStream_t st) {
+            if (!a->pf_armed) return -8;                     // (rlrep_feature_chain_next refuses to arm without a prefetched minibatch)
+            const SlotFill sf = a->pf_fill;
+            a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; a->early_ready_crit = a->early_ready_act = nullptr;
+            return rl_launch_adam_l1(&t, blocks, fdev, nfin, &sf, &g0, &g1, st);
+        }, what});
+        tag(p, RLREP_ENGINE_OPTIMIZER, 0.0, 28.0 * (double)(t.n - n0 - n1) + 12.0 * (double)(target ? pol_n : 0));
     }
     // metric finalisation without an optimizer (diffsrsac's critic step: quirk Q11, its optimizer is a no-op)
     void finalize_only(Program& p, std::vector<FinTask> fin, const char* what) {

@@ -228,9 +228,20 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         if (all_vec(*gb, false)) { if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, true, false>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_COL, 2, true, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
         else if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);
     } else if (la == LD_COL && lb == LD_COL) {
-        // weight gradients with nothing to accumulate into: the instantiation without slot loads
-        bool plain = !getenv("RLREP_GEMM16_GENERIC");
-        for (int q = 0; q < gb->ntasks; ++q) plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM);
+        // weight gradients with nothing to accumulate into: the instantiation without slot loads; with the optimizer in some tasks'
+        // epilogues (FLAG_ADAM): the instantiation that loads the parameter / moment slots (EPI_DWA)
+        bool plain = !getenv("RLREP_GEMM16_GENERIC"), opt = false;
+        for (int q = 0; q < gb->ntasks; ++q) {
+            plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM);
+            if (gb->t[q].flags & FLAG_ADAM) { opt = true; if (!gb->t[q].ad_p || !gb->t[q].ad_grp) return -3; }
+        }
+        if (opt) {
+            if (!plain) return -3;
+            if (nf == 4) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 4, false, false, false, EPI_DWA, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else if (nf == 2) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 2, false, false, false, EPI_DWA, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 1, false, false, false, EPI_DWA, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            return (int)hipGetLastError();
+        }
         if (plain && nf == 4) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 4, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
         else if (plain && nf == 2) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 2, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
         else if (plain && nf == 1) hipLaunchKernelGGL((gemm16_kernel<LD_COL, LD_COL, 1, false, false, false, EPI_DW, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));

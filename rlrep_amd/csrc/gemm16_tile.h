@@ -67,14 +67,16 @@ __device__ __forceinline__ void mask_frag(int base, int lim, int i, int k0, int 
 // NU 16-wide inner chunks of wave w (NU = 4 covers K <= 256 in one go): EVERY load of the group is issued before
 // anything consumes one (hipcc otherwise sinks each load next to its MFMA and drains vmcnt(0) in between: eight
 // serialised L2 round trips instead of one)
-template <int LA, int LB, int NF, bool VA, bool VB, int NU, bool COH = false>
+// GA: A is this lane's ROW already (gathered rows: GemmTask::gidx), not the matrix base
+template <int LA, int LB, int NF, bool VA, bool VB, int NU, bool COH = false, bool GA = false>
 __device__ __forceinline__ void mac_group(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                           int r0, int R, int c0, int Cn, int i, int k0, int K,
                                           f32x4 (&acc)[NF], float& asum, bool want_bias) {
     float a[NU][4], b[NU][NF][4];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        load_raw<LA, VA, COH>(A, lda, r0, R, i, k0 + 64 * u, K, a[u]);
+        if (GA) load_raw<LA, VA, COH>(A, lda, 0, 1, 0, k0 + 64 * u, K, a[u]);
+        else load_raw<LA, VA, COH>(A, lda, r0, R, i, k0 + 64 * u, K, a[u]);
 #pragma unroll
         for (int f = 0; f < NF; ++f) load_raw<LB, VB>(B, ldb, c0 + 16 * f, Cn, i, k0 + 64 * u, K, b[u][f]);
     }
@@ -188,14 +190,17 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // plain forward or dX epilogue runs an instantiation that contains nothing else: the generic body is ~2 900 instructions, and its
 // epilogue walks a ladder of far scalar branches through cold code (instruction-cache misses: 1 200 - 2 800 cycles between "reduction
 // barrier passed" and "tile stored" in tools/exp/gemm_timeline.py, for five VALU instructions and a store).
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1>
+// GATHER: operand-A rows come through the task's row-index table (gidx), e.g. straight out of the replay ring (forward launches that ride in
+// the optimizer launch of the previous step: the minibatch slot is being gathered by other workgroups of the same launch).
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
                                             const float* const* dyn RL_TIM_PARAM) {
     // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
     const float* const pA = t.A; const float* const pB = t.B; float* const pC = t.C; const float* const pbias = t.bias;
     const int lda = t.lda, ldb = t.ldb, ldc = t.ldc;
     const int R = t.R, Cn = t.Cn, K = t.K, tiles_c = t.tiles_c;
-    const int epi = EPI_K >= 0 ? EPI_K : t.epi, act = ACT_K >= 0 ? ACT_K : t.act, flags = t.flags, n0 = t.n0;
+    const int epi = EPI_K == EPI_DWA ? EPI_DW : EPI_K >= 0 ? EPI_K : t.epi, act = ACT_K >= 0 ? ACT_K : t.act, flags = t.flags, n0 = t.n0;
+    const int* const pgidx = GATHER ? t.gidx : nullptr;
     const float scale = t.scale;
     float* const pout2 = t.out2; const int ldout2 = t.ldout2;
     const float* sp[5]; int srs[5], scs[5], sof[5], slo[5], shi[5];
@@ -209,6 +214,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // (materialise the whole record HERE: left to itself hipcc loads each slot field next to its first use, between the operand loads,
     // with a scalar-load round trip in front of every one of them)
     asm volatile("" :: "s"(pA), "s"(pB), "s"(pC), "s"(pbias), "s"(lda), "s"(ldb), "s"(ldc), "s"(R), "s"(Cn), "s"(K), "s"(epi), "s"(act), "s"(flags), "s"(n0), "s"(scale));
+    if constexpr (GATHER) asm volatile("" :: "s"(pgidx));
     asm volatile("" :: "s"(sp[0]), "s"(sp[1]), "s"(sp[2]), "s"(sp[3]), "s"(sp[4]), "s"(srs[0]), "s"(srs[1]), "s"(srs[2]), "s"(srs[3]), "s"(srs[4]),
                  "s"(sof[0]), "s"(sof[1]), "s"(sof[2]), "s"(sof[3]), "s"(sof[4]));
     asm volatile("" :: "s"(slo[0]), "s"(slo[1]), "s"(slo[2]), "s"(slo[3]), "s"(slo[4]), "s"(shi[0]), "s"(shi[1]), "s"(shi[2]), "s"(shi[3]), "s"(shi[4]), "s"(scs0));
@@ -219,6 +225,9 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // divergent control flow -- saveexec ladders, accumulator copies through VGPRs, conservative waits at every merge)
     const int lane = threadIdx.x & 63, w = RL_UNIFORM_W ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     const int i = lane & 15, kq = lane >> 4;
+    // gathered rows: this lane's row of operand A (one dependent load, issued with the tile's first instructions)
+    const float* pArow = pA;
+    if constexpr (GATHER) pArow = pA + (size_t)pgidx[min(r0 + i, R - 1)] * lda;
 
     f32x4 acc[NF];
 #pragma unroll
@@ -244,7 +253,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         constexpr int q = decltype(qtag)::value;
 #pragma unroll
         for (int f = 0; f < NF; ++f) ev[q][f] = 0.f;
-        constexpr bool possible = EPI_K < 0 || (EPI_K == EPI_FWD && q == 0) || (EPI_K == EPI_DX && q < 4) ||
+        constexpr bool possible = EPI_K < 0 || (EPI_K == EPI_FWD && q == 0) || (EPI_K == EPI_DX && q < 4) || (EPI_K == EPI_DWA && q != 1) ||
                                   ((EPI_K == EPI_FWD_MSE || EPI_K == EPI_DX_REPARAM || EPI_K == EPI_DX_POLICYBWD) && q < 3) || (EPI_K == EPI_FWD_POLICY && q < 2);
         if constexpr (possible) {
             const bool used = sp[q] != nullptr;
@@ -260,6 +269,21 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     slot(std::integral_constant<int, 0>()); slot(std::integral_constant<int, 1>()); slot(std::integral_constant<int, 2>());
     slot(std::integral_constant<int, 3>()); slot(std::integral_constant<int, 4>());
 
+    // optimizer in the epilogue (EPI_DWA launches, tasks flagged FLAG_ADAM): Adam scalars of the group, and (column tile 0 only) the bias
+    // element this thread will update
+    AdamScal adsc;
+    bool fuse_opt = false, bias_opt = false;
+    float bpv = 0.f, bmv = 0.f, bvv = 0.f, btv = 0.f;
+    if constexpr (EPI_K == EPI_DWA) {
+        fuse_opt = (flags & FLAG_ADAM) && t.ad_p;
+        if (fuse_opt) adsc = t.ad_grp->sc;
+        bias_opt = want_bias && fuse_opt && t.ad_pb && threadIdx.x < 16 && r0 + (int)threadIdx.x < R;
+        if (bias_opt) {
+            const int o = r0 + threadIdx.x;
+            bpv = t.ad_pb[o]; bmv = t.ad_mb[o]; bvv = t.ad_vb[o];
+            if (t.ad_tb) btv = t.ad_tb[o];
+        }
+    }
     asm volatile("" ::: "memory");      // the pin (see above)
     TIMB(6);
 
@@ -282,10 +306,10 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     for (int kb = w * 16; kb < K; kb += 256) {
         const int k0 = kb + 4 * kq;
         const int nu = (K - kb + 63) >> 6;           // chunks of this group that touch the matrix (uniform per wave)
-        if (nu >= 4) mac_group<LA, LB, NF, VA, VB, 4, COH>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
-        else if (nu == 1) mac_group<LA, LB, NF, VA, VB, 1, COH>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
-        else if (nu == 2) mac_group<LA, LB, NF, VA, VB, 2, COH>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
-        else mac_group<LA, LB, NF, VA, VB, 3, COH>(pA, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        if (nu >= 4) mac_group<LA, LB, NF, VA, VB, 4, COH, GATHER>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        else if (nu == 1) mac_group<LA, LB, NF, VA, VB, 1, COH, GATHER>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        else if (nu == 2) mac_group<LA, LB, NF, VA, VB, 2, COH, GATHER>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
+        else mac_group<LA, LB, NF, VA, VB, 3, COH, GATHER>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, k0, K, acc, asum, want_bias);
     }
 
     TIMB(2);
@@ -320,6 +344,11 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         const int q = threadIdx.x;
         const float gbv = ((bsum[0][q] + bsum[1][q]) + bsum[2][q]) + bsum[3][q];
         pout2[r0 + q] = gbv;
+        if (bias_opt) {
+            adam_elem(adsc, gbv, &bpv, &bmv, &bvv, t.ad_tb ? &btv : nullptr);
+            t.ad_pb[r0 + q] = bpv; t.ad_mb[r0 + q] = bmv; t.ad_vb[r0 + q] = bvv;
+            if (t.ad_tb) t.ad_tb[r0 + q] = btv;
+        }
     }
 
     if (epi == EPI_FWD_MSE) {
@@ -418,9 +447,17 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
             cp[t.F] = cold2[f] + v * e0[f];
             break;
         case EPI_DW:
-        default:
-            *cp = cold[f] + v;
-            break;
+        default: {
+            const float g = cold[f] + v;
+            *cp = g;
+            if (fuse_opt) {      // e0 / cold2 / cold3 / cold4 = parameter, exp_avg, exp_avg_sq, Polyak target (prefetched with the other slots)
+                const size_t o = (size_t)r * ldc + c;
+                float pv = e0[f], mv = cold2[f], vv = cold3[f], tv = cold4[f];
+                adam_elem(adsc, g, &pv, &mv, &vv, t.ad_t ? &tv : nullptr);
+                t.ad_p[o] = pv; t.ad_m[o] = mv; t.ad_v[o] = vv;
+                if (t.ad_t) t.ad_t[o] = tv;
+            }
+        } break;
         }
     }
 }

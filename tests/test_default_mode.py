@@ -305,6 +305,40 @@ def test_snapshot_rides_in_the_last_feature_optimizer_launch(monkeypatch):
     assert counts[False] == counts[True] + 1, counts
 
 
+def test_chained_feature_steps_change_nothing(monkeypatch):
+    """rlrep_feature_chain_next (vlsac_agent.py:250-256's loop of feature steps, chained): the first layers' optimizer runs in the weight-gradient
+    epilogues and the step's optimizer launch carries the next step's encoder.l1 / f.l1 on rows read straight from the ring.  Against
+    RLREP_NO_CHAIN_NEXT=1 (every step its own ten launches): three launches fewer in the captured feature graph, and parameters, moments and
+    targets BIT-identical after 30 pipelined train() calls at the headline dims (adam_elem's operations are pinned for exactly this); both
+    forms against the oracle."""
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
+    c = Case('vlsac_hc')
+    data = synth.replay(17, 6, 8192, seed=0)
+    outs, counts = [], {}
+    for chained in (True, False):
+        if not chained:
+            monkeypatch.setenv('RLREP_NO_CHAIN_NEXT', '1')
+        torch.manual_seed(0)
+        agent = VLSACAgent(state_dim=17, action_dim=6, action_space=_Space(6, 1.0), max_batch=256, pipeline=True, seed=77,
+                           hidden_dim=256, feature_dim=256, extra_feature_steps=3)
+        buf = ReplayBuffer(17, 6, max_size=8192)
+        buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+        for _ in range(30):
+            agent.train(buf, 256)
+        agent.flush()
+        counts[chained] = agent._pipe['launches'][0]
+        st = {k: v.numpy().copy() for k, v in agent.core.state().items()}
+        st['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy(); st['exp_avg_sq'] = agent.core.exp_avg_sq.cpu().numpy().copy()
+        outs.append(st)
+        del agent, buf
+        _check_against_oracle(c, calls=3, expect_pipeline=True)
+    assert counts[False] == counts[True] + 3, counts
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 def test_noise_critic_weight_images_follow_external_parameter_writes():
     """vlsac at the headline dims runs its noise critic from bf16x3 images of critic.l1 / l4 and of their target copies (ShadowEnt kind 1).
     The live images are kept by the critic group's Adam launch and ALL of them are regenerated at the head of every critic step: parameters
