@@ -319,6 +319,23 @@ const float* rlrep_metrics_dev(rlrep_agent* agent);
 /* Profiling hook: launch stage `stage` of step program `program` once (0 feature_bwd, 1 feature_apply,
  * 2 critic_bwd, 3 critic_apply, 4 actor_bwd, 5 actor_apply, 6 update_target); its inputs are whatever the
  * previous full step left in the workspace.  rlrep_stage_count/_name enumerate the stages. */
+/* ---- one-shot gradient all-reduce over peer-mapped inboxes (csrc/comm.hip) ------------------------------------
+ * No reference counterpart (the reference is a single process).  The latency-shaped alternative to RCCL's ring for the <= 2 MB gradient
+ * slices: every rank pushes its slice into its slot of EVERY rank's inbox (hipIpc-mapped, all links at once), signals, waits for the
+ * others' signals (bounded) and adds the slots in rank order -- bit-identical sums on every rank.  Set-up: create -> handle -> (exchange the
+ * handles, world x rlrep_comm_handle_bytes() in rank order, by any means: torch.distributed.all_gather_object) -> connect.
+ * rlrep_comm_allreduce is stream-ordered (three launches) and must be called by every rank with the same n in the same order;
+ * rlrep_comm_status synchronises the stream and reports a timed-out wait.  Opt-in: rlrep_amd/comm.py, RLREP_ONESHOT_ALLREDUCE=1. */
+typedef struct rlrep_comm rlrep_comm;
+int32_t rlrep_comm_create(int32_t rank, int32_t world, int64_t slot_floats, rlrep_comm** out);
+int32_t rlrep_comm_handle_bytes(void);
+int32_t rlrep_comm_handle(rlrep_comm* comm, void* out, int32_t cap);
+int32_t rlrep_comm_connect(rlrep_comm* comm, const void* handles);
+int32_t rlrep_comm_allreduce(rlrep_comm* comm, float* data_dev, int64_t n, int64_t timeout_spins, void* stream);
+int32_t rlrep_comm_status(rlrep_comm* comm, uint32_t* late_mask, void* stream);
+int32_t rlrep_comm_fine_grained(rlrep_comm* comm);
+void rlrep_comm_destroy(rlrep_comm* comm);
+
 /* vlsac noise-critic weight images (bf16x3 shadows of critic.l1 / l4 and their targets; no reference counterpart: nn.Linear has no such
  * copies).  Default: every critic step regenerates them with one launch.  Between rlrep_images_managed(agent, 1) and (agent, 0) the step
  * entry points skip that launch (inside a rlrep_begin_train .. rlrep_update_target bracket the critic group's optimizer launch keeps live and

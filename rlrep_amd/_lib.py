@@ -121,6 +121,14 @@ def _load():
         'rlrep_images_managed': (i32, [vp, i32]),
         'rlrep_refresh_images': (i32, [vp, vp]),
         'rlrep_feature_chain_next': (i32, [vp]),
+        'rlrep_comm_create': (i32, [i32, i32, i64, P(vp)]),
+        'rlrep_comm_handle_bytes': (i32, []),
+        'rlrep_comm_handle': (i32, [vp, vp, i32]),
+        'rlrep_comm_connect': (i32, [vp, vp]),
+        'rlrep_comm_allreduce': (i32, [vp, vp, i64, i64, vp]),
+        'rlrep_comm_status': (i32, [vp, P(C.c_uint32), vp]),
+        'rlrep_comm_fine_grained': (i32, [vp]),
+        'rlrep_comm_destroy': (None, [vp]),
         'rlrep_stage_count': (i32, [vp, i32]),
         'rlrep_stage_name': (C.c_char_p, [vp, i32, i32]),
         'rlrep_run_stage': (i32, [vp, i32, i32, vp]),

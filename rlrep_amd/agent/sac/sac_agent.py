@@ -417,7 +417,25 @@ class SACAgent(object):
         o, n = lay.group_offset[group], lay.group_floats[group]
         end = lay.grad_floats if with_tail else o + n
         view = self.core.grads[o:end]
+        one = self._oneshot(view, pg)
+        if one is not None:
+            self._collective(lambda: one.all_reduce(view))            # (plain kernel launches: they record into a hipGraph like any other stage)
+            return
         self._collective(lambda: dist.all_reduce(view, group=pg))
+
+    def _oneshot(self, view, pg):
+        """RLREP_ONESHOT_ALLREDUCE=1: the one-shot all-reduce over peer-mapped inboxes (rlrep_amd/comm.py) for gradient slices up
+        to RLREP_ONESHOT_MAX_MB (default 4) -- opt-in until it has been timed on a multi-GPU node; larger slices and the default go through
+        torch.distributed (RCCL).  The object is created at the first use: a collective, reached by every rank at the same all-reduce."""
+        if self.world_size <= 1 or os.environ.get('RLREP_ONESHOT_ALLREDUCE') != '1' or pg is not None:
+            return None
+        cap = int(float(os.environ.get('RLREP_ONESHOT_MAX_MB', '4')) * (1 << 20)) // 4
+        if view.numel() > cap or (view.data_ptr() & 15):
+            return None
+        if getattr(self, '_oneshot_comm', None) is None:
+            from rlrep_amd.comm import OneShotAllReduce
+            self._oneshot_comm = OneShotAllReduce(cap)
+        return self._oneshot_comm
 
     def _collective(self, fn):
         """Run a torch.distributed call now, or -- while a data-parallel train() is being captured -- either record it into the open

@@ -17,7 +17,7 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $EXTRA_FLAGS"
 pids=()
-for f in gemm16 gemm_lds noisecritic elementwise replearn $EXP_SRCS engine agents2 $EXTRA_SRCS; do
+for f in gemm16 gemm_lds noisecritic elementwise replearn comm $EXP_SRCS engine agents2 $EXTRA_SRCS; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$OBJ/$f.o")" ] || [ "$HERE/../../include/rlrep.h" -nt "$OBJ/$f.o" ]; then
     PF=""; { [ "$f" = gemm16 ] || [ "$f" = elementwise ]; } && PF="-mllvm -amdgpu-kernarg-preload-count=14"     # gemm16_kernel / adam_kernel: leading scalars preloaded into SGPRs
     $HIPCC $FLAGS $PF -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
@@ -25,6 +25,6 @@ for f in gemm16 gemm_lds noisecritic elementwise replearn $EXP_SRCS engine agent
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-LINK=""; for f in gemm16 gemm_lds noisecritic elementwise replearn $EXP_SRCS engine agents2 $EXTRA_SRCS; do LINK="$LINK $OBJ/$f.o"; done
+LINK=""; for f in gemm16 gemm_lds noisecritic elementwise replearn comm $EXP_SRCS engine agents2 $EXTRA_SRCS; do LINK="$LINK $OBJ/$f.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIBNAME" $LINK
 echo "built $OUT/$LIBNAME"
