@@ -484,6 +484,7 @@ def main():
     ap.add_argument('--dp-form', choices=['segments', 'captured'], default=None,
                     help='N > 1 on RCCL: hipGraph segments around eager all-reduces (default: the form the two-rank tests run) or the all-reduces '
                          'captured into the train() graph (RLREP_DP_CAPTURE=1; rehearsed with one rank only).  Read before any GPU call.')
+    ap.add_argument('--quick', action='store_true', help='only the warm-up and the --steps window (no median repeats, no add / metric-fetch / main-loop legs): profiler runs')
     ap.add_argument('--pmc-json', default=None, help='PMC summary to take roofline.traffic from (default: the latest profiles/r*_pmc_<workload>.json)')
     args = ap.parse_args()
     if args.dp_form is not None:
@@ -543,6 +544,14 @@ def main():
         torch.manual_seed(rank)
     agent = make_agent(alg, S, A, B, kw)
     buf, data = synth_buffer(S, A, seed=rank)
+    # every train() call of this process is counted: a rocprofv3 kernel-stats / PMC table of the same command divides its `Calls` by it
+    n_calls = [0]
+    _train = agent.train
+
+    def _counted(*a, **k):
+        n_calls[0] += 1
+        return _train(*a, **k)
+    agent.train = _counted
 
     def barrier():
         torch.cuda.synchronize()
@@ -573,7 +582,8 @@ def main():
     rep_len = 500 if dt / args.steps < 2e-3 else max(20, min(args.steps, 100))
     smi = _start_clock_probe(clock_helper) if rank == 0 else None
     rep_rates = []
-    for _ in range(5):
+    quick = args.quick          # profiler runs: only the warm-up and the --steps window (clean launch counts, short traces)
+    for _ in range(0 if quick else 5):
         barrier()
         tr = time.perf_counter()
         for _ in range(rep_len):
@@ -590,7 +600,7 @@ def main():
     info = agent.train(buf, B)
     finite = all(np.isfinite(float(v)) for v in info.values())
     # the same loop with the metric dict READ after every train() (a device sync per call, as the reference's .item()s do)
-    n_sync = min(args.steps, 300)
+    n_sync = 0 if quick else min(args.steps, 300)
     barrier()
     t1 = time.perf_counter()
     for _ in range(n_sync):
@@ -599,9 +609,9 @@ def main():
     dt_sync = time.perf_counter() - t1
     # ... and with a ReplayBuffer.add() before every train() (main.py:137-144's call pattern without the env step: the staged row and the size
     # scalar travel to the device ring inside the timed loop)
-    n_add = min(args.steps, 500)
+    n_add = 0 if quick else min(args.steps, 500)
     zs, za = np.zeros(S, np.float32), np.zeros(A, np.float32)
-    for _ in range(20):
+    for _ in range(0 if quick else 20):
         buf.add(zs, za, zs, 0.0, 0.0); agent.train(buf, B)
     agent.flush()
     barrier()
@@ -613,7 +623,7 @@ def main():
     barrier()
     dt_add = time.perf_counter() - t2
     # ... and main.py:126-144's whole iteration without the environment step: select_action (needs the finished actor: a device sync), add, train
-    n_loop = min(args.steps, 300) if world == 1 else 0
+    n_loop = min(args.steps, 300) if (world == 1 and not quick) else 0
     dt_loop = None
     if n_loop:
         for _ in range(10):
@@ -692,12 +702,13 @@ def main():
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B_global if strong else value * B, 1),
             'metrics_finite': bool(finite),
-            'value_with_per_step_metric_fetch': round((1 if strong else world) * n_sync / dt_sync, 2),
-            'value_with_replay_add_per_call': round((1 if strong else world) * n_add / dt_add, 2),
+            'total_train_calls': n_calls[0],
+            'value_with_per_step_metric_fetch': (round((1 if strong else world) * n_sync / dt_sync, 2) if n_sync else None),
+            'value_with_replay_add_per_call': (round((1 if strong else world) * n_add / dt_add, 2) if n_add else None),
             'main_loop_iterations_per_sec': (round(n_loop / dt_loop, 2) if dt_loop else None),        # select_action + add + train, no environment
             # median of 5 repeats of `rep_len` calls each (same loop, same barriers): the low-noise companion of the --steps window
-            'value_median_500' if rep_len == 500 else 'value_median_repeats': round(float(np.median(rep_rates)), 2),
-            'repeats': {'n': 5, 'calls_each': rep_len, 'values': [round(v, 1) for v in rep_rates]},
+            'value_median_500' if rep_len == 500 else 'value_median_repeats': (round(float(np.median(rep_rates)), 2) if rep_rates else None),
+            'repeats': {'n': len(rep_rates), 'calls_each': rep_len, 'values': [round(v, 1) for v in rep_rates]},
             'clocks': clocks,
         }
         # `roofline` describes the RUN: the kernel family with the largest share of GPU time -- its algorithmic flops (bytes), counted by the
@@ -717,10 +728,10 @@ def main():
                 out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)
             elif getattr(agent, '_graph_launches', None):
                 out['launches_per_train'] = int(agent._graph_launches)
-        if alg == 'vlsac':
+        if alg == 'vlsac' and not args.quick:
             out['roofline_heaviest_kernel'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
             out.setdefault('roofline', out['roofline_heaviest_kernel'])
-        elif alg == 'diffsrsac':
+        elif alg == 'diffsrsac' and not args.quick:
             out['roofline_heaviest_kernel'] = big_gemm_roofline(agent, B, S, 256, 512)
             out.setdefault('roofline', out['roofline_heaviest_kernel'])
         # whole-train() view: algorithmic GFLOP per train() per GPU against the fp32 peak

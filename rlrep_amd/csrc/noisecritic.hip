@@ -829,11 +829,13 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
         }
         if (b < t.B) {
             t.Hm[(size_t)b * H + col] = sum * invN;
+#ifndef RL_NC_NOU            /* (timing-only diagnostic build: no U stores) */
             if (t.U) {
                 float* up = t.U + ((size_t)b * N) * H + col;
 #pragma unroll
                 for (int n = 0; n < 20; ++n) up[(size_t)n * H] = y[n];
             }
+#endif
         }
     }
     NCT(3); NCT(5);
