@@ -541,6 +541,197 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmBatch gb) {
     }
 }
 
+// ================================================================================================
+// bf16x3 for the k-major x k-major form (weight gradients: dW = G^T X, both operands stored [K][rows]) -- gemm_x3t_kernel.
+//
+// The MFMA wants, per lane, EIGHT CONSECUTIVE k of one row; a k-major operand has them K-strided in memory.  gemm_x3_kernel<LD_COL, LD_COL>
+// transposed while staging (one row, eight k per thread: 4-byte global loads, 107 TF, no better than the fp32 tile -- which is why weight
+// gradients stayed on fp32 MFMA at 111 TF).  gfx950 can transpose on the way OUT of LDS instead: ds_read_b64_tr_b16 hands every lane of a
+// 16-lane group one COLUMN of a 4 (k) x 16 (row) block of 16-bit elements.  So the slice is staged as it lies in memory -- 16-byte global
+// loads along the rows, split into three bf16 images [32 k][128 rows] (256-byte image rows, 16-byte chunks XOR-swizzled by k so that the
+// 8-byte writes and the transposed reads are both conflict-free: off(k, ch) = 256 k + 16 (ch ^ (((k & 3) << 2) | ((k >> 2) & 3)))) -- and a
+// fragment is two transposed reads per image.  Same tile (128 x 128, 8 waves 4 x 2, 32x32x16 MFMAs, six per product), same epilogue.
+// ================================================================================================
+typedef short x3t_s16x4 __attribute__((ext_vector_type(4)));
+#define X3T_IMGB (32 * 256)          /* one image: 32 k x 128 rows x 2 bytes */
+__device__ __forceinline__ unsigned x3t_off(int k, int ch) { return 256u * k + 16u * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))); }
+
+// 512 threads stage a 32 (k) x 128 (rows) slice: thread -> (k = idx / 32, four rows 4 (idx % 32)), two slots
+__device__ __forceinline__ void x3t_stage_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, f32x4 (&e)[2]) {
+    const int c4 = (int)(threadIdx.x & 31) * 4;
+    const int i = min(base + c4, lim - 4);
+    const bool iok = (base + c4) < lim;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kk = (int)(threadIdx.x >> 5) + 16 * j;
+        const int k = min(k0 + kk, kend - 1);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
+        e[j] = (iok && (k0 + kk) < kend) ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void x3t_stage_write(unsigned char* __restrict__ img, const f32x4 (&e)[2]) {
+    const int c4 = (int)(threadIdx.x & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kk = (int)(threadIdx.x >> 5) + 16 * j;
+        u32x2 hi, mid, lo;
+        unsigned h, m, l;
+        x3_split2(e[j][0], e[j][1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+        x3_split2(e[j][2], e[j][3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        unsigned char* p = img + x3t_off(kk, c4 >> 3) + 8 * ((c4 >> 2) & 1);
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + X3T_IMGB) = mid;
+        *reinterpret_cast<u32x2*>(p + 2 * X3T_IMGB) = lo;
+    }
+}
+// one transposed read: 4 consecutive k of this lane's row (LDS byte address `a` = this lane's share of the block: see x3t_addr)
+template <int OFF> __device__ __forceinline__ x3t_s16x4 x3t_rd(unsigned a) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) x3t_s16x4*>((uintptr_t)(a + OFF)));
+}
+// the eight k (16 c + 8 kg ..) of this lane's row as one MFMA operand: k-blocks h = 0, 1 at addresses a0 / a1 (image and c by immediate offset)
+template <int OFF> __device__ __forceinline__ bf16x8 x3t_frag(unsigned a0, unsigned a1) {
+    const x3t_s16x4 lo = x3t_rd<OFF>(a0), hi = x3t_rd<OFF>(a1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// address a lane supplies for the block (k rows kq .. kq + 3, 16 matrix rows starting at 8 * chunk0): lane 4 q + p of its 16-lane group gives
+// row kq + q, columns 4 p .. 4 p + 3 (cdna_hip_programming.md T10)
+__device__ __forceinline__ unsigned x3t_addr(unsigned lds_base, int kq, int chunk0) {
+    const int li = threadIdx.x & 15, q = li >> 2, pp = li & 3;
+    return lds_base + x3t_off(kq + q, chunk0 + (pp >> 1)) + 8u * (pp & 1);
+}
+
+// LA = LD_COL: both operands k-major (weight gradients).  LA = LD_ROW: A row-major [R, K] -- staged and read as in gemm_x3_kernel ([row][80-byte]
+// images, ds_read_b128 fragments) -- and only B k-major through the transposed reads (dX = G W with W stored [K = out features][Cn = in features]).
+template <int LA>
+__global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GemmBatch gb) {
+    constexpr int BT = 128;
+    constexpr int EPB = 8 * 32 * 68 * 4;                         // epilogue patches [32][68] per wave, bytes
+    constexpr int AIMG = LA == LD_ROW ? X3_IMGB : X3T_IMGB;      // bytes per A image
+    constexpr int STB = 3 * AIMG + 3 * X3T_IMGB;                 // six images
+    constexpr int LDSB = EPB > STB ? EPB : STB;
+    __shared__ __attribute__((aligned(16))) float lds[LDSB / 4];
+    unsigned char* const L = reinterpret_cast<unsigned char*>(lds);
+    const unsigned Lb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L;
+
+    const int bid = blockIdx.x;
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    const GemmTask& t = gb.t[ti];
+    const float* const pA = t.A; const float* const pB = t.B;
+    const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
+    const int tiles_c = t.tiles_c, splits = t.splits, kchunk = t.kchunk;
+    const int tiles_r = (R + BT - 1) / BT;
+    const int local = gl_xcd_remap(bid - t.tile_base, t.ntiles);
+    const int per_split = tiles_r * tiles_c;
+    const int split = local / per_split, rem = local - split * per_split;
+    const int tc = rem / tiles_r, tr = rem - tc * tiles_r;
+    const int r0 = tr * BT, c0 = tc * BT;
+    const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg + GL_BK - 1) / GL_BK;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int r32 = lane & 31, hh = lane >> 5, g1 = (lane >> 4) & 1;
+    const bool want_bias = LA == LD_COL && t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && tc == 0;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ea[2], eb[2];
+    float ear[8];                                               // (row-major A: gemm_x3_kernel's staging registers)
+    if constexpr (LA == LD_ROW) x3_stage_load<LD_ROW>(pA, lda, r0, R, kbeg, kend, ear);
+    else x3t_stage_load(pA, lda, r0, R, kbeg, kend, ea);
+    x3t_stage_load(pB, ldb, c0, Cn, kbeg, kend, eb);
+    if (X3_STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(X3_STAGGER);        // (anti-phase start of a CU's two workgroups: gemm_x3_kernel)
+
+    // transposed-read addresses: k-block h of this lane's k group (k = 8 hh + 4 h within a 16-deep block c; c and the image by immediate offset)
+    const unsigned aA0 = x3t_addr(Lb, 8 * hh, wr * 4 + 2 * g1), aA1 = x3t_addr(Lb, 8 * hh + 4, wr * 4 + 2 * g1);
+    const unsigned aB00 = x3t_addr(Lb + 3 * AIMG, 8 * hh, wc * 8 + 2 * g1), aB01 = x3t_addr(Lb + 3 * AIMG, 8 * hh + 4, wc * 8 + 2 * g1);
+    const unsigned aB10 = x3t_addr(Lb + 3 * AIMG, 8 * hh, wc * 8 + 4 + 2 * g1), aB11 = x3t_addr(Lb + 3 * AIMG, 8 * hh + 4, wc * 8 + 4 + 2 * g1);
+    const unsigned char* const far = L + (wr * 32 + r32) * X3_RSB + 16 * hh;               // row-major A fragments (ds_read_b128)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (want_bias) rs += ea[0] + ea[1];
+        if constexpr (LA == LD_ROW) x3_stage_write<LD_ROW>(L, ear);
+        else x3t_stage_write(L, ea);
+        x3t_stage_write(L + 3 * AIMG, eb);
+        __syncthreads();
+        const int kn = kbeg + GL_BK * (kt + 1);
+        if constexpr (LA == LD_ROW) x3_stage_load<LD_ROW>(pA, lda, r0, R, kn, kend, ear);
+        else x3t_stage_load(pA, lda, r0, R, kn, kend, ea);
+        x3t_stage_load(pB, ldb, c0, Cn, kn, kend, eb);
+#define X3T_BLOCK(C)                                                                                                          \
+        {                                                                                                                     \
+            bf16x8 a[3], b[2][3];                                                                                             \
+            if constexpr (LA == LD_ROW) {                                                                                     \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3_IMGB + 32 * (C)); \
+            } else {                                                                                                          \
+                a[0] = x3t_frag<(C) * 4096>(aA0, aA1); a[1] = x3t_frag<(C) * 4096 + X3T_IMGB>(aA0, aA1);                       \
+                a[2] = x3t_frag<(C) * 4096 + 2 * X3T_IMGB>(aA0, aA1);                                                         \
+            }                                                                                                                 \
+            b[0][0] = x3t_frag<(C) * 4096>(aB00, aB01); b[0][1] = x3t_frag<(C) * 4096 + X3T_IMGB>(aB00, aB01);                 \
+            b[0][2] = x3t_frag<(C) * 4096 + 2 * X3T_IMGB>(aB00, aB01);                                                        \
+            b[1][0] = x3t_frag<(C) * 4096>(aB10, aB11); b[1][1] = x3t_frag<(C) * 4096 + X3T_IMGB>(aB10, aB11);                 \
+            b[1][2] = x3t_frag<(C) * 4096 + 2 * X3T_IMGB>(aB10, aB11);                                                        \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                   \
+                f32x16 v = acc[y];                                                                                            \
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][2], v, 0, 0, 0);                                       \
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[y][0], v, 0, 0, 0);                                       \
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[y][1], v, 0, 0, 0);                                       \
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][1], v, 0, 0, 0);                                       \
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[y][0], v, 0, 0, 0);                                       \
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[y][0], v, 0, 0, 0);                                       \
+                acc[y] = v;                                                                                                   \
+            }                                                                                                                 \
+        }
+        X3T_BLOCK(0) X3T_BLOCK(1)
+#undef X3T_BLOCK
+        __syncthreads();
+    }
+
+    // bias gradient = row sums of operand A: this thread holds four rows (4 (tid % 32) ..) over its k slots -> LDS -> fixed-order sum over the 16 slots
+    if (want_bias) {
+        float* part = lds;                                   // [128 rows][16 k slots]
+        const int c4 = (int)(threadIdx.x & 31) * 4, ks = (int)(threadIdx.x >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[(c4 + q) * 16 + ks] = rs[q];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const float* q = part + threadIdx.x * 16;
+            float s0 = 0.f;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) s0 += q[z];
+            const int r = r0 + threadIdx.x;
+            if (r < R) { if (splits > 1) t.bslab[(size_t)split * R + r] = s0; else t.out2[r] = s0; }
+        }
+        __syncthreads();
+    }
+
+    // accumulators (32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> LDS patch -> row segments
+    float* E = lds + w * (32 * 68);
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) E[((q & 3) + 8 * (q >> 2) + 4 * hh) * 68 + y * 32 + r32] = acc[y][q];
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+        const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * 68 + cc);
+        const int r = r0 + wr * 32 + rr, c = c0 + wc * 64 + cc;
+        if (r < R && c < Cn) {
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
+            else gl_epilogue4(t, r, c, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -555,8 +746,17 @@ static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
 
 static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(512), 0, st, gb);
-    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, gb);
-    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, gb);
+    else if (la == LD_ROW && lb == LD_COL) {
+        // dX form: the k-major B operand through the transposed reads too (RLREP_X3_DW_OLD: both on the form that transposes while staging);
+        // its 16-byte loads along the rows need Cn % 4 == 0 and an aligned B -- which the routing guarantees for every bf16x3 task
+        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, gb);
+        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_ROW>), g, dim3(512), 0, st, gb);
+    }
+    else if (la == LD_COL && lb == LD_COL) {
+        // weight-gradient form: the transposed-read kernel (staged as it lies in memory); RLREP_X3_DW_OLD: the form that transposes while staging
+        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, gb);
+        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_COL>), g, dim3(512), 0, st, gb);
+    }
     else return -1;
     return (int)hipGetLastError();
 }
@@ -641,7 +841,8 @@ extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_fl
     int bt = 0;
     rl_gemm_lds_plan(t, &bt, splits, kchunk);
     *flags = rl_gemm_lds_dim_flags(t, la, lb) | extra_flags;
-    const bool x3 = bt == 128 && la == LD_ROW && 2.0 * t->R * t->Cn * t->K >= 2e9 && !getenv("RLREP_NO_X3") &&
+    // (the k-major / k-major weight-gradient form takes bf16x3 too since round 4: gemm_x3t_kernel; RLREP_X3_DW_FP32 keeps it on the fp32 tile)
+    const bool x3 = bt == 128 && (la == LD_ROW || (lb == LD_COL && !getenv("RLREP_X3_DW_FP32"))) && 2.0 * t->R * t->Cn * t->K >= 2e9 && !getenv("RLREP_NO_X3") &&
                     !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
     return x3 ? 129 : bt;
 }
