@@ -679,7 +679,7 @@ def main():
                        'global_batch': (B_global if strong else B * world) if mode == 'dp' else B, 'scaling': 'strong' if strong else 'weak', 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
                        'parallelism': {'single': 'single GPU',
-                                       'dp': f'dp{world} (replay sharded, RCCL all-reduce of gradients per optimizer step)',
+                                       'dp': f'dp{world} (replay sharded, ' + ('RCCL' if (dist is not None and dist.get_backend() == 'nccl') else (dist.get_backend() if dist is not None else 'no')) + ' all-reduce of gradients per optimizer step)',
                                        'replicas': f'{world} independent agents (own parameters and replay, no collective)'}[mode],
                        'hipgraph': (bool(agent.use_graph) if not agent._dp else
                                     (('collectives captured into the graph(s)' if getattr(agent, '_seg_capture_colls', False) else 'segments between eager collectives')

@@ -75,6 +75,6 @@ if [ $PART = misc ] || [ $PART = all ]; then
   RLREP_FORCE_DP=1 RLREP_PIPELINE_DP=1 python3 bench.py --steps 2000 --warmup 200 --no-cpu --no-profile 2>/dev/null | tail -n 1 >> $OUT/r04_dp_rehearsal.jsonl
   RLREP_STAMP=1 python3 tools/exp/chain_stamps.py > $OUT/r04_chain_stamps.txt 2>&1
   # two gloo ranks on this one GPU through bench.py's N > 1 path: replicas_identical / allreduce_us_per_train fields (not a scaling number)
-  RLREP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu 2>/dev/null | tail -n 1 > $OUT/r04_bench_2ranks_gloo_one_gpu.json
+  RLREP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu --quick 2>/dev/null | tail -n 1 > $OUT/r04_bench_2ranks_gloo_one_gpu.json
 fi
 echo collected

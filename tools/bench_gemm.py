@@ -23,6 +23,9 @@ SHAPES = [
     ('diffsr nabla-mu head fwd', 'fwd', 2048, 96256, 512),
     ('diffsr nabla-mu head dx', 'dx', 2048, 512, 96256),
     ('diffsr nabla-mu head dW', 'dw', 96256, 512, 2048),
+    ('diffsr head fwd with W^T (k-major B)', 'dx', 2048, 96256, 512),
+    ('square 4096 dx', 'dx', 4096, 4096, 4096),
+    ('square 4096 dW', 'dw', 4096, 4096, 4096),
     ('square 4096', 'fwd', 4096, 4096, 4096),
 ]
 
