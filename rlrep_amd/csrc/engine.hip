@@ -1693,11 +1693,12 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         rc = rl_launch_gemm16(la, lb, 1, &gb, t.ntiles, (hipStream_t)stream);
     } else {
         t.flags |= rl_gemm_lds_dim_flags(&t, la, lb) | rl_gemm_lds_ptr_flags(&t);
-        if (engine == 2 && (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B | FLAG_SCALAR_C))) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
+        if (engine == 2 && (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) ) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
+        if (engine == 2 && bt != 64 && (t.flags & FLAG_SCALAR_C)) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
         int pbt = 0, psp = 1, pkc = 0;
         rl_gemm_lds_plan(&t, &pbt, &psp, &pkc);
         if (bt == 64 || bt == 128) pbt = bt;
-        if (engine == 2) pbt = 128;
+        if (engine == 2 && bt != 64) pbt = 128;          // bf16x3: the 128-wide tile, or (bt = 64) the 64-wide one
         if (splits > 0) { psp = splits; pkc = ((K + psp - 1) / psp + 31) / 32 * 32; psp = (K + pkc - 1) / pkc; }
         t.splits = psp; t.kchunk = pkc;
         int fin = 0;
@@ -1709,7 +1710,7 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         }
         t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;
-        rc = rl_launch_gemm_lds(engine == 2 ? 129 : pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
+        rc = rl_launch_gemm_lds(engine == 2 ? (pbt == 64 ? 65 : 129) : pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
     }
     if (rc != 0) { rl_set_error("gemm: launch failed (%d)", rc); return rc < 0 ? RLREP_ERR_ARG : RLREP_ERR_HIP; }
     return 0;
@@ -1722,8 +1723,8 @@ int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K
     t.R = R; t.Cn = Cn; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.epi = la == LD_COL ? EPI_DW : EPI_FWD;
     int sp = 1, kc = 0, fl = 0;
     const int code = rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl);
-    *engine = code == 0 ? 0 : code == 129 ? 2 : 1;
-    if (tile) *tile = code == 0 ? 16 : code == 129 ? 128 : code;
+    *engine = code == 0 ? 0 : (code == 129 || code == 65) ? 2 : 1;
+    if (tile) *tile = code == 0 ? 16 : code == 129 ? 128 : code == 65 ? 64 : code;
     if (splits) *splits = code ? sp : 1;
     if (kchunk) *kchunk = code ? kc : K;
     if (scalar_sides) *scalar_sides = code ? (((fl & FLAG_SCALAR_A) ? 1 : 0) | ((fl & FLAG_SCALAR_B) ? 2 : 0) | ((fl & FLAG_SCALAR_C) ? 4 : 0)) : 0;

@@ -732,6 +732,222 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GemmBatch gb) {
     }
 }
 
+// ================================================================================================
+// gemm_x3s_kernel: the 64 x 64 tile on the bf16 pipe (bf16x3) -- for the layers whose outputs are too small for 128-wide tiles (ctrlsac at
+// M = 256, spedersac at M = 2048 x 512, diffsrsac at HalfCheetah dims) and that ran on the fp32 64-wide tile at 38-60 TF: one wave per SIMD
+// there issues a 16x16x4 fp32 MFMA every 52 cycles, while a 32x32x16 bf16 MFMA does 16x the work in 32.  256 threads = 4 waves (2 x 2), a wave
+// owns 32 x 32 = ONE f32x16 accumulator (<= 128 VGPRs: four workgroups per CU, whose split / read / MFMA phases overlap), 32-deep slices, the
+// exact three-way split while staging.  Row-major operands as in gemm_x3_kernel ([row][80-byte] images, ds_read_b128 fragments); k-major
+// operands as in gemm_x3t_kernel (staged as they lie, [32 k][64 rows] images of 128-byte rows, ds_read_b64_tr_b16) with the chunk swizzle
+// ch ^ (((k >> 1) & 1) << 2): the four k-rows a 32-lane half reads then sit on four different 16-bank groups.
+// ================================================================================================
+#define X3S_RIMGB (64 * X3_RSB)      /* row-major image: 64 rows x 80 bytes */
+#define X3S_TIMGB (32 * 128)         /* k-major image: 32 k x 64 rows x 2 bytes */
+__device__ __forceinline__ unsigned x3s_toff(int k, int ch) { return 128u * k + 16u * (ch ^ (((k >> 1) & 1) << 2)); }
+
+// 256 threads stage a 64 x 32 slice.  Row-major: two row slots x four consecutive k; k-major: (k = tid / 16 + 16 j, four rows 4 (tid % 16))
+// VEC (compile time: a run-time choice puts the prefetch loads into a control-flow diamond, and hipcc drains vmcnt at its merge -- the loads then no
+// longer overlap the MFMAs: measured -10 % on every workload): 16-byte loads are legal for this operand; otherwise clamped 4-byte loads (inner lengths
+// like 119, unaligned rows)
+template <bool VEC>
+__device__ __forceinline__ void x3s_load_row(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[8]) {
+    const int kc = (threadIdx.x & 7) * 4;
+    if constexpr (VEC) {
+        const int k = min(k0 + kc, kend - 4);
+        const bool ok = (k0 + kc) < kend;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[4 * j + q] = ok ? x[q] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* p = P + (size_t)min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1) * ld;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float y = p[min(k0 + kc + q, kend - 1)]; e[4 * j + q] = (k0 + kc + q) < kend ? y : 0.f; }
+        }
+    }
+}
+__device__ __forceinline__ void x3s_write_row(unsigned char* __restrict__ img, const float (&e)[8]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (int)(threadIdx.x >> 3) + 32 * j, kc = (int)(threadIdx.x & 7) * 4;
+        u32x2 hi, mid, lo;
+        unsigned h, m, l;
+        x3_split2(e[4 * j], e[4 * j + 1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+        x3_split2(e[4 * j + 2], e[4 * j + 3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        unsigned char* p = img + row * X3_RSB + kc * 2;
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + X3S_RIMGB) = mid;
+        *reinterpret_cast<u32x2*>(p + 2 * X3S_RIMGB) = lo;
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void x3s_load_col(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, f32x4 (&e)[2]) {
+    const int c4 = (int)(threadIdx.x & 15) * 4;
+    if constexpr (VEC) {
+        const int i = min(base + c4, lim - 4);
+        const bool iok = (base + c4) < lim;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+            const int k = min(k0 + kk, kend - 1);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
+            e[j] = (iok && (k0 + kk) < kend) ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+            const float* p = P + (size_t)min(k0 + kk, kend - 1) * ld;
+            const bool kok = (k0 + kk) < kend;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float y = p[min(base + c4 + q, lim - 1)]; e[j][q] = (kok && (base + c4 + q) < lim) ? y : 0.f; }
+        }
+    }
+}
+__device__ __forceinline__ void x3s_write_col(unsigned char* __restrict__ img, const f32x4 (&e)[2]) {
+    const int c4 = (int)(threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+        u32x2 hi, mid, lo;
+        unsigned h, m, l;
+        x3_split2(e[j][0], e[j][1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+        x3_split2(e[j][2], e[j][3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        unsigned char* p = img + x3s_toff(kk, c4 >> 3) + 8 * ((c4 >> 2) & 1);
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + X3S_TIMGB) = mid;
+        *reinterpret_cast<u32x2*>(p + 2 * X3S_TIMGB) = lo;
+    }
+}
+__device__ __forceinline__ unsigned x3s_taddr(unsigned lds_base, int kq, int chunk0) {
+    const int li = threadIdx.x & 15, q = li >> 2, pp = li & 3;
+    return lds_base + x3s_toff(kq + q, chunk0 + (pp >> 1)) + 8u * (pp & 1);
+}
+
+template <int LA, int LB, bool VEC>
+__global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GemmBatch gb) {
+    constexpr int BT = 64;
+    constexpr int AIMG = LA == LD_ROW ? X3S_RIMGB : X3S_TIMGB, BIMG = LB == LD_ROW ? X3S_RIMGB : X3S_TIMGB;
+    constexpr int EPB = 4 * 32 * 36 * 4;                         // epilogue patches [32][36] per wave, bytes
+    constexpr int STB = 3 * AIMG + 3 * BIMG;
+    constexpr int LDSB = EPB > STB ? EPB : STB;
+    __shared__ __attribute__((aligned(16))) float lds[LDSB / 4];
+    unsigned char* const L = reinterpret_cast<unsigned char*>(lds);
+    const unsigned Lb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L;
+
+    const int bid = blockIdx.x;
+    int ti = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    const GemmTask& t = gb.t[ti];
+    const float* const pA = t.A; const float* const pB = t.B;
+    const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
+    const int tiles_c = t.tiles_c, splits = t.splits, kchunk = t.kchunk;
+    const int tiles_r = (R + BT - 1) / BT;
+    const int local = gl_xcd_remap(bid - t.tile_base, t.ntiles);
+    const int per_split = tiles_r * tiles_c;
+    const int split = local / per_split, rem = local - split * per_split;
+    const int tc = rem / tiles_r, tr = rem - tc * tiles_r;
+    const int r0 = tr * BT, c0 = tc * BT;
+    const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg + GL_BK - 1) / GL_BK;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int r32 = lane & 31, hh = lane >> 5, g1 = (lane >> 4) & 1;
+    const bool want_bias = LA == LD_COL && t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && tc == 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+
+    float ear[8], ebr[8];
+    f32x4 eac[2], ebc[2];
+    if constexpr (LA == LD_ROW) x3s_load_row<VEC>(pA, lda, r0, R, kbeg, kend, ear); else x3s_load_col<VEC>(pA, lda, r0, R, kbeg, kend, eac);
+    if constexpr (LB == LD_ROW) x3s_load_row<VEC>(pB, ldb, c0, Cn, kbeg, kend, ebr); else x3s_load_col<VEC>(pB, ldb, c0, Cn, kbeg, kend, ebc);
+
+    unsigned char* const LBi = L + 3 * AIMG;
+    const unsigned char* const far = L + (wr * 32 + r32) * X3_RSB + 16 * hh;
+    const unsigned char* const fbr = LBi + (wc * 32 + r32) * X3_RSB + 16 * hh;
+    const unsigned aA0 = x3s_taddr(Lb, 8 * hh, wr * 4 + 2 * g1), aA1 = x3s_taddr(Lb, 8 * hh + 4, wr * 4 + 2 * g1);
+    const unsigned aB0 = x3s_taddr(Lb + 3 * AIMG, 8 * hh, wc * 4 + 2 * g1), aB1 = x3s_taddr(Lb + 3 * AIMG, 8 * hh + 4, wc * 4 + 2 * g1);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (want_bias) rs += eac[0] + eac[1];
+        if constexpr (LA == LD_ROW) x3s_write_row(L, ear); else x3s_write_col(L, eac);
+        if constexpr (LB == LD_ROW) x3s_write_row(LBi, ebr); else x3s_write_col(LBi, ebc);
+        __syncthreads();
+        const int kn = kbeg + GL_BK * (kt + 1);
+        if constexpr (LA == LD_ROW) x3s_load_row<VEC>(pA, lda, r0, R, kn, kend, ear); else x3s_load_col<VEC>(pA, lda, r0, R, kn, kend, eac);
+        if constexpr (LB == LD_ROW) x3s_load_row<VEC>(pB, ldb, c0, Cn, kn, kend, ebr); else x3s_load_col<VEC>(pB, ldb, c0, Cn, kn, kend, ebc);
+#define X3S_BLOCK(C)                                                                                                          \
+        {                                                                                                                     \
+            bf16x8 a[3], b[3];                                                                                                \
+            if constexpr (LA == LD_ROW) {                                                                                     \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3S_RIMGB + 32 * (C)); \
+            } else {                                                                                                          \
+                a[0] = x3t_frag<(C) * 2048>(aA0, aA1); a[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>(aA0, aA1);                      \
+                a[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>(aA0, aA1);                                                        \
+            }                                                                                                                 \
+            if constexpr (LB == LD_ROW) {                                                                                     \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) b[m] = *reinterpret_cast<const bf16x8*>(fbr + m * X3S_RIMGB + 32 * (C)); \
+            } else {                                                                                                          \
+                b[0] = x3t_frag<(C) * 2048>(aB0, aB1); b[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>(aB0, aB1);                      \
+                b[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>(aB0, aB1);                                                        \
+            }                                                                                                                 \
+            f32x16 v = acc;                                                                                                   \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], v, 0, 0, 0);                                              \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], v, 0, 0, 0);                                              \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], v, 0, 0, 0);                                              \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], v, 0, 0, 0);                                              \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], v, 0, 0, 0);                                              \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], v, 0, 0, 0);                                              \
+            acc = v;                                                                                                          \
+        }
+        X3S_BLOCK(0) X3S_BLOCK(1)
+#undef X3S_BLOCK
+        __syncthreads();
+    }
+
+    if (want_bias) {       // row sums of the k-major A: this thread holds rows 4 (tid % 16) .. over its 16 k slots
+        float* part = lds;                                   // [64 rows][16 k slots]
+        const int c4 = (int)(threadIdx.x & 15) * 4, ks = (int)(threadIdx.x >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[(c4 + q) * 16 + ks] = rs[q];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const float* q = part + threadIdx.x * 16;
+            float s0 = 0.f;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) s0 += q[z];
+            const int r = r0 + threadIdx.x;
+            if (r < R) { if (splits > 1) t.bslab[(size_t)split * R + r] = s0; else t.out2[r] = s0; }
+        }
+        __syncthreads();
+    }
+
+    // accumulator (32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> LDS patch -> row segments
+    float* E = lds + w * (32 * 36);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) E[((q & 3) + 8 * (q >> 2) + 4 * hh) * 36 + r32] = acc[q];
+#pragma unroll 4
+    for (int it = 0; it < 4; ++it) {
+        const int rr = it * 8 + (lane >> 3), cc = (lane & 7) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * 36 + cc);
+        const int r = r0 + wr * 32 + rr, c = c0 + wc * 32 + cc;
+        if (r < R && c < Cn) {
+            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
+            else gl_epilogue4(t, r, c, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -761,10 +977,19 @@ static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
     return (int)hipGetLastError();
 }
 
-// bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3)
+static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
+    for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) return -2;       // 16-byte staging only (the router guarantees it)
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, true>), g, dim3(256), 0, st, gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, true>), g, dim3(256), 0, st, gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, true>), g, dim3(256), 0, st, gb);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
+// bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3); 65 = the 64-wide tile on the bf16 pipe
 extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    int rc = bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb)
+    int rc = bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb)
            : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb);
     if (rc != 0) return rc;
     if (fin_blocks > 0) {
@@ -844,6 +1069,13 @@ extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_fl
     // (the k-major / k-major weight-gradient form takes bf16x3 too since round 4: gemm_x3t_kernel; RLREP_X3_DW_FP32 keeps it on the fp32 tile)
     const bool x3 = bt == 128 && (la == LD_ROW || (lb == LD_COL && !getenv("RLREP_X3_DW_FP32"))) && 2.0 * t->R * t->Cn * t->K >= 2e9 && !getenv("RLREP_NO_X3") &&
                     !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
-    return x3 ? 129 : bt;
+    if (x3) return 129;
+    // 64-wide tiles: on the bf16 pipe too when both operands allow 16-byte staging (gemm_x3s_kernel); RLREP_X3S_OFF keeps the fp32 tile
+    // (the program builder keeps a STAGE on one engine: a stage whose tasks would be split between this tile and the fp32 one becomes two dependent
+    // launches, which costs more than the faster tile returns -- spedersac: 69 -> 81 launches on the feature chain, 961 -> 903 train()/s)
+    // (operands that need element-wise staging keep their stage on the fp32 tile: a scalar-staging instantiation of the bf16x3 tile was built and
+    // measured -- spedersac 968 with it against 1 002 with those stages on fp32, ctrlsac F = 2048 865 against 904)
+    if (bt == 64 && !getenv("RLREP_NO_X3") && !getenv("RLREP_X3S_OFF") && !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B))) return 65;
+    return bt;
 }
 

@@ -168,6 +168,21 @@ def test_bf16x3_engine_is_fp32_accurate(mode):
     assert rel(got, want) < 2e-6 and rel(ref, want) < 2e-6, (rel(got, want), rel(ref, want))
 
 
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+def test_bf16x3_64_wide_tile_is_fp32_accurate(mode):
+    """engine 2 with bt = 64: gemm_x3s_kernel, the 64 x 64 tile on the bf16 pipe (row-major operands through [row][80-byte] images, k-major
+    ones staged as they lie and read with ds_read_b64_tr_b16) -- the M = 256 / 2048 layers of ctrlsac / spedersac.  Exact tiles, ragged edges
+    in every dimension, split-K with a short last split, epilogues, against float64 at the fp32 engines' 1e-5 (measured ~2e-7)."""
+    check(2, mode, 256, 256, 128, bt=64, splits=1, seed=41)
+    check(2, mode, 148, 92, 100, bt=64, splits=1, seed=42)
+    check(2, mode, 36, 260, 68, bt=64, splits=1, seed=43)
+    check(2, mode, 200, 128, 1024, bt=64, splits=3, seed=44, accum=(mode != 'fwd'))
+    check(2, mode, 128, 192, 708, bt=64, splits=7, seed=45)
+    check(2, mode, 256, 1024, 2048, bt=64, act='elu' if mode != 'dw' else 'none', seed=46)        # a ctrlsac layer, the planner's own split
+    got, want, _ = run_gemm(2, mode, 256, 128, 256, bt=64, splits=1, seed=47)
+    assert rel(got, want) < 2e-6, rel(got, want)
+
+
 def test_bf16x3_engine_wide_dynamic_range():
     """operands spanning 12 decades: the split is exact per element, so the error stays relative to sum |a||b|"""
     from rlrep_amd import _lib

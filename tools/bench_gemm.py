@@ -20,6 +20,9 @@ SHAPES = [
     ('spedersac phi fwd', 'fwd', 2048, 512, 512),
     ('spedersac phi dx', 'dx', 2048, 512, 512),
     ('spedersac phi dW', 'dw', 512, 512, 2048),
+    ('spedersac critic l1|l4 fwd', 'fwd', 1024, 512, 512),
+    ('spedersac critic l1|l4 dW', 'dw', 512, 512, 1024),
+    ('spedersac critic l2 fwd', 'fwd', 1024, 256, 256),
     ('diffsr nabla-mu head fwd', 'fwd', 2048, 96256, 512),
     ('diffsr nabla-mu head dx', 'dx', 2048, 512, 96256),
     ('diffsr nabla-mu head dW', 'dw', 96256, 512, 2048),
@@ -67,7 +70,7 @@ if __name__ == '__main__':
         for eng, label in ((0, 'gemm16'), (1, 'gemm_lds'), (2, 'bf16x3')):
             if eng not in engines:
                 continue
-            if (eng == 0 and fl > 3e10 and os.environ.get('SKIP_SLOW')) or (eng == 2 and fl < 1e9):
+            if (eng == 0 and fl > 3e10 and os.environ.get('SKIP_SLOW')) or (eng == 2 and fl < float(os.environ.get('X3_MIN_FLOP', 1e9))):
                 continue
             us = run(eng, mode, R, Cn, K, reps)
             line += f' | {label} {us:9.1f} us {fl / us / 1e6:6.1f} TF'
