@@ -260,7 +260,20 @@ FAMILIES = {
 _ENGINE_FAMILY = {e: k for k, v in FAMILIES.items() for e in v[0]}
 
 
-def stage_profile(agent, reps=40):
+def _arm_feature_inputs(agent, buf, B):
+    """The stage hooks launch a stage with whatever per-call inputs (noise, noise-level indices) the LAST step left armed.  After a train() that is the
+    actor step's [B, A] noise -- but a feature-step stage reads [B, F] (vlsac) or [B, S] (diffsrsac: 3 MB at Humanoid dims) from that pointer: far
+    beyond the buffer.  One eager feature step arms inputs of the right shape (it performs one more update: harmless after the timed loops)."""
+    if agent._feature_iters() <= 0:
+        return
+    agent.flush()
+    buf.flush()
+    agent._pool, agent._next_key, agent._early_key = None, {}, None
+    agent._feature_once(buf, B, 0, False)
+    torch.cuda.synchronize()
+
+
+def stage_profile(agent, buf, B, reps=40):
     """Every stage of the sequential step programs timed ALONE (hipGraph of `reps` back-to-back launches, HIP events on the launch stream),
     grouped into kernel families by the engine the library reports for the stage (rlrep_stage_info), with the library's own count of the
     stage's algorithmic flops / bytes: launches per train(), us per train(), share, achieved rate against the family's peak.  Standalone
@@ -275,6 +288,7 @@ def stage_profile(agent, reps=40):
         reps = 4
     fam = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _arm_feature_inputs(agent, buf, B)          # (feature noise is at least as large as the policy noise the critic / actor stages read)
     for prog in range(7):
         if mult[prog] == 0:
             continue
@@ -716,7 +730,7 @@ def main():
         # PMC summary of this workload.  Every family is listed in `kernel_families`.
         pmc_path = find_pmc_json(args.workload, args.pmc_json)
         if world == 1 and not args.no_profile:
-            fams = stage_profile(agent)
+            fams = stage_profile(agent, buf, B)
             out['kernel_families'] = [{k: v for k, v in f.items() if k != 'stages'} for f in fams]
             out['stage_times_us'] = {f['family']: f['stages'] for f in fams}
             priced = [f for f in fams if 'frac' in f]
@@ -732,6 +746,7 @@ def main():
             out['roofline_heaviest_kernel'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
             out.setdefault('roofline', out['roofline_heaviest_kernel'])
         elif alg == 'diffsrsac' and not args.quick:
+            _arm_feature_inputs(agent, buf, B)
             out['roofline_heaviest_kernel'] = big_gemm_roofline(agent, B, S, 256, 512)
             out.setdefault('roofline', out['roofline_heaviest_kernel'])
         # whole-train() view: algorithmic GFLOP per train() per GPU against the fp32 peak
