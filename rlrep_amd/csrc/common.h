@@ -54,6 +54,14 @@ enum Epi : int {
 // dX form only: the fused short product's mask is ELU'(M) = (M > 0 ? 1 : M + 1) instead of ReLU'(M) -- the actor head's dX (K1 = 2A) riding in
 // the dX launch of the actor's second layer (agent/sac/actor.py:31-45 backward)
 #define FLAG_PRE_ELU 1024
+// dX form of the fused short product (FLAG_PRE), vlsac decoder only: the short product's ROW operand X [R, K1] is not read from memory either -- it is
+// the gradient of the decoder's 0.5*mse losses, computed here from the layer's own saved activation M:
+//   X = dmse( M Wt^T + bias ; targets ),   Wt = the heads' weight [K1, K] (the short product's own matrix), M [R, K] (= x2),
+// i.e. the `dec.heads + mse` launch (EPI_FWD_MSE) rides in the launch that consumes it: every tile recomputes the K1 <= 32 head outputs of its 16 rows
+// (MFMA, inner dimension split over the waves, fixed-order LDS reduction), column tile 0 files X (x0 / ldx0: the weight-gradient pass reads it) and the
+// per-row-tile squared-error partials (mse_part: [2 * row tile], [.. + 1]).  Targets: tgs [R, n0] (row stride ldtgs) for columns < n0, tgr [R] for column n0;
+// gradient scales s0 / s1.  One dependent launch less per feature step (vlsac_agent.py:137-145).
+#define FLAG_PRE_MSE 4096
 // EPI_DW only: the optimizer runs in this task's epilogue (Adam on the tile's own weights and, column tile 0, bias; Polyak into the target
 // copy where ad_t / ad_tb are set) -- the FIRST layers of the vlsac feature nets, whose updated weights the next feature step's first launch
 // needs, so that the rest of the group's optimizer work can share a launch with that first layer.  GemmTask::ad_*.
@@ -99,6 +107,7 @@ struct GemmTask {
     // generic operands of the fused loss / policy epilogues
     const float* x0; const float* x1; const float* x2; float* y0; float* y1; const double* dptr;
     int ldx0, ldx1; float s0, s1;
+    const float* tgs; const float* tgr; float* mse_part; int ldtgs, pad_mse;      // FLAG_PRE_MSE
     // gemm_lds.hip only: split-K plan (splits > 1: partial tiles go to slab [splits][R][Cn], bias partials to
     // bslab [splits][R]; the finishing launch adds them in split order) -- zero for gemm16 launches
     int splits, kchunk, fin_base;

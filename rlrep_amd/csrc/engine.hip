@@ -323,9 +323,13 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     float* GH2f = ws.f((size_t)B * Hv); float* GH1f = ws.f((size_t)B * Hv);
     // the Gaussian heads of encoder and f and vae_mid as ONE launch (heads_vae_kernel: a 16 x 16 tile per workgroup, one KL partial each;
     // +3 % against the heads launch + an elementwise vae_mid launch, which is gone)
+    // dec.heads + mse inside the dec.l1 dX launch (FLAG_PRE_MSE): needs the 16-byte-aligned rows its first phase loads, K1 = S + 1 <= 32
+    const bool fold_mse = !rl_rowprog_enabled() && !Builder::chain_enabled() && (Hv & 3) == 0 && S + 1 <= 32 && !getenv("RLREP_NO_FOLD_MSE") && !getenv("RLREP_NO_FUSE_DX") &&
+                          ((B + 15) / 16) * ((F + 15) / 16) < 384 * 2;
     const int tiles_vm = ((B + 15) / 16) * ((F + 15) / 16);
-    const int nblk_kl = tiles_vm, nblk_mse = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
-    float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse);
+    const int nblk_kl = tiles_vm, nblk_mse_tiles = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
+    const int nblk_mse = fold_mse ? (B + 15) / 16 : nblk_mse_tiles;                        // (folded: one pair per 16-row tile)
+    float* part_kl = ws.f(nblk_kl); float* part_mse = ws.f((size_t)2 * nblk_mse_tiles);
     // actor buffers are needed by the feature program variant that carries the policy forwards
     ActorBufs ab = alloc_actor(b, B, A, Ha);                                                 // policy on s' (critic step)
     ActorBufs ab_pi = alloc_actor(b, B, A, Ha);                                              // policy on s  (actor step)
@@ -606,7 +610,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                         "dec.l1 actor.head x2 + policy");
         else
         b.fwd_stage(p, {Builder::fwd(Z, F, B, F, Pw("decoder.l1.weight"), F, Pw("decoder.l1.bias"), Hv, D1, Hv, ACT_RELU)}, "dec.l1");
-        {
+        if (!fold_mse) {
             // decoder heads with the 0.5*mse loss fused into the epilogue: the launch writes d loss / d[s_hat | r_hat]
             // (GDH) directly and per-tile partial sums of the squared errors (vlsac_agent.py:137-140)
             GemmTask t = Builder::fwd(D1, Hv, B, Hv, Pw("decoder.state_linear.weight"), Hv, Pw("decoder.state_linear.bias"), S + 1, GDH, S + 1, ACT_NONE);
@@ -618,6 +622,14 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             GemmTask t = Builder::dx(GD1, Hv, B, Hv, Pw("decoder.l1.weight"), F, GEH, 2 * F, F, ACT_NONE, nullptr, 0);
             t.epi = EPI_DX_REPARAM; t.aux3 = EZ; t.ldaux3 = F; t.F = F;
             // the K = 18 product dL/d(dec.l1 output) = d[s_hat|r_hat] W_heads rides in the dec.l1 dX launch (one launch less per feature step)
+            if (fold_mse) {
+                // ... and so does the heads' forward + mse (FLAG_PRE_MSE): every tile of the launch computes d[s_hat|r_hat] of its 16 rows itself
+                t.flags |= FLAG_PRE | FLAG_PRE_MSE;
+                t.x0 = GDH; t.ldx0 = S + 1; t.x1 = Pw("decoder.state_linear.weight"); t.ldx1 = Hv; t.n0 = S + 1; t.x2 = D1; t.ldaux2 = Hv; t.y0 = GD1; t.ldout2 = Hv;
+                t.bias = Pw("decoder.state_linear.bias"); t.tgs = s0.XE ? s0.XE + SA : nullptr; t.ldtgs = KE; t.tgr = s0.R; t.pad_mse = S;
+                t.s0 = ag->inv_batch() / (float)S; t.s1 = ag->inv_batch(); t.mse_part = part_mse;
+                b.gemm_small(p, LD_ROW, LD_COL, {t}, "dec.heads + mse | dec.heads dx | dec.l1 dx -> (dmean, dlog_std)");
+            } else
             b.dx_stage12(p, Builder::dx(GDH, S + 1, B, S + 1, Pw("decoder.state_linear.weight"), Hv, GD1, Hv, Hv, ACT_RELU, D1, Hv), t,
                          "dec.heads dx", "dec.l1 dx -> (dmean, dlog_std)");
         }

@@ -55,7 +55,7 @@ extern "C" unsigned rl_timing_count() { unsigned n = 0; (void)hipMemcpyFromSymbo
 // the eight tasks' first tiles, their column-tile counts packed two to a word -- which the hardware PRELOADS into SGPRs at wave launch
 // (build.sh compiles this file with -mllvm -amdgpu-kernarg-preload-count=14): a workgroup knows its task and tile without a single load,
 // and its first scalar-load round trip is the task record itself.
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false, int EPI_K = -1, int ACT_K = -1>
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false, int EPI_K = -1, int ACT_K = -1, bool MSE = false>
 __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6, int tb7,
                                                      unsigned tc01, unsigned tc23, unsigned tc45, unsigned tc67, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     asm volatile("" :: "s"(tr), "s"(tc), "s"(ti));
     TIM(7);                       // task and tile known (preloaded scalars only): what follows is the record's scalar-load round trip
     float* const pC = t.C; const int epi = t.epi;
-    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K>(t, tr, tc, red, bsum, nullptr, tim_c);
+    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K, false, MSE>(t, tr, tc, red, bsum, nullptr, tim_c);
 #else
-    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K>(t, tr, tc, red, bsum, nullptr);
+    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K, false, MSE>(t, tr, tc, red, bsum, nullptr);
 #endif
     TIM_FIN();
 }
@@ -213,6 +213,16 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
             for (int q = 0; q < gb->ntasks; ++q) {
                 rep = rep && gb->t[q].epi == EPI_DX_REPARAM; plain = plain && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_NONE;
                 elu = elu && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_ELU;
+            }
+            // FLAG_PRE_MSE (vlsac decoder: the heads + mse launch rides here): one task, reparameterisation epilogue, 16-byte-aligned M / Wt rows
+            bool mse = false;
+            for (int q = 0; q < gb->ntasks; ++q) mse = mse || (gb->t[q].flags & FLAG_PRE_MSE);
+            if (mse) {
+                const GemmTask& m0 = gb->t[0];
+                if (gb->ntasks != 1 || !rep || (m0.ldaux2 & 3) || (m0.ldx1 & 3) || (m0.K & 3) || ((((uintptr_t)m0.x2) | ((uintptr_t)m0.x1)) & 15) || !m0.bias || !m0.tgs || !m0.tgr || !m0.mse_part || !m0.x0)
+                    return -3;
+                hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
+                return (int)hipGetLastError();
             }
             if (elu) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(*gb));
             else if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));

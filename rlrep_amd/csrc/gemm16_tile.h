@@ -105,9 +105,11 @@ __device__ __forceinline__ void mac_group(const float* __restrict__ A, int lda, 
 // MLPs, whose weights are stored [k][j] with 92-byte rows, made every fragment load touch 16-23 cache lines and lost: DESIGN.md 5.0.)
 struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const float* M; int ldm; float* out; int ldo; };
 
-template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false>
+// XS (FLAG_PRE_MSE): the row operand X of the short product sits in LDS ([16][RL_XS_LD] floats, written by this tile's first phase) instead of memory
+#define RL_XS_LD 36
+template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false, bool XLDS = false>
 __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
-                                              int i, int kq, int kb, int K, bool store, bool elu, f32x4 (&acc)[NF]) {
+                                              int i, int kq, int kb, int K, bool store, bool elu, f32x4 (&acc)[NF], const float* xs = nullptr) {
     float xf[NJ][4], wf[NU][NJ][4], mk[NU][4], b[NU][NF][4];
     const int K1 = ps.K1;
     const size_t xrow = (size_t)min(r0 + i, R - 1) * ps.ldx;
@@ -116,7 +118,7 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 #pragma unroll
     for (int jc = 0; jc < NJ; ++jc)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xf[jc][m] = rl_ld<COH>(ps.X, xrow + min(16 * jc + 4 * kq + m, K1 - 1));
+        for (int m = 0; m < 4; ++m) xf[jc][m] = XLDS ? xs[i * RL_XS_LD + 16 * jc + 4 * kq + m] : rl_ld<COH>(ps.X, xrow + min(16 * jc + 4 * kq + m, K1 - 1));
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int kcol = min(kb + 64 * u + i, K - 1);
@@ -192,7 +194,8 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // barrier passed" and "tile stored" in tools/exp/gemm_timeline.py, for five VALU instructions and a store).
 // GATHER: operand-A rows come through the task's row-index table (gidx), e.g. straight out of the replay ring (forward launches that ride in
 // the optimizer launch of the previous step: the minibatch slot is being gathered by other workgroups of the same launch).
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false>
+// MSE (with PRE, dX form): FLAG_PRE_MSE launches -- the short product's row operand is computed by a first phase of the tile (common.h)
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false, bool MSE = false>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
                                             const float* const* dyn RL_TIM_PARAM) {
     // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
@@ -295,12 +298,56 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         // forward form (LB = LD_ROW): K1 <= 48, bias + ReLU; dX form (LB = LD_COL): K1 <= 32, ReLU mask
         constexpr int NJ = (LB == LD_ROW) ? 3 : 2;
         constexpr bool FW = (LB == LD_ROW);
+        const float* xs = nullptr;
+        if constexpr (MSE) {
+            // ---- first phase: X = dmse( M Wt^T + bias ; targets ) for this tile's 16 rows, K1 <= 32 columns (FLAG_PRE_MSE) ----
+            // P[16 x 32] over the inner dimension K, split over the four waves as in the main loop (16-byte loads: the launcher checks alignment)
+            f32x4 pacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            float dummy = 0.f;
+            for (int kb = w * 16; kb < K; kb += 256) {
+                const int k0 = kb + 4 * kq;
+                const int nu = (K - kb + 63) >> 6;
+                if (nu >= 4) mac_group<LD_ROW, LD_ROW, 2, true, true, 4, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
+                else if (nu == 1) mac_group<LD_ROW, LD_ROW, 2, true, true, 1, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
+                else if (nu == 2) mac_group<LD_ROW, LD_ROW, 2, true, true, 2, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
+                else mac_group<LD_ROW, LD_ROW, 2, true, true, 3, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
+            }
+            // fixed-order reduction over the waves through the LDS patch of the main product (NF = 1 launches: room for ONE fragment per pass)
+            __shared__ float XS[16 * RL_XS_LD];
+            float es = 0.f, er = 0.f;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[w][0][q][lane] = pacc[f][q];
+                __syncthreads();
+                const int c = 16 * f + (ol & 15);
+                const float v = ((red[0][0][oreg][ol] + red[1][0][oreg][ol]) + red[2][0][oreg][ol]) + red[3][0][oreg][ol];
+                float g = 0.f;
+                if (r < R && c < ps.K1) {
+                    const float pred = v + t.bias[c];
+                    if (c < t.pad_mse) { const float d = pred - t.tgs[(size_t)r * t.ldtgs + c]; es += d * d; g = d * t.s0; }
+                    else { const float d = pred - t.tgr[r]; er += d * d; g = d * t.s1; }
+                    if (tc == 0) const_cast<float*>(ps.X)[(size_t)r * ps.ldx + c] = g;          // the weight-gradient pass reads X
+                }
+                XS[((ol >> 4) * 4 + oreg) * RL_XS_LD + c] = g;
+            }
+            es = wave_sum(es); er = wave_sum(er);
+            __syncthreads();
+            if (lane == 0) { red[0][0][0][w] = es; red[0][0][1][w] = er; }
+            __syncthreads();
+            if (tc == 0 && threadIdx.x == 0) {
+                t.mse_part[2 * tr] = ((red[0][0][0][0] + red[0][0][0][1]) + red[0][0][0][2]) + red[0][0][0][3];
+                t.mse_part[2 * tr + 1] = ((red[0][0][1][0] + red[0][0][1][1]) + red[0][0][1][2]) + red[0][0][1][3];
+            }
+            xs = XS;
+        }
         for (int kb = w * 16; kb < K; kb += 256) {
             const int nu = (K - kb + 63) >> 6;
-            if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
-            else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
-            else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
-            else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc);
+            if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
+            else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
+            else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
+            else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
         }
     } else
     for (int kb = w * 16; kb < K; kb += 256) {

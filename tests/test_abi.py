@@ -77,23 +77,24 @@ def test_gemm_routing_of_the_path_shapes():
     assert _plan(0, 0, 256, 256, 256)['engine'] == 0
     assert _plan(0, 0, 256, 512, 256)['engine'] == 0
     assert _plan(1, 1, 256, 256, 256)['engine'] == 0
-    # ctrlsac main.py dims: M = 256 layers -> 64-wide tiles + split-K; weight gradients -> 64-wide tiles, no split
+    # ctrlsac main.py dims: M = 256 layers -> 64-wide bf16x3 tiles (gemm_x3s_kernel) + split-K; weight gradients -> the same tile, no split
     p = _plan(0, 0, 256, 1024, 1024)
-    assert (p['engine'], p['tile']) == (1, 64) and p['splits'] == 4 and p['splits'] * p['kchunk'] >= 1024 > (p['splits'] - 1) * p['kchunk']
+    assert (p['engine'], p['tile']) == (2, 64) and p['splits'] == 4 and p['splits'] * p['kchunk'] >= 1024 > (p['splits'] - 1) * p['kchunk']
     p = _plan(1, 1, 1024, 1024, 256)
-    assert (p['engine'], p['tile'], p['splits']) == (1, 64, 1)
+    assert (p['engine'], p['tile'], p['splits']) == (2, 64, 1)
     # spedersac: both batches as one M = 2048 problem; the K = 119 first layer and its [512, 119] weight gradient use scalar sides
-    assert _plan(0, 0, 2048, 512, 512)['engine'] == 1
+    # (those stay on the fp32 tile: the bf16x3 64-wide tile has 16-byte loaders only)
+    assert _plan(0, 0, 2048, 512, 512)['engine'] == 2
     p = _plan(0, 0, 2048, 512, 119)
     assert p['engine'] == 1 and p['scalar'] == 3          # A and B rows of 119 floats
     p = _plan(1, 1, 512, 119, 2048, lda=512, ldb=119, ldc=119)
     assert p['engine'] == 1 and p['scalar'] == 6 and p['splits'] > 1
-    # diffsrsac Humanoid nabla-mu head: forward and dX on the bf16 pipe, dW on fp32 MFMA, dX split along its long K
+    # diffsrsac Humanoid nabla-mu head: all three passes on the bf16 pipe (dX / dW through transposed LDS reads), dX split along its long K
     assert _plan(0, 0, 2048, 96256, 512) == dict(engine=2, tile=128, splits=1, kchunk=512, scalar=0)
     p = _plan(0, 1, 2048, 512, 96256)
     assert p['engine'] == 2 and p['splits'] == 8 and p['splits'] * p['kchunk'] >= 96256 > (p['splits'] - 1) * p['kchunk'] and p['kchunk'] % 32 == 0
     p = _plan(1, 1, 96256, 512, 2048)
-    assert (p['engine'], p['tile'], p['splits']) == (1, 128, 1)
+    assert (p['engine'], p['tile'], p['splits']) == (2, 128, 1)
     # every plan over a sweep: splits cover K, chunks are multiples of the 32-deep slice, tiles are 64 or 128
     for R in (256, 1000, 2048, 4096):
         for Cn in (256, 520, 2048):

@@ -305,6 +305,26 @@ def test_snapshot_rides_in_the_last_feature_optimizer_launch(monkeypatch):
     assert counts[False] == counts[True] + 1, counts
 
 
+def test_decoder_heads_and_mse_ride_in_the_decoder_dx_launch(monkeypatch):
+    """FLAG_PRE_MSE (vlsac_agent.py:137-140's s_loss / r_loss): every 16-row tile of the decoder.l1 dX launch computes the heads' forward,
+    the mse gradient and its squared-error partials itself, so the 'dec.heads + mse' launch leaves each feature step.
+    RLREP_NO_FOLD_MSE=1 keeps the separate launch.  Both forms against the oracle (s_loss / r_loss are among the compared metrics), and the
+    captured feature graph is one launch per feature step shorter."""
+    c = Case('vlsac_hc')
+    counts = {}
+    for fold in (True, False):
+        if not fold:
+            monkeypatch.setenv('RLREP_NO_FOLD_MSE', '1')
+        agent, buf = _default_agent(c), _buffer(c)
+        agent.train(buf, c.B)
+        agent.flush()
+        counts[fold] = agent._pipe['launches'][0]
+        steps = agent.extra_feature_steps + 1
+        del agent
+        _check_against_oracle(c, calls=3, expect_pipeline=True)
+    assert counts[False] == counts[True] + steps, counts
+
+
 def test_chained_feature_steps_change_nothing(monkeypatch):
     """rlrep_feature_chain_next (vlsac_agent.py:250-256's loop of feature steps, chained): the first layers' optimizer runs in the weight-gradient
     epilogues and the step's optimizer launch carries the next step's encoder.l1 / f.l1 on rows read straight from the ring.  Against
