@@ -1705,7 +1705,8 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         rc = rl_launch_gemm16(la, lb, 1, &gb, t.ntiles, (hipStream_t)stream);
     } else {
         t.flags |= rl_gemm_lds_dim_flags(&t, la, lb) | rl_gemm_lds_ptr_flags(&t);
-        if (engine == 2 && (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) ) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
+        // (the 64-wide bf16x3 tile has any-alignment loaders; the 128-wide one needs 16-byte-regular operands)
+        if (engine == 2 && (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) && (bt != 64 || R < 4 || Cn < 4 || K < 4)) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
         if (engine == 2 && bt != 64 && (t.flags & FLAG_SCALAR_C)) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
         int pbt = 0, psp = 1, pkc = 0;
         rl_gemm_lds_plan(&t, &pbt, &psp, &pkc);

@@ -747,12 +747,35 @@ __device__ __forceinline__ unsigned x3s_toff(int k, int ch) { return 128u * k + 
 
 // 256 threads stage a 64 x 32 slice.  Row-major: two row slots x four consecutive k; k-major: (k = tid / 16 + 16 j, four rows 4 (tid % 16))
 // VEC (compile time: a run-time choice puts the prefetch loads into a control-flow diamond, and hipcc drains vmcnt at its merge -- the loads then no
-// longer overlap the MFMAs: measured -10 % on every workload): 16-byte loads are legal for this operand; otherwise clamped 4-byte loads (inner lengths
-// like 119, unaligned rows)
-template <bool VEC>
+// longer overlap the MFMAs: measured -10 % on every workload): 1 = 16-byte loads at 16-byte-aligned addresses, lengths multiples of four;
+// 2 = 16-byte loads at ANY 4-byte-aligned address (rows of 119 floats, operands that start inside another buffer: global loads only need dword
+// alignment on this target) with the tail of a length that is no multiple of four fetched as the LAST four elements and shifted into place --
+// no access ever leaves the row; 0 = clamped 4-byte loads (four times the load instructions: slower than the fp32 tile, kept for reference)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// y[q] = x[q + d] (0 beyond the vector): d = how far the load was pulled back to stay inside the row (>= 4: nothing valid)
+__device__ __forceinline__ f32x4 x3s_shift(const f32x4 x, int d) {
+    // two select stages on the bits of d (plain v_cndmask: a chain of comparisons on d became a jump table, and a branch between the prefetch loads
+    // and the MFMAs drains vmcnt)
+    const bool b0 = (d & 1) != 0, b1 = (d & 2) != 0, z = d >= 4;
+    const float t0 = b0 ? x[1] : x[0], t1 = b0 ? x[2] : x[1], t2 = b0 ? x[3] : x[2], t3 = b0 ? 0.f : x[3];
+    f32x4 y;
+    y[0] = b1 ? t2 : t0; y[1] = b1 ? t3 : t1; y[2] = b1 ? 0.f : t2; y[3] = b1 ? 0.f : t3;
+    y[0] = z ? 0.f : y[0]; y[1] = z ? 0.f : y[1]; y[2] = z ? 0.f : y[2]; y[3] = z ? 0.f : y[3];
+    return y;
+}
+template <int VEC>
 __device__ __forceinline__ void x3s_load_row(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[8]) {
     const int kc = (threadIdx.x & 7) * 4;
-    if constexpr (VEC) {
+    if constexpr (VEC == 2) {
+        const int kl = min(k0 + kc, kend - 4), d = k0 + kc - kl;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
+            const f32x4 x = x3s_shift(*reinterpret_cast<const f32x4u*>(P + (size_t)r * ld + kl), d);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
+        }
+    } else if constexpr (VEC == 1) {
         const int k = min(k0 + kc, kend - 4);
         const bool ok = (k0 + kc) < kend;
 #pragma unroll
@@ -785,10 +808,19 @@ __device__ __forceinline__ void x3s_write_row(unsigned char* __restrict__ img, c
         *reinterpret_cast<u32x2*>(p + 2 * X3S_RIMGB) = lo;
     }
 }
-template <bool VEC>
+template <int VEC>
 __device__ __forceinline__ void x3s_load_col(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, f32x4 (&e)[2]) {
     const int c4 = (int)(threadIdx.x & 15) * 4;
-    if constexpr (VEC) {
+    if constexpr (VEC == 2) {
+        const int il = min(base + c4, lim - 4), d = base + c4 - il;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+            const int k = min(k0 + kk, kend - 1);
+            const f32x4 x = x3s_shift(*reinterpret_cast<const f32x4u*>(P + (size_t)k * ld + il), d);
+            e[j] = (k0 + kk) < kend ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    } else if constexpr (VEC == 1) {
         const int i = min(base + c4, lim - 4);
         const bool iok = (base + c4) < lim;
 #pragma unroll
@@ -829,7 +861,7 @@ __device__ __forceinline__ unsigned x3s_taddr(unsigned lds_base, int kq, int chu
     return lds_base + x3s_toff(kq + q, chunk0 + (pp >> 1)) + 8u * (pp & 1);
 }
 
-template <int LA, int LB, bool VEC>
+template <int LA, int LB, int VEC>
 __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GemmBatch gb) {
     constexpr int BT = 64;
     constexpr int AIMG = LA == LD_ROW ? X3S_RIMGB : X3S_TIMGB, BIMG = LB == LD_ROW ? X3S_RIMGB : X3S_TIMGB;
@@ -977,11 +1009,21 @@ static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
     return (int)hipGetLastError();
 }
 
+static bool x3s_unaligned_ok(const GemmTask* t) { return t->R >= 4 && t->Cn >= 4 && t->K >= 4; }       // (the pulled-back tail load needs four elements to exist)
 static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
-    for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) return -2;       // 16-byte staging only (the router guarantees it)
-    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, true>), g, dim3(256), 0, st, gb);
-    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, true>), g, dim3(256), 0, st, gb);
-    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, true>), g, dim3(256), 0, st, gb);
+    // one instantiation per launch: the any-alignment loaders as soon as ONE task of the stage has an operand that is not 16-byte regular
+    bool unal = false;
+    for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) { unal = true; if (!x3s_unaligned_ok(&gb.t[q])) return -2; }
+    if (unal) {
+        if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, 2>), g, dim3(256), 0, st, gb);
+        else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, 2>), g, dim3(256), 0, st, gb);
+        else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, 2>), g, dim3(256), 0, st, gb);
+        else return -1;
+        return (int)hipGetLastError();
+    }
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, 1>), g, dim3(256), 0, st, gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, 1>), g, dim3(256), 0, st, gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, 1>), g, dim3(256), 0, st, gb);
     else return -1;
     return (int)hipGetLastError();
 }
@@ -1073,9 +1115,11 @@ extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_fl
     // 64-wide tiles: on the bf16 pipe too when both operands allow 16-byte staging (gemm_x3s_kernel); RLREP_X3S_OFF keeps the fp32 tile
     // (the program builder keeps a STAGE on one engine: a stage whose tasks would be split between this tile and the fp32 one becomes two dependent
     // launches, which costs more than the faster tile returns -- spedersac: 69 -> 81 launches on the feature chain, 961 -> 903 train()/s)
-    // (operands that need element-wise staging keep their stage on the fp32 tile: a scalar-staging instantiation of the bf16x3 tile was built and
-    // measured -- spedersac 968 with it against 1 002 with those stages on fp32, ctrlsac F = 2048 865 against 904)
-    if (bt == 64 && !getenv("RLREP_NO_X3") && !getenv("RLREP_X3S_OFF") && !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B))) return 65;
+    // (operands that are not 16-byte regular -- rows of 119 floats, a block that starts inside another buffer -- take the any-alignment loaders of the
+    // same tile (x3s_load_*<2>); RLREP_X3S_ALIGNED_ONLY=1 keeps such stages on the fp32 tile as before.  A 4-byte-staging instantiation was built and
+    // measured first -- spedersac 968 with it against 1 002 with those stages on fp32, ctrlsac F = 2048 865 against 904)
+    if (bt == 64 && !getenv("RLREP_NO_X3") && !getenv("RLREP_X3S_OFF") &&
+        (!(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) || (x3s_unaligned_ok(t) && !getenv("RLREP_X3S_ALIGNED_ONLY")))) return 65;
     return bt;
 }
 

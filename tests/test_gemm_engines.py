@@ -183,6 +183,20 @@ def test_bf16x3_64_wide_tile_is_fp32_accurate(mode):
     assert rel(got, want) < 2e-6, rel(got, want)
 
 
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+def test_bf16x3_64_wide_tile_takes_operands_of_any_alignment(mode):
+    """x3s_load_*<2>: rows of 119 / 111 / 333 floats and widths that are no multiples of four (spedersac's K = 119 and 111 first layers and their
+    [512, 119] weight gradients) staged with 16-byte loads at 4-byte-aligned addresses, the tail of a row fetched as its LAST four elements
+    and shifted into place; split-K included.  Same shapes as the fp32 tile's scalar-access test, at the bf16x3 tile's accuracy."""
+    check(2, mode, 260, 119, 119, bt=64, splits=1, seed=60, act='elu' if mode != 'dw' else 'none')
+    check(2, mode, 128, 119, 333, bt=64, splits=3, seed=61, accum=(mode != 'fwd'))
+    check(2, mode, 132, 65, 111, bt=64, splits=1, seed=62)
+    check(2, mode, 2048, 512, 119, bt=64, seed=63)                   # spedersac phi.l0 (forward) / its shapes in the other two forms
+    check(2, mode, 512, 119, 2048, bt=64, seed=64)                   # ... and the [512, 119] weight gradient's, the planner's own split
+    got, want, _ = run_gemm(2, mode, 255, 127, 253, bt=64, splits=1, seed=65)
+    assert rel(got, want) < 2e-6, rel(got, want)
+
+
 def test_bf16x3_engine_wide_dynamic_range():
     """operands spanning 12 decades: the split is exact per element, so the error stays relative to sum |a||b|"""
     from rlrep_amd import _lib
