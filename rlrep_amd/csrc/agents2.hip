@@ -531,7 +531,10 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
             for (int l = 0; l <= phi.depth; ++l) t.push_back(mlp_dw(ag, phi, pf, l, X2, SA));
             for (int l = 0; l <= mu.depth; ++l) t.push_back(mlp_dw(ag, mu, mf, l, S2, KE));
             t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
+            // the split-K partials of these gradients (K = 2B rows) are summed by the optimizer launch below: no finishing launch in the step
+            if (!getenv("RLREP_NO_FOLD_DWFIN")) b.fold_group = 0;
             b.dw_stage(p, t, "feature dW");
+            b.fold_group = -1;
         }
         const LT& p0 = ag->L.get(phi.name(0) + ".weight");
         const LT& pl = ag->L.get(phi.name(phi.depth) + ".bias");

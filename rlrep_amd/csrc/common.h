@@ -65,6 +65,7 @@ enum Epi : int {
 // EPI_DW only: the optimizer runs in this task's epilogue (Adam on the tile's own weights and, column tile 0, bias; Polyak into the target
 // copy where ad_t / ad_tb are set) -- the FIRST layers of the vlsac feature nets, whose updated weights the next feature step's first launch
 // needs, so that the rest of the group's optimizer work can share a launch with that first layer.  GemmTask::ad_*.
+#define FLAG_FIN_IN_ADAM 8192  // split-K task of the LDS-tiled engine whose partial slabs are summed by its group's optimizer launch (AdamTask::Slab): no finishing blocks
 #define FLAG_ADAM 2048
 
 struct GroupCfg;
@@ -185,7 +186,9 @@ struct AdamTask {
     // [off, off + n) of the group the gradient is the sum, in split order, of slab[(q * splits + sp) * per + r] (q = l / per, r = l % per,
     // l = element - off) -- the finishing launch those partials used to need rides here, and the sum is filed in the gradient arena too.
     // per % 4 == 0, off % 4 == 0, 16-byte aligned slabs (the builder only folds then).  nslab = 0: plain gradients.
-    struct Slab { long long off, n, per; const float* slab; int splits, pad; } slabs[2];
+    // cols > 0: ONE matrix of rows of `cols` elements whose slab rows are padded to `ldpad` floats (the LDS-tiled engine's split-K slabs of a
+    // [512, 119] gradient: ldpad = 120), consecutive splits `sstride` floats apart: element l sits at slab[sp * sstride + (l / cols) * ldpad + l % cols].
+    struct Slab { long long off, n, per, sstride; const float* slab; int splits, cols, ldpad, pad; } slabs[8];
     int nslab;
     // ranges of the group that this launch leaves alone (their optimizer ran in the weight-gradient epilogues: FLAG_ADAM); multiples of 4 floats
     int nskip; long long skip_off[2], skip_n[2];

@@ -440,17 +440,34 @@ __device__ __forceinline__ void adam_block(const int bid, float* __restrict__ ap
     if (vec && t.nslab) {
         // split-K partial gradients finished here (AdamTask::Slab): all partials in flight together, summed in split order (the order of
         // the finishing launch this replaces: bit-identical), the sum filed in the gradient arena for whoever reads gradients
+        int qs = -1;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (q >= t.nslab || i < t.slabs[q].off || i >= t.slabs[q].off + t.slabs[q].n) continue;
-            const long long l = i - t.slabs[q].off, task = l / t.slabs[q].per, r = l - task * t.slabs[q].per;
-            const float* s0 = t.slabs[q].slab + (size_t)task * t.slabs[q].splits * t.slabs[q].per + r;
-            f32x4 part[16];
+        for (int q = 0; q < 8; ++q) if (q < t.nslab && i >= t.slabs[q].off && i < t.slabs[q].off + t.slabs[q].n) qs = q;
+        if (qs >= 0) {
+            const AdamTask::Slab& sl = t.slabs[qs];
+            const long long l = i - sl.off;
+            const int splits = sl.splits;
+            if (sl.cols == 0 || sl.cols == sl.ldpad) {
+                const long long task = l / sl.per, r = l - task * sl.per;
+                const long long ss = sl.cols ? sl.sstride : sl.per;
+                const float* s0 = sl.slab + (size_t)task * splits * sl.per + r;
+                f32x4 part[16];
 #pragma unroll
-            for (int sp = 0; sp < 16; ++sp) part[sp] = *reinterpret_cast<const f32x4*>(s0 + (size_t)min(sp, t.slabs[q].splits - 1) * t.slabs[q].per);
-            g = part[0];
+                for (int sp = 0; sp < 16; ++sp) part[sp] = *reinterpret_cast<const f32x4*>(s0 + (size_t)min(sp, splits - 1) * ss);
+                g = part[0];
 #pragma unroll
-            for (int sp = 1; sp < 16; ++sp) if (sp < t.slabs[q].splits) g += part[sp];
+                for (int sp = 1; sp < 16; ++sp) if (sp < splits) g += part[sp];
+            } else {
+                // padded slab rows (cols % 4 != 0): the four elements may sit on two rows -- element-wise, same split order
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const long long ll = l + s, row = ll / sl.cols, col = ll - row * sl.cols;
+                    const float* s0 = sl.slab + (size_t)row * sl.ldpad + col;
+                    float a = s0[0];
+                    for (int sp = 1; sp < splits; ++sp) a += s0[(size_t)sp * sl.sstride];
+                    g[s] = a;
+                }
+            }
             *reinterpret_cast<f32x4*>(const_cast<float*>(agr) + i) = g;
         }
     }

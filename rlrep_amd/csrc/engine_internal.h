@@ -185,13 +185,41 @@ struct Builder {
         if (!big64.empty()) gemm_lds_stage(p, la, lb, 64, big64, what);
         if (!small.empty()) gemm_small(p, la, lb, small, what);
     }
+    // fold_group >= 0 (set by an agent's builder around its weight-gradient stage): the split-K weight-gradient tasks built now leave the sum of
+    // their partial slabs to that group's optimizer launch (AdamTask::Slab) -- no finishing blocks for them, and when no task of the stage
+    // keeps any, no finishing launch.  Only when nothing reads the gradient between the two (one rank), the tensors start on multiples of four
+    // floats inside the group and at most eight slabs ride in one launch.
+    int fold_group = -1;
+    bool fold_fin(GemmTask& t) {
+        if (fold_group < 0 || dry || t.epi != EPI_DW || (t.flags & FLAG_ACCUM) || t.splits > 16 || !t.slab || !ag->a.grad_dev || ag->h.world_size > 1) return false;
+        const bool bias = (t.flags & FLAG_BIASGRAD) && t.out2 && t.bslab;
+        auto& gs = group_slabs[fold_group];
+        if (gs.size() + (bias ? 2 : 1) > 8 || t.ldc != t.Cn) return false;
+        const int64_t g0 = ag->L.group_off[fold_group], gn = ag->L.group_n[fold_group];
+        if (gn & 3) return false;
+        const int64_t offw = (t.C - ag->a.grad_dev) - g0, offb = bias ? (t.out2 - ag->a.grad_dev) - g0 : 0;
+        const int64_t nw = (int64_t)t.R * t.Cn;
+        if (offw < 0 || offw + nw > gn || (offw & 3) || (nw & 3)) return false;
+        if (bias && (offb < 0 || offb + t.R > gn || (offb & 3) || (t.R & 3))) return false;
+        const int ldpad = (t.Cn + 3) & ~3;
+        AdamTask::Slab sw; memset(&sw, 0, sizeof(sw));
+        sw.off = offw; sw.n = nw; sw.per = nw; sw.sstride = (long long)t.R * ldpad; sw.slab = t.slab; sw.splits = t.splits; sw.cols = t.Cn; sw.ldpad = ldpad;
+        gs.push_back(sw);
+        if (bias) {
+            AdamTask::Slab sb; memset(&sb, 0, sizeof(sb));
+            sb.off = offb; sb.n = t.R; sb.per = t.R; sb.sstride = t.R; sb.slab = t.bslab; sb.splits = t.splits;
+            gs.push_back(sb);
+        }
+        t.flags |= FLAG_FIN_IN_ADAM;
+        return true;
+    }
     void gemm_lds_stage(Program& p, int la, int lb, int bt, std::vector<GemmTask> tasks, const char* what) {
         int base = 0, fin = 0;
         const int edge = bt == 129 ? 128 : bt == 65 ? 64 : bt;       // 129 / 65: the 128- / 64-wide tile on the bf16 pipe
         for (auto& t : tasks) {
             t.tiles_c = (t.Cn + edge - 1) / edge;
             t.ntiles = ((t.R + edge - 1) / edge) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
-            if (t.splits > 1) {
+            if (t.splits > 1 && !fold_fin(t)) {
                 const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
                 t.fin_base = fin;
                 fin += (int)(((long long)t.R * ((t.Cn + 3) / 4) + 255) / 256) + (bias ? (t.R + 255) / 256 : 0);
@@ -438,7 +466,7 @@ struct Builder {
         t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = pol_steps; t.pol_period = pol_period;
         t.sh = ag->sh_dev[group]; t.nsh = ag->nsh[group];
-        t.nslab = (int)std::min<size_t>(group_slabs[group].size(), 2);
+        t.nslab = (int)std::min<size_t>(group_slabs[group].size(), 8);
         for (int q = 0; q < t.nslab; ++q) t.slabs[q] = group_slabs[group][q];
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
         const int nfin_all = (int)fin.size();

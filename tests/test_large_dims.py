@@ -103,6 +103,31 @@ def test_spedersac_ant_dimensions_two_trains():
          trains=2)
 
 
+def test_spedersac_split_k_gradients_summed_by_the_optimizer_launch(monkeypatch):
+    """Builder::fold_fin (AdamTask::Slab with padded slab rows): the split-K partials of phi / mu's weight gradients -- [512, 119] and [512, 111]
+    among them, slab rows padded to 120 / 112 floats -- are added in split order by the feature group's optimizer launch instead of a finishing
+    launch.  Against RLREP_NO_FOLD_DWFIN=1: one launch less per feature step, parameters and moments BIT-identical after two train() calls at
+    Ant dimensions (both forms are checked against the oracle by _run)."""
+    outs, counts = [], []
+    for fold in (True, False):
+        if not fold:
+            monkeypatch.setenv('RLREP_NO_FOLD_DWFIN', '1')
+        from rlrep_amd import _lib
+        n0 = _lib.lib.rlrep_launch_counter()
+        a = _run('spedersac', ('rlrep_amd.agent.spedersac.spedersac_agent', 'SPEDERSACAgent'), 111, 8, 1024,
+                 dict(phi_and_mu_lr=1e-5, phi_hidden_dim=512, phi_hidden_depth=1, mu_hidden_dim=512, mu_hidden_depth=0,
+                      critic_and_actor_lr=3e-4, critic_and_actor_hidden_dim=256, feature_dim=512, hidden_dim=256, extra_feature_steps=1),
+                 trains=2)
+        st = {k: v.numpy().copy() for k, v in a.core.state().items()}
+        st['exp_avg'] = a.core.exp_avg.cpu().numpy().copy(); st['exp_avg_sq'] = a.core.exp_avg_sq.cpu().numpy().copy()
+        outs.append(st)
+        counts.append(_lib.lib.rlrep_launch_counter() - n0)
+        del a
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert counts[1] == counts[0] + 2 * 2, counts          # (two train() calls x two feature steps)
+
+
 def test_diffsrsac_wide_nabla_mu_head_on_bf16x3():
     """S = 76, F = 256, B = 1024: the nabla-mu head is 1024 x 512 x 19 456 (20 GFLOP per pass) -- the size class whose
     forward and dX the builder sends to the bf16x3 tile (Humanoid: 2048 x 512 x 96 256)"""
