@@ -82,13 +82,13 @@ def test_gemm_routing_of_the_path_shapes():
     assert (p['engine'], p['tile']) == (2, 64) and p['splits'] == 4 and p['splits'] * p['kchunk'] >= 1024 > (p['splits'] - 1) * p['kchunk']
     p = _plan(1, 1, 1024, 1024, 256)
     assert (p['engine'], p['tile'], p['splits']) == (2, 64, 1)
-    # spedersac: both batches as one M = 2048 problem; the K = 119 first layer and its [512, 119] weight gradient use scalar sides
-    # (those stay on the fp32 tile: the bf16x3 64-wide tile has 16-byte loaders only)
+    # spedersac: both batches as one M = 2048 problem; the K = 119 first layer and its [512, 119] weight gradient have rows that are not
+    # 16-byte regular ("scalar" sides): the 64-wide bf16x3 tile takes them through its any-alignment loaders
     assert _plan(0, 0, 2048, 512, 512)['engine'] == 2
     p = _plan(0, 0, 2048, 512, 119)
-    assert p['engine'] == 1 and p['scalar'] == 3          # A and B rows of 119 floats
+    assert (p['engine'], p['tile']) == (2, 64) and p['scalar'] == 3          # A and B rows of 119 floats
     p = _plan(1, 1, 512, 119, 2048, lda=512, ldb=119, ldc=119)
-    assert p['engine'] == 1 and p['scalar'] == 6 and p['splits'] > 1
+    assert (p['engine'], p['tile']) == (2, 64) and p['scalar'] == 6 and p['splits'] > 1
     # diffsrsac Humanoid nabla-mu head: all three passes on the bf16 pipe (dX / dW through transposed LDS reads), dX split along its long K
     assert _plan(0, 0, 2048, 96256, 512) == dict(engine=2, tile=128, splits=1, kchunk=512, scalar=0)
     p = _plan(0, 1, 2048, 512, 96256)
