@@ -93,6 +93,57 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     TIM_FIN();
 }
 
+// The launches of ONE or TWO plain forward / dX tasks whose inner length is a multiple of 256 (every 256- / 512-deep layer of the feature and
+// critic / actor steps at the headline dimensions): the 14 preloaded scalars carry what the operand LOADS need instead of a task directory --
+// a common base and, per task, the A / B offsets from it in floats, lda | ldb << 16, K | R << 16, Cn | log2(column tiles) << 16 -- so the
+// first operand loads issue from preloaded SGPRs while the record's scalar loads are still in flight (gemm16_tile FAST).
+template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K>
+__global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, const float* base, unsigned a0, unsigned b0, unsigned ld0, unsigned kr0, unsigned ct0,
+                                                          unsigned a1, unsigned b1, unsigned ld1, unsigned kr1, unsigned ct1, GemmBatch gb) {
+    __shared__ float red[4][NF][4][64];
+    __shared__ float bsum[4][16];
+    if (!(hdr & 1)) __builtin_amdgcn_s_setprio(3);
+    const int bid = blockIdx.x;
+    const bool second = bid >= tb1;
+    const unsigned ao = second ? a1 : a0, bo = second ? b1 : b0, ld = second ? ld1 : ld0, kr = second ? kr1 : kr0, ct = second ? ct1 : ct0;
+    const int local = second ? bid - tb1 : bid, sh = (int)(ct >> 16);
+    const int tr = local >> sh, tc = local & ((1 << sh) - 1);
+    FastOps fo;
+    fo.pA = base + (size_t)ao; fo.pB = base + (size_t)bo; fo.lda = (int)(ld & 0xffffu); fo.ldb = (int)(ld >> 16);
+    fo.K = (int)(kr & 0xffffu); fo.R = (int)(kr >> 16); fo.Cn = (int)(ct & 0xffffu); fo.tiles_c = 1 << sh;
+    int ti = __builtin_amdgcn_readfirstlane(second ? 1 : 0);
+    asm volatile("" : "+s"(ti));          // (opaque: with a visible 0 / 1 hipcc loads BOTH records and selects field by field -- behind one s_waitcnt in front of the operand loads)
+    const GemmTask& t = gb.t[ti];
+#ifdef RL_TIMING
+    unsigned long long* const tim_none = nullptr;
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_none, &fo);
+#else
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
+#endif
+}
+// host side of the above: the 13 argument values, or false when the launch does not qualify
+struct FastArgs { int hdr, tb1; const float* base; unsigned a[2], b[2], ld[2], kr[2], ct[2]; };
+static bool fast_args(const GemmBatch& gb, FastArgs& fa) {
+    if (gb.ntasks < 1 || gb.ntasks > 2 || getenv("RLREP_GEMM16_NO_FAST")) return false;
+    uintptr_t lo = ~(uintptr_t)0;
+    for (int q = 0; q < gb.ntasks; ++q) { lo = std::min(lo, (uintptr_t)gb.t[q].A); lo = std::min(lo, (uintptr_t)gb.t[q].B); }
+    lo &= ~(uintptr_t)15;
+    fa.hdr = gb.low_prio ? 1 : 0; fa.tb1 = gb.ntasks > 1 ? gb.t[1].tile_base : 0x7fffffff; fa.base = reinterpret_cast<const float*>(lo);
+    if (gb.t[0].tile_base != 0) return false;
+    for (int q = 0; q < 2; ++q) {
+        const GemmTask& t = gb.t[q < gb.ntasks ? q : 0];
+        const int tcn = t.tiles_c;
+        if (t.K <= 0 || (t.K & 255) || t.K > 0xffff || t.R > 0xffff || t.Cn > 0xffff || t.lda > 0xffff || t.ldb > 0xffff || tcn <= 0 || (tcn & (tcn - 1))) return false;
+        const uintptr_t da = (uintptr_t)t.A - lo, db = (uintptr_t)t.B - lo;
+        if ((da & 3) || (db & 3) || (da >> 2) > 0xffffffffull || (db >> 2) > 0xffffffffull) return false;
+        int sh = 0; while ((1 << sh) < tcn) ++sh;
+        fa.a[q] = (unsigned)(da >> 2); fa.b[q] = (unsigned)(db >> 2); fa.ld[q] = (unsigned)t.lda | ((unsigned)t.ldb << 16);
+        fa.kr[q] = (unsigned)t.K | ((unsigned)t.R << 16); fa.ct[q] = (unsigned)t.Cn | ((unsigned)sh << 16);
+    }
+    return true;
+}
+#define G16_FAST_ARGS(F, B) (F).hdr, (F).tb1, (F).base, (F).a[0], (F).b[0], (F).ld[0], (F).kr[0], (F).ct[0], (F).a[1], (F).b[1], (F).ld[1], (F).kr[1], (F).ct[1], (B)
+
 // TWO tile forms in one launch ("duo"): tasks [0, split) are row-major x k-major products (the dX form, NF = 1), tasks [split, ntasks) k-major
 // x k-major ones (the weight-gradient form, NF = NF2); a workgroup runs the body of the form its task belongs to.  For INDEPENDENT stages of
 // different forms that the step program would otherwise launch one after the other (ctrlsac: d(phi) = dS mu' and d(mu') = dS^T phi both
@@ -147,6 +198,22 @@ static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (getenv("RLREP_GEMM16_GENERIC")) return false;
     const int epi = gb.t[0].epi, act = gb.t[0].act;
     for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].epi != epi || gb.t[q].act != act || (gb.t[q].flags & FLAG_PRE)) return false;
+    // one or two tasks, K % 256 == 0, 16-byte operand A: the front end that loads from preloaded scalars
+    FastArgs fa;
+    if (VA && fast_args(gb, fa)) {
+        if (LB == LD_ROW && epi == EPI_FWD && (act == ACT_NONE || act == ACT_RELU || act == ACT_ELU)) {
+            if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+            else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+            else hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_ELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+            return true;
+        }
+        if (LB == LD_COL && epi == EPI_DX && (act == ACT_NONE || act == ACT_RELU || act == ACT_ELU)) {
+            if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+            else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_DX, ACT_RELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+            else hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+            return true;
+        }
+    }
     if (LB == LD_ROW && epi == EPI_FWD) {
         if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
         else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, G16_ARGS(gb));

@@ -195,13 +195,19 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // GATHER: operand-A rows come through the task's row-index table (gidx), e.g. straight out of the replay ring (forward launches that ride in
 // the optimizer launch of the previous step: the minibatch slot is being gathered by other workgroups of the same launch).
 // MSE (with PRE, dX form): FLAG_PRE_MSE launches -- the short product's row operand is computed by a first phase of the tile (common.h)
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false, bool MSE = false>
+// FAST (gemm16_fast_kernel): what the operand LOADS need -- bases, row strides, extents -- arrives in preloaded SGPRs (FastOps) instead of the
+// record, K is a multiple of 256, and the first 256-deep block's loads are issued BEFORE the record is waited for: the record's scalar-load
+// round trip (~900 cycles, needed by the epilogue only) runs under the operand loads instead of in front of them.
+struct FastOps { const float* pA; const float* pB; int lda, ldb, K, R, Cn, tiles_c; };
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false, bool MSE = false,
+          bool FAST = false>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
-                                            const float* const* dyn RL_TIM_PARAM) {
+                                            const float* const* dyn RL_TIM_PARAM, const FastOps* fo = nullptr) {
+    static_assert(!FAST || (!PRE && !COH && !GATHER && !MSE), "FAST: plain forward / dX tiles only");
     // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
-    const float* const pA = t.A; const float* const pB = t.B; float* const pC = t.C; const float* const pbias = t.bias;
-    const int lda = t.lda, ldb = t.ldb, ldc = t.ldc;
-    const int R = t.R, Cn = t.Cn, K = t.K, tiles_c = t.tiles_c;
+    const float* const pA = FAST ? fo->pA : t.A; const float* const pB = FAST ? fo->pB : t.B; float* const pC = t.C; const float* const pbias = t.bias;
+    const int lda = FAST ? fo->lda : t.lda, ldb = FAST ? fo->ldb : t.ldb, ldc = t.ldc;
+    const int R = FAST ? fo->R : t.R, Cn = FAST ? fo->Cn : t.Cn, K = FAST ? fo->K : t.K, tiles_c = FAST ? fo->tiles_c : t.tiles_c;
     const int epi = EPI_K == EPI_DWA ? EPI_DW : EPI_K >= 0 ? EPI_K : t.epi, act = ACT_K >= 0 ? ACT_K : t.act, flags = t.flags, n0 = t.n0;
     const int* const pgidx = GATHER ? t.gidx : nullptr;
     const float scale = t.scale;
@@ -213,6 +219,18 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     if (COH && dyn && spx2) {
         const float* const px2 = (flags & FLAG_DYN_EPS) ? dyn[0] : (flags & FLAG_DYN_EPS2) ? dyn[1] : (flags & FLAG_DYN_EPS3) ? dyn[2] : sp[1];
         sp[1] = px2;               // (x2 is slot 1 wherever it is a slot)
+    }
+    // FAST: the first 256-deep block's operand loads go out now, from preloaded scalars (the reads of the record above are in flight)
+    float fa[FAST ? 4 : 1][4], fb[FAST ? 4 : 1][NF][4];
+    if constexpr (FAST) {
+        const int lane_ = threadIdx.x & 63, w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int i_ = lane_ & 15, k_ = w_ * 16 + 4 * (lane_ >> 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_raw<LA, VA>(pA, lda, tr * 16, R, i_, k_ + 64 * u, K, fa[u]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) load_raw<LB, VB>(pB, ldb, tc * 16 * NF + 16 * f, Cn, i_, k_ + 64 * u, K, fb[u][f]);
+        }
     }
     // (materialise the whole record HERE: left to itself hipcc loads each slot field next to its first use, between the operand loads,
     // with a scalar-load round trip in front of every one of them)
@@ -349,6 +367,23 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
             else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
             else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
         }
+    } else if constexpr (FAST) {
+        // first block from the registers filled above, then whole 256-deep blocks (K % 256 == 0: the launcher checks)
+        const int k0 = w * 16 + 4 * kq;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mask_frag(r0, R, i, k0 + 64 * u, K, fa[u]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) mask_frag(c0 + 16 * f, Cn, i, k0 + 64 * u, K, fb[u][f]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][s], fb[u][f][s], acc[f], 0, 0, 0);
+        for (int kb = w * 16 + 256; kb < K; kb += 256)
+            mac_group<LA, LB, NF, VA, VB, 4, false, false>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, kb + 4 * kq, K, acc, asum, false);
     } else
     for (int kb = w * 16; kb < K; kb += 256) {
         const int k0 = kb + 4 * kq;
