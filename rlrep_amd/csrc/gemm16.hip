@@ -20,6 +20,7 @@
 // B: lane l holds B[k=l>>4][j=l&15]; C/D: col=l&15, row=4*(l>>4)+reg.  The inner index may be permuted
 // freely as long as A and B agree, so each lane takes FOUR CONSECUTIVE inner indices (one 16-byte load in
 // the row-contiguous case) and feeds them to four successive MFMAs.
+#include <cstdio>
 #include "common.h"
 #include "kparams.h"
 #include "gemm16_tile.h"
@@ -121,6 +122,32 @@ __global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, cons
     gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
+// ... and the launches of up to FOUR tasks of ONE shape (the same layer of sibling networks: f_target on three inputs, the policy beside them): the
+// shape words once, then the A / B offsets of every task; hdr = low_prio | tiles per task << 8.
+template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K>
+__global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float* base, unsigned ld, unsigned kr, unsigned ct, unsigned a0, unsigned b0, unsigned a1, unsigned b1,
+                                                           unsigned a2, unsigned b2, unsigned a3, unsigned b3, GemmBatch gb) {
+    __shared__ float red[4][NF][4][64];
+    __shared__ float bsum[4][16];
+    if (!(hdr & 1)) __builtin_amdgcn_s_setprio(3);
+    const int bid = blockIdx.x, nt = hdr >> 8;
+    int ti = (bid >= nt ? 1 : 0) + (bid >= 2 * nt ? 1 : 0) + (bid >= 3 * nt ? 1 : 0);
+    const unsigned ao = ti == 0 ? a0 : ti == 1 ? a1 : ti == 2 ? a2 : a3, bo = ti == 0 ? b0 : ti == 1 ? b1 : ti == 2 ? b2 : b3;
+    const int local = bid - ti * nt, sh = (int)(ct >> 16);
+    const int tr = local >> sh, tc = local & ((1 << sh) - 1);
+    FastOps fo;
+    fo.pA = base + (size_t)ao; fo.pB = base + (size_t)bo; fo.lda = (int)(ld & 0xffffu); fo.ldb = (int)(ld >> 16);
+    fo.K = (int)(kr & 0xffffu); fo.R = (int)(kr >> 16); fo.Cn = (int)(ct & 0xffffu); fo.tiles_c = 1 << sh;
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    asm volatile("" : "+s"(ti));
+    const GemmTask& t = gb.t[ti];
+#ifdef RL_TIMING
+    unsigned long long* const tim_none = nullptr;
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_none, &fo);
+#else
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
+#endif
+}
 // host side of the above: the 13 argument values, or false when the launch does not qualify
 struct FastArgs { int hdr, tb1; const float* base; unsigned a[2], b[2], ld[2], kr[2], ct[2]; };
 static bool fast_args(const GemmBatch& gb, FastArgs& fa) {
@@ -142,6 +169,28 @@ static bool fast_args(const GemmBatch& gb, FastArgs& fa) {
     }
     return true;
 }
+struct Fast4Args { int hdr; const float* base; unsigned ld, kr, ct, a[4], b[4]; };
+static bool fast4_args(const GemmBatch& gb, Fast4Args& fa) {
+    if (gb.ntasks < 3 || gb.ntasks > 4 || getenv("RLREP_GEMM16_NO_FAST")) return false;
+    const GemmTask& t0 = gb.t[0];
+    uintptr_t lo = ~(uintptr_t)0;
+    for (int q = 0; q < gb.ntasks; ++q) { lo = std::min(lo, (uintptr_t)gb.t[q].A); lo = std::min(lo, (uintptr_t)gb.t[q].B); }
+    lo &= ~(uintptr_t)15;
+    const int tcn = t0.tiles_c, nt = t0.ntiles;
+    if (t0.K <= 0 || (t0.K & 255) || t0.K > 0xffff || t0.R > 0xffff || t0.Cn > 0xffff || t0.lda > 0xffff || t0.ldb > 0xffff || tcn <= 0 || (tcn & (tcn - 1)) || nt <= 0 || nt >= (1 << 22)) return false;
+    int sh = 0; while ((1 << sh) < tcn) ++sh;
+    fa.hdr = (gb.low_prio ? 1 : 0) | (nt << 8); fa.base = reinterpret_cast<const float*>(lo);
+    fa.ld = (unsigned)t0.lda | ((unsigned)t0.ldb << 16); fa.kr = (unsigned)t0.K | ((unsigned)t0.R << 16); fa.ct = (unsigned)t0.Cn | ((unsigned)sh << 16);
+    for (int q = 0; q < 4; ++q) {
+        const GemmTask& t = gb.t[q < gb.ntasks ? q : 0];
+        if (t.K != t0.K || t.R != t0.R || t.Cn != t0.Cn || t.lda != t0.lda || t.ldb != t0.ldb || t.tiles_c != tcn || t.ntiles != nt || (q < gb.ntasks && t.tile_base != q * nt)) return false;
+        const uintptr_t da = (uintptr_t)t.A - lo, db = (uintptr_t)t.B - lo;
+        if ((da & 3) || (db & 3) || (da >> 2) > 0xffffffffull || (db >> 2) > 0xffffffffull) return false;
+        fa.a[q] = (unsigned)(da >> 2); fa.b[q] = (unsigned)(db >> 2);
+    }
+    return true;
+}
+#define G16_FAST4_ARGS(F, B) (F).hdr, (F).base, (F).ld, (F).kr, (F).ct, (F).a[0], (F).b[0], (F).a[1], (F).b[1], (F).a[2], (F).b[2], (F).a[3], (F).b[3], (B)
 #define G16_FAST_ARGS(F, B) (F).hdr, (F).tb1, (F).base, (F).a[0], (F).b[0], (F).ld[0], (F).kr[0], (F).ct[0], (F).a[1], (F).b[1], (F).ld[1], (F).kr[1], (F).ct[1], (B)
 
 // TWO tile forms in one launch ("duo"): tasks [0, split) are row-major x k-major products (the dX form, NF = 1), tasks [split, ntasks) k-major
@@ -193,27 +242,42 @@ static void launch_nf(int nf, dim3 g, hipStream_t st, const GemmBatch& gb) {
 
 // NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
 // instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
+// the front end that loads from preloaded scalars (gemm16_fast_kernel / gemm16_fast4_kernel) with epilogue EPI_K / ACT_K compiled in (-1: from the record)
+template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K>
+static bool launch_fast(dim3 g, hipStream_t st, const GemmBatch& gb) {
+    FastArgs fa; Fast4Args f4;
+    if (fast_args(gb, fa)) { hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb)); return true; }
+    if (fast4_args(gb, f4)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); return true; }
+    return false;
+}
+// NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
+// instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
 template <int LA, int LB, int NF, bool VA, bool VB>
 static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (getenv("RLREP_GEMM16_GENERIC")) return false;
-    const int epi = gb.t[0].epi, act = gb.t[0].act;
-    for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].epi != epi || gb.t[q].act != act || (gb.t[q].flags & FLAG_PRE)) return false;
-    // one or two tasks, K % 256 == 0, 16-byte operand A: the front end that loads from preloaded scalars
-    FastArgs fa;
-    if (VA && fast_args(gb, fa)) {
-        if (LB == LD_ROW && epi == EPI_FWD && (act == ACT_NONE || act == ACT_RELU || act == ACT_ELU)) {
-            if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-            else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-            else hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_ELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-            return true;
-        }
-        if (LB == LD_COL && epi == EPI_DX && (act == ACT_NONE || act == ACT_RELU || act == ACT_ELU)) {
-            if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-            else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_DX, ACT_RELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-            else hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-            return true;
-        }
+    const int epi = gb.t[0].epi;
+    int act = gb.t[0].act;
+    bool same_epi = true;
+    for (int q = 0; q < gb.ntasks; ++q) {
+        if (gb.t[q].flags & FLAG_PRE) return false;
+        if (gb.t[q].epi != epi) same_epi = false;
+        if (gb.t[q].act != act) act = -1;                   // mixed activations: read from the record
     }
+    // one to four tasks, K % 256 == 0, 16-byte operand A: the front end that loads from preloaded scalars
+    if (VA) {
+        if (same_epi && LB == LD_ROW && epi == EPI_FWD) {
+            if (act == ACT_NONE) { if (launch_fast<LA, LB, NF, VA, VB, EPI_FWD, ACT_NONE>(g, st, gb)) return true; }
+            else if (act == ACT_RELU) { if (launch_fast<LA, LB, NF, VA, VB, EPI_FWD, ACT_RELU>(g, st, gb)) return true; }
+            else if (act == ACT_ELU) { if (launch_fast<LA, LB, NF, VA, VB, EPI_FWD, ACT_ELU>(g, st, gb)) return true; }
+            else if (launch_fast<LA, LB, NF, VA, VB, EPI_FWD, -1>(g, st, gb)) return true;
+        } else if (same_epi && LB == LD_COL && epi == EPI_DX) {
+            if (act == ACT_NONE) { if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, ACT_NONE>(g, st, gb)) return true; }
+            else if (act == ACT_RELU) { if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, ACT_RELU>(g, st, gb)) return true; }
+            else if (act == ACT_ELU) { if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, ACT_ELU>(g, st, gb)) return true; }
+            else if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, -1>(g, st, gb)) return true;
+        } else if (launch_fast<LA, LB, NF, VA, VB, -1, -1>(g, st, gb)) return true;       // any other epilogue: the generic body behind the fast front end
+    }
+    if (!same_epi || act < 0) return false;
     if (LB == LD_ROW && epi == EPI_FWD) {
         if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
         else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, G16_ARGS(gb));
@@ -259,6 +323,13 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     planned.total = total_tiles;
     const GemmBatch* const gb = &planned;
     dim3 g(total_tiles);
+    static const bool trace = getenv("RLREP_GEMM16_TRACE") != nullptr;       // one line per launch: which front end it gets (tools/exp/gemm16_trace.py)
+    if (trace) {
+        FastArgs fa; const bool f = fast_args(*gb, fa);
+        fprintf(stderr, "[gemm16] la=%d lb=%d nf=%d tasks=%d tiles=%d fast_args=%d :", la, lb, nf, gb->ntasks, total_tiles, (int)f);
+        for (int q = 0; q < gb->ntasks; ++q) fprintf(stderr, " [R=%d Cn=%d K=%d lda=%d ldb=%d epi=%d act=%d fl=0x%x]", gb->t[q].R, gb->t[q].Cn, gb->t[q].K, gb->t[q].lda, gb->t[q].ldb, gb->t[q].epi, gb->t[q].act, gb->t[q].flags);
+        fprintf(stderr, "\n");
+    }
     if (gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE)) {       // fused-short-product launch: every task carries FLAG_PRE (and agrees on the form)
         const int fw = gb->t[0].flags & FLAG_PRE_FWD;
         for (int q = 0; q < gb->ntasks; ++q) {
