@@ -103,6 +103,11 @@ __global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, cons
                                                           unsigned a1, unsigned b1, unsigned ld1, unsigned kr1, unsigned ct1, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
+#ifdef RL_TIMING
+    unsigned long long tim_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_w0 = 0; unsigned tim_lid = 0;
+    if (threadIdx.x == 0) { tim_lid = *(volatile unsigned*)&g_tim_launch; if (TIM_ON) tim_w0 = wall_clock64(); }
+#endif
+    TIM(0);
     if (!(hdr & 1)) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x;
     const bool second = bid >= tb1;
@@ -116,8 +121,11 @@ __global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, cons
     asm volatile("" : "+s"(ti));          // (opaque: with a visible 0 / 1 hipcc loads BOTH records and selects field by field -- behind one s_waitcnt in front of the operand loads)
     const GemmTask& t = gb.t[ti];
 #ifdef RL_TIMING
-    unsigned long long* const tim_none = nullptr;
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_none, &fo);
+    asm volatile("" :: "s"(tr), "s"(tc));
+    TIM(7);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);       // (tag bit 3: a fast-front-end launch)
+    TIM_FIN();
 #else
     gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
@@ -129,6 +137,11 @@ __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float*
                                                            unsigned a2, unsigned b2, unsigned a3, unsigned b3, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
     __shared__ float bsum[4][16];
+#ifdef RL_TIMING
+    unsigned long long tim_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_w0 = 0; unsigned tim_lid = 0;
+    if (threadIdx.x == 0) { tim_lid = *(volatile unsigned*)&g_tim_launch; if (TIM_ON) tim_w0 = wall_clock64(); }
+#endif
+    TIM(0);
     if (!(hdr & 1)) __builtin_amdgcn_s_setprio(3);
     const int bid = blockIdx.x, nt = hdr >> 8;
     int ti = (bid >= nt ? 1 : 0) + (bid >= 2 * nt ? 1 : 0) + (bid >= 3 * nt ? 1 : 0);
@@ -142,8 +155,11 @@ __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float*
     asm volatile("" : "+s"(ti));
     const GemmTask& t = gb.t[ti];
 #ifdef RL_TIMING
-    unsigned long long* const tim_none = nullptr;
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_none, &fo);
+    asm volatile("" :: "s"(tr), "s"(tc));
+    TIM(7);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);       // (tag bit 3: a fast-front-end launch)
+    TIM_FIN();
 #else
     gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif

@@ -126,8 +126,13 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
         for (int jc = 0; jc < NJ; ++jc)
 #pragma unroll
             for (int m = 0; m < 4; ++m) wf[u][jc][m] = ps.Wt[(size_t)min(16 * jc + 4 * kq + m, K1 - 1) * ps.ldw + kcol];
+        if constexpr (XLDS) {       // (FLAG_PRE_MSE launches: the launcher has checked that M's rows are 16-byte regular and K % 4 == 0)
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(ps.M + mrow + min(kb + 64 * u + 4 * kq, K - 4));
+            mk[u][0] = mv[0]; mk[u][1] = mv[1]; mk[u][2] = mv[2]; mk[u][3] = mv[3];
+        } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) mk[u][m] = rl_ld<COH && !FWD>(ps.M, mrow + min(kb + 64 * u + 4 * kq + m, K - 1));
+            for (int m = 0; m < 4; ++m) mk[u][m] = rl_ld<COH && !FWD>(ps.M, mrow + min(kb + 64 * u + 4 * kq + m, K - 1));
+        }
 #pragma unroll
         for (int f = 0; f < NF; ++f) load_raw<LB, VB>(B, ldb, c0 + 16 * f, Cn, i, kb + 4 * kq + 64 * u, K, b[u][f]);
     }
@@ -231,6 +236,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
 #pragma unroll
             for (int f = 0; f < NF; ++f) load_raw<LB, VB>(pB, ldb, tc * 16 * NF + 16 * f, Cn, i_, k_ + 64 * u, K, fb[u][f]);
         }
+        TIMB(5);                    // FAST: the first block's operand loads are issued (before the record is claimed)
     }
     // (materialise the whole record HERE: left to itself hipcc loads each slot field next to its first use, between the operand loads,
     // with a scalar-load round trip in front of every one of them)
@@ -257,7 +263,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // (weight gradients are the k-major / k-major launches: every other instantiation drops the bias-gradient code)
     constexpr bool DW = !COH && LA == LD_COL && LB == LD_COL;
     const bool want_bias = DW && (epi == EPI_DW) && (flags & FLAG_BIASGRAD) && (tc == 0);
-    TIMB(5);
+    if constexpr (!FAST) TIMB(5);
     const int ol = threadIdx.x & 63, oreg = threadIdx.x >> 6;
     const int r = r0 + (ol >> 4) * 4 + oreg;
     // Plain loads, PINNED above the operand stream by a memory-clobbering empty asm: left alone, hipcc sinks them below the reduction
@@ -322,6 +328,17 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
             // P[16 x 32] over the inner dimension K, split over the four waves as in the main loop (16-byte loads: the launcher checks alignment)
             f32x4 pacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
             float dummy = 0.f;
+            // this thread's two elements of [s_hat | r_hat]: bias and target fetched NOW, under the product (after the reduction they were two
+            // dependent L2 round trips per fragment: 4 us of this launch in tools/exp/gemm_timeline.py)
+            float pbias_[2], ptgt_[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int c = min(16 * f + (ol & 15), ps.K1 - 1), rc = min(r, R - 1);
+                pbias_[f] = t.bias[c];
+                const float* const tp = c < t.pad_mse ? t.tgs + (size_t)rc * t.ldtgs + c : t.tgr + rc;
+                ptgt_[f] = *tp;
+            }
+            asm volatile("" ::: "memory");
             for (int kb = w * 16; kb < K; kb += 256) {
                 const int k0 = kb + 4 * kq;
                 const int nu = (K - kb + 63) >> 6;
@@ -330,35 +347,37 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
                 else if (nu == 2) mac_group<LD_ROW, LD_ROW, 2, true, true, 2, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
                 else mac_group<LD_ROW, LD_ROW, 2, true, true, 3, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
             }
-            // fixed-order reduction over the waves through the LDS patch of the main product (NF = 1 launches: room for ONE fragment per pass)
+            // fixed-order reduction over the waves, both fragments in ONE round through a patch of their own
             __shared__ float XS[16 * RL_XS_LD];
+            __shared__ float red1[4][2][4][64];
             float es = 0.f, er = 0.f;
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                __syncthreads();
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) red[w][0][q][lane] = pacc[f][q];
-                __syncthreads();
+                for (int q = 0; q < 4; ++q) red1[w][f][q][lane] = pacc[f][q];
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
                 const int c = 16 * f + (ol & 15);
-                const float v = ((red[0][0][oreg][ol] + red[1][0][oreg][ol]) + red[2][0][oreg][ol]) + red[3][0][oreg][ol];
+                const float v = ((red1[0][f][oreg][ol] + red1[1][f][oreg][ol]) + red1[2][f][oreg][ol]) + red1[3][f][oreg][ol];
                 float g = 0.f;
                 if (r < R && c < ps.K1) {
-                    const float pred = v + t.bias[c];
-                    if (c < t.pad_mse) { const float d = pred - t.tgs[(size_t)r * t.ldtgs + c]; es += d * d; g = d * t.s0; }
-                    else { const float d = pred - t.tgr[r]; er += d * d; g = d * t.s1; }
+                    const float d = (v + pbias_[f]) - ptgt_[f];
+                    if (c < t.pad_mse) { es += d * d; g = d * t.s0; }
+                    else { er += d * d; g = d * t.s1; }
                     if (tc == 0) const_cast<float*>(ps.X)[(size_t)r * ps.ldx + c] = g;          // the weight-gradient pass reads X
                 }
                 XS[((ol >> 4) * 4 + oreg) * RL_XS_LD + c] = g;
             }
             es = wave_sum(es); er = wave_sum(er);
-            __syncthreads();
-            if (lane == 0) { red[0][0][0][w] = es; red[0][0][1][w] = er; }
-            __syncthreads();
+            if (lane == 0) { red[0][0][0][w] = es; red[0][0][1][w] = er; }       // (the main product's patch is still free)
+            __syncthreads();                                                      // XS and the four partial sums are visible
             if (tc == 0 && threadIdx.x == 0) {
                 t.mse_part[2 * tr] = ((red[0][0][0][0] + red[0][0][0][1]) + red[0][0][0][2]) + red[0][0][0][3];
                 t.mse_part[2 * tr + 1] = ((red[0][0][1][0] + red[0][0][1][1]) + red[0][0][1][2]) + red[0][0][1][3];
             }
             xs = XS;
+            TIMB(5);                // (MSE: the first phase is done)
         }
         for (int kb = w * 16; kb < K; kb += 256) {
             const int nu = (K - kb + 63) >> 6;

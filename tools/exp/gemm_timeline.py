@@ -1,5 +1,5 @@
 """In-kernel timeline of every gemm16 launch of one graph-replayed train() (needs the -DRL_TIMING build:
-   rm rlrep_amd/csrc/.obj/gemm16.o; EXTRA_FLAGS=-DRL_TIMING bash rlrep_amd/csrc/build.sh).
+   OBJDIR=.obj_tim OUTNAME=librlrep_hip_tim.so EXTRA_FLAGS=-DRL_TIMING bash rlrep_amd/csrc/build.sh; run with RLREP_LIB=rlrep_amd/lib/librlrep_hip_tim.so).
    Times are the 100 MHz wall clock (10 ns ticks) read by thread 0 of each workgroup."""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,20 +31,21 @@ torch.cuda.synchronize()
 print('this train(): %.1f us by events' % (e0.elapsed_time(e1) * 1e3))
 nl = raw.rl_timing_count()
 rec = tb.cpu().numpy().reshape(CAP, 12)
-print(f'{nl} gemm16 launches; wall times in us (100 MHz clock), phases in shader cycles / 2200 = us')
-print(' #   WGs  gap_prev  ramp   span  | median per sampled WG (cycles): [task known]  find task+record  -  slot loads issued  operands+mfma  reduce  epilogue |  life us (max)')
+print(f'{nl} gemm16 launches; wall times in us (100 MHz clock); stamps in shader cycles AFTER ENTRY (median over the sampled workgroups; / 2200 = us)')
+print('fast = front end that loads from preloaded scalars (gemm16_fast*_kernel): there "loads" (first operand loads issued) precedes "record"; in the record form "loads" = slot loads about to issue')
+print(' #   WGs fast  gap_prev  span  |  task-known   record    loads  slots-issued  mfma-done  reduced    exit  |  life us (max)')
 prev = None; tot = 0.0
 for k in range(nl):
     r = rec[k * 2048:(k + 1) * 2048]; r = r[(r[:, 11] >> 32) == 1]
     if not len(r): continue
     w0, w4 = r[:, 0], r[:, 1]
-    c = np.stack([r[:, 2], r[:, 3], r[:, 7], r[:, 8], r[:, 4], r[:, 5], r[:, 6]], axis=1)     # entry, record (1), (5), slot loads issued (6), mfma done (2), reduced (3), exit (4)
+    ent = r[:, 2]
+    off = lambda col: np.median(r[:, col] - ent)           # c[q] sits in column 2 + q
     grid = int(r[0, 10] & 0xffffffff)
+    fast = int(np.median(r[:, 7] - r[:, 3]) < 0)          # first operand loads stamped BEFORE the record was in registers
     gap = (w0.min() - prev) / 100 if prev is not None else 0.0
-    d = np.diff(c, axis=1); ph = np.median(d, axis=0); ph = np.array([ph[0], ph[1] + 0, ph[2], ph[3], ph[4], ph[5]])
-    life = (c[:, 6] - c[:, 0]) / 2200.0
-    known = np.median(r[:, 9] - r[:, 2])                  # c[7] - c[0]: entry -> task and tile known (no loads)
-    print(f"{k:3d} {grid:5d}  {gap:7.2f} {(w0.max()-w0.min())/100:6.2f} {(w4.max()-w0.min())/100:6.2f}  |  [{known:6.0f}] {ph[0]:8.0f} {ph[1]:8.0f} {ph[2]:8.0f} {ph[3]:10.0f} {ph[4]:8.0f} {ph[5]:8.0f}  | {np.median(life):6.2f} ({life.max():.2f})")
+    life = (r[:, 6] - ent) / 2200.0
+    print(f"{k:3d} {grid:5d}  {fast:3d}  {gap:7.2f} {(w4.max()-w0.min())/100:6.2f}  |  {off(9):9.0f} {off(3):8.0f} {off(7):8.0f} {off(8):12.0f} {off(4):10.0f} {off(5):8.0f} {off(6):7.0f}  | {np.median(life):6.2f} ({life.max():.2f})")
     tot += (w4.max() - w0.min()) / 100
     prev = w4.max()
 print('sum of gemm16 kernel spans %.1f us' % tot)
