@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
 // critic / actor steps at the headline dimensions): the 14 preloaded scalars carry what the operand LOADS need instead of a task directory --
 // a common base and, per task, the A / B offsets from it in floats, lda | ldb << 16, K | R << 16, Cn | log2(column tiles) << 16 -- so the
 // first operand loads issue from preloaded SGPRs while the record's scalar loads are still in flight (gemm16_tile FAST).
-template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K>
+template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K, int FU = 4>
 __global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, const float* base, unsigned a0, unsigned b0, unsigned ld0, unsigned kr0, unsigned ct0,
                                                           unsigned a1, unsigned b1, unsigned ld1, unsigned kr1, unsigned ct1, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
@@ -123,11 +123,11 @@ __global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, cons
 #ifdef RL_TIMING
     asm volatile("" :: "s"(tr), "s"(tc));
     TIM(7);
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, FU>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
     float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);       // (tag bit 3: a fast-front-end launch)
     TIM_FIN();
 #else
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, FU>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
 // ... and the launches of up to FOUR tasks of ONE shape (the same layer of sibling networks: f_target on three inputs, the policy beside them): the
@@ -157,16 +157,17 @@ __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float*
 #ifdef RL_TIMING
     asm volatile("" :: "s"(tr), "s"(tc));
     TIM(7);
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, 4>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
     float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);       // (tag bit 3: a fast-front-end launch)
     TIM_FIN();
 #else
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, true>(t, tr, tc, red, bsum, nullptr, &fo);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, 4>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
 // host side of the above: the 13 argument values, or false when the launch does not qualify
 struct FastArgs { int hdr, tb1; const float* base; unsigned a[2], b[2], ld[2], kr[2], ct[2]; };
-static bool fast_args(const GemmBatch& gb, FastArgs& fa) {
+// short = false: every K a multiple of 256; short = true: every K <= 64 (the FAST = 1 instantiations)
+static bool fast_args(const GemmBatch& gb, FastArgs& fa, bool short_k = false) {
     if (gb.ntasks < 1 || gb.ntasks > 2 || getenv("RLREP_GEMM16_NO_FAST")) return false;
     uintptr_t lo = ~(uintptr_t)0;
     for (int q = 0; q < gb.ntasks; ++q) { lo = std::min(lo, (uintptr_t)gb.t[q].A); lo = std::min(lo, (uintptr_t)gb.t[q].B); }
@@ -176,7 +177,7 @@ static bool fast_args(const GemmBatch& gb, FastArgs& fa) {
     for (int q = 0; q < 2; ++q) {
         const GemmTask& t = gb.t[q < gb.ntasks ? q : 0];
         const int tcn = t.tiles_c;
-        if (t.K <= 0 || (t.K & 255) || t.K > 0xffff || t.R > 0xffff || t.Cn > 0xffff || t.lda > 0xffff || t.ldb > 0xffff || tcn <= 0 || (tcn & (tcn - 1))) return false;
+        if (t.K <= 0 || (short_k ? t.K > 64 : (t.K & 255) != 0) || t.K > 0xffff || t.R > 0xffff || t.Cn > 0xffff || t.lda > 0xffff || t.ldb > 0xffff || tcn <= 0 || (tcn & (tcn - 1))) return false;
         const uintptr_t da = (uintptr_t)t.A - lo, db = (uintptr_t)t.B - lo;
         if ((da & 3) || (db & 3) || (da >> 2) > 0xffffffffull || (db >> 2) > 0xffffffffull) return false;
         int sh = 0; while ((1 << sh) < tcn) ++sh;
@@ -266,6 +267,14 @@ static bool launch_fast(dim3 g, hipStream_t st, const GemmBatch& gb) {
     if (fast4_args(gb, f4)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); return true; }
     return false;
 }
+// ... and the first layers (K <= 64, forward form, rows of 17 / 23 / 40 floats: with or without 16-byte operand loads)
+template <int LA, int LB, int NF, bool VA, bool VB, int ACT_K>
+static bool launch_fast_short(dim3 g, hipStream_t st, const GemmBatch& gb) {
+    FastArgs fa;
+    if (!fast_args(gb, fa, true)) return false;
+    hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
+    return true;
+}
 // NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
 // instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
 template <int LA, int LB, int NF, bool VA, bool VB>
@@ -278,6 +287,12 @@ static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
         if (gb.t[q].flags & FLAG_PRE) return false;
         if (gb.t[q].epi != epi) same_epi = false;
         if (gb.t[q].act != act) act = -1;                   // mixed activations: read from the record
+    }
+    // first layers (K <= 64): one or two tasks, any alignment
+    if constexpr (LA == LD_ROW && LB == LD_ROW) if (same_epi && epi == EPI_FWD) {
+        if (act == ACT_RELU) { if (launch_fast_short<LA, LB, NF, VA, VB, ACT_RELU>(g, st, gb)) return true; }
+        else if (act == ACT_ELU) { if (launch_fast_short<LA, LB, NF, VA, VB, ACT_ELU>(g, st, gb)) return true; }
+        else if (act < 0) { if (launch_fast_short<LA, LB, NF, VA, VB, -1>(g, st, gb)) return true; }
     }
     // one to four tasks, K % 256 == 0, 16-byte operand A: the front end that loads from preloaded scalars
     if (VA) {
@@ -293,7 +308,14 @@ static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
             else if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, -1>(g, st, gb)) return true;
         } else if (launch_fast<LA, LB, NF, VA, VB, -1, -1>(g, st, gb)) return true;       // any other epilogue: the generic body behind the fast front end
     }
-    if (!same_epi || act < 0) return false;
+    if (!same_epi) return false;
+    // mixed activations (the policy's ELU layers beside f's ReLU layers in one launch): the epilogue KIND compiled in, the activation read from the
+    // record -- the fully generic body spends 5 700 cycles between the reduction barrier and the store of such a tile (tools/exp/gemm_timeline.py)
+    if (act < 0) {
+        if (LB == LD_ROW && epi == EPI_FWD) { hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, -1>), g, dim3(256), 0, st, G16_ARGS(gb)); return true; }
+        if (LB == LD_COL && epi == EPI_DX) { hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_DX, -1>), g, dim3(256), 0, st, G16_ARGS(gb)); return true; }
+        return false;
+    }
     if (LB == LD_ROW && epi == EPI_FWD) {
         if (act == ACT_NONE) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
         else if (act == ACT_RELU) hipLaunchKernelGGL((gemm16_kernel<LA, LB, NF, VA, VB, false, EPI_FWD, ACT_RELU>), g, dim3(256), 0, st, G16_ARGS(gb));
@@ -387,7 +409,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     }
     if (la == LD_ROW && lb == LD_ROW) {
         if (all_vec(*gb, false) && all_vec(*gb, true)) { if (!(nf == 1 && launch_spec<LD_ROW, LD_ROW, 1, true, true>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_ROW, 2, true, true>(g, st, *gb))) launch_nf<LD_ROW, LD_ROW, true, true>(nf, g, st, *gb); }
-        else if (!(nf == 1 && launch_spec<LD_ROW, LD_ROW, 1, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
+        else if (!(nf == 1 && launch_spec<LD_ROW, LD_ROW, 1, false, false>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_ROW, 2, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_ROW, false, false>(nf, g, st, *gb);
     } else if (la == LD_ROW && lb == LD_COL) {
         if (all_vec(*gb, false)) { if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, true, false>(g, st, *gb)) && !(nf == 2 && launch_spec<LD_ROW, LD_COL, 2, true, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, true, false>(nf, g, st, *gb); }
         else if (!(nf == 1 && launch_spec<LD_ROW, LD_COL, 1, false, false>(g, st, *gb))) launch_nf<LD_ROW, LD_COL, false, false>(nf, g, st, *gb);

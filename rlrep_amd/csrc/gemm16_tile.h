@@ -200,12 +200,13 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // GATHER: operand-A rows come through the task's row-index table (gidx), e.g. straight out of the replay ring (forward launches that ride in
 // the optimizer launch of the previous step: the minibatch slot is being gathered by other workgroups of the same launch).
 // MSE (with PRE, dX form): FLAG_PRE_MSE launches -- the short product's row operand is computed by a first phase of the tile (common.h)
-// FAST (gemm16_fast_kernel): what the operand LOADS need -- bases, row strides, extents -- arrives in preloaded SGPRs (FastOps) instead of the
-// record, K is a multiple of 256, and the first 256-deep block's loads are issued BEFORE the record is waited for: the record's scalar-load
-// round trip (~900 cycles, needed by the epilogue only) runs under the operand loads instead of in front of them.
+// FAST (gemm16_fast_kernel; 0 = off): what the operand LOADS need -- bases, row strides, extents -- arrives in preloaded SGPRs (FastOps) instead of
+// the record, and the first block's loads are issued BEFORE the record is waited for: the record's scalar-load round trip (~900 cycles, needed by
+// the epilogue only) runs under the operand loads instead of in front of them.  FAST = 4: K is a multiple of 256 (blocks of four 16-deep chunks
+// per wave); FAST = 1: K <= 64 (the first layers: one chunk per wave is all there is).
 struct FastOps { const float* pA; const float* pB; int lda, ldb, K, R, Cn, tiles_c; };
 template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false, bool MSE = false,
-          bool FAST = false>
+          int FAST = 0>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
                                             const float* const* dyn RL_TIM_PARAM, const FastOps* fo = nullptr) {
     static_assert(!FAST || (!PRE && !COH && !GATHER && !MSE), "FAST: plain forward / dX tiles only");
@@ -226,12 +227,12 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         sp[1] = px2;               // (x2 is slot 1 wherever it is a slot)
     }
     // FAST: the first 256-deep block's operand loads go out now, from preloaded scalars (the reads of the record above are in flight)
-    float fa[FAST ? 4 : 1][4], fb[FAST ? 4 : 1][NF][4];
+    float fa[FAST ? FAST : 1][4], fb[FAST ? FAST : 1][NF][4];
     if constexpr (FAST) {
         const int lane_ = threadIdx.x & 63, w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int i_ = lane_ & 15, k_ = w_ * 16 + 4 * (lane_ >> 4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FAST; ++u) {
             load_raw<LA, VA>(pA, lda, tr * 16, R, i_, k_ + 64 * u, K, fa[u]);
 #pragma unroll
             for (int f = 0; f < NF; ++f) load_raw<LB, VB>(pB, ldb, tc * 16 * NF + 16 * f, Cn, i_, k_ + 64 * u, K, fb[u][f]);
@@ -387,22 +388,23 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
             else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
         }
     } else if constexpr (FAST) {
-        // first block from the registers filled above, then whole 256-deep blocks (K % 256 == 0: the launcher checks)
+        // first block from the registers filled above, then whole 256-deep blocks (FAST = 4: K % 256 == 0; FAST = 1: K <= 64 -- the launcher checks)
         const int k0 = w * 16 + 4 * kq;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FAST; ++u) {
             mask_frag(r0, R, i, k0 + 64 * u, K, fa[u]);
 #pragma unroll
             for (int f = 0; f < NF; ++f) mask_frag(c0 + 16 * f, Cn, i, k0 + 64 * u, K, fb[u][f]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < FAST; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][s], fb[u][f][s], acc[f], 0, 0, 0);
-        for (int kb = w * 16 + 256; kb < K; kb += 256)
-            mac_group<LA, LB, NF, VA, VB, 4, false, false>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, kb + 4 * kq, K, acc, asum, false);
+        if constexpr (FAST == 4)
+            for (int kb = w * 16 + 256; kb < K; kb += 256)
+                mac_group<LA, LB, NF, VA, VB, 4, false, false>(pArow, lda, pB, ldb, r0, R, c0, Cn, i, kb + 4 * kq, K, acc, asum, false);
     } else
     for (int kb = w * 16; kb < K; kb += 256) {
         const int k0 = kb + 4 * kq;
