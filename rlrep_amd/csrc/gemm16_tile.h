@@ -103,39 +103,55 @@ __device__ __forceinline__ void mac_group(const float* __restrict__ A, int lda, 
 // row = 4 (lane >> 4) + reg = k offset 4 kq + reg inside the wave's 16-wide chunk -- exactly the "four consecutive inner indices per
 // lane" layout in which the main loop wants its A operand: no lane movement, no LDS.  (The same construction for the FIRST layers of the
 // MLPs, whose weights are stored [k][j] with 92-byte rows, made every fragment load touch 16-23 cache lines and lost: DESIGN.md 5.0.)
-struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const float* M; int ldm; float* out; int ldo; };
+// st_lo / st_hi: the k range of the recomputed first-layer output that THIS tile stores (every tile of a row block recomputes all of it; the
+// sixteen column tiles of the headline layers each store one 16-wide chunk instead of column tile 0 storing everything: the launch ends when its
+// slowest workgroup does)
+struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const float* M; int ldm; float* out; int ldo; int st_lo, st_hi; };
 
 // XS (FLAG_PRE_MSE): the row operand X of the short product sits in LDS ([16][RL_XS_LD] floats, written by this tile's first phase) instead of memory
 #define RL_XS_LD 36
+// the global operands of one mac_group_pre block (everything but the row operand X): loaded by pre_load, consumed by mac_group_pre<.., PL = true>
+template <int NU, int NJ, int NF> struct PreRegs { float wf[NU][NJ][4], mk[NU][4], b[NU][NF][4]; };
 template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false, bool XLDS = false>
-__device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
-                                              int i, int kq, int kb, int K, bool store, bool elu, f32x4 (&acc)[NF], const float* xs = nullptr) {
-    float xf[NJ][4], wf[NU][NJ][4], mk[NU][4], b[NU][NF][4];
+__device__ __forceinline__ void pre_load(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
+                                         int i, int kq, int kb, int K, PreRegs<NU, NJ, NF>& pr) {
     const int K1 = ps.K1;
-    const size_t xrow = (size_t)min(r0 + i, R - 1) * ps.ldx;
     // dX form: M = the saved ReLU output of this launch's forward half (row of the minibatch); forward form: M = the layer's bias (ldm = 0)
     const size_t mrow = (size_t)min(r0 + i, R - 1) * ps.ldm;
-#pragma unroll
-    for (int jc = 0; jc < NJ; ++jc)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xf[jc][m] = XLDS ? xs[i * RL_XS_LD + 16 * jc + 4 * kq + m] : rl_ld<COH>(ps.X, xrow + min(16 * jc + 4 * kq + m, K1 - 1));
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int kcol = min(kb + 64 * u + i, K - 1);
 #pragma unroll
         for (int jc = 0; jc < NJ; ++jc)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) wf[u][jc][m] = ps.Wt[(size_t)min(16 * jc + 4 * kq + m, K1 - 1) * ps.ldw + kcol];
+            for (int m = 0; m < 4; ++m) pr.wf[u][jc][m] = ps.Wt[(size_t)min(16 * jc + 4 * kq + m, K1 - 1) * ps.ldw + kcol];
         if constexpr (XLDS) {       // (FLAG_PRE_MSE launches: the launcher has checked that M's rows are 16-byte regular and K % 4 == 0)
             const f32x4 mv = *reinterpret_cast<const f32x4*>(ps.M + mrow + min(kb + 64 * u + 4 * kq, K - 4));
-            mk[u][0] = mv[0]; mk[u][1] = mv[1]; mk[u][2] = mv[2]; mk[u][3] = mv[3];
+            pr.mk[u][0] = mv[0]; pr.mk[u][1] = mv[1]; pr.mk[u][2] = mv[2]; pr.mk[u][3] = mv[3];
         } else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) mk[u][m] = rl_ld<COH && !FWD>(ps.M, mrow + min(kb + 64 * u + 4 * kq + m, K - 1));
+            for (int m = 0; m < 4; ++m) pr.mk[u][m] = rl_ld<COH && !FWD>(ps.M, mrow + min(kb + 64 * u + 4 * kq + m, K - 1));
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) load_raw<LB, VB>(B, ldb, c0 + 16 * f, Cn, i, kb + 4 * kq + 64 * u, K, b[u][f]);
+        for (int f = 0; f < NF; ++f) load_raw<LB, VB>(B, ldb, c0 + 16 * f, Cn, i, kb + 4 * kq + 64 * u, K, pr.b[u][f]);
     }
+}
+// PL: the block's global operands were loaded earlier (pre_load into `pl`): only X is fetched here
+template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false, bool XLDS = false, bool PL = false>
+__device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
+                                              int i, int kq, int kb, int K, bool store, bool elu, f32x4 (&acc)[NF], const float* xs = nullptr,
+                                              PreRegs<NU, NJ, NF>* pl = nullptr) {
+    float xf[NJ][4];
+    PreRegs<NU, NJ, NF> own;
+    const int K1 = ps.K1;
+    const size_t xrow = (size_t)min(r0 + i, R - 1) * ps.ldx;
+#pragma unroll
+    for (int jc = 0; jc < NJ; ++jc)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xf[jc][m] = XLDS ? xs[i * RL_XS_LD + 16 * jc + 4 * kq + m] : rl_ld<COH>(ps.X, xrow + min(16 * jc + 4 * kq + m, K1 - 1));
+    if constexpr (!PL) pre_load<LB, NF, VB, NU, NJ, FWD, COH, XLDS>(ps, B, ldb, r0, R, c0, Cn, i, kq, kb, K, own);
+    PreRegs<NU, NJ, NF>& pr = PL ? *pl : own;
+    float (&wf)[NU][NJ][4] = pr.wf; float (&mk)[NU][4] = pr.mk; float (&b)[NU][NF][4] = pr.b;
     __builtin_amdgcn_sched_barrier(0);
     // zero what the clamped loads fetched beyond K1 (inner index); rows beyond R / k beyond K are masked when A is formed
 #pragma unroll
@@ -163,7 +179,7 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
             const float g = FWD ? fmaxf(D[u][m] + mk[u][m], 0.f) : (mk[u][m] > 0.f ? D[u][m] : (elu ? D[u][m] * (mk[u][m] + 1.f) : 0.f));
             a[m] = (rok && (kb + 64 * u + 4 * kq + m) < K) ? g : 0.f;
         }
-        if (store && rok) {
+        if (store && rok && kb + 64 * u >= ps.st_lo && kb + 64 * u < ps.st_hi) {
             float* op = ps.out + (size_t)(r0 + i) * ps.ldo + kb + 64 * u + 4 * kq;
 #pragma unroll
             for (int m = 0; m < 4; ++m) if (kb + 64 * u + 4 * kq + m < K) op[m] = a[m];
@@ -243,6 +259,10 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // with a scalar-load round trip in front of every one of them)
     asm volatile("" :: "s"(pA), "s"(pB), "s"(pC), "s"(pbias), "s"(lda), "s"(ldb), "s"(ldc), "s"(R), "s"(Cn), "s"(K), "s"(epi), "s"(act), "s"(flags), "s"(n0), "s"(scale));
     if constexpr (GATHER) asm volatile("" :: "s"(pgidx));
+    // (the fused short product's operands and the mse phase's: same burst -- each of them read where first used costs a round trip of its own in
+    // front of that phase's loads)
+    if constexpr (PRE) asm volatile("" :: "s"(t.x0), "s"(t.ldx0), "s"(t.x1), "s"(t.ldx1), "s"(t.x2), "s"(t.ldaux2), "s"(t.y0), "s"(ldout2));
+    if constexpr (MSE) asm volatile("" :: "s"(t.tgs), "s"(t.tgr), "s"(t.ldtgs), "s"(t.pad_mse), "s"(t.s0), "s"(t.s1), "s"(t.mse_part));
     asm volatile("" :: "s"(sp[0]), "s"(sp[1]), "s"(sp[2]), "s"(sp[3]), "s"(sp[4]), "s"(srs[0]), "s"(srs[1]), "s"(srs[2]), "s"(srs[3]), "s"(srs[4]),
                  "s"(sof[0]), "s"(sof[1]), "s"(sof[2]), "s"(sof[3]), "s"(sof[4]));
     asm volatile("" :: "s"(slo[0]), "s"(slo[1]), "s"(slo[2]), "s"(slo[3]), "s"(slo[4]), "s"(shi[0]), "s"(shi[1]), "s"(shi[2]), "s"(shi[3]), "s"(shi[4]), "s"(scs0));
@@ -318,12 +338,16 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     // wave w owns the 16-wide inner chunks w, w+4, w+8, ...
     if constexpr (PRE) {
         PreSrc ps; ps.X = t.x0; ps.ldx = t.ldx0; ps.Wt = t.x1; ps.ldw = t.ldx1; ps.K1 = n0; ps.M = t.x2; ps.ldm = t.ldaux2; ps.out = t.y0; ps.ldo = t.ldout2;
-        const bool store = (tc == 0) && ps.out;
+        // who stores the recomputed layer: one 16-wide chunk per column tile when there are enough tiles, else column tile 0 everything
+        const bool spread = tiles_c * 16 >= K;
+        const bool store = ps.out && (spread || tc == 0);
+        ps.st_lo = spread ? tc * 16 : 0; ps.st_hi = spread ? tc * 16 + 16 : K;
         const bool pre_elu = (flags & FLAG_PRE_ELU) != 0;
         // forward form (LB = LD_ROW): K1 <= 48, bias + ReLU; dX form (LB = LD_COL): K1 <= 32, ReLU mask
         constexpr int NJ = (LB == LD_ROW) ? 3 : 2;
         constexpr bool FW = (LB == LD_ROW);
         const float* xs = nullptr;
+        PreRegs<4, NJ, NF> mse_pl;
         if constexpr (MSE) {
             // ---- first phase: X = dmse( M Wt^T + bias ; targets ) for this tile's 16 rows, K1 <= 32 columns (FLAG_PRE_MSE) ----
             // P[16 x 32] over the inner dimension K, split over the four waves as in the main loop (16-byte loads: the launcher checks alignment)
@@ -339,8 +363,36 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
                 const float* const tp = c < t.pad_mse ? t.tgs + (size_t)rc * t.ldtgs + c : t.tgr + rc;
                 ptgt_[f] = *tp;
             }
-            asm volatile("" ::: "memory");
-            for (int kb = w * 16; kb < K; kb += 256) {
+            // this wave's FIRST block of the product (four 16-deep chunks; what lies beyond K is clamped and masked, so any K is handled) ...
+            float a1[4][4], b1[4][2][4];
+            {
+                const int k0 = w * 16 + 4 * kq;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    load_raw<LD_ROW, true, COH>(ps.M, ps.ldm, r0, R, i, k0 + 64 * u, K, a1[u]);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) load_raw<LD_ROW, true>(ps.Wt, ps.ldw, 16 * f, ps.K1, i, k0 + 64 * u, K, b1[u][f]);
+                }
+                // ... and BEHIND them the SECOND phase's global operands of the same block (weights of both products, the ReLU mask): none of
+                // them depends on the first phase, and a launch's first touch of anything costs a trip beyond the XCD's L2 (~1 us) -- one such
+                // trip instead of two.  Unconditional (clamped addresses); used below only if the block is a full one (K >= 256).  Issued AFTER
+                // the first phase's loads: the load counter retires in order, so the product below waits for its own operands only.
+                pre_load<LB, NF, VB, 4, NJ, FW, COH, true>(ps, pB, ldb, r0, R, c0, Cn, i, kq, w * 16, K, mse_pl);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mask_frag(r0, R, i, k0 + 64 * u, K, a1[u]);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) mask_frag(16 * f, ps.K1, i, k0 + 64 * u, K, b1[u][f]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) pacc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][s4], b1[u][f][s4], pacc[f], 0, 0, 0);
+            }
+            for (int kb = w * 16 + 256; kb < K; kb += 256) {
                 const int k0 = kb + 4 * kq;
                 const int nu = (K - kb + 63) >> 6;
                 if (nu >= 4) mac_group<LD_ROW, LD_ROW, 2, true, true, 4, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
@@ -348,6 +400,9 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
                 else if (nu == 2) mac_group<LD_ROW, LD_ROW, 2, true, true, 2, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
                 else mac_group<LD_ROW, LD_ROW, 2, true, true, 3, COH>(ps.M, ps.ldm, ps.Wt, ps.ldw, r0, R, 0, ps.K1, i, k0, K, pacc, dummy, false);
             }
+#ifdef RL_TIMING_MSE
+            TIMB(7);
+#endif
             // fixed-order reduction over the waves, both fragments in ONE round through a patch of their own
             __shared__ float XS[16 * RL_XS_LD];
             __shared__ float red1[4][2][4][64];
@@ -357,6 +412,9 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) red1[w][f][q][lane] = pacc[f][q];
             __syncthreads();
+#ifdef RL_TIMING_MSE
+            TIMB(1);
+#endif
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const int c = 16 * f + (ol & 15);
@@ -382,7 +440,8 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         }
         for (int kb = w * 16; kb < K; kb += 256) {
             const int nu = (K - kb + 63) >> 6;
-            if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
+            if (MSE && nu >= 4 && kb == w * 16) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE, true>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs, &mse_pl);
+            else if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
             else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
             else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
             else mac_group_pre<LB, NF, VB, 3, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
