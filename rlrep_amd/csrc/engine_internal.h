@@ -219,7 +219,8 @@ struct Builder {
         for (auto& t : tasks) {
             t.tiles_c = (t.Cn + edge - 1) / edge;
             t.ntiles = ((t.R + edge - 1) / edge) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
-            if (t.splits > 1 && !fold_fin(t)) {
+            if (t.splits > 1 && fold_fin(t)) t.fin_base = 0x7fffffff;       // (no finishing block ever matches it)
+            else if (t.splits > 1) {
                 const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
                 t.fin_base = fin;
                 fin += (int)(((long long)t.R * ((t.Cn + 3) / 4) + 255) / 256) + (bias ? (t.R + 255) / 256 : 0);

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GemmBatch gb) {
     const int bid = blockIdx.x;
     int ti = -1;
 #pragma unroll
-    for (int q = 0; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && gb.t[q].splits > 1 && !(gb.t[q].flags & FLAG_FIN_IN_ADAM) && bid >= gb.t[q].fin_base) ti = q;
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && gb.t[q].splits > 1 && bid >= gb.t[q].fin_base) ti = q;       // (tasks finished elsewhere -- FLAG_FIN_IN_ADAM -- carry fin_base = INT_MAX)
     if (ti < 0) return;
     const GemmTask& t = gb.t[ti];
     const int lb = bid - t.fin_base;
