@@ -19,7 +19,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $EX
 pids=()
 for f in gemm16 gemm_lds noisecritic elementwise replearn comm $EXP_SRCS engine agents2 $EXTRA_SRCS; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$OBJ/$f.o")" ] || [ "$HERE/../../include/rlrep.h" -nt "$OBJ/$f.o" ]; then
-    PF=""; { [ "$f" = gemm16 ] || [ "$f" = elementwise ]; } && PF="-mllvm -amdgpu-kernarg-preload-count=14"     # gemm16_kernel / adam_kernel: leading scalars preloaded into SGPRs
+    PF=""; { [ "$f" = gemm16 ] || [ "$f" = elementwise ] || [ "$f" = gemm_lds ]; } && PF="-mllvm -amdgpu-kernarg-preload-count=14"     # gemm16_kernel / adam_kernel / the gemm_lds kernels: leading scalars preloaded into SGPRs
     $HIPCC $FLAGS $PF -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi

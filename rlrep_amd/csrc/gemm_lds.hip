@@ -21,6 +21,11 @@
 // of ctrlsac) are split along K over `splits` workgroups per tile; partial tiles go to a slab and a finishing launch
 // adds them in split order (deterministic) and applies the epilogue.  No float atomics anywhere.
 #include "common.h"
+// Every kernel of this file finds its task from EIGHT LEADING SCALAR ARGUMENTS -- the tasks' first tiles (first finishing blocks for the finishing
+// kernel), INT_MAX where there is none -- which the hardware preloads into SGPRs at wave launch (build.sh: kernarg preload for this file): the task
+// search costs no load, and the first scalar-load round trip is the task's own record (it used to be the second).
+#define GL_DIR_PARAMS int d0, int d1, int d2, int d3, int d4, int d5, int d6, int d7
+#define GL_DIR_ARGS(D) (D)[0], (D)[1], (D)[2], (D)[3], (D)[4], (D)[5], (D)[6], (D)[7]
 extern long long g_rl_launches;
 #include "kparams.h"
 
@@ -201,7 +206,8 @@ __device__ __forceinline__ int gl_xcd_remap(int local, int n) {
 }
 
 template <int BT, int LA, int LB>
-__global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(GL_DIR_PARAMS, GemmBatch gb) {
+    const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
     constexpr int WT = BT / 2, TT = WT / 16;
     constexpr int SA = GlTile<BT, LA>::FLOATS, SB = GlTile<BT, LB>::FLOATS;
     constexpr int EPF = 4 * WT * (WT + 4);
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
     const int bid = blockIdx.x;
     int ti = 0;
 #pragma unroll
-    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= gdir[q]) ti = q;          // (preloaded directory: first tiles, INT_MAX beyond the last task)
     const GemmTask& t = gb.t[ti];
     const float* const pA = t.A; const float* const pB = t.B;
     const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
@@ -317,11 +323,12 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(Gemm
 }
 
 // split-K finisher: out = epilogue(sum over splits, in split order); bias gradient likewise
-__global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GL_DIR_PARAMS, GemmBatch gb) {
+    const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
     const int bid = blockIdx.x;
     int ti = -1;
 #pragma unroll
-    for (int q = 0; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && gb.t[q].splits > 1 && bid >= gb.t[q].fin_base) ti = q;       // (tasks finished elsewhere -- FLAG_FIN_IN_ADAM -- carry fin_base = INT_MAX)
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) if (bid >= gdir[q]) ti = q;       // (preloaded directory: first finishing blocks; INT_MAX for tasks that have none)
     if (ti < 0) return;
     const GemmTask& t = gb.t[ti];
     const int lb = bid - t.fin_base;
@@ -428,7 +435,8 @@ __device__ __forceinline__ void x3_stage_write(unsigned char* __restrict__ img, 
 // 8 waves as 4 (rows) x 2 (columns): a wave owns 32 x 64 of the tile = two 32x32 accumulators; four waves per SIMD with
 // two workgroups per CU, so split (VALU), fragment reads (LDS) and the matrix pipe overlap across waves
 template <int LA, int LB>
-__global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GL_DIR_PARAMS, GemmBatch gb) {
+    const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
     constexpr int BT = 128;
     constexpr int EPB = 8 * 32 * 68 * 4;                         // epilogue patches [32][68] per wave, bytes
     constexpr int STB = 6 * X3_IMGB;                             // six images
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GemmBatch gb) {
     const int bid = blockIdx.x;
     int ti = 0;
 #pragma unroll
-    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= gdir[q]) ti = q;          // (preloaded directory: first tiles, INT_MAX beyond the last task)
     const GemmTask& t = gb.t[ti];
     const float* const pA = t.A; const float* const pB = t.B;
     const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
@@ -605,7 +613,8 @@ __device__ __forceinline__ unsigned x3t_addr(unsigned lds_base, int kq, int chun
 // LA = LD_COL: both operands k-major (weight gradients).  LA = LD_ROW: A row-major [R, K] -- staged and read as in gemm_x3_kernel ([row][80-byte]
 // images, ds_read_b128 fragments) -- and only B k-major through the transposed reads (dX = G W with W stored [K = out features][Cn = in features]).
 template <int LA>
-__global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBatch gb) {
+    const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
     constexpr int BT = 128;
     constexpr int EPB = 8 * 32 * 68 * 4;                         // epilogue patches [32][68] per wave, bytes
     constexpr int AIMG = LA == LD_ROW ? X3_IMGB : X3T_IMGB;      // bytes per A image
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GemmBatch gb) {
     const int bid = blockIdx.x;
     int ti = 0;
 #pragma unroll
-    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= gdir[q]) ti = q;          // (preloaded directory: first tiles, INT_MAX beyond the last task)
     const GemmTask& t = gb.t[ti];
     const float* const pA = t.A; const float* const pB = t.B;
     const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
@@ -862,7 +871,8 @@ __device__ __forceinline__ unsigned x3s_taddr(unsigned lds_base, int kq, int chu
 }
 
 template <int LA, int LB, int VEC>
-__global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GemmBatch gb) {
+__global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBatch gb) {
+    const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
     constexpr int BT = 64;
     constexpr int AIMG = LA == LD_ROW ? X3S_RIMGB : X3S_TIMGB, BIMG = LB == LD_ROW ? X3S_RIMGB : X3S_TIMGB;
     constexpr int EPB = 4 * 32 * 36 * 4;                         // epilogue patches [32][36] per wave, bytes
@@ -875,7 +885,7 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GemmBatch gb) {
     const int bid = blockIdx.x;
     int ti = 0;
 #pragma unroll
-    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (q < gb.ntasks && bid >= gb.t[q].tile_base) ti = q;
+    for (int q = 1; q < GEMM_MAX_TASKS; ++q) if (bid >= gdir[q]) ti = q;          // (preloaded directory: first tiles, INT_MAX beyond the last task)
     const GemmTask& t = gb.t[ti];
     const float* const pA = t.A; const float* const pB = t.B;
     const int lda = t.lda, ldb = t.ldb, R = t.R, Cn = t.Cn, K = t.K;
@@ -984,46 +994,46 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GemmBatch gb) {
 // host side
 // ------------------------------------------------------------------------------------------------
 template <int BT>
-static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
-    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_ROW, LD_ROW>), g, dim3(256), 0, st, gb);
-    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_ROW, LD_COL>), g, dim3(256), 0, st, gb);
-    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_COL, LD_COL>), g, dim3(256), 0, st, gb);
+static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb, const int* dir) {
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_ROW, LD_ROW>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_ROW, LD_COL>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_lds_kernel<BT, LD_COL, LD_COL>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
     else return -1;
     return (int)hipGetLastError();
 }
 
-static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
-    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(512), 0, st, gb);
+static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb, const int* dir) {
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
     else if (la == LD_ROW && lb == LD_COL) {
         // dX form: the k-major B operand through the transposed reads too (RLREP_X3_DW_OLD: both on the form that transposes while staging);
         // its 16-byte loads along the rows need Cn % 4 == 0 and an aligned B -- which the routing guarantees for every bf16x3 task
-        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, gb);
-        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_ROW>), g, dim3(512), 0, st, gb);
+        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
+        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_ROW>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
     }
     else if (la == LD_COL && lb == LD_COL) {
         // weight-gradient form: the transposed-read kernel (staged as it lies in memory); RLREP_X3_DW_OLD: the form that transposes while staging
-        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, gb);
-        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_COL>), g, dim3(512), 0, st, gb);
+        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
+        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
     }
     else return -1;
     return (int)hipGetLastError();
 }
 
 static bool x3s_unaligned_ok(const GemmTask* t) { return t->R >= 4 && t->Cn >= 4 && t->K >= 4; }       // (the pulled-back tail load needs four elements to exist)
-static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb) {
+static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb, const int* dir) {
     // one instantiation per launch: the any-alignment loaders as soon as ONE task of the stage has an operand that is not 16-byte regular
     bool unal = false;
     for (int q = 0; q < gb.ntasks; ++q) if (gb.t[q].flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) { unal = true; if (!x3s_unaligned_ok(&gb.t[q])) return -2; }
     if (unal) {
-        if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, 2>), g, dim3(256), 0, st, gb);
-        else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, 2>), g, dim3(256), 0, st, gb);
-        else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, 2>), g, dim3(256), 0, st, gb);
+        if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, 2>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+        else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, 2>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+        else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, 2>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
         else return -1;
         return (int)hipGetLastError();
     }
-    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, 1>), g, dim3(256), 0, st, gb);
-    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, 1>), g, dim3(256), 0, st, gb);
-    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, 1>), g, dim3(256), 0, st, gb);
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_ROW, 1>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_ROW, LD_COL, 1>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3s_kernel<LD_COL, LD_COL, 1>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
     else return -1;
     return (int)hipGetLastError();
 }
@@ -1031,11 +1041,16 @@ static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& g
 // bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3); 65 = the 64-wide tile on the bf16 pipe
 extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st) {
     if (total_tiles <= 0) return 0;
-    int rc = bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb)
-           : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb);
+    int dir[GEMM_MAX_TASKS], fdir[GEMM_MAX_TASKS];
+    for (int q = 0; q < GEMM_MAX_TASKS; ++q) {
+        dir[q] = q < gb->ntasks ? gb->t[q].tile_base : 0x7fffffff;
+        fdir[q] = (q < gb->ntasks && gb->t[q].splits > 1) ? gb->t[q].fin_base : 0x7fffffff;
+    }
+    int rc = bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb, dir) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb, dir)
+           : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb, dir) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb, dir);
     if (rc != 0) return rc;
     if (fin_blocks > 0) {
-        hipLaunchKernelGGL(gemm_lds_fin_kernel, dim3(fin_blocks), dim3(256), 0, st, *gb);
+        hipLaunchKernelGGL(gemm_lds_fin_kernel, dim3(fin_blocks), dim3(256), 0, st, GL_DIR_ARGS(fdir), *gb);
         ++g_rl_launches;              // split-K: the stage is two kernels
         rc = (int)hipGetLastError();
     }
