@@ -245,15 +245,15 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=6.0):
 # name -> (engine ids, bound, peak, unit, regex over rocprofv3 kernel names: which rows of profiles/*_kernel_stats.csv / *_pmc_*.json belong to it)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 measured)
 FAMILIES = {
-    'gemm16': ((1, 2), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm16_kernel|gemm16_duo_kernel|heads_vae_kernel)',
-               'gemm16_kernel + gemm16_duo_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'),
+    'gemm16': ((1, 2), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm16_kernel|gemm16_fast_kernel|gemm16_fast4_kernel|gemm16_duo_kernel|heads_vae_kernel)',
+               'gemm16_kernel + gemm16_fast_kernel + gemm16_fast4_kernel + gemm16_duo_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'),
     'gemm_lds64': ((3,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm_lds_kernel<64|gemm_lds_fin_kernel)',
                    'gemm_lds_kernel<64,...> + gemm_lds_fin_kernel (64-wide LDS tiles on fp32 MFMA, split-K slabs + finishing blocks)'),
     'gemm_lds128': ((4,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^gemm_lds_kernel<128', 'gemm_lds_kernel<128,...> (128-wide LDS tiles on fp32 MFMA)'),
-    'gemm_x3': ((5,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^gemm_x3_kernel',
-                'gemm_x3_kernel (128-wide tiles on the bf16 pipe, exact 3-way split: peak = dense bf16 peak / 6 executed flops per product)'),
+    'gemm_x3': ((5,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^gemm_x3(s|t)?_kernel',
+                'gemm_x3_kernel / gemm_x3t_kernel (128-wide) + gemm_x3s_kernel (64-wide): tiles on the bf16 pipe, exact 3-way split: peak = dense bf16 peak / 6 executed flops per product'),
     'noise_critic': ((6,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^nc_', 'nc_fwd / nc_dx / nc_dw kernels (vlsac noise critic, bf16x3: peak = dense bf16 peak / 6)'),
-    'optimizer': ((7,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^adam_kernel', 'adam_kernel (Adam + Polyak + metrics + riders: 28 B per parameter + 12 B per target element)'),
+    'optimizer': ((7,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^adam_(l1_)?kernel', 'adam_kernel / adam_l1_kernel (Adam + Polyak + metrics + riders: 28 B per parameter + 12 B per target element)'),
     'score': ((8,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^diffsr_score', 'diffsr_score kernels (one pass over the [B, F*S] tensor)'),
     'other': ((0,), None, None, None, r'.*', 'losses, gathers, copies (elementwise + wave reductions)'),
 }

@@ -306,6 +306,8 @@ static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
             else if (act == ACT_RELU) { if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, ACT_RELU>(g, st, gb)) return true; }
             else if (act == ACT_ELU) { if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, ACT_ELU>(g, st, gb)) return true; }
             else if (launch_fast<LA, LB, NF, VA, VB, EPI_DX, -1>(g, st, gb)) return true;
+        } else if (same_epi && NF == 1 && LB == LD_COL && epi == EPI_DX_POLICYBWD) {
+            if (launch_fast<LA, LB, NF, VA, VB, EPI_DX_POLICYBWD, ACT_NONE>(g, st, gb)) return true;     // (the policy's backward: 3 500 cycles of epilogue in the generic body)
         } else if (launch_fast<LA, LB, NF, VA, VB, -1, -1>(g, st, gb)) return true;       // any other epilogue: the generic body behind the fast front end
     }
     if (!same_epi) return false;

@@ -332,6 +332,9 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
             if (t.ad_tb) btv = t.ad_tb[o];
         }
     }
+    // (the policy's backward needs log(alpha): fetched here, under the operand stream, when the epilogue kind is known at compile time)
+    double log_alpha_pre = 0.0;
+    if constexpr (EPI_K == EPI_DX_POLICYBWD) log_alpha_pre = t.dptr[0];
     asm volatile("" ::: "memory");      // the pin (see above)
     TIMB(6);
 
@@ -595,7 +598,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         case EPI_DX_POLICYBWD: {
             // v = dL/da_c from the critic path; e0 = rho, cold = eps, cold2 = a = tanh(x)
             const int A = n0;
-            const float g = (float)exp(t.dptr[0]) * t.s0;            // dL/dlogpi = alpha / B
+            const float g = (float)exp(EPI_K == EPI_DX_POLICYBWD ? log_alpha_pre : t.dptr[0]) * t.s0;            // dL/dlogpi = alpha / B
             const float tt = tanhf(e0[f]);
             const float sg = expf(-5.f + 3.5f * (tt + 1.f));
             const float y = cold2[f], e = cold[f];
