@@ -1004,17 +1004,11 @@ static int launch_bt(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
 
 static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb, const int* dir) {
     if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_ROW>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
-    else if (la == LD_ROW && lb == LD_COL) {
-        // dX form: the k-major B operand through the transposed reads too (RLREP_X3_DW_OLD: both on the form that transposes while staging);
-        // its 16-byte loads along the rows need Cn % 4 == 0 and an aligned B -- which the routing guarantees for every bf16x3 task
-        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
-        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_ROW>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
-    }
-    else if (la == LD_COL && lb == LD_COL) {
-        // weight-gradient form: the transposed-read kernel (staged as it lies in memory); RLREP_X3_DW_OLD: the form that transposes while staging
-        if (getenv("RLREP_X3_DW_OLD")) hipLaunchKernelGGL((gemm_x3_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
-        else hipLaunchKernelGGL((gemm_x3t_kernel<LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
-    }
+    // dX form: the k-major B operand through the transposed LDS reads; its 16-byte loads along the rows need Cn % 4 == 0 and an aligned B -- which the
+    // routing guarantees for every task of the 128-wide bf16x3 tile
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3t_kernel<LD_ROW>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
+    // weight-gradient form: both operands staged as they lie in memory
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3t_kernel<LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb);
     else return -1;
     return (int)hipGetLastError();
 }
