@@ -365,8 +365,16 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     dim3 g(total_tiles);
     static const bool trace = getenv("RLREP_GEMM16_TRACE") != nullptr;       // one line per launch: which front end it gets (tools/exp/gemm16_trace.py)
     if (trace) {
-        FastArgs fa; const bool f = fast_args(*gb, fa);
-        fprintf(stderr, "[gemm16] la=%d lb=%d nf=%d tasks=%d tiles=%d fast_args=%d :", la, lb, nf, gb->ntasks, total_tiles, (int)f);
+        FastArgs fa; Fast4Args f4;
+        const bool pre = gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE), vecA = all_vec(*gb, false), vecB = all_vec(*gb, true);
+        const bool vec_ok = la == LD_ROW && vecA && (lb == LD_COL || vecB), nf_ok = nf == 1 || nf == 2;
+        const char* front = "record";
+        if (!pre && la == LD_ROW && nf_ok && !getenv("RLREP_GEMM16_GENERIC")) {
+            if (lb == LD_ROW && (vecA == vecB) && fast_args(*gb, fa, true) && gb->t[0].epi == EPI_FWD) front = "fast (K <= 64)";
+            else if (vec_ok && fast_args(*gb, fa)) front = "fast";
+            else if (vec_ok && fast4_args(*gb, f4)) front = "fast4";
+        }
+        fprintf(stderr, "[gemm16] la=%d lb=%d nf=%d tasks=%d tiles=%d front=%s :", la, lb, nf, gb->ntasks, total_tiles, front);
         for (int q = 0; q < gb->ntasks; ++q) fprintf(stderr, " [R=%d Cn=%d K=%d lda=%d ldb=%d epi=%d act=%d fl=0x%x]", gb->t[q].R, gb->t[q].Cn, gb->t[q].K, gb->t[q].lda, gb->t[q].ldb, gb->t[q].epi, gb->t[q].act, gb->t[q].flags);
         fprintf(stderr, "\n");
     }
