@@ -184,6 +184,11 @@ int32_t rlrep_replay_row_floats(const rlrep_dims* dims);
  * Asynchronous on `stream`: at most two copies.  nrows <= capacity. */
 int32_t rlrep_replay_add(float* ring_dev, int64_t capacity, int32_t row_floats, int64_t ptr,
                          const float* rows_host, int64_t nrows, void* stream);
+/* The same plus the ring's new fill level written to the device scalar the index generator reads (`size_dev`, may be NULL), in ONE launch that
+ * reads the staged rows in place: `rows_host` must be pinned (mapped) host memory (RLREP_ERR_ARG otherwise).  What ReplayBuffer.flush() issues in
+ * front of every train() of main.py's loop. */
+int32_t rlrep_replay_add_sized(float* ring_dev, int64_t capacity, int32_t row_floats, int64_t ptr, const float* rows_host, int64_t nrows,
+                               int32_t* size_dev, int32_t new_size, void* stream);
 /* gather rows idx_dev[0..batch) of the ring into a batch slot */
 int32_t rlrep_replay_sample(rlrep_agent* agent, int32_t slot, const float* ring_dev, const int32_t* idx_dev,
                             int32_t batch, void* stream);
@@ -311,6 +316,13 @@ int32_t rlrep_sync_frozen(rlrep_agent* agent, void* stream);
 /* action[n,A] = tanh(mu + eps*std) (eps_dev != NULL) or tanh(mu) (NULL), clamped to [lo,hi]. */
 int32_t rlrep_actor_forward(rlrep_agent* agent, const float* obs_dev, int32_t n, const float* eps_dev,
                             float lo, float hi, float* action_dev, void* stream);
+
+/* SACAgent.select_action for ONE observation (sac_agent.py:89-96; main.py:126 calls it once per environment step) in ONE launch: the three
+ * actor layers, the tanh-Gaussian head and -- explore != 0 -- the standard-normal draw rlrep_fill_normal(eps[A], 1, seed, offset) would give,
+ * action = clamp(tanh(mu + eps * std), lo, hi) (explore == 0: tanh(mu)).  obs[S] / action[A]: device pointers, or (the *_on_host flags)
+ * pinned host buffers, which the kernel then reads / writes in place: no copy on either side, the caller synchronises `stream` and reads. */
+int32_t rlrep_select_action(rlrep_agent* agent, const float* obs, int32_t obs_on_host, int32_t explore, uint64_t seed, uint64_t offset,
+                            float lo, float hi, float* action, int32_t action_on_host, void* stream);
 
 /* ---- metrics ------------------------------------------------------------------------------ */
 /* device float array of n_metrics slots, valid after the stream has passed the producing step */

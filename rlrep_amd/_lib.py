@@ -83,6 +83,7 @@ def _load():
         'rlrep_set_batch': (i32, [vp, i32, P(Batch), vp]),
         'rlrep_replay_row_floats': (i32, [P(Dims)]),
         'rlrep_replay_add': (i32, [vp, i64, i32, i64, vp, i64, vp]),
+        'rlrep_replay_add_sized': (i32, [vp, i64, i32, i64, vp, i64, vp, i32, vp]),
         'rlrep_replay_sample': (i32, [vp, i32, vp, vp, i32, vp]),
         'rlrep_fill_indices': (i32, [vp, i64, i32, u64, u64, vp]),
         'rlrep_fill_normal': (i32, [vp, i64, f32, u64, u64, vp]),
@@ -118,6 +119,7 @@ def _load():
         'rlrep_end_train': (i32, [vp]),
         'rlrep_sync_frozen': (i32, [vp, vp]),
         'rlrep_actor_forward': (i32, [vp, vp, i32, vp, f32, f32, vp, vp]),
+        'rlrep_select_action': (i32, [vp, vp, i32, i32, u64, u64, f32, f32, vp, i32, vp]),
         'rlrep_images_managed': (i32, [vp, i32]),
         'rlrep_refresh_images': (i32, [vp, vp]),
         'rlrep_feature_chain_next': (i32, [vp]),

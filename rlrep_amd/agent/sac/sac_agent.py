@@ -15,6 +15,7 @@ from torch import nn
 
 from rlrep_amd.core import HipCore
 from rlrep_amd.utils import util
+from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
@@ -216,6 +217,8 @@ class SACAgent(object):
         # hand-off between the streams: 466 us per call against 431 us for the one-graph sequential train(); tools/exp/rl_loop.py: 1 600 vs 1 880
         # iterations/s).  Both forms perform identical updates (tests), so train() picks per call: three calls in a row whose pair was waited
         # for before the next call -> the sequential graph; two calls in a row with nothing looked at in between -> back to the two chains.
+        self._pipeline_mode = int(os.environ.get('RLREP_PIPELINE', '2'))          # (read once: the per-call paths do not touch os.environ)
+        self._stamp_on = os.environ.get('RLREP_STAMP', '0') == '1'
         self._adaptive = bool(int(os.environ.get('RLREP_ADAPTIVE_PIPELINE', '1'))) and hip_kwargs.get('adaptive', 'pipeline' not in hip_kwargs)      # (an explicit pipeline= argument pins the form)
         self._looked, self._n_looked, self._n_b2b = False, 0, 0
         # two communicators in flight (one per chain): never met a second real rank on hardware, so it is opt-in (RLREP_PIPELINE_DP=1);
@@ -291,6 +294,14 @@ class SACAgent(object):
                                    obs=torch.empty(1, self.state_dim, dtype=torch.float32, device=dev),
                                    out=torch.empty(1, self.action_dim, dtype=torch.float32, device=dev))
         sel['obs_pin'].numpy()[0, :] = np.asarray(state, dtype=np.float32).reshape(-1)
+        if eps is None:
+            # ONE launch (rlrep_select_action): the kernel reads the pinned observation and writes the pinned action in place; the draw is the
+            # one _noise('sel', ...) would have produced (same seed, same counter)
+            if explore:
+                self._ctr += 1
+            self.core.select_action(sel['obs_pin'], explore, self._seed, self._ctr << 20, *self.action_range, sel['act_pin'])
+            _current_stream().synchronize()
+            return sel['act_pin'].numpy()[0].copy()
         sel['obs'].copy_(sel['obs_pin'], non_blocking=True)
         if explore and eps is not None:
             eps = torch.as_tensor(np.asarray(eps, dtype=np.float32)).reshape(1, self.action_dim).to(self.core.device)
@@ -300,7 +311,7 @@ class SACAgent(object):
             eps = None
         self.core.actor_forward(sel['obs'], eps, *self.action_range, out=sel['out'])
         sel['act_pin'].copy_(sel['out'], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        _current_stream().synchronize()
         return sel['act_pin'].numpy()[0].copy()
 
     def update_target(self):
@@ -789,7 +800,7 @@ class SACAgent(object):
 
     def _stamp(self, tag):
         """RLREP_STAMP=1 (diagnostics, tools/exp/chain_stamps.py): a one-thread launch that dates this point of the chain on the device."""
-        if os.environ.get('RLREP_STAMP', '0') != '1':
+        if not self._stamp_on:
             return
         from rlrep_amd._lib import lib as _l, check as _check
         if getattr(self, '_stamp_ring', None) is None:
@@ -809,9 +820,10 @@ class SACAgent(object):
         pipelined train() in flight may still be sampling from on its own stream -- make the caller's stream wait for that chain."""
         P = self._pipe
         if P is not None and self._pending == 2 and P.get('last_f') is not None:
-            if P.get('s_f') is not None and torch.cuda.current_stream() == P['s_f']:
+            cur = _current_stream()
+            if P.get('s_f') is not None and cur == P['s_f']:
                 return                      # the write is issued ON the feature stream: ordered behind the chain by the stream itself
-            torch.cuda.current_stream().wait_event(P['last_f'])
+            cur.wait_event(P['last_f'])
 
     def _train_graph_pipelined(self, buffer, B):
         self._hook_buffer(buffer)
@@ -825,7 +837,7 @@ class SACAgent(object):
             with torch.cuda.stream(P0['s_f']):
                 buffer.flush()
                 buffer.size_dev()
-            cur_id = torch.cuda.current_stream().cuda_stream
+            cur_id = _raw_stream()
             if e0 is not None and P0.get('seen') == (e0, cur_id):
                 P0['seen'] = (buffer.device_epoch, cur_id)        # our own writes need no wait for the caller's stream
         else:
@@ -906,7 +918,7 @@ class SACAgent(object):
         k = P['t'] % P['nset']
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
-        cur = torch.cuda.current_stream()
+        cur = _current_stream()
         # replay rows staged by ReplayBuffer.add() land on the caller's stream: order the feature chain after them -- but only when the
         # buffer has enqueued something since the last call (or the chains were idle): the event record + wait pair is ~5 us of the
         # feature chain's critical path, and a back-to-back train() loop has nothing to wait for
@@ -1013,7 +1025,7 @@ class SACAgent(object):
         k = P['t'] % P['nset']
         P['t'] += 1
         s_ca, s_f = P['s_ca'], P['s_f']
-        cur = torch.cuda.current_stream()
+        cur = _current_stream()
         s_f.wait_stream(cur)
         if not self._pending:
             s_ca.wait_stream(cur)
@@ -1064,7 +1076,7 @@ class SACAgent(object):
     def _prefer_sequential(self):
         """Per-call choice between the two-chain and the one-graph form of train() (see __init__): has the caller been waiting for the critic /
         actor pair between the calls?"""
-        if not self._adaptive or int(os.environ.get('RLREP_PIPELINE', '2')) == 1:
+        if not self._adaptive or self._pipeline_mode == 1:
             return False
         if self._looked:
             self._n_looked, self._n_b2b = min(self._n_looked + 1, 8), 0

@@ -18,8 +18,11 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+from rlrep_amd.utils.streams import raw_stream, current_stream          # (cheap forms of torch.cuda.current_stream())
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(raw_stream())
 
 
 class LazyInfo(dict):
@@ -339,6 +342,10 @@ class HipCore:
             out = torch.empty(n, self.dims.action_dim, dtype=torch.float32, device=self.device)
         check(lib.rlrep_actor_forward(self.h, _ptr(obs), n, _ptr(eps), float(lo), float(hi), _ptr(out), _stream()), 'actor_forward')
         return out
+
+    def select_action(self, obs_pin, explore, seed, offset, lo, hi, act_pin):
+        """One observation -> one action in one launch; both buffers pinned host tensors the kernel reads / writes in place (rlrep_select_action)."""
+        check(lib.rlrep_select_action(self.h, _ptr(obs_pin), 1, 1 if explore else 0, int(seed), int(offset), float(lo), float(hi), _ptr(act_pin), 1, _stream()), 'select_action')
 
     # ---- noise --------------------------------------------------------------------------------
     def fill_normal(self, t, std, seed, offset):

@@ -201,6 +201,75 @@ __global__ __launch_bounds__(256) void policy_fwd_kernel(PolicyFwd p) {
     if (p.logp) p.logp[b] = lp;
 }
 
+// SACAgent.select_action (sac_agent.py:89-96) for ONE observation in ONE launch: the three actor layers as wave-cooperative dot products (a wave
+// per output row, 4-byte loads along the row, fixed-order lane reduction), the tanh-Gaussian head, the Philox draw of fill_normal(seed, offset)
+// for its A elements.  obs / act may be pinned HOST buffers (mapped): no copy launch on either side -- main.py's loop pays one launch and one
+// stream synchronisation per environment step instead of nine dependent operations (tools/exp/host_loop.py).
+__global__ __launch_bounds__(1024) void select_action_kernel(SelectAct p) {
+    extern __shared__ float sm[];                        // obs[S] | h1[Ha] | h2[Ha] | o[2A]
+    float* const x0 = sm; float* const h1 = x0 + p.S; float* const h2 = h1 + p.Ha; float* const o = h2 + p.Ha;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;          // 16 waves
+    for (int k = threadIdx.x; k < p.S; k += 1024) x0[k] = p.obs[k];
+    __syncthreads();
+    // a wave takes rows w, w + 16, ...; EIGHT rows at a time with all their loads in flight together (a row after the other is one exposed
+    // round trip per row: 147 us for the three layers on one workgroup, measured)
+    auto layer = [&](const float* __restrict__ W, const float* __restrict__ b, const float* in, int K, int N, float* out, bool elu) {
+        for (int j0 = w; j0 < N; j0 += 16 * 8) {
+            float s[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s[r] = 0.f;
+            for (int k0 = 0; k0 < K; k0 += 256) {
+                float wv[8][4], xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int k = k0 + lane + 64 * i; xv[i] = k < K ? in[k] : 0.f; }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int j = min(j0 + 16 * r, N - 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wv[r][i] = W[(size_t)j * K + min(k0 + lane + 64 * i, K - 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[r] = fmaf(wv[r][i], xv[i], s[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int j = j0 + 16 * r;
+                const float t = wave_sum(s[r]);
+                if (lane == 0 && j < N) { const float v = t + b[j]; out[j] = elu ? elu_f(v) : v; }
+            }
+        }
+    };
+    layer(p.W1, p.b1, x0, p.S, p.Ha, h1, true);
+    __syncthreads();
+    layer(p.W2, p.b2, h1, p.Ha, p.Ha, h2, true);
+    __syncthreads();
+    layer(p.W3, p.b3, h2, p.Ha, 2 * p.A, o, false);
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < p.A) {
+        float e = 0.f;
+        if (p.explore) {                                  // element j of philox_fill_body's normal stream (kind 0, std 1, stream 0, no device counter)
+            const long long q = j >> 2;
+            uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32)};
+            philox4x32_10(c, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+            const int h = (j & 3) >> 1;
+            const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            e = (j & 1) ? rad * sn : rad * cs;
+        }
+        const float mu = o[j];
+        const float t = tanhf(o[p.A + j]);
+        const float sg = expf(-5.f + 3.5f * (t + 1.f));
+        const float y = tanhf(mu + e * sg);
+        p.act[j] = fminf(fmaxf(y, p.lo), p.hi);
+    }
+}
+
 // gradient of the actor loss w.r.t. the trunk output [mu | rho]; h = dL/d(action) from the critic path
 __global__ __launch_bounds__(256) void policy_bwd_kernel(PolicyBwd p) {
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -629,6 +698,31 @@ extern "C" int rl_launch_philox_raw(const uint32_t* ck, uint32_t* out, long long
 }
 extern "C" int rl_launch_policy_fwd(const PolicyFwd* p, hipStream_t st) {
     hipLaunchKernelGGL(policy_fwd_kernel, dim3((p->B + 255) / 256), dim3(256), 0, st, *p);
+    return (int)hipGetLastError();
+}
+// ReplayBuffer.add's staged rows into the device ring, wrap-around included, and the new fill level into the device scalar the index generator
+// reads: ONE launch that reads the pinned staging rows in place (it replaces an SDMA copy per ring segment plus a fill launch for the scalar --
+// three stream operations in front of every train() graph of main.py's loop)
+__global__ __launch_bounds__(256) void replay_add_kernel(float* __restrict__ ring, long long capacity, int row, long long ptr, const float* __restrict__ rows,
+                                                         long long nrows, int* size_dev, int new_size) {
+    const long long n = nrows * row;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long r = e / row, c = e - r * row;
+        long long dst = ptr + r; if (dst >= capacity) dst -= capacity;
+        ring[dst * row + c] = rows[e];
+    }
+    if (size_dev && blockIdx.x == 0 && threadIdx.x == 0) *size_dev = new_size;
+}
+extern "C" int rl_launch_replay_add(float* ring, long long capacity, int row, long long ptr, const float* rows, long long nrows, int* size_dev, int new_size, hipStream_t st) {
+    const long long n = nrows * row;
+    const int blocks = (int)std::min<long long>(256, std::max<long long>(1, (n + 255) / 256));
+    hipLaunchKernelGGL(replay_add_kernel, dim3(blocks), dim3(256), 0, st, ring, capacity, row, ptr, rows, nrows, size_dev, new_size);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_select_action(const SelectAct* p, hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)p->S + 2 * (size_t)p->Ha + 2 * (size_t)p->A);
+    if (lds > 60 * 1024) return -7;
+    hipLaunchKernelGGL(select_action_kernel, dim3(1), dim3(1024), lds, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_policy_bwd(const PolicyBwd* p, hipStream_t st) {

@@ -1244,6 +1244,22 @@ int32_t rlrep_replay_add(float* ring_dev, int64_t capacity, int32_t row_floats, 
     return 0;
 }
 
+extern "C" int rl_launch_replay_add(float* ring, long long capacity, int row, long long ptr, const float* rows, long long nrows, int* size_dev, int new_size, hipStream_t st);
+// ... the same in ONE launch that also writes the ring's new fill level into `size_dev` (the scalar the device index generator reads): the rows are
+// read in place from PINNED (mapped) host memory -- RLREP_ERR_ARG if `rows_host` is not.
+int32_t rlrep_replay_add_sized(float* ring_dev, int64_t capacity, int32_t row_floats, int64_t ptr, const float* rows_host, int64_t nrows,
+                               int32_t* size_dev, int32_t new_size, void* stream) {
+    if (!ring_dev || !rows_host || capacity <= 0 || row_floats <= 0 || ptr < 0 || ptr >= capacity || nrows < 0 || nrows > capacity || new_size < 0 || new_size > capacity) {
+        rl_set_error("replay_add_sized: bad argument"); return RLREP_ERR_ARG;
+    }
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<float*>(rows_host), 0) != hipSuccess || !d) { rl_set_error("replay_add_sized: the staging rows are not mapped (pinned) host memory"); return RLREP_ERR_ARG; }
+    ++g_rl_launches;
+    const int rc = rl_launch_replay_add(ring_dev, capacity, row_floats, ptr, (const float*)d, nrows, size_dev, new_size, (hipStream_t)stream);
+    if (rc) { rl_set_error("replay_add_sized: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+
 static void slot_fill_params(rlrep_agent* ag, int slot, const float* ring_dev, const int32_t* idx_dev, SlotFill& p) {
     Slot& s = ag->slot[slot];
     memset(&p, 0, sizeof(p));
@@ -1648,6 +1664,27 @@ int32_t rlrep_actor_forward(rlrep_agent* ag, const float* obs, int32_t n, const 
     if (rc) return rc;
     rc = rl_launch_copy(ag->act_out, action, (long long)n * A, st);
     if (rc) { rl_set_error("actor_forward copy-out: hip error %d", rc); return RLREP_ERR_HIP; }
+    return 0;
+}
+
+extern "C" int rl_launch_select_action(const SelectAct* p, hipStream_t st);
+// One observation -> one action in ONE launch.  obs / action: device pointers, or pinned (mapped) host buffers -- resolved here with
+// hipHostGetDevicePointer, so that the kernel reads the observation and writes the action in place and no copy launch stands on either side.
+int32_t rlrep_select_action(rlrep_agent* ag, const float* obs, int32_t obs_on_host, int32_t explore, uint64_t seed, uint64_t offset,
+                            float lo, float hi, float* action, int32_t action_on_host, void* stream) {
+    if (!ag || !obs || !action) { rl_set_error("select_action: bad argument"); return RLREP_ERR_ARG; }
+    SelectAct p; memset(&p, 0, sizeof(p));
+    void* d = nullptr;
+    if (obs_on_host) { if (hipHostGetDevicePointer(&d, const_cast<float*>(obs), 0) != hipSuccess || !d) { rl_set_error("select_action: the observation buffer is not mapped (pinned) host memory"); return RLREP_ERR_ARG; } p.obs = (const float*)d; }
+    else p.obs = obs;
+    if (action_on_host) { if (hipHostGetDevicePointer(&d, action, 0) != hipSuccess || !d) { rl_set_error("select_action: the action buffer is not mapped (pinned) host memory"); return RLREP_ERR_ARG; } p.act = (float*)d; }
+    else p.act = action;
+    p.W1 = ag->P("actor.trunk.0.weight"); p.b1 = ag->P("actor.trunk.0.bias"); p.W2 = ag->P("actor.trunk.2.weight"); p.b2 = ag->P("actor.trunk.2.bias");
+    p.W3 = ag->P("actor.trunk.4.weight"); p.b3 = ag->P("actor.trunk.4.bias");
+    p.S = ag->d.state_dim; p.Ha = ag->d.actor_hidden_dim; p.A = ag->d.action_dim; p.explore = explore ? 1 : 0; p.lo = lo; p.hi = hi; p.seed = seed; p.offset = offset;
+    ++g_rl_launches;
+    const int rc = rl_launch_select_action(&p, (hipStream_t)stream);
+    if (rc) { rl_set_error("select_action: launch failed (%d)", rc); return rc == -7 ? RLREP_ERR_ARG : RLREP_ERR_HIP; }
     return 0;
 }
 

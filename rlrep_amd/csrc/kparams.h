@@ -10,6 +10,14 @@ struct SlotFill {
     float *XE, *XF, *XF2, *XFpi, *R, *D;                    // slot buffers
 };
 
+// rlrep_select_action: ONE observation through the actor in one launch (elementwise.hip select_action_kernel)
+struct SelectAct {
+    const float* obs; float* act;                       // [S] in, [A] out: device pointers (of pinned host buffers, as the launcher maps them)
+    const float *W1, *b1, *W2, *b2, *W3, *b3;           // actor.trunk.{0,2,4}: [Ha,S], [Ha,Ha], [2A,Ha]
+    int S, Ha, A, explore;
+    float lo, hi;
+    unsigned long long seed, offset;                    // the draw = rlrep_fill_normal(eps[A], 1, seed, offset)
+};
 struct PhiloxFill {
     float* dst_f; int* dst_i; long long n;
     int kind;                  // 0: normal*std -> dst_f ; 1: uniform int in [0,hi) -> dst_i

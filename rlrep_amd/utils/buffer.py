@@ -10,6 +10,7 @@ one asynchronous copy per `sample`/`flush`.
 import collections
 import numpy as np
 import torch
+from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream
 
 Batch = collections.namedtuple('Batch', ['state', 'action', 'reward', 'next_state', 'done'])
 
@@ -84,8 +85,10 @@ class ReplayBuffer(object):
             import ctypes as C
             from rlrep_amd._lib import lib, check
             with torch.cuda.device(self.device):
-                check(lib.rlrep_replay_add(C.c_void_p(self.ring.data_ptr()), self.max_size, self.row, a, C.c_void_p(self._stage.data_ptr()), n,
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'replay_add')
+                # (one launch: the staged rows, read in place from the pinned staging buffer, and the new fill level for the device-side sampler)
+                check(lib.rlrep_replay_add_sized(C.c_void_p(self.ring.data_ptr()), self.max_size, self.row, a, C.c_void_p(self._stage.data_ptr()), n,
+                                                 C.c_void_p(self._size_dev.data_ptr()), self.size, C.c_void_p(_raw_stream())), 'replay_add_sized')
+                self._size_pushed = self.size
                 self._copy_done = torch.cuda.Event()
                 self._copy_done.record()
         else:
@@ -140,7 +143,7 @@ class ReplayBuffer(object):
         """A reader on the caller's stream: the last flush may have been issued on ANOTHER stream (a pipelined train() writes the staged rows on its
         feature stream, sac_agent.py) -- wait for it there."""
         if self._copy_done is not None and self.device.type == 'cuda':
-            torch.cuda.current_stream().wait_event(self._copy_done)
+            _current_stream().wait_event(self._copy_done)
 
     def gather(self, ind):
         S, A = self.state_dim, self.action_dim

@@ -89,6 +89,30 @@ def test_select_action_explore_matches_oracle_sample():
         assert np.allclose(a, want[0].numpy(), atol=1e-5), (a, want)
 
 
+@pytest.mark.parametrize('name', ['vlsac_tiny', 'vlsac_hc', 'sac_tiny'])
+def test_select_action_single_launch_equals_the_staged_path(name):
+    """rlrep_select_action (one launch, pinned buffers read / written in place) against the staged path it replaces (copy in, noise launch,
+    three layer launches, policy launch, copy out): same action for the mean and -- with the draw of the agent's own noise stream
+    (seed, counter << 20) reproduced by rlrep_fill_normal -- for the explored action."""
+    from test_hip_parity import make_agent
+    c = Case(name)
+    agent = make_agent(c)
+    rs = np.random.RandomState(5)
+    for _ in range(3):
+        s = rs.standard_normal(c.S).astype(np.float32)
+        ctr0 = agent._ctr
+        a = agent.select_action(s, explore=True)
+        assert agent._ctr == ctr0 + 1
+        eps = torch.empty(1, c.A, device='cuda')
+        agent.core.fill_normal(eps, 1.0, agent._seed, (ctr0 + 1) << 20)
+        b = agent._select_action(s, True, eps=eps.cpu().numpy())
+        assert np.allclose(a, b, atol=2e-6), (a, b)
+        m = agent.select_action(s)
+        obs = torch.as_tensor(s, device='cuda')[None]
+        m2 = agent.core.actor_forward(obs, None, *agent.action_range).cpu().numpy()[0]
+        assert np.allclose(m, m2, atol=2e-6), (m, m2)
+
+
 # ---- feature_step + update_feature_target in the reference's order ---------------------------------------------------------------
 def test_feature_step_then_update_feature_target_matches_oracle():
     """vlsac_agent.py:252-258: `feature_step(batch)` then `update_feature_target()` per feature iteration.  Here the Polyak f -> f_target is
