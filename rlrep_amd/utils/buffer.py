@@ -10,7 +10,7 @@ one asynchronous copy per `sample`/`flush`.
 import collections
 import numpy as np
 import torch
-from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream
+from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream, current_device_index as _current_device_index
 
 Batch = collections.namedtuple('Batch', ['state', 'action', 'reward', 'next_state', 'done'])
 
@@ -36,6 +36,7 @@ class ReplayBuffer(object):
         self._staged = 0            # rows waiting in the staging buffer
         self._stage_start = 0       # ring position of the first staged row
         self._copy_done = None
+        self._copy_event = None
         self._size_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._size_pushed = -1
         self.device_epoch = 0        # bumped whenever this buffer enqueues device work on the caller's stream (a pipelined train() then orders itself after it)
@@ -84,13 +85,21 @@ class ReplayBuffer(object):
             # the C ABI's entry for this row of the path (include/rlrep.h rlrep_replay_add): the staged rows, wrap-around included
             import ctypes as C
             from rlrep_amd._lib import lib, check
-            with torch.cuda.device(self.device):
-                # (one launch: the staged rows, read in place from the pinned staging buffer, and the new fill level for the device-side sampler)
+            # (one launch: the staged rows, read in place from the pinned staging buffer, and the new fill level for the device-side sampler;
+            # the device context manager and a fresh Event per call were 15 us of host time in front of every train() of main.py's loop)
+            def issue():
                 check(lib.rlrep_replay_add_sized(C.c_void_p(self.ring.data_ptr()), self.max_size, self.row, a, C.c_void_p(self._stage.data_ptr()), n,
                                                  C.c_void_p(self._size_dev.data_ptr()), self.size, C.c_void_p(_raw_stream())), 'replay_add_sized')
                 self._size_pushed = self.size
-                self._copy_done = torch.cuda.Event()
-                self._copy_done.record()
+                if self._copy_event is None:
+                    self._copy_event = torch.cuda.Event()
+                self._copy_done = self._copy_event
+                self._copy_done.record(_current_stream())
+            if self.device.index is None or self.device.index == _current_device_index():
+                issue()
+            else:
+                with torch.cuda.device(self.device):
+                    issue()
         else:
             self.ring[a:a + first].copy_(self._stage[:first])
             if first < n:

@@ -27,3 +27,8 @@ def current_stream():
     if s is None:
         s = _stream_objects[key] = torch.cuda.current_stream()
     return s
+
+
+def current_device_index():
+    """torch.cuda.current_device(), as one C call."""
+    return _raw_current_device() if _raw_current_device is not None else torch.cuda.current_device()
