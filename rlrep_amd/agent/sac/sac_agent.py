@@ -15,7 +15,7 @@ from torch import nn
 
 from rlrep_amd.core import HipCore
 from rlrep_amd.utils import util
-from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream
+from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream, on_stream as _on_stream
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
@@ -834,7 +834,7 @@ class SACAgent(object):
             # caller's stream the write had to wait for the chain in flight: a barrier packet parked in the caller's queue for most of every
             # period, which taxes both chains' launches -- DESIGN.md 5.4; add() + train() in a loop: 2 650 -> 3 360 train()/s, tools/exp/add_train_loop.py.)
             e0 = getattr(buffer, 'device_epoch', None)
-            with torch.cuda.stream(P0['s_f']):
+            with _on_stream(P0['s_f']):
                 buffer.flush()
                 buffer.size_dev()
             cur_id = _raw_stream()
@@ -928,13 +928,13 @@ class SACAgent(object):
             P['seen'] = seen
         # (the critic / actor stream needs no wait of its own for the caller's stream: its chain starts behind the snapshot event, which the
         #  feature stream records after a chain that has just been ordered behind the caller's stream)
-        with torch.cuda.stream(s_f):
+        with _on_stream(s_f):
             if P['used'][k]:
                 self._wait_set_free(P, k, s_f)
             P['fs'][k].replay()
             P['ev_snap'][k].record(s_f)
             P['last_f'] = P['ev_snap'][k]
-        with torch.cuda.stream(s_ca):
+        with _on_stream(s_ca):
             s_ca.wait_event(P['ev_snap'][k])
             P['ca'][k].replay()
             P['ev_ca'][k].record(s_ca)
@@ -1035,12 +1035,12 @@ class SACAgent(object):
             else:
                 s_f.wait_event(P['ev_ca'][k])              # the pair that read this snapshot set last (train t-2); a stream wait here: the
                                                            # host, which issues 14 items per call in this form, must keep its run-ahead
-        with torch.cuda.stream(s_f):
+        with _on_stream(s_f):
             for kind, x in P['fs'][k]:
                 x.replay() if kind == 'graph' else x()
             P['ev_snap'][k].record(s_f)
         P['last_f'] = P['ev_snap'][k]
-        with torch.cuda.stream(s_ca):
+        with _on_stream(s_ca):
             s_ca.wait_event(P['ev_snap'][k])
             for kind, x in P['cs'][k]:
                 x.replay() if kind == 'graph' else x()

@@ -32,3 +32,22 @@ def current_stream():
 def current_device_index():
     """torch.cuda.current_device(), as one C call."""
     return _raw_current_device() if _raw_current_device is not None else torch.cuda.current_device()
+
+
+class on_stream:
+    """`with torch.cuda.stream(s):` for the per-call paths: the documented context manager resolves the device index twice on entry (~18 us of
+    host time; three of them sat in every pipelined train()).  Same effect -- torch's current stream is `s` inside the block and restored after it
+    -- through torch.cuda.set_stream and the cached current-stream lookup.  `s` must belong to the current device."""
+    __slots__ = ('s', 'prev')
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        self.prev = current_stream()
+        torch.cuda.set_stream(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
