@@ -514,6 +514,10 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_speder_rows(&sr, st); }, "speder rows (c, d, rhat)"});
         ColSum c2; memset(&c2, 0, sizeof(c2));
         c2.X = MU ? MU + BF : nullptr; c2.ldX = F; c2.w = C; c2.out = V; c2.rows = B; c2.F = F;
+        // theta.l's gradient (sum_i drhat_i phi_i and sum_i drhat_i over the first batch) is a weighted column sum too: it rides here instead of
+        // being a 16-row-engine launch of its own behind the weight-gradient launch (7 us per feature step)
+        const bool theta_here = !getenv("RLREP_NO_FOLD_THETA");
+        if (theta_here) { c2.X2 = PHI; c2.ldX2 = F; c2.w2 = DRH; c2.out2 = ag->G("theta.l.weight"); c2.outb2 = ag->G("theta.l.bias"); c2.rows2 = B; }
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c2, st); }, "v = sum_k c_k mu_r,k"});
         if (ag->h.world_size > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, V, (int64_t)F, 0});
         SpederGrads sg; memset(&sg, 0, sizeof(sg));
@@ -530,7 +534,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
             std::vector<GemmTask> t;
             for (int l = 0; l <= phi.depth; ++l) t.push_back(mlp_dw(ag, phi, pf, l, X2, SA));
             for (int l = 0; l <= mu.depth; ++l) t.push_back(mlp_dw(ag, mu, mf, l, S2, KE));
-            t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
+            if (!theta_here) t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
             // the split-K partials of these gradients (K = 2B rows) are summed by the optimizer launch below: no finishing launch in the step
             if (!getenv("RLREP_NO_FOLD_DWFIN")) b.fold_group = 0;
             b.dw_stage(p, t, "feature dW");

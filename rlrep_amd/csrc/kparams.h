@@ -220,7 +220,9 @@ struct InfoNce {
     const float* rhat; const float* r; float* drhat;
     float* partial; int B, nblk; float inv_batch; GroupCfg* step;
 };
-struct ColSum { const float* X; int ldX; const float* w; float* out; int rows, F; };
+// second set (X2 != nullptr; blockIdx.y == 1): another weighted column sum in the same launch, plus the sum of its weights (outb2) -- spedersac's
+// theta.l weight / bias gradient (sum_i drhat_i phi_i, sum_i drhat_i) rides with v = sum_k c_k mu_r,k instead of a launch of its own
+struct ColSum { const float* X; int ldX; const float* w; float* out; int rows, F; const float* X2; int ldX2; const float* w2; float* out2; float* outb2; int rows2; };
 struct SpederRows {
     const float* phi; const float* mu; const float* mu_r; const float* phibar;
     const float* theta_w; const float* theta_b; const float* r;

@@ -49,13 +49,18 @@ __global__ __launch_bounds__(256) void infonce_kernel(InfoNce p) {
 // 16 columns per workgroup, 64 row groups (16 waves x 4 row sub-groups): a [1024, 512] operand is spread over 32
 // workgroups x 16 waves with eight independent loads in flight per lane (the first version walked 256 rows per lane
 // as one dependent chain on 8 workgroups: 64 us of the 2.1 ms spedersac train(), 12 times).
-__global__ __launch_bounds__(1024) void colsum_kernel(ColSum p) {
+__global__ __launch_bounds__(1024) void colsum_kernel(ColSum q) {
     __shared__ float sh[64][17];
+    const bool second = blockIdx.y == 1;
+    // (the set this workgroup works on, as the one-set kernel's parameter block)
+    struct { const float* X; int ldX; const float* w; float* out; int rows, F; } p = {second ? q.X2 : q.X, second ? q.ldX2 : q.ldX, second ? q.w2 : q.w,
+                                                                                      second ? q.out2 : q.out, second ? q.rows2 : q.rows, q.F};
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 15, rg = w * 4 + (lane >> 4);
     const int f = blockIdx.x * 16 + c;
     const int fc = min(f, p.F - 1);
     const float* __restrict__ X = p.X + fc;
+    float wsum = 0.f;
     float acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.f;
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(ColSum p) {
             x[u] = X[(size_t)kc * p.ldX];
             wt[u] = p.w ? p.w[kc] : 1.f;
             if (k >= p.rows) wt[u] = 0.f;
+            wsum += wt[u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = fmaf(wt[u], x[u], acc[u]);
@@ -76,8 +82,19 @@ __global__ __launch_bounds__(1024) void colsum_kernel(ColSum p) {
     if (threadIdx.x < 16 && f < p.F) {
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 64; ++q) s += sh[q][threadIdx.x];
+        for (int r = 0; r < 64; ++r) s += sh[r][threadIdx.x];
         p.out[f] = s;
+    }
+    // the sum of the second set's weights (fixed order: the row groups of column 0 of workgroup 0, then across them)
+    if (second && q.outb2 && blockIdx.x == 0) {
+        __syncthreads();
+        if (c == 0) sh[rg][0] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int r = 0; r < 64; ++r) s += sh[r][0];
+            q.outb2[0] = s;
+        }
     }
 }
 
@@ -399,7 +416,7 @@ extern "C" int rl_launch_infonce(const InfoNce* p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_colsum(const ColSum* p, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((p->F + 15) / 16), dim3(1024), 0, st, *p);
+    hipLaunchKernelGGL(colsum_kernel, dim3((p->F + 15) / 16, p->X2 ? 2 : 1), dim3(1024), 0, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_speder_rows(const SpederRows* p, hipStream_t st) {

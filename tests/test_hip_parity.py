@@ -167,6 +167,15 @@ def test_hip_matches_oracle_fresh_seed(alg):
             assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, k
 
 
+@pytest.mark.parametrize('name', ['spedersac_tiny', 'spedersac_ant512'])
+def test_spedersac_theta_gradient_in_its_own_launch_matches_golden(name, monkeypatch):
+    """By default theta.l's gradient (sum_i drhat_i phi_i, sum_i drhat_i) rides in the weighted column-sum launch of the spectral loss
+    (colsum_kernel's second set); RLREP_NO_FOLD_THETA=1 keeps it a weight-gradient task of the 16-row engine.  The golden tests above run
+    the default; this runs the other form against the same reference fixtures."""
+    monkeypatch.setenv('RLREP_NO_FOLD_THETA', '1')
+    test_hip_matches_reference_golden(name)
+
+
 @pytest.mark.parametrize('alg,B', [('sac', 7), ('vlsac', 100), ('ctrlsac', 33), ('spedersac', 50), ('diffsrsac', 19)])
 def test_ragged_batch_sizes_match_oracle(alg, B):
     """Batch sizes that are not multiples of the 16-row MFMA tile (and a batch-size change on a live agent)
