@@ -230,9 +230,15 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         b.fwd_stage(p, {phi_fwd(2, nullptr, pf), Builder::fwd(M2, Hm, B, Hm, Pw("mu.l3.weight"), Hm, Pw("mu.l3.bias"), F, ZM, F, ACT_TANH)}, "phi.l3 mu.l3(tanh)");
         // quirk Q6: the score matrix is the GEMM phi mu'^T, not the [B,B,F] broadcast
         if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 1, ZMall, (int64_t)B * F, (int64_t)rank * B * F});
+        // rhat = theta . phi + b (a [B, 1] product) is computed by the InfoNCE launch itself: beside a score matrix that routes to the LDS-tiled engine it was a
+        // 16-row-engine launch of its own on the dependent chain (8 us per feature step at F = 2048); RLREP_NO_FOLD_THETA keeps it
+        const bool theta_in_loss = !getenv("RLREP_NO_FOLD_THETA");
+        if (theta_in_loss) b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE)}, "score matrix");
+        else
         b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE),
                         Builder::fwd(pf.Z, F, B, F, Pw("theta.l.weight"), F, Pw("theta.l.bias"), 1, RH, 1, ACT_NONE)}, "score matrix + theta");
         InfoNce nc; memset(&nc, 0, sizeof(nc));
+        if (theta_in_loss) { nc.Z = pf.Z; nc.ldZ = F; nc.F = F; nc.theta_w = Pw("theta.l.weight"); nc.theta_b = Pw("theta.l.bias"); }
         nc.S = Sx; nc.ldS = WB; nc.ncols = WB; nc.diag_off = rank * B; nc.rhat = RH; nc.r = s0.R; nc.drhat = DRH; nc.partial = part_f; nc.B = B; nc.nblk = nblk_f;
         nc.inv_batch = ag->inv_batch(); nc.step = ag->adam_step + 0;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_infonce(&nc, st); }, "infonce"});

@@ -29,7 +29,14 @@ __global__ __launch_bounds__(256) void infonce_kernel(InfoNce p) {
             const float sm = expf(row[j] - lse);
             row[j] = (sm - (j == di ? 1.f : 0.f)) * p.inv_batch;
         }
-        const float dr = p.rhat[i] - p.r[i];
+        float rh;
+        if (p.Z) {
+            const float* z = p.Z + (size_t)i * p.ldZ;
+            float s = 0.f;
+            for (int f = lane; f < p.F; f += 64) s = fmaf(z[f], p.theta_w[f], s);
+            rh = wave_sum(s) + p.theta_b[0];
+        } else rh = p.rhat[i];
+        const float dr = rh - p.r[i];
         if (lane == 0) p.drhat[i] = dr * p.inv_batch;
         accm += lse - sii;
         accr += dr * dr;

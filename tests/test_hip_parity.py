@@ -167,11 +167,14 @@ def test_hip_matches_oracle_fresh_seed(alg):
             assert rel_l2(st[k].numpy(), P[k].numpy()) < 1e-4, k
 
 
-@pytest.mark.parametrize('name', ['spedersac_tiny', 'spedersac_ant512'])
-def test_spedersac_theta_gradient_in_its_own_launch_matches_golden(name, monkeypatch):
-    """By default theta.l's gradient (sum_i drhat_i phi_i, sum_i drhat_i) rides in the weighted column-sum launch of the spectral loss
-    (colsum_kernel's second set); RLREP_NO_FOLD_THETA=1 keeps it a weight-gradient task of the 16-row engine.  The golden tests above run
-    the default; this runs the other form against the same reference fixtures."""
+@pytest.mark.parametrize('name', ['spedersac_tiny', 'spedersac_ant512', 'ctrlsac_tiny', 'ctrlsac_hc2048'])
+def test_theta_head_in_its_own_launches_matches_golden(name, monkeypatch):
+    """By default the reward head theta rides in the loss launches: spedersac's gradient of theta.l (sum_i drhat_i phi_i, sum_i drhat_i) in the
+    weighted column-sum launch of the spectral loss (colsum_kernel's second set), ctrlsac's rhat = theta . phi + b in the InfoNCE launch.
+    RLREP_NO_FOLD_THETA=1 keeps them tasks of the 16-row engine (a launch of their own when the neighbouring GEMMs route to the LDS-tiled engine).
+    The golden tests above run the default; this runs the other form against the same reference fixtures."""
+    if name not in cases():
+        pytest.skip('fixture not present')
     monkeypatch.setenv('RLREP_NO_FOLD_THETA', '1')
     test_hip_matches_reference_golden(name)
 

@@ -1,5 +1,3 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -k "speder" > gpurun_out/sel_tests.log 2>&1 || { tail -n 30 gpurun_out/sel_tests.log; exit 1; }
-tail -n 2 gpurun_out/sel_tests.log
-bash tools/_ab_env.sh spedersac_ant_f512_b1024 600 "-" "RLREP_NO_FOLD_THETA=1"
+python3 bench.py --workload ctrlsac_halfcheetah_f2048_b256 --steps 300 --warmup 50 --no-cpu 2>/dev/null | tail -n 1 > gpurun_out/ctrl_now.json
