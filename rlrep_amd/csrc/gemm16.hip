@@ -164,6 +164,65 @@ __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float*
     gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, 4>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
+// ... and the single-task launches of the fused short product's dX form (FLAG_PRE; the vlsac decoder launch with its mse phase, the policy's
+// last backward pair): one task's operands PLUS the short product's (X, Wt, M) fit the 14 scalars -- base, A / B / X / Wt / M offsets,
+// lda | ldb << 16, K | R << 16, Cn | K1 << 16, ldx | ldw << 16, ldm; hdr = low_prio | log2(column tiles) << 8.
+template <int EPI_K, int ACT_K, bool MSE>
+__global__ __launch_bounds__(256) void gemm16_fastpre_kernel(int hdr, const float* base, unsigned ao, unsigned bo, unsigned ld, unsigned kr, unsigned ck, unsigned xo, unsigned wo, unsigned mo,
+                                                             unsigned ldxw, unsigned ldm, GemmBatch gb) {
+    __shared__ float red[4][1][4][64];
+    __shared__ float bsum[4][16];
+#ifdef RL_TIMING
+    unsigned long long tim_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_w0 = 0; unsigned tim_lid = 0;
+    if (threadIdx.x == 0) { tim_lid = *(volatile unsigned*)&g_tim_launch; if (TIM_ON) tim_w0 = wall_clock64(); }
+#endif
+    TIM(0);
+    if (!(hdr & 1)) __builtin_amdgcn_s_setprio(3);
+    const int bid = blockIdx.x, sh = hdr >> 8;
+    const int tr = bid >> sh, tc = bid & ((1 << sh) - 1);
+    FastOps fo;
+    fo.pA = base + (size_t)ao; fo.pB = base + (size_t)bo; fo.lda = (int)(ld & 0xffffu); fo.ldb = (int)(ld >> 16);
+    fo.K = (int)(kr & 0xffffu); fo.R = (int)(kr >> 16); fo.Cn = (int)(ck & 0xffffu); fo.tiles_c = 1 << sh;
+    fo.X = base + (size_t)xo; fo.Wt = base + (size_t)wo; fo.M = base + (size_t)mo; fo.K1 = (int)(ck >> 16);
+    fo.ldx = (int)(ldxw & 0xffffu); fo.ldw = (int)(ldxw >> 16); fo.ldm = (int)ldm;
+    const GemmTask& t = gb.t[0];
+#ifdef RL_TIMING
+    asm volatile("" :: "s"(tr), "s"(tc));
+    TIM(7);
+    gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);
+    TIM_FIN();
+#else
+    gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4>(t, tr, tc, red, bsum, nullptr, &fo);
+#endif
+}
+struct FastPreArgs { int hdr; const float* base; unsigned ao, bo, ld, kr, ck, xo, wo, mo, ldxw, ldm; };
+static bool fastpre_args(const GemmBatch& gb, FastPreArgs& fa) {
+    if (gb.ntasks != 1 || getenv("RLREP_GEMM16_NO_FAST")) return false;
+    const GemmTask& t = gb.t[0];
+    if (!(t.flags & FLAG_PRE) || (t.flags & FLAG_PRE_FWD) || !t.x0 || !t.x1 || !t.x2 || t.tile_base != 0) return false;
+    const int tcn = t.tiles_c;
+    if (t.K <= 0 || (t.K & 255) || t.K > 0xffff || t.R > 0xffff || t.Cn > 0xffff || t.lda > 0xffff || t.ldb > 0xffff || t.n0 <= 0 || t.n0 > 32 || t.ldx0 > 0xffff || t.ldx1 > 0xffff ||
+        t.ldaux2 < 0 || tcn <= 0 || (tcn & (tcn - 1))) return false;
+    const void* ptrs[5] = {t.A, t.B, t.x0, t.x1, t.x2};
+    uintptr_t lo = ~(uintptr_t)0;
+    for (const void* q : ptrs) lo = std::min(lo, (uintptr_t)q);
+    lo &= ~(uintptr_t)15;
+    unsigned off[5];
+    for (int q = 0; q < 5; ++q) {
+        const uintptr_t d = (uintptr_t)ptrs[q] - lo;
+        if ((d & 3) || (d >> 2) > 0xffffffffull) return false;
+        off[q] = (unsigned)(d >> 2);
+    }
+    int sh = 0; while ((1 << sh) < tcn) ++sh;
+    fa.hdr = (gb.low_prio ? 1 : 0) | (sh << 8); fa.base = reinterpret_cast<const float*>(lo);
+    fa.ao = off[0]; fa.bo = off[1]; fa.xo = off[2]; fa.wo = off[3]; fa.mo = off[4];
+    fa.ld = (unsigned)t.lda | ((unsigned)t.ldb << 16); fa.kr = (unsigned)t.K | ((unsigned)t.R << 16); fa.ck = (unsigned)t.Cn | ((unsigned)t.n0 << 16);
+    fa.ldxw = (unsigned)t.ldx0 | ((unsigned)t.ldx1 << 16); fa.ldm = (unsigned)t.ldaux2;
+    return true;
+}
+#define G16_FASTPRE_ARGS(F, B) (F).hdr, (F).base, (F).ao, (F).bo, (F).ld, (F).kr, (F).ck, (F).xo, (F).wo, (F).mo, (F).ldxw, (F).ldm, (B)
+
 // host side of the above: the 13 argument values, or false when the launch does not qualify
 struct FastArgs { int hdr, tb1; const float* base; unsigned a[2], b[2], ld[2], kr[2], ct[2]; };
 // short = false: every K a multiple of 256; short = true: every K <= 64 (the FAST = 1 instantiations)
@@ -369,6 +428,8 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         const bool pre = gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE), vecA = all_vec(*gb, false), vecB = all_vec(*gb, true);
         const bool vec_ok = la == LD_ROW && vecA && (lb == LD_COL || vecB), nf_ok = nf == 1 || nf == 2;
         const char* front = "record";
+        FastPreArgs fpt;
+        if (pre && la == LD_ROW && lb == LD_COL && nf == 1 && !getenv("RLREP_GEMM16_GENERIC") && fastpre_args(*gb, fpt)) front = "fast (fused short product)";
         if (!pre && la == LD_ROW && nf_ok && !getenv("RLREP_GEMM16_GENERIC")) {
             if (lb == LD_ROW && (vecA == vecB) && fast_args(*gb, fa, true) && gb->t[0].epi == EPI_FWD) front = "fast (K <= 64)";
             else if (vec_ok && fast_args(*gb, fa)) front = "fast";
@@ -403,11 +464,20 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
             // FLAG_PRE_MSE (vlsac decoder: the heads + mse launch rides here): one task, reparameterisation epilogue, 16-byte-aligned M / Wt rows
             bool mse = false;
             for (int q = 0; q < gb->ntasks; ++q) mse = mse || (gb->t[q].flags & FLAG_PRE_MSE);
+            FastPreArgs fp;
+            const bool fastpre = (rep || plain || elu) && fastpre_args(*gb, fp);          // one task, K % 256 == 0: the front end that loads from preloaded scalars
             if (mse) {
                 const GemmTask& m0 = gb->t[0];
                 if (gb->ntasks != 1 || !rep || (m0.ldaux2 & 3) || (m0.ldx1 & 3) || (m0.K & 3) || ((((uintptr_t)m0.x2) | ((uintptr_t)m0.x1)) & 15) || !m0.bias || !m0.tgs || !m0.tgr || !m0.mse_part || !m0.x0)
                     return -3;
-                hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
+                if (fastpre) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX_REPARAM, ACT_NONE, true>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
+                else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
+                return (int)hipGetLastError();
+            }
+            if (fastpre) {
+                if (elu) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_ELU, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
+                else if (rep) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX_REPARAM, ACT_NONE, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
+                else hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_NONE, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
                 return (int)hipGetLastError();
             }
             if (elu) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(*gb));

@@ -111,13 +111,20 @@ struct PreSrc { const float* X; int ldx; const float* Wt; int ldw; int K1; const
 // XS (FLAG_PRE_MSE): the row operand X of the short product sits in LDS ([16][RL_XS_LD] floats, written by this tile's first phase) instead of memory
 #define RL_XS_LD 36
 // the global operands of one mac_group_pre block (everything but the row operand X): loaded by pre_load, consumed by mac_group_pre<.., PL = true>
-template <int NU, int NJ, int NF> struct PreRegs { float wf[NU][NJ][4], mk[NU][4], b[NU][NF][4]; };
+template <int NU, int NJ, int NF> struct PreRegs { float wf[NU][NJ][4], mk[NU][4], b[NU][NF][4], xf[NJ][4]; };
 template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false, bool XLDS = false>
 __device__ __forceinline__ void pre_load(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
                                          int i, int kq, int kb, int K, PreRegs<NU, NJ, NF>& pr) {
     const int K1 = ps.K1;
     // dX form: M = the saved ReLU output of this launch's forward half (row of the minibatch); forward form: M = the layer's bias (ldm = 0)
     const size_t mrow = (size_t)min(r0 + i, R - 1) * ps.ldm;
+    if constexpr (!XLDS) {          // the row operand X of the short product (from LDS in the mse form: read where it is consumed)
+        const size_t xrow = (size_t)min(r0 + i, R - 1) * ps.ldx;
+#pragma unroll
+        for (int jc = 0; jc < NJ; ++jc)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) pr.xf[jc][m] = rl_ld<COH>(ps.X, xrow + min(16 * jc + 4 * kq + m, K1 - 1));
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int kcol = min(kb + 64 * u + i, K - 1);
@@ -141,17 +148,17 @@ template <int LB, int NF, bool VB, int NU, int NJ, bool FWD, bool COH = false, b
 __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __restrict__ B, int ldb, int r0, int R, int c0, int Cn,
                                               int i, int kq, int kb, int K, bool store, bool elu, f32x4 (&acc)[NF], const float* xs = nullptr,
                                               PreRegs<NU, NJ, NF>* pl = nullptr) {
-    float xf[NJ][4];
     PreRegs<NU, NJ, NF> own;
     const int K1 = ps.K1;
-    const size_t xrow = (size_t)min(r0 + i, R - 1) * ps.ldx;
-#pragma unroll
-    for (int jc = 0; jc < NJ; ++jc)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xf[jc][m] = XLDS ? xs[i * RL_XS_LD + 16 * jc + 4 * kq + m] : rl_ld<COH>(ps.X, xrow + min(16 * jc + 4 * kq + m, K1 - 1));
     if constexpr (!PL) pre_load<LB, NF, VB, NU, NJ, FWD, COH, XLDS>(ps, B, ldb, r0, R, c0, Cn, i, kq, kb, K, own);
     PreRegs<NU, NJ, NF>& pr = PL ? *pl : own;
-    float (&wf)[NU][NJ][4] = pr.wf; float (&mk)[NU][4] = pr.mk; float (&b)[NU][NF][4] = pr.b;
+    float (&wf)[NU][NJ][4] = pr.wf; float (&mk)[NU][4] = pr.mk; float (&b)[NU][NF][4] = pr.b; float (&xf)[NJ][4] = pr.xf;
+    if constexpr (XLDS) {
+#pragma unroll
+        for (int jc = 0; jc < NJ; ++jc)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xf[jc][m] = xs[i * RL_XS_LD + 16 * jc + 4 * kq + m];
+    }
     __builtin_amdgcn_sched_barrier(0);
     // zero what the clamped loads fetched beyond K1 (inner index); rows beyond R / k beyond K are masked when A is formed
 #pragma unroll
@@ -220,12 +227,15 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 // the record, and the first block's loads are issued BEFORE the record is waited for: the record's scalar-load round trip (~900 cycles, needed by
 // the epilogue only) runs under the operand loads instead of in front of them.  FAST = 4: K is a multiple of 256 (blocks of four 16-deep chunks
 // per wave); FAST = 1: K <= 64 (the first layers: one chunk per wave is all there is).
-struct FastOps { const float* pA; const float* pB; int lda, ldb, K, R, Cn, tiles_c; };
+struct FastOps { const float* pA; const float* pB; int lda, ldb, K, R, Cn, tiles_c;
+                 const float* X; const float* Wt; const float* M; int ldx, ldw, K1, ldm; };       // (X .. ldm: the fused short product's operands, gemm16_fastpre_kernel)
 template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false, bool MSE = false,
           int FAST = 0>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
                                             const float* const* dyn RL_TIM_PARAM, const FastOps* fo = nullptr) {
-    static_assert(!FAST || (!PRE && !COH && !GATHER && !MSE), "FAST: plain forward / dX tiles only");
+    static_assert(!FAST || (!COH && !GATHER && (PRE || !MSE) && (!PRE || (FAST == 4 && LA == LD_ROW && LB == LD_COL && NF == 1))), "FAST: plain forward / dX tiles, or the dX form of the fused short product");
+    constexpr int NJ = (LB == LD_ROW) ? 3 : 2;          // fused short product: forward form (LB = LD_ROW) K1 <= 48, dX form K1 <= 32
+    constexpr bool FW = (LB == LD_ROW);
     // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
     const float* const pA = FAST ? fo->pA : t.A; const float* const pB = FAST ? fo->pB : t.B; float* const pC = t.C; const float* const pbias = t.bias;
     const int lda = FAST ? fo->lda : t.lda, ldb = FAST ? fo->ldb : t.ldb, ldc = t.ldc;
@@ -244,7 +254,27 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
     }
     // FAST: the first 256-deep block's operand loads go out now, from preloaded scalars (the reads of the record above are in flight)
     float fa[FAST ? FAST : 1][4], fb[FAST ? FAST : 1][NF][4];
-    if constexpr (FAST) {
+    // the first block of the fused short product's global operands (and, mse form, of the first phase's product): loaded by the mse phase (which
+    // requests them behind its own operands) or, FAST, right here from preloaded scalars
+    PreRegs<4, NJ, NF> mse_pl;
+    float a1[PRE && MSE ? 4 : 1][4], b1[PRE && MSE ? 4 : 1][2][4];
+    if constexpr (FAST && PRE) {
+        const int lane_ = threadIdx.x & 63, w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int i_ = lane_ & 15, kq_ = lane_ >> 4;
+        PreSrc pf; pf.X = fo->X; pf.ldx = fo->ldx; pf.Wt = fo->Wt; pf.ldw = fo->ldw; pf.K1 = fo->K1; pf.M = fo->M; pf.ldm = fo->ldm; pf.out = nullptr; pf.ldo = 0; pf.st_lo = pf.st_hi = 0;
+        if constexpr (MSE) {
+            const int k0_ = w_ * 16 + 4 * kq_;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                load_raw<LD_ROW, true>(pf.M, pf.ldm, tr * 16, R, i_, k0_ + 64 * u, K, a1[u]);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) load_raw<LD_ROW, true>(pf.Wt, pf.ldw, 16 * f, pf.K1, i_, k0_ + 64 * u, K, b1[u][f]);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // (the first phase's operands FIRST: the load counter retires in order)
+        }
+        pre_load<LB, NF, VB, 4, NJ, FW, false, MSE>(pf, pB, ldb, tr * 16, R, tc * 16 * NF, Cn, i_, kq_, w_ * 16, K, mse_pl);
+        TIMB(5);
+    } else if constexpr (FAST) {
         const int lane_ = threadIdx.x & 63, w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int i_ = lane_ & 15, k_ = w_ * 16 + 4 * (lane_ >> 4);
 #pragma unroll
@@ -340,17 +370,16 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
 
     // wave w owns the 16-wide inner chunks w, w+4, w+8, ...
     if constexpr (PRE) {
-        PreSrc ps; ps.X = t.x0; ps.ldx = t.ldx0; ps.Wt = t.x1; ps.ldw = t.ldx1; ps.K1 = n0; ps.M = t.x2; ps.ldm = t.ldaux2; ps.out = t.y0; ps.ldo = t.ldout2;
+        PreSrc ps;
+        if constexpr (FAST) { ps.X = fo->X; ps.ldx = fo->ldx; ps.Wt = fo->Wt; ps.ldw = fo->ldw; ps.K1 = fo->K1; ps.M = fo->M; ps.ldm = fo->ldm; }
+        else { ps.X = t.x0; ps.ldx = t.ldx0; ps.Wt = t.x1; ps.ldw = t.ldx1; ps.K1 = n0; ps.M = t.x2; ps.ldm = t.ldaux2; }
+        ps.out = t.y0; ps.ldo = t.ldout2;
         // who stores the recomputed layer: one 16-wide chunk per column tile when there are enough tiles, else column tile 0 everything
         const bool spread = tiles_c * 16 >= K;
         const bool store = ps.out && (spread || tc == 0);
         ps.st_lo = spread ? tc * 16 : 0; ps.st_hi = spread ? tc * 16 + 16 : K;
         const bool pre_elu = (flags & FLAG_PRE_ELU) != 0;
-        // forward form (LB = LD_ROW): K1 <= 48, bias + ReLU; dX form (LB = LD_COL): K1 <= 32, ReLU mask
-        constexpr int NJ = (LB == LD_ROW) ? 3 : 2;
-        constexpr bool FW = (LB == LD_ROW);
         const float* xs = nullptr;
-        PreRegs<4, NJ, NF> mse_pl;
         if constexpr (MSE) {
             // ---- first phase: X = dmse( M Wt^T + bias ; targets ) for this tile's 16 rows, K1 <= 32 columns (FLAG_PRE_MSE) ----
             // P[16 x 32] over the inner dimension K, split over the four waves as in the main loop (16-byte loads: the launcher checks alignment)
@@ -367,20 +396,22 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
                 ptgt_[f] = *tp;
             }
             // this wave's FIRST block of the product (four 16-deep chunks; what lies beyond K is clamped and masked, so any K is handled) ...
-            float a1[4][4], b1[4][2][4];
             {
                 const int k0 = w * 16 + 4 * kq;
+                if constexpr (!FAST) {          // (FAST: these loads and the prefetch below went out at the top of the tile)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     load_raw<LD_ROW, true, COH>(ps.M, ps.ldm, r0, R, i, k0 + 64 * u, K, a1[u]);
 #pragma unroll
                     for (int f = 0; f < 2; ++f) load_raw<LD_ROW, true>(ps.Wt, ps.ldw, 16 * f, ps.K1, i, k0 + 64 * u, K, b1[u][f]);
                 }
+                __builtin_amdgcn_sched_barrier(0);      // (the first phase's operands FIRST: the load counter retires in order)
+                }
                 // ... and BEHIND them the SECOND phase's global operands of the same block (weights of both products, the ReLU mask): none of
                 // them depends on the first phase, and a launch's first touch of anything costs a trip beyond the XCD's L2 (~1 us) -- one such
                 // trip instead of two.  Unconditional (clamped addresses); used below only if the block is a full one (K >= 256).  Issued AFTER
                 // the first phase's loads: the load counter retires in order, so the product below waits for its own operands only.
-                pre_load<LB, NF, VB, 4, NJ, FW, COH, true>(ps, pB, ldb, r0, R, c0, Cn, i, kq, w * 16, K, mse_pl);
+                if constexpr (!FAST) pre_load<LB, NF, VB, 4, NJ, FW, COH, true>(ps, pB, ldb, r0, R, c0, Cn, i, kq, w * 16, K, mse_pl);
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -443,7 +474,7 @@ __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const 
         }
         for (int kb = w * 16; kb < K; kb += 256) {
             const int nu = (K - kb + 63) >> 6;
-            if (MSE && nu >= 4 && kb == w * 16) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE, true>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs, &mse_pl);
+            if ((MSE || FAST) && nu >= 4 && kb == w * 16) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE, true>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs, &mse_pl);
             else if (nu >= 4) mac_group_pre<LB, NF, VB, 4, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
             else if (nu == 1) mac_group_pre<LB, NF, VB, 1, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
             else if (nu == 2) mac_group_pre<LB, NF, VB, 2, NJ, FW, COH, MSE>(ps, pB, ldb, r0, R, c0, Cn, i, kq, kb, K, store, pre_elu, acc, xs);
