@@ -245,8 +245,8 @@ def cpu_baseline(alg, S, A, B, kw, data, threads, budget_s=6.0):
 # name -> (engine ids, bound, peak, unit, regex over rocprofv3 kernel names: which rows of profiles/*_kernel_stats.csv / *_pmc_*.json belong to it)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 measured)
 FAMILIES = {
-    'gemm16': ((1, 2), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm16_kernel|gemm16_fast_kernel|gemm16_fast4_kernel|gemm16_duo_kernel|heads_vae_kernel)',
-               'gemm16_kernel + gemm16_fast_kernel + gemm16_fast4_kernel + gemm16_duo_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'),
+    'gemm16': ((1, 2), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm16_kernel|gemm16_fast\w*_kernel|gemm16_duo_kernel|heads_vae_kernel)',
+               'gemm16_kernel + gemm16_fast_kernel / gemm16_fast4_kernel / gemm16_fastpre_kernel + gemm16_duo_kernel + heads_vae_kernel (16-row fp32-MFMA tiles: every 256-wide layer forward / dX / dW; the Gaussian heads with vae_mid)'),
     'gemm_lds64': ((3,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm_lds_kernel<64|gemm_lds_fin_kernel)',
                    'gemm_lds_kernel<64,...> + gemm_lds_fin_kernel (64-wide LDS tiles on fp32 MFMA, split-K slabs + finishing blocks)'),
     'gemm_lds128': ((4,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^gemm_lds_kernel<128', 'gemm_lds_kernel<128,...> (128-wide LDS tiles on fp32 MFMA)'),
