@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm16_fast_kernel(int hdr, int tb1, cons
 }
 // ... and the launches of up to FOUR tasks of ONE shape (the same layer of sibling networks: f_target on three inputs, the policy beside them): the
 // shape words once, then the A / B offsets of every task; hdr = low_prio | tiles per task << 8.
-template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K>
+template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K, int FU = 4>
 __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float* base, unsigned ld, unsigned kr, unsigned ct, unsigned a0, unsigned b0, unsigned a1, unsigned b1,
                                                            unsigned a2, unsigned b2, unsigned a3, unsigned b3, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
@@ -157,11 +157,11 @@ __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float*
 #ifdef RL_TIMING
     asm volatile("" :: "s"(tr), "s"(tc));
     TIM(7);
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, 4>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, FU>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
     float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);       // (tag bit 3: a fast-front-end launch)
     TIM_FIN();
 #else
-    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, 4>(t, tr, tc, red, bsum, nullptr, &fo);
+    gemm16_tile<LA, LB, NF, VA, VB, false, false, GemmTask, EPI_K, ACT_K, false, false, FU>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
 // ... and the single-task launches of the fused short product's dX form (FLAG_PRE; the vlsac decoder launch with its mse phase, the policy's
@@ -246,14 +246,14 @@ static bool fast_args(const GemmBatch& gb, FastArgs& fa, bool short_k = false) {
     return true;
 }
 struct Fast4Args { int hdr; const float* base; unsigned ld, kr, ct, a[4], b[4]; };
-static bool fast4_args(const GemmBatch& gb, Fast4Args& fa) {
+static bool fast4_args(const GemmBatch& gb, Fast4Args& fa, bool short_k = false) {
     if (gb.ntasks < 3 || gb.ntasks > 4 || getenv("RLREP_GEMM16_NO_FAST")) return false;
     const GemmTask& t0 = gb.t[0];
     uintptr_t lo = ~(uintptr_t)0;
     for (int q = 0; q < gb.ntasks; ++q) { lo = std::min(lo, (uintptr_t)gb.t[q].A); lo = std::min(lo, (uintptr_t)gb.t[q].B); }
     lo &= ~(uintptr_t)15;
     const int tcn = t0.tiles_c, nt = t0.ntiles;
-    if (t0.K <= 0 || (t0.K & 255) || t0.K > 0xffff || t0.R > 0xffff || t0.Cn > 0xffff || t0.lda > 0xffff || t0.ldb > 0xffff || tcn <= 0 || (tcn & (tcn - 1)) || nt <= 0 || nt >= (1 << 22)) return false;
+    if (t0.K <= 0 || (short_k ? t0.K > 64 : (t0.K & 255) != 0) || t0.K > 0xffff || t0.R > 0xffff || t0.Cn > 0xffff || t0.lda > 0xffff || t0.ldb > 0xffff || tcn <= 0 || (tcn & (tcn - 1)) || nt <= 0 || nt >= (1 << 22)) return false;
     int sh = 0; while ((1 << sh) < tcn) ++sh;
     fa.hdr = (gb.low_prio ? 1 : 0) | (nt << 8); fa.base = reinterpret_cast<const float*>(lo);
     fa.ld = (unsigned)t0.lda | ((unsigned)t0.ldb << 16); fa.kr = (unsigned)t0.K | ((unsigned)t0.R << 16); fa.ct = (unsigned)t0.Cn | ((unsigned)sh << 16);
@@ -329,10 +329,10 @@ static bool launch_fast(dim3 g, hipStream_t st, const GemmBatch& gb) {
 // ... and the first layers (K <= 64, forward form, rows of 17 / 23 / 40 floats: with or without 16-byte operand loads)
 template <int LA, int LB, int NF, bool VA, bool VB, int ACT_K>
 static bool launch_fast_short(dim3 g, hipStream_t st, const GemmBatch& gb) {
-    FastArgs fa;
-    if (!fast_args(gb, fa, true)) return false;
-    hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb));
-    return true;
+    FastArgs fa; Fast4Args f4;
+    if (fast_args(gb, fa, true)) { hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb)); return true; }
+    if (fast4_args(gb, f4, true)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); return true; }
+    return false;
 }
 // NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
 // instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
@@ -431,7 +431,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
         FastPreArgs fpt;
         if (pre && la == LD_ROW && lb == LD_COL && nf == 1 && !getenv("RLREP_GEMM16_GENERIC") && fastpre_args(*gb, fpt)) front = "fast (fused short product)";
         if (!pre && la == LD_ROW && nf_ok && !getenv("RLREP_GEMM16_GENERIC")) {
-            if (lb == LD_ROW && (vecA == vecB) && fast_args(*gb, fa, true) && gb->t[0].epi == EPI_FWD) front = "fast (K <= 64)";
+            if (lb == LD_ROW && (vecA == vecB) && (fast_args(*gb, fa, true) || fast4_args(*gb, f4, true)) && gb->t[0].epi == EPI_FWD) front = "fast (K <= 64)";
             else if (vec_ok && fast_args(*gb, fa)) front = "fast";
             else if (vec_ok && fast4_args(*gb, f4)) front = "fast4";
         }
