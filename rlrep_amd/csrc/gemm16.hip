@@ -391,6 +391,10 @@ static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
         else return false;
         return true;
     }
+    if (NF == 1 && LB == LD_COL && epi == EPI_DX_POLICYBWD) {  // the policy's backward (same epilogue instantiation as on the fast front end)
+        hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, EPI_DX_POLICYBWD, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
+        return true;
+    }
     if (NF == 1 && LB == LD_ROW && epi == EPI_FWD_MSE) {       // vlsac decoder heads + mse
         hipLaunchKernelGGL((gemm16_kernel<LA, LB, 1, VA, VB, false, EPI_FWD_MSE, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(gb));
         return true;

@@ -359,6 +359,34 @@ def test_chained_feature_steps_change_nothing(monkeypatch):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+def test_fast_front_end_changes_nothing(monkeypatch):
+    """gemm16_fast_kernel / gemm16_fast4_kernel / gemm16_fastpre_kernel (operand loads issued from preloaded scalars, the record's loads under them)
+    run the same tile body in the same order: against RLREP_GEMM16_NO_FAST=1 (every launch fetches its record first) parameters, moments and
+    targets are BIT-identical after 20 pipelined train() calls at the headline dims."""
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
+    data = synth.replay(17, 6, 8192, seed=0)
+    outs = []
+    for fast in (True, False):
+        if not fast:
+            monkeypatch.setenv('RLREP_GEMM16_NO_FAST', '1')
+        torch.manual_seed(0)
+        agent = VLSACAgent(state_dim=17, action_dim=6, action_space=_Space(6, 1.0), max_batch=256, pipeline=True, seed=78,
+                           hidden_dim=256, feature_dim=256, extra_feature_steps=3)
+        buf = ReplayBuffer(17, 6, max_size=8192)
+        buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+        for _ in range(20):
+            agent.train(buf, 256)
+        agent.flush()
+        st = {k: v.numpy().copy() for k, v in agent.core.state().items()}
+        st['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy(); st['exp_avg_sq'] = agent.core.exp_avg_sq.cpu().numpy().copy()
+        outs.append(st)
+        del agent, buf
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 def test_noise_critic_weight_images_follow_external_parameter_writes():
     """vlsac at the headline dims runs its noise critic from bf16x3 images of critic.l1 / l4 and of their target copies (ShadowEnt kind 1).
     The live images are kept by the critic group's Adam launch and ALL of them are regenerated at the head of every critic step: parameters
