@@ -213,6 +213,71 @@ __global__ __launch_bounds__(256) void diffsr_score_kernel(DiffsrScore p) {
     }
 }
 
+// Small state dimensions (S <= 32: HalfCheetah 17, Hopper 11, Walker 17, Ant 27): a THREAD per row z of U[b] -- its S values are one contiguous
+// run (a wave reads 64 consecutive rows: fully coalesced) and stay in registers between the two phases, so U is read once; score_s is reduced over
+// the rows with S wave reductions and a fixed-order sum over the waves, and dphi_z = sum_s dscore_s U[z,s] needs no reduction at all.  (The
+// lanes-over-s kernel above keeps 17 of 64 lanes busy and walks the rows as a dependent chain: 31 us per launch at HalfCheetah dims, 4 launches
+// per train().)  NR rows per thread: F <= 256 * NR.
+template <int NR>
+__global__ __launch_bounds__(256) void diffsr_score_small_kernel(DiffsrScore p) {
+    constexpr int SM = 32;
+    __shared__ float part[4][SM];
+    __shared__ float dsc[SM];
+    __shared__ float shl[4];
+    const int b = blockIdx.x, S = p.S, F = p.F;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* U = p.U + (size_t)b * F * S;
+    const float* phi = p.PHI + (size_t)b * F;
+    float u[NR][SM], pz[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int z = threadIdx.x + 256 * j, zc = min(z, F - 1);
+        pz[j] = z < F ? phi[zc] : 0.f;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) u[j][s] = U[(size_t)zc * S + min(s, S - 1)];
+    }
+    // phase 1: score_s = sum_z phi_z U[z, s]
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        if (s < S) {            // (uniform; no `break`: the loop must unroll fully, u[][] are registers)
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) a = fmaf(pz[j], u[j][s], a);
+            a = wave_sum(a);
+            if (lane == 0) part[w][s] = a;
+        }
+    }
+    __syncthreads();
+    const float ab = p.alphabars[p.idx[b]];
+    const float coef = (1.0f - ab) * p.sigma;
+    float l = 0.f;
+    if ((int)threadIdx.x < S) {
+        const int s = threadIdx.x;
+        const float score = ((part[0][s] + part[1][s]) + part[2][s]) + part[3][s];
+        const float diff = p.TGT[(size_t)b * S + s] - coef * score;
+        l = diff * diff;
+        dsc[s] = -2.f * coef * diff * p.inv_batch;
+    }
+    const float lb = block_sum_256(l, shl);
+    if (threadIdx.x == 0) p.partial[b] = lb;
+    __syncthreads();
+    // phase 2: dphi_z = sum_s dscore_s U[z, s];  U <- dU = phi_z dscore_s
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int z = threadIdx.x + 256 * j;
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            if (s < S && z < F) {
+                const float d = dsc[s];
+                a = fmaf(d, u[j][s], a);
+                U[(size_t)z * S + s] = pz[j] * d;
+            }
+        }
+        if (z < F) p.GPHI[(size_t)b * F + z] = a;
+    }
+}
+
 // The same with 16-byte accesses (S % 4 == 0, e.g. Humanoid's 376): a wave walks a row of U as 16-byte lanes (two per
 // lane up to S = 512), four rows in flight per wave; 583 -> us at Humanoid dims, where this kernel moves 2.4 GB per call.
 __global__ __launch_bounds__(256) void diffsr_score_vec_kernel(DiffsrScore p) {
@@ -459,6 +524,11 @@ extern "C" int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st) {
         if (ch == 128) hipLaunchKernelGGL(diffsr_score_lds_kernel<128>, dim3(p->B), dim3(256), ds_lds<128>(p->F), st, *p);
         else if (ch == 64) hipLaunchKernelGGL(diffsr_score_lds_kernel<64>, dim3(p->B), dim3(256), ds_lds<64>(p->F), st, *p);
         else hipLaunchKernelGGL(diffsr_score_lds_kernel<32>, dim3(p->B), dim3(256), ds_lds<32>(p->F), st, *p);
+    }
+    else if (p->S <= 32 && p->F <= 1024 && !getenv("RLREP_SCORE_NO_SMALL")) {
+        if (p->F <= 256) hipLaunchKernelGGL(diffsr_score_small_kernel<1>, dim3(p->B), dim3(256), 0, st, *p);
+        else if (p->F <= 512) hipLaunchKernelGGL(diffsr_score_small_kernel<2>, dim3(p->B), dim3(256), 0, st, *p);
+        else hipLaunchKernelGGL(diffsr_score_small_kernel<4>, dim3(p->B), dim3(256), 0, st, *p);
     }
     else if ((p->S & 3) == 0 && p->S <= 512 && ((((uintptr_t)p->U) & 15) == 0))
         hipLaunchKernelGGL(diffsr_score_vec_kernel, dim3(p->B), dim3(256), (size_t)5 * p->S * sizeof(float), st, *p);

@@ -179,6 +179,16 @@ def test_theta_head_in_its_own_launches_matches_golden(name, monkeypatch):
     test_hip_matches_reference_golden(name)
 
 
+@pytest.mark.parametrize('name', ['diffsrsac_tiny', 'diffsrsac_hc'])
+def test_diffsrsac_score_kernel_for_wide_states_matches_golden_at_small_ones(name, monkeypatch):
+    """State dimensions of up to 32 take diffsr_score_small_kernel (a thread per row of U[b], one read of U); RLREP_SCORE_NO_SMALL=1 sends them
+    through the lanes-over-s kernel that wider, non-multiple-of-four state dimensions use: same fixtures."""
+    if name not in cases():
+        pytest.skip('fixture not present')
+    monkeypatch.setenv('RLREP_SCORE_NO_SMALL', '1')
+    test_hip_matches_reference_golden(name)
+
+
 @pytest.mark.parametrize('alg,B', [('sac', 7), ('vlsac', 100), ('ctrlsac', 33), ('spedersac', 50), ('diffsrsac', 19)])
 def test_ragged_batch_sizes_match_oracle(alg, B):
     """Batch sizes that are not multiples of the 16-row MFMA tile (and a batch-size change on a live agent)
