@@ -56,7 +56,7 @@ extern "C" unsigned rl_timing_count() { unsigned n = 0; (void)hipMemcpyFromSymbo
 // the eight tasks' first tiles, their column-tile counts packed two to a word -- which the hardware PRELOADS into SGPRs at wave launch
 // (build.sh compiles this file with -mllvm -amdgpu-kernarg-preload-count=14): a workgroup knows its task and tile without a single load,
 // and its first scalar-load round trip is the task record itself.
-template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false, int EPI_K = -1, int ACT_K = -1, bool MSE = false>
+template <int LA, int LB, int NF, bool VA, bool VB, bool PRE = false, int EPI_K = -1, int ACT_K = -1, bool MSE = false, int NJ_K = 0>
 __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0, int tb1, int tb2, int tb3, int tb4, int tb5, int tb6, int tb7,
                                                      unsigned tc01, unsigned tc23, unsigned tc45, unsigned tc67, GemmBatch gb) {
     __shared__ float red[4][NF][4][64];
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     asm volatile("" :: "s"(tr), "s"(tc), "s"(ti));
     TIM(7);                       // task and tile known (preloaded scalars only): what follows is the record's scalar-load round trip
     float* const pC = t.C; const int epi = t.epi;
-    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K, false, MSE>(t, tr, tc, red, bsum, nullptr, tim_c);
+    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K, false, MSE, 0, NJ_K>(t, tr, tc, red, bsum, nullptr, tim_c);
 #else
-    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K, false, MSE>(t, tr, tc, red, bsum, nullptr);
+    gemm16_tile<LA, LB, NF, VA, VB, PRE, false, GemmTask, EPI_K, ACT_K, false, MSE, 0, NJ_K>(t, tr, tc, red, bsum, nullptr);
 #endif
     TIM_FIN();
 }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm16_fast4_kernel(int hdr, const float*
 // ... and the single-task launches of the fused short product's dX form (FLAG_PRE; the vlsac decoder launch with its mse phase, the policy's
 // last backward pair): one task's operands PLUS the short product's (X, Wt, M) fit the 14 scalars -- base, A / B / X / Wt / M offsets,
 // lda | ldb << 16, K | R << 16, Cn | K1 << 16, ldx | ldw << 16, ldm; hdr = low_prio | log2(column tiles) << 8.
-template <int EPI_K, int ACT_K, bool MSE>
+template <int EPI_K, int ACT_K, bool MSE, int NJ_K = 0>
 __global__ __launch_bounds__(256) void gemm16_fastpre_kernel(int hdr, const float* base, unsigned ao, unsigned bo, unsigned ld, unsigned kr, unsigned ck, unsigned xo, unsigned wo, unsigned mo,
                                                              unsigned ldxw, unsigned ldm, GemmBatch gb) {
     __shared__ float red[4][1][4][64];
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(256) void gemm16_fastpre_kernel(int hdr, const floa
 #ifdef RL_TIMING
     asm volatile("" :: "s"(tr), "s"(tc));
     TIM(7);
-    gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
+    gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4, NJ_K>(t, tr, tc, red, bsum, nullptr, tim_c, &fo);
     float* const pC = t.C; const int epi = 0x8 | (EPI_K & 7);
     TIM_FIN();
 #else
-    gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4>(t, tr, tc, red, bsum, nullptr, &fo);
+    gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4, NJ_K>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
 struct FastPreArgs { int hdr; const float* base; unsigned ao, bo, ld, kr, ck, xo, wo, mo, ldxw, ldm; };
@@ -478,13 +478,19 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
                 else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE, true>), g, dim3(256), 0, st, G16_ARGS(*gb));
                 return (int)hipGetLastError();
             }
+            // short products of at most 16 inner indices (the policy head's 2 A <= 16 columns): instantiations without the second 16-wide chunk
+            bool nj1 = !getenv("RLREP_GEMM16_GENERIC");
+            for (int q = 0; q < gb->ntasks; ++q) nj1 = nj1 && gb->t[q].n0 <= 16;
             if (fastpre) {
-                if (elu) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_ELU, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
+                if (elu && nj1) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_ELU, false, 1>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
+                else if (elu) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_ELU, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
                 else if (rep) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX_REPARAM, ACT_NONE, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
+                else if (nj1) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_NONE, false, 1>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
                 else hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_NONE, false>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
                 return (int)hipGetLastError();
             }
-            if (elu) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            if (elu && nj1) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_ELU, false, 1>), g, dim3(256), 0, st, G16_ARGS(*gb));
+            else if (elu) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_ELU>), g, dim3(256), 0, st, G16_ARGS(*gb));
             else if (rep) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX_REPARAM, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
             else if (plain) hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true, EPI_DX, ACT_NONE>), g, dim3(256), 0, st, G16_ARGS(*gb));
             else hipLaunchKernelGGL((gemm16_kernel<LD_ROW, LD_COL, 1, false, false, true>), g, dim3(256), 0, st, G16_ARGS(*gb));

@@ -230,11 +230,13 @@ __device__ __forceinline__ void mac_group_pre(const PreSrc& ps, const float* __r
 struct FastOps { const float* pA; const float* pB; int lda, ldb, K, R, Cn, tiles_c;
                  const float* X; const float* Wt; const float* M; int ldx, ldw, K1, ldm; };       // (X .. ldm: the fused short product's operands, gemm16_fastpre_kernel)
 template <int LA, int LB, int NF, bool VA, bool VB, bool PRE, bool COH, class TaskT = GemmTask, int EPI_K = -1, int ACT_K = -1, bool GATHER = false, bool MSE = false,
-          int FAST = 0>
+          int FAST = 0, int NJ_K = 0>
 __device__ __forceinline__ void gemm16_tile(const TaskT& t, const int tr, const int tc, float (&red)[4][NF][4][64], float (&bsum)[4][16],
                                             const float* const* dyn RL_TIM_PARAM, const FastOps* fo = nullptr) {
     static_assert(!FAST || (!COH && !GATHER && (PRE || !MSE) && (!PRE || (FAST == 4 && LA == LD_ROW && LB == LD_COL && NF == 1))), "FAST: plain forward / dX tiles, or the dX form of the fused short product");
-    constexpr int NJ = (LB == LD_ROW) ? 3 : 2;          // fused short product: forward form (LB = LD_ROW) K1 <= 48, dX form K1 <= 32
+    // fused short product: 16-wide chunks of its inner length K1 -- forward form (LB = LD_ROW) K1 <= 48, dX form K1 <= 32; NJ_K = 1: the launcher has
+    // checked K1 <= 16 (the policy head: 2 A columns), and the second chunk's loads and MFMAs (all masked) are not issued at all
+    constexpr int NJ = NJ_K ? NJ_K : (LB == LD_ROW) ? 3 : 2;
     constexpr bool FW = (LB == LD_ROW);
     // the hot block of the task record and the epilogue's operand slots, fetched as ONE burst of scalar loads
     const float* const pA = FAST ? fo->pA : t.A; const float* const pB = FAST ? fo->pB : t.B; float* const pC = t.C; const float* const pbias = t.bias;
