@@ -348,25 +348,35 @@ def pmc_traffic(path, fam):
     except Exception:
         return None
     rx = re.compile(fam['kernel_regex'])
-    nd, tot = 0, 0.0
+    # each counter summed over ALL the dispatches that carry it (the passes are separate runs; a kernel missing from one pass is reported in
+    # `coverage`, never silently dropped from the mean), then divided by the train() calls of the profiled run
+    calls = int(d.get('__meta__', {}).get('train_calls', 0) or 0)
+    tot = {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0}
+    nd = {'FETCH_SIZE': 0, 'WRITE_SIZE': 0}
     per_kernel = {}
     for k, v in d.items():
-        if k.startswith('__') or not rx.search(k) or 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
+        if k.startswith('__') or not rx.search(k):
             continue
-        b = (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0
-        n = int(v.get('dispatches', 1))
-        nd += n
-        tot += b * n
-        per_kernel[k] = round(b)
-    if not nd:
+        by_pass = v.get('dispatches_by_pass', {})
+        for c, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+            if c in v:
+                n = int(by_pass.get(sub, v.get('dispatches', 1)))
+                tot[c] += v[c] * 1024.0 * n
+                nd[c] += n
+        if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            per_kernel[k] = round((2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0)
+    if not nd['FETCH_SIZE'] or not nd['WRITE_SIZE'] or not calls:
         return None
-    per_launch = tot / nd
-    per_train = per_launch * fam['launches_per_train']
+    per_train = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) / calls
+    launches = nd['FETCH_SIZE'] / calls                      # launches of the family per train() IN THE PROFILED RUN (eager sequential programs)
+    per_launch = per_train / launches
     alg = fam['algorithmic_mbytes_per_train'] * 1e6
     return {'bytes_per_launch': round(per_launch), 'bytes_per_train': round(per_train), 'algorithmic_bytes_per_train': round(alg),
             'ratio_to_algorithmic': round(per_train / alg, 2) if alg > 0 else None,
-            'source': os.path.relpath(path, ROOT), 'correction': '(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B, per dispatch; separate --pmc passes; Infinity-Cache hits counted',
-            'dispatches': nd}
+            'source': os.path.relpath(path, ROOT), 'correction': '(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B, each counter summed over every dispatch of its pass / train() calls of the run; separate --pmc passes; Infinity-Cache hits counted',
+            'dispatches': nd['FETCH_SIZE'], 'train_calls': calls, 'launches_per_train_profiled': round(launches, 2),
+            'coverage': {'fetch_dispatches': nd['FETCH_SIZE'], 'write_dispatches': nd['WRITE_SIZE'], 'passes_agree': d.get('__meta__', {}).get('passes_agree'),
+                         'expected_dispatches': fam['launches_per_train'] * calls}}
 
 
 def find_pmc_json(workload, explicit=None):
@@ -742,6 +752,11 @@ def main():
                 out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)
             elif getattr(agent, '_graph_launches', None):
                 out['launches_per_train'] = int(agent._graph_launches)
+        # which front end the 16-row tile engine's launches of ONE train() got when the running graphs were captured (rlrep_front_end_counts):
+        # fast / fast4 / fastpre issue their operand loads from preloaded scalars, `record` fetches its task record first
+        fe = (getattr(agent, '_pipe', None) or {}).get('front_ends') or getattr(agent, '_graph_front_ends', None)
+        if fe:
+            out['front_end_launches'] = fe
         if alg == 'vlsac' and not args.quick:
             out['roofline_heaviest_kernel'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
             out.setdefault('roofline', out['roofline_heaviest_kernel'])

@@ -442,6 +442,12 @@ int32_t rlrep_debug_stamp(int64_t* ring_dev, int32_t cap, int32_t tag, void* str
 int32_t rlrep_last_launch_count(rlrep_agent* agent);
 /* process-wide number of kernel launches the library has issued so far (a captured train()'s launch count = the difference around its capture) */
 int64_t rlrep_launch_counter(void);
+/* process-wide launches of the 16-row tile engine per FRONT END so far: out4[0] = gemm16_fast_kernel, [1] = gemm16_fast4_kernel, [2] =
+ * gemm16_fastpre_kernel (operand loads issued from preloaded scalars; a launch qualifies by its shapes and by all its operands lying within
+ * 16 GiB of one base -- the caller's arenas should be slices of ONE allocation), [3] = the record front end (gemm16_kernel /
+ * gemm16_duo_kernel).  Counted when a launch is issued or captured, like rlrep_launch_counter.  The layers these launches compute:
+ * reference networks/vae.py:40-57,83-85,112-117 and the MLPs of agent/<alg>/<alg>_agent.py. */
+int32_t rlrep_front_end_counts(int64_t* out4);
 
 #ifdef __cplusplus
 }

@@ -146,6 +146,7 @@ def _load():
         'rlrep_metrics_dev': (vp, [vp]),
         'rlrep_last_launch_count': (i32, [vp]),
         'rlrep_launch_counter': (i64, []),
+        'rlrep_front_end_counts': (i32, [P(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
@@ -167,3 +168,10 @@ def check(rc, what=''):
     if rc != 0:
         msg = lib.rlrep_last_error()
         raise RuntimeError(f'rlrep {what} failed ({rc}): {msg.decode() if msg else ""}')
+
+
+def front_end_counts():
+    """Launches of the 16-row tile engine per front end since the library was loaded: dict(fast, fast4, fastpre, record)."""
+    out = (C.c_int64 * 4)()
+    check(lib.rlrep_front_end_counts(out), 'front_end_counts')
+    return dict(zip(('fast', 'fast4', 'fastpre', 'record'), (int(v) for v in out)))

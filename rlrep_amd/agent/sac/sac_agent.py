@@ -883,9 +883,9 @@ class SACAgent(object):
                     # two streams that were TIMED to be concurrent; train(t) uses snapshot set t % nset:
                     #   stream F : [feature steps(t) + snapshot(t -> set)]            after the critic/actor pair of t-2 (same set)
                     #   stream CA: [critic + actor(t) from set]                       after snapshot(t)
-                    from rlrep_amd._lib import lib as _l
+                    from rlrep_amd._lib import lib as _l, front_end_counts as _fe
                     fs, ca = [], []
-                    n0 = _l.rlrep_launch_counter()
+                    n0, f0 = _l.rlrep_launch_counter(), _fe()
                     nset = min(c.defer_supported(), max(2, int(os.environ.get('RLREP_DEFER_SETS', '3'))))
                     for k in range(nset):
                         g = torch.cuda.CUDAGraph()
@@ -905,6 +905,8 @@ class SACAgent(object):
                             self._stamp(4)
                         ca.append(g)
                     P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
+                    f1 = _fe()
+                    P['front_ends'] = {k: (f1[k] - f0[k]) // nset for k in f1}      # 16-row tile engine launches of one train() per front end
                     s_ca, s_f = _concurrent_stream_pair(c)
                     P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, nset=nset, ev_snap=[torch.cuda.Event() for _ in range(nset)],
                              ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
@@ -1112,10 +1114,10 @@ class SACAgent(object):
                 # when the batch size changes), then capture the whole train() into one hipGraph
                 self._sample_into(buffer, B, 'warm', 0, False)
                 torch.cuda.synchronize()
-                from rlrep_amd._lib import lib as _l
+                from rlrep_amd._lib import lib as _l, front_end_counts as _fe
                 s = torch.cuda.Stream()
                 g = torch.cuda.CUDAGraph()
-                n0 = _l.rlrep_launch_counter()
+                n0, f0 = _l.rlrep_launch_counter(), _fe()
                 # the call's metrics are filed in the library's history ring by the last launch of the graph (rlrep_history) and fetched when the
                 # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_INFO_HISTORY=0: a clone per call.
                 self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0'
@@ -1127,6 +1129,8 @@ class SACAgent(object):
                     self.core.history(False)
                 self._graph, self._graph_key = g, key
                 self._graph_launches = _l.rlrep_launch_counter() - n0
+                f1 = _fe()
+                self._graph_front_ends = {k: f1[k] - f0[k] for k in f1}
                 self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
         self._sync_images()
         self._graph.replay()

@@ -121,13 +121,28 @@ class HipCore:
         self.descs = {d.name.decode(): (d.arena, d.group, d.offset, d.rows, d.cols) for d in descs}
         self.order = [d.name.decode() for d in descs]
         dev = self.device
-        self.params = torch.zeros(info.param_floats, dtype=torch.float32, device=dev)
-        self.targets = torch.zeros(info.target_floats, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(info.grad_floats, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(info.param_floats, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(info.param_floats, dtype=torch.float32, device=dev)
-        self.workspace = torch.zeros(info.workspace_bytes, dtype=torch.uint8, device=dev)
-        self.alpha_state = torch.zeros(4, dtype=torch.float64, device=dev)     # log_alpha, m, v, step
+        # ONE device allocation, the seven arenas carved out of it at 256-byte boundaries: the tile engine's fast front ends address every
+        # operand of a launch as a 32-bit float offset from one base (csrc/gemm16.hip fast_args), so whether a launch qualifies must depend
+        # on its shapes, never on where the allocator happened to put two separately allocated tensors (activations live in the workspace,
+        # weights in the parameter arena).  The whole block must span < 16 GiB for that; Humanoid's is 1.7 GB.
+        sizes = [4 * info.param_floats, 4 * info.target_floats, 4 * info.grad_floats, 4 * info.param_floats, 4 * info.param_floats,
+                 int(info.workspace_bytes), 4 * 8]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (int(n) + 255) & ~255
+        if total >= (1 << 34):
+            raise RuntimeError(f'rlrep_amd: the arenas of this agent need {total} bytes in one block; the tile engine addresses operands '
+                               'as 32-bit float offsets from one base (16 GiB)')
+        self._block = torch.zeros(total + 256, dtype=torch.uint8, device=dev)
+        skew = (-self._block.data_ptr()) & 255
+
+        def carve(i, dtype):
+            return self._block[skew + offs[i]:skew + offs[i] + sizes[i]].view(dtype)
+        self.params, self.targets, self.grads = carve(0, torch.float32), carve(1, torch.float32), carve(2, torch.float32)
+        self.exp_avg, self.exp_avg_sq = carve(3, torch.float32), carve(4, torch.float32)
+        self.workspace = carve(5, torch.uint8)
+        self.alpha_state = carve(6, torch.float64)     # log_alpha, m, v, step
         self.alpha_state[0] = float(np.log(0.1))
         ar = _lib.Arenas(self.params.data_ptr(), self.targets.data_ptr(), self.grads.data_ptr(),
                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.workspace.data_ptr(),

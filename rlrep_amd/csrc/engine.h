@@ -132,6 +132,8 @@ struct Workspace {
 // ------------------------------------------------------------------------------------------------
 // process-wide count of kernel launches issued by the library (rlrep_launch_counter: bench.py counts the launches a captured train() holds)
 extern long long g_rl_launches;
+extern long long g_rl_front[4];                 // gemm16.hip: launches per front end (fast, fast4, fastpre, record)
+extern "C" void rl_gemm16_read_env();           // gemm16.hip: RLREP_GEMM16_{NO_FAST,GENERIC,TRACE}, read at agent creation
 // engine / flops / bytes: what rlrep_stage_info reports (include/rlrep.h RLREP_ENGINE_*: which kernel family the stage launches, the
 // ALGORITHMIC flops (2 * MAC) of its products and the bytes of their operands and results, each counted once)
 struct Stage { std::function<int(hipStream_t)> run; const char* what; int engine = 0; double flops = 0.0, bytes = 0.0; };

@@ -1169,6 +1169,7 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
         !arenas->alpha_state_dev || !arenas->target_dev) { rl_set_error("null arena pointer"); return RLREP_ERR_ARG; }
     rlrep_layout_info info;
     if (rlrep_layout(dims, &info, nullptr, 0) != 0) return RLREP_ERR_ARG;
+    rl_gemm16_read_env();          // the tile engine's diagnostic switches are read here, once per agent, not per launch
     std::unique_ptr<rlrep_agent> ag(new rlrep_agent());
     ag->d = *dims; ag->h = *hyper; ag->a = *arenas;
     if (ag->h.world_size <= 0) ag->h.world_size = 1;
@@ -1845,6 +1846,11 @@ int32_t rlrep_build_flags(void) {
 
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
 int64_t rlrep_launch_counter(void) { return g_rl_launches; }
+int32_t rlrep_front_end_counts(int64_t* out4) {
+    if (!out4) return RLREP_ERR_ARG;
+    for (int q = 0; q < 4; ++q) out4[q] = g_rl_front[q];
+    return 0;
+}
 int32_t rlrep_last_launch_count(rlrep_agent* ag) { return ag ? ag->last_launches : 0; }
 
 }  // extern "C"

@@ -196,9 +196,20 @@ __global__ __launch_bounds__(256) void gemm16_fastpre_kernel(int hdr, const floa
     gemm16_tile<LD_ROW, LD_COL, 1, false, false, true, false, GemmTask, EPI_K, ACT_K, false, MSE, 4, NJ_K>(t, tr, tc, red, bsum, nullptr, &fo);
 #endif
 }
+// launches per front end since the library was loaded (rlrep_front_end_counts): 0 = gemm16_fast_kernel, 1 = gemm16_fast4_kernel, 2 = gemm16_fastpre_kernel,
+// 3 = the record front end (gemm16_kernel / gemm16_duo_kernel).  Which one a launch gets depends on its shapes and on every operand lying within
+// 16 GiB of the lowest one (rlrep_amd/core.py carves all arenas out of one block for that); tests and bench.py read the counts.
+long long g_rl_front[4] = {0, 0, 0, 0};
+static int s_front = 3;
+// diagnostic switches, read when an agent is created (rl_gemm16_read_env; no getenv on the per-launch path): RLREP_GEMM16_NO_FAST = every launch on
+// the record front end, RLREP_GEMM16_GENERIC = no compiled-in epilogues (both: bit-identical results, tests/test_default_mode.py)
+static bool s_no_fast = false, s_generic = false, s_trace = false;
+extern "C" void rl_gemm16_read_env() {
+    s_no_fast = getenv("RLREP_GEMM16_NO_FAST") != nullptr; s_generic = getenv("RLREP_GEMM16_GENERIC") != nullptr; s_trace = getenv("RLREP_GEMM16_TRACE") != nullptr;
+}
 struct FastPreArgs { int hdr; const float* base; unsigned ao, bo, ld, kr, ck, xo, wo, mo, ldxw, ldm; };
 static bool fastpre_args(const GemmBatch& gb, FastPreArgs& fa) {
-    if (gb.ntasks != 1 || getenv("RLREP_GEMM16_NO_FAST")) return false;
+    if (gb.ntasks != 1 || s_no_fast) return false;
     const GemmTask& t = gb.t[0];
     if (!(t.flags & FLAG_PRE) || (t.flags & FLAG_PRE_FWD) || !t.x0 || !t.x1 || !t.x2 || t.tile_base != 0) return false;
     const int tcn = t.tiles_c;
@@ -227,7 +238,7 @@ static bool fastpre_args(const GemmBatch& gb, FastPreArgs& fa) {
 struct FastArgs { int hdr, tb1; const float* base; unsigned a[2], b[2], ld[2], kr[2], ct[2]; };
 // short = false: every K a multiple of 256; short = true: every K <= 64 (the FAST = 1 instantiations)
 static bool fast_args(const GemmBatch& gb, FastArgs& fa, bool short_k = false) {
-    if (gb.ntasks < 1 || gb.ntasks > 2 || getenv("RLREP_GEMM16_NO_FAST")) return false;
+    if (gb.ntasks < 1 || gb.ntasks > 2 || s_no_fast) return false;
     uintptr_t lo = ~(uintptr_t)0;
     for (int q = 0; q < gb.ntasks; ++q) { lo = std::min(lo, (uintptr_t)gb.t[q].A); lo = std::min(lo, (uintptr_t)gb.t[q].B); }
     lo &= ~(uintptr_t)15;
@@ -247,7 +258,7 @@ static bool fast_args(const GemmBatch& gb, FastArgs& fa, bool short_k = false) {
 }
 struct Fast4Args { int hdr; const float* base; unsigned ld, kr, ct, a[4], b[4]; };
 static bool fast4_args(const GemmBatch& gb, Fast4Args& fa, bool short_k = false) {
-    if (gb.ntasks < 3 || gb.ntasks > 4 || getenv("RLREP_GEMM16_NO_FAST")) return false;
+    if (gb.ntasks < 3 || gb.ntasks > 4 || s_no_fast) return false;
     const GemmTask& t0 = gb.t[0];
     uintptr_t lo = ~(uintptr_t)0;
     for (int q = 0; q < gb.ntasks; ++q) { lo = std::min(lo, (uintptr_t)gb.t[q].A); lo = std::min(lo, (uintptr_t)gb.t[q].B); }
@@ -322,23 +333,23 @@ static void launch_nf(int nf, dim3 g, hipStream_t st, const GemmBatch& gb) {
 template <int LA, int LB, int NF, bool VA, bool VB, int EPI_K, int ACT_K>
 static bool launch_fast(dim3 g, hipStream_t st, const GemmBatch& gb) {
     FastArgs fa; Fast4Args f4;
-    if (fast_args(gb, fa)) { hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb)); return true; }
-    if (fast4_args(gb, f4)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); return true; }
+    if (fast_args(gb, fa)) { hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb)); s_front = 0; return true; }
+    if (fast4_args(gb, f4)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_K, ACT_K>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); s_front = 1; return true; }
     return false;
 }
 // ... and the first layers (K <= 64, forward form, rows of 17 / 23 / 40 floats: with or without 16-byte operand loads)
 template <int LA, int LB, int NF, bool VA, bool VB, int ACT_K>
 static bool launch_fast_short(dim3 g, hipStream_t st, const GemmBatch& gb) {
     FastArgs fa; Fast4Args f4;
-    if (fast_args(gb, fa, true)) { hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb)); return true; }
-    if (fast4_args(gb, f4, true)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); return true; }
+    if (fast_args(gb, fa, true)) { hipLaunchKernelGGL((gemm16_fast_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST_ARGS(fa, gb)); s_front = 0; return true; }
+    if (fast4_args(gb, f4, true)) { hipLaunchKernelGGL((gemm16_fast4_kernel<LA, LB, NF, VA, VB, EPI_FWD, ACT_K, 1>), g, dim3(256), 0, st, G16_FAST4_ARGS(f4, gb)); s_front = 1; return true; }
     return false;
 }
 // NF = 1 launches whose tasks all share ONE plain epilogue (forward or dX; none / ReLU / ELU; no rank-1 term, no second output): the
 // instantiation with that epilogue compiled in.  Returns false when the launch needs the generic kernel.
 template <int LA, int LB, int NF, bool VA, bool VB>
 static bool launch_spec(dim3 g, hipStream_t st, const GemmBatch& gb) {
-    if (getenv("RLREP_GEMM16_GENERIC")) return false;
+    if (s_generic) return false;
     const int epi = gb.t[0].epi;
     int act = gb.t[0].act;
     bool same_epi = true;
@@ -413,8 +424,15 @@ static bool all_vec(const GemmBatch& gb, bool opB) {
     return true;
 }
 
+static int launch_gemm16_impl(int la, int lb, int nf, const GemmBatch* gb_in, int total_tiles, hipStream_t st);
 extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, int total_tiles, hipStream_t st) {
     if (total_tiles <= 0) return 0;
+    s_front = 3;
+    const int rc = launch_gemm16_impl(la, lb, nf, gb_in, total_tiles, st);
+    if (rc == 0) ++g_rl_front[s_front];
+    return rc;
+}
+static int launch_gemm16_impl(int la, int lb, int nf, const GemmBatch* gb_in, int total_tiles, hipStream_t st) {
     // the epilogue operand slots travel in the record (common.h rl_gemm16_plan): filled here, on the launcher's copy, after the caller's
     // per-call patches (noise pointers)
     GemmBatch planned = *gb_in;
@@ -426,15 +444,14 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     planned.total = total_tiles;
     const GemmBatch* const gb = &planned;
     dim3 g(total_tiles);
-    static const bool trace = getenv("RLREP_GEMM16_TRACE") != nullptr;       // one line per launch: which front end it gets (tools/exp/gemm16_trace.py)
-    if (trace) {
+    if (s_trace) {                                                            // one line per launch: which front end it gets (tools/exp/gemm16_trace.py)
         FastArgs fa; Fast4Args f4;
         const bool pre = gb->ntasks > 0 && (gb->t[0].flags & FLAG_PRE), vecA = all_vec(*gb, false), vecB = all_vec(*gb, true);
         const bool vec_ok = la == LD_ROW && vecA && (lb == LD_COL || vecB), nf_ok = nf == 1 || nf == 2;
         const char* front = "record";
         FastPreArgs fpt;
-        if (pre && la == LD_ROW && lb == LD_COL && nf == 1 && !getenv("RLREP_GEMM16_GENERIC") && fastpre_args(*gb, fpt)) front = "fast (fused short product)";
-        if (!pre && la == LD_ROW && nf_ok && !getenv("RLREP_GEMM16_GENERIC")) {
+        if (pre && la == LD_ROW && lb == LD_COL && nf == 1 && !s_generic && fastpre_args(*gb, fpt)) front = "fast (fused short product)";
+        if (!pre && la == LD_ROW && nf_ok && !s_generic) {
             if (lb == LD_ROW && (vecA == vecB) && (fast_args(*gb, fa, true) || fast4_args(*gb, f4, true)) && gb->t[0].epi == EPI_FWD) front = "fast (K <= 64)";
             else if (vec_ok && fast_args(*gb, fa)) front = "fast";
             else if (vec_ok && fast4_args(*gb, f4)) front = "fast4";
@@ -460,7 +477,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
 #endif
         } else {
             if (lb != LD_COL) return -3;
-            bool rep = !getenv("RLREP_GEMM16_GENERIC"), plain = rep, elu = rep;
+            bool rep = !s_generic, plain = rep, elu = rep;
             for (int q = 0; q < gb->ntasks; ++q) {
                 rep = rep && gb->t[q].epi == EPI_DX_REPARAM; plain = plain && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_NONE;
                 elu = elu && gb->t[q].epi == EPI_DX && gb->t[q].act == ACT_ELU;
@@ -470,6 +487,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
             for (int q = 0; q < gb->ntasks; ++q) mse = mse || (gb->t[q].flags & FLAG_PRE_MSE);
             FastPreArgs fp;
             const bool fastpre = (rep || plain || elu) && fastpre_args(*gb, fp);          // one task, K % 256 == 0: the front end that loads from preloaded scalars
+            if (fastpre) s_front = 2;
             if (mse) {
                 const GemmTask& m0 = gb->t[0];
                 if (gb->ntasks != 1 || !rep || (m0.ldaux2 & 3) || (m0.ldx1 & 3) || (m0.K & 3) || ((((uintptr_t)m0.x2) | ((uintptr_t)m0.x1)) & 15) || !m0.bias || !m0.tgs || !m0.tgr || !m0.mse_part || !m0.x0)
@@ -479,7 +497,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
                 return (int)hipGetLastError();
             }
             // short products of at most 16 inner indices (the policy head's 2 A <= 16 columns): instantiations without the second 16-wide chunk
-            bool nj1 = !getenv("RLREP_GEMM16_GENERIC");
+            bool nj1 = !s_generic;
             for (int q = 0; q < gb->ntasks; ++q) nj1 = nj1 && gb->t[q].n0 <= 16;
             if (fastpre) {
                 if (elu && nj1) hipLaunchKernelGGL((gemm16_fastpre_kernel<EPI_DX, ACT_ELU, false, 1>), g, dim3(256), 0, st, G16_FASTPRE_ARGS(fp, *gb));
@@ -506,7 +524,7 @@ extern "C" int rl_launch_gemm16(int la, int lb, int nf, const GemmBatch* gb_in, 
     } else if (la == LD_COL && lb == LD_COL) {
         // weight gradients with nothing to accumulate into: the instantiation without slot loads; with the optimizer in some tasks'
         // epilogues (FLAG_ADAM): the instantiation that loads the parameter / moment slots (EPI_DWA)
-        bool plain = !getenv("RLREP_GEMM16_GENERIC"), opt = false;
+        bool plain = !s_generic, opt = false;
         for (int q = 0; q < gb->ntasks; ++q) {
             plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM);
             if (gb->t[q].flags & FLAG_ADAM) { opt = true; if (!gb->t[q].ad_p || !gb->t[q].ad_grp) return -3; }
@@ -550,5 +568,6 @@ extern "C" int rl_launch_gemm16_duo(int split, int nf2, const GemmBatch* gb_in, 
     else if (nf2 == 1) hipLaunchKernelGGL((gemm16_duo_kernel<false, 1>), g, dim3(256), 0, st, DUO_ARGS);
     else hipLaunchKernelGGL((gemm16_duo_kernel<false, 4>), g, dim3(256), 0, st, DUO_ARGS);
 #undef DUO_ARGS
+    ++g_rl_front[3];
     return (int)hipGetLastError();
 }

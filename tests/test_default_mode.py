@@ -367,7 +367,7 @@ def test_fast_front_end_changes_nothing(monkeypatch):
     from rlrep_amd.utils.buffer import ReplayBuffer
     from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
     data = synth.replay(17, 6, 8192, seed=0)
-    outs = []
+    outs, routes = [], []
     for fast in (True, False):
         if not fast:
             monkeypatch.setenv('RLREP_GEMM16_NO_FAST', '1')
@@ -379,10 +379,20 @@ def test_fast_front_end_changes_nothing(monkeypatch):
         for _ in range(20):
             agent.train(buf, 256)
         agent.flush()
+        # the routing itself (rlrep_front_end_counts, taken around the capture of the running graphs): the comparison below is vacuous if the
+        # default run silently fell back to the record front end (a launch qualifies only if all its operands lie within 16 GiB of one base:
+        # HipCore carves every arena out of ONE allocation for that)
+        fe = agent._pipe['front_ends']
+        if fast:
+            assert fe['fast'] + fe['fast4'] + fe['fastpre'] >= 20 and fe['fast'] >= 8 and fe['fast4'] >= 1 and fe['fastpre'] >= 4, fe
+        else:
+            assert fe['fast'] == fe['fast4'] == fe['fastpre'] == 0 and fe['record'] >= 30, fe
+        routes.append(fe)
         st = {k: v.numpy().copy() for k, v in agent.core.state().items()}
         st['exp_avg'] = agent.core.exp_avg.cpu().numpy().copy(); st['exp_avg_sq'] = agent.core.exp_avg_sq.cpu().numpy().copy()
         outs.append(st)
         del agent, buf
+    assert sum(routes[0].values()) == sum(routes[1].values()), routes        # same launches, different front ends
     for k in outs[1]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
 

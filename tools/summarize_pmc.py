@@ -18,7 +18,7 @@ def short(name):
     return re.sub(r'\(.*$', '', name).replace('void ', '').strip()
 
 
-pmc = {}
+pmc, passes = {}, {}
 for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
     files = glob.glob(os.path.join(G, f'{sub}_{wl}', '*', '*_counter_collection.csv'))
     if not files:
@@ -30,11 +30,29 @@ for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
             continue
         d = acc.setdefault(k, {}).setdefault(r['Counter_Name'], {})
         d[r['Dispatch_Id']] = d.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
+    passes[sub] = {k: len(next(iter(cs.values()))) for k, cs in acc.items()}
     for k, cs in acc.items():
         for c, per in cs.items():
             pmc.setdefault(k, {})[c] = round(sum(per.values()) / len(per), 1)
             pmc[k]['dispatches'] = len(per)
-pmc['__meta__'] = {'workload': wl, 'train_calls': calls,
+            pmc[k].setdefault('dispatches_by_pass', {})[sub] = len(per)
+# The three passes are three RUNS of the same command: a summary is only meaningful if they launched the same kernels the same number of
+# times (round 4's headline summary mixed two routings of the tile engine -- fast front ends in one pass, record front end in the others --
+# and every figure derived from "kernels that carry both counters" was an artefact).  Refuse to write such a file.
+names = [set(v) for v in passes.values()]
+bad = []
+if len(passes) > 1:
+    allk = set().union(*names)
+    for k in sorted(allk):
+        cnt = {sub: passes[sub].get(k, 0) for sub in passes}
+        if len(set(cnt.values())) != 1:
+            bad.append((k, cnt))
+if bad and os.environ.get('RLREP_PMC_ALLOW_MISMATCH') != '1':
+    print('summarize_pmc: the passes disagree on kernels / dispatches per kernel -- not written:', file=sys.stderr)
+    for k, cnt in bad[:20]:
+        print('   ', k, cnt, file=sys.stderr)
+    sys.exit(3)
+pmc['__meta__'] = {'workload': wl, 'train_calls': calls, 'passes': sorted(passes), 'passes_agree': not bad,
                    'command': f'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --workload {wl} --steps <N> --warmup 5 --no-cpu --no-graph --no-profile  (three passes: SQ_* / FETCH_SIZE / WRITE_SIZE + LDS, instruction counters)',
                    'units': 'FETCH_SIZE / WRITE_SIZE in KB, raw (gfx950: x2 on FETCH_SIZE for wide reads before comparing with bytes)'}
 out = os.path.join(P, f'{tag}_pmc_{wl}.json')
