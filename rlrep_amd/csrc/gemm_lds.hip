@@ -370,8 +370,15 @@ __global__ __launch_bounds__(256) void gemm_lds_fin_kernel(GL_DIR_PARAMS, GemmBa
 #ifndef X3_STAGGER
 #define X3_STAGGER 24                /* s_sleep units (64 cycles) */
 #endif
-#define X3_RSB 80                    /* image row stride in bytes: 32 bf16 + 16 bytes pad */
+#define X3_RSB 64                    /* image row stride in bytes: 32 bf16, no pad -- the four 16-byte chunks of a row are XOR-swizzled instead (x3r_off) */
 #define X3_IMGB (128 * X3_RSB)       /* bytes per image */
+// Byte offset of 16-byte chunk ch (eight consecutive k) of image row `row`.  A 256-byte LDS bank row holds four image rows; the chunk index is
+// XORed with (row >> 2) & 3, so that the sixteen rows one ds_read_b128 lane group reads at one chunk index -- {0-3, 12-15, 20-27} or
+// {4-11, 16-19, 28-31}: four rows of every residue mod 4, with four different (row >> 2) & 3 -- cover all sixteen 16-byte slots of the bank row,
+// and the two rows a 16-lane ds_write_b64 group fills are two whole, adjacent 64-byte rows (the 32 write banks once each).  The padded form
+// ([row][80 bytes]) read conflict-free too but every staging write was a 2-way conflict on four banks: SQ_LDS_BANK_CONFLICT 77.0 M cycles per
+// launch of the Humanoid forward (profiles/r04_pmc_diffsrsac_humanoid_b2048.json); tools/lds_banks.py does the arithmetic for both.
+__device__ __forceinline__ int x3r_off(int row, int ch) { return X3_RSB * row + 16 * (ch ^ ((row >> 2) & 3)); }
 
 // 512 threads stage a 128 x 32 slice: every thread two row slots x four consecutive k (row-major operand) or four rows x
 // two consecutive k (k-major operand): e[slot][..]
@@ -412,7 +419,7 @@ __device__ __forceinline__ void x3_stage_write(unsigned char* __restrict__ img, 
             unsigned h, m, l;
             x3_split2(e[4 * j], e[4 * j + 1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
             x3_split2(e[4 * j + 2], e[4 * j + 3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
-            unsigned char* p = img + row * X3_RSB + kc * 2;
+            unsigned char* p = img + x3r_off(row, kc >> 3) + 8 * ((kc >> 2) & 1);
             *reinterpret_cast<u32x2*>(p) = hi;
             *reinterpret_cast<u32x2*>(p + X3_IMGB) = mid;
             *reinterpret_cast<u32x2*>(p + 2 * X3_IMGB) = lo;
@@ -425,7 +432,7 @@ __device__ __forceinline__ void x3_stage_write(unsigned char* __restrict__ img, 
             unsigned h, m, l;
             x3_split2(e[2 * q], e[2 * q + 1], h, m, l); hi[q] = h; mid[q] = m; lo[q] = l;
         }
-        unsigned char* p = img + row * X3_RSB + kc * 2;
+        unsigned char* p = img + x3r_off(row, kc >> 3);
         *reinterpret_cast<u32x4*>(p) = hi;
         *reinterpret_cast<u32x4*>(p + X3_IMGB) = mid;
         *reinterpret_cast<u32x4*>(p + 2 * X3_IMGB) = lo;
@@ -482,8 +489,10 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GL_DIR_PARAMS, GemmBatc
     // every second group of 256 by about one VALU phase starts the pair in anti-phase.
     if (X3_STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(X3_STAGGER);
 
-    const unsigned char* const fa = L + (wr * 32 + r32) * X3_RSB + 16 * hh;
-    const unsigned char* const fb = L + 3 * X3_IMGB + (wc * 64 + r32) * X3_RSB + 16 * hh;
+    // fragment of 16-deep block c: chunk 2 c + hh of this lane's row -- the swizzle term (row >> 2) & 3 is the same for rows r32, 32 + r32, ...
+    const unsigned char* const fa = L + x3r_off(wr * 32 + r32, hh);
+    const unsigned char* const fb = L + 3 * X3_IMGB + x3r_off(wc * 64 + r32, hh);
+    const int fsw = x3r_off(r32, 2 + hh) - x3r_off(r32, hh);            // block 1 relative to block 0: +32 or -32 bytes
 
     for (int kt = 0; kt < nk; ++kt) {
         if (want_bias) rs += ((ea[0] + ea[1]) + (ea[2] + ea[3])) + ((ea[4] + ea[5]) + (ea[6] + ea[7]));
@@ -498,9 +507,9 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GL_DIR_PARAMS, GemmBatc
             bf16x8 a[3], b[2][3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                a[m] = *reinterpret_cast<const bf16x8*>(fa + m * X3_IMGB + 32 * c);
-                b[0][m] = *reinterpret_cast<const bf16x8*>(fb + m * X3_IMGB + 32 * c);
-                b[1][m] = *reinterpret_cast<const bf16x8*>(fb + 32 * X3_RSB + m * X3_IMGB + 32 * c);
+                a[m] = *reinterpret_cast<const bf16x8*>(fa + m * X3_IMGB + fsw * c);
+                b[0][m] = *reinterpret_cast<const bf16x8*>(fb + m * X3_IMGB + fsw * c);
+                b[1][m] = *reinterpret_cast<const bf16x8*>(fb + 32 * X3_RSB + m * X3_IMGB + fsw * c);
             }
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
@@ -664,7 +673,8 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBat
     const unsigned aA0 = x3t_addr(Lb, 8 * hh, wr * 4 + 2 * g1), aA1 = x3t_addr(Lb, 8 * hh + 4, wr * 4 + 2 * g1);
     const unsigned aB00 = x3t_addr(Lb + 3 * AIMG, 8 * hh, wc * 8 + 2 * g1), aB01 = x3t_addr(Lb + 3 * AIMG, 8 * hh + 4, wc * 8 + 2 * g1);
     const unsigned aB10 = x3t_addr(Lb + 3 * AIMG, 8 * hh, wc * 8 + 4 + 2 * g1), aB11 = x3t_addr(Lb + 3 * AIMG, 8 * hh + 4, wc * 8 + 4 + 2 * g1);
-    const unsigned char* const far = L + (wr * 32 + r32) * X3_RSB + 16 * hh;               // row-major A fragments (ds_read_b128)
+    const unsigned char* const far = L + x3r_off(wr * 32 + r32, hh);                       // row-major A fragments (ds_read_b128; swizzled chunks: x3r_off)
+    const int fsw = x3r_off(r32, 2 + hh) - x3r_off(r32, hh);
 
     for (int kt = 0; kt < nk; ++kt) {
         if (want_bias) rs += ea[0] + ea[1];
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBat
         {                                                                                                                     \
             bf16x8 a[3], b[2][3];                                                                                             \
             if constexpr (LA == LD_ROW) {                                                                                     \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3_IMGB + 32 * (C)); \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3_IMGB + fsw * (C)); \
             } else {                                                                                                          \
                 a[0] = x3t_frag<(C) * 4096>(aA0, aA1); a[1] = x3t_frag<(C) * 4096 + X3T_IMGB>(aA0, aA1);                       \
                 a[2] = x3t_frag<(C) * 4096 + 2 * X3T_IMGB>(aA0, aA1);                                                         \
@@ -750,7 +760,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBat
 // operands as in gemm_x3t_kernel (staged as they lie, [32 k][64 rows] images of 128-byte rows, ds_read_b64_tr_b16) with the chunk swizzle
 // ch ^ (((k >> 1) & 1) << 2): the four k-rows a 32-lane half reads then sit on four different 16-bank groups.
 // ================================================================================================
-#define X3S_RIMGB (64 * X3_RSB)      /* row-major image: 64 rows x 80 bytes */
+#define X3S_RIMGB (64 * X3_RSB)      /* row-major image: 64 rows x 64 bytes, chunks swizzled (x3r_off) */
 #define X3S_TIMGB (32 * 128)         /* k-major image: 32 k x 64 rows x 2 bytes */
 __device__ __forceinline__ unsigned x3s_toff(int k, int ch) { return 128u * k + 16u * (ch ^ (((k >> 1) & 1) << 2)); }
 
@@ -811,7 +821,7 @@ __device__ __forceinline__ void x3s_write_row(unsigned char* __restrict__ img, c
         unsigned h, m, l;
         x3_split2(e[4 * j], e[4 * j + 1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
         x3_split2(e[4 * j + 2], e[4 * j + 3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
-        unsigned char* p = img + row * X3_RSB + kc * 2;
+        unsigned char* p = img + x3r_off(row, kc >> 3) + 8 * ((kc >> 2) & 1);
         *reinterpret_cast<u32x2*>(p) = hi;
         *reinterpret_cast<u32x2*>(p + X3S_RIMGB) = mid;
         *reinterpret_cast<u32x2*>(p + 2 * X3S_RIMGB) = lo;
@@ -915,8 +925,9 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     if constexpr (LB == LD_ROW) x3s_load_row<VEC>(pB, ldb, c0, Cn, kbeg, kend, ebr); else x3s_load_col<VEC>(pB, ldb, c0, Cn, kbeg, kend, ebc);
 
     unsigned char* const LBi = L + 3 * AIMG;
-    const unsigned char* const far = L + (wr * 32 + r32) * X3_RSB + 16 * hh;
-    const unsigned char* const fbr = LBi + (wc * 32 + r32) * X3_RSB + 16 * hh;
+    const unsigned char* const far = L + x3r_off(wr * 32 + r32, hh);
+    const unsigned char* const fbr = LBi + x3r_off(wc * 32 + r32, hh);
+    const int fsw = x3r_off(r32, 2 + hh) - x3r_off(r32, hh);            // block 1 relative to block 0 (swizzled chunks)
     const unsigned aA0 = x3s_taddr(Lb, 8 * hh, wr * 4 + 2 * g1), aA1 = x3s_taddr(Lb, 8 * hh + 4, wr * 4 + 2 * g1);
     const unsigned aB0 = x3s_taddr(Lb + 3 * AIMG, 8 * hh, wc * 4 + 2 * g1), aB1 = x3s_taddr(Lb + 3 * AIMG, 8 * hh + 4, wc * 4 + 2 * g1);
 
@@ -932,13 +943,13 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
         {                                                                                                                     \
             bf16x8 a[3], b[3];                                                                                                \
             if constexpr (LA == LD_ROW) {                                                                                     \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3S_RIMGB + 32 * (C)); \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3S_RIMGB + fsw * (C)); \
             } else {                                                                                                          \
                 a[0] = x3t_frag<(C) * 2048>(aA0, aA1); a[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>(aA0, aA1);                      \
                 a[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>(aA0, aA1);                                                        \
             }                                                                                                                 \
             if constexpr (LB == LD_ROW) {                                                                                     \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) b[m] = *reinterpret_cast<const bf16x8*>(fbr + m * X3S_RIMGB + 32 * (C)); \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) b[m] = *reinterpret_cast<const bf16x8*>(fbr + m * X3S_RIMGB + fsw * (C)); \
             } else {                                                                                                          \
                 b[0] = x3t_frag<(C) * 2048>(aB0, aB1); b[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>(aB0, aB1);                      \
                 b[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>(aB0, aB1);                                                        \
