@@ -703,9 +703,11 @@ def main():
                        'global_batch': (B_global if strong else B * world) if mode == 'dp' else B, 'scaling': 'strong' if strong else 'weak', 'feature_dim': kw.get('feature_dim'), 'hidden_dim': kw.get('hidden_dim'),
                        'feature_steps_per_train': (kw.get('extra_feature_steps', -1) + 1), 'replay_rows_per_gpu': REPLAY_N,
                        'parallelism': {'single': 'single GPU',
-                                       'dp': f'dp{world} (replay sharded, ' + ('RCCL' if (dist is not None and dist.get_backend() == 'nccl') else (dist.get_backend() if dist is not None else 'no')) + ' all-reduce of gradients per optimizer step)',
+                                       'dp': f'dp{world} (replay sharded, ' + (('gradients summed over the ranks INSIDE the optimizer launches: peer-mapped gradient arenas, rank-ordered sums, no collective launch' + ('' if getattr(agent, '_fused_all', False) else '; larger slices / batch-coupled exchanges over ' + (dist.get_backend() if dist is not None else '-')))
+                                                                                if getattr(agent.core, 'fused_groups', None) else
+                                                                                (('RCCL' if (dist is not None and dist.get_backend() == 'nccl') else (dist.get_backend() if dist is not None else 'no')) + ' all-reduce of gradients per optimizer step')) + ')',
                                        'replicas': f'{world} independent agents (own parameters and replay, no collective)'}[mode],
-                       'hipgraph': (bool(agent.use_graph) if not agent._dp else
+                       'hipgraph': (bool(agent.use_graph) if (not agent._dp or getattr(agent, '_fused_all', False)) else
                                     (('collectives captured into the graph(s)' if getattr(agent, '_seg_capture_colls', False) else 'segments between eager collectives')
                                      if agent.use_graph and agent.use_graph_dp else False)),
                        # critic + actor steps of train(t) as a graph branch beside the feature steps of train(t+1) (same updates, same order)
@@ -723,6 +725,7 @@ def main():
             # all-reduces of ONE train() issued back to back with nothing else running (segments form only: in the captured form they are graph nodes)
             'replicas_identical': replicas_identical,
             'allreduce_us_per_train': (round(allreduce_us, 1) if allreduce_us is not None else None),
+            'dp_fused_groups': (sorted(agent.core.fused_groups) if getattr(agent.core, 'fused_groups', None) else None),
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B_global if strong else value * B, 1),
             'metrics_finite': bool(finite),

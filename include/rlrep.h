@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RLREP_ABI_VERSION 2      /* 2: rlrep_replay_add takes rows (no agent), rlrep_chain_status */
+#define RLREP_ABI_VERSION 3      /* 3: rlrep_comm_* = the shared gradient arena (exchange inside the optimizer launches), rlrep_front_end_counts */
 
 typedef enum {
     RLREP_OK = 0,
@@ -331,20 +331,28 @@ const float* rlrep_metrics_dev(rlrep_agent* agent);
 /* Profiling hook: launch stage `stage` of step program `program` once (0 feature_bwd, 1 feature_apply,
  * 2 critic_bwd, 3 critic_apply, 4 actor_bwd, 5 actor_apply, 6 update_target); its inputs are whatever the
  * previous full step left in the workspace.  rlrep_stage_count/_name enumerate the stages. */
-/* ---- one-shot gradient all-reduce over peer-mapped inboxes (csrc/comm.hip) ------------------------------------
- * No reference counterpart (the reference is a single process).  The latency-shaped alternative to RCCL's ring for the <= 2 MB gradient
- * slices: every rank pushes its slice into its slot of EVERY rank's inbox (hipIpc-mapped, all links at once), signals, waits for the
- * others' signals (bounded) and adds the slots in rank order -- bit-identical sums on every rank.  Set-up: create -> handle -> (exchange the
- * handles, world x rlrep_comm_handle_bytes() in rank order, by any means: torch.distributed.all_gather_object) -> connect.
- * rlrep_comm_allreduce is stream-ordered (three launches) and must be called by every rank with the same n in the same order;
- * rlrep_comm_status synchronises the stream and reports a timed-out wait.  Opt-in: rlrep_amd/comm.py, RLREP_ONESHOT_ALLREDUCE=1. */
+/* ---- data-parallel gradient exchange inside the optimizer launches (csrc/comm.hip, csrc/dp_pull.h) ----------
+ * The reference is one process: no counterpart.  The exchange belongs between its `loss.backward()` and `optimizer.step()` pairs
+ * (agent/vlsac/vlsac_agent.py:153-154, 183-184, 229-230; ctrlsac_agent.py:243-244; spedersac_agent.py:211-212; diffsrsac_agent.py:311-314).
+ * A comm owns ONE block of device memory, [arena_floats floats | flag words], exported over hipIpc and mapped by every peer: the caller
+ * passes rlrep_comm_arena() as rlrep_arenas.grad_dev, so every rank's gradients lie where every peer can read them.  Lifecycle, identical on
+ * every rank: create -> handle -> (exchange the handles, world x rlrep_comm_handle_bytes() in rank order, by any means:
+ * torch.distributed.all_gather_object) -> connect -> rlrep_agent_create(..., grad_dev = rlrep_comm_arena()) -> attach.  After rlrep_comm_attach
+ * the optimizer launch of every attached group (rlrep_*_apply, the fused *_step entry points, the deferred chain) waits -- bounded -- for the
+ * peers' gradients of that step, sums every rank's gradient of its elements IN RANK ORDER (bit-identical on every rank) and does not end
+ * before every peer has read this rank's: ZERO launches per all-reduce, nothing on the host changes between calls (hipGraph-capturable), and
+ * the caller issues NO collective for those groups.  Groups above max_floats stay with the caller's all-reduce between backward and apply.
+ * rlrep_comm_allreduce is the same exchange as one stand-alone launch (probe / tests).  A wait that runs out sets a bit of the error word and
+ * proceeds (launches always drain; the step is invalid): rlrep_comm_status reads that word from mapped host memory WITHOUT synchronising. */
 typedef struct rlrep_comm rlrep_comm;
-int32_t rlrep_comm_create(int32_t rank, int32_t world, int64_t slot_floats, rlrep_comm** out);
+int32_t rlrep_comm_create(int32_t rank, int32_t world, int64_t arena_floats, rlrep_comm** out);
+float* rlrep_comm_arena(rlrep_comm* comm);
 int32_t rlrep_comm_handle_bytes(void);
 int32_t rlrep_comm_handle(rlrep_comm* comm, void* out, int32_t cap);
 int32_t rlrep_comm_connect(rlrep_comm* comm, const void* handles);
-int32_t rlrep_comm_allreduce(rlrep_comm* comm, float* data_dev, int64_t n, int64_t timeout_spins, void* stream);
-int32_t rlrep_comm_status(rlrep_comm* comm, uint32_t* late_mask, void* stream);
+int32_t rlrep_comm_attach(rlrep_agent* agent, rlrep_comm* comm, int64_t max_floats, int32_t* attached_mask);
+int32_t rlrep_comm_allreduce(rlrep_comm* comm, int64_t arena_offset_floats, int64_t n, float* out_dev, int64_t timeout_spins, void* stream);
+int32_t rlrep_comm_status(rlrep_comm* comm, uint32_t* late_mask, int32_t clear);
 int32_t rlrep_comm_fine_grained(rlrep_comm* comm);
 void rlrep_comm_destroy(rlrep_comm* comm);
 

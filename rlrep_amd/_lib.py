@@ -127,8 +127,10 @@ def _load():
         'rlrep_comm_handle_bytes': (i32, []),
         'rlrep_comm_handle': (i32, [vp, vp, i32]),
         'rlrep_comm_connect': (i32, [vp, vp]),
-        'rlrep_comm_allreduce': (i32, [vp, vp, i64, i64, vp]),
-        'rlrep_comm_status': (i32, [vp, P(C.c_uint32), vp]),
+        'rlrep_comm_arena': (vp, [vp]),
+        'rlrep_comm_attach': (i32, [vp, vp, i64, P(i32)]),
+        'rlrep_comm_allreduce': (i32, [vp, i64, i64, vp, i64, vp]),
+        'rlrep_comm_status': (i32, [vp, P(C.c_uint32), i32]),
         'rlrep_comm_fine_grained': (i32, [vp]),
         'rlrep_comm_destroy': (None, [vp]),
         'rlrep_stage_count': (i32, [vp, i32]),
@@ -151,7 +153,7 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.rlrep_abi_version() != 2:
+    if lib.rlrep_abi_version() != 3:
         raise RuntimeError('librlrep_hip.so ABI version mismatch')
     return lib, sig
 

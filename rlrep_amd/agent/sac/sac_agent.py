@@ -205,6 +205,12 @@ class SACAgent(object):
         # backward -> all-reduce -> apply form of every optimizer step.  RLREP_FORCE_DP=1 takes it with a one-rank process group too
         # (sac / vlsac: rehearses the RCCL stream / graph-segment machinery on a single GPU; tests/test_dp.py)
         self._dp = self.world_size > 1 or (self.ALG in ('sac', 'vlsac', 'diffsrsac') and bool(int(os.environ.get('RLREP_FORCE_DP', '0'))))
+        # every gradient slice of this agent is summed inside its optimizer launch (HipCore.fused_groups) and its backward needs no collective of
+        # its own: a data-parallel train() is then the SAME sequence of launches as on one GPU, and takes the single-GPU graph forms
+        # (one graph, or the two chains on two streams) -- nothing for the host to do between two optimizer steps
+        lay = self.core.layout
+        self._fused_all = (self.world_size > 1 and all(self._fused(g) for g in range(4) if lay.group_floats[g] > 0)
+                           and self.core.feature_exchange_count() == 0)
         self._inject = None
         self._pool = None
         self._next_key = {}
@@ -337,7 +343,9 @@ class SACAgent(object):
         actor steps of this call may still be in flight when it returns; everything that looks at them waits (`flush()`), including
         reading the returned info dict -- which therefore has to be read before the NEXT train() call to describe THIS one."""
         self.steps += 1
-        if self.use_graph and not self._dp:
+        if (self.steps & 255) == 0:
+            self.core.exchange_check()           # (a word in mapped host memory: no synchronisation)
+        if self.use_graph and (not self._dp or self._fused_all):
             if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
                 if self._prefer_sequential():
                     self.flush()
@@ -422,31 +430,19 @@ class SACAgent(object):
     def _feature_once(self, buffer, B, i, g):
         raise NotImplementedError
 
+    def _fused(self, group):
+        """The optimizer launch of `group` sums the ranks' gradients itself (rlrep_amd/comm.py, csrc/dp_pull.h): no collective to issue."""
+        return group in self.core.fused_groups
+
     def _allreduce(self, group, with_tail=False, pg=None):
         import torch.distributed as dist
+        if self._fused(group):
+            return
         lay = self.core.layout
         o, n = lay.group_offset[group], lay.group_floats[group]
         end = lay.grad_floats if with_tail else o + n
         view = self.core.grads[o:end]
-        one = self._oneshot(view, pg)
-        if one is not None:
-            self._collective(lambda: one.all_reduce(view))            # (plain kernel launches: they record into a hipGraph like any other stage)
-            return
         self._collective(lambda: dist.all_reduce(view, group=pg))
-
-    def _oneshot(self, view, pg):
-        """RLREP_ONESHOT_ALLREDUCE=1: the one-shot all-reduce over peer-mapped inboxes (rlrep_amd/comm.py) for gradient slices up
-        to RLREP_ONESHOT_MAX_MB (default 4) -- opt-in until it has been timed on a multi-GPU node; larger slices and the default go through
-        torch.distributed (RCCL).  The object is created at the first use: a collective, reached by every rank at the same all-reduce."""
-        if self.world_size <= 1 or os.environ.get('RLREP_ONESHOT_ALLREDUCE') != '1' or pg is not None:
-            return None
-        cap = int(float(os.environ.get('RLREP_ONESHOT_MAX_MB', '4')) * (1 << 20)) // 4
-        if view.numel() > cap or (view.data_ptr() & 15):
-            return None
-        if getattr(self, '_oneshot_comm', None) is None:
-            from rlrep_amd.comm import OneShotAllReduce
-            self._oneshot_comm = OneShotAllReduce(cap)
-        return self._oneshot_comm
 
     def _collective(self, fn):
         """Run a torch.distributed call now, or -- while a data-parallel train() is being captured -- either record it into the open
@@ -482,6 +478,8 @@ class SACAgent(object):
                     views = [buf[r * count:(r + 1) * count] for r in range(self.world_size)]
                     local = views[self.rank]
                     self._collective(lambda views=views, local=local: dist.all_gather(views, local))
+                elif kind == 3 and self._fused(self._group_of(off)):
+                    pass                                 # its group's optimizer launch reads every rank's arena itself
                 elif kind == 3:
                     # a slice of the gradient arena that is already final (diffsrsac: the nabla-mu head, 99 % of the bytes): its all-reduce is
                     # ISSUED here and travels under the rest of the backward; _wait_early_reduces() joins it before the optimizer launch
@@ -489,6 +487,13 @@ class SACAgent(object):
                     self._collective(lambda buf=buf: self._early_works.append(dist.all_reduce(buf, async_op=True)))
                 else:
                     self._collective(lambda buf=buf: dist.all_reduce(buf))
+
+    def _group_of(self, grad_offset):
+        lay = self.core.layout
+        for g in range(4):
+            if lay.group_floats[g] > 0 and lay.group_offset[g] <= grad_offset < lay.group_offset[g] + lay.group_floats[g]:
+                return g
+        return -1
 
     def _wait_early_reduces(self):
         def join():
@@ -500,6 +505,8 @@ class SACAgent(object):
     def _allreduce_rest(self, group):
         """All-reduce what the early (kind 3) exchanges of this backward left of `group`'s gradient slice, then join them."""
         import torch.distributed as dist
+        if self._fused(group):
+            return
         lay = self.core.layout
         lo, hi = lay.group_offset[group], lay.group_offset[group] + lay.group_floats[group]
         done = sorted(s for s in self._early_slices if s[0] >= lo and s[1] <= hi)
@@ -1091,6 +1098,7 @@ class SACAgent(object):
     def flush(self):
         """Finish the critic + actor steps of the last pipelined train() (no-op otherwise)."""
         self._looked = True
+        self.core.exchange_check()               # a peer that never arrived (bounded waits of the in-launch gradient exchange): raise, do not train on
         if self._pending == 2:                         # two-stream forms: the pair is already in flight on its own streams
             self._pending = False
             P = self._pipe

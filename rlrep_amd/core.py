@@ -4,6 +4,8 @@ torch is used for what the C ABI asks the caller to provide -- device memory (ar
 and index buffers), the current HIP stream -- and nothing else: no torch op runs on the update path.
 """
 import ctypes as C
+import os
+import warnings
 import weakref
 import numpy as np
 import torch
@@ -140,6 +142,22 @@ class HipCore:
         def carve(i, dtype):
             return self._block[skew + offs[i]:skew + offs[i] + sizes[i]].view(dtype)
         self.params, self.targets, self.grads = carve(0, torch.float32), carve(1, torch.float32), carve(2, torch.float32)
+        # Data parallel: the gradient arena moves into a block every peer has mapped (rlrep_amd/comm.py), and the optimizer launches sum the
+        # ranks' gradients themselves -- but only after the exchange has passed its probe on THIS set of ranks (same answer on every rank);
+        # otherwise the arena stays where it is and the agent all-reduces with torch.distributed between backward and apply, as before.
+        self.exchange, self.fused_groups = None, frozenset()
+        if int(world_size) > 1 and os.environ.get('RLREP_DP_FUSED', '1') != '0':
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                from .comm import GradientExchange
+                ex = GradientExchange(info.grad_floats)
+                if ex.probe():
+                    self.exchange, self.grads = ex, ex.arena[:info.grad_floats]
+                else:
+                    if dist.get_rank() == 0:
+                        warnings.warn('rlrep_amd: the in-launch gradient exchange did not pass its probe on this set of ranks '
+                                      f'(fine-grained block: {ex.fine_grained}, ranks on one device: {ex.same_device}); gradients go through torch.distributed')
+                    ex.close()
         self.exp_avg, self.exp_avg_sq = carve(3, torch.float32), carve(4, torch.float32)
         self.workspace = carve(5, torch.uint8)
         self.alpha_state = carve(6, torch.float64)     # log_alpha, m, v, step
@@ -151,6 +169,11 @@ class HipCore:
         torch.cuda.synchronize()
         check(lib.rlrep_agent_create(C.byref(self.dims), C.byref(self.hyper), C.byref(ar), _stream(), C.byref(h)), 'agent_create')
         self.h = h
+        if self.exchange is not None:
+            # gradient slices up to RLREP_DP_FUSED_MAX_MB are summed inside their optimizer launch; larger ones (diffsrsac's 198 MB nabla-mu
+            # group at Humanoid dims: bandwidth-bound, RCCL's ring is the right shape) keep the all-reduce between backward and apply
+            cap = int(float(os.environ.get('RLREP_DP_FUSED_MAX_MB', '4')) * (1 << 20)) // 4
+            self.fused_groups = frozenset(self.exchange.attach(self.h, cap))
         names = (C.c_char * 32 * METRIC_SLOTS)()
         lib.rlrep_metric_names(self.dims.alg, C.cast(names, C.c_void_p), METRIC_SLOTS)
         self.metric_names = [bytes(n).split(b'\0', 1)[0].decode() for n in names]
@@ -164,6 +187,10 @@ class HipCore:
                 torch.cuda.synchronize()
                 lib.rlrep_agent_destroy(self.h)
                 self.h = None
+            if getattr(self, 'exchange', None) is not None:
+                self.grads = None
+                self.exchange.close()
+                self.exchange = None
         except Exception:
             pass
 
@@ -203,6 +230,12 @@ class HipCore:
         out['log_alpha'] = self.alpha_state[0].detach().cpu().clone()
         self.chain_check()
         return out
+
+    def exchange_check(self):
+        """Raise if a wait of the in-launch gradient exchange has run out since the last check (a peer that never arrived: the affected
+        step is invalid).  A read of mapped host memory: no device synchronisation, cheap enough for every flush()."""
+        if self.exchange is not None:
+            self.exchange.status(raise_on_error=True, clear=True)
 
     def chain_check(self):
         """Raise if a persistent chain launch (csrc/xchain.hip) failed its device-side checks since the agent was created: a wait that

@@ -1846,6 +1846,24 @@ int32_t rlrep_build_flags(void) {
 
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
 int64_t rlrep_launch_counter(void) { return g_rl_launches; }
+// rlrep_comm_attach (comm.hip): from now on the optimizer launches of the attached groups carry the data-parallel exchange
+extern "C" int rl_agent_attach_dp(rlrep_agent* ag, const DpPull* proto, long long arena_floats, long long max_floats, int* attached_mask) {
+    if (!ag || !proto) return RLREP_ERR_ARG;
+    if (proto->world != ag->h.world_size) { rl_set_error("comm_attach: the comm spans %d ranks, the agent was created with world_size = %d", proto->world, ag->h.world_size); return RLREP_ERR_ARG; }
+    if (ag->a.grad_dev != proto->base[proto->rank]) { rl_set_error("comm_attach: the agent's gradient arena is not the comm's arena (create the agent with rlrep_comm_arena() as grad_dev)"); return RLREP_ERR_ARG; }
+    rlrep_layout_info info;
+    if (rlrep_layout(&ag->d, &info, nullptr, 0) != 0) return RLREP_ERR_ARG;
+    if (arena_floats < info.grad_floats) { rl_set_error("comm_attach: the comm's arena holds %lld floats, the gradient arena needs %lld", arena_floats, (long long)info.grad_floats); return RLREP_ERR_ARG; }
+    ag->dp_proto = *proto;
+    int mask = 0;
+    for (int g = 0; g < 4; ++g) {
+        const bool on = proto->world > 1 && ag->L.group_n[g] > 0 && ag->L.group_n[g] <= max_floats;
+        ag->dp_on[g] = on;
+        if (on) mask |= 1 << g;
+    }
+    if (attached_mask) *attached_mask = mask;
+    return 0;
+}
 int32_t rlrep_front_end_counts(int64_t* out4) {
     if (!out4) return RLREP_ERR_ARG;
     for (int q = 0; q < 4; ++q) out4[q] = g_rl_front[q];

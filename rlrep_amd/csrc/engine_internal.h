@@ -87,6 +87,9 @@ struct rlrep_agent {
     // xchain.hip: error word of the persistent chain launches (rlrep_chain_status) and the names of their stages (owned here: Stage::what is a
     // plain pointer)
     unsigned* xc_err = nullptr; std::deque<std::string> stage_names;
+    // data parallel inside the optimizer launches (rlrep_comm_attach, dp_pull.h): the gradient arena is a block every peer has mapped; the
+    // optimizer launch of an attached group sums its gradients over the ranks itself (channel = group)
+    DpPull dp_proto = DpPull(); bool dp_on[4] = {false, false, false, false};
 
     float* overridden(const std::string& n) const {
         if (!ov_base || n.compare(0, ov_prefix.size(), ov_prefix) != 0) return nullptr;
@@ -497,7 +500,9 @@ struct Builder {
                 a->snap_armed = false; a->snap_done = a->snap_set;
             }
             const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
-            return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, st);
+            DpPull dp = a->dp_proto;
+            dp.channel = group;
+            return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, a->dp_on[group] ? &dp : nullptr, st);
         }, what});
         tag(p, RLREP_ENGINE_OPTIMIZER, 0.0, 28.0 * (double)t.n + 12.0 * (double)(target ? pol_n : 0));     // read p, g, m, v; write p, m, v (+ target: read, read source, write)
     }
@@ -536,7 +541,7 @@ struct Builder {
         if (fin.empty()) return;
         const FinTask* fdev = upload(fin);
         const int nfin = (int)fin.size();
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, fdev, nfin, nullptr, nullptr, nullptr, st); }, what});
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_adam(nullptr, 0, fdev, nfin, nullptr, nullptr, nullptr, nullptr, st); }, what});
     }
 
     static FinTask fin_sum(const float* partials, int count, int stride, float scale, float* out) {

@@ -1,6 +1,7 @@
 // Kernel parameter blocks shared by the device code and the host-side program builder.
 #pragma once
 #include <stdint.h>
+#include "dp_pull.h"
 struct GroupCfg;
 
 struct SlotFill {
@@ -120,7 +121,9 @@ struct FinTask {
 // into the weight-gradient launch) the extra trailing workgroup of that launch.
 // torch/optim/adam.py::_single_tensor_adam operation order; SURVEY Appendix A.11/A.12
 #ifdef __HIPCC__
-__device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin, int lane) {
+// dp (data parallel, dp_pull.h): partial sums that live in the gradient arena (FIN_ALPHA's: the temperature gradient) are read from EVERY rank's
+// arena, in rank order -- the caller has passed the READY wait
+__device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin, int lane, const DpPull* dp = nullptr) {
     for (int q = 0; q < nfin; ++q) {
         const FinTask f = fin[q];
         if (f.kind == FIN_SUM) {
@@ -137,7 +140,12 @@ __device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin,
         } else if (f.kind == FIN_ALPHA) {
             // L_alpha = mean(exp(log_alpha) * c), c detached; d/dlog_alpha = alpha * mean(c); fp64 Adam (quirk Q1)
             float s = 0.f;
-            for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
+            if (dp) {
+                const long long toff = (long long)(f.partials - dp->base[dp->rank]);
+                for (int i = lane; i < f.count; i += 64) s += dp_sum1(*dp, toff + (long long)i * f.stride);
+            } else {
+                for (int i = lane; i < f.count; i += 64) s += f.partials[(size_t)i * f.stride];
+            }
             s = wave_sum(s);
             if (lane == 0) {
                 double* st = f.alpha_state;           // log_alpha, m, v, step

@@ -237,6 +237,7 @@ def test_hip_dp_two_ranks_match_global_batch_oracle(case):
 def _gpu_graph_worker(rank, world, port, q):
     from fixture_io import Case
     from test_hip_parity import make_agent, make_buffer
+    os.environ['RLREP_DP_FUSED'] = '0'       # this test is about the torch.distributed form: graph segments around eager all-reduces (the in-launch exchange: tests/test_comm.py)
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     c = Case('vlsac_tiny')
@@ -276,6 +277,7 @@ def _gpu_pipe_worker(rank, world, port, q, pipelined):
     from fixture_io import Case
     from test_hip_parity import make_agent, make_buffer
     os.environ['RLREP_PIPELINE_DP'] = '1' if pipelined else '0'
+    os.environ['RLREP_DP_FUSED'] = '0'       # the torch.distributed forms (the in-launch exchange takes the single-GPU graph forms: tests/test_comm.py)
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     c = Case('vlsac_tiny')
@@ -416,6 +418,7 @@ def _gpu_pipe_big_worker(rank, world, port, q, pipelined):
     from rlrep_amd.utils.buffer import ReplayBuffer
     from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
     os.environ['RLREP_PIPELINE_DP'] = '1' if pipelined else '0'
+    os.environ['RLREP_DP_FUSED'] = '0'       # the torch.distributed forms (the in-launch exchange takes the single-GPU graph forms: tests/test_comm.py)
     try:
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
         torch.cuda.set_device(0)
