@@ -103,7 +103,7 @@ def dominant_kernel_roofline(agent, B, F, H, reps=200):
     _lib.lib.rlrep_nc_fwd_plan(4, B, F, H, *[C.byref(o) for o in plan])
     x3 = plan[0].value == 1
     # bf16x3 engine: six bf16 MFMA flops are executed per algorithmic fp32 flop, so the ceiling for ALGORITHMIC flops is the dense
-    # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_NO_X3) it is the fp32 MFMA peak
+    # bf16 peak / 6 (417 TF); on the fp32-MFMA engine (RLREP_DISABLE=x3) it is the fp32 MFMA peak
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x3 else FP32_MFMA_PEAK_TFLOPS
     # the launcher's choice (noisecritic.hip rl_launch_nc_fwd): the 32x32x16 one-role kernel for a 128-wide tile
     kname = ('nc_fwd_x3q_kernel' if plan[2].value == 128 else 'nc_fwd_x3_kernel<%d>' % (plan[2].value // 64)) if x3 else 'nc_fwd_kernel'

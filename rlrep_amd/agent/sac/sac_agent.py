@@ -13,6 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from rlrep_amd.utils import switches as _sw
 from rlrep_amd.core import HipCore
 from rlrep_amd.utils import util
 from rlrep_amd.utils.streams import raw_stream as _raw_stream, current_stream as _current_stream, on_stream as _on_stream
@@ -193,7 +194,7 @@ class SACAgent(object):
         self._early_works, self._early_slices = [], []       # async gradient all-reduces issued inside a backward (exchange kind 3)
         self._n_captured_colls = 0
         self._fresh_dp_graph = False
-        self.use_graph_dp = bool(int(os.environ.get('RLREP_GRAPH_DP', '1')))
+        self.use_graph_dp = not _sw.off('graph_dp')
         # sequential data-parallel form on the RCCL backend: the gradient all-reduces may be CAPTURED into the hipGraph of train() (one graph
         # instead of 7 segments + 6 eager calls of ~14 us of host time each; one stream, one communicator: the collectives of a replay
         # are issued in program order, identical on every rank).  That form has only ever run over a ONE-rank RCCL group (the only RCCL
@@ -224,8 +225,8 @@ class SACAgent(object):
         # iterations/s).  Both forms perform identical updates (tests), so train() picks per call: three calls in a row whose pair was waited
         # for before the next call -> the sequential graph; two calls in a row with nothing looked at in between -> back to the two chains.
         self._pipeline_mode = int(os.environ.get('RLREP_PIPELINE', '2'))          # (read once: the per-call paths do not touch os.environ)
-        self._stamp_on = os.environ.get('RLREP_STAMP', '0') == '1'
-        self._adaptive = bool(int(os.environ.get('RLREP_ADAPTIVE_PIPELINE', '1'))) and hip_kwargs.get('adaptive', 'pipeline' not in hip_kwargs)      # (an explicit pipeline= argument pins the form)
+        self._stamp_on = _sw.opt('stamp') is not None
+        self._adaptive = not _sw.off('adaptive_pipeline') and hip_kwargs.get('adaptive', 'pipeline' not in hip_kwargs)      # (an explicit pipeline= argument pins the form)
         self._looked, self._n_looked, self._n_b2b = False, 0, 0
         # two communicators in flight (one per chain): never met a second real rank on hardware, so it is opt-in (RLREP_PIPELINE_DP=1);
         # the default N > 1 form is the sequential one (one communicator, program order identical on every rank)
@@ -432,7 +433,7 @@ class SACAgent(object):
 
     def _fused(self, group):
         """The optimizer launch of `group` sums the ranks' gradients itself (rlrep_amd/comm.py, csrc/dp_pull.h): no collective to issue."""
-        return group in self.core.fused_groups
+        return group in getattr(self.core, 'fused_groups', ())
 
     def _allreduce(self, group, with_tail=False, pg=None):
         import torch.distributed as dist
@@ -531,7 +532,7 @@ class SACAgent(object):
         ne = sum(int(np.prod(sh)) for _, sh in eps_specs)
         ipool = self._buf('pool_idx', (ni,), torch.int32)
         epool = self._buf('pool_eps', (ne,))
-        if g and os.environ.get('RLREP_NO_PROLOGUE'):
+        if g and _sw.off('prologue'):
             self.core.fill_indices_dev(ipool, buffer.size_dev(), self._seed, 1 << 40)
             self.core.fill_normal_dev(epool, 1.0, self._seed, 2 << 40)
         elif g:
@@ -615,7 +616,7 @@ class SACAgent(object):
         self._pool = None
         self._next_key = {}
         self._early_key = None
-        if self._inject is None and g and not os.environ.get('RLREP_NO_PROLOGUE'):
+        if self._inject is None and g and not _sw.off('prologue'):
             self._fill_pools(buffer, B, g)          # includes begin_train (rlrep_train_prologue)
         else:
             c.begin_train()
@@ -649,11 +650,11 @@ class SACAgent(object):
     @contextlib.contextmanager
     def _managed_images(self):
         """Around the capture of a single-GPU train() graph: the critic steps recorded inside do not carry the image-refresh launch."""
-        # OPT-IN (RLREP_MANAGED_IMAGES=1).  Measured on MI355X, three alternations in one call (profiles/r04_ab_chain_cuts.txt): the launch it
+        # OPT-IN (RLREP_ENABLE=managed_images).  Measured on MI355X, three alternations in one call (profiles/r04_ab_chain_cuts.txt): the launch it
         # takes off the critic / actor chain is worth +0.3 % in the sequential form and COSTS 2.9 % in the two-chain form (3 510 -> 3 380
         # train()/s): the chains are balanced, and the critic / actor chain starting 5 us earlier shifts its chip-filling noise-critic launches
         # onto other feature-chain launches.  The default keeps the refresh launch at the head of every critic step.
-        on = os.environ.get('RLREP_MANAGED_IMAGES') == '1' and self.core.images_managed(True)
+        on = _sw.opt('managed_images') is not None and self.core.images_managed(True)
         self._img_on = self._img_on or on
         try:
             yield
@@ -745,7 +746,7 @@ class SACAgent(object):
                     # every rank builds its graph at the same train() call, so this is a matched collective
                     dist.all_reduce(torch.zeros(1, device=self.core.device))
                     torch.cuda.synchronize()
-                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0'      # see _train_graph
+                self._hist = not _sw.off('info_history')      # see _train_graph
                 self.core.history(self._hist)
                 try:
                     with torch.cuda.stream(s):
@@ -806,7 +807,7 @@ class SACAgent(object):
         return self._pool['eps_crit'], self._pool['eps_act']
 
     def _stamp(self, tag):
-        """RLREP_STAMP=1 (diagnostics, tools/exp/chain_stamps.py): a one-thread launch that dates this point of the chain on the device."""
+        """RLREP_ENABLE=stamp (diagnostics, tools/exp/chain_stamps.py): a one-thread launch that dates this point of the chain on the device."""
         if not self._stamp_on:
             return
         from rlrep_amd._lib import lib as _l, check as _check
@@ -819,7 +820,7 @@ class SACAgent(object):
         (train t-nset) must have finished.  Waited for on the HOST: a wait packet in the feature stream costs ~12 us of its critical path
         (2 816 -> 2 917 train()/s); the host then runs at most nset calls ahead of the device.  With nset = 2 that wait ends about one
         graph-launch latency before the running feature chain does and the feature queue idles between calls; the third set
-        (RLREP_DEFER_SETS, default 3) removes it."""
+        (RLREP_ENABLE=defer_sets=N, default 3) removes it."""
         P['ev_ca'][k].synchronize()
 
     def _order_buffer_writes(self):
@@ -893,7 +894,7 @@ class SACAgent(object):
                     from rlrep_amd._lib import lib as _l, front_end_counts as _fe
                     fs, ca = [], []
                     n0, f0 = _l.rlrep_launch_counter(), _fe()
-                    nset = min(c.defer_supported(), max(2, int(os.environ.get('RLREP_DEFER_SETS', '3'))))
+                    nset = min(c.defer_supported(), max(2, int(_sw.opt('defer_sets', '3'))))
                     for k in range(nset):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, stream=s1):
@@ -1127,8 +1128,8 @@ class SACAgent(object):
                 g = torch.cuda.CUDAGraph()
                 n0, f0 = _l.rlrep_launch_counter(), _fe()
                 # the call's metrics are filed in the library's history ring by the last launch of the graph (rlrep_history) and fetched when the
-                # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_INFO_HISTORY=0: a clone per call.
-                self._hist = os.environ.get('RLREP_INFO_HISTORY', '1') != '0'
+                # returned dict is read: no snapshot launch per call (sac: 10 120 -> 10 600 train()/s).  RLREP_DISABLE=info_history: a clone per call.
+                self._hist = not _sw.off('info_history')
                 self.core.history(self._hist)
                 try:
                     with self._managed_images(), torch.cuda.graph(g, stream=s):

@@ -170,9 +170,10 @@ class HipCore:
         check(lib.rlrep_agent_create(C.byref(self.dims), C.byref(self.hyper), C.byref(ar), _stream(), C.byref(h)), 'agent_create')
         self.h = h
         if self.exchange is not None:
-            # gradient slices up to RLREP_DP_FUSED_MAX_MB are summed inside their optimizer launch; larger ones (diffsrsac's 198 MB nabla-mu
+            # gradient slices up to 4 MB (RLREP_ENABLE=dp_fused_mb=N) are summed inside their optimizer launch; larger ones (diffsrsac's 198 MB nabla-mu
             # group at Humanoid dims: bandwidth-bound, RCCL's ring is the right shape) keep the all-reduce between backward and apply
-            cap = int(float(os.environ.get('RLREP_DP_FUSED_MAX_MB', '4')) * (1 << 20)) // 4
+            from .utils import switches as _sw
+            cap = int(float(_sw.opt('dp_fused_mb', '4')) * (1 << 20)) // 4
             self.fused_groups = frozenset(self.exchange.attach(self.h, cap))
         names = (C.c_char * 32 * METRIC_SLOTS)()
         lib.rlrep_metric_names(self.dims.alg, C.cast(names, C.c_void_p), METRIC_SLOTS)

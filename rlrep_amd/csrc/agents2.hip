@@ -231,8 +231,8 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         // quirk Q6: the score matrix is the GEMM phi mu'^T, not the [B,B,F] broadcast
         if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 1, ZMall, (int64_t)B * F, (int64_t)rank * B * F});
         // rhat = theta . phi + b (a [B, 1] product) is computed by the InfoNCE launch itself: beside a score matrix that routes to the LDS-tiled engine it was a
-        // 16-row-engine launch of its own on the dependent chain (8 us per feature step at F = 2048); RLREP_NO_FOLD_THETA keeps it
-        const bool theta_in_loss = !getenv("RLREP_NO_FOLD_THETA");
+        // 16-row-engine launch of its own on the dependent chain (8 us per feature step at F = 2048); RLREP_DISABLE=fold_theta keeps it
+        const bool theta_in_loss = !rl_off("fold_theta");
         if (theta_in_loss) b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE)}, "score matrix");
         else
         b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE),
@@ -522,7 +522,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         c2.X = MU ? MU + BF : nullptr; c2.ldX = F; c2.w = C; c2.out = V; c2.rows = B; c2.F = F;
         // theta.l's gradient (sum_i drhat_i phi_i and sum_i drhat_i over the first batch) is a weighted column sum too: it rides here instead of
         // being a 16-row-engine launch of its own behind the weight-gradient launch (7 us per feature step)
-        const bool theta_here = !getenv("RLREP_NO_FOLD_THETA");
+        const bool theta_here = !rl_off("fold_theta");
         if (theta_here) { c2.X2 = PHI; c2.ldX2 = F; c2.w2 = DRH; c2.out2 = ag->G("theta.l.weight"); c2.outb2 = ag->G("theta.l.bias"); c2.rows2 = B; }
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c2, st); }, "v = sum_k c_k mu_r,k"});
         if (ag->h.world_size > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, V, (int64_t)F, 0});
@@ -542,7 +542,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
             for (int l = 0; l <= mu.depth; ++l) t.push_back(mlp_dw(ag, mu, mf, l, S2, KE));
             if (!theta_here) t.push_back(Builder::dw(DRH, 1, 1, PHI, F, F, B, ag->G("theta.l.weight"), F, ag->G("theta.l.bias")));
             // the split-K partials of these gradients (K = 2B rows) are summed by the optimizer launch below: no finishing launch in the step
-            if (!getenv("RLREP_NO_FOLD_DWFIN")) b.fold_group = 0;
+            if (!rl_off("fold_dwfin")) b.fold_group = 0;
             b.dw_stage(p, t, "feature dW");
             b.fold_group = -1;
         }
@@ -603,8 +603,8 @@ void build_diffsrsac(Builder& b, rlrep_agent* ag) {
         // only dU (just written) and the last hidden activation -- so it is taken FIRST, and exchange 3 tells the caller that the slice
         // [head.weight .. end of group 3] of the gradient arena is complete: its all-reduce can travel while the head's dX (202 GFLOP), the
         // rest of the backward and the small weight gradients run ("198 MB => RCCL, overlapped with backward").  The caller
-        // reduces the remainder of the group after the backward.  RLREP_NO_BUCKET_DP: one all-reduce after the whole backward, as before.
-        const bool head_first = (ag->h.world_size > 1 || getenv("RLREP_FORCE_DP")) && nm.depth >= 1 && !getenv("RLREP_NO_BUCKET_DP");      // (RLREP_FORCE_DP: the one-rank RCCL rehearsal)
+        // reduces the remainder of the group after the backward.  RLREP_DISABLE=bucket_dp: one all-reduce after the whole backward, as before.
+        const bool head_first = (ag->h.world_size > 1 || getenv("RLREP_FORCE_DP")) && nm.depth >= 1 && !rl_off("bucket_dp");      // (RLREP_FORCE_DP: the one-rank RCCL rehearsal)
         if (head_first) {
             b.dw_stage(p, {mlp_dw(ag, nm, nf, nm.depth, XN, S + 1)}, "nabla-mu head dW");
             const LT& hw = ag->L.get(nm.name(nm.depth) + ".weight");

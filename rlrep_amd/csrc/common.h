@@ -2,6 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// diagnostic switches (engine.hip): a token listed in RLREP_DISABLE / the value of a token of RLREP_ENABLE ("1" when listed bare; nullptr: not
+// listed), as parsed at the last library entry (rlrep_layout / rlrep_agent_create / rlrep_gemm*: rl_switches_read) -- never read on a launch path
+void rl_switches_read();
+bool rl_off(const char* token);
+const char* rl_opt(const char* token);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

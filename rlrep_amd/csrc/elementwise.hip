@@ -464,8 +464,12 @@ __device__ __forceinline__ void copy_segs_body(const CopySegs& p, int blk, int n
 // group's scalars with its first instructions, instead of after three dependent round trips (task table -> record -> group record).
 // hdr = adam_blocks | vec_ok << 30 (vec_ok: every arena pointer 16-byte aligned and the Polyak sub-range on multiples of four floats).
 // (the body of an optimizer block; `bid` = block index within the optimizer part of the launch)
+// DP (compile time): the data-parallel instantiation (dp_pull.h).  A run-time switch would put the prefetched loads of p / g / m / v into
+// control-flow diamonds (hipcc drains vmcnt at their merges): the single-GPU launch must not pay for code it never runs (measured: 5.4 -> 11.7 us).
+template <bool DP>
 __device__ __forceinline__ void adam_elems(const int bid, float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
                                            const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, const AdamTask& t, const AdamSnap& snap, const DpPull& dp);
+template <bool DP>
 __device__ __forceinline__ void adam_block(const int bid, float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
                                            const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, const AdamTask& t,
                                            const FinTask* __restrict__ fin, int nfin, const SlotFill& sf, int fill_blocks, const SlotFill& sf2, int fill2_blocks,
@@ -473,7 +477,7 @@ __device__ __forceinline__ void adam_block(const int bid, float* __restrict__ ap
     const int adam_blocks = hdr & 0x3fffffff;
     // Data parallel (dp.world > 1, dp_pull.h): the optimizer blocks and the trailing block wait for the peers' gradients, read every rank's arena in
     // rank order where they used to read one gradient, and the last of them to finish runs the DONE handshake.  The riders below take no part.
-    const bool dpon = dp.world > 1;
+    constexpr bool dpon = DP;
     if (bid > adam_blocks + fill_blocks + fill2_blocks) {       // the small segments of a folded snapshot (AdamSnap)
         copy_segs_body(snap.segs, bid - adam_blocks - fill_blocks - fill2_blocks - 1, snap_blocks);
         return;
@@ -493,21 +497,22 @@ __device__ __forceinline__ void adam_block(const int bid, float* __restrict__ ap
     if (bid == adam_blocks) {
         // trailing block: finalises the step's metrics / temperature
         unsigned dpe = 0;
-        if (dpon) dpe = dp_begin(dp, false, true);
+        if constexpr (dpon) dpe = dp_begin(dp, false, true);
         if (threadIdx.x < 64) finalize_tasks(fin, nfin, threadIdx.x, dpon ? &dp : nullptr);
-        if (dpon) dp_end(dp, dpe, true);
+        if constexpr (dpon) dp_end(dp, dpe, true);
         return;
     }
     unsigned dpe = 0;
-    if (dpon) dpe = dp_begin(dp, bid == 0, true);
-    adam_elems(bid, ap, agr, am, av, agrp, atarget, an, hdr, t, snap, dp);
-    if (dpon) dp_end(dp, dpe, true);
+    if constexpr (dpon) dpe = dp_begin(dp, bid == 0, true);
+    adam_elems<DP>(bid, ap, agr, am, av, agrp, atarget, an, hdr, t, snap, dp);
+    if constexpr (dpon) dp_end(dp, dpe, true);
 }
 
 // the elements of one optimizer block (thread-level early exits inside: the caller brackets it with the data-parallel handshake)
+template <bool DP>
 __device__ __forceinline__ void adam_elems(const int bid, float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
                                            const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, const AdamTask& t, const AdamSnap& snap, const DpPull& dp) {
-    const bool dpon = dp.world > 1;
+    constexpr bool dpon = DP;
     // (the arena pointers and the group record are preloaded arguments: these loads go out before the record `t` has arrived)
     const long long i = ((long long)bid * 256 + threadIdx.x) * 4;
     if (i >= an) return;
@@ -515,12 +520,12 @@ __device__ __forceinline__ void adam_elems(const int bid, float* __restrict__ ap
     const bool vec = (i + 4 <= an) && ((hdr >> 30) & 1);
     f32x4 g = {0.f, 0.f, 0.f, 0.f}, p4 = g, m4 = g, v4 = g;
     if (vec) {
-        g = *reinterpret_cast<const f32x4*>(agr + i);
+        if constexpr (!dpon) g = *reinterpret_cast<const f32x4*>(agr + i);
         p4 = *reinterpret_cast<f32x4*>(ap + i); m4 = *reinterpret_cast<f32x4*>(am + i); v4 = *reinterpret_cast<f32x4*>(av + i);
     }
     asm volatile("" ::: "memory");      // (pin: the loads above stay ahead of the reads of the record below)
-    const long long goff = dpon ? (long long)(agr - dp.base[dp.rank]) : 0;     // the group slice inside the shared arena (same layout on every rank)
-    if (dpon && vec) g = dp_sum4(dp, goff + i);
+    long long goff = 0;                                                        // the group slice inside the shared arena (same layout on every rank)
+    if constexpr (dpon) { goff = (long long)(agr - dp.base[dp.rank]); if (vec) g = dp_sum4(dp, goff + i); }
     const int ti = 0;
     // ranges whose optimizer ran in the weight-gradient epilogues (FLAG_ADAM): nothing to do here
     if (t.nskip > 0 && i >= t.skip_off[0] && i < t.skip_off[0] + t.skip_n[0]) return;
@@ -609,7 +614,9 @@ __device__ __forceinline__ void adam_elems(const int bid, float* __restrict__ ap
         for (int s = 0; s < 4 && i + s < an; ++s) {
             const long long e = i + s;
             float* tp = (pol_on && e >= t.pol_off && e < t.pol_off + t.pol_n) ? atarget + (e - t.pol_off) : nullptr;
-            adam_elem(sc, dpon ? dp_sum1(dp, goff + e) : agr[e], ap + e, am + e, av + e, tp);
+            float ge;
+            if constexpr (dpon) ge = dp_sum1(dp, goff + e); else ge = agr[e];
+            adam_elem(sc, ge, ap + e, am + e, av + e, tp);
             if (snap.on && ti == 0 && e >= snap.off && e < snap.off + snap.n) snap.block[e - snap.off] = snap.which == 0 ? ap[e] : atarget[e - t.pol_off];
             for (int q = 0; t.sh && q < t.nsh; ++q) {
                 const ShadowEnt se = t.sh[q];
@@ -629,11 +636,12 @@ __device__ __forceinline__ void adam_elems(const int bid, float* __restrict__ ap
     }
 }
 
+template <bool DP>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ ap, const float* __restrict__ agr, float* __restrict__ am, float* __restrict__ av,
                                                    const GroupCfg* __restrict__ agrp, float* __restrict__ atarget, int an, int hdr, AdamTask t,
                                                    const FinTask* __restrict__ fin, int nfin, SlotFill sf, int fill_blocks, SlotFill sf2, int fill2_blocks, AdamSnap snap, int snap_blocks, DpPull dp) {
     __builtin_amdgcn_s_setprio(3);      // small launch on a latency-critical chain (see gemm16_kernel)
-    adam_block(blockIdx.x, ap, agr, am, av, agrp, atarget, an, hdr, t, fin, nfin, sf, fill_blocks, sf2, fill2_blocks, snap, snap_blocks, dp);
+    adam_block<DP>(blockIdx.x, ap, agr, am, av, agrp, atarget, an, hdr, t, fin, nfin, sf, fill_blocks, sf2, fill2_blocks, snap, snap_blocks, dp);
 }
 
 // The optimizer launch of feature step k AND the first launch of feature step k + 1: blocks [0, gtiles) are 16 x 16 tiles of the
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(256) void adam_l1_kernel(float* __restrict__ ap, co
         return;
     }
     SlotFill none2 = SlotFill(); AdamSnap nosnap = AdamSnap(); DpPull nodp = DpPull();
-    adam_block(bid - gtiles, ap, agr, am, av, agrp, atarget, an, hdr, t, fin, nfin, sf, fill_blocks, none2, 0, nosnap, 0, nodp);
+    adam_block<false>(bid - gtiles, ap, agr, am, av, agrp, atarget, an, hdr, t, fin, nfin, sf, fill_blocks, none2, 0, nosnap, 0, nodp);
 }
 
 __global__ __launch_bounds__(256) void polyak_kernel(PolyakTask t) {
@@ -789,8 +797,12 @@ extern "C" int rl_launch_adam(const AdamTask* task, int adam_blocks, const FinTa
     if (t.nslab > 0 && (!vec_ok || (t.n & 3))) return -6;          // (the builder folds split-K partials in only for groups on the 16-byte path)
     for (int q = 0; q < t.nslab; ++q) if (t.slabs[q].splits < 1 || t.slabs[q].splits > 16) return -6;
     const int hdr = adam_blocks | (vec_ok ? (1 << 30) : 0);
-    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, t,
-                       fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb, dpv);
+    if (dpv.world > 1)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, t,
+                           fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb, dpv);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(adam_blocks + 1 + fb + fb2 + sb), dim3(256), 0, st, t.p, t.g, t.m, t.v, t.grp, t.target, (int)t.n, hdr, t,
+                           fin, nfin, sf ? *sf : none, fb, sf2 ? *sf2 : none, fb2, snap ? *snap : nosnap, sb, dpv);
     return (int)hipGetLastError();
 }
 // optimizer launch of one group + the two first-layer tasks of the NEXT feature step as leading tiles (adam_l1_kernel); sf: the gather of that

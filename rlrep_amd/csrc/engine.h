@@ -55,6 +55,11 @@ int rl_launch_shadow(const ShadowEnt* sh_dev, int nsh, int ntiles, const float* 
 }
 
 void rl_set_error(const char* fmt, ...);
+// diagnostic switches (engine.hip): token listed in RLREP_DISABLE / value of a token of RLREP_ENABLE ("1" when listed bare; nullptr: not listed),
+// as parsed at the last library entry (rl_switches_read)
+void rl_switches_read();
+bool rl_off(const char* token);
+const char* rl_opt(const char* token);
 
 // metric slots (union over the agents; names per agent in rlrep_metric_names)
 enum Metric : int {
@@ -133,7 +138,7 @@ struct Workspace {
 // process-wide count of kernel launches issued by the library (rlrep_launch_counter: bench.py counts the launches a captured train() holds)
 extern long long g_rl_launches;
 extern long long g_rl_front[4];                 // gemm16.hip: launches per front end (fast, fast4, fastpre, record)
-extern "C" void rl_gemm16_read_env();           // gemm16.hip: RLREP_GEMM16_{NO_FAST,GENERIC,TRACE}, read at agent creation
+extern "C" void rl_gemm16_read_env();           // gemm16.hip: RLREP_DISABLE=gemm16_fast / gemm16_spec, RLREP_ENABLE=gemm16_trace, read at agent creation
 // engine / flops / bytes: what rlrep_stage_info reports (include/rlrep.h RLREP_ENGINE_*: which kernel family the stage launches, the
 // ALGORITHMIC flops (2 * MAC) of its products and the bytes of their operands and results, each counted once)
 struct Stage { std::function<int(hipStream_t)> run; const char* what; int engine = 0; double flops = 0.0, bytes = 0.0; };

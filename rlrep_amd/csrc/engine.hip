@@ -14,6 +14,31 @@ void rl_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 
+// ---- diagnostic switches (engine.h: rl_off / rl_opt) ---------------------------------------------------------------------------------
+// TWO environment variables, comma-separated tokens, parsed when the library is entered through rlrep_layout / rlrep_agent_create / rlrep_gemm*
+// (never on a launch path): RLREP_DISABLE lists default mechanisms to switch off (every one of them has an equivalence test that compares the two
+// forms), RLREP_ENABLE lists opt-in ones, optionally with a value (token=value).  INTEGRATION.md has the table.
+static std::map<std::string, std::string> g_sw_off, g_sw_on;
+static void sw_parse(const char* env, std::map<std::string, std::string>& m) {
+    m.clear();
+    const char* e = getenv(env);
+    if (!e) return;
+    std::string s(e), tok;
+    s.push_back(',');
+    for (char ch : s) {
+        if (ch == ',' || ch == ' ' || ch == ';') {
+            if (!tok.empty()) {
+                const size_t eq = tok.find('=');
+                if (eq == std::string::npos) m[tok] = "1"; else m[tok.substr(0, eq)] = tok.substr(eq + 1);
+                tok.clear();
+            }
+        } else tok.push_back(ch);
+    }
+}
+void rl_switches_read() { sw_parse("RLREP_DISABLE", g_sw_off); sw_parse("RLREP_ENABLE", g_sw_on); rl_gemm16_read_env(); }
+bool rl_off(const char* token) { return g_sw_off.count(token) != 0; }
+const char* rl_opt(const char* token) { auto it = g_sw_on.find(token); return it == g_sw_on.end() ? nullptr : it->second.c_str(); }
+
 // ================================================================================================
 // layout (names = reference state_dict keys; see oracle/shapes.py for the reference order)
 // ================================================================================================
@@ -111,7 +136,7 @@ void policy_fwd_stage(Program& p, rlrep_agent* ag, const ActorBufs& ab, float* a
 }
 
 // the tanh-Gaussian sampling runs in the head GEMM's epilogue when [mu | rho] fits one 16-column tile
-bool policy_fusable(const rlrep_agent* ag) { return 2 * ag->d.action_dim <= 16 && !getenv("RLREP_NO_FUSE_POLICY"); }
+bool policy_fusable(const rlrep_agent* ag) { return 2 * ag->d.action_dim <= 16 && !rl_off("fuse_policy"); }
 GemmTask policy_head_task(rlrep_agent* ag, const ActorBufs& ab, float* act, int ld_act, int dyn_flag) {
     GemmTask head = actor_l(ag, 2, nullptr, 0, ab);
     head.epi = EPI_FWD_POLICY; head.n0 = ag->d.action_dim; head.y0 = act; head.ldx0 = ld_act; head.y1 = ab.logp; head.flags |= dyn_flag;
@@ -134,7 +159,7 @@ void actor_head_stage(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& 
 void actor_backward(Builder& b, Program& p, rlrep_agent* ag, const ActorBufs& ab, const float* X, int ldx,
                            const float* act, int ld_act, GemmTask action_dx) {
     const int S = ag->d.state_dim, A = ag->d.action_dim, Ha = ag->d.actor_hidden_dim, B = ag->B;
-    if (A <= 16 && !getenv("RLREP_NO_FUSE_POLICY")) {
+    if (A <= 16 && !rl_off("fuse_policy")) {
         action_dx.epi = EPI_DX_POLICYBWD; action_dx.n0 = A; action_dx.x0 = ab.AO; action_dx.x1 = act; action_dx.ldx1 = ld_act;
         action_dx.y0 = ab.Ghead; action_dx.dptr = ag->a.alpha_state_dev; action_dx.s0 = ag->inv_batch(); action_dx.flags |= FLAG_DYN_EPS;
         b.dx_stage(p, {action_dx}, "dx(action) -> dL/d[mu|rho]");
@@ -177,7 +202,7 @@ void update_target_program(rlrep_agent* ag, const std::string& first_src, const 
 }
 // critic Adam with the target update folded in (same Polyak, same period gate, run by the Adam launch's own lanes)
 void critic_apply_folded(Builder& b, rlrep_agent* ag, const std::string& first_dst, std::vector<FinTask> fins, Program* into, const int* steps) {
-    if (!into && getenv("RLREP_NO_FOLD_TARGET")) return;
+    if (!into && rl_off("fold_target")) return;
     float* dst = ag->a.target_dev ? ag->a.target_dev + ag->L.get(first_dst).off : nullptr;
     b.adam(into ? *into : ag->critic_apply_f, 1, ag->h.lr_critic, dst, ag->L.group_off[1], ag->L.group_n[1], ag->h.tau, fins, "adam critic + polyak critic",
            steps ? steps : ag->steps, ag->h.target_update_period);
@@ -208,7 +233,7 @@ static void build_sac(Builder& b, rlrep_agent* ag) {
     // ---- critic step ----
     // hoist: the variant that also carries the forward half of the FOLLOWING actor step (policy on s): its three layers read nothing the
     // critic update writes, and as extra tasks of launches that exist anyway they take three launches off train() (rlrep_prefetch_policy)
-    const bool can_hoist = policy_fusable(ag) && !getenv("RLREP_NO_HOIST");
+    const bool can_hoist = policy_fusable(ag) && !rl_off("hoist");
     auto critic_program = [&](Program& p, bool hoist, bool emit_apply) {
         if (hoist) {
             b.fwd_stage(p, {actor_l(ag, 0, s0.XF2, SA, ab), actor_l(ag, 0, s0.XFpi, SA, ab_pi)}, "actor.l1(s') actor.l1(s)");
@@ -324,7 +349,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     // the Gaussian heads of encoder and f and vae_mid as ONE launch (heads_vae_kernel: a 16 x 16 tile per workgroup, one KL partial each;
     // +3 % against the heads launch + an elementwise vae_mid launch, which is gone)
     // dec.heads + mse inside the dec.l1 dX launch (FLAG_PRE_MSE): needs the 16-byte-aligned rows its first phase loads, K1 = S + 1 <= 32
-    const bool fold_mse = !rl_rowprog_enabled() && !Builder::chain_enabled() && (Hv & 3) == 0 && S + 1 <= 32 && !getenv("RLREP_NO_FOLD_MSE") && !getenv("RLREP_NO_FUSE_DX") &&
+    const bool fold_mse = !rl_rowprog_enabled() && !Builder::chain_enabled() && (Hv & 3) == 0 && S + 1 <= 32 && !rl_off("fold_mse") && !rl_off("fuse_dx") &&
                           ((B + 15) / 16) * ((F + 15) / 16) < 384 * 2;
     const int tiles_vm = ((B + 15) / 16) * ((F + 15) / 16);
     const int nblk_kl = tiles_vm, nblk_mse_tiles = ((B + 15) / 16) * ((S + 1 + 15) / 16);   // mse partials: one pair per dec.heads tile
@@ -343,7 +368,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     int* rp_flags = (int*)ws.alloc(sizeof(int) * 2 * nrb);
     if (!b.dry && rp_flags && b.ws.ok()) (void)hipMemset(rp_flags, 0, sizeof(int) * 2 * nrb);
     auto rp_feature = [&](RpAsm& A_, bool early) {
-        const bool pair = !getenv("RLREP_ROWPROG_SINGLE");
+        const bool pair = !rl_off("rowprog_pair");
         auto Wp = [&](const char* n) { return ag->P(n); };
         const bool useT = ag->nsh[0] > 0;
         // forward layer `name`: from the transposed shadow when the agent keeps one (wide layers), else from W itself
@@ -444,12 +469,12 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             }
         }
     };
-    // OPT-IN (RLREP_ROWPROG=1): measured on MI355X at the headline dimensions the fused launch takes 91-95 us against 44 us (stages timed
+    // OPT-IN (RLREP_ENABLE=rowprog): measured on MI355X at the headline dimensions the fused launch takes 91-95 us against 44 us (stages timed
     // alone) / ~57 us (in the dependent chain) for the nine launches it replaces -- one CU per 16-row block ingests every weight matrix
     // (256 KB per 256 x 256 layer at ~50-65 GB/s per CU) and runs fp32 MFMA at 41-53 cycles per instruction: 5-6 us per layer and row
     // block, i.e. a dependent launch.  DESIGN.md section 5.2 has the per-op timeline.
 
-    // ---- cluster form (RLREP_ROWPROG=2): C workgroups per row block and chain, member m owns a column slice of every layer and the
+    // ---- cluster form (RLREP_ENABLE=rowprog=2): C workgroups per row block and chain, member m owns a column slice of every layer and the
     // members complete each other's vectors through tagged 8-byte granules in global memory (RP_XCHG; tools/exp/cluster_hop.hip: 1.9-2.4 us
     // per hop with 256 workgroups exchanging at once).  Masks come from the activations in global memory (each member wrote its own slice).
     int CS = 0;                                   // cluster size: 0 = not applicable
@@ -650,8 +675,8 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
                                  nft ? nullptr : Tw("f_target.l1.weight"), nft ? nullptr : Tw("f_target.l1.bias"))}, fuse_l1 ? "feature dW (+ adam l1)" : "feature dW");
     };
     feature_program(ag->feat_bwd, false);
-    const bool can_hoist = policy_fusable(ag) && !getenv("RLREP_NO_HOIST");
-    if (can_hoist && !getenv("RLREP_NO_EARLY_POLICY")) feature_program(ag->feat_bwd_h, true);
+    const bool can_hoist = policy_fusable(ag) && !rl_off("hoist");
+    if (can_hoist && !rl_off("early_policy")) feature_program(ag->feat_bwd_h, true);
     {
         // apply: Adam over (encoder, decoder, f) + Polyak f -> f_target (vlsac_agent.py:152-154, 240-242)
         const std::vector<FinTask> feat_fins = {
@@ -668,7 +693,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         if (nft) b.adam(ag->feat_apply, 0, ag->h.lr_feature, nullptr, 0, 0, 0.f, feat_fins, "adam feature");
         else b.adam(ag->feat_apply, 0, ag->h.lr_feature, Tw("f_target.l1.weight"), f0.off, fn, ag->h.feature_tau, feat_fins, "adam feature + polyak f");
         // chained form (rlrep_feature_chain_next): first layers' optimizer in the weight-gradient epilogues, the rest + the NEXT step's first layers in one launch
-        if (!use_rp && !Builder::chain_enabled() && ag->h.world_size <= 1 && ag->nsh[0] == 0 && !getenv("RLREP_NO_CHAIN_NEXT")) {
+        if (!use_rp && !Builder::chain_enabled() && ag->h.world_size <= 1 && ag->nsh[0] == 0 && !rl_off("chain_next")) {
             feature_program(ag->feat_bwd_m, false, true);
             GemmTask te[3], tf[3];
             gauss_tasks(ag, false, "encoder", s0.XE, KE, KE, ge, te);
@@ -742,7 +767,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
     const int ncdw_splits = rl_nc_dw_splits(B, F, H, 2);
     float* const ncdw_slab = ws.f((size_t)2 * ncdw_splits * H * F);
     float* const ncdw_bslab = ws.f((size_t)2 * ncdw_splits * H);
-    const bool ncdw_in_adam = rl_nc_dw_engine() == 1 && ag->h.world_size <= 1 && ((H * F) & 3) == 0 && (H & 3) == 0 && ncdw_splits <= 16 && !getenv("RLREP_NO_FOLD_NCDW");
+    const bool ncdw_in_adam = rl_nc_dw_engine() == 1 && ag->h.world_size <= 1 && ((H * F) & 3) == 0 && (H & 3) == 0 && ncdw_splits <= 16 && !rl_off("fold_ncdw");
     if (ncdw_in_adam) {
         const LT& w1 = ag->L.get("critic.l1.weight"); const LT& b1 = ag->L.get("critic.l1.bias");
         AdamTask::Slab sw; memset(&sw, 0, sizeof(sw));
@@ -890,7 +915,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             rlrep_agent::DeferSet& D = ag->dset[set];
             const LT& p0 = ag->L.get("f.l1.weight");
             D.block_off = p0.off - ag->L.group_off[0]; D.block_n = fl.off + fl.rows - f0.off; D.block_which = nft ? 0 : 1;
-            if (getenv("RLREP_NO_FOLD_SNAPSHOT") || ag->h.world_size > 1) D.block_which = -1;
+            if (rl_off("fold_snapshot") || ag->h.world_size > 1) D.block_which = -1;
         }
         critic_program(ag->dset[set].critic_bwd, can_hoist ? 1 : 0);
         actor_program(ag->dset[set].actor_bwd, ag->dset[set].actor_resume);
@@ -1013,17 +1038,17 @@ static void static_state(rlrep_agent* ag) {
     // transposed weight shadows (see rlrep_agent::sh_dev): vlsac's feature group, read by the feature step's row programs
     ag->shadow_of.clear();
     for (int g = 0; g < 4; ++g) { ag->sh_dev[g] = nullptr; ag->nsh[g] = ag->sh_tiles[g] = 0; }
-    // ... and, with RLREP_FUSE_L1=1, the two FIRST layers of its feature nets (K = 2S+A / S+A) for the variant in which they ride in the
+    // ... and, with RLREP_ENABLE=fuse_l1, the two FIRST layers of its feature nets (K = 2S+A / S+A) for the variant in which they ride in the
     // second layers' launch (Builder::fwd_stage12 reads W1 transposed).  OPT-IN: measured 11.2 us for the fused launch against 3.7 + 4.9 us
     // for the pair (every one of the 512 tiles re-reads W1^T and X: twice the L2 traffic, three times the load instructions): 2 763 vs
     // 2 865 train()/s.
-    const char* fl1 = getenv("RLREP_FUSE_L1");
+    const char* fl1 = rl_opt("fuse_l1");
 #ifdef RL_EXPERIMENTS
     const bool sh_all = rl_rowprog_enabled(), sh_l1 = fl1 && fl1[0] == '1';
 #else
     const bool sh_all = false, sh_l1 = false; (void)fl1;       // (the fused-first-layers launch is an experiments-build kernel)
 #endif
-    if (ag->d.alg == RLREP_ALG_VLSAC && (sh_all || sh_l1) && !getenv("RLREP_NO_SHADOWS")) {
+    if (ag->d.alg == RLREP_ALG_VLSAC && (sh_all || sh_l1) && !rl_off("shadows")) {
         std::vector<ShadowEnt> tab; std::vector<std::string> first;
         const auto& T = ag->L.t;
         for (size_t q = 0; q < T.size(); ++q) {
@@ -1057,7 +1082,7 @@ static void static_state(rlrep_agent* ag) {
     ag->x3_refresh = nullptr; ag->x3_n = ag->x3_tiles = 0; ag->x3_of.clear();
     {
         const int F = ag->d.feature_dim, H = ag->d.hidden_dim;
-        if (ag->d.alg == RLREP_ALG_VLSAC && !getenv("RLREP_NO_X3") && F > 0 && (F % 32) == 0 && ag->L.index.count("critic.l1.weight") && ag->L.index.count("critic_target.l1.weight")) {
+        if (ag->d.alg == RLREP_ALG_VLSAC && !rl_off("x3") && F > 0 && (F % 32) == 0 && ag->L.index.count("critic.l1.weight") && ag->L.index.count("critic_target.l1.weight")) {
             std::vector<ShadowEnt> all, live;
             const char* names[4] = {"critic.l1.weight", "critic.l4.weight", "critic_target.l1.weight", "critic_target.l4.weight"};
             for (int q = 0; q < 4; ++q) {
@@ -1116,6 +1141,7 @@ int32_t rlrep_abi_version(void) { return RLREP_ABI_VERSION; }
 const char* rlrep_last_error(void) { return g_err; }
 
 int32_t rlrep_layout(const rlrep_dims* dims, rlrep_layout_info* info, rlrep_tensor_desc* descs, int32_t cap) {
+    rl_switches_read();
     if (!check_dims(dims) || !info) return RLREP_ERR_ARG;
     rlrep_agent tmp;
     tmp.d = *dims; memset(&tmp.h, 0, sizeof(tmp.h)); memset(&tmp.a, 0, sizeof(tmp.a));
@@ -1169,7 +1195,7 @@ int32_t rlrep_agent_create(const rlrep_dims* dims, const rlrep_hyper* hyper, con
         !arenas->alpha_state_dev || !arenas->target_dev) { rl_set_error("null arena pointer"); return RLREP_ERR_ARG; }
     rlrep_layout_info info;
     if (rlrep_layout(dims, &info, nullptr, 0) != 0) return RLREP_ERR_ARG;
-    rl_gemm16_read_env();          // the tile engine's diagnostic switches are read here, once per agent, not per launch
+    rl_switches_read();            // RLREP_DISABLE / RLREP_ENABLE are read here, once per agent, never per launch
     std::unique_ptr<rlrep_agent> ag(new rlrep_agent());
     ag->d = *dims; ag->h = *hyper; ag->a = *arenas;
     if (ag->h.world_size <= 0) ag->h.world_size = 1;
@@ -1271,7 +1297,7 @@ static void slot_fill_params(rlrep_agent* ag, int slot, const float* ring_dev, c
 int32_t rlrep_prefetch_batch(rlrep_agent* ag, const float* ring_dev, const int32_t* idx_dev, int32_t batch) {
     if (!ag || !ring_dev || !idx_dev) { rl_set_error("prefetch_batch: bad argument"); return RLREP_ERR_ARG; }
     ag->pf_armed = false;
-    if (batch != ag->B || getenv("RLREP_NO_PREFETCH_BATCH")) return 0;      // would need a rebuild: let replay_sample do it
+    if (batch != ag->B || rl_off("prefetch_batch")) return 0;      // would need a rebuild: let replay_sample do it
     slot_fill_params(ag, 0, ring_dev, idx_dev, ag->pf_fill);
     ag->pf_ring = ring_dev; ag->pf_idx = idx_dev; ag->pf_armed = true;
     return 1;
@@ -1281,7 +1307,7 @@ int32_t rlrep_prefetch_batch_slot(rlrep_agent* ag, int32_t slot, const float* ri
     if (slot == 0) return rlrep_prefetch_batch(ag, ring_dev, idx_dev, batch);
     if (!ag || !ring_dev || !idx_dev || slot != 1 || ag->d.alg != RLREP_ALG_SPEDERSAC) { rl_set_error("prefetch_batch_slot: bad argument"); return RLREP_ERR_ARG; }
     ag->pf2_armed = false;
-    if (batch != ag->B || getenv("RLREP_NO_PREFETCH_BATCH")) return 0;
+    if (batch != ag->B || rl_off("prefetch_batch")) return 0;
     slot_fill_params(ag, 1, ring_dev, idx_dev, ag->pf2_fill);
     ag->pf2_ring = ring_dev; ag->pf2_idx = idx_dev; ag->pf2_armed = true;
     return 1;
@@ -1728,6 +1754,7 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
                    float* Cm, int32_t ldc, int32_t R, int32_t Cn, int32_t K, int32_t epi, int32_t act, int32_t flags,
                    const float* bias, const float* aux, int32_t ldaux, float* out2, int32_t bt, int32_t splits,
                    float* wsp, int64_t ws_floats, void* stream) {
+    rl_switches_read();
     if (!A || !B || !Cm || R <= 0 || Cn <= 0 || K <= 0 || (epi != EPI_FWD && epi != EPI_DX && epi != EPI_DW)) { rl_set_error("gemm: bad argument"); return RLREP_ERR_ARG; }
     GemmTask t; memset(&t, 0, sizeof(t));
     t.scale = 1.f; t.A = A; t.lda = lda; t.B = B; t.ldb = ldb; t.C = Cm; t.ldc = ldc; t.R = R; t.Cn = Cn; t.K = K;
@@ -1769,6 +1796,7 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
 
 int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
                         int32_t* engine, int32_t* tile, int32_t* splits, int32_t* kchunk, int32_t* scalar_sides) {
+    rl_switches_read();
     if (R <= 0 || Cn <= 0 || K <= 0 || !engine) { rl_set_error("gemm_plan: bad argument"); return RLREP_ERR_ARG; }
     GemmTask t; memset(&t, 0, sizeof(t));
     t.R = R; t.Cn = Cn; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.epi = la == LD_COL ? EPI_DW : EPI_FWD;
@@ -1783,6 +1811,7 @@ int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K
 }
 
 int32_t rlrep_nc_fwd_plan(int32_t heads, int32_t B, int32_t F, int32_t H, int32_t* engine, int32_t* rows, int32_t* cols) {
+    rl_switches_read();
     if (heads <= 0 || heads > NC_MAX_TASKS || B <= 0 || F <= 0 || H <= 0 || !engine) { rl_set_error("nc_fwd_plan: bad argument"); return RLREP_ERR_ARG; }
     NcFwdTask t[NC_MAX_TASKS]; memset(t, 0, sizeof(t));
     for (int q = 0; q < heads; ++q) { t[q].B = B; t[q].F = F; t[q].H = H; t[q].N = 20; t[q].ld_ml = 2 * F; }
@@ -1802,7 +1831,7 @@ int32_t rlrep_chain_status(rlrep_agent* ag, uint32_t* status, void* stream) {
     if (e != hipSuccess) { rl_set_error("chain_status: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
     if (status) *status = w;
     if (w) {
-        rl_set_error("a persistent chain launch failed its run-time checks (word %u:%s%s); results are invalid -- RLREP_XCHAIN=0 runs one launch per stage",
+        rl_set_error("a persistent chain launch failed its run-time checks (word %u:%s%s); results are invalid -- leaving xchain out of RLREP_ENABLE runs one launch per stage",
                      w, (w & 5u) ? " wait timed out" : "", (w & 2u) ? " workgroups of a group on different XCDs" : "");
         return RLREP_ERR_STATE;
     }

@@ -80,7 +80,7 @@ struct rlrep_agent {
     bool images_managed = false;          // rlrep_images_managed: the step entry points leave the refresh launch to the caller
     std::map<std::string, const unsigned char*> x3_of;
     const unsigned char* W3(const std::string& n) const { auto it = x3_of.find(n); return it == x3_of.end() ? nullptr : it->second; }
-    // cluster row programs (RLREP_ROWPROG=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
+    // cluster row programs (RLREP_ENABLE=rowprog=2): the launch epoch that tags their exchange granules (bumped by the feature Adam launch; by an
     // extra launch before an eager step outside a train())
     int* rp_epoch = nullptr;
     float* hist = nullptr; int* hist_seq = nullptr; bool hist_on = false;      // metric history ring (kparams.h FIN_HISTORY, rlrep_history)
@@ -282,10 +282,10 @@ struct Builder {
 
     // Two INDEPENDENT stages of different tile forms -- d1: row-major x k-major products (the dX form), d2: k-major x k-major ones (the
     // weight-gradient form) -- as ONE launch (gemm16_duo_kernel): a dependent launch less.  Falls back to the two stages (d1 first) when a
-    // task is routed to the LDS-tiled engines, carries a fused short product, or the table does not fit.  RLREP_NO_DUO: always the two stages.
+    // task is routed to the LDS-tiled engines, carries a fused short product, or the table does not fit.  RLREP_DISABLE=duo: always the two stages.
     bool routes_small(const GemmTask& t, int la, int lb) { int sp = 1, kc = 0, fl = 0; GemmTask c = t; return !rl_gemm_lds_route(&c, la, lb, 0, &sp, &kc, &fl); }
     void gemm_duo(Program& p, std::vector<GemmTask> d1, std::vector<GemmTask> d2, const char* w1, const char* w2, const char* what) {
-        bool ok = !getenv("RLREP_NO_DUO") && !chain_prog && !d1.empty() && !d2.empty() && d1.size() + d2.size() <= GEMM_MAX_TASKS;
+        bool ok = !rl_off("duo") && !chain_prog && !d1.empty() && !d2.empty() && d1.size() + d2.size() <= GEMM_MAX_TASKS;
         for (auto& t : d1) ok = ok && routes_small(t, LD_ROW, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3));
         for (auto& t : d2) ok = ok && routes_small(t, LD_COL, LD_COL) && !(t.flags & (FLAG_PRE | FLAG_DYN_EPS | FLAG_DYN_EPS2 | FLAG_DYN_EPS3));
         if (!ok) { gemm(p, LD_ROW, LD_COL, d1, w1); gemm(p, LD_COL, LD_COL, d2, w2); return; }
@@ -311,13 +311,13 @@ struct Builder {
     // themselves.  A chain of one phase is emitted as the ordinary launch it would have been.
     struct ChainPhase { XcPhase ph; std::vector<GemmTask> tasks; HeadsVae hv; const char* what; int la, lb; };
     std::vector<ChainPhase> chain; Program* chain_prog = nullptr; int chain_R = -1;
-    // OPT-IN while it is slower than the launches it replaces beside the deferred chain: RLREP_XCHAIN=1
+    // OPT-IN while it is slower than the launches it replaces beside the deferred chain: RLREP_ENABLE=xchain
 #ifdef RL_EXPERIMENTS
-    static bool chain_enabled() { const char* e = getenv("RLREP_XCHAIN"); return e && e[0] == '1'; }
+    static bool chain_enabled() { const char* e = rl_opt("xchain"); return e && e[0] == '1'; }
 #else
     static bool chain_enabled() { return false; }
 #endif
-    static int chain_mpg() { const char* e = getenv("RLREP_XCHAIN_MPG"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }
+    static int chain_mpg() { const char* e = rl_opt("xchain_mpg"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }
     bool chain_fits(int R) const { return chain_enabled() && R <= 512 && (chain_R < 0 || chain_R == R); }
     void chain_begin(Program& p) { chain_flush(); chain_prog = &p; chain_R = -1; }
     void chain_end() { chain_flush(); chain_prog = nullptr; }
@@ -421,7 +421,7 @@ struct Builder {
     // Two consecutive dX stages of which the FIRST has a short inner length (<= 32) and a ReLU or ELU mask: one launch in which every tile of
     // the second recomputes its 16 rows of the first (gemm16.hip, FLAG_PRE).  Falls back to the two stages when the pair does not fit.
     void dx_stage12(Program& p, GemmTask d1, GemmTask d2, const char* w1, const char* w2) {
-        const bool ok = !getenv("RLREP_NO_FUSE_DX") && d1.epi == EPI_DX && (d1.act == ACT_RELU || d1.act == ACT_ELU) && !(d1.flags & FLAG_ACCUM) && !d1.r1u && d1.K <= 32 &&
+        const bool ok = !rl_off("fuse_dx") && d1.epi == EPI_DX && (d1.act == ACT_RELU || d1.act == ACT_ELU) && !(d1.flags & FLAG_ACCUM) && !d1.r1u && d1.K <= 32 &&
                         d1.scale == 1.f && d2.A == d1.C && d2.lda == d1.ldc && d2.K == d1.Cn && d2.R == d1.R &&
                         (d2.epi == EPI_DX || d2.epi == EPI_DX_REPARAM) && ((d2.R + 15) / 16) * ((d2.Cn + 15) / 16) < 384 * 2;
         if (!ok) { dx_stage(p, {d1}, w1); dx_stage(p, {d2}, w2); return; }
@@ -573,8 +573,8 @@ struct Builder {
 // ------------------------------------------------------------------------------------------------
 // (opt-in engines: compiled into the experiments library only, rlrep_amd/csrc/build.sh)
 #ifdef RL_EXPERIMENTS
-static inline bool rl_rowprog_enabled() { const char* e = getenv("RLREP_ROWPROG"); return e && (e[0] == '1' || e[0] == '2'); }
-static inline bool rl_rowprog_cluster() { const char* e = getenv("RLREP_ROWPROG"); return e && e[0] == '2'; }
+static inline bool rl_rowprog_enabled() { const char* e = rl_opt("rowprog"); return e && (e[0] == '1' || e[0] == '2'); }
+static inline bool rl_rowprog_cluster() { const char* e = rl_opt("rowprog"); return e && e[0] == '2'; }
 #else
 static inline bool rl_rowprog_enabled() { return false; }
 static inline bool rl_rowprog_cluster() { return false; }

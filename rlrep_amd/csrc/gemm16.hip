@@ -201,11 +201,11 @@ __global__ __launch_bounds__(256) void gemm16_fastpre_kernel(int hdr, const floa
 // 16 GiB of the lowest one (rlrep_amd/core.py carves all arenas out of one block for that); tests and bench.py read the counts.
 long long g_rl_front[4] = {0, 0, 0, 0};
 static int s_front = 3;
-// diagnostic switches, read when an agent is created (rl_gemm16_read_env; no getenv on the per-launch path): RLREP_GEMM16_NO_FAST = every launch on
-// the record front end, RLREP_GEMM16_GENERIC = no compiled-in epilogues (both: bit-identical results, tests/test_default_mode.py)
+// diagnostic switches, read when an agent is created (rl_gemm16_read_env; no getenv on the per-launch path): RLREP_DISABLE=gemm16_fast = every launch on
+// the record front end, RLREP_DISABLE=gemm16_spec = no compiled-in epilogues (both: bit-identical results, tests/test_default_mode.py)
 static bool s_no_fast = false, s_generic = false, s_trace = false;
 extern "C" void rl_gemm16_read_env() {
-    s_no_fast = getenv("RLREP_GEMM16_NO_FAST") != nullptr; s_generic = getenv("RLREP_GEMM16_GENERIC") != nullptr; s_trace = getenv("RLREP_GEMM16_TRACE") != nullptr;
+    s_no_fast = rl_off("gemm16_fast"); s_generic = rl_off("gemm16_spec"); s_trace = rl_opt("gemm16_trace") != nullptr;
 }
 struct FastPreArgs { int hdr; const float* base; unsigned ao, bo, ld, kr, ck, xo, wo, mo, ldxw, ldm; };
 static bool fastpre_args(const GemmBatch& gb, FastPreArgs& fa) {

@@ -1124,22 +1124,22 @@ extern "C" void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* k
 // bf16x3: 159 / 137 TF against 110 on the fp32 pipe; the k-major/k-major weight-gradient form stays on fp32 MFMA (107 vs 116).
 extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_flags, int* splits, int* kchunk, int* flags) {
     const bool combo = (la == LD_ROW && lb == LD_ROW) || (la == LD_ROW && lb == LD_COL) || (la == LD_COL && lb == LD_COL);
-    if (!combo || getenv("RLREP_NO_GEMM_LDS") || !rl_gemm_lds_dims_ok(t, la, lb)) return 0;
+    if (!combo || rl_off("gemm_lds") || !rl_gemm_lds_dims_ok(t, la, lb)) return 0;
     int bt = 0;
     rl_gemm_lds_plan(t, &bt, splits, kchunk);
     *flags = rl_gemm_lds_dim_flags(t, la, lb) | extra_flags;
-    // (the k-major / k-major weight-gradient form takes bf16x3 too since round 4: gemm_x3t_kernel; RLREP_X3_DW_FP32 keeps it on the fp32 tile)
-    const bool x3 = bt == 128 && (la == LD_ROW || (lb == LD_COL && !getenv("RLREP_X3_DW_FP32"))) && 2.0 * t->R * t->Cn * t->K >= 2e9 && !getenv("RLREP_NO_X3") &&
+    // (the k-major / k-major weight-gradient form takes bf16x3 too since round 4: gemm_x3t_kernel; RLREP_DISABLE=x3_dw keeps it on the fp32 tile)
+    const bool x3 = bt == 128 && (la == LD_ROW || (lb == LD_COL && !rl_off("x3_dw"))) && 2.0 * t->R * t->Cn * t->K >= 2e9 && !rl_off("x3") &&
                     !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
     if (x3) return 129;
-    // 64-wide tiles: on the bf16 pipe too when both operands allow 16-byte staging (gemm_x3s_kernel); RLREP_X3S_OFF keeps the fp32 tile
+    // 64-wide tiles: on the bf16 pipe too when both operands allow 16-byte staging (gemm_x3s_kernel); RLREP_DISABLE=x3s keeps the fp32 tile
     // (the program builder keeps a STAGE on one engine: a stage whose tasks would be split between this tile and the fp32 one becomes two dependent
     // launches, which costs more than the faster tile returns -- spedersac: 69 -> 81 launches on the feature chain, 961 -> 903 train()/s)
     // (operands that are not 16-byte regular -- rows of 119 floats, a block that starts inside another buffer -- take the any-alignment loaders of the
-    // same tile (x3s_load_*<2>); RLREP_X3S_ALIGNED_ONLY=1 keeps such stages on the fp32 tile as before.  A 4-byte-staging instantiation was built and
+    // same tile (x3s_load_*<2>); RLREP_DISABLE=x3s_unaligned keeps such stages on the fp32 tile as before.  A 4-byte-staging instantiation was built and
     // measured first -- spedersac 968 with it against 1 002 with those stages on fp32, ctrlsac F = 2048 865 against 904)
-    if (bt == 64 && !getenv("RLREP_NO_X3") && !getenv("RLREP_X3S_OFF") &&
-        (!(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) || (x3s_unaligned_ok(t) && !getenv("RLREP_X3S_ALIGNED_ONLY")))) return 65;
+    if (bt == 64 && !rl_off("x3") && !rl_off("x3s") &&
+        (!(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) || (x3s_unaligned_ok(t) && !rl_off("x3s_unaligned")))) return 65;
     return bt;
 }
 

@@ -1663,10 +1663,10 @@ __global__ __launch_bounds__(256) void nc_dw_fin_kernel(NcDwBatch nb) {
 // hidden units per nc_fwd workgroup (64 or 128); the builder sizes tiles_h with it
 extern "C" int rl_nc_fwd_cols() { return 128; }
 // Tiling of one nc_fwd launch: engine (0 fp32 MFMA, 1 bf16x3), batch-row groups per workgroup (g2, 4 rows each) and hidden
-// units per workgroup.  bf16x3 needs 32-deep K steps and 16-byte rows everywhere; RLREP_NO_X3 keeps fp32 (tests: both engines).
+// units per workgroup.  bf16x3 needs 32-deep K steps and 16-byte rows everywhere; RLREP_DISABLE=x3 keeps fp32 (tests: both engines).
 extern "C" void rl_nc_fwd_plan(const NcFwdTask* tasks, int ntasks, int* engine, int* g2, int* cols) {
     const int B = tasks[0].B, F = tasks[0].F, H = tasks[0].H;
-    const bool want_x3 = !getenv("RLREP_NO_X3");             // read per plan (agent construction), so a test can flip it
+    const bool want_x3 = !rl_off("x3");             // read per plan (agent construction), so a test can flip it
     bool x3 = want_x3 && (F % 32) == 0 && F >= 64;
     for (int q = 0; q < ntasks; ++q) {
         const NcFwdTask& t = tasks[q];
@@ -1691,8 +1691,8 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
         if ((F % 32) != 0 || g2 != 2) return -3;
 #ifdef RL_EXPERIMENTS
         // (the superseded two-role / 16x16x32 forms of the 128-wide tile: experiments library only)
-        static const int wide = [] { const char* e = getenv("RLREP_NC_X3_WIDE"); return e ? atoi(e) : 1; }();
-        static const int quad = [] { const char* e = getenv("RLREP_NC_X3_Q"); return e ? atoi(e) : 1; }();
+        const int wide = rl_off("nc_x3_wide") ? 0 : 1;
+        const int quad = rl_off("nc_x3_q") ? 0 : 1;
         if (nb->cols == 128 && quad) hipLaunchKernelGGL(nc_fwd_x3q_kernel, dim3(total_tiles), dim3(256), 2 * NX_BUFB, st, *nb);
         else if (nb->cols == 128 && wide) hipLaunchKernelGGL((nc_fwd_x3w_kernel<8>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);     // superseded by x3q
         else if (nb->cols == 128) hipLaunchKernelGGL((nc_fwd_x3_kernel<2>), dim3(total_tiles), dim3(512), 2 * NX_BUFB, st, *nb);             // superseded by x3q
@@ -1717,9 +1717,9 @@ extern "C" int rl_launch_nc_fwd(const NcFwdBatch* nb, int total_tiles, int g2, h
     return (int)hipGetLastError();
 }
 
-// engine of the dX launch: 1 = bf16x3 (H % 32 == 0, even row strides, 8-byte aligned U / GH; RLREP_NO_X3 keeps fp32 MFMA)
+// engine of the dX launch: 1 = bf16x3 (H % 32 == 0, even row strides, 8-byte aligned U / GH; RLREP_DISABLE=x3 keeps fp32 MFMA)
 extern "C" int rl_nc_dx_engine(const NcDxTask* t) {
-    if (getenv("RLREP_NO_X3")) return 0;
+    if (rl_off("x3")) return 0;
     if (t->N != 4 * NC_NF || (t->H % 32) != 0 || (t->ldgh & 1) || t->nheads < 1 || t->nheads > 2 || t->tiles_k != (t->F + 63) / 64) return 0;
     for (int h = 0; h < t->nheads; ++h) if (((((uintptr_t)t->U[h]) | ((uintptr_t)t->GH[h])) & 7) != 0) return 0;
     return 1;
@@ -1755,8 +1755,8 @@ extern "C" int rl_nc_init() {
     return (int)hipFuncSetAttribute((const void*)nc_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-// engine of the dW launch: 1 = bf16x3 split-K (needs slabs from the caller; RLREP_NO_X3 keeps fp32)
-extern "C" int rl_nc_dw_engine() { return getenv("RLREP_NO_X3") ? 0 : 1; }
+// engine of the dW launch: 1 = bf16x3 split-K (needs slabs from the caller; RLREP_DISABLE=x3 keeps fp32)
+extern "C" int rl_nc_dw_engine() { return rl_off("x3") ? 0 : 1; }
 extern "C" int rl_nc_dw_splits(int B, int F, int H, int ntasks) {
     const int tiles = ((H + 63) / 64) * ((F + 63) / 64) * ntasks;
     int sp = (256 + tiles - 1) / tiles;                               // about one workgroup per CU

@@ -517,15 +517,15 @@ extern "C" int rl_replearn_init() {
 extern "C" int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st) {
     // one pass through LDS where it applies; column chunks of 64 floats (64 KB of LDS at F = 256: two workgroups per CU, whose load and store
     // phases overlap) measured best at Humanoid dims: 380 us against 393 (32), 514 (128: one workgroup per CU) and 462 for the two-pass kernel.
-    // RLREP_SCORE_CH = 32 / 64 / 128 selects the chunk, 0 the two-pass kernels.
-    const char* e = getenv("RLREP_SCORE_CH");
+    // RLREP_ENABLE=score_ch=32 / 64 / 128 selects the chunk, 0 the two-pass kernels.
+    const char* e = rl_opt("score_ch");
     const int ch = e ? atoi(e) : 64;
     if (ch && (p->S & 3) == 0 && p->F <= 256 && ((((uintptr_t)p->U) & 15) == 0)) {
         if (ch == 128) hipLaunchKernelGGL(diffsr_score_lds_kernel<128>, dim3(p->B), dim3(256), ds_lds<128>(p->F), st, *p);
         else if (ch == 64) hipLaunchKernelGGL(diffsr_score_lds_kernel<64>, dim3(p->B), dim3(256), ds_lds<64>(p->F), st, *p);
         else hipLaunchKernelGGL(diffsr_score_lds_kernel<32>, dim3(p->B), dim3(256), ds_lds<32>(p->F), st, *p);
     }
-    else if (p->S <= 32 && p->F <= 1024 && !getenv("RLREP_SCORE_NO_SMALL")) {
+    else if (p->S <= 32 && p->F <= 1024 && !rl_off("score_small")) {
         if (p->F <= 256) hipLaunchKernelGGL(diffsr_score_small_kernel<1>, dim3(p->B), dim3(256), 0, st, *p);
         else if (p->F <= 512) hipLaunchKernelGGL(diffsr_score_small_kernel<2>, dim3(p->B), dim3(256), 0, st, *p);
         else hipLaunchKernelGGL(diffsr_score_small_kernel<4>, dim3(p->B), dim3(256), 0, st, *p);

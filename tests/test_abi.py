@@ -115,11 +115,11 @@ def _nc_plan(heads, B, F, H):
 def test_noise_critic_engine_plan(monkeypatch):
     """Host-only: the vlsac noise critic's first layer goes to the bf16x3 engine when its K steps are 32 deep (8-row tiles, 128
     hidden units per workgroup once that still gives every CU a workgroup, else 64); other shapes stay on fp32 MFMA."""
-    monkeypatch.delenv('RLREP_NO_X3', raising=False)
+    monkeypatch.delenv('RLREP_DISABLE', raising=False)
     assert _nc_plan(4, 256, 256, 256) == (1, 8, 128)       # headline critic step: target + live, two heads each
     assert _nc_plan(2, 256, 256, 256) == (1, 8, 64)        # actor step: the live heads only
     assert _nc_plan(2, 100, 96, 72)[0] == 1
     assert _nc_plan(2, 8, 8, 16)[0] == 0                   # tiny fixtures: K = 8
     assert _nc_plan(2, 256, 80, 256)[0] == 0               # 80 % 32 != 0
-    monkeypatch.setenv('RLREP_NO_X3', '1')
+    monkeypatch.setenv('RLREP_DISABLE', 'x3')
     assert _nc_plan(4, 256, 256, 256)[0] == 0

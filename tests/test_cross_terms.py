@@ -153,16 +153,16 @@ def test_feature_step_then_update_feature_target_matches_oracle():
 def test_info_of_graph_replays_is_per_call_and_outlives_the_ring(monkeypatch):
     """sac_agent.py:157-166 returns the metrics of THAT call as plain floats that stay valid forever.  The one-graph train() files them in the
     library's history ring (rlrep_history) and the dict fetches its record on first read: dicts read late and out of order equal, bit for bit,
-    what a twin agent that snapshots per call (RLREP_INFO_HISTORY=0) returned; a dict the caller KEEPS unread while the ring wraps (per-epoch
+    what a twin agent that snapshots per call (RLREP_DISABLE=info_history) returned; a dict the caller KEEPS unread while the ring wraps (per-epoch
     logging) is resolved by the library before its record is overwritten (HipCore.history_resolve, every capacity / 2 calls) and still holds
     its own call's values; the raw source of an overwritten record raises instead of reporting a later call."""
     from test_default_mode import _default_agent, _buffer
     c = Case('sac_tiny')
     a, buf, n = _default_agent(c), _buffer(c), 6
-    monkeypatch.setenv('RLREP_INFO_HISTORY', '0')          # (read when the graph is captured: at the first train())
+    monkeypatch.setenv('RLREP_DISABLE', 'info_history')          # (read when the graph is captured: at the first train())
     b = _default_agent(c)
     ib = [dict(b.train(buf, c.B).items()) for _ in range(n)]
-    monkeypatch.delenv('RLREP_INFO_HISTORY')
+    monkeypatch.delenv('RLREP_DISABLE')
     ia = [a.train(buf, c.B) for _ in range(n)]
     assert a._hist and not b._hist
     for t in (4, 0, 5, 2):

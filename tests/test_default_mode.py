@@ -249,13 +249,13 @@ def test_train_pools_are_the_documented_streams():
 @_needs_experiments()
 @pytest.mark.parametrize('name,single', [('vlsac_tiny', False), ('vlsac_hc', False), ('vlsac_tiny', True)])
 def test_row_program_feature_step_matches_oracle(name, single, monkeypatch):
-    """RLREP_ROWPROG=1: forward + dX chains of a feature step as one launch of row-block programs (two workgroups per 16-row block that
-    hand the Gaussian heads / KL gradients to each other through flags; RLREP_ROWPROG_SINGLE=1: one workgroup per block, no hand-off),
+    """RLREP_ENABLE=rowprog: forward + dX chains of a feature step as one launch of row-block programs (two workgroups per 16-row block that
+    hand the Gaussian heads / KL gradients to each other through flags; RLREP_DISABLE=rowprog_pair: one workgroup per block, no hand-off),
     reading the forward layers' weights from transposed shadows that the Adam launch keeps current -- in the default (graph, pipelined)
     mode against the oracle on the read-back draws, like every other default-mode test."""
-    monkeypatch.setenv('RLREP_ROWPROG', '1')
+    monkeypatch.setenv('RLREP_ENABLE', 'rowprog')
     if single:
-        monkeypatch.setenv('RLREP_ROWPROG_SINGLE', '1')
+        monkeypatch.setenv('RLREP_DISABLE', 'rowprog_pair')
     c = Case(name)
     worst = _check_against_oracle(c, calls=3, expect_pipeline=True)
     print(f'{name} row programs vs oracle: worst param rel-L2 {worst:.2e}')
@@ -267,7 +267,7 @@ def test_row_program_shadows_follow_external_parameter_writes(monkeypatch):
     the caller between calls (load_state / checkpoint load) are what the next step uses."""
     from oracle import make_oracle
     from oracle.agents import gather_batch
-    monkeypatch.setenv('RLREP_ROWPROG', '1')
+    monkeypatch.setenv('RLREP_ENABLE', 'rowprog')
     c = Case('vlsac_tiny')
     agent, buf = _default_agent(c), _buffer(c)
     agent.train(buf, c.B)
@@ -289,13 +289,13 @@ def test_row_program_shadows_follow_external_parameter_writes(monkeypatch):
 
 def test_snapshot_rides_in_the_last_feature_optimizer_launch(monkeypatch):
     """rlrep_defer_arm: the deferred chain's snapshot is written by the last feature step's optimizer launch (one dependent launch less on
-    the chain that bounds train()); RLREP_NO_FOLD_SNAPSHOT=1 keeps the separate copy launch.  Both forms against the oracle, and the
+    the chain that bounds train()); RLREP_DISABLE=fold_snapshot keeps the separate copy launch.  Both forms against the oracle, and the
     launch counts of the captured feature graph differ by exactly one."""
     c = Case('vlsac_hc')
     counts = {}
     for fold in (True, False):
         if not fold:
-            monkeypatch.setenv('RLREP_NO_FOLD_SNAPSHOT', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'fold_snapshot')
         agent, buf = _default_agent(c), _buffer(c)
         agent.train(buf, c.B)
         agent.flush()
@@ -308,13 +308,13 @@ def test_snapshot_rides_in_the_last_feature_optimizer_launch(monkeypatch):
 def test_decoder_heads_and_mse_ride_in_the_decoder_dx_launch(monkeypatch):
     """FLAG_PRE_MSE (vlsac_agent.py:137-140's s_loss / r_loss): every 16-row tile of the decoder.l1 dX launch computes the heads' forward,
     the mse gradient and its squared-error partials itself, so the 'dec.heads + mse' launch leaves each feature step.
-    RLREP_NO_FOLD_MSE=1 keeps the separate launch.  Both forms against the oracle (s_loss / r_loss are among the compared metrics), and the
+    RLREP_DISABLE=fold_mse keeps the separate launch.  Both forms against the oracle (s_loss / r_loss are among the compared metrics), and the
     captured feature graph is one launch per feature step shorter."""
     c = Case('vlsac_hc')
     counts = {}
     for fold in (True, False):
         if not fold:
-            monkeypatch.setenv('RLREP_NO_FOLD_MSE', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'fold_mse')
         agent, buf = _default_agent(c), _buffer(c)
         agent.train(buf, c.B)
         agent.flush()
@@ -328,7 +328,7 @@ def test_decoder_heads_and_mse_ride_in_the_decoder_dx_launch(monkeypatch):
 def test_chained_feature_steps_change_nothing(monkeypatch):
     """rlrep_feature_chain_next (vlsac_agent.py:250-256's loop of feature steps, chained): the first layers' optimizer runs in the weight-gradient
     epilogues and the step's optimizer launch carries the next step's encoder.l1 / f.l1 on rows read straight from the ring.  Against
-    RLREP_NO_CHAIN_NEXT=1 (every step its own ten launches): three launches fewer in the captured feature graph, and parameters, moments and
+    RLREP_DISABLE=chain_next (every step its own ten launches): three launches fewer in the captured feature graph, and parameters, moments and
     targets BIT-identical after 30 pipelined train() calls at the headline dims (adam_elem's operations are pinned for exactly this); both
     forms against the oracle."""
     import synth
@@ -339,7 +339,7 @@ def test_chained_feature_steps_change_nothing(monkeypatch):
     outs, counts = [], {}
     for chained in (True, False):
         if not chained:
-            monkeypatch.setenv('RLREP_NO_CHAIN_NEXT', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'chain_next')
         torch.manual_seed(0)
         agent = VLSACAgent(state_dim=17, action_dim=6, action_space=_Space(6, 1.0), max_batch=256, pipeline=True, seed=77,
                            hidden_dim=256, feature_dim=256, extra_feature_steps=3)
@@ -361,7 +361,7 @@ def test_chained_feature_steps_change_nothing(monkeypatch):
 
 def test_fast_front_end_changes_nothing(monkeypatch):
     """gemm16_fast_kernel / gemm16_fast4_kernel / gemm16_fastpre_kernel (operand loads issued from preloaded scalars, the record's loads under them)
-    run the same tile body in the same order: against RLREP_GEMM16_NO_FAST=1 (every launch fetches its record first) parameters, moments and
+    run the same tile body in the same order: against RLREP_DISABLE=gemm16_fast (every launch fetches its record first) parameters, moments and
     targets are BIT-identical after 20 pipelined train() calls at the headline dims."""
     import synth
     from rlrep_amd.utils.buffer import ReplayBuffer
@@ -370,7 +370,7 @@ def test_fast_front_end_changes_nothing(monkeypatch):
     outs, routes = [], []
     for fast in (True, False):
         if not fast:
-            monkeypatch.setenv('RLREP_GEMM16_NO_FAST', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'gemm16_fast')
         torch.manual_seed(0)
         agent = VLSACAgent(state_dim=17, action_dim=6, action_space=_Space(6, 1.0), max_batch=256, pipeline=True, seed=78,
                            hidden_dim=256, feature_dim=256, extra_feature_steps=3)
@@ -436,9 +436,9 @@ def test_default_mode_without_feature_target(name):
 
 @_needs_experiments()
 def test_fused_first_layers_match_oracle(monkeypatch):
-    """RLREP_FUSE_L1=1 (opt-in, measured slower): encoder.l1 / f.l1 recomputed inside the encoder.l2 / f.l2 launch from transposed weight
+    """RLREP_ENABLE=fuse_l1 (opt-in, measured slower): encoder.l1 / f.l1 recomputed inside the encoder.l2 / f.l2 launch from transposed weight
     shadows (gemm16.hip FLAG_PRE_FWD); K1 = 13 and 8 at the tiny dimensions, 40 and 23 at the headline ones."""
-    monkeypatch.setenv('RLREP_FUSE_L1', '1')
+    monkeypatch.setenv('RLREP_ENABLE', 'fuse_l1')
     for name in ('vlsac_tiny', 'vlsac_hc'):
         c = Case(name)
         agent = _default_agent(c)
@@ -450,10 +450,10 @@ def test_fused_first_layers_match_oracle(monkeypatch):
 @_needs_experiments()
 @pytest.mark.parametrize('name', ['vlsac_tiny', 'vlsac_hc'])
 def test_cluster_row_programs_match_oracle(name, monkeypatch):
-    """RLREP_ROWPROG=2: the cluster form -- C workgroups per row block and chain (4 at the tiny dimensions, 8 at the headline ones), each
+    """RLREP_ENABLE=rowprog=2: the cluster form -- C workgroups per row block and chain (4 at the tiny dimensions, 8 at the headline ones), each
     owning a column slice of every layer, completing each other's activation vectors through tagged 8-byte granules (rowprog.hip
     RP_XCHG / RP_PUBLISH / RP_GATHER) -- in the default mode against the oracle on the read-back draws."""
-    monkeypatch.setenv('RLREP_ROWPROG', '2')
+    monkeypatch.setenv('RLREP_ENABLE', 'rowprog=2')
     c = Case(name)
     worst = _check_against_oracle(c, calls=3, expect_pipeline=True)
     print(f'{name} cluster row programs vs oracle: worst param rel-L2 {worst:.2e}')
@@ -462,14 +462,13 @@ def test_cluster_row_programs_match_oracle(name, monkeypatch):
 @_needs_experiments()
 @pytest.mark.parametrize('name,mpg', [('vlsac_tiny', 32), ('vlsac_hc', 32), ('vlsac_hc', 64)])
 def test_xcd_chain_feature_step_matches_oracle(name, mpg, monkeypatch):
-    """RLREP_XCHAIN=1 (opt-in, csrc/xchain.hip): the forward + dX stages of a feature step as ONE persistent launch whose workgroups hand
+    """RLREP_ENABLE=xchain (opt-in, csrc/xchain.hip): the forward + dX stages of a feature step as ONE persistent launch whose workgroups hand
     their tiles over inside one XCD's L2 (plain stores, a flag per workgroup, sc1 loads; 32 or 64 workgroups per XCD) -- in the default
     (graph, pipelined) mode against the oracle on the read-back draws; the launch's own device-side checks (every flag carries its
     writer's XCC id; bounded waits) must stay clean."""
     import ctypes as C
     from rlrep_amd._lib import lib
-    monkeypatch.setenv('RLREP_XCHAIN', '1')
-    monkeypatch.setenv('RLREP_XCHAIN_MPG', str(mpg))
+    monkeypatch.setenv('RLREP_ENABLE', f'xchain,xchain_mpg={mpg}')
     c = Case(name)
     worst = _check_against_oracle(c, calls=3, expect_pipeline=True)
     print(f'{name} XCD chain ({mpg} workgroups per XCD) vs oracle: worst param rel-L2 {worst:.2e}')

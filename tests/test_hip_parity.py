@@ -171,21 +171,21 @@ def test_hip_matches_oracle_fresh_seed(alg):
 def test_theta_head_in_its_own_launches_matches_golden(name, monkeypatch):
     """By default the reward head theta rides in the loss launches: spedersac's gradient of theta.l (sum_i drhat_i phi_i, sum_i drhat_i) in the
     weighted column-sum launch of the spectral loss (colsum_kernel's second set), ctrlsac's rhat = theta . phi + b in the InfoNCE launch.
-    RLREP_NO_FOLD_THETA=1 keeps them tasks of the 16-row engine (a launch of their own when the neighbouring GEMMs route to the LDS-tiled engine).
+    RLREP_DISABLE=fold_theta keeps them tasks of the 16-row engine (a launch of their own when the neighbouring GEMMs route to the LDS-tiled engine).
     The golden tests above run the default; this runs the other form against the same reference fixtures."""
     if name not in cases():
         pytest.skip('fixture not present')
-    monkeypatch.setenv('RLREP_NO_FOLD_THETA', '1')
+    monkeypatch.setenv('RLREP_DISABLE', 'fold_theta')
     test_hip_matches_reference_golden(name)
 
 
 @pytest.mark.parametrize('name', ['diffsrsac_tiny', 'diffsrsac_hc'])
 def test_diffsrsac_score_kernel_for_wide_states_matches_golden_at_small_ones(name, monkeypatch):
-    """State dimensions of up to 32 take diffsr_score_small_kernel (a thread per row of U[b], one read of U); RLREP_SCORE_NO_SMALL=1 sends them
+    """State dimensions of up to 32 take diffsr_score_small_kernel (a thread per row of U[b], one read of U); RLREP_DISABLE=score_small sends them
     through the lanes-over-s kernel that wider, non-multiple-of-four state dimensions use: same fixtures."""
     if name not in cases():
         pytest.skip('fixture not present')
-    monkeypatch.setenv('RLREP_SCORE_NO_SMALL', '1')
+    monkeypatch.setenv('RLREP_DISABLE', 'score_small')
     test_hip_matches_reference_golden(name)
 
 
@@ -440,7 +440,7 @@ def test_deferred_pipeline_soak_is_bit_identical(alg, S, A, B, calls, kw, monkey
     import importlib
     # both forms on the same POLICY-FORWARD kernels: the sequential form would otherwise run both policy forwards inside the last feature
     # step's launches, the pipelined form inside the critic step's tile launches (different summation order, last-bit differences)
-    monkeypatch.setenv('RLREP_NO_EARLY_POLICY', '1')
+    monkeypatch.setenv('RLREP_DISABLE', 'early_policy')
     import synth
     from rlrep_amd.utils.buffer import ReplayBuffer
     name = {'vlsac': 'VLSACAgent', 'ctrlsac': 'CTRLSACAgent', 'spedersac': 'SPEDERSACAgent'}[alg]

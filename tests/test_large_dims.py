@@ -106,12 +106,12 @@ def test_spedersac_ant_dimensions_two_trains():
 def test_spedersac_split_k_gradients_summed_by_the_optimizer_launch(monkeypatch):
     """Builder::fold_fin (AdamTask::Slab with padded slab rows): the split-K partials of phi / mu's weight gradients -- [512, 119] and [512, 111]
     among them, slab rows padded to 120 / 112 floats -- are added in split order by the feature group's optimizer launch instead of a finishing
-    launch.  Against RLREP_NO_FOLD_DWFIN=1: one launch less per feature step, parameters and moments BIT-identical after two train() calls at
+    launch.  Against RLREP_DISABLE=fold_dwfin: one launch less per feature step, parameters and moments BIT-identical after two train() calls at
     Ant dimensions (both forms are checked against the oracle by _run)."""
     outs, counts = [], []
     for fold in (True, False):
         if not fold:
-            monkeypatch.setenv('RLREP_NO_FOLD_DWFIN', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'fold_dwfin')
         from rlrep_amd import _lib
         n0 = _lib.lib.rlrep_launch_counter()
         a = _run('spedersac', ('rlrep_amd.agent.spedersac.spedersac_agent', 'SPEDERSACAgent'), 111, 8, 1024,
@@ -136,11 +136,11 @@ def test_diffsrsac_wide_nabla_mu_head_on_bf16x3():
 
 
 def test_large_engines_off_gives_the_same_step(monkeypatch):
-    """RLREP_NO_GEMM_LDS=1 keeps every GEMM on the 16-row engine: same train() within fp32 summation-order noise"""
+    """RLREP_DISABLE=gemm_lds keeps every GEMM on the 16-row engine: same train() within fp32 summation-order noise"""
     outs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv('RLREP_NO_GEMM_LDS', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'gemm_lds')
         a = _run('ctrlsac', ('rlrep_amd.agent.ctrlsac.ctrlsac_agent', 'CTRLSACAgent'), 17, 6, 128,
                  dict(hidden_dim=512, feature_dim=1024, extra_feature_steps=0))
         outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})
@@ -160,7 +160,7 @@ def test_vlsac_noise_critic_first_layer_on_bf16x3(S, A, B, F, H, monkeypatch):
     over 8 ranges."""
     import ctypes as C
     from rlrep_amd import _lib
-    monkeypatch.delenv('RLREP_NO_X3', raising=False)
+    monkeypatch.delenv('RLREP_DISABLE', raising=False)
     out = [C.c_int32() for _ in range(3)]
     assert _lib.lib.rlrep_nc_fwd_plan(2, B, F, H, *[C.byref(o) for o in out]) == 0 and out[0].value == 1
     _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), S, A, B,
@@ -177,13 +177,13 @@ def test_vlsac_fused_heads_and_vae_mid_at_odd_shapes(S, A, B, F, H, Hv):
 
 
 def test_vlsac_noise_critic_engines_agree(monkeypatch):
-    """RLREP_NO_X3 keeps the first layer on fp32 MFMA: the same two train() calls end within fp32 rounding of the bf16x3 run."""
+    """RLREP_DISABLE=x3 keeps the first layer on fp32 MFMA: the same two train() calls end within fp32 rounding of the bf16x3 run."""
     outs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv('RLREP_NO_X3', '1')
+            monkeypatch.setenv('RLREP_DISABLE', 'x3')
         else:
-            monkeypatch.delenv('RLREP_NO_X3', raising=False)
+            monkeypatch.delenv('RLREP_DISABLE', raising=False)
         a = _run('vlsac', ('rlrep_amd.agent.vlsac.vlsac_agent', 'VLSACAgent'), 17, 6, 128,
                  dict(hidden_dim=128, feature_dim=128, extra_feature_steps=0), trains=2)
         outs.append({k: v.numpy().copy() for k, v in a.core.state().items()})

@@ -77,10 +77,10 @@ if [ $PART = misc ] || [ $PART = all ]; then
   RLREP_FORCE_DP=1 python3 bench.py --steps 2000 --warmup 200 --no-cpu --no-profile 2>/dev/null | tail -n 1 >> $OUT/r05_dp_rehearsal.jsonl
   RLREP_FORCE_DP=1 RLREP_DP_CAPTURE=0 python3 bench.py --steps 2000 --warmup 200 --no-cpu --no-profile 2>/dev/null | tail -n 1 >> $OUT/r05_dp_rehearsal.jsonl
   RLREP_FORCE_DP=1 RLREP_PIPELINE_DP=1 python3 bench.py --steps 2000 --warmup 200 --no-cpu --no-profile 2>/dev/null | tail -n 1 >> $OUT/r05_dp_rehearsal.jsonl
-  RLREP_STAMP=1 python3 tools/exp/chain_stamps.py > $OUT/r05_chain_stamps.txt 2>&1
+  RLREP_ENABLE=stamp python3 tools/exp/chain_stamps.py > $OUT/r05_chain_stamps.txt 2>&1
   # in-kernel timeline of the 16-row engine's launches (instrumented library: OBJDIR=.obj_tim OUTNAME=librlrep_hip_tim.so EXTRA_FLAGS=-DRL_TIMING bash rlrep_amd/csrc/build.sh)
   [ -f $R/rlrep_amd/lib/librlrep_hip_tim.so ] && RLREP_LIB=$R/rlrep_amd/lib/librlrep_hip_tim.so python3 tools/exp/gemm_timeline.py 2>/dev/null | grep -v amdgpu.ids > $OUT/r05_gemm_timeline.txt
-  RLREP_GEMM16_TRACE=1 python3 tools/exp/gemm16_trace.py 2>&1 | awk '/==== traced/{f=1;next} f' | grep gemm16 > $OUT/r05_gemm16_trace.txt
+  RLREP_ENABLE=gemm16_trace python3 tools/exp/gemm16_trace.py 2>&1 | awk '/==== traced/{f=1;next} f' | grep gemm16 > $OUT/r05_gemm16_trace.txt
   # two gloo ranks on this one GPU through bench.py's N > 1 path: replicas_identical / allreduce_us_per_train fields (not a scaling number)
   RLREP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu --quick 2>/dev/null | tail -n 1 > $OUT/r05_bench_2ranks_gloo_one_gpu.json
 fi

@@ -1,9 +1,9 @@
 """Device-side dates of the two launch chains of the pipelined train() (no profiler): a one-thread stamp launch (rlrep_debug_stamp,
-100 MHz wall clock) is captured at the head and tail of the feature graph and of the critic/actor graph (RLREP_STAMP=1, read by
+100 MHz wall clock) is captured at the head and tail of the feature graph and of the critic/actor graph (RLREP_ENABLE=stamp, read by
 SACAgent).  Prints, over the last calls: chain lengths, the idle time of the feature queue between two calls, the period.
-    RLREP_STAMP=1 python tools/exp/chain_stamps.py [workload]"""
+    RLREP_ENABLE=stamp python tools/exp/chain_stamps.py [workload]"""
 import os, sys
-os.environ.setdefault('RLREP_STAMP', '1')
+os.environ.setdefault('RLREP_ENABLE', 'stamp')
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 import numpy as np, torch

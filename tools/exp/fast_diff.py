@@ -1,4 +1,4 @@
-"""Which tensors differ between the fast front end and RLREP_GEMM16_NO_FAST=1 after n train() calls (two processes, same seeds)."""
+"""Which tensors differ between the fast front end and RLREP_DISABLE=gemm16_fast after n train() calls (two processes, same seeds)."""
 import os, sys, subprocess, pickle
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
@@ -22,7 +22,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.exit(0)
 n, mode = sys.argv[1], sys.argv[2]
 outs = []
-for arm, env in (('fast', {}), ('nofast', {'RLREP_GEMM16_NO_FAST': '1'})):
+for arm, env in (('fast', {}), ('nofast', {'RLREP_DISABLE': 'gemm16_fast'})):
     f = f'/tmp/fast_diff_{arm}.pkl'
     subprocess.check_call([sys.executable, __file__, 'child', n, mode, f], env=dict(os.environ, **env))
     outs.append(pickle.load(open(f, 'rb')))

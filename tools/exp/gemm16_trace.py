@@ -1,8 +1,8 @@
-"""Which front end every gemm16 launch of one train() gets (RLREP_GEMM16_TRACE=1 makes the launcher print one line per launch):
+"""Which front end every gemm16 launch of one train() gets (RLREP_ENABLE=gemm16_trace makes the launcher print one line per launch):
 python tools/exp/gemm16_trace.py [workload]   -- eager train() (stage by stage), the third call traced."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ['RLREP_GEMM16_TRACE'] = '1'
+os.environ['RLREP_ENABLE'] = 'gemm16_trace'
 import torch
 import bench
 

@@ -1,7 +1,7 @@
 """Device-side dating (rlrep_debug_stamp) of the FIRST calls of a timed window: sync, K pipelined train() calls, flush.  Shows where a short
-window (the driver's --steps 20) loses time against the steady state.   RLREP_STAMP=1 python tools/exp/window_stamps.py"""
+window (the driver's --steps 20) loses time against the steady state.   RLREP_ENABLE=stamp python tools/exp/window_stamps.py"""
 import os, sys
-os.environ.setdefault('RLREP_STAMP', '1')
+os.environ.setdefault('RLREP_ENABLE', 'stamp')
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 import numpy as np, torch, time
