@@ -257,9 +257,14 @@ int32_t rlrep_update_target(rlrep_agent* agent, void* stream);
  * method does. */
 int32_t rlrep_begin_train(rlrep_agent* agent, void* stream);
 
-/* Split entry points for data-parallel training: backward part writes the group's gradient arena
- * (caller all-reduces grad_dev[group_offset .. +group_floats (+tail)] over RCCL), apply part runs
- * Adam / Polyak / temperature update.  rlrep_*_step == backward immediately followed by apply. */
+/* Split entry points for data-parallel training: backward part writes the group's gradient arena, apply part runs
+ * Adam / Polyak / temperature update; rlrep_*_step == backward immediately followed by apply.  With hyper.world_size > 1 the
+ * gradient arena is COMPLETE after the backward part: the caller all-reduces grad_dev[group_offset .. +group_floats (+tail)]
+ * between the two -- or has attached a comm (rlrep_comm_attach), in which case the apply part sums the ranks' arenas itself and
+ * the caller issues nothing.  EXCEPTION, hyper.world_size == 1 only: gradients that arrive as split-K partials (vlsac critic
+ * l1 / l4, spedersac phi / mu weight gradients) are summed BY THE APPLY PART's optimizer launch, which files the sums in grad_dev
+ * too; between backward and apply those ranges of grad_dev hold the previous step's values.  A single-rank caller that inspects
+ * or clips gradients between the two parts sets RLREP_DISABLE=fold_ncdw,fold_dwfin (the finishing launches come back). */
 int32_t rlrep_feature_backward(rlrep_agent* agent, const float* eps_dev, const int32_t* noise_idx_dev, void* stream);
 int32_t rlrep_feature_apply(rlrep_agent* agent, void* stream);
 int32_t rlrep_critic_backward(rlrep_agent* agent, const float* eps_dev, void* stream);

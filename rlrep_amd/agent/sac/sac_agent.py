@@ -387,6 +387,8 @@ class SACAgent(object):
         # library's (include/rlrep.h RLREP_GROUP_CFG_WORDS) and changes with it -- a checkpoint of another format is refused by name, not
         # by an opaque copy_ shape error
         fmt, nbytes = snap.get('format'), snap.get('device_state_bytes', snap['device_state'].numel())
+        if fmt is None and int(nbytes) == int(c.device_state().numel()):
+            fmt = self.CHECKPOINT_FORMAT       # a snapshot written before the key existed, with device records of exactly this layout's size
         if fmt != self.CHECKPOINT_FORMAT or int(nbytes) != int(c.device_state().numel()) or snap['device_state'].numel() != c.device_state().numel():
             raise RuntimeError(f'checkpoint does not match this library: format {fmt!r} with {int(nbytes)} bytes of device records, this build '
                                f'writes format {self.CHECKPOINT_FORMAT!r} with {int(c.device_state().numel())} (saved by another version of rlrep_amd)')

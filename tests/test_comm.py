@@ -136,8 +136,9 @@ def test_a_rank_that_never_arrives_sets_the_mask_and_raises_within_the_timeout()
     assert took < 30.0, took
 
 
-def _agent_body(rank, world, q, case, fused, graph, calls):
+def _agent_body(rank, world, q, case, fused, graph, calls, pipe_dp=False):
     os.environ['RLREP_DP_FUSED'] = '1' if fused else '0'
+    os.environ['RLREP_PIPELINE_DP'] = '1' if pipe_dp else '0'
     from fixture_io import Case
     from test_hip_parity import make_agent, make_buffer
     from test_dp import _inputs
@@ -155,7 +156,7 @@ def _agent_body(rank, world, q, case, fused, graph, calls):
             if rank == 0 and t == 1:
                 float(next(iter(info.values())))             # ONE rank reads its metrics (a flush): no collective behind it, the ranks stay in step
         agent.flush()
-        took = 'pipe' if agent._pipe is not None else ('graph' if not isinstance(agent._graph, list) else 'segments:%d' % sum(1 for k, _ in agent._graph if k == 'coll'))
+        took = ('pipe' if agent._pipe.get('mode') != 3 else 'pipe_dp') if agent._pipe is not None else ('graph' if not isinstance(agent._graph, list) else 'segments:%d' % sum(1 for k, _ in agent._graph if k == 'coll'))
     else:
         rs = np.random.RandomState(11)
         for t in range(calls):
@@ -192,17 +193,20 @@ def test_train_with_gradients_summed_in_the_optimizer_launches_equals_gloo(case,
 
 
 @pytest.mark.parametrize('case', ['vlsac_tiny', 'vlsac_hc'])
-def test_default_graph_forms_with_two_ranks_equal_the_gloo_segments(case):
+def test_default_graph_forms_with_two_ranks_equal_the_gloo_forms(case):
     """The default train() with two ranks: with the exchange inside the optimizer launches it is the single-GPU form -- two chains on two streams,
-    whole hipGraphs, no collective anywhere -- and ends in exactly the state of the torch.distributed form (graph segments around six gloo
-    all-reduces), select_action and a one-sided metrics read in between."""
+    whole hipGraphs, no collective anywhere -- and ends in exactly the state of BOTH torch.distributed forms: graph segments around six gloo
+    all-reduces (sequential), and the two-chain form with one process group per chain (RLREP_PIPELINE_DP=1); select_action and a one-sided
+    metrics read in between.  vlsac_hc = the headline dimensions."""
     out = {}
-    for fused in (True, False):
-        res = _spawn('_agent_body', 2, case, fused, True, 6, timeout=600)
+    for form, (fused, pipe_dp) in (('fused', (True, False)), ('segments', (False, False)), ('pipe_dp', (False, True))):
+        res = _spawn('_agent_body', 2, case, fused, True, 6, pipe_dp, timeout=600)
         for k, v in res[0][0].items():
-            assert np.array_equal(v, res[1][0][k]), f'replicas diverged at {k} (fused={fused})'
-        out[fused] = res[0]
-    assert out[True][1] == 'pipe', out[True][1]
-    assert out[False][1].startswith('segments:6'), out[False][1]
-    for k, v in out[True][0].items():
-        assert np.array_equal(v, out[False][0][k]), f'in-launch exchange != gloo segments at {k}'
+            assert np.array_equal(v, res[1][0][k]), f'replicas diverged at {k} ({form})'
+        out[form] = res[0]
+    assert out['fused'][1] == 'pipe', out['fused'][1]
+    assert out['segments'][1].startswith('segments:6'), out['segments'][1]
+    assert out['pipe_dp'][1] == 'pipe_dp', out['pipe_dp'][1]
+    for form in ('segments', 'pipe_dp'):
+        for k, v in out['fused'][0].items():
+            assert np.array_equal(v, out[form][0][k]), f'in-launch exchange != gloo {form} at {k}'
