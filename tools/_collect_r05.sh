@@ -82,6 +82,11 @@ if [ $PART = misc ] || [ $PART = all ]; then
   [ -f $R/rlrep_amd/lib/librlrep_hip_tim.so ] && RLREP_LIB=$R/rlrep_amd/lib/librlrep_hip_tim.so python3 tools/exp/gemm_timeline.py 2>/dev/null | grep -v amdgpu.ids > $OUT/r05_gemm_timeline.txt
   RLREP_ENABLE=gemm16_trace python3 tools/exp/gemm16_trace.py 2>&1 | awk '/==== traced/{f=1;next} f' | grep gemm16 > $OUT/r05_gemm16_trace.txt
   # two gloo ranks on this one GPU through bench.py's N > 1 path: replicas_identical / allreduce_us_per_train fields (not a scaling number)
-  RLREP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu --quick 2>/dev/null | tail -n 1 > $OUT/r05_bench_2ranks_gloo_one_gpu.json
+  # (a protocol rehearsal, not a scaling number: the two processes time-share the GPU).  Default = gradients summed inside the optimizer launches;
+  # RLREP_DP_FUSED=0 = gloo all-reduces between graph segments
+  RLREP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 500 --warmup 100 --no-cpu --quick 2>/dev/null | tail -n 1 > $OUT/r05_bench_2ranks_fused_one_gpu.json
+  cat $OUT/r05_bench_2ranks_fused_one_gpu.json >> $OUT/r05_dp_rehearsal.jsonl
+  RLREP_DP_FUSED=0 RLREP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 30 --warmup 5 --no-cpu --quick 2>/dev/null | tail -n 1 > $OUT/r05_bench_2ranks_gloo_one_gpu.json
+  cat $OUT/r05_bench_2ranks_gloo_one_gpu.json >> $OUT/r05_dp_rehearsal.jsonl
 fi
 echo collected
