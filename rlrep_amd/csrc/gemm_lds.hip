@@ -152,7 +152,15 @@ __device__ __forceinline__ void gl_epilogue1(const GemmTask& t, int r, int c, fl
     }
 }
 
-__device__ __forceinline__ void gl_epilogue4(const GemmTask& t, int r, int c, f32x4 v) {
+// bias_pre: the four bias values of columns c .. c + 3, loaded by the caller BEFORE its store loop (a tile's store loop keeps its columns and walks the
+// rows: loaded here, the bias was a dependent global round trip in every iteration -- eight per wave and 128-wide tile, ~15 us of a 60 us workgroup
+// in the 788 MB forward of the nabla-mu head); nullptr: load it here
+__device__ __forceinline__ f32x4 gl_bias4(const GemmTask& t, int c) {
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (t.epi == EPI_FWD && t.bias && !(t.flags & FLAG_SCALAR_C) && c + 4 <= t.Cn) b = ld4(t.bias + c);
+    return b;
+}
+__device__ __forceinline__ void gl_epilogue4(const GemmTask& t, int r, int c, f32x4 v, const f32x4* bias_pre = nullptr) {
     if (t.flags & FLAG_SCALAR_C) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (c + q < t.Cn) gl_epilogue1(t, r, c + q, v[q]);
@@ -161,7 +169,7 @@ __device__ __forceinline__ void gl_epilogue4(const GemmTask& t, int r, int c, f3
     v *= t.scale;
     float* cp = t.C + (size_t)r * t.ldc + c;
     if (t.epi == EPI_FWD) {
-        if (t.bias) v += ld4(t.bias + c);
+        if (t.bias) v += bias_pre ? *bias_pre : ld4(t.bias + c);
         f32x4 y;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(GL_D
 #pragma unroll
             for (int q = 0; q < 4; ++q) E[(a * 16 + 4 * kq + q) * (WT + 4) + b * 16 + i] = acc[a][b][q];
     constexpr int LPR = WT / 4, RPI = 64 / LPR;
+    const f32x4 bpre = splits > 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : gl_bias4(t, c0 + wc * WT + (lane % LPR) * 4);      // (this lane's columns: the same in every iteration)
 #pragma unroll 4
     for (int it = 0; it < WT / RPI; ++it) {
         const int rr = it * RPI + lane / LPR, cc = (lane % LPR) * 4;
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 4)) void gemm_lds_kernel(GL_D
         const int r = r0 + wr * WT + rr, c = c0 + wc * WT + cc;
         if (r < R && c < Cn) {
             if (splits > 1) st4(t.slab + ((size_t)split * R + r) * C4w + c, v);       // partial tile: the finishing blocks add the slabs in split order
-            else gl_epilogue4(t, r, c, v);
+            else gl_epilogue4(t, r, c, v, &bpre);
         }
     }
 }
@@ -546,6 +555,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GL_DIR_PARAMS, GemmBatc
     for (int y = 0; y < 2; ++y)
 #pragma unroll
         for (int q = 0; q < 16; ++q) E[((q & 3) + 8 * (q >> 2) + 4 * hh) * 68 + y * 32 + r32] = acc[y][q];
+    const f32x4 bpre = splits > 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : gl_bias4(t, c0 + wc * 64 + (lane & 15) * 4);      // (this lane's columns: the same in every iteration)
 #pragma unroll 4
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(GL_DIR_PARAMS, GemmBatc
         const int r = r0 + wr * 32 + rr, c = c0 + wc * 64 + cc;
         if (r < R && c < Cn) {
             if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
-            else gl_epilogue4(t, r, c, v);
+            else gl_epilogue4(t, r, c, v, &bpre);
         }
     }
 }
@@ -739,6 +749,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBat
     for (int y = 0; y < 2; ++y)
 #pragma unroll
         for (int q = 0; q < 16; ++q) E[((q & 3) + 8 * (q >> 2) + 4 * hh) * 68 + y * 32 + r32] = acc[y][q];
+    const f32x4 bpre = splits > 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : gl_bias4(t, c0 + wc * 64 + (lane & 15) * 4);      // (this lane's columns: the same in every iteration)
 #pragma unroll 4
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + (lane >> 4), cc = (lane & 15) * 4;
@@ -746,7 +757,7 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBat
         const int r = r0 + wr * 32 + rr, c = c0 + wc * 64 + cc;
         if (r < R && c < Cn) {
             if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
-            else gl_epilogue4(t, r, c, v);
+            else gl_epilogue4(t, r, c, v, &bpre);
         }
     }
 }
@@ -989,6 +1000,7 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     float* E = lds + w * (32 * 36);
 #pragma unroll
     for (int q = 0; q < 16; ++q) E[((q & 3) + 8 * (q >> 2) + 4 * hh) * 36 + r32] = acc[q];
+    const f32x4 bpre = splits > 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : gl_bias4(t, c0 + wc * 32 + (lane & 7) * 4);       // (this lane's columns: the same in every iteration)
 #pragma unroll 4
     for (int it = 0; it < 4; ++it) {
         const int rr = it * 8 + (lane >> 3), cc = (lane & 7) * 4;
@@ -996,7 +1008,7 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
         const int r = r0 + wr * 32 + rr, c = c0 + wc * 32 + cc;
         if (r < R && c < Cn) {
             if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
-            else gl_epilogue4(t, r, c, v);
+            else gl_epilogue4(t, r, c, v, &bpre);
         }
     }
 }
