@@ -37,26 +37,42 @@ class GradientExchange:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.arena_floats = int(arena_floats)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        h = C.c_void_p()
-        torch.cuda.synchronize()
-        check(lib.rlrep_comm_create(self.rank, self.world, self.arena_floats, C.byref(h)), 'comm_create')
-        self.h = h
-        self.fine_grained = bool(lib.rlrep_comm_fine_grained(self.h))
+        # Every step that can fail on ONE rank only (allocation, export, mapping a peer's block) is caught and turned into a flag the ranks
+        # agree on: a rank that raised here while its peers went on to the next collective would hang them.
+        self.h, self.arena, self.fine_grained, self.error = None, None, False, None
         dev = torch.cuda.current_device()
-        self.arena = torch.as_tensor(_Arena(lib.rlrep_comm_arena(self.h), self.arena_floats), device=f'cuda:{dev}')
-        nb = lib.rlrep_comm_handle_bytes()
-        mine = C.create_string_buffer(nb)
-        check(lib.rlrep_comm_handle(self.h, mine, nb), 'comm_handle')
+        mine = None
+        try:
+            h = C.c_void_p()
+            torch.cuda.synchronize()
+            check(lib.rlrep_comm_create(self.rank, self.world, self.arena_floats, C.byref(h)), 'comm_create')
+            self.h = h
+            self.fine_grained = bool(lib.rlrep_comm_fine_grained(self.h))
+            self.arena = torch.as_tensor(_Arena(lib.rlrep_comm_arena(self.h), self.arena_floats), device=f'cuda:{dev}')
+            nb = lib.rlrep_comm_handle_bytes()
+            buf = C.create_string_buffer(nb)
+            check(lib.rlrep_comm_handle(self.h, buf, nb), 'comm_handle')
+            mine = bytes(buf.raw)
+        except Exception as e:                     # noqa: BLE001 (reported through self.error / probe())
+            self.error = f'{type(e).__name__}: {e}'
         props = torch.cuda.get_device_properties(dev)
         where = (socket.gethostname(), str(getattr(props, 'uuid', '')) or str(getattr(props, 'pci_bus_id', dev)), dev)
         everyone = [None] * self.world
-        dist.all_gather_object(everyone, (bytes(mine.raw), where, self.fine_grained), group=group)
+        dist.all_gather_object(everyone, (mine, where, self.fine_grained), group=group)
         self.same_device = len({w[1][:2] for w in everyone}) == 1
         # plain (coarse-grained) device memory is only coherent for peers on the SAME GPU; across GPUs the block must be fine-grained on every rank
-        self.usable = self.same_device or all(w[2] for w in everyone)
-        blob = C.create_string_buffer(b''.join(w[0] for w in everyone), nb * self.world)
-        check(lib.rlrep_comm_connect(self.h, blob), 'comm_connect')
-        dist.barrier(group=group)                # nobody signals before every block is mapped everywhere
+        self.usable = all(w[0] is not None for w in everyone) and (self.same_device or all(w[2] for w in everyone))
+        connected = False
+        if self.usable:
+            try:
+                nb = lib.rlrep_comm_handle_bytes()
+                blob = C.create_string_buffer(b''.join(w[0] for w in everyone), nb * self.world)
+                check(lib.rlrep_comm_connect(self.h, blob), 'comm_connect')
+                connected = True
+            except Exception as e:                 # noqa: BLE001
+                self.error = f'{type(e).__name__}: {e}'
+        # nobody signals before every block is mapped everywhere -- and everybody learns whether it is
+        self.usable = self._agree(self.usable and connected)
         self._scratch = None
 
     # ---- the stand-alone exchange (probe, tests) -------------------------------------------------------------------------------------
@@ -78,18 +94,29 @@ class GradientExchange:
         n = int(min(self.arena_floats, n or (1 << 18)))
         ok = self.usable
         if ok:
-            for r in range(rounds):
-                pats = [self._pattern(q, r, n) for q in range(self.world)]
-                self.arena[:n].copy_(torch.from_numpy(pats[self.rank]))
+            try:
+                for r in range(rounds):
+                    pats = [self._pattern(q, r, n) for q in range(self.world)]
+                    self.arena[:n].copy_(torch.from_numpy(pats[self.rank]))
+                    torch.cuda.synchronize()
+                    self._agree(True)                  # (every rank's pattern is in its arena before anybody reads it: the probe has no producer launch in front)
+                    got = self.all_reduce(0, n).cpu().numpy()
+                    want = pats[0].copy()
+                    for q in range(1, self.world):
+                        want = want + pats[q]
+                    ok = ok and bool(np.array_equal(got, want))
+                    if not ok and self.error is None:
+                        self.error = f'probe round {r}: the exchange did not return the rank-ordered sum'
+                ok = ok and self.status(raise_on_error=False) == 0
+                self.arena[:n].zero_()
                 torch.cuda.synchronize()
-                got = self.all_reduce(0, n).cpu().numpy()
-                want = pats[0].copy()
-                for q in range(1, self.world):
-                    want = want + pats[q]
-                ok = ok and bool(np.array_equal(got, want))
-            ok = ok and self.status(raise_on_error=False) == 0
-            self.arena[:n].zero_()
-            torch.cuda.synchronize()
+            except Exception as e:                     # noqa: BLE001 (a rank that raised here would leave its peers in the next collective)
+                ok, self.error = False, f'{type(e).__name__}: {e}'
+        return self._agree(ok)
+
+    def _agree(self, ok):
+        """True only if `ok` on every rank (a collective; also the barrier between mapping and first use)."""
+        import torch.distributed as dist
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
         if dist.get_backend(self.group) == 'nccl':
             flag = flag.cuda()
@@ -110,6 +137,8 @@ class GradientExchange:
 
     def status(self, raise_on_error=True, clear=False):
         """Late-rank mask of the waits that ran out so far (0: none).  Reads a word in mapped host memory: no device synchronisation."""
+        if not self.h:
+            return 0
         m = C.c_uint32(0)
         rc = lib.rlrep_comm_status(self.h, C.byref(m), 1 if clear else 0)
         if rc != 0 and raise_on_error:

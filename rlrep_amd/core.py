@@ -156,7 +156,7 @@ class HipCore:
                 else:
                     if dist.get_rank() == 0:
                         warnings.warn('rlrep_amd: the in-launch gradient exchange did not pass its probe on this set of ranks '
-                                      f'(fine-grained block: {ex.fine_grained}, ranks on one device: {ex.same_device}); gradients go through torch.distributed')
+                                      f'(fine-grained block: {ex.fine_grained}, ranks on one device: {ex.same_device}, {ex.error or "a peer reported the failure"}); gradients go through torch.distributed')
                     ex.close()
         self.exp_avg, self.exp_avg_sq = carve(3, torch.float32), carve(4, torch.float32)
         self.workspace = carve(5, torch.uint8)
