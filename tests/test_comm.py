@@ -210,3 +210,22 @@ def test_default_graph_forms_with_two_ranks_equal_the_gloo_forms(case):
     for form in ('segments', 'pipe_dp'):
         for k, v in out['fused'][0].items():
             assert np.array_equal(v, out[form][0][k]), f'in-launch exchange != gloo {form} at {k}'
+
+
+def test_four_ranks_match_the_global_batch_oracle():
+    """Four processes on the one GPU, every gradient slice summed inside its optimizer launch: replicas bit-identical, and equal (1e-4) to the
+    CPU oracle run on the concatenated global batch of 4 B rows -- the rank-ordered sum of four arenas against autograd on one batch."""
+    from fixture_io import Case, rel_l2
+    from test_dp import _inputs, _oracle_global
+    world, case = 4, 'vlsac_tiny'
+    res = _spawn('_agent_body', world, case, True, False, 2, timeout=600)
+    for r in range(1, world):
+        for k, v in res[0][0].items():
+            assert np.array_equal(v, res[r][0][k]), f'replicas diverged at {k} (rank {r})'
+    c = Case(case)
+    rs = np.random.RandomState(11)
+    per_rank = [_inputs(c, rs, world) for _ in range(2)]
+    P = _oracle_global(c, per_rank, trains=2).state()
+    for k, v in res[0][0].items():
+        if k in P and not k.endswith('noise'):
+            assert rel_l2(v, P[k].numpy()) < 1e-4, k
