@@ -652,11 +652,11 @@ class SACAgent(object):
     @contextlib.contextmanager
     def _managed_images(self):
         """Around the capture of a single-GPU train() graph: the critic steps recorded inside do not carry the image-refresh launch."""
-        # OPT-IN (RLREP_ENABLE=managed_images).  Measured on MI355X, three alternations in one call (profiles/r04_ab_chain_cuts.txt): the launch it
-        # takes off the critic / actor chain is worth +0.3 % in the sequential form and COSTS 2.9 % in the two-chain form (3 510 -> 3 380
-        # train()/s): the chains are balanced, and the critic / actor chain starting 5 us earlier shifts its chip-filling noise-critic launches
-        # onto other feature-chain launches.  The default keeps the refresh launch at the head of every critic step.
-        on = _sw.opt('managed_images') is not None and self.core.images_managed(True)
+        # Default since round 5 (RLREP_DISABLE=managed_images keeps the refresh launch at the head of every critic step).  Round 4 had measured it
+        # at +0.3 % in the sequential form and -2.9 % in the two-chain form, when the feature chain alone bounded the period; with both chains
+        # co-critical (docs/history/r05.md: a delay launch on either chain lengthens the period) the launch it takes off the critic / actor chain
+        # returns +0.8 % (3 877 / 3 886 / 3 874 -> 3 914 / 3 916 / 3 899 train()/s, three alternations on one box).
+        on = not _sw.off('managed_images') and self.core.images_managed(True)
         self._img_on = self._img_on or on
         try:
             yield

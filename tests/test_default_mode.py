@@ -424,6 +424,45 @@ def test_noise_critic_weight_images_follow_external_parameter_writes():
             assert abs(float(info[k]) - v) <= 1e-4 * max(abs(v), 1e-2), (step, k, float(info[k]), v)
 
 
+def test_managed_weight_images_follow_external_writes_between_graph_replays(monkeypatch):
+    """Captured train() graphs leave the noise critic's bf16x3 weight images to the optimizer launches (no refresh launch at the head of the critic
+    step: rlrep_images_managed).  Anything else that writes the critic -- here the caller overwrites parameters, targets and optimizer state between
+    two replays -- is noticed (torch's version counter of the arena block, the agent's dirty flag) and the images are regenerated before the next
+    replay: the run ends bit-identical to the same run with the refresh launch kept (RLREP_DISABLE=managed_images), at the headline dimensions."""
+    import synth
+    from rlrep_amd.utils.buffer import ReplayBuffer
+    from rlrep_amd.agent.vlsac.vlsac_agent import VLSACAgent
+    c = Case('vlsac_hc')
+    data = synth.replay(17, 6, 8192, seed=0)
+    outs = []
+    for managed in (True, False):
+        if not managed:
+            monkeypatch.setenv('RLREP_DISABLE', 'managed_images')
+        torch.manual_seed(0)
+        agent = VLSACAgent(state_dim=17, action_dim=6, action_space=_Space(6, 1.0), max_batch=256, pipeline=True, seed=79,
+                           hidden_dim=256, feature_dim=256, extra_feature_steps=3)
+        assert agent._img_on is False
+        buf = ReplayBuffer(17, 6, max_size=8192)
+        buf.load(data['state'], data['action'], data['next_state'], data['reward'], data['done'])
+        for _ in range(5):
+            agent.train(buf, 256)
+        agent.flush()
+        assert agent._img_on == managed
+        agent.core.load_state(c.init)                                 # parameters AND targets replaced behind the library's back
+        agent.core.exp_avg.zero_(); agent.core.exp_avg_sq.zero_()
+        for _ in range(5):
+            agent.train(buf, 256)
+        agent.select_action(np.zeros(17, np.float32))                 # (the one-graph form's capture goes through the same bracket)
+        for _ in range(4):
+            agent.train(buf, 256); agent.select_action(np.zeros(17, np.float32))
+        agent.flush()
+        st = {k: v.numpy().copy() for k, v in agent.core.state().items()}
+        outs.append(st)
+        del agent, buf
+    for k in outs[1]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize('name', ['vlsac_tiny_noft', 'ctrlsac_tiny_noft', 'spedersac_tiny_noft'])
 def test_default_mode_without_feature_target(name):
     """use_feature_target=False in the default (graph, pipelined) mode: vlsac's deferred critic / actor chain then runs against a snapshot
