@@ -755,6 +755,12 @@ def main():
                 out['launches_per_train'] = out['chains'].get('feature_chain_launches', 0) + out['chains'].get('critic_actor_chain_launches', 0)
             elif getattr(agent, '_graph_launches', None):
                 out['launches_per_train'] = int(agent._graph_launches)
+        if 'launches_per_train' not in out:          # (N > 1, or --no-profile: the count needs no timing)
+            P = getattr(agent, '_pipe', None)
+            if P and 'launches' in P:
+                out['launches_per_train'] = int(P['launches'][0]) + int(P['launches'][1])
+            elif getattr(agent, '_graph_launches', None):
+                out['launches_per_train'] = int(agent._graph_launches)
         # which front end the 16-row tile engine's launches of ONE train() got when the running graphs were captured (rlrep_front_end_counts):
         # fast / fast4 / fastpre issue their operand loads from preloaded scalars, `record` fetches its task record first
         fe = (getattr(agent, '_pipe', None) or {}).get('front_ends') or getattr(agent, '_graph_front_ends', None)

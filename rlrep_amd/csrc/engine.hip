@@ -915,7 +915,8 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
             rlrep_agent::DeferSet& D = ag->dset[set];
             const LT& p0 = ag->L.get("f.l1.weight");
             D.block_off = p0.off - ag->L.group_off[0]; D.block_n = fl.off + fl.rows - f0.off; D.block_which = nft ? 0 : 1;
-            if (rl_off("fold_snapshot") || ag->h.world_size > 1) D.block_which = -1;
+            // (with N > 1 ranks too: the optimizer launch that writes the snapshot is the one that has summed the ranks' gradients)
+            if (rl_off("fold_snapshot")) D.block_which = -1;
         }
         critic_program(ag->dset[set].critic_bwd, can_hoist ? 1 : 0);
         actor_program(ag->dset[set].actor_bwd, ag->dset[set].actor_resume);
