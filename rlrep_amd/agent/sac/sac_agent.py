@@ -398,6 +398,7 @@ class SACAgent(object):
         hyper = c.group_cfg()[:, 1:6].clone()          # lr, betas, eps, tau are THIS agent's constructor arguments, not the checkpoint's:
         c.device_state().copy_(snap['device_state'])   # the device records come back with the checkpoint's step counters only
         c.group_cfg()[:, 1:6].copy_(hyper)
+        c.sync_step_mirror()
         self.steps, self._ctr, self._seed = snap['steps'], snap['noise_ctr'], snap['seed']
         self._img_dirty = True
         self._graph = None

@@ -491,6 +491,13 @@ class HipCore:
         end = self._metrics_ptr - self.workspace.data_ptr() + 4 * METRIC_SLOTS
         return self.workspace[:end]
 
+    def sync_step_mirror(self):
+        """After foreign writes into the device records (a checkpoint load): word 2 of the train() counter block -- what the next train prologue
+        reads -- follows word 0 (csrc/elementwise.hip train_prologue_kernel).  Snapshots written before the split carry a zero there."""
+        off = lib.rlrep_steps_dev(self.h) - self.workspace.data_ptr()
+        w = self.workspace[off:off + 32].view(torch.int32)
+        w[2] = w[0]
+
     def group_cfg(self):
         """float32[4, 22] view of the optimizer groups' device records (include/rlrep.h rlrep_group_cfg_dev): column 0 is the int32
         step counter (bit pattern), columns 1..5 = lr, beta1, beta2, eps, tau."""

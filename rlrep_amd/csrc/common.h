@@ -197,6 +197,9 @@ struct AdamTask {
     int nslab;
     // ranges of the group that this launch leaves alone (their optimizer ran in the weight-gradient epilogues: FLAG_ADAM); multiples of 4 floats
     int nskip; long long skip_off[2], skip_n[2];
+    // train() counter block {counter, -, counter as the NEXT train prologue will read it}: the optimizer launches that follow a prologue in ITS launch
+    // chain (the feature group's; every group's for an agent without one) bring word 2 up to word 0 (elementwise.hip train_prologue_kernel)
+    int* sync_steps;
 };
 
 struct PolyakTask {

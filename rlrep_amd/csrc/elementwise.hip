@@ -168,15 +168,12 @@ __global__ __launch_bounds__(256) void train_prologue_kernel(TrainPrologue p) {
         g.hi = p.idx.hi_dev ? *p.idx.hi_dev : p.idx.hi;
         fill_slot_body(p.fill, g, bid - p.nb_idx - p.nb_eps, p.nb_fill);
     }
-    // steps += 1 once EVERY block has read the old value: the block that draws the last ticket does it
-    // (no fence: the barrier is passed only by threads whose reads of the counter have returned -- their values were
-    // used above -- and the increment is ordered behind every block's ticket; the agent-scope fence that used to sit
-    // here was executed by ~300 blocks and cost most of this launch's 11 us)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tk = atomicAdd(p.ticket, 1);
-        if (tk == (int)gridDim.x - 1) { *p.counter += 1; *p.ticket = 0; }
-    }
+    // steps += 1.  Every block of this launch reads the counter -- so none of them may write what the others read: the blocks read word 2 of the
+    // counter block ("the counter as the next prologue will read it", p.idx.step_dev), ONE thread writes word 0 = word 2 + 1 (what every later
+    // launch reads), and the first optimizer launch behind this one in the chain brings word 2 up to word 0 (AdamTask::sync_steps).  (It used to
+    // be one word, bumped by the block that drew the last of ~300 tickets from an atomic counter: 3.6 us of same-address atomics at the head of
+    // every train(); timing-only build without it: 3 921 -> 3 958 train()/s.)
+    if (bid == 0 && threadIdx.x == 0) *p.counter = *p.idx.step_dev + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,6 +495,7 @@ __device__ __forceinline__ void adam_block(const int bid, float* __restrict__ ap
         // trailing block: finalises the step's metrics / temperature
         unsigned dpe = 0;
         if constexpr (dpon) dpe = dp_begin(dp, false, true);
+        if (threadIdx.x == 64 && t.sync_steps) t.sync_steps[2] = t.sync_steps[0];          // (beside the metric tasks, not in their serial chain)
         if (threadIdx.x < 64) finalize_tasks(fin, nfin, threadIdx.x, dpon ? &dp : nullptr);
         if constexpr (dpon) dp_end(dp, dpe, true);
         return;
@@ -689,7 +687,7 @@ __global__ __launch_bounds__(256) void polyak_kernel(PolyakTask t) {
         t.dst[i] = t.tau * t.src[i] + omt * t.dst[i];
 }
 
-__global__ void counter_inc_kernel(int* c) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1; }
+__global__ void counter_inc_kernel(int* c, int mirror) { if (threadIdx.x == 0 && blockIdx.x == 0) { const int v = *c + 1; *c = v; if (mirror) c[mirror] = v; } }
 
 __global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
@@ -841,8 +839,9 @@ extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {
     hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(t->n, 1024, 1024)), dim3(256), 0, st, *t);
     return (int)hipGetLastError();
 }
-extern "C" int rl_launch_counter_inc(int* c, hipStream_t st) {
-    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, c);
+// mirror > 0: c[mirror] follows c[0] (the train() counter's copy for the next train prologue)
+extern "C" int rl_launch_counter_inc(int* c, int mirror, hipStream_t st) {
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, c, mirror);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_copy_segs(const CopySegs* p, hipStream_t st) {

@@ -48,7 +48,7 @@ int rl_launch_adam(const AdamTask* task, int adam_blocks, const FinTask* fin, in
 int rl_launch_adam_l1(const AdamTask* task, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const GemmTask* g0, const GemmTask* g1, hipStream_t st);
 int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st);
 int rl_launch_polyak(const PolyakTask* t, hipStream_t st);
-int rl_launch_counter_inc(int* c, hipStream_t st);
+int rl_launch_counter_inc(int* c, int mirror, hipStream_t st);
 int rl_launch_copy(const float* src, float* dst, long long n, hipStream_t st);
 int rl_launch_copy_segs(const CopySegs* p, hipStream_t st);
 int rl_launch_shadow(const ShadowEnt* sh_dev, int nsh, int ntiles, const float* base, int target, hipStream_t st);

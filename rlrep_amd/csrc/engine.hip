@@ -1327,11 +1327,11 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
     if (rc) return rc;
     TrainPrologue tp; memset(&tp, 0, sizeof(tp));
     tp.idx.dst_i = idx_pool_dev; tp.idx.n = n_idx; tp.idx.kind = 1; tp.idx.hi = 1; tp.idx.hi_dev = size_dev;
-    tp.idx.seed = seed; tp.idx.offset = idx_offset; tp.idx.step_dev = ag->steps; tp.idx.step_add = 1;
+    tp.idx.seed = seed; tp.idx.offset = idx_offset; tp.idx.step_dev = ag->steps + 2; tp.idx.step_add = 1;
     tp.eps.dst_f = eps_pool_dev; tp.eps.n = n_eps; tp.eps.kind = 0; tp.eps.std = 1.0f;
-    tp.eps.seed = seed; tp.eps.offset = eps_offset; tp.eps.step_dev = ag->steps; tp.eps.step_add = 1;
+    tp.eps.seed = seed; tp.eps.offset = eps_offset; tp.eps.step_dev = ag->steps + 2; tp.eps.step_add = 1;
     slot_fill_params(ag, 0, ring_dev, nullptr, tp.fill);
-    tp.counter = ag->steps; tp.ticket = ag->steps + 1;
+    tp.counter = ag->steps; tp.ticket = nullptr;          // (word 2 of the counter block is what the prologue's blocks read: train_prologue_kernel)
     tp.sh = ag->sh_dev[0]; tp.nsh = ag->nsh[0]; tp.nb_tr = ag->sh_tiles[0]; tp.sh_base = ag->a.param_dev + ag->L.group_off[0];
     rc = (++g_rl_launches, rl_launch_train_prologue(&tp, (hipStream_t)stream));
     if (rc) { rl_set_error("train_prologue: hip error %d", rc); return RLREP_ERR_HIP; }
@@ -1418,7 +1418,7 @@ int32_t rlrep_feature_backward(rlrep_agent* ag, const float* eps, const int32_t*
     if (ag->d.alg == RLREP_ALG_SPEDERSAC && !ag->slot[1].filled) { rl_set_error("spedersac feature step needs batch slot 1"); return RLREP_ERR_STATE; }
     ag->cur_eps = eps; ag->cur_idx = idx; ag->last_launches = 0;
     if (!ag->in_train && ag->has_shadows()) { const int rs = refresh_shadows(ag, stream); if (rs) return rs; }     // parameters may have been written by the caller
-    if (!ag->in_train && rl_rowprog_enabled() && ag->rp_epoch) (void)(++g_rl_launches, rl_launch_counter_inc(ag->rp_epoch, (hipStream_t)stream));   // a fresh epoch whatever ran before
+    if (!ag->in_train && rl_rowprog_enabled() && ag->rp_epoch) (void)(++g_rl_launches, rl_launch_counter_inc(ag->rp_epoch, 0, (hipStream_t)stream));   // a fresh epoch whatever ran before
     ag->pi_ready = nullptr;                                       // f_target is about to change
     ag->early_ready_crit = ag->early_ready_act = nullptr;
     // chained feature steps: the previous step's optimizer launch already ran this step's first stage (encoder.l1 / f.l1)
@@ -1543,7 +1543,7 @@ int32_t rlrep_update_target(rlrep_agent* ag, void* stream) {
 }
 int32_t rlrep_begin_train(rlrep_agent* ag, void* stream) {
     if (!ag) return RLREP_ERR_ARG;
-    int rc = (++g_rl_launches, rl_launch_counter_inc(ag->steps, (hipStream_t)stream));
+    int rc = (++g_rl_launches, rl_launch_counter_inc(ag->steps, 2, (hipStream_t)stream));
     if (rc) { rl_set_error("begin_train: hip error %d", rc); return RLREP_ERR_HIP; }
     if (ag->has_shadows() && (rc = refresh_shadows(ag, stream)) != 0) return rc;
     ag->in_train = true; ag->target_done = false;

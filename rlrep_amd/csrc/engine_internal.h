@@ -470,6 +470,7 @@ struct Builder {
         t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = pol_steps; t.pol_period = pol_period;
         t.sh = ag->sh_dev[group]; t.nsh = ag->nsh[group];
+        t.sync_steps = (group == 0 || ag->d.alg == RLREP_ALG_SAC) ? ag->steps : nullptr;      // (launches in the train prologue's own chain)
         t.nslab = (int)std::min<size_t>(group_slabs[group].size(), 8);
         for (int q = 0; q < t.nslab; ++q) t.slabs[q] = group_slabs[group][q];
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
@@ -522,6 +523,7 @@ struct Builder {
         t.grp = ag->adam_step + group;
         t.target = target; t.pol_off = pol_off - off; t.pol_n = pol_n; t.tau = tau; t.pol_steps = nullptr; t.pol_period = 1;
         t.nskip = 2; t.skip_off[0] = skip0; t.skip_n[0] = n0; t.skip_off[1] = skip1; t.skip_n[1] = n1;
+        t.sync_steps = ag->steps;          // (group 0: in the train prologue's own chain)
         if (!fin.empty() && fin.back().kind == FIN_HISTORY) fin.pop_back();
         const FinTask* fdev = fin.empty() ? nullptr : upload(fin);
         const int nfin = (int)fin.size();

@@ -34,7 +34,7 @@ struct TrainPrologue {
     PhiloxFill idx, eps;
     SlotFill fill;             // fill.idx == nullptr: row b uses element b of the `idx` stream
     int nb_idx, nb_eps, nb_fill;
-    int* counter; int* ticket;
+    int* counter; int* ticket;          // counter: word 0 of the train() counter block (written); idx.step_dev: word 2 (read); ticket: unused
     // transposed weight shadows regenerated from the parameters as they stand at the head of this train() (32 x 32 tiles, one per block)
     const struct ShadowEnt* sh; int nsh, nb_tr; const float* sh_base;
 };
