@@ -373,18 +373,22 @@ __global__ __launch_bounds__(256) void qhead_critic_kernel(QHeadCritic p) {
         const size_t ro = (size_t)b * (p.ldE ? p.ldE : p.H);
         // the four dot products of the row in ONE pass: 8 loads per step in flight together (one after the other they were four exposed
         // L2 round trips per row, each followed by its wave reduction); per-lane summation order and reductions as row_dot
+        // the row's scalars go out with the first operand loads (issued behind the reductions they were a second exposed round trip per row)
+        const float bt0 = p.bt[0][0], bt1 = p.bt[1][0], bc0 = p.bc[0][0], bc1 = p.bc[1][0], lpb = p.logp[b], Rb = p.R[b], Db = p.D[b];
+        __builtin_amdgcn_sched_barrier(0);
         float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f, dd3 = 0.f;
+#pragma unroll 4
         for (int k = lane; k < p.H; k += 64) {
             const float e0 = p.Et[0][ro + k], e1 = p.Et[1][ro + k], e2 = p.Ec[0][ro + k], e3 = p.Ec[1][ro + k];
             const float w0 = p.wt[0][k], w1 = p.wt[1][k], w2 = p.wc[0][k], w3 = p.wc[1][k];
             dd0 = fmaf(e0, w0, dd0); dd1 = fmaf(e1, w1, dd1); dd2 = fmaf(e2, w2, dd2); dd3 = fmaf(e3, w3, dd3);
         }
-        const float tq1 = wave_sum(dd0) + p.bt[0][0];
-        const float tq2 = wave_sum(dd1) + p.bt[1][0];
-        const float q1 = wave_sum(dd2) + p.bc[0][0];
-        const float q2 = wave_sum(dd3) + p.bc[1][0];
-        const float tv = fminf(tq1, tq2) - alpha * p.logp[b];
-        const float y = p.R[b] + (1.f - p.D[b]) * p.gamma * tv;
+        const float tq1 = wave_sum(dd0) + bt0;
+        const float tq2 = wave_sum(dd1) + bt1;
+        const float q1 = wave_sum(dd2) + bc0;
+        const float q2 = wave_sum(dd3) + bc1;
+        const float tv = fminf(tq1, tq2) - alpha * lpb;
+        const float y = Rb + (1.f - Db) * p.gamma * tv;
         const float d1 = q1 - y, d2 = q2 - y;
         const float g1 = 2.f * d1 * p.inv_batch, g2 = 2.f * d2 * p.inv_batch;
         if (p.train) {
@@ -412,13 +416,16 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
     float accl = 0.f, accc = 0.f;
     for (int b = blockIdx.x * 4 + w; b < p.B; b += gridDim.x * 4) {
         const size_t ro = (size_t)b * (p.ldE ? p.ldE : p.H);
+        const float bc0 = p.bc[0][0], bc1 = p.bc[1][0], lp = p.logp[b];          // (out with the first operand loads: see qhead_critic_kernel)
+        __builtin_amdgcn_sched_barrier(0);
         float d0 = 0.f, d1 = 0.f;                  // both dot products in one pass (see qhead_critic_kernel)
+#pragma unroll 4
         for (int k = lane; k < p.H; k += 64) {
             const float e0 = p.Ec[0][ro + k], e1 = p.Ec[1][ro + k], w0 = p.wc[0][k], w1 = p.wc[1][k];
             d0 = fmaf(e0, w0, d0); d1 = fmaf(e1, w1, d1);
         }
-        const float q1 = wave_sum(d0) + p.bc[0][0];
-        const float q2 = wave_sum(d1) + p.bc[1][0];
+        const float q1 = wave_sum(d0) + bc0;
+        const float q2 = wave_sum(d1) + bc1;
         // d(-min(q1,q2))/dq_i : -1 to the arg-min head, ties split 1/2 (torch.min backward)
         float s1, s2;
         if (q1 < q2) { s1 = 1.f; s2 = 0.f; } else if (q2 < q1) { s1 = 0.f; s2 = 1.f; } else { s1 = s2 = 0.5f; }
@@ -427,7 +434,6 @@ __global__ __launch_bounds__(256) void qhead_actor_kernel(QHeadActor p) {
             p.GE[0][ro + k] = g1 * p.wc[0][k] * elu_grad_from_out(p.Ec[0][ro + k]);
             p.GE[1][ro + k] = g2 * p.wc[1][k] * elu_grad_from_out(p.Ec[1][ro + k]);
         }
-        const float lp = p.logp[b];
         accl += alpha * lp - fminf(q1, q2);
         accc += -lp - p.target_entropy;
     }
