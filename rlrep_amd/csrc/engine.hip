@@ -1787,9 +1787,11 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
             t.slab = wsp; t.bslab = wsp + (size_t)psp * R * ((Cn + 3) & ~3); t.fin_base = 0;
             fin = (int)(((long long)R * ((Cn + 3) / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
         }
-        t.tiles_c = (Cn + pbt - 1) / pbt; t.ntiles = ((R + pbt - 1) / pbt) * t.tiles_c * psp; t.tile_base = 0;
+        const bool wide = engine == 2 && bt == 256;          // the 256 x 128 persistent tile (gemm_x3w.h)
+        const int er = wide ? 256 : pbt, ec = wide ? 128 : pbt;
+        t.tiles_c = (Cn + ec - 1) / ec; t.ntiles = ((R + er - 1) / er) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;
-        rc = rl_launch_gemm_lds(engine == 2 ? (pbt == 64 ? 65 : 129) : pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
+        rc = rl_launch_gemm_lds(wide ? 257 : engine == 2 ? (pbt == 64 ? 65 : 129) : pbt, la, lb, &gb, t.ntiles, fin, (hipStream_t)stream);
     }
     if (rc != 0) { rl_set_error("gemm: launch failed (%d)", rc); return rc < 0 ? RLREP_ERR_ARG : RLREP_ERR_HIP; }
     return 0;

@@ -762,6 +762,8 @@ __global__ __launch_bounds__(512, 4) void gemm_x3t_kernel(GL_DIR_PARAMS, GemmBat
     }
 }
 
+#include "gemm_x3w.h"
+
 // ================================================================================================
 // gemm_x3s_kernel: the 64 x 64 tile on the bf16 pipe (bf16x3) -- for the layers whose outputs are too small for 128-wide tiles (ctrlsac at
 // M = 256, spedersac at M = 2048 x 512, diffsrsac at HalfCheetah dims) and that ran on the fp32 64-wide tile at 38-60 TF: one wave per SIMD
@@ -1036,6 +1038,25 @@ static int launch_x3(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb
     return (int)hipGetLastError();
 }
 
+// 256 x 128 tile, persistent: one workgroup per CU walks tiles blockIdx, blockIdx + grid, ...
+static int x3w_grid(int total_tiles) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return total_tiles < 256 ? total_tiles : 256;
+        cus = pr.multiProcessorCount;
+    }
+    return total_tiles < cus ? total_tiles : cus;
+}
+static int launch_x3w(int la, int lb, int total_tiles, hipStream_t st, const GemmBatch& gb, const int* dir) {
+    const dim3 g(x3w_grid(total_tiles));
+    if (la == LD_ROW && lb == LD_ROW) hipLaunchKernelGGL((gemm_x3w_kernel<LD_ROW, LD_ROW>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb, total_tiles);
+    else if (la == LD_ROW && lb == LD_COL) hipLaunchKernelGGL((gemm_x3w_kernel<LD_ROW, LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb, total_tiles);
+    else if (la == LD_COL && lb == LD_COL) hipLaunchKernelGGL((gemm_x3w_kernel<LD_COL, LD_COL>), g, dim3(512), 0, st, GL_DIR_ARGS(dir), gb, total_tiles);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
 static bool x3s_unaligned_ok(const GemmTask* t) { return t->R >= 4 && t->Cn >= 4 && t->K >= 4; }       // (the pulled-back tail load needs four elements to exist)
 static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb, const int* dir) {
     // one instantiation per launch: the any-alignment loaders as soon as ONE task of the stage has an operand that is not 16-byte regular
@@ -1055,7 +1076,8 @@ static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& g
     return (int)hipGetLastError();
 }
 
-// bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3); 65 = the 64-wide tile on the bf16 pipe
+// bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3); 65 = the 64-wide tile on the bf16 pipe; 257 = the 256 x 128 tile on the
+// bf16 pipe (persistent workgroups: gemm_x3w.h)
 extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     int dir[GEMM_MAX_TASKS], fdir[GEMM_MAX_TASKS];
@@ -1063,7 +1085,7 @@ extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, i
         dir[q] = q < gb->ntasks ? gb->t[q].tile_base : 0x7fffffff;
         fdir[q] = (q < gb->ntasks && gb->t[q].splits > 1) ? gb->t[q].fin_base : 0x7fffffff;
     }
-    int rc = bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb, dir) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb, dir)
+    int rc = bt == 257 ? launch_x3w(la, lb, total_tiles, st, *gb, dir) : bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb, dir) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb, dir)
            : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb, dir) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb, dir);
     if (rc != 0) return rc;
     if (fin_blocks > 0) {

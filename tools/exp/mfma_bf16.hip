@@ -1,0 +1,87 @@
+// Micro-benchmark: sustained v_mfma_f32_32x32x16_bf16 rate (and shader clock) with every SIMD of the chip issuing: the practical ceiling of the bf16x3
+// tiles (six such MFMAs per 32x32x16 fp32 product: ceiling = rate / 6).  Variants: waves per SIMD 1 / 2 / 4, accumulators per wave 1 / 4; with the
+// fragment reads of gemm_x3w.h's loop (12 ds_read_b128 per 24 MFMAs) re-read from LDS or not.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_bf16 tools/exp/mfma_bf16.hip && /tmp/mfma_bf16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NACC, bool LDS>
+__global__ __launch_bounds__(256) void loop(float* out, int iters, unsigned long long* clk) {
+    __shared__ __attribute__((aligned(16))) float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = 1e-3f * i;
+    __syncthreads();
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int f = 0; f < NACC; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[f][q] = 0.f;
+    bf16x8 a[3], b[3];
+    const f32x4* L = reinterpret_cast<const f32x4*>(lds) + (threadIdx.x & 63);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { a[m] = __builtin_bit_cast(bf16x8, L[64 * m]); b[m] = __builtin_bit_cast(bf16x8, L[64 * (m + 3)]); }
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (LDS) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                a[m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * m + 512 * (it & 1)));
+                b[m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * (m + 3) + 512 * (it & 1)));
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NACC; ++f) {
+            f32x16 v = acc[f];
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], v, 0, 0, 0);
+            acc[f] = v;
+        }
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < NACC; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += acc[f][q];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+
+template <int NACC, bool LDS>
+static int run(float* out, unsigned long long* clk, hipEvent_t e0, hipEvent_t e1, int cus) {
+    for (int wps : {1, 2, 4}) {                   // waves per SIMD: blocks of 256 threads (4 waves = one per SIMD), wps blocks per CU
+        const int G = cus * wps, iters = 2048;
+        float best = 1e9f; unsigned long long h[2] = {0, 0};
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((loop<NACC, LDS>), dim3(G), dim3(256), 0, 0, out, iters, clk);
+            CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) { best = ms; CK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost)); }
+        }
+        const double fl = 2.0 * 32 * 32 * 16 * 6.0 * NACC * iters * (double)G * 4;
+        printf("acc %d lds %d waves/SIMD %d: %8.3f ms  %7.1f TF bf16 = %6.1f TF as bf16x3   shader clock %.0f MHz (clock64 %llu / wall %llu x 100 MHz), cycles per MFMA per SIMD %.1f\n",
+               NACC, (int)LDS, wps, best, fl / best / 1e9, fl / best / 1e9 / 6.0, 100.0 * h[0] / (double)h[1], h[0], h[1], (double)h[0] / (6.0 * NACC * iters * wps));
+    }
+    return 0;
+}
+
+int main() {
+    int dev = 0; hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
+    const int cus = pr.multiProcessorCount;
+    printf("%s, %d CUs, clockRate %d kHz\n", pr.name, cus, pr.clockRate);
+    float* out; unsigned long long* clk;
+    CK(hipMalloc(&out, sizeof(float) * 256 * cus * 4)); CK(hipMalloc(&clk, 16));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (run<1, false>(out, clk, e0, e1, cus)) return 1;
+    if (run<4, false>(out, clk, e0, e1, cus)) return 1;
+    if (run<4, true>(out, clk, e0, e1, cus)) return 1;
+    return 0;
+}
