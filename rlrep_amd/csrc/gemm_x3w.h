@@ -6,78 +6,60 @@
 // 12 MFMAs cost 9 fragment reads and the split of 8 staged elements per thread; one LDS buffer, two barriers per 32-deep block, so the eight
 // waves of a workgroup are all in their VALU phase or all in their matrix phase and only the co-resident workgroup fills the other pipe; the
 // global loads of block i + 1 are issued one matrix phase before they are needed (an HBM miss is longer); the prologue and the 64 KB epilogue
-// of a tile overlap with nothing of the same workgroup.  143-180 TF of 417.
+// of a tile overlap with nothing of the same workgroup.  130-190 TF of the 305-340 the matrix pipe sustains (tools/exp/mfma_bf16.hip).
 //
 // This kernel: eight waves as 4 (rows) x 2 (columns), a wave owns 64 x 64 = four 32x32 accumulators (6 fragment reads and 6 staged elements
-// per 12 MFMAs); TWO LDS stages of 72 KB (three bf16 images of 256 rows of A and of 128 rows of B, 32 deep) and ONE barrier per block: block
-// i + 1 is split and written while block i is multiplied, and the two waves of a SIMD (w and w + 4) run the two halves of an iteration in
-// OPPOSITE order -- one multiplies while the other splits; the workgroup walks its tiles (index = blockIdx + k * gridDim) as ONE stream of
-// (tile, block) items, so the loads of the next tile's first blocks are in flight during the last blocks of this one and the accumulator
-// stores of a tile drain under the next tile's MFMAs.  The MFMA takes the B fragment as its first operand: a lane then holds FOUR CONSECUTIVE
-// COLUMNS of one output row per register quad, and the tile is stored from the accumulators with 16-byte stores -- no LDS patch (there is no
-// LDS left for one: 2 x 72 KB + the 16 KB of the bias-gradient sums = 160 KB).
+// per 12 MFMAs); TWO LDS stages of 72 KB (three bf16 images of 256 rows of A and of 128 rows of B, 32 deep) and ONE barrier per block.  An
+// iteration is ONE basic block: the 16-byte global loads of block i + 2 (two register sets), the 24 fragment reads of block i, its 48 MFMAs,
+// and between them (sched_group_barrier) the split of block i + 1 and its LDS writes into the other stage.  The workgroup walks its tiles
+// (index = blockIdx + k * gridDim) as ONE stream of (tile, block) items, so the loads of the next tile's first blocks are in flight during
+// the last blocks of this one and the accumulator stores of a tile drain under the next tile's MFMAs; the tile is stored from the
+// accumulators, a wave-instruction = two whole 128-byte lines (lane = column) -- there is no LDS left for a patch: 2 x 72 KB + the 16 KB of
+// the bias-gradient sums = 160 KB.  Epilogues: forward / dX with no activation, ReLU or ELU, dW (+ bias gradient), split-K slabs.
 // Image layouts are those of the 128 x 128 kernels: row-major operands [row][64 B] with swizzled 16-byte chunks (x3r_off, ds_read_b128),
 // k-major operands [32 k][128 rows] per 128-row half (x3t_off, ds_read_b64_tr_b16).
 // ================================================================================================
 #ifndef X3W_ABL
-#define X3W_ABL 0          /* timing-only ablations: 1 no global loads, 2 no split / LDS writes, 4 no MFMAs, 8 no fragment reads */
+#define X3W_ABL 0          /* timing-only ablations: 1 no global loads, 2 no split / LDS writes, 4 no MFMAs */
+#endif
+#ifndef X3W_SCHED
+#define X3W_SCHED 1        /* 0: leave the iteration's instruction order to the compiler */
 #endif
 #define X3W_BM 256
 #define X3W_BN 128
 #define X3W_AIMG (X3W_BM * 64)                       /* bytes per A image */
 #define X3W_BIMG (X3W_BN * 64)                       /* bytes per B image */
 #define X3W_STAGE (3 * X3W_AIMG + 3 * X3W_BIMG)      /* 73 728 */
-#define X3W_LDSB (2 * X3W_STAGE + 16384)             /* + [256 rows][16 k slots] floats of the bias-gradient sums */
 
-// 512 threads load a [64 NJ rows] x 32 slice: NJ 16-byte loads per thread
-template <int LD, int NJ>
-__device__ __forceinline__ void x3w_load(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, f32x4 (&e)[NJ]) {
-    if (LD == LD_ROW) {
-        const int kc = (int)(threadIdx.x & 7) * 4;
-        const int k = min(k0 + kc, kend - 4);
-        const bool ok = (k0 + kc) < kend;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int r = min(base + (int)(threadIdx.x >> 3) + 64 * j, lim - 1);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
-            e[j] = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    } else {
-        const int c4 = (int)(threadIdx.x & 31) * 4;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = base + 128 * (j >> 1) + c4, kk = (int)(threadIdx.x >> 5) + 16 * (j & 1);
-            const int i = min(col, lim - 4), k = min(k0 + kk, kend - 1);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + i);
-            e[j] = (col < lim && (k0 + kk) < kend) ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-}
-// split and write them: img = LDS byte address of the operand's first image, IMG = bytes per image
-template <int LD, int NJ, int IMG>
-__device__ __forceinline__ void x3w_write(unsigned img, const f32x4 (&e)[NJ]) {
+// split four consecutive elements and write them: 8 bytes into each of the three images (p = LDS byte address in image 0)
+// (LDS accesses go through pointers INTO the stage's own __shared__ array, not through integer addresses: the compiler then knows that the
+// fragment reads of one stage and the staging writes of the other cannot alias and is free to interleave them)
+typedef __attribute__((address_space(3))) unsigned char* x3w_lds;
+template <int IMG, int OFF>
+__device__ __forceinline__ void x3w_split_write(x3w_lds p, const f32x4& e) {
     typedef __attribute__((address_space(3))) u32x2* lp;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        unsigned p;
-        if (LD == LD_ROW) {
-            const int row = (int)(threadIdx.x >> 3) + 64 * j, kc = (int)(threadIdx.x & 7) * 4;
-            p = img + (unsigned)x3r_off(row, kc >> 3) + 8u * ((kc >> 2) & 1);
-        } else {
-            const int c4 = (int)(threadIdx.x & 31) * 4, kk = (int)(threadIdx.x >> 5) + 16 * (j & 1);
-            p = img + 8192u * (j >> 1) + x3t_off(kk, c4 >> 3) + 8u * ((c4 >> 2) & 1);
-        }
-        u32x2 hi, mid, lo;
-        unsigned h, m, l;
-        x3_split2(e[j][0], e[j][1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
-        x3_split2(e[j][2], e[j][3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
-        *(lp)(uintptr_t)p = hi;
-        *(lp)(uintptr_t)(p + IMG) = mid;
-        *(lp)(uintptr_t)(p + 2 * IMG) = lo;
-    }
+    u32x2 hi, mid, lo;
+    unsigned h, m, l;
+    x3_split2(e[0], e[1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+    x3_split2(e[2], e[3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+    *(lp)(p + OFF) = hi;
+    *(lp)(p + OFF + IMG) = mid;
+    *(lp)(p + OFF + 2 * IMG) = lo;
 }
-template <int OFF> __device__ __forceinline__ bf16x8 x3w_rd128(unsigned a) {
-    return *(__attribute__((address_space(3))) bf16x8*)(uintptr_t)(a + OFF);
+template <int OFF> __device__ __forceinline__ bf16x8 x3w_rd128(x3w_lds a) {
+    return *(__attribute__((address_space(3))) bf16x8*)(a + OFF);
+}
+// k-major fragment: two transposed reads (k-blocks h = 0, 1 at a0 / a1; x3t_frag with pointers)
+template <int OFF> __device__ __forceinline__ bf16x8 x3w_tr(x3w_lds a0, x3w_lds a1) {
+    typedef __attribute__((address_space(3))) x3t_s16x4* tp;
+    const x3t_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tp)(a0 + OFF)), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tp)(a1 + OFF));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// which tasks the tile's epilogue covers (the host routes the others to the 128 x 128 tile)
+static inline bool x3w_epilogue_ok(const GemmTask* t) {
+    return (t->epi == EPI_FWD || t->epi == EPI_DX || t->epi == EPI_DW) && (t->act == ACT_NONE || t->act == ACT_RELU || t->act == ACT_ELU);
 }
 
 struct X3wTile { int ti, r0, c0, kbeg, kend, nk, split, tc; };
@@ -85,10 +67,11 @@ struct X3wTile { int ti, r0, c0, kbeg, kend, nk, split, tc; };
 template <int LA, int LB>
 __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBatch gb, int total_tiles) {
     const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
-    __shared__ __attribute__((aligned(16))) float lds[X3W_LDSB / 4];
-    const unsigned Lb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(lds);
+    __shared__ __attribute__((aligned(16))) unsigned char stage0[X3W_STAGE], stage1[X3W_STAGE];
+    __shared__ __attribute__((aligned(16))) float bias_part[4096];          // [256 rows][16 k slots]
+    const x3w_lds S0 = (x3w_lds)stage0, S1 = (x3w_lds)stage1;
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int r32 = lane & 31, hh = lane >> 5, g1 = (lane >> 4) & 1;
 
@@ -120,9 +103,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][y][q] = 0.f;
-    f32x4 rs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, rs_done[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // (k-major A: bias-gradient partial sums)
+    f32x4 rs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // (k-major A: bias-gradient partial sums of the tile whose blocks are being split)
+    f32x4 rs_tile[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // (... of the tile being multiplied: complete when its last block is)
 
-    // fragment addresses inside a stage (the stage offset is added per iteration)
+    // fragment addresses inside stage 0
     // row-major: chunk 2 c + hh of this lane's row; the swizzle term (row >> 2) & 3 is the same for rows r32, 32 + r32, ...
     const unsigned faR = (unsigned)x3r_off(wr * 64 + r32, hh), fbR = 3 * X3W_AIMG + (unsigned)x3r_off(wc * 64 + r32, hh);
     const int fsw = x3r_off(r32, 2 + hh) - x3r_off(r32, hh);
@@ -136,131 +120,148 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
             aA[i][h] = x3t_addr(8192u * (wr >> 1), 8 * hh + 4 * h, 8 * (wr & 1) + 4 * i + 2 * g1);
             aB[i][h] = x3t_addr(3 * X3W_AIMG, 8 * hh + 4 * h, 8 * wc + 4 * i + 2 * g1);
         }
+    // staging-write addresses (image 0 of stage 0; slot j by constant offset: 4096 j in either layout)
+    const unsigned wA = (LA == LD_ROW ? (unsigned)x3r_off(tid >> 3, (tid & 7) >> 1) + 8u * (tid & 1)
+                                           : x3t_off(tid >> 5, (tid & 31) >> 1) + 8u * (tid & 1));
+    const unsigned wB = 3 * X3W_AIMG + (LB == LD_ROW ? (unsigned)x3r_off(tid >> 3, (tid & 7) >> 1) + 8u * (tid & 1)
+                                                          : x3t_off(tid >> 5, (tid & 31) >> 1) + 8u * (tid & 1));
 
-    f32x4 ea[4], eb[2];
-    bool e_valid = false, e_first = false;
-
-    int tile = blockIdx.x;
-    if (tile >= total_tiles) return;
-    X3wTile cur = tile_of(tile);
-    int ckt = 0;
-    // the loader's position in the stream
-    int ltile = tile, lkt = 0;
-    X3wTile lt = cur;
-    auto issue_loads = [&]() __attribute__((always_inline)) {
-        e_valid = ltile < total_tiles;
-        if (!e_valid) return;
+    // ---- the loader: position (lt, lkt) in the stream of (tile, block) items, two items ahead of the multiplier -------------------------
+    // per-thread base pointers of the loader's tile: row-major operand: the thread's rows 64 j + tid / 8 (k offset added per block); k-major: its columns
+    // 128 s + 4 (tid % 32) (k row added per block)
+    const float* pa[4]; const float* pb[2];
+    int l_lda = 0, l_ldb = 0, l_kend = 0;
+    int ltile = blockIdx.x, lkt = 0;
+    if (ltile >= total_tiles) return;
+    X3wTile lt = tile_of(ltile);
+    auto loader_setup = [&]() __attribute__((always_inline)) {
         const GemmTask& t = gb.t[lt.ti];
-        const int k0 = lt.kbeg + GL_BK * lkt;
-        if (!(X3W_ABL & 1) || (ltile == (int)blockIdx.x && lkt == 0)) {
-            x3w_load<LA, 4>(t.A, t.lda, lt.r0, t.R, k0, lt.kend, ea);
-            x3w_load<LB, 2>(t.B, t.ldb, lt.c0, t.Cn, k0, lt.kend, eb);
-        }
-        e_first = lkt == 0;
-        if (++lkt == lt.nk) { lkt = 0; ltile += gridDim.x; if (ltile < total_tiles) lt = tile_of(ltile); }
-    };
-    auto split_write = [&](unsigned stage) __attribute__((always_inline)) {
-        if (!e_valid) return;
-        if constexpr (LA == LD_COL) {
-            if (e_first) { rs_done[0] = rs[0]; rs_done[1] = rs[1]; rs[0] = rs[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            rs[0] += ea[0] + ea[1]; rs[1] += ea[2] + ea[3];
-        }
-        if (!(X3W_ABL & 2)) {
-            x3w_write<LA, 4, X3W_AIMG>(Lb + stage, ea);
-            x3w_write<LB, 2, X3W_BIMG>(Lb + stage + 3 * X3W_AIMG, eb);
+        l_lda = t.lda; l_ldb = t.ldb; l_kend = lt.kend;
+        if (LA == LD_ROW) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pa[j] = t.A + (size_t)min(lt.r0 + (tid >> 3) + 64 * j, t.R - 1) * t.lda;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(ea[j]));
+            for (int s = 0; s < 2; ++s) pa[s] = t.A + min(lt.r0 + 128 * s + (tid & 31) * 4, t.R - 4);
+            pa[2] = pa[3] = nullptr;
+        }
+        if (LB == LD_ROW) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(eb[j]));
+            for (int j = 0; j < 2; ++j) pb[j] = t.B + (size_t)min(lt.c0 + (tid >> 3) + 64 * j, t.Cn - 1) * t.ldb;
+        } else { pb[0] = t.B + min(lt.c0 + (tid & 31) * 4, t.Cn - 4); pb[1] = nullptr; }
+    };
+    loader_setup();
+    // issue the 16-byte loads of the loader's item (no bounds selects here: the K tail is zeroed when the block is split, and rows / columns beyond the
+    // edge are clamped duplicates whose outputs are never stored)
+    bool l_tail = false, l_dup = false;        // (the item just issued ends inside its 32-deep block; the loader has run out of items and repeats the last)
+    int l_k0 = 0;
+    auto issue_loads = [&](f32x4 (&ea)[4], f32x4 (&eb)[2]) __attribute__((always_inline)) {
+        const int k0 = lt.kbeg + GL_BK * lkt;
+        l_k0 = k0; l_tail = k0 + GL_BK > l_kend;
+        if (!(X3W_ABL & 1)) {
+            if (LA == LD_ROW) {
+                const int ko = min(k0 + (tid & 7) * 4, l_kend - 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ea[j] = ld4(pa[j] + ko);
+            } else {
+                const size_t o0 = (size_t)min(k0 + (tid >> 5), l_kend - 1) * l_lda, o1 = (size_t)min(k0 + (tid >> 5) + 16, l_kend - 1) * l_lda;
+                ea[0] = ld4(pa[0] + o0); ea[1] = ld4(pa[0] + o1); ea[2] = ld4(pa[1] + o0); ea[3] = ld4(pa[1] + o1);
+            }
+            if (LB == LD_ROW) {
+                const int ko = min(k0 + (tid & 7) * 4, l_kend - 4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) eb[j] = ld4(pb[j] + ko);
+            } else {
+                const size_t o0 = (size_t)min(k0 + (tid >> 5), l_kend - 1) * l_ldb, o1 = (size_t)min(k0 + (tid >> 5) + 16, l_kend - 1) * l_ldb;
+                eb[0] = ld4(pb[0] + o0); eb[1] = ld4(pb[0] + o1);
+            }
         }
     };
+    // step the loader; at the end of the stream it stays on the last item (the duplicates it loads are split into a stage nobody reads)
+    auto loader_step = [&]() __attribute__((always_inline)) {
+        if (++lkt == lt.nk) {
+            if (ltile + (int)gridDim.x < total_tiles) { ltile += gridDim.x; lt = tile_of(ltile); lkt = 0; loader_setup(); }
+            else { lkt = lt.nk - 1; l_dup = true; }
+        }
+    };
+    // zero the K tail of a loaded block (rare: only a block that ends inside its 32 k)
+    auto zero_tail = [&](f32x4 (&ea)[4], f32x4 (&eb)[2], int k0, int kend) __attribute__((always_inline)) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (LA == LD_ROW) { if (k0 + (tid & 7) * 4 >= kend) { ea[0] = z; ea[1] = z; ea[2] = z; ea[3] = z; } }
+        else { if (k0 + (tid >> 5) >= kend) { ea[0] = z; ea[2] = z; } if (k0 + (tid >> 5) + 16 >= kend) { ea[1] = z; ea[3] = z; } }
+        if (LB == LD_ROW) { if (k0 + (tid & 7) * 4 >= kend) { eb[0] = z; eb[1] = z; } }
+        else { if (k0 + (tid >> 5) >= kend) eb[0] = z; if (k0 + (tid >> 5) + 16 >= kend) eb[1] = z; }
+    };
 
-#define X3W_MMA(C)                                                                                                            \
-    {                                                                                                                         \
-        bf16x8 a[2][3], b[2][3];                                                                                              \
-        if constexpr (LA == LD_ROW) {                                                                                         \
-            const unsigned p = Lb + stage + faR + (unsigned)(fsw * (C));                                                      \
-            a[0][0] = x3w_rd128<0>(p); a[0][1] = x3w_rd128<X3W_AIMG>(p); a[0][2] = x3w_rd128<2 * X3W_AIMG>(p);                 \
-            a[1][0] = x3w_rd128<32 * 64>(p); a[1][1] = x3w_rd128<32 * 64 + X3W_AIMG>(p); a[1][2] = x3w_rd128<32 * 64 + 2 * X3W_AIMG>(p); \
-        } else {                                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
-                const unsigned p0 = Lb + stage + aA[i][0], p1 = Lb + stage + aA[i][1];                                        \
-                a[i][0] = x3t_frag<(C) * 4096>(p0, p1); a[i][1] = x3t_frag<(C) * 4096 + X3W_AIMG>(p0, p1);                     \
-                a[i][2] = x3t_frag<(C) * 4096 + 2 * X3W_AIMG>(p0, p1);                                                        \
-            }                                                                                                                 \
-        }                                                                                                                     \
-        if constexpr (LB == LD_ROW) {                                                                                         \
-            const unsigned p = Lb + stage + fbR + (unsigned)(fsw * (C));                                                      \
-            b[0][0] = x3w_rd128<0>(p); b[0][1] = x3w_rd128<X3W_BIMG>(p); b[0][2] = x3w_rd128<2 * X3W_BIMG>(p);                 \
-            b[1][0] = x3w_rd128<32 * 64>(p); b[1][1] = x3w_rd128<32 * 64 + X3W_BIMG>(p); b[1][2] = x3w_rd128<32 * 64 + 2 * X3W_BIMG>(p); \
-        } else {                                                                                                              \
-            _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                   \
-                const unsigned p0 = Lb + stage + aB[y][0], p1 = Lb + stage + aB[y][1];                                        \
-                b[y][0] = x3t_frag<(C) * 4096>(p0, p1); b[y][1] = x3t_frag<(C) * 4096 + X3W_BIMG>(p0, p1);                     \
-                b[y][2] = x3t_frag<(C) * 4096 + 2 * X3W_BIMG>(p0, p1);                                                        \
-            }                                                                                                                 \
-        }                                                                                                                     \
-        if (X3W_ABL & 4) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int m = 0; m < 3; ++m) { asm volatile("" :: "v"(a[i][m])); asm volatile("" :: "v"(b[i][m])); } \
-        } else                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                         \
-        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                       \
-            f32x16 v = acc[i][y];                                                                                             \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][2], a[i][0], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[i][2], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][1], a[i][1], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][1], a[i][0], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[i][1], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[y][0], a[i][0], v, 0, 0, 0);                                        \
-            acc[i][y] = v;                                                                                                    \
-        }                                                                                                                     \
-    }
+    // ---- the multiplier's position ---------------------------------------------------------------------------------------------------------
+    int tile = blockIdx.x, ckt = 0;
+    X3wTile cur = lt;
 
-    // the tile's accumulators -> memory (lane: output row r32 of its row block; register quad g: columns 8 g + 4 hh .. + 3 of its column block)
-    auto store_tile = [&](const f32x4 (&rsum)[2]) __attribute__((always_inline)) {
+    // the tile's accumulators -> memory (32x32 C/D map: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): a wave-instruction stores
+    // 32 consecutive columns of two rows
+    auto store_tile = [&]() __attribute__((always_inline)) {
         const GemmTask& t = gb.t[cur.ti];
         const int R = t.R, Cn = t.Cn, splits = t.splits;
         if constexpr (LA == LD_COL) {
             if (t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && cur.tc == 0) {
                 // bias gradient = row sums of operand A: this thread holds rows 128 s + 4 (tid % 32) .. + 3 of its k slot -> LDS -> fixed-order sum over the 16 slots
-                float* part = lds + 2 * X3W_STAGE / 4;                  // [256 rows][16 k slots]
-                const int c4 = (int)(threadIdx.x & 31) * 4, ks = (int)(threadIdx.x >> 5);
+                float* part = bias_part;
+                const int c4 = (tid & 31) * 4, ks = tid >> 5;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) part[(128 * s + c4 + q) * 16 + ks] = rsum[s][q];
+                    for (int q = 0; q < 4; ++q) part[(128 * s + c4 + q) * 16 + ks] = rs_tile[s][q];
                 __syncthreads();
-                if (threadIdx.x < 256) {
-                    const float* q = part + threadIdx.x * 16;
+                if (tid < 256) {
+                    const float* q = part + tid * 16;
                     float s0 = 0.f;
 #pragma unroll
                     for (int z = 0; z < 16; ++z) s0 += q[z];
-                    const int r = cur.r0 + (int)threadIdx.x;
+                    const int r = cur.r0 + tid;
                     if (r < R) { if (splits > 1) t.bslab[(size_t)cur.split * R + r] = s0; else t.out2[r] = s0; }
                 }
                 __syncthreads();
             }
         }
-        f32x4 bias[2][4];
+        const int epi = t.epi, act = t.act;
+        const bool accum = (t.flags & FLAG_ACCUM) != 0;
+        const float scale = t.scale;
+        const int ldo = splits > 1 ? ((Cn + 3) & ~3) : t.ldc;
+        float* const obase = splits > 1 ? t.slab + (size_t)cur.split * R * ldo : t.C;
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < 2; ++y) {
+            const int c = cur.c0 + wc * 64 + 32 * y + r32;
+            if (c < Cn) {
+                const float bias = (splits == 1 && epi == EPI_FWD && t.bias) ? t.bias[c] : 0.f;
+                const float r1v = (splits == 1 && epi == EPI_DX && t.r1u) ? t.r1v[c] : 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias[y][g] = splits > 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : gl_bias4(t, cur.c0 + wc * 64 + 32 * y + 8 * g + 4 * hh);
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = cur.r0 + wr * 64 + 32 * i + r32;
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = cur.c0 + wc * 64 + 32 * y + 8 * g + 4 * hh;
-                    const f32x4 v = {acc[i][y][4 * g], acc[i][y][4 * g + 1], acc[i][y][4 * g + 2], acc[i][y][4 * g + 3]};
-                    if (r < R && c < Cn) {
-                        if (splits > 1) st4(t.slab + ((size_t)cur.split * R + r) * ((Cn + 3) & ~3) + c, v);
-                        else gl_epilogue4(t, r, c, v, &bias[y][g]);
+                    for (int q = 0; q < 16; ++q) {
+                        const int r = cur.r0 + wr * 64 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                        if (r < R) {
+                            float v = acc[i][y][q];
+                            float* cp = obase + (size_t)r * ldo + c;
+                            if (splits == 1) {
+                                v *= scale;
+                                if (epi == EPI_FWD) {
+                                    v += bias;
+                                    v = act == ACT_RELU ? fmaxf(v, 0.f) : act == ACT_ELU ? elu_f(v) : v;
+                                } else {
+                                    if (epi == EPI_DX) {
+                                        if (t.r1u) v += t.r1u[r] * r1v;
+                                        if (act != ACT_NONE) {
+                                            const float a = t.aux[(size_t)r * t.ldaux + c];
+                                            v = act == ACT_RELU ? (a > 0.f ? v : 0.f) : v * elu_grad_from_out(a);
+                                        }
+                                    }
+                                    if (accum) v += *cp;
+                                }
+                            }
+                            *cp = v;
+                        }
                     }
-                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -270,32 +271,125 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
                 for (int q = 0; q < 16; ++q) acc[i][y][q] = 0.f;
     };
 
-    // prologue: item 0 into stage 0, item 1 into the staging registers
-    issue_loads();
-    split_write(0);
-    issue_loads();
-    unsigned stage = 0;
-    for (;;) {
-        __syncthreads();
-        const bool last = ckt + 1 == cur.nk;
-        if (w & 4) {
-            const bool handed = e_valid && e_first;          // (the next tile's first block is split now: this tile's sums move to rs_done)
-            split_write(X3W_STAGE - stage);
-            issue_loads();
-            X3W_MMA(0) X3W_MMA(1)
-            if (last) { if (handed) store_tile(rs_done); else store_tile(rs); }
-        } else {
-            X3W_MMA(0) X3W_MMA(1)
-            if (last) store_tile(rs);
-            split_write(X3W_STAGE - stage);
-            issue_loads();
-        }
-        if (last) {
-            tile += gridDim.x;
-            if (tile >= total_tiles) break;
-            cur = tile_of(tile); ckt = 0;
-        } else ++ckt;
-        stage = X3W_STAGE - stage;
+    // fragments of 16-deep block C of the stage at byte offset ST
+#define X3W_FRAGS(C, ST, a, b)                                                                                                \
+    {                                                                                                                         \
+        if constexpr (LA == LD_ROW) {                                                                                         \
+            const x3w_lds p = (ST) + (faR + (unsigned)(fsw * (C)));                                                            \
+            a[0][0] = x3w_rd128<0>(p); a[0][1] = x3w_rd128<X3W_AIMG>(p); a[0][2] = x3w_rd128<2 * X3W_AIMG>(p);                   \
+            a[1][0] = x3w_rd128<2048>(p); a[1][1] = x3w_rd128<2048 + X3W_AIMG>(p); a[1][2] = x3w_rd128<2048 + 2 * X3W_AIMG>(p);  \
+        } else {                                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
+                const x3w_lds p0 = (ST) + aA[i][0], p1 = (ST) + aA[i][1];                                                     \
+                a[i][0] = x3w_tr<(C) * 4096>(p0, p1); a[i][1] = x3w_tr<(C) * 4096 + X3W_AIMG>(p0, p1);                         \
+                a[i][2] = x3w_tr<(C) * 4096 + 2 * X3W_AIMG>(p0, p1);                                                          \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        if constexpr (LB == LD_ROW) {                                                                                         \
+            const x3w_lds p = (ST) + (fbR + (unsigned)(fsw * (C)));                                                            \
+            b[0][0] = x3w_rd128<0>(p); b[0][1] = x3w_rd128<X3W_BIMG>(p); b[0][2] = x3w_rd128<2 * X3W_BIMG>(p);                   \
+            b[1][0] = x3w_rd128<2048>(p); b[1][1] = x3w_rd128<2048 + X3W_BIMG>(p); b[1][2] = x3w_rd128<2048 + 2 * X3W_BIMG>(p);  \
+        } else {                                                                                                              \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                   \
+                const x3w_lds p0 = (ST) + aB[y][0], p1 = (ST) + aB[y][1];                                                     \
+                b[y][0] = x3w_tr<(C) * 4096>(p0, p1); b[y][1] = x3w_tr<(C) * 4096 + X3W_BIMG>(p0, p1);                         \
+                b[y][2] = x3w_tr<(C) * 4096 + 2 * X3W_BIMG>(p0, p1);                                                          \
+            }                                                                                                                 \
+        }                                                                                                                     \
     }
+#define X3W_MMA(a, b)                                                                                                         \
+    if (!(X3W_ABL & 4)) {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                         \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                       \
+            f32x16 v = acc[i][y];                                                                                             \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[y][2], v, 0, 0, 0);                                        \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[y][0], v, 0, 0, 0);                                        \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[y][1], v, 0, 0, 0);                                        \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[y][1], v, 0, 0, 0);                                        \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[y][0], v, 0, 0, 0);                                        \
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[y][0], v, 0, 0, 0);                                        \
+            acc[i][y] = v;                                                                                                    \
+        }                                                                                                                     \
+    } else {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int m = 0; m < 3; ++m) { asm volatile("" :: "v"(a[i][m])); asm volatile("" :: "v"(b[i][m])); } \
+    }
+    // split the block in (EA, EB) into the stage at byte offset ST
+#define X3W_SPLIT(EA, EB, ST)                                                                                                 \
+    if (!(X3W_ABL & 2)) {                                                                                                     \
+        x3w_split_write<X3W_AIMG, 0>((ST) + wA, EA[0]); x3w_split_write<X3W_AIMG, 4096>((ST) + wA, EA[1]);                      \
+        x3w_split_write<X3W_AIMG, 8192>((ST) + wA, EA[2]); x3w_split_write<X3W_AIMG, 12288>((ST) + wA, EA[3]);                 \
+        x3w_split_write<X3W_BIMG, 0>((ST) + wB, EB[0]); x3w_split_write<X3W_BIMG, 4096>((ST) + wB, EB[1]);                      \
+    } else {                                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(EA[j]));                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(EB[j]));                                          \
+    }
+    // the order of one iteration's instructions: the loads first (longest latency), all fragment reads, then per MFMA three or four vector
+    // instructions of the split and, for the first 18, one LDS write
+#if X3W_SCHED
+#define X3W_PIPELINE()                                                                                                        \
+    {                                                                                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);                                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);                                                                   \
+        _Pragma("unroll") for (int z = 0; z < 48; ++z) {                                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                \
+        }                                                                                                                     \
+    }
+#else
+#define X3W_PIPELINE()
+#endif
+
+    // One iteration: multiply the block in the stage at RD, split the block in (EA, EB) into the stage at WR, load the loader's block into (NA, NB).
+    // first / tail / k0 / kend of the block in (EA, EB) were noted when it was loaded (F_*), those of the block being loaded go to (N_*).
+#define X3W_ITER(EA, EB, NA, NB, RD, WR, F, N)                                                                                \
+    {                                                                                                                         \
+        __syncthreads();                                                                                                      \
+        if (F##_tail) zero_tail(EA, EB, F##_k0, F##_kend);                                                                    \
+        if constexpr (LA == LD_COL) {                                                                                         \
+            if (F##_first) { rs_tile[0] = rs[0]; rs_tile[1] = rs[1]; rs[0] = rs[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }           \
+        }                                                                                                                     \
+        {                                                                                                                     \
+            bf16x8 a0[2][3], b0[2][3], a1[2][3], b1[2][3];                                                                    \
+            issue_loads(NA, NB);                                                                                              \
+            X3W_FRAGS(0, RD, a0, b0)                                                                                          \
+            X3W_FRAGS(1, RD, a1, b1)                                                                                          \
+            X3W_MMA(a0, b0)                                                                                                   \
+            X3W_MMA(a1, b1)                                                                                                   \
+            if constexpr (LA == LD_COL) { rs[0] += EA[0] + EA[1]; rs[1] += EA[2] + EA[3]; }                                   \
+            X3W_SPLIT(EA, EB, WR)                                                                                             \
+            X3W_PIPELINE()                                                                                                    \
+        }                                                                                                                     \
+        N##_tail = l_tail; N##_k0 = l_k0; N##_kend = l_kend; N##_first = l_dup || lkt == 0;                                   \
+        loader_step();                                                                                                        \
+        if (ckt + 1 == cur.nk) {                                                                                              \
+            store_tile();                                                                                                     \
+            tile += gridDim.x;                                                                                                \
+            if (tile >= total_tiles) break;                                                                                   \
+            cur = tile_of(tile); ckt = 0;                                                                                     \
+        } else ++ckt;                                                                                                         \
+    }
+
+    // prologue: item 0 -> stage 0, item 1 -> (ea0, eb0)
+    f32x4 ea0[4], eb0[2], ea1[4], eb1[2];
+    bool p_tail = false, q_tail = false, p_first = false, q_first = false;
+    int p_k0 = 0, q_k0 = 0, p_kend = 0, q_kend = 0;
+    issue_loads(ea0, eb0);
+    if (l_tail) zero_tail(ea0, eb0, l_k0, l_kend);
+    if constexpr (LA == LD_COL) { rs[0] += ea0[0] + ea0[1]; rs[1] += ea0[2] + ea0[3]; }
+    X3W_SPLIT(ea0, eb0, S0)
+    loader_step();
+    issue_loads(ea0, eb0);
+    p_tail = l_tail; p_k0 = l_k0; p_kend = l_kend; p_first = l_dup || lkt == 0;
+    loader_step();
+    for (;;) {
+        X3W_ITER(ea0, eb0, ea1, eb1, S0, S1, p, q)
+        X3W_ITER(ea1, eb1, ea0, eb0, S1, S0, q, p)
+    }
+#undef X3W_ITER
+#undef X3W_PIPELINE
+#undef X3W_SPLIT
 #undef X3W_MMA
+#undef X3W_FRAGS
 }
