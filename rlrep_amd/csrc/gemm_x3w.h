@@ -223,45 +223,61 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
                 __syncthreads();
             }
         }
+        // The case analysis is done ONCE per tile, outside the element loops: inside them every store was followed by uniform branches and, where a value
+        // loaded before the loop (the bias) was first used, an `s_waitcnt vmcnt(0)` -- which also waits for every store issued so far: 20 us per tile
         const int epi = t.epi, act = t.act;
         const bool accum = (t.flags & FLAG_ACCUM) != 0;
         const float scale = t.scale;
         const int ldo = splits > 1 ? ((Cn + 3) & ~3) : t.ldc;
         float* const obase = splits > 1 ? t.slab + (size_t)cur.split * R * ldo : t.C;
+        auto each = [&](auto fn) __attribute__((always_inline)) {
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int c = cur.c0 + wc * 64 + 32 * y + r32;
-            if (c < Cn) {
-                const float bias = (splits == 1 && epi == EPI_FWD && t.bias) ? t.bias[c] : 0.f;
-                const float r1v = (splits == 1 && epi == EPI_DX && t.r1u) ? t.r1v[c] : 0.f;
+            for (int y = 0; y < 2; ++y) {
+                const int c = cur.c0 + wc * 64 + 32 * y + r32;
+                if (c < Cn) {
+                    float* const col = obase + c;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int r = cur.r0 + wr * 64 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
-                        if (r < R) {
-                            float v = acc[i][y][q];
-                            float* cp = obase + (size_t)r * ldo + c;
-                            if (splits == 1) {
-                                v *= scale;
-                                if (epi == EPI_FWD) {
-                                    v += bias;
-                                    v = act == ACT_RELU ? fmaxf(v, 0.f) : act == ACT_ELU ? elu_f(v) : v;
-                                } else {
-                                    if (epi == EPI_DX) {
-                                        if (t.r1u) v += t.r1u[r] * r1v;
-                                        if (act != ACT_NONE) {
-                                            const float a = t.aux[(size_t)r * t.ldaux + c];
-                                            v = act == ACT_RELU ? (a > 0.f ? v : 0.f) : v * elu_grad_from_out(a);
-                                        }
-                                    }
-                                    if (accum) v += *cp;
-                                }
-                            }
-                            *cp = v;
+                        for (int q = 0; q < 16; ++q) {
+                            const int r = cur.r0 + wr * 64 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                            if (r < R) fn(y, r, c, col + (size_t)r * ldo, acc[i][y][q]);
                         }
-                    }
+                }
             }
+        };
+        if (splits > 1) each([&](int, int, int, float* cp, float v) __attribute__((always_inline)) { *cp = v; });
+        else if (epi == EPI_FWD) {
+            float bias[2] = {0.f, 0.f};
+            if (t.bias) {
+#pragma unroll
+                for (int y = 0; y < 2; ++y) { const int c = cur.c0 + wc * 64 + 32 * y + r32; bias[y] = t.bias[min(c, Cn - 1)]; }
+            }
+            asm volatile("" :: "v"(bias[0]), "v"(bias[1]));             // (the loads have landed before the first store is issued)
+            if (act == ACT_NONE) each([&](int y, int, int, float* cp, float v) __attribute__((always_inline)) { *cp = v * scale + bias[y]; });
+            else if (act == ACT_RELU) each([&](int y, int, int, float* cp, float v) __attribute__((always_inline)) { *cp = fmaxf(v * scale + bias[y], 0.f); });
+            else each([&](int y, int, int, float* cp, float v) __attribute__((always_inline)) { *cp = elu_f(v * scale + bias[y]); });
+        } else if (!accum && !(epi == EPI_DX && (act != ACT_NONE || t.r1u))) {
+            each([&](int, int, int, float* cp, float v) __attribute__((always_inline)) { *cp = v * scale; });
+        } else {
+            const bool dx = epi == EPI_DX;
+            float r1v[2] = {0.f, 0.f};
+            if (dx && t.r1u) {
+#pragma unroll
+                for (int y = 0; y < 2; ++y) { const int c = cur.c0 + wc * 64 + 32 * y + r32; r1v[y] = t.r1v[min(c, Cn - 1)]; }
+            }
+            each([&](int y, int r, int c, float* cp, float v) __attribute__((always_inline)) {
+                v *= scale;
+                if (dx) {
+                    if (t.r1u) v += t.r1u[r] * r1v[y];
+                    if (act != ACT_NONE) {
+                        const float a = t.aux[(size_t)r * t.ldaux + c];
+                        v = act == ACT_RELU ? (a > 0.f ? v : 0.f) : v * elu_grad_from_out(a);
+                    }
+                }
+                if (accum) v += *cp;
+                *cp = v;
+            });
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -330,8 +346,18 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
     {                                                                                                                         \
         __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                                                   \
         __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);                                                                    \
-        __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);                                                                   \
-        _Pragma("unroll") for (int z = 0; z < 48; ++z) {                                                                      \
+        /* the fragment reads of the first 16-deep block (6 per row-major operand, 12 transposed reads per k-major one) ... */      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                                                   \
+        if constexpr (LA == LD_COL) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
+        if constexpr (LB == LD_COL) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
+        /* ... those of the second under the first twelve MFMAs */                                                             \
+        _Pragma("unroll") for (int z = 0; z < 12; ++z) {                                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x100, (LA == LD_COL || LB == LD_COL) ? 2 : 1, 0);                           \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int z = 0; z < 36; ++z) {                                                                      \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                \
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                \
