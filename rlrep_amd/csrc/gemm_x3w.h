@@ -104,7 +104,6 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][y][q] = 0.f;
     f32x4 rs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // (k-major A: bias-gradient partial sums of the tile whose blocks are being split)
-    f32x4 rs_tile[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // (... of the tile being multiplied: complete when its last block is)
 
     // fragment addresses inside stage 0
     // row-major: chunk 2 c + hh of this lane's row; the swizzle term (row >> 2) & 3 is the same for rows r32, 32 + r32, ...
@@ -151,31 +150,23 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
         } else { pb[0] = t.B + min(lt.c0 + (tid & 31) * 4, t.Cn - 4); pb[1] = nullptr; }
     };
     loader_setup();
-    // issue the 16-byte loads of the loader's item (no bounds selects here: the K tail is zeroed when the block is split, and rows / columns beyond the
-    // edge are clamped duplicates whose outputs are never stored)
-    bool l_tail = false, l_dup = false;        // (the item just issued ends inside its 32-deep block; the loader has run out of items and repeats the last)
+    // The loader's item: per-thread element offsets (no bounds selects: the K tail is zeroed when the block is split, and rows / columns beyond the edge
+    // are clamped duplicates whose outputs are never stored).  The six 16-byte loads themselves are issued one by one (load_piece), each right after
+    // the split of the piece whose registers it refills: ONE set of staging registers, and every load still has a whole iteration to land.
+    bool l_tail = false, l_dup = false;        // (the item being loaded ends inside its 32-deep block; the loader has run out of items and repeats the last)
     int l_k0 = 0;
-    auto issue_loads = [&](f32x4 (&ea)[4], f32x4 (&eb)[2]) __attribute__((always_inline)) {
+    size_t oA0 = 0, oA1 = 0, oB0 = 0, oB1 = 0;
+    auto loader_offsets = [&]() __attribute__((always_inline)) {
         const int k0 = lt.kbeg + GL_BK * lkt;
         l_k0 = k0; l_tail = k0 + GL_BK > l_kend;
-        if (!(X3W_ABL & 1)) {
-            if (LA == LD_ROW) {
-                const int ko = min(k0 + (tid & 7) * 4, l_kend - 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ea[j] = ld4(pa[j] + ko);
-            } else {
-                const size_t o0 = (size_t)min(k0 + (tid >> 5), l_kend - 1) * l_lda, o1 = (size_t)min(k0 + (tid >> 5) + 16, l_kend - 1) * l_lda;
-                ea[0] = ld4(pa[0] + o0); ea[1] = ld4(pa[0] + o1); ea[2] = ld4(pa[1] + o0); ea[3] = ld4(pa[1] + o1);
-            }
-            if (LB == LD_ROW) {
-                const int ko = min(k0 + (tid & 7) * 4, l_kend - 4);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) eb[j] = ld4(pb[j] + ko);
-            } else {
-                const size_t o0 = (size_t)min(k0 + (tid >> 5), l_kend - 1) * l_ldb, o1 = (size_t)min(k0 + (tid >> 5) + 16, l_kend - 1) * l_ldb;
-                eb[0] = ld4(pb[0] + o0); eb[1] = ld4(pb[0] + o1);
-            }
-        }
+        const int kr = min(k0 + (tid & 7) * 4, l_kend - 4), k_lo = min(k0 + (tid >> 5), l_kend - 1), k_hi = min(k0 + (tid >> 5) + 16, l_kend - 1);
+        if (LA == LD_ROW) oA0 = (size_t)kr; else { oA0 = (size_t)k_lo * l_lda; oA1 = (size_t)k_hi * l_lda; }
+        if (LB == LD_ROW) oB0 = (size_t)kr; else { oB0 = (size_t)k_lo * l_ldb; oB1 = (size_t)k_hi * l_ldb; }
+    };
+    auto load_piece = [&](int j, f32x4& e) __attribute__((always_inline)) {          // j = 0..3: A slot j; 4, 5: B slot j - 4
+        if (X3W_ABL & 1) return;
+        if (j < 4) e = LA == LD_ROW ? ld4(pa[j] + oA0) : ld4(pa[j >> 1] + ((j & 1) ? oA1 : oA0));
+        else e = LB == LD_ROW ? ld4(pb[j - 4] + oB0) : ld4(pb[0] + ((j & 1) ? oB1 : oB0));
     };
     // step the loader; at the end of the stream it stays on the last item (the duplicates it loads are split into a stage nobody reads)
     auto loader_step = [&]() __attribute__((always_inline)) {
@@ -205,12 +196,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
         if constexpr (LA == LD_COL) {
             if (t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD) && cur.tc == 0) {
                 // bias gradient = row sums of operand A: this thread holds rows 128 s + 4 (tid % 32) .. + 3 of its k slot -> LDS -> fixed-order sum over the 16 slots
+                // (the partial sums were put into bias_part when the first block of the NEXT tile came up for splitting: hand_over below)
                 float* part = bias_part;
-                const int c4 = (tid & 31) * 4, ks = tid >> 5;
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) part[(128 * s + c4 + q) * 16 + ks] = rs_tile[s][q];
                 __syncthreads();
                 if (tid < 256) {
                     const float* q = part + tid * 16;
@@ -329,62 +316,66 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
     } else {                                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int m = 0; m < 3; ++m) { asm volatile("" :: "v"(a[i][m])); asm volatile("" :: "v"(b[i][m])); } \
     }
-    // split the block in (EA, EB) into the stage at byte offset ST
-#define X3W_SPLIT(EA, EB, ST)                                                                                                 \
-    if (!(X3W_ABL & 2)) {                                                                                                     \
-        x3w_split_write<X3W_AIMG, 0>((ST) + wA, EA[0]); x3w_split_write<X3W_AIMG, 4096>((ST) + wA, EA[1]);                      \
-        x3w_split_write<X3W_AIMG, 8192>((ST) + wA, EA[2]); x3w_split_write<X3W_AIMG, 12288>((ST) + wA, EA[3]);                 \
-        x3w_split_write<X3W_BIMG, 0>((ST) + wB, EB[0]); x3w_split_write<X3W_BIMG, 4096>((ST) + wB, EB[1]);                      \
-    } else {                                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(EA[j]));                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(EB[j]));                                          \
+    // split the block in (ea, eb) into the stage ST, and refill each piece's registers with the loader's item as soon as the piece is split
+#define X3W_PIECE(J, E, PTR, IMG, OFF)                                                                                        \
+    if (!(X3W_ABL & 2)) x3w_split_write<IMG, OFF>(PTR, E); else asm volatile("" :: "v"(E));                                   \
+    if (RELOAD) load_piece(J, E);
+#define X3W_SPLIT(ST)                                                                                                         \
+    {                                                                                                                         \
+        X3W_PIECE(0, ea[0], (ST) + wA, X3W_AIMG, 0) X3W_PIECE(1, ea[1], (ST) + wA, X3W_AIMG, 4096)                             \
+        X3W_PIECE(2, ea[2], (ST) + wA, X3W_AIMG, 8192) X3W_PIECE(3, ea[3], (ST) + wA, X3W_AIMG, 12288)                         \
+        X3W_PIECE(4, eb[0], (ST) + wB, X3W_BIMG, 0) X3W_PIECE(5, eb[1], (ST) + wB, X3W_BIMG, 4096)                             \
     }
     // the order of one iteration's instructions: the loads first (longest latency), all fragment reads, then per MFMA three or four vector
     // instructions of the split and, for the first 18, one LDS write
 #if X3W_SCHED
 #define X3W_PIPELINE()                                                                                                        \
     {                                                                                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);                                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);                                                                   \
         /* the fragment reads of the first 16-deep block (6 per row-major operand, 12 transposed reads per k-major one) ... */      \
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                                                   \
         if constexpr (LA == LD_COL) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
         if constexpr (LB == LD_COL) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
-        /* ... those of the second under the first twelve MFMAs */                                                             \
-        _Pragma("unroll") for (int z = 0; z < 12; ++z) {                                                                      \
+        /* ... those of the second under the first twelve MFMAs; per MFMA three vector instructions of the split, its LDS writes as they */ \
+        /* become ready, and after every sixth (one 16-byte piece split) the load that refills the piece's registers */        \
+        _Pragma("unroll") for (int z = 0; z < 48; ++z) {                                                                      \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x100, (LA == LD_COL || LB == LD_COL) ? 2 : 1, 0);                           \
+            if (z < 12) __builtin_amdgcn_sched_group_barrier(0x100, (LA == LD_COL || LB == LD_COL) ? 2 : 1, 0);               \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                \
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                \
-        }                                                                                                                     \
-        _Pragma("unroll") for (int z = 0; z < 36; ++z) {                                                                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                \
+            if (z % 6 == 5 && z < 36) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                      \
         }                                                                                                                     \
     }
 #else
 #define X3W_PIPELINE()
 #endif
 
-    // One iteration: multiply the block in the stage at RD, split the block in (EA, EB) into the stage at WR, load the loader's block into (NA, NB).
-    // first / tail / k0 / kend of the block in (EA, EB) were noted when it was loaded (F_*), those of the block being loaded go to (N_*).
-#define X3W_ITER(EA, EB, NA, NB, RD, WR, F, N)                                                                                \
+    // One iteration: multiply the block in the stage RD, split the block in (ea, eb) into the stage WR and refill (ea, eb) with the loader's block.
+    // first / tail / k0 / kend of the block in (ea, eb) were noted when its loads were issued (F_*), those of the block being loaded go to (N_*).
+    auto hand_over = [&]() __attribute__((always_inline)) {
+        // (ea, eb) hold the first block of the next tile: the bias-gradient sums of the tile being finished are complete -> LDS (store_tile reduces them)
+        const int c4 = (tid & 31) * 4, ks = tid >> 5;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias_part[(128 * s + c4 + q) * 16 + ks] = rs[s][q];
+        rs[0] = rs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+#define X3W_ITER(RD, WR, F, N)                                                                                                \
     {                                                                                                                         \
         __syncthreads();                                                                                                      \
-        if (F##_tail) zero_tail(EA, EB, F##_k0, F##_kend);                                                                    \
-        if constexpr (LA == LD_COL) {                                                                                         \
-            if (F##_first) { rs_tile[0] = rs[0]; rs_tile[1] = rs[1]; rs[0] = rs[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }           \
-        }                                                                                                                     \
+        if (F##_tail) zero_tail(ea, eb, F##_k0, F##_kend);                                                                    \
+        if constexpr (LA == LD_COL) { if (F##_first) hand_over(); }                                                           \
         {                                                                                                                     \
+            constexpr bool RELOAD = true;                                                                                     \
             bf16x8 a0[2][3], b0[2][3], a1[2][3], b1[2][3];                                                                    \
-            issue_loads(NA, NB);                                                                                              \
+            loader_offsets();                                                                                                 \
             X3W_FRAGS(0, RD, a0, b0)                                                                                          \
             X3W_FRAGS(1, RD, a1, b1)                                                                                          \
             X3W_MMA(a0, b0)                                                                                                   \
             X3W_MMA(a1, b1)                                                                                                   \
-            if constexpr (LA == LD_COL) { rs[0] += EA[0] + EA[1]; rs[1] += EA[2] + EA[3]; }                                   \
-            X3W_SPLIT(EA, EB, WR)                                                                                             \
+            if constexpr (LA == LD_COL) { rs[0] += ea[0] + ea[1]; rs[1] += ea[2] + ea[3]; }                                   \
+            X3W_SPLIT(WR)                                                                                                     \
             X3W_PIPELINE()                                                                                                    \
         }                                                                                                                     \
         N##_tail = l_tail; N##_k0 = l_k0; N##_kend = l_kend; N##_first = l_dup || lkt == 0;                                   \
@@ -397,25 +388,30 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
         } else ++ckt;                                                                                                         \
     }
 
-    // prologue: item 0 -> stage 0, item 1 -> (ea0, eb0)
-    f32x4 ea0[4], eb0[2], ea1[4], eb1[2];
+    // prologue: item 0 -> stage 0, item 1 -> (ea, eb)
+    f32x4 ea[4], eb[2];
     bool p_tail = false, q_tail = false, p_first = false, q_first = false;
     int p_k0 = 0, q_k0 = 0, p_kend = 0, q_kend = 0;
-    issue_loads(ea0, eb0);
-    if (l_tail) zero_tail(ea0, eb0, l_k0, l_kend);
-    if constexpr (LA == LD_COL) { rs[0] += ea0[0] + ea0[1]; rs[1] += ea0[2] + ea0[3]; }
-    X3W_SPLIT(ea0, eb0, S0)
+    loader_offsets();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_piece(j, ea[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) load_piece(4 + j, eb[j]);
+    if (l_tail) zero_tail(ea, eb, l_k0, l_kend);
+    if constexpr (LA == LD_COL) { rs[0] += ea[0] + ea[1]; rs[1] += ea[2] + ea[3]; }
     loader_step();
-    issue_loads(ea0, eb0);
+    loader_offsets();
     p_tail = l_tail; p_k0 = l_k0; p_kend = l_kend; p_first = l_dup || lkt == 0;
+    { constexpr bool RELOAD = true; X3W_SPLIT(S0) }
     loader_step();
     for (;;) {
-        X3W_ITER(ea0, eb0, ea1, eb1, S0, S1, p, q)
-        X3W_ITER(ea1, eb1, ea0, eb0, S1, S0, q, p)
+        X3W_ITER(S0, S1, p, q)
+        X3W_ITER(S1, S0, q, p)
     }
 #undef X3W_ITER
 #undef X3W_PIPELINE
 #undef X3W_SPLIT
+#undef X3W_PIECE
 #undef X3W_MMA
 #undef X3W_FRAGS
 }
