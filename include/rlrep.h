@@ -403,7 +403,8 @@ int32_t rlrep_stage_info(rlrep_agent* agent, int32_t program, int32_t stage, int
  *        1 dX:      acc * act'(aux), flags & 1: C += ...
  *        3 dW:      acc, flags & 1: C += ..., flags & 2: out2[r] = sum_k opA(r,k) (bias gradient)
  *   engine: 0 = 16-row tile engine (gemm16), 1 = LDS-tiled engine (gemm_lds), 2 = its 128-wide tile on the bf16 pipe
- *   (bf16x3: three-way operand split, six MFMAs, fp32 accuracy); bt (0 auto, 64, 128) and splits
+ *   (bf16x3: three-way operand split, six MFMAs, fp32 accuracy); bt (0 auto, 64, 128; with engine 2 also 256 = the persistent
+ *   256 x 128 tile, which has no sin / tanh epilogue) and splits
  *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats), which a finishing launch adds
  *   in split order.
  * Returns 0, or RLREP_ERR_ARG when the engine cannot run the shape (alignment rules in gemm_lds.hip). */
@@ -413,8 +414,8 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, i
                    float* workspace_dev, int64_t workspace_floats, void* stream);
 
 /* Host-only (no GPU call): the GEMM engine the program builder picks for a product of these dimensions and layouts --
- * *engine 0 = 16-row tile engine, 1 = LDS-tiled fp32-MFMA, 2 = LDS-tiled bf16x3 -- with its tile edge (64 / 128), split-K
- * plan and which sides fall back to 4-byte accesses (bit 0: A, bit 1: B, bit 2: C). */
+ * *engine 0 = 16-row tile engine, 1 = LDS-tiled fp32-MFMA, 2 = LDS-tiled bf16x3 -- with its tile edge (64 / 128; 256 = the persistent
+ * 256 x 128 tile of engine 2), split-K plan and which sides fall back to 4-byte accesses (bit 0: A, bit 1: B, bit 2: C). */
 int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t rows, int32_t cols, int32_t inner, int32_t lda, int32_t ldb, int32_t ldc,
                         int32_t* engine, int32_t* tile, int32_t* splits, int32_t* kchunk, int32_t* scalar_sides);
 

@@ -1788,6 +1788,7 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
             fin = (int)(((long long)R * ((Cn + 3) / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
         }
         const bool wide = engine == 2 && bt == 256;          // the 256 x 128 persistent tile (gemm_x3w.h)
+        if (wide && (act == ACT_SIN || act == ACT_TANH)) { rl_set_error("gemm: the 256 x 128 tile has no sin / tanh epilogue"); return RLREP_ERR_ARG; }
         const int er = wide ? 256 : pbt, ec = wide ? 128 : pbt;
         t.tiles_c = (Cn + ec - 1) / ec; t.ntiles = ((R + er - 1) / er) * t.tiles_c * psp; t.tile_base = 0;
         gb.t[0] = t;
@@ -1805,8 +1806,8 @@ int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K
     t.R = R; t.Cn = Cn; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.epi = la == LD_COL ? EPI_DW : EPI_FWD;
     int sp = 1, kc = 0, fl = 0;
     const int code = rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl);
-    *engine = code == 0 ? 0 : (code == 129 || code == 65) ? 2 : 1;
-    if (tile) *tile = code == 0 ? 16 : code == 129 ? 128 : code == 65 ? 64 : code;
+    *engine = code == 0 ? 0 : (code == 257 || code == 129 || code == 65) ? 2 : 1;
+    if (tile) *tile = code == 0 ? 16 : code == 257 ? 256 : code == 129 ? 128 : code == 65 ? 64 : code;
     if (splits) *splits = code ? sp : 1;
     if (kchunk) *kchunk = code ? kc : K;
     if (scalar_sides) *scalar_sides = code ? (((fl & FLAG_SCALAR_A) ? 1 : 0) | ((fl & FLAG_SCALAR_B) ? 2 : 0) | ((fl & FLAG_SCALAR_C) ? 4 : 0)) : 0;

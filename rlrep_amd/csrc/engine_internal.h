@@ -163,7 +163,7 @@ struct Builder {
     // only, so the dry sizing pass and the real pass allocate identically; a task whose pointers turn out not to be
     // 16-byte aligned simply stays on gemm16 and leaves its slab unused.
     void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
-        std::vector<GemmTask> small, big128, big64, bigx3, bigx3s;
+        std::vector<GemmTask> small, big128, big64, bigx3, bigx3s, bigx3w;
         for (auto& t : tasks) {
             int sp = 1, kc = 0, fl = 0;
             // dimensions decide the engine and the slab reservation (identical in the dry and the real pass) ...
@@ -174,14 +174,15 @@ struct Builder {
                 // ... pointer alignment can only add scalar-access flags (and take bf16x3 away)
                 const int code = rl_gemm_lds_route(&t, la, lb, dry ? 0 : rl_gemm_lds_ptr_flags(&t), &sp, &kc, &fl);
                 t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab; t.flags |= fl;
-                (code == 129 ? bigx3 : code == 65 ? bigx3s : code == 128 ? big128 : big64).push_back(t);
+                (code == 257 ? bigx3w : code == 129 ? bigx3 : code == 65 ? bigx3s : code == 128 ? big128 : big64).push_back(t);
                 continue;
             }
             small.push_back(t);
         }
         // one launch per tile width: if some 64-wide tasks of the stage cannot take the bf16x3 tile (scalar staging), all of them stay on fp32
         if (!big64.empty() && !bigx3s.empty()) { big64.insert(big64.end(), bigx3s.begin(), bigx3s.end()); bigx3s.clear(); }
-        if (!bigx3.empty() || !big128.empty() || !big64.empty() || !bigx3s.empty()) chain_flush();
+        if (!bigx3w.empty() || !bigx3.empty() || !big128.empty() || !big64.empty() || !bigx3s.empty()) chain_flush();
+        if (!bigx3w.empty()) gemm_lds_stage(p, la, lb, 257, bigx3w, what);
         if (!bigx3.empty()) gemm_lds_stage(p, la, lb, 129, bigx3, what);
         if (!big128.empty()) gemm_lds_stage(p, la, lb, 128, big128, what);
         if (!bigx3s.empty()) gemm_lds_stage(p, la, lb, 65, bigx3s, what);
@@ -219,9 +220,10 @@ struct Builder {
     void gemm_lds_stage(Program& p, int la, int lb, int bt, std::vector<GemmTask> tasks, const char* what) {
         int base = 0, fin = 0;
         const int edge = bt == 129 ? 128 : bt == 65 ? 64 : bt;       // 129 / 65: the 128- / 64-wide tile on the bf16 pipe
+        const int er = bt == 257 ? 256 : edge, ec = bt == 257 ? 128 : edge;     // 257: 256 rows x 128 columns (gemm_x3w.h)
         for (auto& t : tasks) {
-            t.tiles_c = (t.Cn + edge - 1) / edge;
-            t.ntiles = ((t.R + edge - 1) / edge) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
+            t.tiles_c = (t.Cn + ec - 1) / ec;
+            t.ntiles = ((t.R + er - 1) / er) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
             if (t.splits > 1 && fold_fin(t)) t.fin_base = 0x7fffffff;       // (no finishing block ever matches it)
             else if (t.splits > 1) {
                 const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
@@ -233,7 +235,7 @@ struct Builder {
         gb.ntasks = (int)tasks.size();
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm_lds(bt, la, lb, &gb, base, fin, st); }, what});
-        tag_gemms(p, (bt == 129 || bt == 65) ? RLREP_ENGINE_X3 : bt == 128 ? RLREP_ENGINE_LDS128 : RLREP_ENGINE_LDS64, tasks);
+        tag_gemms(p, (bt == 257 || bt == 129 || bt == 65) ? RLREP_ENGINE_X3 : bt == 128 ? RLREP_ENGINE_LDS128 : RLREP_ENGINE_LDS64, tasks);
     }
     void gemm_small(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
         if (chain_take(p, la, lb, tasks, what)) return;

@@ -1154,7 +1154,7 @@ extern "C" void rl_gemm_lds_plan(const GemmTask* t, int* bt, int* splits, int* k
 
 // The program builder's routing decision for one task, from dimensions alone (pointer alignment may add scalar flags
 // later, which also rules out bf16x3): returns 0 = stays on the 16-row engine, 64 / 128 = fp32-MFMA tile, 129 = the 128-wide
-// tile on the bf16 pipe.  Products of >= 2 GFLOP with a row-major A (forward, dX: diffsrsac's 202-GFLOP nabla-mu head) take
+// tile on the bf16 pipe, 257 = the 256 x 128 persistent tile on the bf16 pipe, 65 = the 64-wide one.  Products of >= 2 GFLOP with a row-major A (forward, dX: diffsrsac's 202-GFLOP nabla-mu head) take
 // bf16x3: 159 / 137 TF against 110 on the fp32 pipe; the k-major/k-major weight-gradient form stays on fp32 MFMA (107 vs 116).
 extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_flags, int* splits, int* kchunk, int* flags) {
     const bool combo = (la == LD_ROW && lb == LD_ROW) || (la == LD_ROW && lb == LD_COL) || (la == LD_COL && lb == LD_COL);
@@ -1165,7 +1165,14 @@ extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_fl
     // (the k-major / k-major weight-gradient form takes bf16x3 too since round 4: gemm_x3t_kernel; RLREP_DISABLE=x3_dw keeps it on the fp32 tile)
     const bool x3 = bt == 128 && (la == LD_ROW || (lb == LD_COL && !rl_off("x3_dw"))) && 2.0 * t->R * t->Cn * t->K >= 2e9 && !rl_off("x3") &&
                     !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B));
-    if (x3) return 129;
+    if (x3) {
+        // the 256 x 128 persistent tile (gemm_x3w.h) where its tiles fill the chip's 256 CUs evenly: >= 85 % of the last round of workgroups busy
+        // (RLREP_DISABLE=x3w keeps the 128 x 128 tile)
+        const long long wt = (long long)((t->R + 255) / 256) * ((t->Cn + 127) / 128) * *splits;
+        const bool fills = wt >= 256 && (double)wt / (double)(((wt + 255) / 256) * 256) >= 0.85;
+        if (fills && x3w_epilogue_ok(t) && !rl_off("x3w")) return 257;
+        return 129;
+    }
     // 64-wide tiles: on the bf16 pipe too when both operands allow 16-byte staging (gemm_x3s_kernel); RLREP_DISABLE=x3s keeps the fp32 tile
     // (the program builder keeps a STAGE on one engine: a stage whose tasks would be split between this tile and the fp32 one becomes two dependent
     // launches, which costs more than the faster tile returns -- spedersac: 69 -> 81 launches on the feature chain, 961 -> 903 train()/s)

@@ -89,19 +89,22 @@ def test_gemm_routing_of_the_path_shapes():
     assert (p['engine'], p['tile']) == (2, 64) and p['scalar'] == 3          # A and B rows of 119 floats
     p = _plan(1, 1, 512, 119, 2048, lda=512, ldb=119, ldc=119)
     assert (p['engine'], p['tile']) == (2, 64) and p['scalar'] == 6 and p['splits'] > 1
-    # diffsrsac Humanoid nabla-mu head: all three passes on the bf16 pipe (dX / dW through transposed LDS reads), dX split along its long K
-    assert _plan(0, 0, 2048, 96256, 512) == dict(engine=2, tile=128, splits=1, kchunk=512, scalar=0)
+    # diffsrsac Humanoid nabla-mu head: all three passes on the bf16 pipe (dX / dW through transposed LDS reads), dX split along its long K; the
+    # 256 x 128 persistent tile (tile = 256) wherever its tiles fill the 256 CUs evenly: 6 016 / 32 x 8 splits / 1 504 of them here
+    assert _plan(0, 0, 2048, 96256, 512) == dict(engine=2, tile=256, splits=1, kchunk=512, scalar=0)
     p = _plan(0, 1, 2048, 512, 96256)
-    assert p['engine'] == 2 and p['splits'] == 8 and p['splits'] * p['kchunk'] >= 96256 > (p['splits'] - 1) * p['kchunk'] and p['kchunk'] % 32 == 0
+    assert p['engine'] == 2 and p['tile'] == 256 and p['splits'] == 8 and p['splits'] * p['kchunk'] >= 96256 > (p['splits'] - 1) * p['kchunk'] and p['kchunk'] % 32 == 0
     p = _plan(1, 1, 96256, 512, 2048)
-    assert (p['engine'], p['tile'], p['splits']) == (2, 128, 1)
-    # every plan over a sweep: splits cover K, chunks are multiples of the 32-deep slice, tiles are 64 or 128
+    assert (p['engine'], p['tile'], p['splits']) == (2, 256, 1)
+    # ... and not where they would leave most of a round of workgroups idle: 2048 x 2048 x 2048 = 128 of them
+    assert _plan(0, 0, 2048, 2048, 2048)['tile'] == 128
+    # every plan over a sweep: splits cover K, chunks are multiples of the 32-deep slice, tiles are 64, 128 or 256 (x 128)
     for R in (256, 1000, 2048, 4096):
         for Cn in (256, 520, 2048):
             for K in (64, 256, 1000, 4096, 50000):
                 p = _plan(0, 0, R, Cn, K)
                 if p['engine']:
-                    assert p['tile'] in (64, 128) and p['kchunk'] % 32 == 0 and 1 <= p['splits'] <= 32
+                    assert p['tile'] in (64, 128, 256) and p['kchunk'] % 32 == 0 and 1 <= p['splits'] <= 32
                     assert p['splits'] * p['kchunk'] >= K > (p['splits'] - 1) * p['kchunk'], (R, Cn, K, p)
 
 

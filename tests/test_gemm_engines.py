@@ -169,6 +169,34 @@ def test_bf16x3_engine_is_fp32_accurate(mode):
 
 
 @pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+def test_bf16x3_256_by_128_persistent_tile_is_fp32_accurate(mode):
+    """engine 2 with bt = 256: gemm_x3w_kernel, the 256 x 128 tile of ONE persistent workgroup per CU (csrc/gemm_x3w.h: the nabla-mu head of
+    diffsrsac at Humanoid dims).  One tile, tiles that end inside the 256 rows / 128 columns / the 32-deep block, a one-block K (every tile
+    hands its bias sums over at once), more tiles than workgroups (the stream of (tile, block) items crosses tile boundaries; 40 x 33 = 1 320
+    tiles of one block each on 256 workgroups), split-K slabs with accumulation, the ELU epilogues, and the bias gradient of the k-major form.
+    2e-6 against float64 like the 128-wide tile."""
+    check(2, mode, 256, 128, 64, bt=256, splits=1, seed=71)
+    check(2, mode, 148, 92, 100, bt=256, splits=1, seed=72)
+    check(2, mode, 1032, 644, 196, bt=256, splits=1, seed=73)
+    check(2, mode, 300, 132, 1024, bt=256, splits=3, seed=74, accum=(mode != 'fwd'))
+    check(2, mode, 768, 640, 512, bt=256, act='elu' if mode != 'dw' else 'none', seed=75)
+    check(2, mode, 768, 640, 96, bt=256, splits=1, act='relu' if mode != 'dw' else 'none', seed=76, bias=False)
+    check(2, mode, 10240, 4224, 32, bt=256, splits=1, seed=77)
+    check(2, mode, 5000, 128, 320, bt=256, splits=2, seed=78)
+    got, want, _ = run_gemm(2, mode, 512, 256, 256, bt=256, splits=1, seed=79)
+    ref, _, _ = run_gemm(1, mode, 512, 256, 256, bt=128, splits=1, seed=79)
+    assert rel(got, want) < 2e-6 and rel(ref, want) < 2e-6, (rel(got, want), rel(ref, want))
+
+
+def test_bf16x3_256_by_128_tile_refuses_the_epilogues_it_does_not_have():
+    from rlrep_amd import _lib
+    x = torch.zeros(256 * 256, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    rc = _lib.lib.rlrep_gemm(2, 0, 0, x.data_ptr(), 256, x.data_ptr(), 256, x.data_ptr(), 128, 256, 128, 256, 0, 3, 0, None, None, 128, x.data_ptr(), 256, 1, None, 0, st)
+    assert rc != 0 and b'sin / tanh' in _lib.lib.rlrep_last_error()
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
 def test_bf16x3_64_wide_tile_is_fp32_accurate(mode):
     """engine 2 with bt = 64: gemm_x3s_kernel, the 64 x 64 tile on the bf16 pipe (row-major operands through [row][80-byte] images, k-major
     ones staged as they lie and read with ds_read_b64_tr_b16) -- the M = 256 / 2048 layers of ctrlsac / spedersac.  Exact tiles, ragged edges
