@@ -146,10 +146,10 @@ def big_gemm_roofline(agent, B, S, F, Hn, reps=20):
     flops = 2.0 * B * Hn * (F * S)
     achieved = flops / (us * 1e-6) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0          # six bf16 MFMA flops per algorithmic fp32 flop
-    return {'bound': 'mfma', 'kernel': 'gemm_x3_kernel<row,row> (nabla-mu head forward [B,512]x[512,F*S], bf16x3)',
+    return {'bound': 'mfma', 'kernel': 'gemm_x3w_kernel<row,row> (nabla-mu head forward [B,512]x[512,F*S], bf16x3, 256 x 128 persistent tile)',
             'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
             'us_per_launch': round(us, 1), 'flop_per_launch': flops,
-            'note': 'achieved = algorithmic fp32 flops / time; peak = dense bf16 MFMA peak (2500 TF) / 6 executed flops per product',
+            'note': 'achieved = algorithmic fp32 flops / time; peak = dense bf16 MFMA peak (2500 TF) / 6 executed flops per product (a bare v_mfma_f32_32x32x16_bf16 loop on every SIMD sustains 1830-2030 TF at the clock the chip then holds: tools/exp/mfma_bf16.hip)',
             'executed_bf16_tflops': round(6 * achieved, 1), 'vs_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
 
 

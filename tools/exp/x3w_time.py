@@ -31,6 +31,7 @@ def timeit(mode, R, Cn, K, bt, reps=5, splits=0):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+timeit('fwd', 4096, 4096, 4096, BT, reps=30)          # (clocks up before the first measured product)
 line = os.path.basename(os.environ.get('RLREP_LIB', 'product')) + f' bt {BT}:'
 for name, mode, R, Cn, K, sp in (('fwd', 'fwd', 2048, 96256, 512, 0), ('dX', 'dx', 2048, 512, 96256, 16), ('dW', 'dw', 96256, 512, 2048, 0), ('4096 fwd', 'fwd', 4096, 4096, 4096, 0),
                                  ('4096 dW', 'dw', 4096, 4096, 4096, 0)):
