@@ -250,8 +250,8 @@ FAMILIES = {
     'gemm_lds64': ((3,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^(gemm_lds_kernel<64|gemm_lds_fin_kernel)',
                    'gemm_lds_kernel<64,...> + gemm_lds_fin_kernel (64-wide LDS tiles on fp32 MFMA, split-K slabs + finishing blocks)'),
     'gemm_lds128': ((4,), 'mfma', FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s', r'^gemm_lds_kernel<128', 'gemm_lds_kernel<128,...> (128-wide LDS tiles on fp32 MFMA)'),
-    'gemm_x3': ((5,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^gemm_x3(s|t)?_kernel',
-                'gemm_x3_kernel / gemm_x3t_kernel (128-wide) + gemm_x3s_kernel (64-wide): tiles on the bf16 pipe, exact 3-way split: peak = dense bf16 peak / 6 executed flops per product'),
+    'gemm_x3': ((5,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^gemm_x3(s|t|w)?_kernel',
+                'gemm_x3w_kernel (256 x 128, persistent) + gemm_x3_kernel / gemm_x3t_kernel (128-wide) + gemm_x3s_kernel (64-wide): tiles on the bf16 pipe, exact 3-way split: peak = dense bf16 peak / 6 executed flops per product'),
     'noise_critic': ((6,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^nc_', 'nc_fwd / nc_dx / nc_dw kernels (vlsac noise critic, bf16x3: peak = dense bf16 peak / 6)'),
     'optimizer': ((7,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^adam_(l1_)?kernel', 'adam_kernel / adam_l1_kernel (Adam + Polyak + metrics + riders: 28 B per parameter + 12 B per target element)'),
     'score': ((8,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^diffsr_score', 'diffsr_score kernels (one pass over the [B, F*S] tensor)'),

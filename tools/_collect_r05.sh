@@ -71,6 +71,13 @@ if [ $PART = bench ] || [ $PART = all ]; then
   python3 bench.py --workload diffsrsac_humanoid_b2048 --steps 20 --warmup 3 > gpurun_out/bench_diffsrsac_humanoid_b2048.log 2>&1 || exit 1
   tail -n 1 gpurun_out/bench_diffsrsac_humanoid_b2048.log >> $OUT/r05_bench_all.jsonl
 fi
+if [ $PART = hum ]; then      # diffsrsac Humanoid alone (re-collected after the 256 x 128 bf16x3 tile was routed): PMC first, bench.py reads roofline.traffic from it
+  pmc_one diffsrsac_humanoid_b2048 3 || exit 1
+  stats_one diffsrsac_humanoid_b2048 10 || exit 1
+  cd $R
+  python3 bench.py --workload diffsrsac_humanoid_b2048 --steps 20 --warmup 3 > gpurun_out/bench_diffsrsac_humanoid_b2048.log 2>&1 || exit 1
+  tail -n 1 gpurun_out/bench_diffsrsac_humanoid_b2048.log > $OUT/r05_bench_humanoid.json
+fi
 if [ $PART = misc ] || [ $PART = all ]; then
   cd $R
   : > $OUT/r05_dp_rehearsal.jsonl
