@@ -22,9 +22,8 @@
 #ifndef X3W_ABL
 #define X3W_ABL 0          /* timing-only ablations: 1 no global loads, 2 no split / LDS writes, 4 no MFMAs */
 #endif
-#ifndef X3W_SCHED
-#define X3W_SCHED 1        /* 0: leave the iteration's instruction order to the compiler */
-#endif
+#include <utility>
+#include <type_traits>
 #define X3W_BM 256
 #define X3W_BN 128
 #define X3W_AIMG (X3W_BM * 64)                       /* bytes per A image */
@@ -62,14 +61,17 @@ static inline bool x3w_epilogue_ok(const GemmTask* t) {
     return (t->epi == EPI_FWD || t->epi == EPI_DX || t->epi == EPI_DW) && (t->act == ACT_NONE || t->act == ACT_RELU || t->act == ACT_ELU);
 }
 
+template <class F, int... I> __device__ __forceinline__ void x3w_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void x3w_for(F&& f) { x3w_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 struct X3wTile { int ti, r0, c0, kbeg, kend, nk, split, tc; };
 
 template <int LA, int LB>
 __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBatch gb, int total_tiles) {
     const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
-    __shared__ __attribute__((aligned(16))) unsigned char stage0[X3W_STAGE], stage1[X3W_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char stages[2 * X3W_STAGE];
     __shared__ __attribute__((aligned(16))) float bias_part[4096];          // [256 rows][16 k slots]
-    const x3w_lds S0 = (x3w_lds)stage0, S1 = (x3w_lds)stage1;
+    const x3w_lds S0 = (x3w_lds)stages;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
@@ -266,6 +268,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
                 *cp = v;
             });
         }
+        // The stores must have left before the loop goes on: a store's source registers count as busy until its vmcnt retires, the compiler cannot tell
+        // an iteration that follows a tile's end from one that does not, and so it put an `s_waitcnt vmcnt(0)` in front of the first instruction of
+        // EVERY iteration that overwrites such a register -- a wait for the six loads issued in the previous iteration, the youngest 0.4 us earlier:
+        // the iteration took 2.5 us instead of 1.7.  Waited for here, once per tile (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -274,81 +281,78 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
                 for (int q = 0; q < 16; ++q) acc[i][y][q] = 0.f;
     };
 
-    // fragments of 16-deep block C of the stage at byte offset ST
-#define X3W_FRAGS(C, ST, a, b)                                                                                                \
-    {                                                                                                                         \
-        if constexpr (LA == LD_ROW) {                                                                                         \
-            const x3w_lds p = (ST) + (faR + (unsigned)(fsw * (C)));                                                            \
-            a[0][0] = x3w_rd128<0>(p); a[0][1] = x3w_rd128<X3W_AIMG>(p); a[0][2] = x3w_rd128<2 * X3W_AIMG>(p);                   \
-            a[1][0] = x3w_rd128<2048>(p); a[1][1] = x3w_rd128<2048 + X3W_AIMG>(p); a[1][2] = x3w_rd128<2048 + 2 * X3W_AIMG>(p);  \
-        } else {                                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
-                const x3w_lds p0 = (ST) + aA[i][0], p1 = (ST) + aA[i][1];                                                     \
-                a[i][0] = x3w_tr<(C) * 4096>(p0, p1); a[i][1] = x3w_tr<(C) * 4096 + X3W_AIMG>(p0, p1);                         \
-                a[i][2] = x3w_tr<(C) * 4096 + 2 * X3W_AIMG>(p0, p1);                                                          \
-            }                                                                                                                 \
-        }                                                                                                                     \
-        if constexpr (LB == LD_ROW) {                                                                                         \
-            const x3w_lds p = (ST) + (fbR + (unsigned)(fsw * (C)));                                                            \
-            b[0][0] = x3w_rd128<0>(p); b[0][1] = x3w_rd128<X3W_BIMG>(p); b[0][2] = x3w_rd128<2 * X3W_BIMG>(p);                   \
-            b[1][0] = x3w_rd128<2048>(p); b[1][1] = x3w_rd128<2048 + X3W_BIMG>(p); b[1][2] = x3w_rd128<2048 + 2 * X3W_BIMG>(p);  \
-        } else {                                                                                                              \
-            _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                   \
-                const x3w_lds p0 = (ST) + aB[y][0], p1 = (ST) + aB[y][1];                                                     \
-                b[y][0] = x3w_tr<(C) * 4096>(p0, p1); b[y][1] = x3w_tr<(C) * 4096 + X3W_BIMG>(p0, p1);                         \
-                b[y][2] = x3w_tr<(C) * 4096 + 2 * X3W_BIMG>(p0, p1);                                                          \
-            }                                                                                                                 \
-        }                                                                                                                     \
-    }
-#define X3W_MMA(a, b)                                                                                                         \
-    if (!(X3W_ABL & 4)) {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                         \
-        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                       \
-            f32x16 v = acc[i][y];                                                                                             \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[y][2], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[y][0], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[y][1], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[y][1], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[y][0], v, 0, 0, 0);                                        \
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[y][0], v, 0, 0, 0);                                        \
-            acc[i][y] = v;                                                                                                    \
-        }                                                                                                                     \
-    } else {                                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int m = 0; m < 3; ++m) { asm volatile("" :: "v"(a[i][m])); asm volatile("" :: "v"(b[i][m])); } \
-    }
-    // split the block in (ea, eb) into the stage ST, and refill each piece's registers with the loader's item as soon as the piece is split
-#define X3W_PIECE(J, E, PTR, IMG, OFF)                                                                                        \
-    if (!(X3W_ABL & 2)) x3w_split_write<IMG, OFF>(PTR, E); else asm volatile("" :: "v"(E));                                   \
-    if (RELOAD) load_piece(J, E);
-#define X3W_SPLIT(ST)                                                                                                         \
-    {                                                                                                                         \
-        X3W_PIECE(0, ea[0], (ST) + wA, X3W_AIMG, 0) X3W_PIECE(1, ea[1], (ST) + wA, X3W_AIMG, 4096)                             \
-        X3W_PIECE(2, ea[2], (ST) + wA, X3W_AIMG, 8192) X3W_PIECE(3, ea[3], (ST) + wA, X3W_AIMG, 12288)                         \
-        X3W_PIECE(4, eb[0], (ST) + wB, X3W_BIMG, 0) X3W_PIECE(5, eb[1], (ST) + wB, X3W_BIMG, 4096)                             \
-    }
-    // the order of one iteration's instructions: the loads first (longest latency), all fragment reads, then per MFMA three or four vector
-    // instructions of the split and, for the first 18, one LDS write
-#if X3W_SCHED
-#define X3W_PIPELINE()                                                                                                        \
-    {                                                                                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);                                                                   \
-        /* the fragment reads of the first 16-deep block (6 per row-major operand, 12 transposed reads per k-major one) ... */      \
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                                                   \
-        if constexpr (LA == LD_COL) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
-        if constexpr (LB == LD_COL) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                        \
-        /* ... those of the second under the first twelve MFMAs; per MFMA three vector instructions of the split, its LDS writes as they */ \
-        /* become ready, and after every sixth (one 16-byte piece split) the load that refills the piece's registers */        \
-        _Pragma("unroll") for (int z = 0; z < 48; ++z) {                                                                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
-            if (z < 12) __builtin_amdgcn_sched_group_barrier(0x100, (LA == LD_COL || LB == LD_COL) ? 2 : 1, 0);               \
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                                \
-            if (z % 6 == 5 && z < 36) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                      \
-        }                                                                                                                     \
-    }
-#else
-#define X3W_PIPELINE()
-#endif
+    // ---- one iteration, slot by slot ---------------------------------------------------------------------------------------------------------
+    // 48 slots = the 48 MFMAs of a 32-deep block (16-deep half c, row block i, column block y, six products), in this order, each followed by what
+    // rides in its shadow, and a sched_barrier(0) so that it stays there:
+    //   * slots 0-11: one fragment read of the SECOND half (the first half's twelve are issued before slot 0);
+    //   * slots 0-41: one seventh of the split of one 16-byte piece of the next block (piece = slot / 7: hi pair; residuals of elements 0,1; of 2,3; mid
+    //     pair + the LDS writes of hi and mid; second residuals x 2; lo pair + its LDS write + the global load that refills the piece's registers).
+    // Every piece's load is thus issued 42 slots before its first use and waited for alone (vmcnt(5)); nothing is left to the scheduler, whose
+    // sched_group_barrier pipelines held for one operand layout and fell apart for the next, or pulled the first instructions of several pieces --
+    // and with them a wait for ALL loads -- to the top of the iteration (docs/history/r05.md).
+    bf16x8 fa[2][2][3], fb[2][2][3];                        // [half c][32-row block][image]
+    unsigned sh0 = 0, sh1 = 0, sm0 = 0, sm1 = 0;             // (the piece being split: packed hi / mid pairs, residuals)
+    float sr0 = 0.f, sr1 = 0.f, sr2 = 0.f, sr3 = 0.f;
+    auto frag_read = [&](auto C_, auto IDX_, x3w_lds ST) __attribute__((always_inline)) {
+        constexpr int C = decltype(C_)::value, IDX = decltype(IDX_)::value, blk = (IDX % 6) / 3, img = IDX % 3;      // 0..5: A; 6..11: B
+        if constexpr (IDX < 6) {
+            if constexpr (LA == LD_ROW) fa[C][blk][img] = x3w_rd128<2048 * blk + img * X3W_AIMG>(ST + (faR + (unsigned)(fsw * C)));
+            else fa[C][blk][img] = x3w_tr<C * 4096 + img * X3W_AIMG>(ST + aA[blk][0], ST + aA[blk][1]);
+        } else {
+            if constexpr (LB == LD_ROW) fb[C][blk][img] = x3w_rd128<2048 * blk + img * X3W_BIMG>(ST + (fbR + (unsigned)(fsw * C)));
+            else fb[C][blk][img] = x3w_tr<C * 4096 + img * X3W_BIMG>(ST + aB[blk][0], ST + aB[blk][1]);
+        }
+    };
+    auto mma = [&](auto N_) __attribute__((always_inline)) {
+        constexpr int n = decltype(N_)::value, c = n / 24, i = ((n % 24) / 6) >> 1, y = ((n % 24) / 6) & 1, pr = n % 6;
+        constexpr int IA[6] = {0, 2, 1, 0, 1, 0}, IB[6] = {2, 0, 1, 1, 0, 0};            // smallest partial products first
+        if (!(X3W_ABL & 4)) acc[i][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][IA[pr]], fb[c][y][IB[pr]], acc[i][y], 0, 0, 0);
+        else { asm volatile("" :: "v"(fa[c][i][IA[pr]]), "v"(fb[c][y][IB[pr]])); }
+    };
+    auto split_step = [&](auto N_, x3w_lds WR, f32x4 (&ea)[4], f32x4 (&eb)[2], bool reload) __attribute__((always_inline)) {
+        constexpr int n = decltype(N_)::value, pc = n / 7, st = n % 7;
+        if constexpr (n < 42) {
+            typedef __attribute__((address_space(3))) u32x2* lp;
+            f32x4& E = [&]() -> f32x4& { if constexpr (pc < 4) return ea[pc]; else return eb[pc - 4]; }();
+            constexpr int IMG = pc < 4 ? X3W_AIMG : X3W_BIMG, OFF = 4096 * (pc < 4 ? pc : pc - 4);
+            const x3w_lds P = WR + (pc < 4 ? wA : wB);
+            if (X3W_ABL & 2) { if constexpr (st == 6) { asm volatile("" :: "v"(E)); if (reload) load_piece(pc, E); } return; }
+            if constexpr (st == 0) {
+                if constexpr (LA == LD_COL && pc < 4) rs[pc >> 1] += E;
+                sh0 = x3_pk(E[0], E[1]); sh1 = x3_pk(E[2], E[3]);
+            } else if constexpr (st == 1) {
+                sr0 = E[0] - __builtin_bit_cast(float, sh0 << 16); sr1 = E[1] - __builtin_bit_cast(float, sh0 & 0xffff0000u);
+            } else if constexpr (st == 2) {
+                sr2 = E[2] - __builtin_bit_cast(float, sh1 << 16); sr3 = E[3] - __builtin_bit_cast(float, sh1 & 0xffff0000u);
+            } else if constexpr (st == 3) {
+                sm0 = x3_pk(sr0, sr1); sm1 = x3_pk(sr2, sr3);
+                *(lp)(P + OFF) = (u32x2){sh0, sh1};
+                *(lp)(P + OFF + IMG) = (u32x2){sm0, sm1};
+            } else if constexpr (st == 4) {
+                sr0 -= __builtin_bit_cast(float, sm0 << 16); sr1 -= __builtin_bit_cast(float, sm0 & 0xffff0000u);
+            } else if constexpr (st == 5) {
+                sr2 -= __builtin_bit_cast(float, sm1 << 16); sr3 -= __builtin_bit_cast(float, sm1 & 0xffff0000u);
+            } else {
+                *(lp)(P + OFF + 2 * IMG) = (u32x2){x3_pk(sr0, sr1), x3_pk(sr2, sr3)};
+                if (reload) load_piece(pc, E);
+            }
+        }
+    };
+    auto iteration = [&](x3w_lds RD, x3w_lds WR, f32x4 (&ea)[4], f32x4 (&eb)[2]) __attribute__((always_inline)) {
+        loader_offsets();
+        x3w_for<12>([&](auto I) __attribute__((always_inline)) { frag_read(std::integral_constant<int, 0>{}, I, RD); });
+        __builtin_amdgcn_sched_barrier(0);
+        x3w_for<48>([&](auto N) __attribute__((always_inline)) {
+            mma(N);
+            if constexpr (decltype(N)::value < 12) frag_read(std::integral_constant<int, 1>{}, N, RD);
+            split_step(N, WR, ea, eb, true);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // (the prologue's split of item 0: all seven steps of all six pieces, no MFMAs)
+    auto split_all = [&](x3w_lds WR, f32x4 (&ea)[4], f32x4 (&eb)[2]) __attribute__((always_inline)) {
+        x3w_for<42>([&](auto N) __attribute__((always_inline)) { split_step(N, WR, ea, eb, true); });
+    };
 
     // One iteration: multiply the block in the stage RD, split the block in (ea, eb) into the stage WR and refill (ea, eb) with the loader's block.
     // first / tail / k0 / kend of the block in (ea, eb) were noted when its loads were issued (F_*), those of the block being loaded go to (N_*).
@@ -364,20 +368,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
 #define X3W_ITER(RD, WR, F, N)                                                                                                \
     {                                                                                                                         \
         __syncthreads();                                                                                                      \
-        if (F##_tail) zero_tail(ea, eb, F##_k0, F##_kend);                                                                    \
+        if (__builtin_expect(F##_tail, 0)) { asm volatile("" ::: "memory"); zero_tail(ea, eb, F##_k0, F##_kend); }   /* (kept a BRANCH: as selects it waits for every load) */ \
         if constexpr (LA == LD_COL) { if (F##_first) hand_over(); }                                                           \
-        {                                                                                                                     \
-            constexpr bool RELOAD = true;                                                                                     \
-            bf16x8 a0[2][3], b0[2][3], a1[2][3], b1[2][3];                                                                    \
-            loader_offsets();                                                                                                 \
-            X3W_FRAGS(0, RD, a0, b0)                                                                                          \
-            X3W_FRAGS(1, RD, a1, b1)                                                                                          \
-            X3W_MMA(a0, b0)                                                                                                   \
-            X3W_MMA(a1, b1)                                                                                                   \
-            if constexpr (LA == LD_COL) { rs[0] += ea[0] + ea[1]; rs[1] += ea[2] + ea[3]; }                                   \
-            X3W_SPLIT(WR)                                                                                                     \
-            X3W_PIPELINE()                                                                                                    \
-        }                                                                                                                     \
+        iteration(RD, WR, ea, eb);                                                                                            \
         N##_tail = l_tail; N##_k0 = l_k0; N##_kend = l_kend; N##_first = l_dup || lkt == 0;                                   \
         loader_step();                                                                                                        \
         if (ckt + 1 == cur.nk) {                                                                                              \
@@ -390,28 +383,26 @@ __global__ __launch_bounds__(512, 2) void gemm_x3w_kernel(GL_DIR_PARAMS, GemmBat
 
     // prologue: item 0 -> stage 0, item 1 -> (ea, eb)
     f32x4 ea[4], eb[2];
-    bool p_tail = false, q_tail = false, p_first = false, q_first = false;
-    int p_k0 = 0, q_k0 = 0, p_kend = 0, q_kend = 0;
+    bool p_tail = false, p_first = false;
+    int p_k0 = 0, p_kend = 0;
     loader_offsets();
 #pragma unroll
     for (int j = 0; j < 4; ++j) load_piece(j, ea[j]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) load_piece(4 + j, eb[j]);
     if (l_tail) zero_tail(ea, eb, l_k0, l_kend);
-    if constexpr (LA == LD_COL) { rs[0] += ea[0] + ea[1]; rs[1] += ea[2] + ea[3]; }
     loader_step();
     loader_offsets();
     p_tail = l_tail; p_k0 = l_k0; p_kend = l_kend; p_first = l_dup || lkt == 0;
-    { constexpr bool RELOAD = true; X3W_SPLIT(S0) }
+    split_all(S0, ea, eb);
     loader_step();
+    // (ONE copy of the iteration, the stage offsets toggling: with the order of every LDS access fixed by hand the compiler needs no proof that the
+    // two stages do not alias; two unrolled copies made it alternate the staging registers between two physical sets in the k-major form, with
+    // conservative vmcnt waits at the top of each copy)
+    unsigned rd = 0;
     for (;;) {
-        X3W_ITER(S0, S1, p, q)
-        X3W_ITER(S1, S0, q, p)
+        X3W_ITER(S0 + rd, S0 + (X3W_STAGE - rd), p, p)
+        rd = X3W_STAGE - rd;
     }
 #undef X3W_ITER
-#undef X3W_PIPELINE
-#undef X3W_SPLIT
-#undef X3W_PIECE
-#undef X3W_MMA
-#undef X3W_FRAGS
 }
