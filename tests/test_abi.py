@@ -70,7 +70,7 @@ def _plan(la, lb, R, Cn, K, lda=None, ldb=None, ldc=None):
     return dict(zip(('engine', 'tile', 'splits', 'kchunk', 'scalar'), (o.value for o in out)))
 
 
-def test_gemm_routing_of_the_path_shapes():
+def test_gemm_routing_of_the_path_shapes(monkeypatch):
     """Host-only routing of the program builder (rlrep_gemm_plan): which engine / tile / split-K plan each layer class of
     the five agents gets.  The split plan must cover the inner dimension exactly once."""
     # the headline configuration's 256-wide layers stay on the latency-tuned 16-row engine
@@ -98,6 +98,10 @@ def test_gemm_routing_of_the_path_shapes():
     assert (p['engine'], p['tile'], p['splits']) == (2, 256, 1)
     # ... and not where they would leave most of a round of workgroups idle: 2048 x 2048 x 2048 = 128 of them
     assert _plan(0, 0, 2048, 2048, 2048)['tile'] == 128
+    # RLREP_DISABLE=x3w keeps those products on the 128-wide tile (tests/test_gemm_engines.py holds both tiles to 2e-6 of float64)
+    monkeypatch.setenv('RLREP_DISABLE', 'x3w')
+    assert _plan(0, 0, 2048, 96256, 512)['tile'] == 128 and _plan(1, 1, 96256, 512, 2048)['tile'] == 128
+    monkeypatch.delenv('RLREP_DISABLE')
     # every plan over a sweep: splits cover K, chunks are multiples of the 32-deep slice, tiles are 64, 128 or 256 (x 128)
     for R in (256, 1000, 2048, 4096):
         for Cn in (256, 520, 2048):

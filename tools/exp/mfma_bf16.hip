@@ -1,6 +1,6 @@
 // Micro-benchmark: sustained v_mfma_f32_32x32x16_bf16 rate (and shader clock) with every SIMD of the chip issuing: the practical ceiling of the bf16x3
 // tiles (six such MFMAs per 32x32x16 fp32 product: ceiling = rate / 6).  Variants: waves per SIMD 1 / 2 / 4, accumulators per wave 1 / 4; with the
-// fragment reads of gemm_x3w.h's loop (12 ds_read_b128 per 24 MFMAs) re-read from LDS or not.
+// fragment reads re-read from LDS or not; operands = small regular values, or (last block) random bf16 -- the chip holds a lower clock for those.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_bf16 tools/exp/mfma_bf16.hip && /tmp/mfma_bf16
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,10 +9,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NACC, bool LDS>
+template <int NACC, bool LDS, bool RAND = false>
 __global__ __launch_bounds__(256) void loop(float* out, int iters, unsigned long long* clk) {
     __shared__ __attribute__((aligned(16))) float lds[8192];
-    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = 1e-3f * i;
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) {
+        if (RAND) {          // two bf16 per word: random sign and mantissa, exponents 124..131 (|x| in 0.125 .. 16): the operands of a real product
+            unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+            const unsigned lo = (h & 0x807fu) | ((124u + ((h >> 20) & 7u)) << 7), hi = ((h >> 16) & 0x807fu) | ((124u + ((h >> 8) & 7u)) << 7);
+            lds[i] = __builtin_bit_cast(float, lo | (hi << 16));
+        } else lds[i] = 1e-3f * i;
+    }
     __syncthreads();
     f32x16 acc[NACC];
 #pragma unroll
@@ -28,8 +34,8 @@ __global__ __launch_bounds__(256) void loop(float* out, int iters, unsigned long
         if (LDS) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                a[m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * m + 512 * (it & 1)));
-                b[m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * (m + 3) + 512 * (it & 1)));
+                a[m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * m + 512 * (it & 3)));
+                b[m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * (m + 3) + 512 * ((it >> 1) & 3)));
             }
         }
 #pragma unroll
@@ -54,21 +60,21 @@ __global__ __launch_bounds__(256) void loop(float* out, int iters, unsigned long
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
 }
 
-template <int NACC, bool LDS>
+template <int NACC, bool LDS, bool RAND = false>
 static int run(float* out, unsigned long long* clk, hipEvent_t e0, hipEvent_t e1, int cus) {
     for (int wps : {1, 2, 4}) {                   // waves per SIMD: blocks of 256 threads (4 waves = one per SIMD), wps blocks per CU
         const int G = cus * wps, iters = 2048;
         float best = 1e9f; unsigned long long h[2] = {0, 0};
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL((loop<NACC, LDS>), dim3(G), dim3(256), 0, 0, out, iters, clk);
+            hipLaunchKernelGGL((loop<NACC, LDS, RAND>), dim3(G), dim3(256), 0, 0, out, iters, clk);
             CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) { best = ms; CK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost)); }
         }
         const double fl = 2.0 * 32 * 32 * 16 * 6.0 * NACC * iters * (double)G * 4;
-        printf("acc %d lds %d waves/SIMD %d: %8.3f ms  %7.1f TF bf16 = %6.1f TF as bf16x3   shader clock %.0f MHz (clock64 %llu / wall %llu x 100 MHz), cycles per MFMA per SIMD %.1f\n",
-               NACC, (int)LDS, wps, best, fl / best / 1e9, fl / best / 1e9 / 6.0, 100.0 * h[0] / (double)h[1], h[0], h[1], (double)h[0] / (6.0 * NACC * iters * wps));
+        printf("acc %d lds %d random operands %d waves/SIMD %d: %8.3f ms  %7.1f TF bf16 = %6.1f TF as bf16x3   shader clock %.0f MHz (clock64 %llu / wall %llu x 100 MHz), cycles per MFMA per SIMD %.1f\n",
+               NACC, (int)LDS, (int)RAND, wps, best, fl / best / 1e9, fl / best / 1e9 / 6.0, 100.0 * h[0] / (double)h[1], h[0], h[1], (double)h[0] / (6.0 * NACC * iters * wps));
     }
     return 0;
 }
@@ -83,5 +89,6 @@ int main() {
     if (run<1, false>(out, clk, e0, e1, cus)) return 1;
     if (run<4, false>(out, clk, e0, e1, cus)) return 1;
     if (run<4, true>(out, clk, e0, e1, cus)) return 1;
+    if (run<4, true, true>(out, clk, e0, e1, cus)) return 1;
     return 0;
 }

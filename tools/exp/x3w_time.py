@@ -10,8 +10,9 @@ BT = int(os.environ.get('BT', 256))
 
 def timeit(mode, R, Cn, K, bt, reps=5, splits=0):
     la, lb = {'fwd': (0, 0), 'dx': (0, 1), 'dw': (1, 1)}[mode]
-    A = torch.randn((K, R) if la else (R, K), device='cuda')
-    B = torch.randn((K, Cn) if lb else (Cn, K), device='cuda')
+    mk = {'randn': torch.randn, 'zeros': torch.zeros, 'ones': torch.ones}[os.environ.get('DATA', 'randn')]          # (operand values decide the matrix pipe's power, and with it the clock)
+    A = mk((K, R) if la else (R, K), device='cuda')
+    B = mk((K, Cn) if lb else (Cn, K), device='cuda')
     C = torch.empty(R, Cn, device='cuda')
     ws = torch.empty(min(32 * R * (Cn + 5), 40_000_000 + 2 * (R + 128) * (Cn + 133)), device='cuda')
     epi = {'fwd': 0, 'dx': 1, 'dw': 3}[mode]
@@ -32,7 +33,7 @@ def timeit(mode, R, Cn, K, bt, reps=5, splits=0):
 
 
 timeit('fwd', 4096, 4096, 4096, BT, reps=30)          # (clocks up before the first measured product)
-line = os.path.basename(os.environ.get('RLREP_LIB', 'product')) + f' bt {BT}:'
+line = os.path.basename(os.environ.get('RLREP_LIB', 'product')) + f' bt {BT} {os.environ.get("DATA", "randn")}:'
 for name, mode, R, Cn, K, sp in (('fwd', 'fwd', 2048, 96256, 512, 0), ('dX', 'dx', 2048, 512, 96256, 16), ('dW', 'dw', 96256, 512, 2048, 0), ('4096 fwd', 'fwd', 4096, 4096, 4096, 0),
                                  ('4096 dW', 'dw', 4096, 4096, 4096, 0)):
     us = timeit(mode, R, Cn, K, BT, splits=sp)
