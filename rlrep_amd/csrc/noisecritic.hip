@@ -1140,29 +1140,12 @@ __global__ __launch_bounds__(512) void nc_dx_x3_kernel(NcDxTask t) {
     const int aofs = m16 * NX_RSB + kq * 16;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L + (unsigned)aofs;
     struct WReg { float v[8]; };
-    // (volatile asm loads, claimed by hand at the top of the step that splits them -- `s_waitcnt vmcnt(8)`: the other set's eight may stay in flight.
-    // As plain loads the SECOND of the loop's two bodies waited with vmcnt(6) .. vmcnt(0), i.e. also for the eight loads the first body had just issued:
-    // the compiler's count is exact at the loop header and too strict one body later, so every other step paid the whole W latency.)
     auto wload = [&](int s, WReg& r) {
         s = min(s, S - 1);
         const int h = s >= SH ? 1 : 0, j0 = 32 * (s - h * SH);
         const float* wp = (h ? t.W[1] : t.W[0]) + (size_t)(j0 + 8 * kq) * F + kcl;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float* p = wp + (size_t)q * F;
-#ifdef NDX_PLAIN_LOADS          /* (A/B build: the loads as the compiler sees them) */
-            r.v[q] = *p;
-#else
-            asm volatile("global_load_dword %0, %1, off" : "=v"(r.v[q]) : "v"(p));
-#endif
-        }
-    };
-    auto wclaim = [&](WReg& r) {
-#ifndef NDX_PLAIN_LOADS
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(r.v[q]));
-#endif
+        for (int q = 0; q < 8; ++q) r.v[q] = wp[(size_t)q * F];
     };
     // epilogue operands (this lane's noise column and log-std): volatile asm loads, older than every load of the loop
     float nzv[20], lsv;
@@ -1188,7 +1171,6 @@ __global__ __launch_bounds__(512) void nc_dx_x3_kernel(NcDxTask t) {
         u32x4 fa[2][3];
         ndx_fload_at<0>(fa[0], aaddr);
         u32x4 bh, bm, bl;
-        wclaim(rw);
         {
             unsigned h, m, l;
 #pragma unroll
