@@ -10,12 +10,15 @@
 //
 // This kernel: eight waves as 4 (rows) x 2 (columns), a wave owns 64 x 64 = four 32x32 accumulators (6 fragment reads and 6 staged elements
 // per 12 MFMAs); TWO LDS stages of 72 KB (three bf16 images of 256 rows of A and of 128 rows of B, 32 deep) and ONE barrier per block.  An
-// iteration is ONE basic block: the 16-byte global loads of block i + 2 (two register sets), the 24 fragment reads of block i, its 48 MFMAs,
-// and between them (sched_group_barrier) the split of block i + 1 and its LDS writes into the other stage.  The workgroup walks its tiles
+// iteration multiplies block i out of one stage while it splits block i + 1 (in the staging registers since the previous iteration) into the
+// other and refills those registers with block i + 2 -- written SLOT BY SLOT (48 MFMAs, each with its share of the rest behind it: see
+// `iteration` below), because no scheduler directive kept that order for all three operand layouts.  The workgroup walks its tiles
 // (index = blockIdx + k * gridDim) as ONE stream of (tile, block) items, so the loads of the next tile's first blocks are in flight during
-// the last blocks of this one and the accumulator stores of a tile drain under the next tile's MFMAs; the tile is stored from the
-// accumulators, a wave-instruction = two whole 128-byte lines (lane = column) -- there is no LDS left for a patch: 2 x 72 KB + the 16 KB of
-// the bias-gradient sums = 160 KB.  Epilogues: forward / dX with no activation, ReLU or ELU, dW (+ bias gradient), split-K slabs.
+// the last blocks of this one; the tile is stored from the accumulators, a wave-instruction = two whole 128-byte lines (lane = column) --
+// there is no LDS left for a patch: 2 x 72 KB + the 16 KB of the bias-gradient sums = 160 KB.  Epilogues: forward / dX with no activation,
+// ReLU or ELU, dW (+ bias gradient), split-K slabs.  207 / 219 / 236 VGPRs (row x row / row x k-major / k-major x k-major), two waves per SIMD.
+// Measured (tools/exp/x3w_check.py, x3w_time.py): the nabla-mu head forward / dX / dW 1 029 / 955 / 997 us (196 / 211 / 202 TF) against 1 535 /
+// 1 105 / 1 149 on the 128 x 128 tiles; 4096^3 615-646 us (213-223 TF) on random operands, 439 us (313 TF) on zeros: the matrix pipe's power.
 // Image layouts are those of the 128 x 128 kernels: row-major operands [row][64 B] with swizzled 16-byte chunks (x3r_off, ds_read_b128),
 // k-major operands [32 k][128 rows] per 128-row half (x3t_off, ds_read_b64_tr_b16).
 // ================================================================================================
@@ -30,21 +33,8 @@
 #define X3W_BIMG (X3W_BN * 64)                       /* bytes per B image */
 #define X3W_STAGE (3 * X3W_AIMG + 3 * X3W_BIMG)      /* 73 728 */
 
-// split four consecutive elements and write them: 8 bytes into each of the three images (p = LDS byte address in image 0)
-// (LDS accesses go through pointers INTO the stage's own __shared__ array, not through integer addresses: the compiler then knows that the
-// fragment reads of one stage and the staging writes of the other cannot alias and is free to interleave them)
+// LDS accesses go through pointers into the kernel's __shared__ arrays (address space 3), byte offsets as immediates
 typedef __attribute__((address_space(3))) unsigned char* x3w_lds;
-template <int IMG, int OFF>
-__device__ __forceinline__ void x3w_split_write(x3w_lds p, const f32x4& e) {
-    typedef __attribute__((address_space(3))) u32x2* lp;
-    u32x2 hi, mid, lo;
-    unsigned h, m, l;
-    x3_split2(e[0], e[1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
-    x3_split2(e[2], e[3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
-    *(lp)(p + OFF) = hi;
-    *(lp)(p + OFF + IMG) = mid;
-    *(lp)(p + OFF + 2 * IMG) = lo;
-}
 template <int OFF> __device__ __forceinline__ bf16x8 x3w_rd128(x3w_lds a) {
     return *(__attribute__((address_space(3))) bf16x8*)(a + OFF);
 }
