@@ -795,34 +795,100 @@ __device__ __forceinline__ f32x4 x3s_shift(const f32x4 x, int d) {
     y[0] = z ? 0.f : y[0]; y[1] = z ? 0.f : y[1]; y[2] = z ? 0.f : y[2]; y[3] = z ? 0.f : y[3];
     return y;
 }
-template <int VEC>
+// (a 16-byte load the compiler does not track: claimed by hand with x3s_claim -- `s_waitcnt vmcnt(4)`, the four loads of the OTHER register set may
+// stay in flight.  Tracked by the compiler, the second of the loop's two unrolled bodies waited with vmcnt(0), i.e. for the loads it had just issued.)
+__device__ __forceinline__ f32x4 x3s_ld16(const float* p) {
+    f32x4 x;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p));
+    return x;
+}
+// PHASE 0: issue the loads, raw, into e.  PHASE 1: what depends on the loaded VALUES -- zero fill of the K tail / the edge, the shift of an unaligned
+// group -- in place, with the same arguments, right before the split.  (Done at load time these selects sat between the loads and the second barrier:
+// every slice waited for the loads it had just issued, whatever the prefetch depth.)
+template <int VEC, int PHASE>
 __device__ __forceinline__ void x3s_load_row(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[8]) {
     const int kc = (threadIdx.x & 7) * 4;
     if constexpr (VEC == 2) {
         const int kl = min(k0 + kc, kend - 4), d = k0 + kc - kl;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
-            const f32x4 x = x3s_shift(*reinterpret_cast<const f32x4u*>(P + (size_t)r * ld + kl), d);
+            if constexpr (PHASE == 0) {
+                const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
+                const f32x4 x = x3s_ld16(P + (size_t)r * ld + kl);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
+                for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
+            } else {
+                const f32x4 x = x3s_shift((f32x4){e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]}, d);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
+            }
         }
     } else if constexpr (VEC == 1) {
         const int k = min(k0 + kc, kend - 4);
         const bool ok = (k0 + kc) < kend;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
+            if constexpr (PHASE == 0) {
+                const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
+                const f32x4 x = x3s_ld16(P + (size_t)r * ld + k);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[4 * j + q] = ok ? x[q] : 0.f;
+                for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[4 * j + q] = ok ? e[4 * j + q] : 0.f;
+            }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* p = P + (size_t)min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1) * ld;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const float y = p[min(k0 + kc + q, kend - 1)]; e[4 * j + q] = (k0 + kc + q) < kend ? y : 0.f; }
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (PHASE == 0) e[4 * j + q] = p[min(k0 + kc + q, kend - 1)];
+                else e[4 * j + q] = (k0 + kc + q) < kend ? e[4 * j + q] : 0.f;
+            }
+        }
+    }
+}
+template <int VEC, int PHASE>
+__device__ __forceinline__ void x3s_load_col(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, f32x4 (&e)[2]) {
+    const int c4 = (int)(threadIdx.x & 15) * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC == 2) {
+        const int il = min(base + c4, lim - 4), d = base + c4 - il;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+            if constexpr (PHASE == 0) {
+                const int k = min(k0 + kk, kend - 1);
+                e[j] = x3s_ld16(P + (size_t)k * ld + il);
+            } else {
+                const f32x4 x = x3s_shift(e[j], d);
+                e[j] = (k0 + kk) < kend ? x : zero;
+            }
+        }
+    } else if constexpr (VEC == 1) {
+        const int i = min(base + c4, lim - 4);
+        const bool iok = (base + c4) < lim;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+            if constexpr (PHASE == 0) {
+                const int k = min(k0 + kk, kend - 1);
+                e[j] = x3s_ld16(P + (size_t)k * ld + i);
+            } else e[j] = (iok && (k0 + kk) < kend) ? e[j] : zero;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = (int)(threadIdx.x >> 4) + 16 * j;
+            const float* p = P + (size_t)min(k0 + kk, kend - 1) * ld;
+            const bool kok = (k0 + kk) < kend;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (PHASE == 0) e[j][q] = p[min(base + c4 + q, lim - 1)];
+                else e[j][q] = (kok && (base + c4 + q) < lim) ? e[j][q] : 0.f;
+            }
         }
     }
 }
@@ -932,10 +998,17 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     f32x4 rs = {0.f, 0.f, 0.f, 0.f};
 
-    float ear[8], ebr[8];
-    f32x4 eac[2], ebc[2];
-    if constexpr (LA == LD_ROW) x3s_load_row<VEC>(pA, lda, r0, R, kbeg, kend, ear); else x3s_load_col<VEC>(pA, lda, r0, R, kbeg, kend, eac);
-    if constexpr (LB == LD_ROW) x3s_load_row<VEC>(pB, ldb, c0, Cn, kbeg, kend, ebr); else x3s_load_col<VEC>(pB, ldb, c0, Cn, kbeg, kend, ebc);
+    // TWO sets of staging registers, loads two slices ahead of their split.  One set (the slice after this one loaded behind the first barrier, split
+    // before the next iteration's: 12 MFMAs = 384 cycles of cover) left a load's whole latency in every slice wherever fewer than four workgroups
+    // share a CU -- the M = 256 layers of ctrlsac, 256-512 workgroups in all: 16-23 us per launch.
+    float ear[2][8], ebr[2][8];
+    f32x4 eac[2][2], ebc[2][2];
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const int kz = kbeg + GL_BK * z;
+        if constexpr (LA == LD_ROW) x3s_load_row<VEC, 0>(pA, lda, r0, R, kz, kend, ear[z]); else x3s_load_col<VEC, 0>(pA, lda, r0, R, kz, kend, eac[z]);
+        if constexpr (LB == LD_ROW) x3s_load_row<VEC, 0>(pB, ldb, c0, Cn, kz, kend, ebr[z]); else x3s_load_col<VEC, 0>(pB, ldb, c0, Cn, kz, kend, ebc[z]);
+    }
 
     unsigned char* const LBi = L + 3 * AIMG;
     const unsigned char* const far = L + x3r_off(wr * 32 + r32, hh);
@@ -944,14 +1017,6 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     const unsigned aA0 = x3s_taddr(Lb, 8 * hh, wr * 4 + 2 * g1), aA1 = x3s_taddr(Lb, 8 * hh + 4, wr * 4 + 2 * g1);
     const unsigned aB0 = x3s_taddr(Lb + 3 * AIMG, 8 * hh, wc * 4 + 2 * g1), aB1 = x3s_taddr(Lb + 3 * AIMG, 8 * hh + 4, wc * 4 + 2 * g1);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        if (want_bias) rs += eac[0] + eac[1];
-        if constexpr (LA == LD_ROW) x3s_write_row(L, ear); else x3s_write_col(L, eac);
-        if constexpr (LB == LD_ROW) x3s_write_row(LBi, ebr); else x3s_write_col(LBi, ebc);
-        __syncthreads();
-        const int kn = kbeg + GL_BK * (kt + 1);
-        if constexpr (LA == LD_ROW) x3s_load_row<VEC>(pA, lda, r0, R, kn, kend, ear); else x3s_load_col<VEC>(pA, lda, r0, R, kn, kend, eac);
-        if constexpr (LB == LD_ROW) x3s_load_row<VEC>(pB, ldb, c0, Cn, kn, kend, ebr); else x3s_load_col<VEC>(pB, ldb, c0, Cn, kn, kend, ebc);
 #define X3S_BLOCK(C)                                                                                                          \
         {                                                                                                                     \
             bf16x8 a[3], b[3];                                                                                                \
@@ -976,10 +1041,37 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
             v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], v, 0, 0, 0);                                              \
             acc = v;                                                                                                          \
         }
-        X3S_BLOCK(0) X3S_BLOCK(1)
-#undef X3S_BLOCK
-        __syncthreads();
+    // one slice: split register set Z into the images, refill the set with the slice two further on, multiply
+#define X3S_SLICE(Z, KT)                                                                                                      \
+    {                                                                                                                         \
+        {                                                                                                                     \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      /* this set's four loads have landed; the other set's may be in flight */ \
+            if constexpr (LA == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ear[Z][q])); }  \
+            else { asm volatile("" : "+v"(eac[Z][0]), "+v"(eac[Z][1])); }                                                     \
+            if constexpr (LB == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ebr[Z][q])); }  \
+            else { asm volatile("" : "+v"(ebc[Z][0]), "+v"(ebc[Z][1])); }                                                     \
+            const int kc = kbeg + GL_BK * (KT);                                                                               \
+            if constexpr (LA == LD_ROW) x3s_load_row<VEC, 1>(pA, lda, r0, R, kc, kend, ear[Z]); else x3s_load_col<VEC, 1>(pA, lda, r0, R, kc, kend, eac[Z]); \
+            if constexpr (LB == LD_ROW) x3s_load_row<VEC, 1>(pB, ldb, c0, Cn, kc, kend, ebr[Z]); else x3s_load_col<VEC, 1>(pB, ldb, c0, Cn, kc, kend, ebc[Z]); \
+        }                                                                                                                     \
+        if (want_bias) rs += eac[Z][0] + eac[Z][1];                                                                           \
+        if constexpr (LA == LD_ROW) x3s_write_row(L, ear[Z]); else x3s_write_col(L, eac[Z]);                                  \
+        if constexpr (LB == LD_ROW) x3s_write_row(LBi, ebr[Z]); else x3s_write_col(LBi, ebc[Z]);                              \
+        __syncthreads();                                                                                                      \
+        const int kn = kbeg + GL_BK * ((KT) + 2);                                                                             \
+        if constexpr (LA == LD_ROW) x3s_load_row<VEC, 0>(pA, lda, r0, R, kn, kend, ear[Z]); else x3s_load_col<VEC, 0>(pA, lda, r0, R, kn, kend, eac[Z]); \
+        if constexpr (LB == LD_ROW) x3s_load_row<VEC, 0>(pB, ldb, c0, Cn, kn, kend, ebr[Z]); else x3s_load_col<VEC, 0>(pB, ldb, c0, Cn, kn, kend, ebc[Z]); \
+        X3S_BLOCK(0) X3S_BLOCK(1)                                                                                             \
+        __syncthreads();                                                                                                      \
     }
+    for (int kt = 0; kt < nk; kt += 2) {
+        X3S_SLICE(0, kt)
+        if (kt + 1 < nk) X3S_SLICE(1, kt + 1)
+    }
+#undef X3S_SLICE
+#undef X3S_BLOCK
+    // (the two prefetches past the last slice are never used -- and must not land in registers the epilogue has reused by then)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (want_bias) {       // row sums of the k-major A: this thread holds rows 4 (tid % 16) .. over its 16 k slots
         float* part = lds;                                   // [64 rows][16 k slots]
