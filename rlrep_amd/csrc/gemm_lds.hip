@@ -1070,8 +1070,18 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     }
 #undef X3S_SLICE
 #undef X3S_BLOCK
-    // (the two prefetches past the last slice are never used -- and must not land in registers the epilogue has reused by then)
+    // The two prefetches past the last slice are never used -- and must not land in registers that hold something else by then: the compiler does not
+    // know these loads are in flight, their outputs are dead on the loop's exit path, so it handed the registers to the epilogue's address arithmetic
+    // at once, and a late load overwrote it (random wrong tiles, only with enough workgroups in flight to make the loads slow).  So: drain, and only
+    // then let the registers die.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        if constexpr (LA == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(ear[z][q])); }
+        else { asm volatile("" :: "v"(eac[z][0]), "v"(eac[z][1])); }
+        if constexpr (LB == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(ebr[z][q])); }
+        else { asm volatile("" :: "v"(ebc[z][0]), "v"(ebc[z][1])); }
+    }
 
     if (want_bias) {       // row sums of the k-major A: this thread holds rows 4 (tid % 16) .. over its 16 k slots
         float* part = lds;                                   // [64 rows][16 k slots]
