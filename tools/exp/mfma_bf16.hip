@@ -79,6 +79,77 @@ static int run(float* out, unsigned long long* clk, hipEvent_t e0, hipEvent_t e1
     return 0;
 }
 
+// the same products on v_mfma_f32_16x16x32_bf16: four 16x16 accumulators per 32x32 one (same flops per loop iteration, same operand bytes)
+template <int NACC, bool RAND>
+__global__ __launch_bounds__(256) void loop16(float* out, int iters, unsigned long long* clk) {
+    __shared__ __attribute__((aligned(16))) float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) {
+        if (RAND) {
+            unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+            const unsigned lo = (h & 0x807fu) | ((124u + ((h >> 20) & 7u)) << 7), hi = ((h >> 16) & 0x807fu) | ((124u + ((h >> 8) & 7u)) << 7);
+            lds[i] = __builtin_bit_cast(float, lo | (hi << 16));
+        } else lds[i] = 1e-3f * i;
+    }
+    __syncthreads();
+    f32x4 acc[NACC][4];
+#pragma unroll
+    for (int f = 0; f < NACC; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[f][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[2][3], b[2][3];
+    const f32x4* L = reinterpret_cast<const f32x4*>(lds) + (threadIdx.x & 63);
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[h][m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * m + 256 * h + 512 * (it & 1)));
+                b[h][m] = __builtin_bit_cast(bf16x8, *(volatile const f32x4*)(L + 64 * (m + 3) + 256 * h + 512 * ((it >> 1) & 1)));
+            }
+#pragma unroll
+        for (int f = 0; f < NACC; ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = acc[f][q];
+                const int i = q >> 1, y = q & 1;
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[y][2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[y][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[y][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[y][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[y][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[y][0], v, 0, 0, 0);
+                acc[f][q] = v;
+            }
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < NACC; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += acc[f][q][0] + acc[f][q][1] + acc[f][q][2] + acc[f][q][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+template <int NACC, bool RAND>
+static int run16(float* out, unsigned long long* clk, hipEvent_t e0, hipEvent_t e1, int cus) {
+    for (int wps : {1, 2, 4}) {
+        const int G = cus * wps, iters = 2048;
+        float best = 1e9f; unsigned long long h[2] = {0, 0};
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((loop16<NACC, RAND>), dim3(G), dim3(256), 0, 0, out, iters, clk);
+            CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) { best = ms; CK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost)); }
+        }
+        const double fl = 2.0 * 16 * 16 * 32 * 6.0 * 4 * NACC * iters * (double)G * 4;
+        printf("16x16x32: acc %d x 4, lds 1 random operands %d waves/SIMD %d: %8.3f ms  %7.1f TF bf16 = %6.1f TF as bf16x3   shader clock %.0f MHz\n",
+               NACC, (int)RAND, wps, best, fl / best / 1e9, fl / best / 1e9 / 6.0, 100.0 * h[0] / (double)h[1]);
+    }
+    return 0;
+}
+
 int main() {
     int dev = 0; hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
     const int cus = pr.multiProcessorCount;
@@ -90,5 +161,7 @@ int main() {
     if (run<4, false>(out, clk, e0, e1, cus)) return 1;
     if (run<4, true>(out, clk, e0, e1, cus)) return 1;
     if (run<4, true, true>(out, clk, e0, e1, cus)) return 1;
+    if (run16<4, false>(out, clk, e0, e1, cus)) return 1;
+    if (run16<4, true>(out, clk, e0, e1, cus)) return 1;
     return 0;
 }
