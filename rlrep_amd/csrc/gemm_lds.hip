@@ -795,48 +795,32 @@ __device__ __forceinline__ f32x4 x3s_shift(const f32x4 x, int d) {
     y[0] = z ? 0.f : y[0]; y[1] = z ? 0.f : y[1]; y[2] = z ? 0.f : y[2]; y[3] = z ? 0.f : y[3];
     return y;
 }
-// (a 16-byte load the compiler does not track: claimed by hand with x3s_claim -- `s_waitcnt vmcnt(4)`, the four loads of the OTHER register set may
-// stay in flight.  Tracked by the compiler, the second of the loop's two unrolled bodies waited with vmcnt(0), i.e. for the loads it had just issued.)
-__device__ __forceinline__ f32x4 x3s_ld16(const float* p) {
-    f32x4 x;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p));
-    return x;
+// (16-byte load of a group that is only 4-byte aligned in the any-alignment forms)
+template <int VEC> __device__ __forceinline__ void x3s_ld16(f32x4& dst, const float* p) {
+    if constexpr (VEC == 2) dst = *reinterpret_cast<const f32x4u*>(p);
+    else dst = *reinterpret_cast<const f32x4*>(p);
 }
 // PHASE 0: issue the loads, raw, into e.  PHASE 1: what depends on the loaded VALUES -- zero fill of the K tail / the edge, the shift of an unaligned
 // group -- in place, with the same arguments, right before the split.  (Done at load time these selects sat between the loads and the second barrier:
 // every slice waited for the loads it had just issued, whatever the prefetch depth.)
 template <int VEC, int PHASE>
-__device__ __forceinline__ void x3s_load_row(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, float (&e)[8]) {
+__device__ __forceinline__ void x3s_load_row(const float* __restrict__ P, int ld, int base, int lim, int k0, int kend, f32x4 (&e)[2]) {
     const int kc = (threadIdx.x & 7) * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if constexpr (VEC == 2) {
         const int kl = min(k0 + kc, kend - 4), d = k0 + kc - kl;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if constexpr (PHASE == 0) {
-                const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
-                const f32x4 x = x3s_ld16(P + (size_t)r * ld + kl);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
-            } else {
-                const f32x4 x = x3s_shift((f32x4){e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]}, d);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
-            }
+            if constexpr (PHASE == 0) x3s_ld16<2>(e[j], P + (size_t)min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1) * ld + kl);
+            else e[j] = x3s_shift(e[j], d);
         }
     } else if constexpr (VEC == 1) {
         const int k = min(k0 + kc, kend - 4);
         const bool ok = (k0 + kc) < kend;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if constexpr (PHASE == 0) {
-                const int r = min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1);
-                const f32x4 x = x3s_ld16(P + (size_t)r * ld + k);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[4 * j + q] = x[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[4 * j + q] = ok ? e[4 * j + q] : 0.f;
-            }
+            if constexpr (PHASE == 0) x3s_ld16<1>(e[j], P + (size_t)min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1) * ld + k);
+            else e[j] = ok ? e[j] : zero;
         }
     } else {
 #pragma unroll
@@ -844,8 +828,8 @@ __device__ __forceinline__ void x3s_load_row(const float* __restrict__ P, int ld
             const float* p = P + (size_t)min(base + (int)(threadIdx.x >> 3) + 32 * j, lim - 1) * ld;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if constexpr (PHASE == 0) e[4 * j + q] = p[min(k0 + kc + q, kend - 1)];
-                else e[4 * j + q] = (k0 + kc + q) < kend ? e[4 * j + q] : 0.f;
+                if constexpr (PHASE == 0) e[j][q] = p[min(k0 + kc + q, kend - 1)];
+                else e[j][q] = (k0 + kc + q) < kend ? e[j][q] : 0.f;
             }
         }
     }
@@ -861,7 +845,7 @@ __device__ __forceinline__ void x3s_load_col(const float* __restrict__ P, int ld
             const int kk = (int)(threadIdx.x >> 4) + 16 * j;
             if constexpr (PHASE == 0) {
                 const int k = min(k0 + kk, kend - 1);
-                e[j] = x3s_ld16(P + (size_t)k * ld + il);
+                x3s_ld16<2>(e[j], P + (size_t)k * ld + il);
             } else {
                 const f32x4 x = x3s_shift(e[j], d);
                 e[j] = (k0 + kk) < kend ? x : zero;
@@ -875,7 +859,7 @@ __device__ __forceinline__ void x3s_load_col(const float* __restrict__ P, int ld
             const int kk = (int)(threadIdx.x >> 4) + 16 * j;
             if constexpr (PHASE == 0) {
                 const int k = min(k0 + kk, kend - 1);
-                e[j] = x3s_ld16(P + (size_t)k * ld + i);
+                x3s_ld16<1>(e[j], P + (size_t)k * ld + i);
             } else e[j] = (iok && (k0 + kk) < kend) ? e[j] : zero;
         }
     } else {
@@ -892,14 +876,14 @@ __device__ __forceinline__ void x3s_load_col(const float* __restrict__ P, int ld
         }
     }
 }
-__device__ __forceinline__ void x3s_write_row(unsigned char* __restrict__ img, const float (&e)[8]) {
+__device__ __forceinline__ void x3s_write_row(unsigned char* __restrict__ img, const f32x4 (&e)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (int)(threadIdx.x >> 3) + 32 * j, kc = (int)(threadIdx.x & 7) * 4;
         u32x2 hi, mid, lo;
         unsigned h, m, l;
-        x3_split2(e[4 * j], e[4 * j + 1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
-        x3_split2(e[4 * j + 2], e[4 * j + 3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        x3_split2(e[j][0], e[j][1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+        x3_split2(e[j][2], e[j][3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
         unsigned char* p = img + x3r_off(row, kc >> 3) + 8 * ((kc >> 2) & 1);
         *reinterpret_cast<u32x2*>(p) = hi;
         *reinterpret_cast<u32x2*>(p + X3S_RIMGB) = mid;
@@ -1001,7 +985,7 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     // TWO sets of staging registers, loads two slices ahead of their split.  One set (the slice after this one loaded behind the first barrier, split
     // before the next iteration's: 12 MFMAs = 384 cycles of cover) left a load's whole latency in every slice wherever fewer than four workgroups
     // share a CU -- the M = 256 layers of ctrlsac, 256-512 workgroups in all: 16-23 us per launch.
-    float ear[2][8], ebr[2][8];
+    f32x4 ear[2][2], ebr[2][2];
     f32x4 eac[2][2], ebc[2][2];
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
@@ -1045,11 +1029,6 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
 #define X3S_SLICE(Z, KT)                                                                                                      \
     {                                                                                                                         \
         {                                                                                                                     \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      /* this set's four loads have landed; the other set's may be in flight */ \
-            if constexpr (LA == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ear[Z][q])); }  \
-            else { asm volatile("" : "+v"(eac[Z][0]), "+v"(eac[Z][1])); }                                                     \
-            if constexpr (LB == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ebr[Z][q])); }  \
-            else { asm volatile("" : "+v"(ebc[Z][0]), "+v"(ebc[Z][1])); }                                                     \
             const int kc = kbeg + GL_BK * (KT);                                                                               \
             if constexpr (LA == LD_ROW) x3s_load_row<VEC, 1>(pA, lda, r0, R, kc, kend, ear[Z]); else x3s_load_col<VEC, 1>(pA, lda, r0, R, kc, kend, eac[Z]); \
             if constexpr (LB == LD_ROW) x3s_load_row<VEC, 1>(pB, ldb, c0, Cn, kc, kend, ebr[Z]); else x3s_load_col<VEC, 1>(pB, ldb, c0, Cn, kc, kend, ebc[Z]); \
@@ -1064,24 +1043,14 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
         X3S_BLOCK(0) X3S_BLOCK(1)                                                                                             \
         __syncthreads();                                                                                                      \
     }
+    // (ONE basic block per pair of slices: with a branch between the two the compiler's wait-count pass waited with vmcnt(0) in the second -- for the
+    // loads the first had just issued.  A slice past the end of an odd chunk multiplies the zeros its own K-tail fill produces.)
     for (int kt = 0; kt < nk; kt += 2) {
         X3S_SLICE(0, kt)
-        if (kt + 1 < nk) X3S_SLICE(1, kt + 1)
+        X3S_SLICE(1, kt + 1)
     }
 #undef X3S_SLICE
 #undef X3S_BLOCK
-    // The two prefetches past the last slice are never used -- and must not land in registers that hold something else by then: the compiler does not
-    // know these loads are in flight, their outputs are dead on the loop's exit path, so it handed the registers to the epilogue's address arithmetic
-    // at once, and a late load overwrote it (random wrong tiles, only with enough workgroups in flight to make the loads slow).  So: drain, and only
-    // then let the registers die.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int z = 0; z < 2; ++z) {
-        if constexpr (LA == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(ear[z][q])); }
-        else { asm volatile("" :: "v"(eac[z][0]), "v"(eac[z][1])); }
-        if constexpr (LB == LD_ROW) { _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(ebr[z][q])); }
-        else { asm volatile("" :: "v"(ebc[z][0]), "v"(ebc[z][1])); }
-    }
 
     if (want_bias) {       // row sums of the k-major A: this thread holds rows 4 (tid % 16) .. over its 16 k slots
         float* part = lds;                                   // [64 rows][16 k slots]

@@ -207,8 +207,9 @@ def test_bf16x3_64_wide_tile_is_fp32_accurate(mode):
     check(2, mode, 200, 128, 1024, bt=64, splits=3, seed=44, accum=(mode != 'fwd'))
     check(2, mode, 128, 192, 708, bt=64, splits=7, seed=45)
     check(2, mode, 256, 1024, 2048, bt=64, act='elu' if mode != 'dw' else 'none', seed=46)        # a ctrlsac layer, the planner's own split
-    # 320 workgroups, every split ONE 32-deep slice (its two prefetches past the end are never used: they must have landed before their registers are
-    # reused -- round 5 found random wrong tiles here), and diffsrsac's dX at HalfCheetah dims whose last split is one slice (the planner's own plan)
+    # 320 workgroups, every split ONE 32-deep slice (the tile prefetches two slices ahead: what it loads past the end must never reach the result --
+    # an asm-load form of the prefetch produced random wrong tiles here in round 5), and diffsrsac's dX at HalfCheetah dims whose last split is one
+    # slice (the planner's own plan)
     for rep in range(3):
         check(2, mode, 256, 512, 320, bt=64, splits=10, seed=48 + rep)
     check(2, mode, 256, 512, 4352, bt=64, seed=51)
