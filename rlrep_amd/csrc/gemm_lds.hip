@@ -944,16 +944,20 @@ __device__ __forceinline__ unsigned x3s_taddr(unsigned lds_base, int kq, int chu
 }
 
 template <int LA, int LB, int VEC>
-__global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBatch gb) {
+__global__ __launch_bounds__(256, 3) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBatch gb) {      // (48 KB of LDS: three workgroups per CU)
     const int gdir[GEMM_MAX_TASKS] = {d0, d1, d2, d3, d4, d5, d6, d7};
     constexpr int BT = 64;
     constexpr int AIMG = LA == LD_ROW ? X3S_RIMGB : X3S_TIMGB, BIMG = LB == LD_ROW ? X3S_RIMGB : X3S_TIMGB;
     constexpr int EPB = 4 * 32 * 36 * 4;                         // epilogue patches [32][36] per wave, bytes
     constexpr int STB = 3 * AIMG + 3 * BIMG;
-    constexpr int LDSB = EPB > STB ? EPB : STB;
-    __shared__ __attribute__((aligned(16))) float lds[LDSB / 4];
-    unsigned char* const L = reinterpret_cast<unsigned char*>(lds);
-    const unsigned Lb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L;
+    static_assert(EPB <= STB, "the epilogue patches live in stage 0");
+    // TWO LDS stages (two arrays: the compiler then knows that the fragment reads of one and the staging writes of the other do not alias), ONE
+    // barrier per slice: slice kt is multiplied out of one stage while slice kt + 1 is split into the other.
+    __shared__ __attribute__((aligned(16))) float lds[STB / 4], lds1[STB / 4];
+    unsigned char* const L0 = reinterpret_cast<unsigned char*>(lds);
+    unsigned char* const L1 = reinterpret_cast<unsigned char*>(lds1);
+    const unsigned Lb0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L0;
+    const unsigned Lb1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)L1;
 
     const int bid = blockIdx.x;
     int ti = 0;
@@ -982,39 +986,49 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     f32x4 rs = {0.f, 0.f, 0.f, 0.f};
 
-    // TWO sets of staging registers, loads two slices ahead of their split.  One set (the slice after this one loaded behind the first barrier, split
-    // before the next iteration's: 12 MFMAs = 384 cycles of cover) left a load's whole latency in every slice wherever fewer than four workgroups
-    // share a CU -- the M = 256 layers of ctrlsac, 256-512 workgroups in all: 16-23 us per launch.
+    // TWO sets of staging registers, loads two slices ahead of their split: set z holds the slices of parity z.  (One set, loaded behind the barrier
+    // and split before the next one, left a load's whole latency in every slice wherever fewer than four workgroups share a CU.)
     f32x4 ear[2][2], ebr[2][2];
     f32x4 eac[2][2], ebc[2][2];
-#pragma unroll
-    for (int z = 0; z < 2; ++z) {
-        const int kz = kbeg + GL_BK * z;
-        if constexpr (LA == LD_ROW) x3s_load_row<VEC, 0>(pA, lda, r0, R, kz, kend, ear[z]); else x3s_load_col<VEC, 0>(pA, lda, r0, R, kz, kend, eac[z]);
-        if constexpr (LB == LD_ROW) x3s_load_row<VEC, 0>(pB, ldb, c0, Cn, kz, kend, ebr[z]); else x3s_load_col<VEC, 0>(pB, ldb, c0, Cn, kz, kend, ebc[z]);
+#define X3S_LOAD(Z, KS)                                                                                                       \
+    {                                                                                                                         \
+        const int kz_ = kbeg + GL_BK * (KS);                                                                                  \
+        if constexpr (LA == LD_ROW) x3s_load_row<VEC, 0>(pA, lda, r0, R, kz_, kend, ear[Z]); else x3s_load_col<VEC, 0>(pA, lda, r0, R, kz_, kend, eac[Z]); \
+        if constexpr (LB == LD_ROW) x3s_load_row<VEC, 0>(pB, ldb, c0, Cn, kz_, kend, ebr[Z]); else x3s_load_col<VEC, 0>(pB, ldb, c0, Cn, kz_, kend, ebc[Z]); \
     }
+    // what depends on the loaded values (K tail / edge zero fill, unaligned shift), then split set Z = slice KS into the stage at LW
+#define X3S_SPLIT(Z, KS, LW)                                                                                                  \
+    {                                                                                                                         \
+        const int kz_ = kbeg + GL_BK * (KS);                                                                                  \
+        if constexpr (LA == LD_ROW) x3s_load_row<VEC, 1>(pA, lda, r0, R, kz_, kend, ear[Z]); else x3s_load_col<VEC, 1>(pA, lda, r0, R, kz_, kend, eac[Z]); \
+        if constexpr (LB == LD_ROW) x3s_load_row<VEC, 1>(pB, ldb, c0, Cn, kz_, kend, ebr[Z]); else x3s_load_col<VEC, 1>(pB, ldb, c0, Cn, kz_, kend, ebc[Z]); \
+        if (want_bias) rs += eac[Z][0] + eac[Z][1];                                                                           \
+        if constexpr (LA == LD_ROW) x3s_write_row(LW, ear[Z]); else x3s_write_col(LW, eac[Z]);                                \
+        if constexpr (LB == LD_ROW) x3s_write_row((LW) + 3 * AIMG, ebr[Z]); else x3s_write_col((LW) + 3 * AIMG, ebc[Z]);      \
+    }
+    X3S_LOAD(0, 0) X3S_LOAD(1, 1)
+    X3S_SPLIT(0, 0, L0)
+    X3S_LOAD(0, 2)
 
-    unsigned char* const LBi = L + 3 * AIMG;
-    const unsigned char* const far = L + x3r_off(wr * 32 + r32, hh);
-    const unsigned char* const fbr = LBi + x3r_off(wc * 32 + r32, hh);
+    const int foA = x3r_off(wr * 32 + r32, hh), foB = 3 * AIMG + x3r_off(wc * 32 + r32, hh);
     const int fsw = x3r_off(r32, 2 + hh) - x3r_off(r32, hh);            // block 1 relative to block 0 (swizzled chunks)
-    const unsigned aA0 = x3s_taddr(Lb, 8 * hh, wr * 4 + 2 * g1), aA1 = x3s_taddr(Lb, 8 * hh + 4, wr * 4 + 2 * g1);
-    const unsigned aB0 = x3s_taddr(Lb + 3 * AIMG, 8 * hh, wc * 4 + 2 * g1), aB1 = x3s_taddr(Lb + 3 * AIMG, 8 * hh + 4, wc * 4 + 2 * g1);
+    const unsigned tA0 = x3s_taddr(0, 8 * hh, wr * 4 + 2 * g1), tA1 = x3s_taddr(0, 8 * hh + 4, wr * 4 + 2 * g1);
+    const unsigned tB0 = x3s_taddr(3 * AIMG, 8 * hh, wc * 4 + 2 * g1), tB1 = x3s_taddr(3 * AIMG, 8 * hh + 4, wc * 4 + 2 * g1);
 
-#define X3S_BLOCK(C)                                                                                                          \
+#define X3S_BLOCK(C, LR, LBR)                                                                                                 \
         {                                                                                                                     \
             bf16x8 a[3], b[3];                                                                                                \
             if constexpr (LA == LD_ROW) {                                                                                     \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>(far + m * X3S_RIMGB + fsw * (C)); \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const bf16x8*>((LR) + foA + m * X3S_RIMGB + fsw * (C)); \
             } else {                                                                                                          \
-                a[0] = x3t_frag<(C) * 2048>(aA0, aA1); a[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>(aA0, aA1);                      \
-                a[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>(aA0, aA1);                                                        \
+                a[0] = x3t_frag<(C) * 2048>((LBR) + tA0, (LBR) + tA1); a[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>((LBR) + tA0, (LBR) + tA1); \
+                a[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>((LBR) + tA0, (LBR) + tA1);                                         \
             }                                                                                                                 \
             if constexpr (LB == LD_ROW) {                                                                                     \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) b[m] = *reinterpret_cast<const bf16x8*>(fbr + m * X3S_RIMGB + fsw * (C)); \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) b[m] = *reinterpret_cast<const bf16x8*>((LR) + foB + m * X3S_RIMGB + fsw * (C)); \
             } else {                                                                                                          \
-                b[0] = x3t_frag<(C) * 2048>(aB0, aB1); b[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>(aB0, aB1);                      \
-                b[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>(aB0, aB1);                                                        \
+                b[0] = x3t_frag<(C) * 2048>((LBR) + tB0, (LBR) + tB1); b[1] = x3t_frag<(C) * 2048 + X3S_TIMGB>((LBR) + tB0, (LBR) + tB1); \
+                b[2] = x3t_frag<(C) * 2048 + 2 * X3S_TIMGB>((LBR) + tB0, (LBR) + tB1);                                         \
             }                                                                                                                 \
             f32x16 v = acc;                                                                                                   \
             v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], v, 0, 0, 0);                                              \
@@ -1025,32 +1039,25 @@ __global__ __launch_bounds__(256, 4) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
             v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], v, 0, 0, 0);                                              \
             acc = v;                                                                                                          \
         }
-    // one slice: split register set Z into the images, refill the set with the slice two further on, multiply
-#define X3S_SLICE(Z, KT)                                                                                                      \
+    // one slice: multiply slice KT out of the stage LR while set Z (slice KT + 1) is split into LW and refilled with slice KT + 3
+#define X3S_ITER(Z, KT, LR, LBR, LW)                                                                                          \
     {                                                                                                                         \
-        {                                                                                                                     \
-            const int kc = kbeg + GL_BK * (KT);                                                                               \
-            if constexpr (LA == LD_ROW) x3s_load_row<VEC, 1>(pA, lda, r0, R, kc, kend, ear[Z]); else x3s_load_col<VEC, 1>(pA, lda, r0, R, kc, kend, eac[Z]); \
-            if constexpr (LB == LD_ROW) x3s_load_row<VEC, 1>(pB, ldb, c0, Cn, kc, kend, ebr[Z]); else x3s_load_col<VEC, 1>(pB, ldb, c0, Cn, kc, kend, ebc[Z]); \
-        }                                                                                                                     \
-        if (want_bias) rs += eac[Z][0] + eac[Z][1];                                                                           \
-        if constexpr (LA == LD_ROW) x3s_write_row(L, ear[Z]); else x3s_write_col(L, eac[Z]);                                  \
-        if constexpr (LB == LD_ROW) x3s_write_row(LBi, ebr[Z]); else x3s_write_col(LBi, ebc[Z]);                              \
         __syncthreads();                                                                                                      \
-        const int kn = kbeg + GL_BK * ((KT) + 2);                                                                             \
-        if constexpr (LA == LD_ROW) x3s_load_row<VEC, 0>(pA, lda, r0, R, kn, kend, ear[Z]); else x3s_load_col<VEC, 0>(pA, lda, r0, R, kn, kend, eac[Z]); \
-        if constexpr (LB == LD_ROW) x3s_load_row<VEC, 0>(pB, ldb, c0, Cn, kn, kend, ebr[Z]); else x3s_load_col<VEC, 0>(pB, ldb, c0, Cn, kn, kend, ebc[Z]); \
-        X3S_BLOCK(0) X3S_BLOCK(1)                                                                                             \
-        __syncthreads();                                                                                                      \
+        X3S_SPLIT(Z, (KT) + 1, LW)                                                                                            \
+        X3S_LOAD(Z, (KT) + 3)                                                                                                 \
+        X3S_BLOCK(0, LR, LBR) X3S_BLOCK(1, LR, LBR)                                                                           \
     }
     // (ONE basic block per pair of slices: with a branch between the two the compiler's wait-count pass waited with vmcnt(0) in the second -- for the
     // loads the first had just issued.  A slice past the end of an odd chunk multiplies the zeros its own K-tail fill produces.)
     for (int kt = 0; kt < nk; kt += 2) {
-        X3S_SLICE(0, kt)
-        X3S_SLICE(1, kt + 1)
+        X3S_ITER(1, kt, L0, Lb0, L1)
+        X3S_ITER(0, kt + 1, L1, Lb1, L0)
     }
-#undef X3S_SLICE
+#undef X3S_ITER
 #undef X3S_BLOCK
+#undef X3S_SPLIT
+#undef X3S_LOAD
+    __syncthreads();                                             // (the epilogue's patches and the bias sums reuse stage 0)
 
     if (want_bias) {       // row sums of the k-major A: this thread holds rows 4 (tid % 16) .. over its 16 k slots
         float* part = lds;                                   // [64 rows][16 k slots]
