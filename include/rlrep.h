@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RLREP_ABI_VERSION 3      /* 3: rlrep_comm_* = the shared gradient arena (exchange inside the optimizer launches), rlrep_front_end_counts */
+#define RLREP_ABI_VERSION 4      /* 4: exchange scratch + reduced region in the comm block (two-shot, batch-coupled exchanges inside the launches), rlrep_comm_connect_local, time-bounded waits; dims.world_size, layout_info.exchange_floats */
 
 typedef enum {
     RLREP_OK = 0,
@@ -78,7 +78,8 @@ typedef struct {
     int32_t max_batch;         /* largest batch size this agent will be stepped with */
     int32_t rank;              /* data-parallel rank of this replica (0 when world_size == 1) */
     int32_t flags;             /* RLREP_FLAG_* */
-    int32_t reserved[1];
+    int32_t world_size;        /* data-parallel replicas the WORKSPACE is sized for (0 / 1: one; must equal hyper.world_size when > 1): ctrlsac's score
+                                  matrix is [B, world * B], and an attached agent (rlrep_comm_attach) keeps its deferred step programs */
 } rlrep_dims;
 
 /* vlsac / ctrlsac / spedersac constructed with use_feature_target=False (vlsac_agent.py:113-114,176-179,214-219,257-258;
@@ -131,6 +132,7 @@ typedef struct {
     int64_t group_floats[4];
     int32_t n_tensors;
     int32_t n_metrics;
+    int64_t exchange_floats;   /* exchange scratch (rlrep_comm_create) that moves the agent's batch-coupled feature exchanges into its launches (0: none) */
 } rlrep_layout_info;
 
 #define RLREP_GRAD_TAIL 256
@@ -336,29 +338,44 @@ const float* rlrep_metrics_dev(rlrep_agent* agent);
 /* Profiling hook: launch stage `stage` of step program `program` once (0 feature_bwd, 1 feature_apply,
  * 2 critic_bwd, 3 critic_apply, 4 actor_bwd, 5 actor_apply, 6 update_target); its inputs are whatever the
  * previous full step left in the workspace.  rlrep_stage_count/_name enumerate the stages. */
-/* ---- data-parallel gradient exchange inside the optimizer launches (csrc/comm.hip, csrc/dp_pull.h) ----------
- * The reference is one process: no counterpart.  The exchange belongs between its `loss.backward()` and `optimizer.step()` pairs
- * (agent/vlsac/vlsac_agent.py:153-154, 183-184, 229-230; ctrlsac_agent.py:243-244; spedersac_agent.py:211-212; diffsrsac_agent.py:311-314).
- * A comm owns ONE block of device memory, [arena_floats floats | flag words], exported over hipIpc and mapped by every peer: the caller
- * passes rlrep_comm_arena() as rlrep_arenas.grad_dev, so every rank's gradients lie where every peer can read them.  Lifecycle, identical on
- * every rank: create -> handle -> (exchange the handles, world x rlrep_comm_handle_bytes() in rank order, by any means:
- * torch.distributed.all_gather_object) -> connect -> rlrep_agent_create(..., grad_dev = rlrep_comm_arena()) -> attach.  After rlrep_comm_attach
- * the optimizer launch of every attached group (rlrep_*_apply, the fused *_step entry points, the deferred chain) waits -- bounded -- for the
- * peers' gradients of that step, sums every rank's gradient of its elements IN RANK ORDER (bit-identical on every rank) and does not end
- * before every peer has read this rank's: ZERO launches per all-reduce, nothing on the host changes between calls (hipGraph-capturable), and
- * the caller issues NO collective for those groups.  Groups above max_floats stay with the caller's all-reduce between backward and apply.
- * rlrep_comm_allreduce is the same exchange as one stand-alone launch (probe / tests).  A wait that runs out sets a bit of the error word and
- * proceeds (launches always drain; the step is invalid): rlrep_comm_status reads that word from mapped host memory WITHOUT synchronising. */
+/* ---- data-parallel exchanges inside the launches (csrc/comm.hip, csrc/dp_pull.h) ---------------------------
+ * The reference is one process: no counterpart.  The gradient exchange belongs between its `loss.backward()` and `optimizer.step()` pairs
+ * (agent/vlsac/vlsac_agent.py:153-154, 183-184, 229-230; ctrlsac_agent.py:243-244; spedersac_agent.py:211-212; diffsrsac_agent.py:311-314), the
+ * batch-coupled ones inside the feature losses (spedersac_agent.py:197-205: Phibar and v over the global batch; ctrlsac_agent.py:226-231: in-batch
+ * negatives over the global batch).
+ * A comm owns ONE block of device memory, [arena_floats | scratch_floats | reduced region (world >= 3) | flag words], exported over hipIpc and
+ * mapped by every peer: the caller passes rlrep_comm_arena() as rlrep_arenas.grad_dev, so every rank's gradients lie where every peer can read
+ * them.  Lifecycle, identical on every rank: create -> handle -> (exchange the handles, world x rlrep_comm_handle_bytes() in rank order, by any
+ * means: torch.distributed.all_gather_object) -> connect -> rlrep_agent_create(..., grad_dev = rlrep_comm_arena()) -> attach.  (Several ranks in
+ * ONE process -- the loopback form of tools/exp/dp_loopback.py and tests -- skip handle / connect and call rlrep_comm_connect_local.)
+ * After rlrep_comm_attach the optimizer launch of every attached group (rlrep_*_apply, the fused *_step entry points, the deferred chain)
+ * waits -- bounded -- for the peers' gradients of that step, sums every rank's gradient of its elements IN RANK ORDER (bit-identical on every
+ * rank; one-shot pull, or reduce-scatter + all-gather inside the same launch for slices of at least two_shot_floats when world >= 3) and does
+ * not end before every peer has read this rank's: ZERO launches per all-reduce, nothing on the host changes between calls (hipGraph-capturable),
+ * and the caller issues NO collective for those groups.  Groups above max_floats stay with the caller's all-reduce between backward and apply.
+ * With scratch_floats >= rlrep_layout_info.exchange_floats the batch-coupled exchanges move into the step programs too (spedersac: pushed by the
+ * column-sum launches, summed by their consumers, no launch; ctrlsac: one pull launch each) and rlrep_feature_exchange_count() drops to 0.
+ * rlrep_comm_allreduce / _allgather are the same exchanges as stand-alone launches (probe / tests).  A wait that runs out (rlrep_comm_set_timeout;
+ * default 120 s: a watchdog) sets a bit of the error word; the launch applies NOTHING and drains: rlrep_comm_status reads that word from mapped
+ * host memory WITHOUT synchronising. */
 typedef struct rlrep_comm rlrep_comm;
-int32_t rlrep_comm_create(int32_t rank, int32_t world, int64_t arena_floats, rlrep_comm** out);
+int32_t rlrep_comm_create(int32_t rank, int32_t world, int64_t arena_floats, int64_t scratch_floats, rlrep_comm** out);
 float* rlrep_comm_arena(rlrep_comm* comm);
+float* rlrep_comm_scratch(rlrep_comm* comm);
 int32_t rlrep_comm_handle_bytes(void);
 int32_t rlrep_comm_handle(rlrep_comm* comm, void* out, int32_t cap);
 int32_t rlrep_comm_connect(rlrep_comm* comm, const void* handles);
-int32_t rlrep_comm_attach(rlrep_agent* agent, rlrep_comm* comm, int64_t max_floats, int32_t* attached_mask);
-int32_t rlrep_comm_allreduce(rlrep_comm* comm, int64_t arena_offset_floats, int64_t n, float* out_dev, int64_t timeout_spins, void* stream);
+int32_t rlrep_comm_connect_local(rlrep_comm* comm, rlrep_comm* const* peers);
+int32_t rlrep_comm_set_timeout(rlrep_comm* comm, int64_t timeout_us);
+int32_t rlrep_comm_attach(rlrep_agent* agent, rlrep_comm* comm, int64_t max_floats, int64_t two_shot_floats, int32_t* attached_mask);
+int32_t rlrep_comm_allreduce(rlrep_comm* comm, int64_t block_offset_floats, int64_t n, float* out_dev, int32_t mode, int64_t timeout_us, void* stream);
+int32_t rlrep_comm_allgather(rlrep_comm* comm, int64_t block_offset_floats, int64_t n_per_rank, void* stream);
+int32_t rlrep_comm_probe_fill(rlrep_comm* comm, int64_t block_offset_floats, int64_t n, int32_t round, void* stream);
+float rlrep_comm_probe_value(int32_t rank, int32_t round, int64_t i);
 int32_t rlrep_comm_status(rlrep_comm* comm, uint32_t* late_mask, int32_t clear);
 int32_t rlrep_comm_fine_grained(rlrep_comm* comm);
+/* debug / measurement only: mark every peer as arrived for the NEXT epoch of `channel` in this rank's flags (one stream then plays several ranks in turn) */
+int32_t rlrep_comm_debug_preset(rlrep_comm* comm, int32_t channel);
 void rlrep_comm_destroy(rlrep_comm* comm);
 
 /* vlsac noise-critic weight images (bf16x3 shadows of critic.l1 / l4 and their targets; no reference counterpart: nn.Linear has no such

@@ -23,8 +23,7 @@ FLAG_NO_FEATURE_TARGET = 1
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'alg', 'state_dim', 'action_dim', 'hidden_dim', 'actor_hidden_dim', 'feature_dim', 'vae_hidden_dim',
-        'phi_hidden_dim', 'phi_hidden_depth', 'mu_hidden_dim', 'mu_hidden_depth', 'num_noise', 'max_batch', 'rank', 'flags')] + \
-        [('reserved', C.c_int32 * 1)]
+        'phi_hidden_dim', 'phi_hidden_depth', 'mu_hidden_dim', 'mu_hidden_depth', 'num_noise', 'max_batch', 'rank', 'flags', 'world_size')]
 
 
 class Hyper(C.Structure):
@@ -44,7 +43,7 @@ class TensorDesc(C.Structure):
 class LayoutInfo(C.Structure):
     _fields_ = [('param_floats', C.c_int64), ('target_floats', C.c_int64), ('grad_floats', C.c_int64),
                 ('workspace_bytes', C.c_int64), ('group_offset', C.c_int64 * 4), ('group_floats', C.c_int64 * 4),
-                ('n_tensors', C.c_int32), ('n_metrics', C.c_int32)]
+                ('n_tensors', C.c_int32), ('n_metrics', C.c_int32), ('exchange_floats', C.c_int64)]
 
 
 class Arenas(C.Structure):
@@ -123,15 +122,22 @@ def _load():
         'rlrep_images_managed': (i32, [vp, i32]),
         'rlrep_refresh_images': (i32, [vp, vp]),
         'rlrep_feature_chain_next': (i32, [vp]),
-        'rlrep_comm_create': (i32, [i32, i32, i64, P(vp)]),
+        'rlrep_comm_create': (i32, [i32, i32, i64, i64, P(vp)]),
         'rlrep_comm_handle_bytes': (i32, []),
         'rlrep_comm_handle': (i32, [vp, vp, i32]),
         'rlrep_comm_connect': (i32, [vp, vp]),
+        'rlrep_comm_connect_local': (i32, [vp, P(vp)]),
+        'rlrep_comm_set_timeout': (i32, [vp, i64]),
         'rlrep_comm_arena': (vp, [vp]),
-        'rlrep_comm_attach': (i32, [vp, vp, i64, P(i32)]),
-        'rlrep_comm_allreduce': (i32, [vp, i64, i64, vp, i64, vp]),
+        'rlrep_comm_scratch': (vp, [vp]),
+        'rlrep_comm_attach': (i32, [vp, vp, i64, i64, P(i32)]),
+        'rlrep_comm_allreduce': (i32, [vp, i64, i64, vp, i32, i64, vp]),
+        'rlrep_comm_allgather': (i32, [vp, i64, i64, vp]),
+        'rlrep_comm_probe_fill': (i32, [vp, i64, i64, i32, vp]),
+        'rlrep_comm_probe_value': (f32, [i32, i32, i64]),
         'rlrep_comm_status': (i32, [vp, P(C.c_uint32), i32]),
         'rlrep_comm_fine_grained': (i32, [vp]),
+        'rlrep_comm_debug_preset': (i32, [vp, i32]),
         'rlrep_comm_destroy': (None, [vp]),
         'rlrep_stage_count': (i32, [vp, i32]),
         'rlrep_stage_name': (C.c_char_p, [vp, i32, i32]),
@@ -153,7 +159,7 @@ def _load():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.rlrep_abi_version() != 3:
+    if lib.rlrep_abi_version() != 4:
         raise RuntimeError('librlrep_hip.so ABI version mismatch')
     return lib, sig
 

@@ -74,16 +74,19 @@ class ArenaModule(nn.Module):
 _STREAM_PAIR = {}
 
 
-def _concurrent_stream_pair(core):
-    """Two torch streams that really run side by side.  ROCm maps HIP streams onto a handful of hardware queues (4 by default) and
-    two streams that share one are serialised -- measured here: the same two launch chains overlapped 1.8x or 1.00x depending only on
-    which streams they were given.  So candidates are TIMED: two short kernel chains back to back on one stream against one chain on
-    each stream of a pair; the first pair that overlaps is kept for the life of the process."""
+def _concurrent_stream_pair(core, index=0):
+    """Two torch streams that really run side by side.  ROCm maps HIP streams onto a handful of hardware queues (4 by default; this package
+    asks for 16) and two streams that share one are serialised -- measured here: the same two launch chains overlapped 1.8x or 1.00x
+    depending only on which streams they were given.  So candidates are TIMED: two short kernel chains back to back on one stream against
+    one chain on each stream of a pair; streams that overlap with every stream kept so far are kept for the life of the process.
+    index > 0 (several replicas inside one process: the loopback form of rlrep_amd/comm.py): pair `index` of a set whose members are ALL
+    mutually concurrent -- a replica's optimizer launch waits on the device for its peers', which must not be queued behind it."""
     dev = core.device
-    if dev in _STREAM_PAIR:
-        return _STREAM_PAIR[dev]
+    kept = _STREAM_PAIR.setdefault(dev, [])
+    need = 2 * (index + 1)
+    if len(kept) >= need:
+        return kept[2 * index], kept[2 * index + 1]
     import time
-    cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
     bufs = [torch.empty(1 << 21, device=dev) for _ in range(2)]
 
     def chain(k):
@@ -100,25 +103,37 @@ def _concurrent_stream_pair(core):
             best = min(best, time.perf_counter() - t0)
         return best
 
+    first = kept[0] if kept else torch.cuda.Stream(device=dev)
+
     def serial():
-        with torch.cuda.stream(cands[0]):
+        with torch.cuda.stream(first):
             chain(0); chain(1)
 
     serial()
     t_seq = timed(serial)
-    pair = (cands[0], cands[1])
-    for i in range(len(cands)):
-        for j in range(i + 1, len(cands)):
-            def both(a=cands[i], b=cands[j]):
+    if not kept:
+        kept.append(first)
+    tried = 0
+    while len(kept) < need and tried < 24:
+        cand = torch.cuda.Stream(device=dev)
+        tried += 1
+        ok = True
+        for other in kept:
+            def both(a=other, b=cand):
                 with torch.cuda.stream(a):
                     chain(0)
                 with torch.cuda.stream(b):
                     chain(1)
-            if timed(both) < 0.72 * t_seq:
-                _STREAM_PAIR[dev] = (cands[i], cands[j])
-                return _STREAM_PAIR[dev]
-    _STREAM_PAIR[dev] = pair            # nothing overlapped (single hardware queue?): still correct, just not concurrent
-    return pair
+            if not timed(both) < 0.72 * t_seq:
+                ok = False
+                break
+        if ok:
+            kept.append(cand)
+    while len(kept) < need:            # nothing (more) overlapped (single hardware queue?): still correct for ONE replica, just not concurrent
+        if index > 0:
+            raise RuntimeError('rlrep_amd: could not find %d mutually concurrent HIP streams for the loopback replicas (GPU_MAX_HW_QUEUES?)' % need)
+        kept.append(torch.cuda.Stream(device=dev))
+    return kept[2 * index], kept[2 * index + 1]
 
 
 def _world():
@@ -167,6 +182,10 @@ class SACAgent(object):
     def _finish_init(self, hip_kwargs):
         self.max_batch = int(hip_kwargs.get('max_batch', os.environ.get('RLREP_MAX_BATCH', 256)))
         self.world_size, self.rank = _world()
+        # loopback=(LoopbackGroup, rank): this agent is one of several replicas inside ONE process (rlrep_amd/comm.py; tools/exp/dp_loopback.py, tests)
+        self._loopback = hip_kwargs.get('loopback')
+        if self._loopback is not None:
+            self.world_size, self.rank = self._loopback[0].world, int(self._loopback[1])
         dims = dict(feature_dim=0, vae_hidden_dim=0, phi_hidden_dim=0, phi_hidden_depth=0, mu_hidden_dim=0,
                     mu_hidden_depth=0, num_noise=0, max_batch=self.max_batch, flags=0)
         dims.update(self._dims)
@@ -176,10 +195,17 @@ class SACAgent(object):
                      target_update_period=self.target_update_period,
                      extra_feature_steps=int(self.extra_feature_steps), learn_alpha=int(self.learnable_temperature))
         hyper.update({k: float(v) for k, v in self._hyper.items()})
-        self.core = HipCore(self.ALG, dims, hyper, world_size=self.world_size)
+        self.core = HipCore(self.ALG, dims, hyper, world_size=self.world_size, loopback=self._loopback)
         self.core.alpha_state[0] = float(np.log(self._alpha0))      # quirk Q1: float64 log_alpha
         self._init_parameters()
-        if self.world_size > 1:
+        if self._loopback is not None:
+            grp = self._loopback[0]
+            if self.rank == 0:
+                grp.reference_core = self.core
+            else:
+                for name in ('params', 'targets', 'alpha_state'):
+                    getattr(self.core, name).copy_(getattr(grp.reference_core, name))
+        elif self.world_size > 1:
             import torch.distributed as dist
             for t in (self.core.params, self.core.targets, self.core.alpha_state):
                 dist.broadcast(t, src=0)
@@ -213,6 +239,7 @@ class SACAgent(object):
         self._fused_all = (self.world_size > 1 and all(self._fused(g) for g in range(4) if lay.group_floats[g] > 0)
                            and self.core.feature_exchange_count() == 0)
         self._inject = None
+        self._prepare_only = False
         self._pool = None
         self._next_key = {}
         self._early_key = None
@@ -344,8 +371,8 @@ class SACAgent(object):
         actor steps of this call may still be in flight when it returns; everything that looks at them waits (`flush()`), including
         reading the returned info dict -- which therefore has to be read before the NEXT train() call to describe THIS one."""
         self.steps += 1
-        if (self.steps & 255) == 0:
-            self.core.exchange_check()           # (a word in mapped host memory: no synchronisation)
+        if (self.steps & 31) == 0:
+            self.core.exchange_check()           # (a word in mapped host memory: no synchronisation; a launch that saw a timeout applied nothing)
         if self.use_graph and (not self._dp or self._fused_all):
             if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
                 if self._prefer_sequential():
@@ -364,17 +391,35 @@ class SACAgent(object):
 
     update = train      # BASELINE.json's north_star calls it agent.update()
 
+    def prepare(self, buffer, batch_size):
+        """Capture the hipGraphs the next train(buffer, batch_size) will replay, WITHOUT launching anything of a train().  Several replicas in
+        one process (the loopback form: rlrep_amd/comm.py LoopbackGroup) must build their graphs one after the other -- a capture synchronises
+        the device, which would wait for a peer's optimizer launch that in turn waits for this replica's -- and replay them side by side
+        afterwards.  No-op for the forms that are not whole graphs."""
+        if not (self.use_graph and (not self._dp or self._fused_all)):
+            return
+        self._prepare_only = True
+        try:
+            if self.use_pipeline and self._feature_iters() > 0 and self.core.defer_supported():
+                self._train_graph_pipelined(buffer, batch_size)         # (the two-chain form ...
+            self._train_graph(buffer, batch_size)                       #  ... and the one-graph form train() switches to for a caller that looks at the actor between calls)
+        finally:
+            self._prepare_only = False
+
     # ---- checkpoint / resume (absent in the reference: `--save_model` is parsed and never read, main.py:37) ------
     def state_snapshot(self):
         c = self.core
         self.flush()
         torch.cuda.synchronize()
+        c.exchange_check()                       # behind the device synchronisation: a replica whose last launches timed out is never written out
         return {'format': self.CHECKPOINT_FORMAT, 'device_state_bytes': int(c.device_state().numel()), 'alg': self.ALG, 'params': c.params.cpu(), 'targets': c.targets.cpu(), 'exp_avg': c.exp_avg.cpu(),
                 'exp_avg_sq': c.exp_avg_sq.cpu(), 'alpha_state': c.alpha_state.cpu(), 'device_state': c.device_state().cpu(),
                 'steps': self.steps, 'noise_ctr': self._ctr, 'seed': self._seed, 'layout': list(c.order)}
 
     def save(self, path):
-        torch.save(self.state_snapshot(), path)
+        snap = self.state_snapshot()
+        self.core.exchange_check()               # (the copies above were synchronous; refuse to persist a replica that is out of step)
+        torch.save(snap, path)
 
     def load(self, path_or_snapshot):
         snap = torch.load(path_or_snapshot) if isinstance(path_or_snapshot, (str, bytes, os.PathLike)) else path_or_snapshot
@@ -918,11 +963,13 @@ class SACAgent(object):
                     P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
                     f1 = _fe()
                     P['front_ends'] = {k: (f1[k] - f0[k]) // nset for k in f1}      # 16-row tile engine launches of one train() per front end
-                    s_ca, s_f = _concurrent_stream_pair(c)
+                    s_ca, s_f = _concurrent_stream_pair(c, self.rank if self._loopback is not None else 0)
                     P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, nset=nset, ev_snap=[torch.cuda.Event() for _ in range(nset)],
                              ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
                 self._pipe = P
         P = self._pipe
+        if self._prepare_only:
+            return None
         self._sync_images()
         if P['mode'] == 1:
             (P['steady'] if self._pending else P['first']).replay()
@@ -1031,7 +1078,7 @@ class SACAgent(object):
                         cs.append(self._capture_segments(ca_chain))
                 torch.cuda.current_stream().wait_stream(cap)
                 torch.cuda.synchronize()
-                s_ca, s_f = _concurrent_stream_pair(c)
+                s_ca, s_f = _concurrent_stream_pair(c, self.rank if self._loopback is not None else 0)
                 self._pipe = dict(key=key, mode=3, t=0, nset=nset, host_wait=nset == 3, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f,
                                   ev_snap=[torch.cuda.Event() for _ in range(nset)], ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
         P = self._pipe
@@ -1112,6 +1159,7 @@ class SACAgent(object):
             # 283 -> 315-335 us, the last critic / actor chain 193 -> 227 us; the same effect that made the set-reuse wait a host wait).
             # The critic / actor chain of the last call is the last thing in flight: its feature chain ended before it started.
             P['ev_ca'][(P['t'] - 1) % P['nset']].synchronize()
+            self.core.exchange_check()           # ... and again behind the wait: a timeout raised by the launches that were still running (advisor r05)
         elif self._pending:
             self._pending = False
             self._pipe['tail'].replay()
@@ -1144,6 +1192,8 @@ class SACAgent(object):
                 f1 = _fe()
                 self._graph_front_ends = {k: f1[k] - f0[k] for k in f1}
                 self._hist_n = self.core.history_seq() if self._hist else 0           # (synchronises; once per capture)
+        if self._prepare_only:
+            return None
         self._sync_images()
         self._graph.replay()
         if self._hist:

@@ -7,9 +7,12 @@ over hipIpc; once `attach()`ed, the optimizer launches of the agent do the excha
 rank's in rank order (bit-identical everywhere), do not end before every peer has read this rank's -- with NO extra launch and nothing for the
 host to do between calls: a data-parallel train() is captured into the same hipGraphs as a single-GPU one.
 
-`probe()` runs the same exchange as stand-alone launches on patterns whose rank-ordered sum is known and lets every rank agree on the outcome:
-`HipCore` only attaches after a clean probe and falls back to torch.distributed all-reduces (RCCL) otherwise -- the exchange can be TESTED
-on a one-GPU box (several processes mapping each other's block: tests/test_comm.py) but its first run across xGMI is the user's.
+`probe()` runs the same exchanges as stand-alone launches on patterns whose rank-ordered sum is known -- first filled by the host, then by a
+PRODUCER KERNEL that is the graph node right in front of the pull (the production order: no host between the launch that writes gradients and
+the launch that signals READY), one-shot and two-shot, plus the pushed-slot exchange -- and lets every rank agree on the outcome: `HipCore` only
+attaches after a clean probe and falls back to torch.distributed all-reduces (RCCL) otherwise -- the exchange can be TESTED on a one-GPU box
+(several processes mapping each other's block: tests/test_comm.py; several ranks in one process: `LoopbackGroup`) but its first run across
+xGMI is the user's.
 """
 import ctypes as C
 import os
@@ -28,14 +31,83 @@ class _Arena:
         self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2, 'strides': None}
 
 
-class GradientExchange:
-    def __init__(self, arena_floats, group=None):
-        """Collective constructor: every rank of `group` (default: the world) calls it with the same `arena_floats`.  The IPC handles and the
+class _ExchangeBase:
+    """What both forms share: the stand-alone exchanges, attachment, the error word."""
+    h = None
+    arena = None
+    scratch_floats = 0
+
+    def all_reduce(self, offset, n, out=None, mode=0, timeout_us=0):
+        """out[0 .. n) = sum over the ranks, in rank order, of block[offset .. offset + n): ONE launch on the current stream (mode 1: one-shot
+        pull, 2: two-shot, 0: by size).  Every rank calls it with the same (offset, n, mode) in the same order."""
+        if out is None:
+            out = torch.empty(int(n), dtype=torch.float32, device=self.arena.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n
+        check(lib.rlrep_comm_allreduce(self.h, int(offset), int(n), C.c_void_p(out.data_ptr()), int(mode), int(timeout_us),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_allreduce')
+        return out
+
+    def all_gather(self, offset, n):
+        """block[offset + q n .. + n) of every rank q into every rank's block (one pull launch on the current stream)."""
+        check(lib.rlrep_comm_allgather(self.h, int(offset), int(n), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_allgather')
+
+    def probe_fill(self, offset, n, rnd):
+        check(lib.rlrep_comm_probe_fill(self.h, int(offset), int(n), int(rnd), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_probe_fill')
+
+    @staticmethod
+    def probe_pattern(rank, rnd, n):
+        """What probe_fill writes (the same function evaluated on the host: csrc/comm.hip comm_pattern)."""
+        i = np.arange(n, dtype=np.uint64)
+        h = ((i * np.uint64(2654435761)) & np.uint64(0xffffffff)).astype(np.uint32) ^ np.uint32((rank * 40503 + rnd * 9176 + 12345) & 0xffffffff)
+        h ^= h >> np.uint32(15)
+        h = (h.astype(np.uint64) * np.uint64(2246822519) & np.uint64(0xffffffff)).astype(np.uint32)
+        h ^= h >> np.uint32(13)
+        m = (h & np.uint32(0xffff)).astype(np.int32).astype(np.float32) * np.float32(1.0 / 32768.0) - np.float32(1.0)
+        ex = ((h >> np.uint32(16)) % np.uint32(13)).astype(np.int32) - 6
+        return np.ldexp(m, ex).astype(np.float32)
+
+    def set_timeout(self, seconds):
+        """Bound of every device-side wait of attachments made from now on (default 120 s: a watchdog, not a schedule)."""
+        check(lib.rlrep_comm_set_timeout(self.h, int(float(seconds) * 1e6)), 'comm_set_timeout')
+
+    def attach(self, agent_handle, max_floats, two_shot_floats=0):
+        """-> set of optimizer groups whose launches now carry the exchange (gradient slices of at most max_floats floats; slices of at least
+        two_shot_floats take the two-shot form when world >= 3).  Rebuilds the agent's step programs: call before capturing graphs."""
+        mask = C.c_int32(0)
+        check(lib.rlrep_comm_attach(agent_handle, self.h, int(max_floats), int(two_shot_floats), C.byref(mask)), 'comm_attach')
+        return {g for g in range(4) if mask.value & (1 << g)}
+
+    def status(self, raise_on_error=True, clear=False):
+        """Late-rank mask of the waits that ran out so far (0: none).  Reads a word in mapped host memory: no device synchronisation."""
+        if not self.h:
+            return 0
+        m = C.c_uint32(0)
+        rc = lib.rlrep_comm_status(self.h, C.byref(m), 1 if clear else 0)
+        if rc != 0 and raise_on_error:
+            check(rc, 'comm_status')
+        return int(m.value)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.arena = None
+            lib.rlrep_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GradientExchange(_ExchangeBase):
+    def __init__(self, arena_floats, scratch_floats=0, group=None):
+        """Collective constructor: every rank of `group` (default: the world) calls it with the same sizes.  The IPC handles and the
         placement of the ranks travel through torch.distributed (any backend: gloo works)."""
         import torch.distributed as dist
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.arena_floats = int(arena_floats)
+        self.arena_floats, self.scratch_floats = int(arena_floats), int(scratch_floats)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # Every step that can fail on ONE rank only (allocation, export, mapping a peer's block) is caught and turned into a flag the ranks
         # agree on: a rank that raised here while its peers went on to the next collective would hang them.
@@ -45,7 +117,7 @@ class GradientExchange:
         try:
             h = C.c_void_p()
             torch.cuda.synchronize()
-            check(lib.rlrep_comm_create(self.rank, self.world, self.arena_floats, C.byref(h)), 'comm_create')
+            check(lib.rlrep_comm_create(self.rank, self.world, self.arena_floats, self.scratch_floats, C.byref(h)), 'comm_create')
             self.h = h
             self.fine_grained = bool(lib.rlrep_comm_fine_grained(self.h))
             self.arena = torch.as_tensor(_Arena(lib.rlrep_comm_arena(self.h), self.arena_floats), device=f'cuda:{dev}')
@@ -75,44 +147,89 @@ class GradientExchange:
         self.usable = self._agree(self.usable and connected)
         self._scratch = None
 
-    # ---- the stand-alone exchange (probe, tests) -------------------------------------------------------------------------------------
-    def all_reduce(self, offset, n, out=None, timeout_spins=0):
-        """out[0 .. n) = sum over the ranks, in rank order, of arena[offset .. offset + n): ONE launch on the current stream.  Every rank calls
-        it with the same (offset, n) in the same order."""
-        if out is None:
-            out = torch.empty(int(n), dtype=torch.float32, device=self.arena.device)
-        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n
-        check(lib.rlrep_comm_allreduce(self.h, int(offset), int(n), C.c_void_p(out.data_ptr()), int(timeout_spins),
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_allreduce')
-        return out
-
+    # ---- the probe ------------------------------------------------------------------------------------------------------------------------
     def probe(self, rounds=3, n=None):
-        """The exchange on known patterns, `rounds` times over the SAME addresses (a cache that served an earlier round's line would show), each
-        compared with the rank-ordered float32 sum computed on the host.  Collective; returns True only if EVERY rank saw every round right and
-        no wait ran out -- all ranks return the same value."""
-        import torch.distributed as dist
-        n = int(min(self.arena_floats, n or (1 << 18)))
+        """The exchanges on known patterns, each compared with the rank-ordered float32 sum computed on the host:
+          (1) `rounds` times over the SAME addresses with the arena filled by the host (a cache that served an earlier round's line would show);
+          (2) ONE hipGraph of `rounds` x [producer kernel -> pull], replayed twice: the pattern is written by an ordinary launch with ordinary
+              stores and the NEXT node signals READY and pulls -- no host synchronisation in between, as in a train() -- one-shot and (world >= 3)
+              two-shot; the next round's producer overwrites the arena right behind the pull (the DONE handshake);
+        Collective with a FIXED sequence of collectives whatever happens on any rank (a rank that raises still takes part in every agreement,
+        so no rank can be left waiting in one); returns True only if EVERY rank saw everything right and no wait ran out."""
+        n = int(min(self.arena_floats, n or (1 << 18))) & ~3
         ok = self.usable
-        if ok:
-            try:
-                for r in range(rounds):
-                    pats = [self._pattern(q, r, n) for q in range(self.world)]
-                    self.arena[:n].copy_(torch.from_numpy(pats[self.rank]))
-                    torch.cuda.synchronize()
-                    self._agree(True)                  # (every rank's pattern is in its arena before anybody reads it: the probe has no producer launch in front)
-                    got = self.all_reduce(0, n).cpu().numpy()
-                    want = pats[0].copy()
-                    for q in range(1, self.world):
-                        want = want + pats[q]
-                    ok = ok and bool(np.array_equal(got, want))
-                    if not ok and self.error is None:
-                        self.error = f'probe round {r}: the exchange did not return the rank-ordered sum'
-                ok = ok and self.status(raise_on_error=False) == 0
-                self.arena[:n].zero_()
+
+        def step(fn):
+            """run fn on every rank that is still good; all ranks then agree (one collective per step, always executed)"""
+            nonlocal ok
+            if ok:
+                try:
+                    res = fn()
+                    if res is False:
+                        ok = False
+                except Exception as e:             # noqa: BLE001
+                    ok, self.error = False, self.error or f'{type(e).__name__}: {e}'
+            ok = self._agree(ok)
+            return ok
+
+        def want(rnd, pat):
+            w = pat(0, rnd, n).copy()
+            for q in range(1, self.world):
+                w = w + pat(q, rnd, n)
+            return w
+
+        for r in range(rounds):
+            def fill(r=r):
+                self.arena[:n].copy_(torch.from_numpy(self._pattern(self.rank, r, n)))
                 torch.cuda.synchronize()
-            except Exception as e:                     # noqa: BLE001 (a rank that raised here would leave its peers in the next collective)
-                ok, self.error = False, f'{type(e).__name__}: {e}'
-        return self._agree(ok)
+            step(fill)                                 # (every rank's pattern is in its arena before anybody reads it: this form has no producer launch in front)
+
+            def pull(r=r):
+                got = self.all_reduce(0, n, mode=1).cpu().numpy()
+                if not np.array_equal(got, want(r, self._pattern)):
+                    self.error = self.error or f'probe round {r}: the exchange did not return the rank-ordered sum (host-filled arena)'
+                    return False
+            step(pull)
+        for mode in ((1, 2) if self.world >= 3 else (1,)):
+            outs = []
+
+            def build(mode=mode):
+                outs[:] = [torch.zeros(n, dtype=torch.float32, device=self.arena.device) for _ in range(rounds)]
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    g.capture_begin(capture_error_mode='thread_local')
+                    try:
+                        for r in range(rounds):
+                            self.probe_fill(0, n, 100 * mode + r)          # producer: an ordinary kernel writes this rank's pattern ...
+                            self.all_reduce(0, n, out=outs[r], mode=mode)  # ... and the NEXT node pulls (no host in between)
+                    finally:
+                        g.capture_end()
+                torch.cuda.current_stream().wait_stream(s)
+                self._probe_graph = g
+            step(build)
+
+            def replay(mode=mode):
+                for rep in range(2):
+                    self._probe_graph.replay()
+                torch.cuda.synchronize()
+                for r in range(rounds):
+                    if not np.array_equal(outs[r].cpu().numpy(), want(100 * mode + r, self.probe_pattern)):
+                        self.error = self.error or f'probe: producer kernel -> pull in one graph (mode {mode}, round {r}) did not return the rank-ordered sum'
+                        return False
+            step(replay)
+            self._probe_graph = None
+
+        def finish():
+            if self.status(raise_on_error=False) != 0:
+                self.error = self.error or 'probe: a wait ran out'
+                return False
+            self.arena[:n].zero_()
+            torch.cuda.synchronize()
+        step(finish)
+        return ok
 
     def _agree(self, ok):
         """True only if `ok` on every rank (a collective; also the barrier between mapping and first use)."""
@@ -128,31 +245,54 @@ class GradientExchange:
         rs = np.random.RandomState(7919 * rnd + rank + 1)
         return (rs.standard_normal(n) * (10.0 ** rs.randint(-3, 4, size=n))).astype(np.float32)
 
-    # ---- attachment and status ----------------------------------------------------------------------------------------------------------
-    def attach(self, agent_handle, max_floats):
-        """-> set of optimizer groups whose launches now carry the exchange (gradient slices of at most max_floats floats)."""
-        mask = C.c_int32(0)
-        check(lib.rlrep_comm_attach(agent_handle, self.h, int(max_floats), C.byref(mask)), 'comm_attach')
-        return {g for g in range(4) if mask.value & (1 << g)}
 
-    def status(self, raise_on_error=True, clear=False):
-        """Late-rank mask of the waits that ran out so far (0: none).  Reads a word in mapped host memory: no device synchronisation."""
-        if not self.h:
-            return 0
-        m = C.c_uint32(0)
-        rc = lib.rlrep_comm_status(self.h, C.byref(m), 1 if clear else 0)
-        if rc != 0 and raise_on_error:
-            check(rc, 'comm_status')
-        return int(m.value)
+class LoopbackGroup:
+    """`world` ranks inside ONE process on one GPU: every rank's block is plain device memory and the peers are plain pointers
+    (rlrep_comm_connect_local) -- no IPC, no torch.distributed, no process time-slicing.  What tools/exp/dp_loopback.py measures the cost of the
+    in-launch exchange with (N agents on N stream pairs, attached against unattached) and what the one-process multi-rank tests run on.
+    Launches of different ranks must be issued on DIFFERENT streams (a rank's optimizer launch waits for the peers' on the device), and the
+    host must never wait for one rank before it has issued the matching launches of the others."""
+
+    def __init__(self, world, arena_floats=None, scratch_floats=0):
+        """arena_floats None: the blocks are allocated when the first agent joins (HipCore calls ensure() with its layout's sizes)."""
+        self.world, self.arena_floats, self.scratch_floats = int(world), None, 0
+        self.members = []
+        self.reference_core = None          # rank 0's HipCore: the later ranks copy their initial parameters from it
+        self.timeout_s = None
+        if arena_floats is not None:
+            self.ensure(arena_floats, scratch_floats)
+
+    def ensure(self, arena_floats, scratch_floats=0):
+        if self.members:
+            assert self.arena_floats >= int(arena_floats) and self.scratch_floats >= int(scratch_floats), 'loopback group is too small for this agent'
+            return
+        self.arena_floats, self.scratch_floats = int(arena_floats), int(scratch_floats)
+        self.members = [LoopbackExchange(self, r) for r in range(self.world)]
+        arr = (C.c_void_p * self.world)(*[m.h for m in self.members])
+        for m in self.members:
+            check(lib.rlrep_comm_connect_local(m.h, arr), 'comm_connect_local')
+            if self.timeout_s is not None:
+                m.set_timeout(self.timeout_s)
+
+    def __getitem__(self, rank):
+        return self.members[rank]
 
     def close(self):
-        if getattr(self, 'h', None):
-            self.arena = None
-            lib.rlrep_comm_destroy(self.h)
-            self.h = None
+        torch.cuda.synchronize()
+        for m in self.members:
+            m.close()
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+
+class LoopbackExchange(_ExchangeBase):
+    def __init__(self, group, rank):
+        self.group, self.rank, self.world = group, int(rank), group.world
+        self.arena_floats, self.scratch_floats = group.arena_floats, group.scratch_floats
+        self.fine_grained, self.same_device, self.usable, self.error = False, True, True, None
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(lib.rlrep_comm_create(self.rank, self.world, self.arena_floats, self.scratch_floats, C.byref(h)), 'comm_create')
+        self.h = h
+        self.arena = torch.as_tensor(_Arena(lib.rlrep_comm_arena(self.h), self.arena_floats), device=f'cuda:{torch.cuda.current_device()}')
+
+    def probe(self, *a, **k):
+        return True                         # (same device, plain pointers: nothing to find out; tests/test_comm.py checks the arithmetic)

@@ -101,7 +101,8 @@ class LazyInfo(dict):
 
 
 class HipCore:
-    def __init__(self, alg, dims, hyper, device=None, world_size=1):
+    def __init__(self, alg, dims, hyper, device=None, world_size=1, loopback=None):
+        """loopback: a (LoopbackGroup, rank) pair -- this core is rank `rank` of `world_size` replicas inside ONE process (rlrep_amd/comm.py)."""
         if not torch.cuda.is_available():
             raise RuntimeError('rlrep_amd needs an MI355X (no CPU fallback): torch.cuda.is_available() is False')
         self.alg = alg
@@ -114,6 +115,7 @@ class HipCore:
         for k, v in hyper.items():
             setattr(self.hyper, k, v)
         self.hyper.world_size = int(world_size)
+        self.dims.world_size = int(world_size)          # the workspace is sized for the data-parallel forms of the feature step (ctrlsac: [B, world * B] scores)
         self.hyper.beta1, self.hyper.beta2, self.hyper.adam_eps = 0.9, 0.999, 1e-8
         info = _lib.LayoutInfo()
         check(lib.rlrep_layout(C.byref(self.dims), C.byref(info), None, 0), 'layout')
@@ -146,11 +148,18 @@ class HipCore:
         # ranks' gradients themselves -- but only after the exchange has passed its probe on THIS set of ranks (same answer on every rank);
         # otherwise the arena stays where it is and the agent all-reduces with torch.distributed between backward and apply, as before.
         self.exchange, self.fused_groups = None, frozenset()
-        if int(world_size) > 1 and os.environ.get('RLREP_DP_FUSED', '1') != '0':
+        if loopback is not None:
+            group, lrank = loopback
+            group.ensure(info.grad_floats, info.exchange_floats)
+            assert group.world == int(world_size) and self.dims.rank == lrank, 'loopback group does not fit this agent'
+            self.exchange = group[lrank]
+            self.grads = self.exchange.arena[:info.grad_floats]
+        elif int(world_size) > 1 and os.environ.get('RLREP_DP_FUSED', '1') != '0':
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 from .comm import GradientExchange
-                ex = GradientExchange(info.grad_floats)
+                from .utils import switches as _sw0
+                ex = GradientExchange(info.grad_floats, 0 if _sw0.off('dp_fold_exchanges') else info.exchange_floats)
                 if ex.probe():
                     self.exchange, self.grads = ex, ex.arena[:info.grad_floats]
                 else:
@@ -171,10 +180,15 @@ class HipCore:
         self.h = h
         if self.exchange is not None:
             # gradient slices up to 4 MB (RLREP_ENABLE=dp_fused_mb=N) are summed inside their optimizer launch; larger ones (diffsrsac's 198 MB nabla-mu
-            # group at Humanoid dims: bandwidth-bound, RCCL's ring is the right shape) keep the all-reduce between backward and apply
+            # group at Humanoid dims: bandwidth-bound, RCCL's ring is the right shape) keep the all-reduce between backward and apply.  Slices of at least 512 KB (RLREP_ENABLE=dp_two_shot_kb=N; 0: never) take the two-shot form
+            # inside the launch when world >= 3: (N - 1) S / N bytes per phase and GPU instead of (N - 1) S (csrc/dp_pull.h).
             from .utils import switches as _sw
             cap = int(float(_sw.opt('dp_fused_mb', '4')) * (1 << 20)) // 4
-            self.fused_groups = frozenset(self.exchange.attach(self.h, cap))
+            two = int(float(_sw.opt('dp_two_shot_kb', '512')) * 1024) // 4
+            t = _sw.opt('dp_timeout_s')
+            if t is not None:
+                self.exchange.set_timeout(float(t))
+            self.fused_groups = frozenset(self.exchange.attach(self.h, cap, two))
         names = (C.c_char * 32 * METRIC_SLOTS)()
         lib.rlrep_metric_names(self.dims.alg, C.cast(names, C.c_void_p), METRIC_SLOTS)
         self.metric_names = [bytes(n).split(b'\0', 1)[0].decode() for n in names]
@@ -190,7 +204,8 @@ class HipCore:
                 self.h = None
             if getattr(self, 'exchange', None) is not None:
                 self.grads = None
-                self.exchange.close()
+                if not hasattr(self.exchange.group, 'members'):          # (a loopback group owns its members)
+                    self.exchange.close()
                 self.exchange = None
         except Exception:
             pass

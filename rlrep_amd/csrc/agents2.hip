@@ -11,6 +11,9 @@ int rl_launch_speder_grads(const SpederGrads* p, hipStream_t st);
 int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st);
 int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st);
 int rl_launch_copy2(const float* src, float* d1, float* d2, long long n, hipStream_t st);
+// comm.hip: ctrlsac's batch-coupled exchanges as launches of the step program (attached agents)
+int rl_launch_xchg_gather(const DpPull* proto, int channel, long long off, long long n, hipStream_t st);
+int rl_launch_xchg_reduce(const DpPull* proto, int channel, long long off, long long n, float* out, int two_shot, hipStream_t st);
 }
 
 // ================================================================================================
@@ -216,10 +219,16 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
     // all-gathered into ZMall [W*B, F] (this rank's rows sit at rank*B), the score matrix is [B, W*B], and the
     // partial dL/dmu'_all [W*B, F] is all-reduced before this rank back-propagates its own B rows.
     const int Wd = ag->h.world_size > 1 ? ag->h.world_size : 1, rank = Wd > 1 ? d.rank : 0, WB = Wd * B;
-    float* M1 = ws.f((size_t)B * Hm); float* M2 = ws.f((size_t)B * Hm); float* ZMall = ws.f((size_t)WB * F);
+    // attached (rlrep_comm_attach with exchange scratch, dp_pull.h): mu(s') of all ranks and the partial dmu'_all live in the shared block, and
+    // the two exchanges are ONE pull launch each inside the step program (comm.hip comm_gather_kernel / comm_pull_kernel) -- no cut, no host
+    const bool xf = ag->xfold && Wd > 1 && (((long long)B * F) & 3) == 0 && 2ll * WB * F <= ag->xscratch_floats;
+    float* M1 = ws.f((size_t)B * Hm); float* M2 = ws.f((size_t)B * Hm);
+    float* ZMall = xf ? ag->xscratch[rank] : ws.f((size_t)WB * F);
     float* ZM = ZMall ? ZMall + (size_t)rank * B * F : nullptr;
-    float* GM2 = ws.f((size_t)B * Hm); float* GM1 = ws.f((size_t)B * Hm); float* GZMall = ws.f((size_t)WB * F);
+    float* GM2 = ws.f((size_t)B * Hm); float* GM1 = ws.f((size_t)B * Hm);
+    float* GZMall = xf ? ag->xscratch[rank] + (size_t)WB * F : ws.f((size_t)WB * F);
     float* GZM = GZMall ? GZMall + (size_t)rank * B * F : nullptr;
+    rlrep_agent* const agp = ag;
     float* Sx = ws.f((size_t)B * WB); float* RH = ws.f(B); float* DRH = ws.f(B);
     const int nblk_f = qhead_blocks(B);
     float* part_f = ws.f((size_t)2 * nblk_f);
@@ -229,6 +238,10 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         b.fwd_stage(p, {phi_fwd(1, nullptr, pf), Builder::fwd(M1, Hm, B, Hm, Pw("mu.l2.weight"), Hm, Pw("mu.l2.bias"), Hm, M2, Hm, ACT_ELU)}, "phi.l2 mu.l2");
         b.fwd_stage(p, {phi_fwd(2, nullptr, pf), Builder::fwd(M2, Hm, B, Hm, Pw("mu.l3.weight"), Hm, Pw("mu.l3.bias"), F, ZM, F, ACT_TANH)}, "phi.l3 mu.l3(tanh)");
         // quirk Q6: the score matrix is the GEMM phi mu'^T, not the [B,B,F] broadcast
+        if (xf) {
+            const long long off = ag->xarena_floats, nseg = (long long)B * F;
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_xchg_gather(&agp->dp_proto, 4, off, nseg, st); }, "all-gather mu(s') (pull)"});
+        } else
         if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 1, ZMall, (int64_t)B * F, (int64_t)rank * B * F});
         // rhat = theta . phi + b (a [B, 1] product) is computed by the InfoNCE launch itself: beside a score matrix that routes to the LDS-tiled engine it was a
         // 16-row-engine launch of its own on the dependent chain (8 us per feature step at F = 2048); RLREP_DISABLE=fold_theta keeps it
@@ -251,6 +264,12 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
             if (Wd > 1) {          // data parallel: the all-reduce of dmu'_all sits right behind its own stage
                 b.dx_stage(p, {t}, "dphi = dS mu' + drhat theta");
                 b.gemm(p, LD_COL, LD_COL, {u}, "dmu'_all = dS^T phi");
+                if (xf) {
+                    // this rank needs only ITS rows of the sum: a reduce-scatter, in place (peers read their own rows of this block)
+                    const long long off = ag->xarena_floats + (long long)WB * F + (long long)rank * B * F, nseg = (long long)B * F;
+                    float* out = GZM;
+                    p.stages.push_back({[=](hipStream_t st) { return rl_launch_xchg_reduce(&agp->dp_proto, 5, off, nseg, out, 0, st); }, "reduce-scatter dmu' (pull)"});
+                } else
                 ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, GZMall, (int64_t)WB * F, 0});
             } else {
                 // both products consume the InfoNCE gradient dS and nothing of each other: ONE launch of two tile forms (gemm16_duo_kernel)
@@ -330,7 +349,7 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
     // deferred variants: the critic / actor programs against a snapshot set (phi copy + minibatch copy); the snapshot launch also runs
     // sync_prog (frozen_phi* <- phi), which belongs to the end of the feature steps
-    if (ag->h.world_size <= 1) {
+    if (ag->h.world_size <= 1 || xf) {
         const LT& q0 = ag->L.get("phi.l1.weight");
         const LT& ql = ag->L.get("phi.l3.bias");
         for (int set = 0; set < rlrep_agent::NSETS; ++set) {
@@ -466,7 +485,7 @@ static void build_rff_critic_actor(Builder& b, rlrep_agent* ag, const Mlp& phi, 
     (void)GZ;
     update_target_program(ag, "critic.l1.weight", "critic_target.l1.weight");
     // deferred variants (spedersac: critic and actor read the LIVE phi, so the snapshot carries a copy of it)
-    if (train_critic && ag->h.world_size <= 1) {
+    if (train_critic && (ag->h.world_size <= 1 || ag->xfold)) {
         const LT& q0 = ag->L.get(phi.name(0) + ".weight");
         const LT& ql = ag->L.get(phi.name(phi.depth) + ".bias");
         const std::string pre = phi.prefix + ".", first = phi.name(0) + ".weight";
@@ -498,6 +517,11 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
     const float* S2 = s0.XE ? s0.XE + SA : nullptr;            // next_state columns, row stride 2S+A, 2B rows
     float* PHI = pf.act[phi.depth]; float* MU = mf.act[mu.depth];
     float* PHIBAR = ws.f(F); float* V = ws.f(F); float* C = ws.f(B); float* DRH = ws.f(B);
+    // attached (rlrep_comm_attach with exchange scratch): Phibar and v are sums over the GLOBAL random batch -- the colsum launches push this rank's
+    // partial into every rank's slot area, the launches that consume them sum the partials in rank order (dp_pull.h DpSlots): zero extra launches
+    const int Wd = ag->h.world_size > 1 ? ag->h.world_size : 1;
+    const int Fp = (F + 63) & ~63;
+    const bool xf = ag->xfold && Wd > 1 && F <= RL_SLOTS_MAX_F && 4ll * Wd * Fp <= ag->xscratch_floats;
     const int nblk_f = qhead_blocks(B);
     float* part_f = ws.f((size_t)3 * nblk_f);
     const size_t BF = (size_t)B * F;
@@ -511,22 +535,26 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         }
         ColSum c1; memset(&c1, 0, sizeof(c1));
         c1.X = PHI ? PHI + BF : nullptr; c1.ldX = F; c1.w = nullptr; c1.out = PHIBAR; c1.rows = B; c1.F = F;
+        if (xf) c1.dp = ag->slots(4, 0, Fp);
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c1, st); }, "Phibar = colsum phi_r"});
         // data parallel: Phibar and v are sums over the GLOBAL "random" batch: two F-float all-reduces
-        if (ag->h.world_size > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, PHIBAR, (int64_t)F, 0});
+        if (ag->h.world_size > 1 && !xf) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, PHIBAR, (int64_t)F, 0});
         SpederRows sr; memset(&sr, 0, sizeof(sr));
+        if (xf) { sr.dp = ag->slots(4, 0, Fp); sr.phibar_out = PHIBAR; }
         sr.phi = PHI; sr.mu = MU; sr.mu_r = MU ? MU + BF : nullptr; sr.phibar = PHIBAR; sr.theta_w = ag->P("theta.l.weight"); sr.theta_b = ag->P("theta.l.bias");
         sr.r = s0.R; sr.c = C; sr.drhat = DRH; sr.partial = part_f; sr.B = B; sr.F = F; sr.nblk = nblk_f; sr.inv_batch = ag->inv_batch(); sr.step = ag->adam_step + 0;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_speder_rows(&sr, st); }, "speder rows (c, d, rhat)"});
         ColSum c2; memset(&c2, 0, sizeof(c2));
         c2.X = MU ? MU + BF : nullptr; c2.ldX = F; c2.w = C; c2.out = V; c2.rows = B; c2.F = F;
+        if (xf) c2.dp = ag->slots(5, 2ll * Wd * Fp, Fp);
         // theta.l's gradient (sum_i drhat_i phi_i and sum_i drhat_i over the first batch) is a weighted column sum too: it rides here instead of
         // being a 16-row-engine launch of its own behind the weight-gradient launch (7 us per feature step)
         const bool theta_here = !rl_off("fold_theta");
         if (theta_here) { c2.X2 = PHI; c2.ldX2 = F; c2.w2 = DRH; c2.out2 = ag->G("theta.l.weight"); c2.outb2 = ag->G("theta.l.bias"); c2.rows2 = B; }
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c2, st); }, "v = sum_k c_k mu_r,k"});
-        if (ag->h.world_size > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, V, (int64_t)F, 0});
+        if (ag->h.world_size > 1 && !xf) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, V, (int64_t)F, 0});
         SpederGrads sg; memset(&sg, 0, sizeof(sg));
+        if (xf) sg.dp = ag->slots(5, 2ll * Wd * Fp, Fp);
         sg.phi = PHI; sg.mu = MU; sg.c = C; sg.drhat = DRH; sg.phibar = PHIBAR; sg.v = V; sg.theta_w = ag->P("theta.l.weight");
         sg.Gphi = pf.g[phi.depth]; sg.Gmu = mf.g[mu.depth]; sg.B = B; sg.F = F; sg.inv_batch = ag->inv_batch();
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_speder_grads(&sg, st); }, "speder grads"});

@@ -1136,6 +1136,15 @@ static int refresh_x3(rlrep_agent* ag, void* stream) {
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// floats of exchange scratch the batch-coupled feature exchanges of this agent need once attached (rlrep_layout_info.exchange_floats)
+static long long exchange_floats(const rlrep_dims& d, int world) {
+    if (world <= 1) return 0;
+    const long long F = d.feature_dim, B = d.max_batch, W = world;
+    if (d.alg == RLREP_ALG_SPEDERSAC) return F <= RL_SLOTS_MAX_F ? 2 * (2 * W * ((F + 63) & ~63ll)) : 0;      // Phibar and v: [2 parities][world][F] each
+    if (d.alg == RLREP_ALG_CTRLSAC) return 2 * W * B * F;                                                      // mu(s') of all ranks + its partial gradients
+    return 0;
+}
+
 extern "C" {
 
 int32_t rlrep_abi_version(void) { return RLREP_ABI_VERSION; }
@@ -1146,17 +1155,25 @@ int32_t rlrep_layout(const rlrep_dims* dims, rlrep_layout_info* info, rlrep_tens
     if (!check_dims(dims) || !info) return RLREP_ERR_ARG;
     rlrep_agent tmp;
     tmp.d = *dims; memset(&tmp.h, 0, sizeof(tmp.h)); memset(&tmp.a, 0, sizeof(tmp.a));
-    tmp.h.world_size = 1;
+    tmp.h.world_size = dims->world_size > 1 ? dims->world_size : 1;       // (sizes the workspace of the batch-coupled feature steps: ctrlsac's [B, W B] score matrix)
     if (!build_layout(*dims, tmp.L)) return RLREP_ERR_ARG;
     tmp.L.align(RLREP_ARENA_PARAM); tmp.L.align(RLREP_ARENA_TARGET);
     tmp.ws.dry = true;
     static_state(&tmp);
     if (build_programs(&tmp, dims->max_batch) != 0) return RLREP_ERR_ARG;
+    if (tmp.h.world_size > 1 && exchange_floats(*dims, tmp.h.world_size) > 0) {
+        // ... and the ATTACHED form (rl_agent_attach_dp: exchanges inside the launches, deferred step programs kept): the larger of the two
+        const size_t plain = tmp.ws.used;
+        tmp.xfold = true; tmp.xscratch_floats = exchange_floats(*dims, tmp.h.world_size); tmp.dp_proto.world = tmp.h.world_size; tmp.dp_proto.rank = dims->rank;
+        if (build_programs(&tmp, dims->max_batch) != 0) return RLREP_ERR_ARG;
+        if (tmp.ws.used < plain) tmp.ws.used = plain;
+    }
     memset(info, 0, sizeof(*info));
     info->param_floats = tmp.L.cur[RLREP_ARENA_PARAM];
     info->target_floats = tmp.L.cur[RLREP_ARENA_TARGET] > 0 ? tmp.L.cur[RLREP_ARENA_TARGET] : 4;
     info->grad_floats = info->param_floats + RLREP_GRAD_TAIL;
     info->workspace_bytes = (int64_t)tmp.ws.used + 4096;
+    info->exchange_floats = exchange_floats(*dims, tmp.h.world_size);
     for (int g = 0; g < 4; ++g) { info->group_offset[g] = tmp.L.group_off[g]; info->group_floats[g] = tmp.L.group_n[g]; }
     info->n_tensors = (int32_t)tmp.L.t.size();
     info->n_metrics = M_COUNT;
@@ -1879,22 +1896,59 @@ int32_t rlrep_build_flags(void) {
 
 const float* rlrep_metrics_dev(rlrep_agent* ag) { return ag ? ag->metrics : nullptr; }
 int64_t rlrep_launch_counter(void) { return g_rl_launches; }
-// rlrep_comm_attach (comm.hip): from now on the optimizer launches of the attached groups carry the data-parallel exchange
-extern "C" int rl_agent_attach_dp(rlrep_agent* ag, const DpPull* proto, long long arena_floats, long long max_floats, int* attached_mask) {
-    if (!ag || !proto) return RLREP_ERR_ARG;
+// rlrep_comm_attach (comm.hip): from now on the optimizer launches of the attached groups carry the data-parallel exchange, and -- with
+// exchange scratch -- the feature step carries its batch-coupled exchanges (the programs are rebuilt)
+extern "C" int rl_adam_dp_occupancy(int* one_shot, int* two_shot);
+extern "C" int rl_agent_attach_dp(rlrep_agent* ag, const DpAttach* at, int* attached_mask) {
+    if (!ag || !at) return RLREP_ERR_ARG;
+    const DpPull* proto = &at->proto;
     if (proto->world != ag->h.world_size) { rl_set_error("comm_attach: the comm spans %d ranks, the agent was created with world_size = %d", proto->world, ag->h.world_size); return RLREP_ERR_ARG; }
+    if (proto->world > 1 && proto->rank != ag->d.rank) { rl_set_error("comm_attach: the comm's rank is %d, the agent's dims.rank %d", proto->rank, ag->d.rank); return RLREP_ERR_ARG; }
     if (ag->a.grad_dev != proto->base[proto->rank]) { rl_set_error("comm_attach: the agent's gradient arena is not the comm's arena (create the agent with rlrep_comm_arena() as grad_dev)"); return RLREP_ERR_ARG; }
     rlrep_layout_info info;
     if (rlrep_layout(&ag->d, &info, nullptr, 0) != 0) return RLREP_ERR_ARG;
-    if (arena_floats < info.grad_floats) { rl_set_error("comm_attach: the comm's arena holds %lld floats, the gradient arena needs %lld", arena_floats, (long long)info.grad_floats); return RLREP_ERR_ARG; }
-    ag->dp_proto = *proto;
-    int mask = 0;
-    for (int g = 0; g < 4; ++g) {
-        const bool on = proto->world > 1 && ag->L.group_n[g] > 0 && ag->L.group_n[g] <= max_floats;
-        ag->dp_on[g] = on;
-        if (on) mask |= 1 << g;
+    if (at->arena_floats < info.grad_floats) { rl_set_error("comm_attach: the comm's arena holds %lld floats, the gradient arena needs %lld", at->arena_floats, (long long)info.grad_floats); return RLREP_ERR_ARG; }
+    // Co-residency (dp_pull.h, "Progress with SEVERAL channels in flight"): the blocks of the two largest attached optimizer launches (riders
+    // included: two minibatch gathers of at most 2048 blocks are NOT counted -- they wait for nothing and drain) must fit the chip together.
+    int occ1 = 0, occ2 = 0, cus = 0, dev = 0;
+    if (proto->world > 1) {
+        if (rl_adam_dp_occupancy(&occ1, &occ2) != 0 || hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            rl_set_error("comm_attach: cannot query the occupancy of the optimizer kernels"); return RLREP_ERR_HIP;
+        }
     }
+    ag->dp_proto = *proto;
+    int mask = 0; long long big[2] = {0, 0};
+    for (int g = 0; g < 4; ++g) {
+        const bool on = proto->world > 1 && ag->L.group_n[g] > 0 && ag->L.group_n[g] <= at->max_floats;
+        ag->dp_on[g] = on;
+        ag->dp_two[g] = on && proto->world >= 3 && at->two_shot_floats > 0 && ag->L.group_n[g] >= at->two_shot_floats && proto->red[proto->rank] != nullptr;
+        if (on) {
+            mask |= 1 << g;
+            const long long blocks = (ag->L.group_n[g] + 1023) / 1024 + 1 + 256;            // optimizer blocks + trailing block + a folded snapshot's segments
+            if (blocks > big[0]) { big[1] = big[0]; big[0] = blocks; } else if (blocks > big[1]) big[1] = blocks;
+        }
+    }
+    if (mask) {
+        const long long slots = (long long)cus * std::min(occ1, occ2 > 0 ? occ2 : occ1);
+        if (big[0] + big[1] > slots) {
+            for (int g = 0; g < 4; ++g) ag->dp_on[g] = ag->dp_two[g] = false;
+            rl_set_error("comm_attach: two optimizer launches of this agent (%lld + %lld blocks) do not fit the device together (%d CUs x %d resident blocks): "
+                         "a spinning launch could keep the one it waits for from becoming resident; lower max_floats", big[0], big[1], cus, std::min(occ1, occ2 > 0 ? occ2 : occ1));
+            if (attached_mask) *attached_mask = 0;
+            return RLREP_ERR_ARG;
+        }
+    }
+    // batch-coupled exchanges: only when the feature group itself is attached (a train() is then one uninterrupted sequence of launches)
+    const long long need = exchange_floats(ag->d, proto->world);
+    const bool was = ag->xfold;
+    ag->xfold = proto->world > 1 && ag->dp_on[0] && need > 0 && at->scratch_floats >= need && at->scratch[proto->rank] != nullptr && !rl_off("dp_fold_exchanges");
+    ag->xscratch_floats = at->scratch_floats; ag->xarena_floats = at->arena_floats;
+    for (int q = 0; q < RL_DP_MAX_WORLD; ++q) ag->xscratch[q] = q < proto->world ? at->scratch[q] : nullptr;
     if (attached_mask) *attached_mask = mask;
+    if ((ag->xfold || was) && ag->B > 0) {
+        (void)hipDeviceSynchronize();                      // (table re-upload uses blocking copies: rare path, once per attachment)
+        return build_programs(ag, ag->B);
+    }
     return 0;
 }
 int32_t rlrep_front_end_counts(int64_t* out4) {

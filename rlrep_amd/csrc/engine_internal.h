@@ -89,7 +89,17 @@ struct rlrep_agent {
     unsigned* xc_err = nullptr; std::deque<std::string> stage_names;
     // data parallel inside the optimizer launches (rlrep_comm_attach, dp_pull.h): the gradient arena is a block every peer has mapped; the
     // optimizer launch of an attached group sums its gradients over the ranks itself (channel = group)
-    DpPull dp_proto = DpPull(); bool dp_on[4] = {false, false, false, false};
+    DpPull dp_proto = DpPull(); bool dp_on[4] = {false, false, false, false}, dp_two[4] = {false, false, false, false};
+    // ... and the batch-coupled exchanges of the feature step (spedersac Phibar / v: pushed slots, zero launches; ctrlsac mu(s') / dmu': one
+    // pull launch each) when the comm carries exchange scratch (rlrep_layout_info.exchange_floats): xfold = the step programs were rebuilt
+    // with them inside, feat_cuts is empty and a data-parallel train() is ONE uninterrupted sequence of launches
+    bool xfold = false; float* xscratch[RL_DP_MAX_WORLD] = {nullptr}; long long xscratch_floats = 0, xarena_floats = 0;
+    DpSlots slots(int channel, long long off_floats, int n) const {          // slot area [2][world][n] of `channel` at scratch offset off_floats
+        DpSlots d; memset(&d, 0, sizeof(d));
+        d.world = dp_proto.world; d.rank = dp_proto.rank; d.channel = channel; d.n = n; d.timeout = dp_proto.timeout; d.err = dp_proto.err;
+        for (int q = 0; q < d.world; ++q) { d.slot[q] = xscratch[q] + off_floats; d.flags[q] = dp_proto.flags[q]; }
+        return d;
+    }
 
     float* overridden(const std::string& n) const {
         if (!ov_base || n.compare(0, ov_prefix.size(), ov_prefix) != 0) return nullptr;
@@ -504,7 +514,7 @@ struct Builder {
             }
             const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
             DpPull dp = a->dp_proto;
-            dp.channel = group;
+            dp.channel = group; dp.mode = a->dp_two[group] ? 2 : 1;
             return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, a->dp_on[group] ? &dp : nullptr, st);
         }, what});
         tag(p, RLREP_ENGINE_OPTIMIZER, 0.0, 28.0 * (double)t.n + 12.0 * (double)(target ? pol_n : 0));     // read p, g, m, v; write p, m, v (+ target: read, read source, write)

@@ -11,7 +11,7 @@ def test_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), n
         assert n in _lib.SIGNATURES, f'{n} declared in rlrep.h but not bound in _lib.py'
-    assert _lib.lib.rlrep_abi_version() == 3
+    assert _lib.lib.rlrep_abi_version() == 4
 
 
 @pytest.mark.parametrize('alg,kw', [

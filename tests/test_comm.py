@@ -40,15 +40,24 @@ def _spawn(fn, world, *args, timeout=400):
     q = ctx.Queue()
     procs = [ctx.Process(target=_entry, args=(r, world, port, q, fn) + args) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
     res = {}
-    for _ in range(world):
-        r = q.get(timeout=timeout)
-        assert not isinstance(r[1], str), r[1]
-        res[r[0]] = r[1:]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        for _ in range(world):
+            r = q.get(timeout=timeout)
+            assert not isinstance(r[1], str), r[1]
+            res[r[0]] = r[1:]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                 # (a rank that failed leaves its peers in a collective: never let them outlive the test)
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
     return res
 
 
@@ -74,7 +83,9 @@ def _pull_body(rank, world, q):
     out = []
     for call, (n, off) in enumerate(list(zip(SIZES, OFFSETS)) * 2):           # twice over the same addresses, back to back without a host sync
         ex.arena[off:off + n].copy_(torch.from_numpy(_data(rank, n, call)))
-        out.append(ex.all_reduce(off, n))
+        # first pass: one-shot pull; second pass: two-shot (reduce-scatter + all-gather in one launch; world >= 3 and 16-byte ranges, else the
+        # library falls back to the one-shot form by itself)
+        out.append(ex.all_reduce(off, n, mode=1 if call < len(SIZES) else 2))
     torch.cuda.synchronize()
     assert ex.status() == 0
     res = [t.cpu().numpy() for t in out]
@@ -90,7 +101,7 @@ def _pull_body(rank, world, q):
 
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 4])
 def test_in_launch_exchange_is_the_rank_ordered_sum_on_every_rank(world):
     res = _spawn('_pull_body', world)
     for call, (n, off) in enumerate(list(zip(SIZES, OFFSETS)) * 2):
@@ -112,7 +123,7 @@ def _late_body(rank, world, q):
     if rank == 0:
         ex.arena[:1024].fill_(1.0)
         t0 = time.time()
-        ex.all_reduce(0, 1024, timeout_spins=20000)
+        ex.all_reduce(0, 1024, timeout_us=300000)
         torch.cuda.synchronize()
         took = time.time() - t0
         mask = ex.status(raise_on_error=False)
@@ -136,9 +147,31 @@ def test_a_rank_that_never_arrives_sets_the_mask_and_raises_within_the_timeout()
     assert took < 30.0, took
 
 
-def _agent_body(rank, world, q, case, fused, graph, calls, pipe_dp=False):
+def _ordered_all_reduce():
+    """torch.distributed.all_reduce(SUM) with the sum formed in RANK order on every rank (gloo's ring order is not the rank order): what the
+    in-launch exchange computes, so that the two forms can be compared bit for bit with any number of ranks."""
+    real = dist.all_reduce
+
+    def ordered(t, *a, op=dist.ReduceOp.SUM, group=None, async_op=False, **k):
+        if op != dist.ReduceOp.SUM or not t.is_floating_point() or async_op:
+            return real(t, *a, op=op, group=group, async_op=async_op, **k)
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        acc = parts[0].clone()
+        for p in parts[1:]:
+            acc = acc + p
+        t.copy_(acc)
+    dist.all_reduce = ordered
+
+
+def _agent_body(rank, world, q, case, fused, graph, calls, pipe_dp=False, enable='', ordered=False, pipeline=True):
     os.environ['RLREP_DP_FUSED'] = '1' if fused else '0'
     os.environ['RLREP_PIPELINE_DP'] = '1' if pipe_dp else '0'
+    os.environ['RLREP_ENABLE'] = ','.join(t for t in (enable, 'dp_timeout_s=20') if t)      # (a protocol bug must fail the test in seconds, not in the watchdog's minutes)
+    if not pipeline:
+        os.environ['RLREP_PIPELINE'] = '0'
+    if ordered:
+        _ordered_all_reduce()
     from fixture_io import Case
     from test_hip_parity import make_agent, make_buffer
     from test_dp import _inputs
@@ -166,30 +199,68 @@ def _agent_body(rank, world, q, case, fused, graph, calls, pipe_dp=False):
     if fused:
         assert agent.core.exchange.status() == 0
     st = {k: v.numpy() for k, v in agent.core.state().items()}
-    q.put((rank, st, took, sorted(agent.core.fused_groups)))
+    q.put((rank, st, took, sorted(agent.core.fused_groups), agent.core.feature_exchange_count()))
     dist.barrier()
     del agent
 
 
 
-@pytest.mark.parametrize('case,world', [('vlsac_tiny', 2), ('spedersac_tiny', 2), ('sac_tiny', 3)])
-def test_train_with_gradients_summed_in_the_optimizer_launches_equals_gloo(case, world):
-    """Eager step programs, injected draws: every gradient slice summed inside its optimizer launch (spedersac: its Phibar / v exchange still
-    over gloo) ends in exactly the state of the same run with torch.distributed all-reduces between backward and apply; replicas bit-identical.
-    (Two ranks: a + b in either order.  Three ranks, sac: gloo's ring order is not the rank order -- replicas identical, states equal to 1e-6.)"""
+@pytest.mark.parametrize('case,world', [('vlsac_tiny', 2), ('spedersac_tiny', 2), ('ctrlsac_tiny', 2), ('sac_tiny', 3), ('spedersac_tiny', 3), ('ctrlsac_tiny', 3)])
+def test_train_with_exchanges_inside_the_launches_equals_gloo(case, world):
+    """Eager step programs, injected draws: every gradient slice summed inside its optimizer launch AND the batch-coupled exchanges of the
+    feature step inside the step program (spedersac: Phibar / v pushed by the column-sum launches and summed by their consumers; ctrlsac: one pull
+    launch each for the all-gather of mu(s') and the reduce-scatter of its gradient) ends in EXACTLY the state of the same run with
+    torch.distributed collectives between the launches, summed in rank order -- bit for bit with two and with three ranks; replicas bit-identical."""
     out = {}
     for fused in (True, False):
-        res = _spawn('_agent_body', world, case, fused, False, 2)
+        res = _spawn('_agent_body', world, case, fused, False, 2, False, '', True)
         for r in range(1, world):
             for k, v in res[0][0].items():
                 assert np.array_equal(v, res[r][0][k]), f'replicas diverged at {k} (fused={fused}, rank {r})'
         out[fused] = res[0]
     assert out[True][2], 'no group was attached'
+    assert out[True][3] == 0, 'a batch-coupled exchange was left outside the launches'
+    if case.startswith(('spedersac', 'ctrlsac')):
+        assert out[False][3] > 0
     for k, v in out[True][0].items():
-        if world == 2:
-            assert np.array_equal(v, out[False][0][k]), f'in-launch exchange != gloo at {k}'
-        else:
-            assert np.allclose(v, out[False][0][k], rtol=1e-5, atol=1e-6), k
+        assert np.array_equal(v, out[False][0][k]), f'in-launch exchanges != rank-ordered gloo at {k}'
+
+
+@pytest.mark.parametrize('case', ['sac_tiny', 'vlsac_tiny'])
+def test_two_shot_in_the_optimizer_launch_is_the_rank_ordered_sum_bit_for_bit(case):
+    """Three ranks: the two-shot form inside the optimizer launches (forced for every slice: RLREP_ENABLE=dp_two_shot_kb=0.001 -- reduce-scatter
+    into the reduced region, RED handshake, all-gather from the shards' owners) == the one-shot pull == gloo summed in rank order."""
+    world, out = 3, {}
+    for form, (fused, enable) in (('two_shot', (True, 'dp_two_shot_kb=0.001')), ('one_shot', (True, 'dp_two_shot_kb=0')), ('gloo', (False, ''))):
+        res = _spawn('_agent_body', world, case, fused, False, 3, False, enable, True)
+        for r in range(1, world):
+            for k, v in res[0][0].items():
+                assert np.array_equal(v, res[r][0][k]), f'replicas diverged at {k} ({form}, rank {r})'
+        out[form] = res[0][0]
+    for form in ('one_shot', 'gloo'):
+        for k, v in out['two_shot'].items():
+            assert np.array_equal(v, out[form][k]), f'two-shot != {form} at {k}'
+
+
+@pytest.mark.parametrize('case,world,pipeline', [('spedersac_ant512', 2, True), ('ctrlsac_hc256', 2, True), ('vlsac_hc', 3, False)])
+def test_default_graph_forms_with_exchanges_inside_equal_rank_ordered_gloo_segments(case, world, pipeline):
+    """BASELINE's configs 4 / 3 / 2 at their dimensions, data parallel, DEFAULT train(): with every exchange inside the launches the agents take
+    the single-GPU graph forms (two chains on two streams: spedersac and ctrlsac keep their deferred step programs now) and end in exactly the
+    state of graph segments around gloo collectives summed in rank order.  vlsac_hc with three ranks: its 1.93 MB feature slice and 1.05 MB
+    critic slice take the two-shot form inside the optimizer launch -- as ONE graph per train() (RLREP_PIPELINE=0): three ranks share the test
+    box's one GPU, and the waiting blocks of three ranks' two chains (3 x (472 + 265) of 1 280 resident) would leave no room for the launches
+    they wait for; between GPUs every rank has a chip of its own (csrc/dp_pull.h, "Progress with SEVERAL channels in flight")."""
+    out = {}
+    for form, fused in (('fused', True), ('segments', False)):
+        res = _spawn('_agent_body', world, case, fused, True, 5, False, '', True, pipeline, timeout=300)
+        for r in range(1, world):
+            for k, v in res[0][0].items():
+                assert np.array_equal(v, res[r][0][k]), f'replicas diverged at {k} ({form}, rank {r})'
+        out[form] = res[0]
+    assert out['fused'][1] == ('pipe' if pipeline else 'graph'), out['fused'][1]
+    assert out['fused'][3] == 0 and out['segments'][1].startswith('segments:'), (out['fused'][3], out['segments'][1])
+    for k, v in out['fused'][0].items():
+        assert np.array_equal(v, out['segments'][0][k]), f'exchanges inside the launches != rank-ordered gloo segments at {k}'
 
 
 @pytest.mark.parametrize('case', ['vlsac_tiny', 'vlsac_hc'])
