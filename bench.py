@@ -253,7 +253,7 @@ FAMILIES = {
     'gemm_x3': ((5,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^gemm_x3(s|t|w)?_kernel',
                 'gemm_x3w_kernel (256 x 128, persistent) + gemm_x3_kernel / gemm_x3t_kernel (128-wide) + gemm_x3s_kernel (64-wide): tiles on the bf16 pipe, exact 3-way split: peak = dense bf16 peak / 6 executed flops per product'),
     'noise_critic': ((6,), 'mfma', BF16_MFMA_PEAK_TFLOPS / 6.0, 'TFLOP/s', r'^nc_', 'nc_fwd / nc_dx / nc_dw kernels (vlsac noise critic, bf16x3: peak = dense bf16 peak / 6)'),
-    'optimizer': ((7,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^adam_(l1_)?kernel', 'adam_kernel / adam_l1_kernel (Adam + Polyak + metrics + riders: 28 B per parameter + 12 B per target element)'),
+    'optimizer': ((7,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^(void )?adam_(l1_|dp_)?kernel', 'adam_kernel / adam_l1_kernel / adam_dp_kernel (Adam + Polyak + metrics + riders: 28 B per parameter + 12 B per target element)'),
     'score': ((8,), 'hbm', HBM_PEAK_GBS, 'GB/s', r'^diffsr_score', 'diffsr_score kernels (one pass over the [B, F*S] tensor)'),
     'other': ((0,), None, None, None, r'.*', 'losses, gathers, copies (elementwise + wave reductions)'),
 }
@@ -505,14 +505,17 @@ def main():
                          '(SURVEY.md 8e; BASELINE configs 4 and 5 name a total batch on 4 / 8 GPUs)')
     ap.add_argument('--replicas', action='store_true',
                     help='N > 1: N independent agents (own parameters, own replay, NO gradient all-reduce) instead of data-parallel training')
-    ap.add_argument('--dp-form', choices=['segments', 'captured'], default=None,
-                    help='N > 1 on RCCL: hipGraph segments around eager all-reduces (default: the form the two-rank tests run) or the all-reduces '
-                         'captured into the train() graph (RLREP_DP_CAPTURE=1; rehearsed with one rank only).  Read before any GPU call.')
+    ap.add_argument('--dp-form', choices=['fused', 'segments', 'captured', 'captured_two_chain'], default=None,
+                    help='N > 1: run ONLY this data-parallel form.  fused: every exchange inside the launches (csrc/dp_pull.h); segments: hipGraph segments '
+                         'around eager collectives; captured: the RCCL all-reduces captured into the train() graph; captured_two_chain: the same on the two '
+                         'chains with one communicator each (vlsac).  Default: --dp-sweep.')
+    ap.add_argument('--dp-sweep', choices=['safe', 'all'], default='safe',
+                    help='N > 1 without --dp-form: the forms that are timed, each over the whole warm-up + --steps protocol with a replicas_identical '
+                         'check; `value` is the fastest one whose replicas stayed identical, all are listed in `dp_forms`.  safe: fused + segments (bounded '
+                         'waits / eager collectives); all: + the captured RCCL forms (rehearsed with one rank only: a hang there is RCCL\'s to time out)')
     ap.add_argument('--quick', action='store_true', help='only the warm-up and the --steps window (no median repeats, no add / metric-fetch / main-loop legs): profiler runs')
     ap.add_argument('--pmc-json', default=None, help='PMC summary to take roofline.traffic from (default: the latest profiles/r*_pmc_<workload>.json)')
     args = ap.parse_args()
-    if args.dp_form is not None:
-        os.environ['RLREP_DP_CAPTURE'] = '1' if args.dp_form == 'captured' else '0'
     under_profiler = args.no_profile or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
     clock_helper = _spawn_clock_probe(under_profiler) if (args.gpus == 1 and int(os.environ.get('RANK', 0)) == 0) else None
 
@@ -566,16 +569,8 @@ def main():
         import rlrep_amd.agent.sac.sac_agent as _sa
         _sa._world = lambda: (1, 0)
         torch.manual_seed(rank)
-    agent = make_agent(alg, S, A, B, kw)
     buf, data = synth_buffer(S, A, seed=rank)
-    # every train() call of this process is counted: a rocprofv3 kernel-stats / PMC table of the same command divides its `Calls` by it
     n_calls = [0]
-    _train = agent.train
-
-    def _counted(*a, **k):
-        n_calls[0] += 1
-        return _train(*a, **k)
-    agent.train = _counted
 
     def barrier():
         torch.cuda.synchronize()
@@ -583,23 +578,98 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def replicas_check(agent):
+        """parameter / target arenas and the fp64 temperature state equal on every rank: wrap-around int64 sums of the bit patterns, max == min"""
+        agent.flush()
+        torch.cuda.synchronize()
+        chk = torch.stack([agent.core.params.view(torch.int32).to(torch.int64).sum(), agent.core.targets.view(torch.int32).to(torch.int64).sum(),
+                           agent.core.alpha_state.view(torch.int64).sum()]).to(torch.float64)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        return bool((hi == lo).all().item())
+
     # untimed: the W warm-up steps the caller asked for, and at least ~0.15 s of train() calls on top (graph instantiation, the two-stream
     # pipeline's probe, the clock ramp: with the driver's W = 5 the 20-step window otherwise sits 6 % below the steady state)
     extra = max(0, (300 if alg in ('vlsac', 'sac', 'ctrlsac') and B <= 256 else 10) - args.warmup)
-    for _ in range(args.warmup + extra):
-        agent.train(buf, B)
-    agent.flush()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        agent.train(buf, B)
-    agent.flush()           # pipelined graph mode: the last train()'s critic / actor steps belong inside the timed window
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+
+    def build_and_time(form):
+        """One agent in data-parallel form `form` (None: whatever the environment says), the driver's protocol: W (+ extra) untimed calls, then
+        EXACTLY --steps calls between barriers, the MAX over ranks."""
+        if form is not None:
+            os.environ['RLREP_DP_FUSED'] = '1' if form == 'fused' else '0'
+            os.environ['RLREP_DP_CAPTURE'] = '1' if form in ('captured', 'captured_two_chain') else '0'
+            os.environ['RLREP_PIPELINE_DP'] = '1' if form == 'captured_two_chain' else '0'
+        torch.manual_seed(rank if replicas else 0)
+        agent = make_agent(alg, S, A, B, kw)
+        # every train() call of this process is counted: a rocprofv3 kernel-stats / PMC table of the same command divides its `Calls` by it
+        _train = agent.train
+
+        def _counted(*a, **k):
+            n_calls[0] += 1
+            return _train(*a, **k)
+        agent.train = _counted
+        for _ in range(args.warmup + extra):
+            agent.train(buf, B)
+        agent.flush()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            agent.train(buf, B)
+        agent.flush()           # pipelined graph mode: the last train()'s critic / actor steps belong inside the timed window
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return agent, dt
+
+    def form_of(agent):
+        """what the agent actually runs (the fused form falls back to torch.distributed when its probe fails on this set of ranks)"""
+        if getattr(agent, '_fused_all', False):
+            return 'fused'
+        if getattr(agent, '_pipe', None) is not None and agent._pipe.get('mode') == 3:
+            return 'captured_two_chain'
+        if getattr(agent, '_seg_capture_colls', False):
+            return 'captured'
+        return 'segments' if isinstance(getattr(agent, '_graph', None), list) else ('fused+' if getattr(agent.core, 'fused_groups', None) else 'eager')
+
+    dp_forms = None
+    if dist is not None and world > 1 and not replicas and not force_dp:
+        # N > 1: every available data-parallel form over the whole protocol (VERDICT r05 item 1d); `value` = the fastest one whose replicas are identical
+        nccl = dist.get_backend() == 'nccl'
+        if 'dp_timeout_s' not in os.environ.get('RLREP_ENABLE', ''):          # (a form that stalls on this node must fail within the bench's minutes)
+            os.environ['RLREP_ENABLE'] = ','.join(t for t in (os.environ.get('RLREP_ENABLE', ''), 'dp_timeout_s=30') if t)
+        forms = [args.dp_form] if args.dp_form else (['fused', 'segments'] + (['captured'] + (['captured_two_chain'] if alg == 'vlsac' else []) if (nccl and args.dp_sweep == 'all') else []))
+        dp_forms, best = [], None
+        for form in forms:
+            rec = {'form': form}
+            agent_f, dt_f, ok = None, None, True
+            try:
+                agent_f, dt_f = build_and_time(form)
+                rec['ran_as'] = form_of(agent_f)
+                rec['replicas_identical'] = replicas_check(agent_f)
+            except Exception as e:          # noqa: BLE001  (every rank must drop the form together: agreed below)
+                ok, rec['error'] = False, f'{type(e).__name__}: {str(e)[:200]}'
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cuda' if nccl else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+            if ok:
+                rec.update(value=round((1 if args.scaling == 'strong' else world) * args.steps / dt_f, 2), ms_per_step=round(dt_f / args.steps * 1e3, 4),
+                           fused_groups=sorted(agent_f.core.fused_groups) if getattr(agent_f.core, 'fused_groups', None) else None)
+                if rec['replicas_identical'] and (best is None or dt_f < best[1]):
+                    best = (agent_f, dt_f, form)
+            elif 'error' not in rec:
+                rec['error'] = 'failed on another rank'
+            dp_forms.append(rec)
+        if best is None:
+            raise SystemExit('bench: no data-parallel form completed with identical replicas: ' + json.dumps(dp_forms))
+        agent, dt = best[0], best[1]
+        for d in dp_forms:
+            d['chosen'] = d['form'] == best[2]
+    else:
+        agent, dt = build_and_time(args.dp_form if (dist is not None and args.dp_form) else None)
     # SURVEY 8(d): median of 5 repeats.  The --steps window above is what `value` reports (the driver's contract: EXACTLY K steps); a short
     # window (the driver's 20 steps = 7 ms) is noisy by construction, so the same loop is also timed as 5 repeats of `rep_len` calls and the
     # median reported beside it.  The shader clock is sampled by rocm-smi WHILE those repeats run.
@@ -667,15 +737,7 @@ def main():
     # all-reduces of one train() cost when nothing else runs
     replicas_identical, allreduce_us = None, None
     if dist is not None and not replicas:
-        agent.flush()
-        torch.cuda.synchronize()
-        # checksum of the parameter / target arenas and the fp64 temperature state: wrap-around int64 sum of the bit patterns
-        chk = torch.stack([agent.core.params.view(torch.int32).to(torch.int64).sum(), agent.core.targets.view(torch.int32).to(torch.int64).sum(),
-                           agent.core.alpha_state.view(torch.int64).sum()]).to(torch.float64)
-        hi, lo = chk.clone(), chk.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        replicas_identical = bool((hi == lo).all().item())
+        replicas_identical = replicas_check(agent)
         colls = [x for kind, x in (agent._graph or []) if kind == 'coll'] if isinstance(getattr(agent, '_graph', None), list) else []
         if colls:
             for fn in colls:
@@ -726,6 +788,9 @@ def main():
             'replicas_identical': replicas_identical,
             'allreduce_us_per_train': (round(allreduce_us, 1) if allreduce_us is not None else None),
             'dp_fused_groups': (sorted(agent.core.fused_groups) if getattr(agent.core, 'fused_groups', None) else None),
+            # N > 1: every data-parallel form that was timed over the same protocol (form asked for, form actually run, value, replicas_identical);
+            # `value` above is the chosen one -- the fastest with identical replicas
+            'dp_forms': dp_forms,
             'optimizer_steps_per_sec': round(value * OPT_STEPS[alg], 1),
             'samples_per_sec': round(value * B_global if strong else value * B, 1),
             'metrics_finite': bool(finite),

@@ -372,10 +372,12 @@ int32_t rlrep_comm_allreduce(rlrep_comm* comm, int64_t block_offset_floats, int6
 int32_t rlrep_comm_allgather(rlrep_comm* comm, int64_t block_offset_floats, int64_t n_per_rank, void* stream);
 int32_t rlrep_comm_probe_fill(rlrep_comm* comm, int64_t block_offset_floats, int64_t n, int32_t round, void* stream);
 float rlrep_comm_probe_value(int32_t rank, int32_t round, int64_t i);
+int32_t rlrep_comm_probe_slots(rlrep_comm* comm, int64_t n, int32_t round, float* out_dev, int64_t timeout_us, void* stream);
 int32_t rlrep_comm_status(rlrep_comm* comm, uint32_t* late_mask, int32_t clear);
 int32_t rlrep_comm_fine_grained(rlrep_comm* comm);
-/* debug / measurement only: mark every peer as arrived for the NEXT epoch of `channel` in this rank's flags (one stream then plays several ranks in turn) */
-int32_t rlrep_comm_debug_preset(rlrep_comm* comm, int32_t channel);
+/* debug / measurement only: mark every peer as arrived for the next `ahead` epochs of `channel` in this rank's flags (one stream then plays several ranks
+ * in turn; 1 << 30: one attached replica runs alone and pays the protocol, not the waiting -- tools/exp/dp_loopback.py) */
+int32_t rlrep_comm_debug_preset(rlrep_comm* comm, int32_t channel, int32_t ahead);
 void rlrep_comm_destroy(rlrep_comm* comm);
 
 /* vlsac noise-critic weight images (bf16x3 shadows of critic.l1 / l4 and their targets; no reference counterpart: nn.Linear has no such
@@ -423,7 +425,8 @@ int32_t rlrep_stage_info(rlrep_agent* agent, int32_t program, int32_t stage, int
  *   (bf16x3: three-way operand split, six MFMAs, fp32 accuracy); bt (0 auto, 64, 128; with engine 2 also 256 = the persistent
  *   256 x 128 tile, which has no sin / tanh epilogue) and splits
  *   (0 auto) override the LDS engine's plan; workspace holds its split-K slabs (splits*R*(Cn+1) floats), which a finishing launch adds
- *   in split order.
+ *   in split order -- or, with flags & 4 on the 64-wide bf16x3 tile (engine 2, bt 64), the last split workgroup of every output tile
+ *   (a ticket word per tile behind the slabs: + ceil(R/64)*ceil(Cn/64) floats of workspace), bit-identically and without a second launch.
  * Returns 0, or RLREP_ERR_ARG when the engine cannot run the shape (alignment rules in gemm_lds.hip). */
 int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* a_dev, int32_t lda, const float* b_dev, int32_t ldb,
                    float* c_dev, int32_t ldc, int32_t rows, int32_t cols, int32_t inner, int32_t epi, int32_t act, int32_t flags,

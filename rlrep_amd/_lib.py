@@ -135,9 +135,10 @@ def _load():
         'rlrep_comm_allgather': (i32, [vp, i64, i64, vp]),
         'rlrep_comm_probe_fill': (i32, [vp, i64, i64, i32, vp]),
         'rlrep_comm_probe_value': (f32, [i32, i32, i64]),
+        'rlrep_comm_probe_slots': (i32, [vp, i64, i32, vp, i64, vp]),
         'rlrep_comm_status': (i32, [vp, P(C.c_uint32), i32]),
         'rlrep_comm_fine_grained': (i32, [vp]),
-        'rlrep_comm_debug_preset': (i32, [vp, i32]),
+        'rlrep_comm_debug_preset': (i32, [vp, i32, i32]),
         'rlrep_comm_destroy': (None, [vp]),
         'rlrep_stage_count': (i32, [vp, i32]),
         'rlrep_stage_name': (C.c_char_p, [vp, i32, i32]),

@@ -476,6 +476,18 @@ class SACAgent(object):
     def _feature_iters(self):
         return 0
 
+    def _stream_pair(self):
+        """The two streams of the two-chain train().  Several replicas inside one process (loopback) take disjoint pairs of ONE set of mutually
+        concurrent streams, found by trial (rlrep_amd/comm.py concurrent_streams): a replica's optimizer launch waits on the device for its
+        peers', which must not be queued behind it."""
+        if getattr(self, '_stream_pair_override', None) is not None:
+            return self._stream_pair_override
+        if self._loopback is not None:
+            from rlrep_amd.comm import concurrent_streams
+            ss = concurrent_streams(2 * self.world_size)
+            return ss[2 * self.rank], ss[2 * self.rank + 1]
+        return _concurrent_stream_pair(self.core)
+
     def _feature_once(self, buffer, B, i, g):
         raise NotImplementedError
 
@@ -963,7 +975,7 @@ class SACAgent(object):
                     P['launches'] = ((n1 - n0) // nset, (_l.rlrep_launch_counter() - n1) // nset)      # kernels in the feature / critic+actor graph
                     f1 = _fe()
                     P['front_ends'] = {k: (f1[k] - f0[k]) // nset for k in f1}      # 16-row tile engine launches of one train() per front end
-                    s_ca, s_f = _concurrent_stream_pair(c, self.rank if self._loopback is not None else 0)
+                    s_ca, s_f = self._stream_pair()
                     P.update(fs=fs, ca=ca, s_ca=s_ca, s_f=s_f, nset=nset, ev_snap=[torch.cuda.Event() for _ in range(nset)],
                              ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
                 self._pipe = P
@@ -1078,7 +1090,7 @@ class SACAgent(object):
                         cs.append(self._capture_segments(ca_chain))
                 torch.cuda.current_stream().wait_stream(cap)
                 torch.cuda.synchronize()
-                s_ca, s_f = _concurrent_stream_pair(c, self.rank if self._loopback is not None else 0)
+                s_ca, s_f = self._stream_pair()
                 self._pipe = dict(key=key, mode=3, t=0, nset=nset, host_wait=nset == 3, fs=fs, cs=cs, s_ca=s_ca, s_f=s_f,
                                   ev_snap=[torch.cuda.Event() for _ in range(nset)], ev_ca=[torch.cuda.Event() for _ in range(nset)], used=[False] * nset)
         P = self._pipe

@@ -51,6 +51,13 @@ class _ExchangeBase:
         """block[offset + q n .. + n) of every rank q into every rank's block (one pull launch on the current stream)."""
         check(lib.rlrep_comm_allgather(self.h, int(offset), int(n), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_allgather')
 
+    def probe_slots(self, n, rnd, out=None, timeout_us=0):
+        """The pushed-slot exchange on the pattern of round `rnd` (two launches on the current stream) -> out[0 .. n) = rank-ordered sum."""
+        if out is None:
+            out = torch.empty(int(n), dtype=torch.float32, device=self.arena.device)
+        check(lib.rlrep_comm_probe_slots(self.h, int(n), int(rnd), C.c_void_p(out.data_ptr()), int(timeout_us), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_probe_slots')
+        return out
+
     def probe_fill(self, offset, n, rnd):
         check(lib.rlrep_comm_probe_fill(self.h, int(offset), int(n), int(rnd), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'comm_probe_fill')
 
@@ -158,6 +165,7 @@ class GradientExchange(_ExchangeBase):
         so no rank can be left waiting in one); returns True only if EVERY rank saw everything right and no wait ran out."""
         n = int(min(self.arena_floats, n or (1 << 18))) & ~3
         ok = self.usable
+        tmo = 10_000_000        # every wait of the probe is bounded by ten seconds (a node where it fails must fall back within the minute)
 
         def step(fn):
             """run fn on every rank that is still good; all ranks then agree (one collective per step, always executed)"""
@@ -185,7 +193,7 @@ class GradientExchange(_ExchangeBase):
             step(fill)                                 # (every rank's pattern is in its arena before anybody reads it: this form has no producer launch in front)
 
             def pull(r=r):
-                got = self.all_reduce(0, n, mode=1).cpu().numpy()
+                got = self.all_reduce(0, n, mode=1, timeout_us=tmo).cpu().numpy()
                 if not np.array_equal(got, want(r, self._pattern)):
                     self.error = self.error or f'probe round {r}: the exchange did not return the rank-ordered sum (host-filled arena)'
                     return False
@@ -204,7 +212,7 @@ class GradientExchange(_ExchangeBase):
                     try:
                         for r in range(rounds):
                             self.probe_fill(0, n, 100 * mode + r)          # producer: an ordinary kernel writes this rank's pattern ...
-                            self.all_reduce(0, n, out=outs[r], mode=mode)  # ... and the NEXT node pulls (no host in between)
+                            self.all_reduce(0, n, out=outs[r], mode=mode, timeout_us=tmo)  # ... and the NEXT node pulls (no host in between)
                     finally:
                         g.capture_end()
                 torch.cuda.current_stream().wait_stream(s)
@@ -221,6 +229,21 @@ class GradientExchange(_ExchangeBase):
                         return False
             step(replay)
             self._probe_graph = None
+
+        ns = min(512, self.scratch_floats // (2 * self.world)) if self.scratch_floats else 0
+        if ns >= 64:
+            # (3) the PUSHED exchange (spedersac's Phibar / v): producer launch stores into every rank's slots, the next launch sums its own block's
+            def slots():
+                outs = [self.probe_slots(ns, 300 + r, timeout_us=tmo) for r in range(rounds + 1)]      # (rounds + 1: both parities twice)
+                torch.cuda.synchronize()
+                for r, o in enumerate(outs):
+                    w = self.probe_pattern(0, 300 + r, ns).copy()
+                    for q in range(1, self.world):
+                        w = w + self.probe_pattern(q, 300 + r, ns)
+                    if not np.array_equal(o.cpu().numpy(), w):
+                        self.error = self.error or f'probe: pushed-slot exchange, round {r}: not the rank-ordered sum'
+                        return False
+            step(slots)
 
         def finish():
             if self.status(raise_on_error=False) != 0:
@@ -296,3 +319,42 @@ class LoopbackExchange(_ExchangeBase):
 
     def probe(self, *a, **k):
         return True                         # (same device, plain pointers: nothing to find out; tests/test_comm.py checks the arithmetic)
+
+
+_CONCURRENT = {}
+
+
+def concurrent_streams(n, tries=48):
+    """`n` torch streams of the current device that really run side by side.  HIP maps streams onto a few hardware queues and two streams
+    that share one are serialised; a launch that WAITS on the device for a launch queued behind it in the same queue never ends.  Found by
+    trial, not by timing: a two-rank exchange (one rank per stream, 20 ms bound) completes only if the two streams are concurrent.  The set
+    is kept for the life of the process; raises if the runtime does not have `n` concurrent queues (this image: four per process)."""
+    dev = torch.cuda.current_device()
+    kept = _CONCURRENT.setdefault(dev, [])
+    if len(kept) >= n:
+        return kept[:n]
+    grp = LoopbackGroup(2, 64)
+    try:
+        def together(a, b):
+            for first, second in ((a, b), (b, a)):
+                with torch.cuda.stream(first):
+                    grp[0].all_reduce(0, 4, mode=1, timeout_us=20000)
+                with torch.cuda.stream(second):
+                    grp[1].all_reduce(0, 4, mode=1, timeout_us=20000)
+                torch.cuda.synchronize()
+                bad = grp[0].status(raise_on_error=False, clear=True) | grp[1].status(raise_on_error=False, clear=True)
+                if bad:
+                    return False
+            return True
+        if not kept:
+            kept.append(torch.cuda.Stream())
+        while len(kept) < n and tries > 0:
+            tries -= 1
+            cand = torch.cuda.Stream()
+            if all(together(k, cand) for k in kept):
+                kept.append(cand)
+    finally:
+        grp.close()
+    if len(kept) < n:
+        raise RuntimeError(f'rlrep_amd: found only {len(kept)} mutually concurrent HIP streams, {n} are needed (hardware queues per process: GPU_MAX_HW_QUEUES)')
+    return kept[:n]

@@ -12,8 +12,9 @@ int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st);
 int rl_launch_diffsr_score(const DiffsrScore* p, hipStream_t st);
 int rl_launch_copy2(const float* src, float* d1, float* d2, long long n, hipStream_t st);
 // comm.hip: ctrlsac's batch-coupled exchanges as launches of the step program (attached agents)
-int rl_launch_xchg_gather(const DpPull* proto, int channel, long long off, long long n, hipStream_t st);
-int rl_launch_xchg_reduce(const DpPull* proto, int channel, long long off, long long n, float* out, int two_shot, hipStream_t st);
+int rl_launch_xchg_gather(const DpPull* proto, int channel, long long off, long long n, int no_done, hipStream_t st);
+int rl_launch_xchg_reduce(const DpPull* proto, int channel, long long off, long long n, float* out, int two_shot, int no_done, hipStream_t st);
+int rl_launch_slots_sum(const DpSlots* d, float* out, hipStream_t st);
 }
 
 // ================================================================================================
@@ -240,7 +241,9 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         // quirk Q6: the score matrix is the GEMM phi mu'^T, not the [B,B,F] broadcast
         if (xf) {
             const long long off = ag->xarena_floats, nseg = (long long)B * F;
-            p.stages.push_back({[=](hipStream_t st) { return rl_launch_xchg_gather(&agp->dp_proto, 4, off, nseg, st); }, "all-gather mu(s') (pull)"});
+            // (no DONE round trip in either exchange launch: this rank's mu(s') rows are next written a whole feature step later, behind the reduce-scatter
+            //  below, whose READY a peer sends only after its gather has completed; and its dmu'_all behind the NEXT step's gather, likewise)
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_xchg_gather(&agp->dp_proto, 4, off, nseg, 1, st); }, "all-gather mu(s') (pull)"});
         } else
         if (Wd > 1) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 1, ZMall, (int64_t)B * F, (int64_t)rank * B * F});
         // rhat = theta . phi + b (a [B, 1] product) is computed by the InfoNCE launch itself: beside a score matrix that routes to the LDS-tiled engine it was a
@@ -261,19 +264,19 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
             GemmTask u = Builder::base();     // dmu'[j,f] = (sum_i dS[i,j] phi[i,f]) * (1 - mu'^2)
             u.A = Sx; u.lda = WB; u.B = pf.Z; u.ldb = F; u.C = GZMall; u.ldc = F; u.R = WB; u.Cn = F; u.K = B;
             u.epi = EPI_DX; u.act = ACT_TANH; u.aux = ZMall; u.ldaux = F;
-            if (Wd > 1) {          // data parallel: the all-reduce of dmu'_all sits right behind its own stage
+            if (Wd > 1 && !xf) {          // data parallel over torch.distributed: the all-reduce of dmu'_all sits right behind its own stage
                 b.dx_stage(p, {t}, "dphi = dS mu' + drhat theta");
                 b.gemm(p, LD_COL, LD_COL, {u}, "dmu'_all = dS^T phi");
-                if (xf) {
-                    // this rank needs only ITS rows of the sum: a reduce-scatter, in place (peers read their own rows of this block)
-                    const long long off = ag->xarena_floats + (long long)WB * F + (long long)rank * B * F, nseg = (long long)B * F;
-                    float* out = GZM;
-                    p.stages.push_back({[=](hipStream_t st) { return rl_launch_xchg_reduce(&agp->dp_proto, 5, off, nseg, out, 0, st); }, "reduce-scatter dmu' (pull)"});
-                } else
                 ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, GZMall, (int64_t)WB * F, 0});
             } else {
                 // both products consume the InfoNCE gradient dS and nothing of each other: ONE launch of two tile forms (gemm16_duo_kernel)
                 b.gemm_duo(p, {t}, {u}, "dphi = dS mu' + drhat theta", "dmu'_all = dS^T phi", "dphi = dS mu' + drhat theta | dmu'_all = dS^T phi");
+                if (xf) {
+                    // this rank needs only ITS rows of the sum: a reduce-scatter, in place (peers read their own rows of this block)
+                    const long long off = ag->xarena_floats + (long long)WB * F + (long long)rank * B * F, nseg = (long long)B * F;
+                    float* out = GZM;
+                    p.stages.push_back({[=](hipStream_t st) { return rl_launch_xchg_reduce(&agp->dp_proto, 5, off, nseg, out, 0, 1, st); }, "reduce-scatter dmu' (pull)"});
+                }
             }
         }
         b.dx_stage(p, {Builder::dx(pf.GZ, F, B, F, Pw("phi.l3.weight"), Hp, pf.G2, Hp, Hp, ACT_ELU, pf.P2, Hp),
@@ -518,7 +521,7 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
     float* PHI = pf.act[phi.depth]; float* MU = mf.act[mu.depth];
     float* PHIBAR = ws.f(F); float* V = ws.f(F); float* C = ws.f(B); float* DRH = ws.f(B);
     // attached (rlrep_comm_attach with exchange scratch): Phibar and v are sums over the GLOBAL random batch -- the colsum launches push this rank's
-    // partial into every rank's slot area, the launches that consume them sum the partials in rank order (dp_pull.h DpSlots): zero extra launches
+    // partial into every rank's slot area (dp_pull.h DpSlots), a one-block launch behind each waits for all ranks and files the rank-ordered sum
     const int Wd = ag->h.world_size > 1 ? ag->h.world_size : 1;
     const int Fp = (F + 63) & ~63;
     const bool xf = ag->xfold && Wd > 1 && F <= RL_SLOTS_MAX_F && 4ll * Wd * Fp <= ag->xscratch_floats;
@@ -539,8 +542,11 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c1, st); }, "Phibar = colsum phi_r"});
         // data parallel: Phibar and v are sums over the GLOBAL "random" batch: two F-float all-reduces
         if (ag->h.world_size > 1 && !xf) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, PHIBAR, (int64_t)F, 0});
+        if (xf) {
+            const DpSlots sl = ag->slots(4, 0, Fp);
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_slots_sum(&sl, PHIBAR, st); }, "Phibar over all ranks (pushed slots)"});
+        }
         SpederRows sr; memset(&sr, 0, sizeof(sr));
-        if (xf) { sr.dp = ag->slots(4, 0, Fp); sr.phibar_out = PHIBAR; }
         sr.phi = PHI; sr.mu = MU; sr.mu_r = MU ? MU + BF : nullptr; sr.phibar = PHIBAR; sr.theta_w = ag->P("theta.l.weight"); sr.theta_b = ag->P("theta.l.bias");
         sr.r = s0.R; sr.c = C; sr.drhat = DRH; sr.partial = part_f; sr.B = B; sr.F = F; sr.nblk = nblk_f; sr.inv_batch = ag->inv_batch(); sr.step = ag->adam_step + 0;
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_speder_rows(&sr, st); }, "speder rows (c, d, rhat)"});
@@ -553,8 +559,11 @@ void build_spedersac(Builder& b, rlrep_agent* ag) {
         if (theta_here) { c2.X2 = PHI; c2.ldX2 = F; c2.w2 = DRH; c2.out2 = ag->G("theta.l.weight"); c2.outb2 = ag->G("theta.l.bias"); c2.rows2 = B; }
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_colsum(&c2, st); }, "v = sum_k c_k mu_r,k"});
         if (ag->h.world_size > 1 && !xf) ag->feat_cuts.push_back({(int)p.stages.size() - 1, 2, V, (int64_t)F, 0});
+        if (xf) {
+            const DpSlots sl = ag->slots(5, 2ll * Wd * Fp, Fp);
+            p.stages.push_back({[=](hipStream_t st) { return rl_launch_slots_sum(&sl, V, st); }, "v over all ranks (pushed slots)"});
+        }
         SpederGrads sg; memset(&sg, 0, sizeof(sg));
-        if (xf) sg.dp = ag->slots(5, 2ll * Wd * Fp, Fp);
         sg.phi = PHI; sg.mu = MU; sg.c = C; sg.drhat = DRH; sg.phibar = PHIBAR; sg.v = V; sg.theta_w = ag->P("theta.l.weight");
         sg.Gphi = pf.g[phi.depth]; sg.Gmu = mf.g[mu.depth]; sg.B = B; sg.F = F; sg.inv_batch = ag->inv_batch();
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_speder_grads(&sg, st); }, "speder grads"});

@@ -103,18 +103,37 @@ __global__ __launch_bounds__(256) void comm_fill_kernel(float* __restrict__ aren
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) arena[off + i] = comm_pattern(rank, round, i);
 }
 
-extern "C" int rl_launch_xchg_gather(const DpPull* proto, int channel, long long off, long long n, hipStream_t st) {
+// the pushed-slot exchange (dp_pull.h DpSlots: spedersac's Phibar / v) as a stand-alone producer / consumer pair -- the probe's third form
+__global__ __launch_bounds__(256) void comm_slots_put_kernel(DpSlots d, int rank, int round) {
+    const unsigned e = dp_slots_epoch(d);
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < d.n; f += gridDim.x * 256) dp_slots_put(d, e, f, comm_pattern(rank, round, f));
+    dp_slots_publish(d, e);
+}
+__global__ __launch_bounds__(256) void comm_slots_sum_kernel(DpSlots d, float* __restrict__ out) {
+    dp_slots_sum(d, out);         // (one block: every thread of it takes part in the barriers inside)
+}
+
+// the consumer half of a pushed exchange as a stage of a step program (spedersac: Phibar, v): out[0 .. d.n) = rank-ordered sum of the slots
+extern "C" int rl_launch_slots_sum(const DpSlots* d, float* out, hipStream_t st) {
+    if (!d || d->world < 2 || !out || d->n <= 0) return -7;
+    hipLaunchKernelGGL(comm_slots_sum_kernel, dim3(1), dim3(256), 0, st, *d, out);
+    return (int)hipGetLastError();
+}
+
+// no_done (both launchers): see DpPull::no_done -- ctrlsac's step program alternates gather and reduce-scatter on two channels; a peer's READY for one
+// is sent after it has completed the other (stream order), so neither needs its own DONE round trip
+extern "C" int rl_launch_xchg_gather(const DpPull* proto, int channel, long long off, long long n, int no_done, hipStream_t st) {
     if (!proto || proto->world < 2 || (off & 3) || (n & 3) || n <= 0) return -7;
-    DpPull d = *proto; d.channel = channel; d.mode = 1;
+    DpPull d = *proto; d.channel = channel; d.mode = 1; d.no_done = no_done;
     const long long want = (n / 4 * d.world + 255) / 256;
     d.nblocks = (int)(want < 1 ? 1 : (want > 512 ? 512 : want));
     hipLaunchKernelGGL(comm_gather_kernel, dim3(d.nblocks), dim3(256), 0, st, d, off, n);
     return (int)hipGetLastError();
 }
 // out (device, may alias this rank's block at `off`) = rank-ordered sum of every rank's block[off .. off + n)
-extern "C" int rl_launch_xchg_reduce(const DpPull* proto, int channel, long long off, long long n, float* out, int two_shot, hipStream_t st) {
+extern "C" int rl_launch_xchg_reduce(const DpPull* proto, int channel, long long off, long long n, float* out, int two_shot, int no_done, hipStream_t st) {
     if (!proto || proto->world < 2 || n <= 0 || !out) return -7;
-    DpPull d = *proto; d.channel = channel;
+    DpPull d = *proto; d.channel = channel; d.no_done = no_done && !two_shot;
     const bool two = two_shot && d.world >= 3 && d.red[d.rank] && (off & 3) == 0 && (n & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (n >> 2) <= 256ll * 65535;
     if (two) {
         d.mode = 2;
@@ -229,7 +248,7 @@ int32_t rlrep_comm_allreduce(rlrep_comm* c, int64_t off, int64_t n, float* out_d
     DpPull d; rl_comm_fill_pull(c, &d);
     if (timeout_us > 0) d.timeout = timeout_us * RL_DP_TICKS_PER_US;
     const int two = mode == 2 || (mode == 0 && n >= (1 << 17));
-    const int rc = rl_launch_xchg_reduce(&d, 7, off, n, out_dev, two, (hipStream_t)stream);
+    const int rc = rl_launch_xchg_reduce(&d, 7, off, n, out_dev, two, 0, (hipStream_t)stream);
     ++g_rl_launches;
     if (rc != 0) { rl_set_error("comm_allreduce: launch failed (%d)", rc); return RLREP_ERR_HIP; }
     return 0;
@@ -240,7 +259,7 @@ int32_t rlrep_comm_allgather(rlrep_comm* c, int64_t off, int64_t n, void* stream
     if (!c || n <= 0 || off < 0 || (off & 3) || (n & 3) || off + n * c->world > c->arena_floats + c->scratch_floats) { rl_set_error("comm_allgather: bad argument"); return RLREP_ERR_ARG; }
     if (!c->connected) { rl_set_error("comm_allgather before rlrep_comm_connect"); return RLREP_ERR_STATE; }
     DpPull d; rl_comm_fill_pull(c, &d);
-    const int rc = rl_launch_xchg_gather(&d, 6, off, n, (hipStream_t)stream);
+    const int rc = rl_launch_xchg_gather(&d, 6, off, n, 0, (hipStream_t)stream);
     ++g_rl_launches;
     if (rc != 0) { rl_set_error("comm_allgather: launch failed (%d)", rc); return RLREP_ERR_HIP; }
     return 0;
@@ -258,6 +277,26 @@ int32_t rlrep_comm_probe_fill(rlrep_comm* c, int64_t off, int64_t n, int32_t rou
     return 0;
 }
 float rlrep_comm_probe_value(int32_t rank, int32_t round, int64_t i) { return comm_pattern(rank, round, i); }
+
+// the probe of the PUSHED exchange (what carries spedersac's Phibar and v): a producer launch stores pattern(rank, round, .) of n floats into every
+// rank's slot area (the head of the exchange scratch: needs 2 * world * n floats of it) and raises READY everywhere; the NEXT launch waits for all
+// ranks' READY and sums the slots of its own block in rank order into out_dev[0 .. n).  Channel 6; two launches, capturable.
+int32_t rlrep_comm_probe_slots(rlrep_comm* c, int64_t n, int32_t round, float* out_dev, int64_t timeout_us, void* stream) {
+    if (!c || !out_dev || n <= 0 || n > 65536 || 2 * (int64_t)c->world * n > c->scratch_floats) { rl_set_error("comm_probe_slots: bad argument (needs 2 * world * n floats of exchange scratch)"); return RLREP_ERR_ARG; }
+    if (!c->connected) { rl_set_error("comm_probe_slots before rlrep_comm_connect"); return RLREP_ERR_STATE; }
+    DpSlots d; memset(&d, 0, sizeof(d));
+    d.world = c->world; d.rank = c->rank; d.channel = 6; d.n = (int)n; d.err = c->err_dev;
+    d.timeout = timeout_us > 0 ? timeout_us * RL_DP_TICKS_PER_US : c->timeout_ticks;
+    for (int q = 0; q < c->world; ++q) { d.slot[q] = reinterpret_cast<float*>(c->peer[q] + c->scratch_off); d.flags[q] = reinterpret_cast<DpFlags*>(c->peer[q] + c->flags_off); }
+    const int nb = (int)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256);
+    d.nblocks = nb;
+    hipLaunchKernelGGL(comm_slots_put_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d, c->rank, round);
+    hipLaunchKernelGGL(comm_slots_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, out_dev);
+    g_rl_launches += 2;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("comm_probe_slots: %s", hipGetErrorString(e)); return RLREP_ERR_HIP; }
+    return 0;
+}
 
 // Optimizer groups of `agent` whose gradient slice holds at most max_floats floats sum their gradients over the ranks INSIDE their optimizer
 // launch from now on (the agent must have been created with this comm's arena as its gradient arena and hyper.world_size = world); slices of
@@ -291,18 +330,18 @@ int32_t rlrep_comm_status(rlrep_comm* c, uint32_t* mask, int32_t clear) {
 
 int32_t rlrep_comm_fine_grained(rlrep_comm* c) { return c && c->fine_grained ? 1 : 0; }
 
-// DEBUG / measurement: mark every peer as "arrived" and "has read" for the NEXT epoch of `channel` in this rank's flag block, so that the next
+// DEBUG / measurement: mark every peer as "arrived" and "has read" for the next `ahead` epochs of `channel` in this rank's flag block, so that the next
 // one-shot launch of this rank on that channel runs without a live peer (synchronous; the peers' blocks must hold the data already).  What lets
 // one stream play eight ranks one after the other: the arithmetic and the read fan-in of a full node on a one-GPU box (HIP gives a process four
 // concurrent hardware queues: eight waiting launches cannot all be resident).  Never part of a train().
-int32_t rlrep_comm_debug_preset(rlrep_comm* c, int32_t channel) {
-    if (!c || channel < 0 || channel >= RL_DP_CHANNELS) { rl_set_error("comm_debug_preset: bad argument"); return RLREP_ERR_ARG; }
+int32_t rlrep_comm_debug_preset(rlrep_comm* c, int32_t channel, int32_t ahead) {
+    if (!c || channel < 0 || channel >= RL_DP_CHANNELS || ahead < 1) { rl_set_error("comm_debug_preset: bad argument"); return RLREP_ERR_ARG; }
     if (hipDeviceSynchronize() != hipSuccess) return RLREP_ERR_HIP;
     DpFlags* f = reinterpret_cast<DpFlags*>(c->local + c->flags_off);
     unsigned e = 0;
     if (hipMemcpy(&e, &f->epoch[channel], sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return RLREP_ERR_HIP;
     unsigned words[RL_DP_MAX_WORLD];
-    for (int q = 0; q < RL_DP_MAX_WORLD; ++q) words[q] = e + 1u;
+    for (int q = 0; q < RL_DP_MAX_WORLD; ++q) words[q] = e + (unsigned)ahead;          // (ahead = 1 << 30: the peers have "arrived" for the next 2^30 epochs)
     if (hipMemcpy(f->ready[channel], words, sizeof(words), hipMemcpyHostToDevice) != hipSuccess) return RLREP_ERR_HIP;
     if (hipMemcpy(f->done[channel], words, sizeof(words), hipMemcpyHostToDevice) != hipSuccess) return RLREP_ERR_HIP;
     return 0;

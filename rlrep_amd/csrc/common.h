@@ -71,6 +71,7 @@ enum Epi : int {
 // copy where ad_t / ad_tb are set) -- the FIRST layers of the vlsac feature nets, whose updated weights the next feature step's first launch
 // needs, so that the rest of the group's optimizer work can share a launch with that first layer.  GemmTask::ad_*.
 #define FLAG_FIN_IN_ADAM 8192  // split-K task of the LDS-tiled engine whose partial slabs are summed by its group's optimizer launch (AdamTask::Slab): no finishing blocks
+#define FLAG_FIN_INLINE 16384  // split-K task of the 64-wide bf16x3 tile whose LAST split workgroup of every tile sums the slabs and runs the epilogue itself (gemm_x3s_kernel): no finishing launch
 #define FLAG_ADAM 2048
 
 struct GroupCfg;
@@ -164,7 +165,7 @@ static inline void rl_gemm16_plan(GemmTask& t) {
 // tb / tcs: first tile and column tiles of each task, copied next to the header by the launcher so that a workgroup finds its task and its
 // tile coordinates from ONE burst of scalar loads (then the task record with a second one), instead of a round trip per dependent field
 // total: tiles of the launch
-struct GemmBatch { int ntasks; int low_prio; int total; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
+struct GemmBatch { int ntasks; int low_prio; int total; int tb[GEMM_MAX_TASKS], tcs[GEMM_MAX_TASKS]; int xcd_runs; GemmTask t[GEMM_MAX_TASKS]; };    // low_prio: launch of a chain with slack (deferred critic / actor)
 
 // ------------------------------------------------------------------------------------------------
 // elementwise task (Adam / Polyak)

@@ -73,6 +73,8 @@ struct DpFlags {
 struct DpPull {
     int world, rank, channel, nblocks;                     // nblocks: the blocks of the launch that take a ticket
     int mode, nblocks_a;                                   // mode 2: two-shot (nblocks_a = the blocks that sum a piece of this rank's shard)
+    int no_done;                                           // the launch ends without the DONE handshake: the caller's program guarantees that this rank's data are
+                                                           // not overwritten before every peer has passed a LATER handshake (ctrlsac's alternating gather / reduce)
     long long timeout;                                     // bound of every wait, ticks of the 100 MHz wall clock
     long long tail_off, tail_n;                            // (optimizer launches) arena-relative range that the trailing block sums too (the temperature gradient's partials); tail_n = 0: none
     long long shard4;                                      // two-shot: 16-byte elements per shard (the slice's elements / world, rounded up)
@@ -123,6 +125,14 @@ __device__ __forceinline__ void dp_store1(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Ordering WITHOUT cache maintenance.  Everything a peer reads of this GPU was either written by an EARLIER kernel (the kernel boundary has
+// written the XCDs' L2s back) or by write-through stores of this launch (dp_store*: sc0 sc1), and everything read of a peer goes past this GPU's
+// caches (dp_load*: sc0 sc1).  So a signal needs only "my stores have left" (vmcnt(0)) in front of it, and a wait only a compiler barrier behind
+// it -- a system-scope release / acquire FENCE here is a write-back / invalidate of the L2 by every block of the launch: the optimizer launch
+// measured 20.2 us against 7.2 us single-GPU with them, the other chain's kernels losing their L2 lines on top (docs/history/r06.md).
+__device__ __forceinline__ void dp_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }      // vmcnt(0): this wave's stores have been acknowledged
+__device__ __forceinline__ void dp_signal(unsigned* word, unsigned e) { __hip_atomic_store(word, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // the first wave of a block waits until word[q] of every peer q has reached epoch e; returns false (and reports the late ranks) on a timeout
 __device__ __forceinline__ bool dp_wait_all(const unsigned* words, int world, int rank, unsigned e, long long timeout, unsigned* err) {
     const int q = threadIdx.x & 63;
@@ -136,7 +146,7 @@ __device__ __forceinline__ bool dp_wait_all(const unsigned* words, int world, in
         __builtin_amdgcn_s_sleep(4);
     }
     if (!ok) atomicOr(err, 1u << q);                                    // never hang the GPU: report, skip, drain
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                      // system scope: nothing read after this comes from a cache line of an earlier epoch
+    asm volatile("" ::: "memory");                                     // (the reads that follow are issued behind the poll that saw the word; they bypass the caches)
     return __all(ok);
 }
 
@@ -145,13 +155,12 @@ __device__ __forceinline__ bool dp_wait_all(const unsigned* words, int world, in
 __device__ __forceinline__ unsigned dp_begin(const DpPull& d, bool signaller, bool bar, bool* good) {
     __shared__ int dp_good_s;
     DpFlags* const mine = d.flags[d.rank];
-    const unsigned e = __hip_atomic_load(&mine->epoch[d.channel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // (a plain load: the word was written by the last block of the PREVIOUS launch of this channel -- an earlier kernel of the same stream; a
+    //  coherent load here was a cache-bypassing round trip at the head of every block's critical path)
+    const unsigned e = mine->epoch[d.channel] + 1u;
     if (threadIdx.x < 64) {
         const int q = threadIdx.x;
-        if (signaller && q < d.world && q != d.rank) {
-            __threadfence_system();
-            __hip_atomic_store(&d.flags[q]->ready[d.channel][d.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (signaller && q < d.world && q != d.rank) dp_signal(&d.flags[q]->ready[d.channel][d.rank], e);      // (the data were written by earlier kernels)
         const bool ok = dp_wait_all(mine->ready[d.channel], d.world, d.rank, e, d.timeout, d.err);
         if (threadIdx.x == 0) dp_good_s = ok ? 1 : 0;
         if (!bar) *good = ok;
@@ -169,12 +178,14 @@ __device__ __forceinline__ void dp_end(const DpPull& d, unsigned e, bool bar) {
     if (bar) __syncthreads();
     if (!dp_last_s || threadIdx.x >= 64) return;
     const int q = threadIdx.x;
-    if (q < d.world && q != d.rank) __hip_atomic_store(&d.flags[q]->done[d.channel][d.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    (void)dp_wait_all(mine->done[d.channel], d.world, d.rank, e, d.timeout, d.err);
+    if (!d.no_done) {
+        if (q < d.world && q != d.rank) dp_signal(&d.flags[q]->done[d.channel][d.rank], e);       // (this rank's reads were consumed before its blocks took their tickets)
+        (void)dp_wait_all(mine->done[d.channel], d.world, d.rank, e, d.timeout, d.err);
+    }
     if (q == 0) {
         __hip_atomic_store(&mine->ticket[d.channel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&mine->ticket2[d.channel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->epoch[d.channel], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->epoch[d.channel], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read by LATER kernels only)
     }
 }
 
@@ -224,14 +235,13 @@ __device__ __forceinline__ bool dp_reduce_scatter(const DpPull& d, unsigned e, i
     if (bid < d.nblocks_a) {
         const long long j = (long long)bid * 256 + threadIdx.x, i4 = (long long)d.rank * d.shard4 + j;
         if (good && j < d.shard4 && i4 < n4) dp_store4(d.red[d.rank] + goff + 4 * i4, dp_sum4(d, goff + 4 * i4));
-        __threadfence_system();
-        __syncthreads();
+        dp_drain();                                        // the write-through stores of this thread have reached memory ...
+        __syncthreads();                                   // ... and those of the whole block
         if (threadIdx.x == 0) dp_rs_s = (atomicAdd(&mine->ticket2[d.channel], 1u) == (unsigned)(d.nblocks_a - 1)) ? 1 : 0;
         __syncthreads();
         if (dp_rs_s && threadIdx.x < 64) {
-            __threadfence_system();
             const int q = threadIdx.x;
-            if (q < d.world) __hip_atomic_store(&d.flags[q]->red[d.channel][d.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (own word too: the local blocks wait on it)
+            if (q < d.world) dp_signal(&d.flags[q]->red[d.channel][d.rank], e);      // (own word too: the local blocks wait on it)
         }
     }
     if (threadIdx.x < 64) {
@@ -251,7 +261,7 @@ __device__ __forceinline__ dp_f32x4 dp_gather4(const DpPull& d, long long goff, 
 // ---- DpSlots: producer side.  Every thread that owns element f of the partial calls dp_slots_put; then EVERY thread of every ticket-taking
 // block calls dp_slots_publish (256 or 1024 threads per block; contains barriers).
 __device__ __forceinline__ unsigned dp_slots_epoch(const DpSlots& d) {       // the epoch this producer launch publishes (read before any ticket is taken)
-    return __hip_atomic_load(&d.flags[d.rank]->epoch[d.channel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    return d.flags[d.rank]->epoch[d.channel] + 1u;
 }
 __device__ __forceinline__ void dp_slots_put(const DpSlots& d, unsigned e, int f, float v) {
     const size_t at = ((size_t)(e & 1u) * d.world + d.rank) * d.n + f;
@@ -260,17 +270,16 @@ __device__ __forceinline__ void dp_slots_put(const DpSlots& d, unsigned e, int f
 __device__ __forceinline__ void dp_slots_publish(const DpSlots& d, unsigned e) {
     __shared__ int dp_sl_s;
     DpFlags* const mine = d.flags[d.rank];
-    __threadfence_system();
-    __syncthreads();
+    dp_drain();                                            // this thread's pushed (write-through) stores have been acknowledged ...
+    __syncthreads();                                       // ... and the block's
     if (threadIdx.x == 0) dp_sl_s = (atomicAdd(&mine->ticket[d.channel], 1u) == (unsigned)(d.nblocks - 1)) ? 1 : 0;
     __syncthreads();
     if (!dp_sl_s || threadIdx.x >= 64) return;
-    __threadfence_system();
     const int q = threadIdx.x;
-    if (q < d.world) __hip_atomic_store(&d.flags[q]->ready[d.channel][d.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (q < d.world) dp_signal(&d.flags[q]->ready[d.channel][d.rank], e);
     if (q == 0) {
         __hip_atomic_store(&mine->ticket[d.channel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->epoch[d.channel], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->epoch[d.channel], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // ---- consumer side (a LATER launch of the same stream).  Every thread of the block (any size that is a multiple of 64): waits for all ranks'
@@ -278,7 +287,7 @@ __device__ __forceinline__ void dp_slots_publish(const DpSlots& d, unsigned e) {
 // (LDS or global).  Contains barriers.
 __device__ __forceinline__ void dp_slots_sum(const DpSlots& d, float* dst) {
     DpFlags* const mine = d.flags[d.rank];
-    const unsigned e = __hip_atomic_load(&mine->epoch[d.channel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned e = mine->epoch[d.channel];            // (written by the producer launch: an earlier kernel of this stream)
     if (threadIdx.x < 64) (void)dp_wait_all(mine->ready[d.channel], d.world, -1, e, d.timeout, d.err);
     __syncthreads();
     const float* sl = d.slot[d.rank] + (size_t)(e & 1u) * d.world * d.n;

@@ -710,6 +710,9 @@ __global__ __launch_bounds__(256) void polyak_kernel(PolyakTask t) {
 
 __global__ void counter_inc_kernel(int* c, int mirror) { if (threadIdx.x == 0 && blockIdx.x == 0) { const int v = *c + 1; *c = v; if (mirror) c[mirror] = v; } }
 
+// c[mirror] = c[0] (the train() counter's copy that the next train prologue reads: rlrep_train_prologue's catch-up launch)
+__global__ void counter_sync_kernel(int* c, int mirror) { if (threadIdx.x == 0 && blockIdx.x == 0) c[mirror] = c[0]; }
+
 __global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
@@ -887,6 +890,10 @@ extern "C" int rl_launch_polyak(const PolyakTask* t, hipStream_t st) {
 // mirror > 0: c[mirror] follows c[0] (the train() counter's copy for the next train prologue)
 extern "C" int rl_launch_counter_inc(int* c, int mirror, hipStream_t st) {
     hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, c, mirror);
+    return (int)hipGetLastError();
+}
+extern "C" int rl_launch_counter_sync(int* c, int mirror, hipStream_t st) {
+    hipLaunchKernelGGL(counter_sync_kernel, dim3(1), dim3(64), 0, st, c, mirror);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_copy_segs(const CopySegs* p, hipStream_t st) {

@@ -44,6 +44,7 @@ int rl_launch_qhead_critic(const QHeadCritic* p, hipStream_t st);
 int rl_launch_qhead_actor(const QHeadActor* p, hipStream_t st);
 int rl_launch_gemm16_duo(int split, int nf2, const GemmBatch* gb, int total_tiles, hipStream_t st);
 extern "C" int rl_replearn_init();
+int rl_launch_counter_sync(int* c, int mirror, hipStream_t st);
 int rl_launch_adam(const AdamTask* task, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const SlotFill* sf2, const AdamSnap* snap, const DpPull* dp, hipStream_t st);
 int rl_launch_adam_l1(const AdamTask* task, int adam_blocks, const FinTask* fin, int nfin, const SlotFill* sf, const GemmTask* g0, const GemmTask* g1, hipStream_t st);
 int rl_launch_train_prologue(TrainPrologue* p, hipStream_t st);

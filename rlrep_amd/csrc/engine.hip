@@ -740,7 +740,7 @@ static void build_vlsac(Builder& b, rlrep_agent* ag) {
         rl_nc_fwd_plan(tasks.data(), (int)tasks.size(), &engine, &g2, &cols);
         NcFwdBatch nb; memset(&nb, 0, sizeof(nb));
         int base_tile = 0;
-        nb.ntasks = (int)tasks.size(); nb.engine = engine; nb.cols = cols;
+        nb.ntasks = (int)tasks.size(); nb.engine = engine; nb.cols = cols; nb.nt_u = rl_opt("nc_u_nt") ? 1 : 0;
         for (size_t q = 0; q < tasks.size(); ++q) {
             NcFwdTask& t = tasks[q];
             t.tiles_h = (H + cols - 1) / cols; t.ntiles = ((B + 4 * g2 - 1) / (4 * g2)) * t.tiles_h; t.tile_base = base_tile; base_tile += t.ntiles;
@@ -1342,6 +1342,10 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
     ag->early_crit = ag->early_act = ag->early_ready_crit = ag->early_ready_act = nullptr;
     int rc = ensure_batch(ag, batch);
     if (rc) return rc;
+    if (ag->mirror_pending) {      // the previous prologue was followed by no optimizer launch that refreshes the counter's mirror: catch up (rare path)
+        rc = (++g_rl_launches, rl_launch_counter_sync(ag->steps, 2, (hipStream_t)stream));
+        if (rc) { rl_set_error("train_prologue: hip error %d", rc); return RLREP_ERR_HIP; }
+    }
     TrainPrologue tp; memset(&tp, 0, sizeof(tp));
     tp.idx.dst_i = idx_pool_dev; tp.idx.n = n_idx; tp.idx.kind = 1; tp.idx.hi = 1; tp.idx.hi_dev = size_dev;
     tp.idx.seed = seed; tp.idx.offset = idx_offset; tp.idx.step_dev = ag->steps + 2; tp.idx.step_add = 1;
@@ -1355,6 +1359,7 @@ int32_t rlrep_train_prologue(rlrep_agent* ag, const float* ring_dev, const int32
     ag->slot[0].filled = true;
     ag->pf_done = true; ag->pf_ring = ring_dev; ag->pf_idx = idx_pool_dev;     // the first `batch` pool entries are in slot 0
     ag->in_train = true; ag->target_done = false;
+    ag->mirror_pending = true;          // cleared by the optimizer launch that refreshes the mirror (engine_internal.h Builder::adam)
     return 0;
 }
 
@@ -1790,7 +1795,17 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
         t.flags |= rl_gemm_lds_dim_flags(&t, la, lb) | rl_gemm_lds_ptr_flags(&t);
         // (the 64-wide bf16x3 tile has any-alignment loaders; the 128-wide one needs 16-byte-regular operands)
         if (engine == 2 && (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) && (bt != 64 || R < 4 || Cn < 4 || K < 4)) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
-        if (engine == 2 && bt != 64 && (t.flags & FLAG_SCALAR_C)) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
+        if (engine == 2 && bt != 64 && bt != 32 && (t.flags & FLAG_SCALAR_C)) { rl_set_error("gemm: shape/alignment not eligible for the bf16x3 tile"); return RLREP_ERR_ARG; }
+        if (engine == 2 && bt == 32) {
+            // the 32 x 32 tile whose four waves split K (gemm_x3q.h): row-major A, K % 16 == 0, no slabs
+            if (la != LD_ROW || (t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) || (K & 15) || K < 32 || (lb == LD_COL && ((Cn & 7) || Cn < 8))) { rl_set_error("gemm: shape/alignment not eligible for the 32 x 32 bf16x3 tile"); return RLREP_ERR_ARG; }
+            t.splits = 1; t.kchunk = K;
+            t.tiles_c = (Cn + 31) / 32; t.ntiles = ((R + 31) / 32) * t.tiles_c; t.tile_base = 0;
+            gb.t[0] = t;
+            rc = rl_launch_gemm_lds(33, la, lb, &gb, t.ntiles, 0, (hipStream_t)stream);
+            if (rc != 0) { rl_set_error("gemm: launch failed (%d)", rc); return rc < 0 ? RLREP_ERR_ARG : RLREP_ERR_HIP; }
+            return 0;
+        }
         int pbt = 0, psp = 1, pkc = 0;
         rl_gemm_lds_plan(&t, &pbt, &psp, &pkc);
         if (bt == 64 || bt == 128) pbt = bt;
@@ -1803,6 +1818,14 @@ int32_t rlrep_gemm(int32_t engine, int32_t la, int32_t lb, const float* A, int32
             if (!wsp || ws_floats < (int64_t)psp * R * (((Cn + 3) & ~3) + 1)) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
             t.slab = wsp; t.bslab = wsp + (size_t)psp * R * ((Cn + 3) & ~3); t.fin_base = 0;
             fin = (int)(((long long)R * ((Cn + 3) / 4) + 255) / 256) + (bg ? (R + 255) / 256 : 0);
+            if ((flags & 4) && engine == 2 && pbt == 64) {
+                // flags & 4: the 64-wide bf16x3 tile finishes its split-K products inside the launch (FLAG_FIN_INLINE: one ticket word per output
+                // tile behind the slabs, zero between launches) -- no finishing launch
+                const size_t ticks = (size_t)((R + 63) / 64) * ((Cn + 63) / 64);
+                if (ws_floats < (int64_t)psp * R * (((Cn + 3) & ~3) + 1) + (int64_t)ticks) { rl_set_error("gemm: workspace too small for %d splits", psp); return RLREP_ERR_ARG; }
+                if (hipMemsetAsync(t.bslab, 0, ticks * sizeof(int), (hipStream_t)stream) != hipSuccess) return RLREP_ERR_HIP;
+                t.bslab += ticks; t.flags |= FLAG_FIN_INLINE; t.fin_base = 0x7fffffff; fin = 0;
+            }
         }
         const bool wide = engine == 2 && bt == 256;          // the 256 x 128 persistent tile (gemm_x3w.h)
         if (wide && (act == ACT_SIN || act == ACT_TANH)) { rl_set_error("gemm: the 256 x 128 tile has no sin / tanh epilogue"); return RLREP_ERR_ARG; }
@@ -1823,8 +1846,8 @@ int32_t rlrep_gemm_plan(int32_t la, int32_t lb, int32_t R, int32_t Cn, int32_t K
     t.R = R; t.Cn = Cn; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.epi = la == LD_COL ? EPI_DW : EPI_FWD;
     int sp = 1, kc = 0, fl = 0;
     const int code = rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl);
-    *engine = code == 0 ? 0 : (code == 257 || code == 129 || code == 65) ? 2 : 1;
-    if (tile) *tile = code == 0 ? 16 : code == 257 ? 256 : code == 129 ? 128 : code == 65 ? 64 : code;
+    *engine = code == 0 ? 0 : (code == 257 || code == 129 || code == 65 || code == 33) ? 2 : 1;
+    if (tile) *tile = code == 0 ? 16 : code == 257 ? 256 : code == 129 ? 128 : code == 65 ? 64 : code == 33 ? 32 : code;
     if (splits) *splits = code ? sp : 1;
     if (kchunk) *kchunk = code ? kc : K;
     if (scalar_sides) *scalar_sides = code ? (((fl & FLAG_SCALAR_A) ? 1 : 0) | ((fl & FLAG_SCALAR_B) ? 2 : 0) | ((fl & FLAG_SCALAR_C) ? 4 : 0)) : 0;

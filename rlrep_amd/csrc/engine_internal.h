@@ -89,6 +89,10 @@ struct rlrep_agent {
     unsigned* xc_err = nullptr; std::deque<std::string> stage_names;
     // data parallel inside the optimizer launches (rlrep_comm_attach, dp_pull.h): the gradient arena is a block every peer has mapped; the
     // optimizer launch of an attached group sums its gradients over the ranks itself (channel = group)
+    // the train() counter's mirror (word 2 of `steps`, read by the NEXT train prologue) is refreshed by the optimizer launches that carry
+    // AdamTask::sync_steps (group 0; any group for sac).  A caller that runs rlrep_train_prologue and then no such launch (advisor r05: critic /
+    // actor steps only) would draw the same Philox indices again: the next prologue then refreshes the mirror itself, with one extra launch.
+    bool mirror_pending = false;
     DpPull dp_proto = DpPull(); bool dp_on[4] = {false, false, false, false}, dp_two[4] = {false, false, false, false};
     // ... and the batch-coupled exchanges of the feature step (spedersac Phibar / v: pushed slots, zero launches; ctrlsac mu(s') / dmu': one
     // pull launch each) when the comm carries exchange scratch (rlrep_layout_info.exchange_floats): xfold = the step programs were rebuilt
@@ -173,25 +177,42 @@ struct Builder {
     // only, so the dry sizing pass and the real pass allocate identically; a task whose pointers turn out not to be
     // 16-byte aligned simply stays on gemm16 and leaves its slab unused.
     void gemm(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
-        std::vector<GemmTask> small, big128, big64, bigx3, bigx3s, bigx3w;
+        std::vector<GemmTask> small, big128, big64, bigx3, bigx3s, bigx3w, bigx3q;
         for (auto& t : tasks) {
             int sp = 1, kc = 0, fl = 0;
             // dimensions decide the engine and the slab reservation (identical in the dry and the real pass) ...
             if (rl_gemm_lds_route(&t, la, lb, 0, &sp, &kc, &fl)) {
+                // (a task routed to the slab-free 32 x 32 tile still reserves the slabs of its 64-wide plan: pointer alignment, or a neighbour in its
+                //  stage, may send it back there)
+                { int b0 = 0, k0 = 0; if (sp == 1) rl_gemm_lds_plan(&t, &b0, &sp, &k0); }
                 // (the bias-gradient flag depends on a pointer that is null in the dry pass: reserve for every dW task)
-                float* slab = sp > 1 ? ws.f((size_t)sp * t.R * ((t.Cn + 3) & ~3)) : nullptr;
+                // (+ one ticket word per 64 x 64 output tile behind the slabs: gemm_x3s_kernel's in-launch finish, FLAG_FIN_INLINE; zeroed once, self-resetting)
+                const size_t slab_floats = (size_t)sp * t.R * ((t.Cn + 3) & ~3), ticks = (size_t)((t.R + 63) / 64) * ((t.Cn + 63) / 64);
+                float* slab = sp > 1 ? ws.f(slab_floats + ticks) : nullptr;
+                if (slab && !dry && ws.ok()) (void)hipMemset(slab + slab_floats, 0, ticks * sizeof(int));
                 float* bslab = (sp > 1 && t.epi == EPI_DW) ? ws.f((size_t)sp * t.R) : nullptr;
                 // ... pointer alignment can only add scalar-access flags (and take bf16x3 away)
                 const int code = rl_gemm_lds_route(&t, la, lb, dry ? 0 : rl_gemm_lds_ptr_flags(&t), &sp, &kc, &fl);
                 t.splits = sp; t.kchunk = kc; t.slab = slab; t.bslab = bslab; t.flags |= fl;
-                (code == 257 ? bigx3w : code == 129 ? bigx3 : code == 65 ? bigx3s : code == 128 ? big128 : big64).push_back(t);
+                (code == 33 ? bigx3q : code == 257 ? bigx3w : code == 129 ? bigx3 : code == 65 ? bigx3s : code == 128 ? big128 : big64).push_back(t);
                 continue;
             }
             small.push_back(t);
         }
         // one launch per tile width: if some 64-wide tasks of the stage cannot take the bf16x3 tile (scalar staging), all of them stay on fp32
         if (!big64.empty() && !bigx3s.empty()) { big64.insert(big64.end(), bigx3s.begin(), bigx3s.end()); bigx3s.clear(); }
-        if (!bigx3w.empty() || !bigx3.empty() || !big128.empty() || !big64.empty() || !bigx3s.empty()) chain_flush();
+        // (a stage stays ONE launch where it can: 32 x 32 tasks beside 64-wide ones of the same stage all take the 64-wide tile -- with their split plan)
+        if (!bigx3q.empty() && (!bigx3s.empty() || !big64.empty())) {
+            for (auto t : bigx3q) {
+                int sp = 1, kc = 0, bt0 = 0;
+                rl_gemm_lds_plan(&t, &bt0, &sp, &kc);
+                t.splits = sp; t.kchunk = kc;
+                (big64.empty() ? bigx3s : big64).push_back(t);
+            }
+            bigx3q.clear();
+        }
+        if (!bigx3q.empty() || !bigx3w.empty() || !bigx3.empty() || !big128.empty() || !big64.empty() || !bigx3s.empty()) chain_flush();
+        if (!bigx3q.empty()) gemm_lds_stage(p, la, lb, 33, bigx3q, what);
         if (!bigx3w.empty()) gemm_lds_stage(p, la, lb, 257, bigx3w, what);
         if (!bigx3.empty()) gemm_lds_stage(p, la, lb, 129, bigx3, what);
         if (!big128.empty()) gemm_lds_stage(p, la, lb, 128, big128, what);
@@ -229,12 +250,16 @@ struct Builder {
     }
     void gemm_lds_stage(Program& p, int la, int lb, int bt, std::vector<GemmTask> tasks, const char* what) {
         int base = 0, fin = 0;
-        const int edge = bt == 129 ? 128 : bt == 65 ? 64 : bt;       // 129 / 65: the 128- / 64-wide tile on the bf16 pipe
+        const int edge = bt == 129 ? 128 : bt == 65 ? 64 : bt == 33 ? 32 : bt;       // 129 / 65 / 33: the 128- / 64- / 32-wide tile on the bf16 pipe
         const int er = bt == 257 ? 256 : edge, ec = bt == 257 ? 128 : edge;     // 257: 256 rows x 128 columns (gemm_x3w.h)
         for (auto& t : tasks) {
             t.tiles_c = (t.Cn + ec - 1) / ec;
             t.ntiles = ((t.R + er - 1) / er) * t.tiles_c * t.splits; t.tile_base = base; base += t.ntiles;
             if (t.splits > 1 && fold_fin(t)) t.fin_base = 0x7fffffff;       // (no finishing block ever matches it)
+            // (OPT-IN, RLREP_ENABLE=fin_inline: the last split workgroup of a tile finishes it inside the launch.  Bit-identical and one launch less per
+            //  split stage -- and 1.1x (spedersac) to 3.5x (ctrlsac F = 2048) SLOWER per train(): the slabs have to go through to memory and come back past
+            //  the L2s, docs/history/r06.md)
+            else if (t.splits > 1 && bt == 65 && rl_opt("fin_inline")) { t.flags |= FLAG_FIN_INLINE; t.fin_base = 0x7fffffff; }
             else if (t.splits > 1) {
                 const bool bias = t.epi == EPI_DW && (t.flags & FLAG_BIASGRAD);
                 t.fin_base = fin;
@@ -245,7 +270,7 @@ struct Builder {
         gb.ntasks = (int)tasks.size();
         for (size_t q = 0; q < tasks.size(); ++q) gb.t[q] = tasks[q];
         p.stages.push_back({[=](hipStream_t st) { return rl_launch_gemm_lds(bt, la, lb, &gb, base, fin, st); }, what});
-        tag_gemms(p, (bt == 257 || bt == 129 || bt == 65) ? RLREP_ENGINE_X3 : bt == 128 ? RLREP_ENGINE_LDS128 : RLREP_ENGINE_LDS64, tasks);
+        tag_gemms(p, (bt == 257 || bt == 129 || bt == 65 || bt == 33) ? RLREP_ENGINE_X3 : bt == 128 ? RLREP_ENGINE_LDS128 : RLREP_ENGINE_LDS64, tasks);
     }
     void gemm_small(Program& p, int la, int lb, std::vector<GemmTask> tasks, const char* what) {
         if (chain_take(p, la, lb, tasks, what)) return;
@@ -515,6 +540,7 @@ struct Builder {
             const int nfin = (hist_last && !a->hist_on) ? nfin_all - 1 : nfin_all;
             DpPull dp = a->dp_proto;
             dp.channel = group; dp.mode = a->dp_two[group] ? 2 : 1;
+            if (t.sync_steps) a->mirror_pending = false;
             return rl_launch_adam(&t, blocks, fdev, nfin, sf, sf2, sn.on ? &sn : nullptr, a->dp_on[group] ? &dp : nullptr, st);
         }, what});
         tag(p, RLREP_ENGINE_OPTIMIZER, 0.0, 28.0 * (double)t.n + 12.0 * (double)(target ? pol_n : 0));     // read p, g, m, v; write p, m, v (+ target: read, read source, write)
@@ -543,6 +569,7 @@ struct Builder {
         rlrep_agent* a = ag;
         p.stages.push_back({[=](hipStream_t st) {
             if (!a->pf_armed) return -8;                     // (rlrep_feature_chain_next refuses to arm without a prefetched minibatch)
+            a->mirror_pending = false;
             const SlotFill sf = a->pf_fill;
             a->pf_armed = false; a->pf_done = true; a->slot[0].filled = true; a->pi_ready = nullptr; a->early_ready_crit = a->early_ready_act = nullptr;
             return rl_launch_adam_l1(&t, blocks, fdev, nfin, &sf, &g0, &g1, st);

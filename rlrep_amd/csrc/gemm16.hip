@@ -75,7 +75,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(int hdr, int total, int tb0
     const int tcs[GEMM_MAX_TASKS] = {(int)(tc01 & 0xffffu), (int)(tc01 >> 16), (int)(tc23 & 0xffffu), (int)(tc23 >> 16),
                                      (int)(tc45 & 0xffffu), (int)(tc45 >> 16), (int)(tc67 & 0xffffu), (int)(tc67 >> 16)};
     if (!low_prio) __builtin_amdgcn_s_setprio(3);
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    if constexpr (LA == LD_COL && LB == LD_COL) {
+        // Weight gradients (hdr bit 1): workgroup b runs on XCD b % 8, and BOTH operands of these products are activations that every XCD's L2
+        // has to fetch -- in launch order each XCD saw an eighth of EVERY task (18.8 MB fetched for 4 MB of inputs at the headline dims,
+        // profiles/r05_pmc_*).  Dealt as contiguous runs, XCD x owns tiles [x T / 8, (x + 1) T / 8): about one task, i.e. one G and one X.
+        if (hdr & 2) {
+            const int x = bid & 7, j = bid >> 3, q = total >> 3, r = total & 7;
+            bid = x * q + min(x, r) + j;
+        }
+    }
     (void)total;
     int ti = 0, base = tb[0], tiles_c = tcs[0];
 #pragma unroll
@@ -203,9 +212,10 @@ long long g_rl_front[4] = {0, 0, 0, 0};
 static int s_front = 3;
 // diagnostic switches, read when an agent is created (rl_gemm16_read_env; no getenv on the per-launch path): RLREP_DISABLE=gemm16_fast = every launch on
 // the record front end, RLREP_DISABLE=gemm16_spec = no compiled-in epilogues (both: bit-identical results, tests/test_default_mode.py)
-static bool s_no_fast = false, s_generic = false, s_trace = false;
+static bool s_no_fast = false, s_generic = false, s_trace = false, s_dw_xcd = true;
 extern "C" void rl_gemm16_read_env() {
     s_no_fast = rl_off("gemm16_fast"); s_generic = rl_off("gemm16_spec"); s_trace = rl_opt("gemm16_trace") != nullptr;
+    s_dw_xcd = !rl_off("dw_xcd");              // weight-gradient tiles dealt to the XCDs as contiguous runs (same tiles, same arithmetic: bit-identical)
 }
 struct FastPreArgs { int hdr; const float* base; unsigned ao, bo, ld, kr, ck, xo, wo, mo, ldxw, ldm; };
 static bool fastpre_args(const GemmBatch& gb, FastPreArgs& fa) {
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm16_duo_kernel(int hdr, int total, int
 // host launcher
 // ------------------------------------------------------------------------------------------------
 // the 14 preloaded header scalars of a planned batch, then the batch
-#define G16_ARGS(B) ((B).low_prio ? 1 : 0), (B).total, (B).tb[0], (B).tb[1], (B).tb[2], (B).tb[3], (B).tb[4], (B).tb[5], (B).tb[6], (B).tb[7], \
+#define G16_ARGS(B) (((B).low_prio ? 1 : 0) | ((B).xcd_runs ? 2 : 0)), (B).total, (B).tb[0], (B).tb[1], (B).tb[2], (B).tb[3], (B).tb[4], (B).tb[5], (B).tb[6], (B).tb[7], \
     (unsigned)((B).tcs[0] | ((B).tcs[1] << 16)), (unsigned)((B).tcs[2] | ((B).tcs[3] << 16)), (unsigned)((B).tcs[4] | ((B).tcs[5] << 16)), (unsigned)((B).tcs[6] | ((B).tcs[7] << 16)), (B)
 
 template <int LA, int LB, bool VA, bool VB>
@@ -525,6 +535,7 @@ static int launch_gemm16_impl(int la, int lb, int nf, const GemmBatch* gb_in, in
         // weight gradients with nothing to accumulate into: the instantiation without slot loads; with the optimizer in some tasks'
         // epilogues (FLAG_ADAM): the instantiation that loads the parameter / moment slots (EPI_DWA)
         bool plain = !s_generic, opt = false;
+        planned.xcd_runs = s_dw_xcd && total_tiles >= 64 ? 1 : 0;
         for (int q = 0; q < gb->ntasks; ++q) {
             plain = plain && gb->t[q].epi == EPI_DW && !(gb->t[q].flags & FLAG_ACCUM);
             if (gb->t[q].flags & FLAG_ADAM) { opt = true; if (!gb->t[q].ad_p || !gb->t[q].ad_grp) return -3; }

@@ -1059,6 +1059,12 @@ __global__ __launch_bounds__(256, 3) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
 #undef X3S_LOAD
     __syncthreads();                                             // (the epilogue's patches and the bias sums reuse stage 0)
 
+    // split-K without a finishing launch (FLAG_FIN_INLINE): every split workgroup writes its partial tile THROUGH to memory (the XCDs' L2s are
+    // not coherent with each other inside a launch), takes a ticket on the tile's counter, and the LAST one to arrive sums the slabs IN SPLIT ORDER
+    // (its own included, from memory: the arithmetic of gemm_lds_fin_kernel, bit for bit) and runs the epilogue.  The counters sit behind the
+    // task's slabs, zero between launches (the last arrival resets its own).
+    const bool inl = splits > 1 && (t.flags & FLAG_FIN_INLINE);
+    const int C4p = (Cn + 3) & ~3;
     if (want_bias) {       // row sums of the k-major A: this thread holds rows 4 (tid % 16) .. over its 16 k slots
         float* part = lds;                                   // [64 rows][16 k slots]
         const int c4 = (int)(threadIdx.x & 15) * 4, ks = (int)(threadIdx.x >> 4);
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
 #pragma unroll
             for (int z = 0; z < 16; ++z) s0 += q[z];
             const int r = r0 + threadIdx.x;
-            if (r < R) { if (splits > 1) t.bslab[(size_t)split * R + r] = s0; else t.out2[r] = s0; }
+            if (r < R) { if (inl) dp_store1(t.bslab + (size_t)split * R + r, s0); else if (splits > 1) t.bslab[(size_t)split * R + r] = s0; else t.out2[r] = s0; }
         }
         __syncthreads();
     }
@@ -1087,11 +1093,46 @@ __global__ __launch_bounds__(256, 3) void gemm_x3s_kernel(GL_DIR_PARAMS, GemmBat
         const f32x4 v = *reinterpret_cast<const f32x4*>(E + rr * 36 + cc);
         const int r = r0 + wr * 32 + rr, c = c0 + wc * 32 + cc;
         if (r < R && c < Cn) {
-            if (splits > 1) st4(t.slab + ((size_t)split * R + r) * ((Cn + 3) & ~3) + c, v);
+            if (inl) dp_store4(t.slab + ((size_t)split * R + r) * C4p + c, v);
+            else if (splits > 1) st4(t.slab + ((size_t)split * R + r) * C4p + c, v);
             else gl_epilogue4(t, r, c, v, &bpre);
         }
     }
+    if (!inl) return;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this thread's write-through stores have reached memory
+    __syncthreads();
+    int* const tick = reinterpret_cast<int*>(t.slab + (size_t)splits * R * C4p) + rem;
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(tick, 1);
+        const int last = old == splits - 1;
+        if (last) atomicExch(tick, 0);
+        reinterpret_cast<volatile int*>(lds)[0] = last;          // (stage 0 is free: the patches above were consumed before the barrier)
+    }
+    __syncthreads();
+    if (reinterpret_cast<volatile int*>(lds)[0] == 0) return;
+#pragma unroll 2
+    for (int it = 0; it < 4; ++it) {
+        const int rr = it * 8 + (lane >> 3), cc = (lane & 7) * 4;
+        const int r = r0 + wr * 32 + rr, c = c0 + wc * 32 + cc;
+        if (r < R && c < Cn) {
+            const float* p = t.slab + (size_t)r * C4p + c;
+            const size_t stride = (size_t)R * C4p;
+            f32x4 v = dp_load4(p);
+            for (int s = 1; s < splits; ++s) v += dp_load4(p + s * stride);
+            gl_epilogue4(t, r, c, v);
+        }
+    }
+    if (want_bias && threadIdx.x < 64) {
+        const int r = r0 + threadIdx.x;
+        if (r < R) {
+            float s0 = dp_load1(t.bslab + r);
+            for (int q = 1; q < splits; ++q) s0 += dp_load1(t.bslab + (size_t)q * R + r);
+            t.out2[r] = s0;
+        }
+    }
 }
+
+#include "gemm_x3q.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1154,8 +1195,20 @@ static int launch_x3s(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& g
     return (int)hipGetLastError();
 }
 
+static int launch_x3q(int la, int lb, dim3 g, hipStream_t st, const GemmBatch& gb, const int* dir) {
+    if (la != LD_ROW) return -1;
+    for (int q = 0; q < gb.ntasks; ++q) {
+        const GemmTask& t = gb.t[q];
+        if ((t.flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) || (t.K & 15) || t.K < 32 || t.splits != 1 || (lb == LD_COL && ((t.Cn & 7) || t.Cn < 8))) return -2;
+    }
+    if (lb == LD_ROW) hipLaunchKernelGGL((gemm_x3q_kernel<LD_ROW>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+    else if (lb == LD_COL) hipLaunchKernelGGL((gemm_x3q_kernel<LD_COL>), g, dim3(256), 0, st, GL_DIR_ARGS(dir), gb);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
 // bt: 64 / 128 = fp32-MFMA tiles; 129 = the 128-wide tile on the bf16 pipe (bf16x3); 65 = the 64-wide tile on the bf16 pipe; 257 = the 256 x 128 tile on the
-// bf16 pipe (persistent workgroups: gemm_x3w.h)
+// bf16 pipe (persistent workgroups: gemm_x3w.h); 33 = the 32 x 32 tile on the bf16 pipe whose four waves split K (gemm_x3q.h)
 extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, int total_tiles, int fin_blocks, hipStream_t st) {
     if (total_tiles <= 0) return 0;
     int dir[GEMM_MAX_TASKS], fdir[GEMM_MAX_TASKS];
@@ -1163,7 +1216,8 @@ extern "C" int rl_launch_gemm_lds(int bt, int la, int lb, const GemmBatch* gb, i
         dir[q] = q < gb->ntasks ? gb->t[q].tile_base : 0x7fffffff;
         fdir[q] = (q < gb->ntasks && gb->t[q].splits > 1) ? gb->t[q].fin_base : 0x7fffffff;
     }
-    int rc = bt == 257 ? launch_x3w(la, lb, total_tiles, st, *gb, dir) : bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb, dir) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb, dir)
+    int rc = bt == 33 ? launch_x3q(la, lb, dim3(total_tiles), st, *gb, dir)
+           : bt == 257 ? launch_x3w(la, lb, total_tiles, st, *gb, dir) : bt == 65 ? launch_x3s(la, lb, dim3(total_tiles), st, *gb, dir) : bt == 129 ? launch_x3(la, lb, dim3(total_tiles), st, *gb, dir)
            : bt == 128 ? launch_bt<128>(la, lb, dim3(total_tiles), st, *gb, dir) : launch_bt<64>(la, lb, dim3(total_tiles), st, *gb, dir);
     if (rc != 0) return rc;
     if (fin_blocks > 0) {
@@ -1257,6 +1311,15 @@ extern "C" int rl_gemm_lds_route(const GemmTask* t, int la, int lb, int extra_fl
     // (operands that are not 16-byte regular -- rows of 119 floats, a block that starts inside another buffer -- take the any-alignment loaders of the
     // same tile (x3s_load_*<2>); RLREP_DISABLE=x3s_unaligned keeps such stages on the fp32 tile as before.  A 4-byte-staging instantiation was built and
     // measured first -- spedersac 968 with it against 1 002 with those stages on fp32, ctrlsac F = 2048 865 against 904)
+    // few rows, long inner dimension (ctrlsac's M = 256 layers at main.py's dimensions): where the 64-wide tile would cut K into slabs and a
+    // 32 x 32 tiling has enough workgroups without them, the tile whose four waves split K among themselves (gemm_x3q.h): no slab, no finishing
+    // launch.  RLREP_DISABLE=x3q keeps the 64-wide tile.
+    if (bt == 64 && *splits > 1 && la == LD_ROW && !rl_off("x3") && !rl_off("x3q") && !(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) &&
+        (t->K & 15) == 0 && t->K >= 512 && (lb == LD_ROW || (t->Cn & 7) == 0) && t->Cn >= 32 && t->R <= 256 &&
+        (long long)((t->R + 31) / 32) * ((t->Cn + 31) / 32) >= 192) {          // (R <= 256: spedersac's M = 1024 critic layers measured 0.8 % slower on it)
+        *splits = 1; *kchunk = t->K;
+        return 33;
+    }
     if (bt == 64 && !rl_off("x3") && !rl_off("x3s") &&
         (!(*flags & (FLAG_SCALAR_A | FLAG_SCALAR_B)) || (x3s_unaligned_ok(t) && !rl_off("x3s_unaligned")))) return 65;
     return bt;

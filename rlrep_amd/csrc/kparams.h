@@ -192,7 +192,7 @@ struct NcFwdTask {
 };
 
 #define NC_MAX_TASKS 4
-struct NcFwdBatch { int ntasks; int engine; int cols; NcFwdTask t[NC_MAX_TASKS]; };     // passed by value (kernarg)
+struct NcFwdBatch { int ntasks; int engine; int cols; int nt_u; NcFwdTask t[NC_MAX_TASKS]; };     // nt_u: U stored non-temporally (RLREP_ENABLE=nc_u_nt)     // passed by value (kernarg)
 
 struct NcDwTask {
     const float* U; const float* GH; int ldgh;     // [B*N, H], [B, H]
@@ -234,20 +234,20 @@ struct InfoNce {
 // second set (X2 != nullptr; blockIdx.y == 1): another weighted column sum in the same launch, plus the sum of its weights (outb2) -- spedersac's
 // theta.l weight / bias gradient (sum_i drhat_i phi_i, sum_i drhat_i) rides with v = sum_k c_k mu_r,k instead of a launch of its own
 // dp.world > 1 (attached data-parallel agent; dp_pull.h DpSlots): the FIRST set's column sums are this rank's PARTIAL of a sum over the global
-// batch -- they are pushed into every rank's slot area and the launch's last block raises READY; the launch that consumes the vector sums the
-// ranks' partials itself (speder_rows_kernel: Phibar; speder_grads_kernel: v)
+// batch -- they are pushed into every rank's slot area and the launch's last block raises READY; a ONE-block launch behind it (comm.hip
+// comm_slots_sum_kernel) waits for all ranks and files the rank-ordered sum where the single-GPU kernels read the vector.  (The consumers
+// summing the slots themselves -- zero launches -- was built first: 512 workgroups x 1 024 cache-bypassing loads of the SAME two lines took
+// 1.4 ms per train(), docs/history/r06.md.)
 struct ColSum { const float* X; int ldX; const float* w; float* out; int rows, F; const float* X2; int ldX2; const float* w2; float* out2; float* outb2; int rows2; DpSlots dp; };
-#define RL_SLOTS_MAX_F 2048            /* the consumers keep the summed vector in LDS */
+#define RL_SLOTS_MAX_F 65536
 struct SpederRows {
     const float* phi; const float* mu; const float* mu_r; const float* phibar;
     const float* theta_w; const float* theta_b; const float* r;
     float* c; float* drhat; float* partial; int B, F, nblk; float inv_batch; GroupCfg* step;
-    float* phibar_out; DpSlots dp;       // dp.world > 1: Phibar = rank-ordered sum of the ranks' partials (block 0 files it in phibar_out for speder_grads)
 };
 struct SpederGrads {
     const float* phi; const float* mu; const float* c; const float* drhat; const float* phibar; const float* v;
     const float* theta_w; float* Gphi; float* Gmu; int B, F; float inv_batch;
-    DpSlots dp;                          // dp.world > 1: v = rank-ordered sum of the ranks' partials
 };
 // diffsrsac critic regulariser (diffsrsac_agent.py:62-75): per head x = l2(elu(l2(sin(l1 z)))) [B, H] and its Gram matrix C = x^T x [H, H]:
 //   reg = lambda * ( (sum C^2 - sum_i |x_i|^4) / ((B - 1) B)  -  2 mean_i |x_i|^2 / H  +  1 / H ),  sum C^2 = sum_ij (x_i . x_j)^2

@@ -832,8 +832,15 @@ __global__ __launch_bounds__(256) void nc_fwd_x3q_kernel(NcFwdBatch nb) {
 #ifndef RL_NC_NOU            /* (timing-only diagnostic build: no U stores) */
             if (t.U) {
                 float* up = t.U + ((size_t)b * N) * H + col;
+                if (nb.nt_u) {
+                    // (10.5 MB of elu outputs per forward that nothing reads before the backward -- streamed past the L2 lines the
+                    //  feature chain's launches live in; RLREP_ENABLE=nc_u_nt, measured in docs/history/r06.md)
 #pragma unroll
-                for (int n = 0; n < 20; ++n) up[(size_t)n * H] = y[n];
+                    for (int n = 0; n < 20; ++n) __builtin_nontemporal_store(y[n], up + (size_t)n * H);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 20; ++n) up[(size_t)n * H] = y[n];
+                }
             }
 #endif
         }

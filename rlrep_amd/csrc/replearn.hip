@@ -115,18 +115,9 @@ __global__ __launch_bounds__(1024) void colsum_kernel(ColSum q) {
 //   L = -(2/B) sum_i phi_i.mu'_i + (1/B^2) sum_k (Phibar.mu_r,k)^2 + 0.5*mean (theta.phi_i + b - r_i)^2
 // rows kernel: c_k = Phibar.mu_r,k ; d_i = phi_i.mu'_i ; rhat_i ; partial sums
 // ------------------------------------------------------------------------------------------------
-template <bool DP>
 __global__ __launch_bounds__(256) void speder_rows_kernel(SpederRows p) {
     __shared__ float shp[4][3];
-    __shared__ float sphibar[DP ? RL_SLOTS_MAX_F : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float* __restrict__ phibar = p.phibar;
-    if constexpr (DP) {
-        // Phibar over the GLOBAL random batch: the ranks' partials were pushed by the colsum launch in front of this one
-        dp_slots_sum(p.dp, sphibar);
-        if (blockIdx.x == 0) for (int f = threadIdx.x; f < p.F; f += 256) p.phibar_out[f] = sphibar[f];
-        phibar = sphibar;
-    }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int i = blockIdx.x * 4 + w; i < p.B; i += gridDim.x * 4) {
         const float* ph = p.phi + (size_t)i * p.F;
@@ -136,7 +127,7 @@ __global__ __launch_bounds__(256) void speder_rows_kernel(SpederRows p) {
         for (int f = lane; f < p.F; f += 64) {
             const float x = ph[f];
             d = fmaf(x, mu[f], d);
-            c = fmaf(mr[f], phibar[f], c);
+            c = fmaf(mr[f], p.phibar[f], c);
             rh = fmaf(x, p.theta_w[f], rh);
         }
         d = wave_sum(d); c = wave_sum(c); rh = wave_sum(rh) + p.theta_b[0];
@@ -155,18 +146,14 @@ __global__ __launch_bounds__(256) void speder_rows_kernel(SpederRows p) {
 
 // gradients w.r.t. the four feature matrices, written as one [2B, F] block each for phi and mu
 // (rows 0..B-1: batch 1, rows B..2B-1: the "random" batch) so that the backward GEMMs see M = 2B
-template <bool DP>
 __global__ __launch_bounds__(256) void speder_grads_kernel(SpederGrads p) {
-    __shared__ float sv[DP ? RL_SLOTS_MAX_F : 1];
-    const float* __restrict__ v = p.v;
-    if constexpr (DP) { dp_slots_sum(p.dp, sv); v = sv; }
     const long long n = (long long)p.B * p.F;
     const float k1 = -2.f * p.inv_batch, k2 = 2.f * p.inv_batch * p.inv_batch;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
         const int i = (int)(e / p.F), f = (int)(e - (long long)i * p.F);
         p.Gphi[e] = k1 * p.mu[e] + p.drhat[i] * p.theta_w[f];
         p.Gmu[e] = k1 * p.phi[e];
-        p.Gphi[n + e] = k2 * v[f];
+        p.Gphi[n + e] = k2 * p.v[f];
         p.Gmu[n + e] = k2 * p.c[i] * p.phibar[f];
     }
 }
@@ -513,21 +500,13 @@ extern "C" int rl_launch_colsum(const ColSum* p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_speder_rows(const SpederRows* p, hipStream_t st) {
-    if (p->dp.world > 1) {
-        if (p->F > RL_SLOTS_MAX_F || p->dp.n < p->F || !p->phibar_out) return -7;
-        hipLaunchKernelGGL(speder_rows_kernel<true>, dim3(p->nblk), dim3(256), 0, st, *p);
-    } else
-    hipLaunchKernelGGL(speder_rows_kernel<false>, dim3(p->nblk), dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(speder_rows_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_speder_grads(const SpederGrads* p, hipStream_t st) {
     long long n = (long long)p->B * p->F;
     int g = (int)((n + 1023) / 1024); if (g > 2048) g = 2048; if (g < 1) g = 1;
-    if (p->dp.world > 1) {
-        if (p->F > RL_SLOTS_MAX_F || p->dp.n < p->F) return -7;
-        hipLaunchKernelGGL(speder_grads_kernel<true>, dim3(g), dim3(256), 0, st, *p);
-    } else
-    hipLaunchKernelGGL(speder_grads_kernel<false>, dim3(g), dim3(256), 0, st, *p);
+    hipLaunchKernelGGL(speder_grads_kernel, dim3(g), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 extern "C" int rl_launch_diffsr_perturb(const DiffsrPerturb* p, hipStream_t st) {

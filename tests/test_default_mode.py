@@ -245,6 +245,27 @@ def test_train_pools_are_the_documented_streams():
         assert np.max(np.abs(ep - philox.normals(ep.size, 1.0, agent._seed, (2 << 40) + call))) <= 4e-6
 
 
+def test_train_prologue_without_a_feature_step_still_advances_the_streams():
+    """A C-ABI caller that runs rlrep_train_prologue and then only the critic step (no launch that refreshes the train() counter's mirror:
+    advisor r05) must not draw the same indices and noise again: the next prologue catches the mirror up itself (one extra launch)."""
+    from oracle import philox
+    c = Case('vlsac_tiny')
+    agent, buf = _default_agent(c), _buffer(c)
+    core = agent.core
+    ip = torch.zeros(c.B, dtype=torch.int32, device='cuda')
+    ep = torch.zeros(2 * c.B * c.A, device='cuda')
+    seen = []
+    for call in range(1, 4):
+        core.train_prologue(buf.ring, buf.size_dev(), ip, ep, 99, 1 << 40, 2 << 40, c.B)
+        core.critic_step(ep[:c.B * c.A].view(c.B, c.A))
+        core.end_train()
+        torch.cuda.synchronize()
+        got = ip.cpu().numpy()
+        assert np.array_equal(got, philox.indices(got.size, c.meta['replay_n'], 99, (1 << 40) + call)), call
+        seen.append(got.copy())
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+
+
 # ---- the opt-in row-program form of the vlsac feature step (rowprog.hip) ---------------------------------------------------------
 @_needs_experiments()
 @pytest.mark.parametrize('name,single', [('vlsac_tiny', False), ('vlsac_hc', False), ('vlsac_tiny', True)])

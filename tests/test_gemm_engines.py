@@ -4,6 +4,8 @@ use (forward X W^T, dX = G W, dW = G^T X), every generic epilogue, ragged tile e
 
 Tolerance: 1e-5 relative L2 per output (fp32 MFMA is an exact fma chain; the only difference to NumPy is summation
 order), well inside the 1e-4 parity bar of BASELINE.json."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -45,7 +47,7 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0):
+def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, splits=0, seed=0, inline_fin=False):
     """mode: 'fwd' (A [R,K], B [Cn,K]), 'dx' (A [R,K], B [K,Cn]), 'dw' (A [K,R], B [K,Cn]).  Returns (got, want, extra)."""
     from rlrep_amd import _lib
     rs = np.random.RandomState(seed)
@@ -60,7 +62,7 @@ def run_gemm(engine, mode, R, Cn, K, act='none', accum=False, bias=True, bt=0, s
     dA, dB, dC = _dev(A), _dev(Bm), _dev(C0)
     bias_v = aux = out2 = None
     epi = {'fwd': 0, 'dx': 1, 'dw': 3}[mode]
-    flags = 1 if accum else 0
+    flags = (1 if accum else 0) | (4 if inline_fin else 0)
     extra_want = None
     if mode == 'fwd':
         bias_v = rs.standard_normal(Cn).astype(np.float32) if bias else None
@@ -104,6 +106,49 @@ def check(engine, mode, R, Cn, K, **kw):
     assert rel(got, want) < 1e-5, (engine, mode, R, Cn, K, kw, rel(got, want))
     if extra is not None:
         assert rel(extra[0], extra[1]) < 1e-5, ('second output', engine, mode, R, Cn, K, kw, rel(extra[0], extra[1]))
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx'])
+def test_bf16x3_32_by_32_tile_with_k_split_over_its_waves_is_fp32_accurate(mode):
+    """gemm_x3q_kernel (csrc/gemm_x3q.h): 32 x 32 output tiles, the four waves of a workgroup take a quarter of K each through private LDS
+    patches, partial tiles added in quarter order -- ctrlsac's M = 256 layers at main.py's dimensions without slabs or a finishing launch.
+    fp32 accuracy against float64 (bf16x3: exact three-way split), ragged rows / columns / quarters, every epilogue of its forms, bit-identical
+    reruns, and through the automatic plan."""
+    act = 'elu'
+    check(2, mode, 256, 1024, 1024, bt=32, act=act, seed=101)
+    check(2, mode, 256, 2048, 1024, bt=32, act='relu', seed=102)
+    check(2, mode, 256, 1024, 2048, bt=32, seed=103, accum=(mode == 'dx'))
+    check(2, mode, 200, 136, 528, bt=32, act='tanh', seed=104)            # ragged rows, columns (multiple of 8) and K quarters (528 = 4 x 132 -> 160-deep quarters)
+    check(2, mode, 36, 64, 48, bt=32, seed=105)                           # K shorter than four slices: two waves multiply nothing
+    check(2, mode, 64, 40, 32, bt=32, act='sin' if mode == 'fwd' else 'none', seed=106)
+    a, _, _ = run_gemm(2, mode, 256, 1024, 1024, bt=32, seed=107)
+    b, _, _ = run_gemm(2, mode, 256, 1024, 1024, bt=32, seed=107)
+    assert np.array_equal(a, b)
+    ref, _, _ = run_gemm(1, mode, 256, 1024, 1024, bt=64, splits=1, seed=107)
+    assert rel(a, ref) < 2e-6
+    if mode == 'fwd':
+        from rlrep_amd import _lib
+        eng, tile, sp = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib.rlrep_gemm_plan(0, 0, 256, 1024, 1024, 1024, 1024, 1024, C.byref(eng), C.byref(tile), C.byref(sp), None, None), 'plan')
+        assert (eng.value, tile.value, sp.value) == (2, 32, 1)
+        _lib.check(_lib.lib.rlrep_gemm_plan(0, 0, 2048, 512, 512, 512, 512, 512, C.byref(eng), C.byref(tile), C.byref(sp), None, None), 'plan')
+        assert tile.value == 64          # (spedersac's M = 2048 layers: enough 64-wide tiles without a split)
+
+
+@pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])
+@pytest.mark.parametrize('splits', [2, 3, 7])
+def test_bf16x3_64_tile_finishes_split_k_inside_the_launch_bit_for_bit(mode, splits):
+    """The 64-wide bf16x3 tile with split-K: the LAST split workgroup of every output tile sums the slabs in split order and runs the epilogue
+    (FLAG_FIN_INLINE: write-through slab stores, a ticket word per tile) == the finishing launch it replaces, bit for bit -- ragged edges, the
+    activation epilogues, accumulation and the bias gradient included; run twice over the same workspace (the tickets reset themselves)."""
+    for R, Cn, K, kw in ((256, 1024, 1024, dict(act='elu' if mode != 'dw' else 'none')), (200, 132, 708, dict(accum=(mode != 'fwd'))), (256, 2048, 1056, {})):
+        for rep in range(2):
+            a, want, ea = run_gemm(2, mode, R, Cn, K, bt=64, splits=splits, seed=90 + rep, inline_fin=True, **kw)
+            b, _, eb = run_gemm(2, mode, R, Cn, K, bt=64, splits=splits, seed=90 + rep, inline_fin=False, **kw)
+            assert np.array_equal(a, b), (mode, splits, R, Cn, K)
+            assert rel(a, want) < 1e-5
+            if ea is not None:
+                assert np.array_equal(ea[0], eb[0]), ('second output', mode, splits, R, Cn, K)
 
 
 @pytest.mark.parametrize('mode', ['fwd', 'dx', 'dw'])

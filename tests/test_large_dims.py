@@ -106,12 +106,15 @@ def test_spedersac_ant_dimensions_two_trains():
 def test_spedersac_split_k_gradients_summed_by_the_optimizer_launch(monkeypatch):
     """Builder::fold_fin (AdamTask::Slab with padded slab rows): the split-K partials of phi / mu's weight gradients -- [512, 119] and [512, 111]
     among them, slab rows padded to 120 / 112 floats -- are added in split order by the feature group's optimizer launch instead of a finishing
-    launch.  Against RLREP_DISABLE=fold_dwfin: one launch less per feature step, parameters and moments BIT-identical after two train() calls at
-    Ant dimensions (both forms are checked against the oracle by _run)."""
+    launch.  Against RLREP_DISABLE=fold_dwfin (a finishing launch: one more per feature step) and RLREP_ENABLE=fin_inline on top of it (the 64-wide
+    bf16x3 tile finishes EVERY split-K product inside the launch -- the last split workgroup of a tile, FLAG_FIN_INLINE; opt-in: measured slower):
+    parameters and moments BIT-identical after two train() calls at Ant dimensions (all forms are checked against the oracle by _run)."""
     outs, counts = [], []
-    for fold in (True, False):
-        if not fold:
-            monkeypatch.setenv('RLREP_DISABLE', 'fold_dwfin')
+    for off, on in (('', ''), ('fold_dwfin', ''), ('fold_dwfin', 'fin_inline')):
+        if off:
+            monkeypatch.setenv('RLREP_DISABLE', off)
+        if on:
+            monkeypatch.setenv('RLREP_ENABLE', on)
         from rlrep_amd import _lib
         n0 = _lib.lib.rlrep_launch_counter()
         a = _run('spedersac', ('rlrep_amd.agent.spedersac.spedersac_agent', 'SPEDERSACAgent'), 111, 8, 1024,
@@ -125,7 +128,9 @@ def test_spedersac_split_k_gradients_summed_by_the_optimizer_launch(monkeypatch)
         del a
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[2][k]), k
     assert counts[1] == counts[0] + 2 * 2, counts          # (two train() calls x two feature steps)
+    assert counts[2] < counts[0], counts                   # (no finishing launch behind any split stage)
 
 
 def test_diffsrsac_wide_nabla_mu_head_on_bf16x3():

@@ -56,13 +56,13 @@ def test_loopback_exchanges_are_rank_ordered_sums(world):
     """One-shot pull, two-shot (reduce-scatter + all-gather inside one launch) and the pull all-gather, `world` ranks on `world` streams of one
     GPU (HIP gives a process four concurrent hardware queues: four waiting ranks at most).  Every rank must hold exactly the rank-ordered float32 sum."""
     from rlrep_amd._lib import lib
-    from rlrep_amd.comm import LoopbackGroup, _Arena
+    from rlrep_amd.comm import LoopbackGroup, _Arena, concurrent_streams
     torch.cuda.set_device(0)
     sizes = list(zip(SIZES, OFFSETS))
     grp = LoopbackGroup(world, max(SIZES) + 256, scratch_floats=world * 1024)
     for m in grp.members:
         m.set_timeout(5.0)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = concurrent_streams(world)
     outs = {}
     gathered = {}
 
@@ -107,7 +107,7 @@ def test_eight_ranks_one_after_the_other_read_fan_in_of_a_full_node():
         grp[r].arena[off:off + n].copy_(torch.from_numpy(_data(r, n, 77)).cuda())
     torch.cuda.synchronize()
     for r in range(world):
-        check(lib.rlrep_comm_debug_preset(grp[r].h, 7), 'debug_preset')
+        check(lib.rlrep_comm_debug_preset(grp[r].h, 7, 1), 'debug_preset')
         got = grp[r].all_reduce(off, n, mode=1, timeout_us=2_000_000)
         torch.cuda.synchronize()
         assert grp[r].status() == 0
@@ -171,7 +171,8 @@ def test_loopback_three_ranks_two_shot_equals_one_shot_and_the_oracle(case):
         assert all(a.core.fused_groups for a in agents) and all(a.core.feature_exchange_count() == 0 for a in agents)
         rs = np.random.RandomState(11)
         per_call = [_inputs(c, rs, world) for _ in range(trains)]
-        streams = [torch.cuda.Stream() for _ in range(world)]
+        from rlrep_amd.comm import concurrent_streams
+        streams = concurrent_streams(world)
 
         def body(r):
             with torch.cuda.stream(streams[r]):

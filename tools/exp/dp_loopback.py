@@ -45,20 +45,12 @@ def run_arm(workload, world, calls, warm, attached, two_shot_kb):
         extra = dict(loopback=(grp, r)) if attached else {}
         agents.append(bench.make_agent(alg, S, A, B, {**kw, **extra}))
         bufs.append(bench.synth_buffer(S, A, seed=r)[0])
+    from rlrep_amd.comm import concurrent_streams
+    ss = concurrent_streams(2 * world)          # (HIP gives a process four concurrent hardware queues: world <= 2 for the two-chain form)
     if not attached:
-        # independent replicas still need their own stream pairs: hand each one pair `r` of the mutually concurrent set
-        import rlrep_amd.agent.sac.sac_agent as sa
-        for r, a in enumerate(agents):
-            a._loopback_index = r
-        orig = sa._concurrent_stream_pair
-
-        def pair(core, index=0):
-            for r, a in enumerate(agents):
-                if a.core is core:
-                    return orig(core, r)
-            return orig(core, index)
-        sa._concurrent_stream_pair = pair
-    streams = [torch.cuda.Stream() for _ in range(world)]
+        for r, a in enumerate(agents):          # independent replicas: the same disjoint stream pairs the attached ones take
+            a._stream_pair_override = (ss[2 * r], ss[2 * r + 1])
+    streams = [ss[2 * r] for r in range(world)]      # the caller's stream of replica r = one of ITS OWN two (a fifth stream would share a hardware queue with some chain)
     for r in range(world):                      # graphs are captured one replica after the other (a capture synchronises the device), replayed side by side
         with torch.cuda.stream(streams[r]):
             agents[r].prepare(bufs[r], B)
@@ -113,6 +105,44 @@ def run_arm(workload, world, calls, warm, attached, two_shot_kb):
     return out
 
 
+def run_alone(workload, calls, warm, attached):
+    """ONE replica on the chip: a plain single-GPU agent, or rank 0 of a two-rank group whose peer is marked as always arrived
+    (rlrep_comm_debug_preset: every wait passes at once, the peer's arena holds zeros) -- the protocol's own price (flag reads, the handshake's
+    stores and polls, system-scope loads of two arenas where one gradient was read) with no waiting and no contention in it."""
+    import bench
+    from rlrep_amd._lib import lib, check
+    from rlrep_amd.comm import LoopbackGroup
+    alg, S, A, B, kw = bench.WORKLOADS[workload]
+    grp = LoopbackGroup(2) if attached else None
+    torch.manual_seed(0)
+    agent = bench.make_agent(alg, S, A, B, {**kw, **(dict(loopback=(grp, 0)) if attached else {})})
+    buf = bench.synth_buffer(S, A, seed=0)[0]
+    if attached:
+        for ch in range(8):
+            check(lib.rlrep_comm_debug_preset(grp[0].h, ch, 1 << 30), 'debug_preset')
+    for _ in range(warm):
+        agent.train(buf, B)
+    agent.flush()
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            agent.train(buf, B)
+        agent.flush()
+        torch.cuda.synchronize()
+        rates.append(calls / (time.perf_counter() - t0))
+    out = dict(arm='alone_attached_peer_preset' if attached else 'alone_single_gpu', calls=calls, train_per_s=[round(r, 1) for r in rates], median=round(float(np.median(rates)), 1),
+               form=('pipe' if agent._pipe is not None else 'graph'))
+    if attached:
+        out['fused_groups'] = sorted(agent.core.fused_groups)
+        out['status'] = int(agent.core.exchange.status(raise_on_error=False))
+    del agent
+    if grp is not None:
+        grp.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='vlsac_halfcheetah_f256_b256')
@@ -125,9 +155,14 @@ def main():
     torch.cuda.set_device(0)
     res = []
     for arm in args.arms.split(','):
-        res.append(run_arm(args.workload, args.world, args.calls, args.warm, arm == 'attached', args.two_shot_kb))
+        if arm.startswith('alone'):
+            res.append(run_alone(args.workload, args.calls, args.warm, arm == 'alone_attached'))
+        else:
+            res.append(run_arm(args.workload, args.world, args.calls, args.warm, arm == 'attached', args.two_shot_kb))
         print(json.dumps(res[-1]), flush=True)
     by = {r['arm']: r for r in res}
+    if 'alone_attached_peer_preset' in by and 'alone_single_gpu' in by:
+        print(json.dumps(dict(workload=args.workload, protocol_only_attached_over_single=round(by['alone_attached_peer_preset']['median'] / by['alone_single_gpu']['median'], 4))), flush=True)
     if 'attached' in by and 'unattached' in by:
         print(json.dumps(dict(workload=args.workload, world=args.world, two_shot_kb=args.two_shot_kb,
                               attached_over_unattached=round(by['attached']['aggregate_train_per_s'] / by['unattached']['aggregate_train_per_s'], 4))), flush=True)
