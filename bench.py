@@ -368,13 +368,15 @@ def pmc_traffic(path, fam):
     if not nd['FETCH_SIZE'] or not nd['WRITE_SIZE'] or not calls:
         return None
     per_train = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) / calls
-    launches = nd['FETCH_SIZE'] / calls                      # launches of the family per train() IN THE PROFILED RUN (eager sequential programs)
+    launches = nd['FETCH_SIZE'] / calls                      # launches of the family per train() IN THE PROFILED RUN (see profiled_form)
     per_launch = per_train / launches
     alg = fam['algorithmic_mbytes_per_train'] * 1e6
     return {'bytes_per_launch': round(per_launch), 'bytes_per_train': round(per_train), 'algorithmic_bytes_per_train': round(alg),
             'ratio_to_algorithmic': round(per_train / alg, 2) if alg > 0 else None,
             'source': os.path.relpath(path, ROOT), 'correction': '(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B, each counter summed over every dispatch of its pass / train() calls of the run; separate --pmc passes; Infinity-Cache hits counted',
             'dispatches': nd['FETCH_SIZE'], 'train_calls': calls, 'launches_per_train_profiled': round(launches, 2),
+            # 'graph': the PMC passes ran the form that is timed (hipGraph replay, two chains); 'eager': --no-graph (same kernels, sequential programs)
+            'profiled_form': d.get('__meta__', {}).get('form', 'eager'),
             'coverage': {'fetch_dispatches': nd['FETCH_SIZE'], 'write_dispatches': nd['WRITE_SIZE'], 'passes_agree': d.get('__meta__', {}).get('passes_agree'),
                          'expected_dispatches': fam['launches_per_train'] * calls}}
 
@@ -831,6 +833,14 @@ def main():
         fe = (getattr(agent, '_pipe', None) or {}).get('front_ends') or getattr(agent, '_graph_front_ends', None)
         if fe:
             out['front_end_launches'] = fe
+            td = (out.get('roofline') or {}).get('traffic_detail')
+            if td and td.get('profiled_form') == 'graph' and (out.get('roofline') or {}).get('family') == 'gemm16':
+                # the PMC passes ran the TIMED form (graph replay): its family launches per train() = the 16-row engine's launches in the captured graphs
+                # (+ the heads_vae launch of every vlsac feature step); the stage count above it (`launches_per_train` of the family) is that of the
+                # sequential step programs, in which the chained feature steps' first layers are launches of their own
+                n_timed = sum(int(v) for v in fe.values()) + ((kw.get('extra_feature_steps', -1) + 1) if alg == 'vlsac' else 0)
+                td['launches_per_train_timed_form'] = n_timed
+                td['coverage']['expected_dispatches'] = n_timed * int(td['train_calls'])
         if alg == 'vlsac' and not args.quick:
             out['roofline_heaviest_kernel'] = dominant_kernel_roofline(agent, B, kw['feature_dim'], kw['hidden_dim'])
             out.setdefault('roofline', out['roofline_heaviest_kernel'])

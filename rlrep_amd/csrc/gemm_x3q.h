@@ -11,7 +11,9 @@
 //     __syncthreads in the loop, so the four waves of a workgroup (one per SIMD) and the two or three workgroups of a CU drift apart and cover
 //     each other's load / split / multiply phases;
 //   * LDS is only the transposition buffer: a slice's twelve fragments are read into registers at once, the next slice is split into the same
-//     patch while the MFMAs of this one run (same-wave LDS operations execute in order); loads run two slices ahead in two register sets;
+//     patch while the MFMAs of this one run (same-wave LDS operations execute in order); loads run two slices ahead in two register sets
+//     (three sets, loads three slices ahead, were measured: 12.6 us against 10.7 for 256 x 1024 x 1024 -- 216 VGPRs, a ninth slice of zeros per
+//     quarter of eight -- and ctrlsac 850 against 873 train()/s: docs/history/r06.md);
 //   * two accumulators (k-block 0 / k-block 1 of every slice) halve the dependent-MFMA chain;
 //   * at the end the four partial tiles meet in LDS, every wave adds its 8 rows of them IN QUARTER ORDER and runs the epilogue (gl_epilogue4: the
 //     forward / dX epilogues of the engine) -- deterministic, no slab, no finishing launch.

@@ -165,8 +165,11 @@ __device__ inline void finalize_tasks(const FinTask* __restrict__ fin, int nfin,
                 *f.out2 = (float)exp(st[0]);          // info['alpha'] is read after the optimizer step
             }
         } else if (f.kind == FIN_HISTORY) {
-            // the slots were written by earlier launches and by lane 0 of this wave just above: order those stores, then read past the L1
-            __threadfence();
+            // the slots were written by earlier launches and by lane 0 of this wave just above: wait until those stores have left (the vector L1 is
+            // write-through; the L2 is this XCD's point of coherence), then read past the L1.  (A __threadfence() here was an agent-scope release + acquire:
+            // a write-back and an invalidate of the XCD's L2 by the tail of a launch on the critical chain, once per train().)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
             int* seq = reinterpret_cast<int*>(const_cast<float*>(f.partials));
             const int n = *seq;
             float* rec = f.out + (size_t)(n % f.count) * RL_HIST_REC;

@@ -53,7 +53,8 @@ if bad and os.environ.get('RLREP_PMC_ALLOW_MISMATCH') != '1':
         print('   ', k, cnt, file=sys.stderr)
     sys.exit(3)
 pmc['__meta__'] = {'workload': wl, 'train_calls': calls, 'passes': sorted(passes), 'passes_agree': not bad,
-                   'command': f'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --workload {wl} --steps <N> --warmup 5 --no-cpu --no-graph --no-profile  (three passes: SQ_* / FETCH_SIZE / WRITE_SIZE + LDS, instruction counters)',
+                   'form': os.environ.get('RLREP_PMC_FORM', 'eager'),       # 'graph': the passes ran the timed form (hipGraph replay); 'eager': --no-graph
+                   'command': f'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --workload {wl} --steps <N> --warmup 5 --no-cpu ' + ('' if os.environ.get('RLREP_PMC_FORM') == 'graph' else '--no-graph ') + '--no-profile --quick  (three passes: SQ_* / FETCH_SIZE / WRITE_SIZE + LDS, instruction counters)',
                    'units': 'FETCH_SIZE / WRITE_SIZE in KB, raw (gfx950: x2 on FETCH_SIZE for wide reads before comparing with bytes)'}
 out = os.path.join(P, f'{tag}_pmc_{wl}.json')
 json.dump(pmc, open(out, 'w'), indent=1, sort_keys=True)
