@@ -46,7 +46,7 @@
 // launches they wait for -- rank 0's channel-1 launch, rank 1's channel-0 launch -- are on the OTHER stream of their rank and must become
 // resident BESIDE the spinning one.  They do if (1) the two streams map to different hardware queues (GPU_MAX_HW_QUEUES >= 2: HIP's default
 // is 4) and (2) the blocks of two optimizer launches fit the chip together: rl_agent_attach_dp asserts
-// max-two-groups (blocks + riders) <= CUs x occupancy(adam_dp_kernel) and refuses the attachment otherwise.  Launches of other kinds that
+// max-two-groups (blocks + riders) <= CUs x occupancy(adam_dp_kernel) and leaves the largest groups unattached until it holds.  Launches of other kinds that
 // share the chip with a spinning one finish on their own (they wait for nothing).  Within a two-shot launch a block spins on RED words that
 // depend on phase-A blocks of EVERY rank; phase-A blocks are the lowest-numbered ones and are dispatched first, and a launch that fits the
 // chip as a whole (asserted) has all of them resident.

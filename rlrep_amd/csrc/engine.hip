@@ -1940,26 +1940,22 @@ extern "C" int rl_agent_attach_dp(rlrep_agent* ag, const DpAttach* at, int* atta
         }
     }
     ag->dp_proto = *proto;
-    int mask = 0; long long big[2] = {0, 0};
+    int mask = 0;
+    long long blocks[4] = {0, 0, 0, 0};
     for (int g = 0; g < 4; ++g) {
         const bool on = proto->world > 1 && ag->L.group_n[g] > 0 && ag->L.group_n[g] <= at->max_floats;
         ag->dp_on[g] = on;
         ag->dp_two[g] = on && proto->world >= 3 && at->two_shot_floats > 0 && ag->L.group_n[g] >= at->two_shot_floats && proto->red[proto->rank] != nullptr;
-        if (on) {
-            mask |= 1 << g;
-            const long long blocks = (ag->L.group_n[g] + 1023) / 1024 + 1 + 256;            // optimizer blocks + trailing block + a folded snapshot's segments
-            if (blocks > big[0]) { big[1] = big[0]; big[0] = blocks; } else if (blocks > big[1]) big[1] = blocks;
-        }
+        if (on) { mask |= 1 << g; blocks[g] = (ag->L.group_n[g] + 1023) / 1024 + 1 + 256; }       // optimizer blocks + trailing block + a folded snapshot's segments
     }
-    if (mask) {
-        const long long slots = (long long)cus * std::min(occ1, occ2 > 0 ? occ2 : occ1);
-        if (big[0] + big[1] > slots) {
-            for (int g = 0; g < 4; ++g) ag->dp_on[g] = ag->dp_two[g] = false;
-            rl_set_error("comm_attach: two optimizer launches of this agent (%lld + %lld blocks) do not fit the device together (%d CUs x %d resident blocks): "
-                         "a spinning launch could keep the one it waits for from becoming resident; lower max_floats", big[0], big[1], cus, std::min(occ1, occ2 > 0 ? occ2 : occ1));
-            if (attached_mask) *attached_mask = 0;
-            return RLREP_ERR_ARG;
-        }
+    // the two largest attached launches must fit the chip together; a group that does not leave room for a second one is NOT attached (its
+    // gradients stay with the caller's all-reduce, as for every group above max_floats) -- largest first, until the bound holds
+    const long long slots = (long long)cus * std::min(occ1, occ2 > 0 ? occ2 : occ1);
+    while (mask) {
+        int g0 = -1, g1 = -1;
+        for (int g = 0; g < 4; ++g) if (mask & (1 << g)) { if (g0 < 0 || blocks[g] > blocks[g0]) { g1 = g0; g0 = g; } else if (g1 < 0 || blocks[g] > blocks[g1]) g1 = g; }
+        if (blocks[g0] + (g1 >= 0 ? blocks[g1] : 0) <= slots) break;
+        mask &= ~(1 << g0); ag->dp_on[g0] = ag->dp_two[g0] = false;
     }
     // batch-coupled exchanges: only when the feature group itself is attached (a train() is then one uninterrupted sequence of launches)
     const long long need = exchange_floats(ag->d, proto->world);

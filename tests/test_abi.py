@@ -77,9 +77,18 @@ def test_gemm_routing_of_the_path_shapes(monkeypatch):
     assert _plan(0, 0, 256, 256, 256)['engine'] == 0
     assert _plan(0, 0, 256, 512, 256)['engine'] == 0
     assert _plan(1, 1, 256, 256, 256)['engine'] == 0
-    # ctrlsac main.py dims: M = 256 layers -> 64-wide bf16x3 tiles (gemm_x3s_kernel) + split-K; weight gradients -> the same tile, no split
+    # ctrlsac main.py dims: M = 256 layers (forward, dX) -> the 32 x 32 bf16x3 tile whose four waves split K (gemm_x3q_kernel): no slabs; with
+    # RLREP_DISABLE=x3q the 64-wide tile (gemm_x3s_kernel) + split-K as before; weight gradients -> the 64-wide tile, no split
+    for la, lb in ((0, 0), (0, 1)):
+        p = _plan(la, lb, 256, 1024, 1024)
+        assert (p['engine'], p['tile'], p['splits'], p['kchunk']) == (2, 32, 1, 1024), p
+        assert _plan(la, lb, 256, 2048 if lb == 0 else 1024, 1024 if lb == 0 else 2048)['tile'] == 32      # phi.l3 forward / its dX
+    assert _plan(0, 0, 256, 256, 2048)['tile'] == 64                   # the score matrix: 64 tiles of 32 x 32 are too few
+    assert _plan(0, 0, 1024, 512, 512)['tile'] == 64                   # spedersac's M = 1024 critic layers stay on the 64-wide tile (R <= 256 only)
+    monkeypatch.setenv('RLREP_DISABLE', 'x3q')
     p = _plan(0, 0, 256, 1024, 1024)
     assert (p['engine'], p['tile']) == (2, 64) and p['splits'] == 4 and p['splits'] * p['kchunk'] >= 1024 > (p['splits'] - 1) * p['kchunk']
+    monkeypatch.delenv('RLREP_DISABLE')
     p = _plan(1, 1, 1024, 1024, 256)
     assert (p['engine'], p['tile'], p['splits']) == (2, 64, 1)
     # spedersac: both batches as one M = 2048 problem; the K = 119 first layer and its [512, 119] weight gradient have rows that are not
@@ -108,7 +117,7 @@ def test_gemm_routing_of_the_path_shapes(monkeypatch):
             for K in (64, 256, 1000, 4096, 50000):
                 p = _plan(0, 0, R, Cn, K)
                 if p['engine']:
-                    assert p['tile'] in (64, 128, 256) and p['kchunk'] % 32 == 0 and 1 <= p['splits'] <= 32
+                    assert p['tile'] in (32, 64, 128, 256) and (p['kchunk'] % 32 == 0 or p['tile'] == 32) and 1 <= p['splits'] <= 32
                     assert p['splits'] * p['kchunk'] >= K > (p['splits'] - 1) * p['kchunk'], (R, Cn, K, p)
 
 

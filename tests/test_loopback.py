@@ -199,3 +199,36 @@ def test_loopback_three_ranks_two_shot_equals_one_shot_and_the_oracle(case):
     for k, v in states['two_shot'].items():
         if k in P and not k.endswith('noise'):
             assert rel_l2(v, P[k].numpy()) < 1e-4, k
+
+
+def test_attach_leaves_out_groups_that_could_starve_the_other_chain():
+    """The co-residency bound of the two-chain train() (csrc/dp_pull.h, "Progress with SEVERAL channels in flight"): the waiting blocks of the two
+    largest attached optimizer launches must fit the chip together.  With the size cap lifted (RLREP_ENABLE=dp_fused_mb=64) ctrlsac at main.py's
+    dimensions has a 25 MB feature group -- 6 400 blocks of the 1 280 resident ones: it must stay with the caller's all-reduce, the critic and the
+    actor group are attached; at the default cap nothing changes for the headline agent (all three groups attached)."""
+    import bench
+    from rlrep_amd.comm import LoopbackGroup
+    old = os.environ.get('RLREP_ENABLE')
+    try:
+        os.environ['RLREP_ENABLE'] = 'dp_fused_mb=64'
+        alg, S, A, B, kw = bench.WORKLOADS['ctrlsac_halfcheetah_f2048_b256']
+        grp = LoopbackGroup(2)
+        agents = [bench.make_agent(alg, S, A, B, {**kw, 'loopback': (grp, r)}) for r in range(2)]
+        lay = agents[0].core.layout
+        assert lay.group_floats[0] * 4 > 20e6
+        assert 0 not in agents[0].core.fused_groups and {2} <= set(agents[0].core.fused_groups), agents[0].core.fused_groups
+        assert agents[0].core.fused_groups == agents[1].core.fused_groups
+        assert not agents[0]._fused_all
+        del agents
+        grp.close()
+    finally:
+        if old is None:
+            os.environ.pop('RLREP_ENABLE', None)
+        else:
+            os.environ['RLREP_ENABLE'] = old
+    alg, S, A, B, kw = bench.WORKLOADS['vlsac_halfcheetah_f256_b256']
+    grp = LoopbackGroup(2)
+    agents = [bench.make_agent(alg, S, A, B, {**kw, 'loopback': (grp, r)}) for r in range(2)]
+    assert set(agents[0].core.fused_groups) == {0, 1, 2} and agents[0]._fused_all
+    del agents
+    grp.close()
