@@ -23,6 +23,7 @@ extern long long g_rl_launches;
 struct rlrep_comm {
     int rank = 0, world = 1;
     long long arena_floats = 0, scratch_floats = 0, red_floats = 0;
+    long long ticks_per_us = RL_DP_TICKS_PER_US;   // wall_clock64() rate of THIS device (hipDeviceAttributeWallClockRate; 100 MHz on gfx950)
     long long timeout_ticks = 120ll * 1000000ll * RL_DP_TICKS_PER_US;       // two minutes: a watchdog (rlrep_comm_set_timeout)
     char* local = nullptr;                         // my block
     char* peer[RL_DP_MAX_WORLD] = {nullptr};       // everyone's block as mapped here (peer[rank] = local)
@@ -175,6 +176,12 @@ int32_t rlrep_comm_create(int32_t rank, int32_t world, int64_t arena_floats, int
         (void)hipFree(c->local); delete c; rl_set_error("comm_create: cannot allocate the mapped error word"); return RLREP_ERR_NOMEM;
     }
     *c->err_host = 0;
+    {
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz >= 1000) c->ticks_per_us = khz / 1000;
+        else (void)hipGetLastError();
+        c->timeout_ticks = 120ll * 1000000ll * c->ticks_per_us;
+    }
     (void)hipMemset(c->local, 0, bytes);
     (void)hipDeviceSynchronize();
     c->peer[rank] = c->local;
@@ -233,7 +240,7 @@ int32_t rlrep_comm_connect_local(rlrep_comm* c, rlrep_comm* const* peers) {
 // bound of every device-side wait from now on (attachments made LATER carry it; rlrep_comm_allreduce takes its own).  Default: 120 s.
 int32_t rlrep_comm_set_timeout(rlrep_comm* c, int64_t timeout_us) {
     if (!c || timeout_us <= 0) { rl_set_error("comm_set_timeout: bad argument"); return RLREP_ERR_ARG; }
-    c->timeout_ticks = timeout_us * RL_DP_TICKS_PER_US;
+    c->timeout_ticks = timeout_us * c->ticks_per_us;
     return 0;
 }
 
@@ -246,7 +253,7 @@ int32_t rlrep_comm_allreduce(rlrep_comm* c, int64_t off, int64_t n, float* out_d
     if (!c || !out_dev || n <= 0 || off < 0 || off + n > c->arena_floats + c->scratch_floats) { rl_set_error("comm_allreduce: bad argument (off = %lld, n = %lld, block = %lld floats)", (long long)off, (long long)n, c ? c->arena_floats + c->scratch_floats : 0ll); return RLREP_ERR_ARG; }
     if (!c->connected) { rl_set_error("comm_allreduce before rlrep_comm_connect"); return RLREP_ERR_STATE; }
     DpPull d; rl_comm_fill_pull(c, &d);
-    if (timeout_us > 0) d.timeout = timeout_us * RL_DP_TICKS_PER_US;
+    if (timeout_us > 0) d.timeout = timeout_us * c->ticks_per_us;
     const int two = mode == 2 || (mode == 0 && n >= (1 << 17));
     const int rc = rl_launch_xchg_reduce(&d, 7, off, n, out_dev, two, 0, (hipStream_t)stream);
     ++g_rl_launches;
@@ -286,7 +293,7 @@ int32_t rlrep_comm_probe_slots(rlrep_comm* c, int64_t n, int32_t round, float* o
     if (!c->connected) { rl_set_error("comm_probe_slots before rlrep_comm_connect"); return RLREP_ERR_STATE; }
     DpSlots d; memset(&d, 0, sizeof(d));
     d.world = c->world; d.rank = c->rank; d.channel = 6; d.n = (int)n; d.err = c->err_dev;
-    d.timeout = timeout_us > 0 ? timeout_us * RL_DP_TICKS_PER_US : c->timeout_ticks;
+    d.timeout = timeout_us > 0 ? timeout_us * c->ticks_per_us : c->timeout_ticks;
     for (int q = 0; q < c->world; ++q) { d.slot[q] = reinterpret_cast<float*>(c->peer[q] + c->scratch_off); d.flags[q] = reinterpret_cast<DpFlags*>(c->peer[q] + c->flags_off); }
     const int nb = (int)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256);
     d.nblocks = nb;
