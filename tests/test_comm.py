@@ -1,7 +1,9 @@
-"""The data-parallel gradient exchange INSIDE the optimizer launches (rlrep_amd/csrc/comm.hip, dp_pull.h, rlrep_amd/comm.py).
-The reference is a single process: there is nothing to compare with but arithmetic -- the sum in RANK ORDER, which every rank must produce bit
-for bit -- and the same train() over torch.distributed (gloo), which must end in exactly the same state.  Several processes share the one GPU
-of the test box and map each other's gradient arena (a multi-GPU node only changes the wires: there the block is fine-grained memory)."""
+"""The data-parallel exchanges INSIDE the launches (rlrep_amd/csrc/comm.hip, dp_pull.h, rlrep_amd/comm.py): the gradient
+sums in the optimizer launches (one-shot pull, two-shot reduce-scatter + all-gather), spedersac's pushed Phibar / v, ctrlsac's pull gather /
+reduce-scatter.  The reference is a single process: there is nothing to compare with but arithmetic -- the sum in RANK ORDER, which every rank must
+produce bit for bit -- and the same train() over torch.distributed (gloo) summed in rank order, which must end in exactly the same state.
+Several processes share the one GPU of the test box and map each other's block over hipIpc (a multi-GPU node only changes the wires: there the
+block is fine-grained memory); tests/test_loopback.py runs the same device code with all ranks in one process."""
 import os
 import socket
 import sys
