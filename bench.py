@@ -515,6 +515,7 @@ def main():
                     help='N > 1 without --dp-form: the forms that are timed, each over the whole warm-up + --steps protocol with a replicas_identical '
                          'check; `value` is the fastest one whose replicas stayed identical, all are listed in `dp_forms`.  safe: fused + segments (bounded '
                          'waits / eager collectives); all: + the captured RCCL forms (rehearsed with one rank only: a hang there is RCCL\'s to time out)')
+    ap.add_argument('--no-extra-warmup', action='store_true', help='only the --warmup calls before the timed window (tests: a short run is a protocol check, not a measurement)')
     ap.add_argument('--quick', action='store_true', help='only the warm-up and the --steps window (no median repeats, no add / metric-fetch / main-loop legs): profiler runs')
     ap.add_argument('--pmc-json', default=None, help='PMC summary to take roofline.traffic from (default: the latest profiles/r*_pmc_<workload>.json)')
     args = ap.parse_args()
@@ -593,7 +594,7 @@ def main():
 
     # untimed: the W warm-up steps the caller asked for, and at least ~0.15 s of train() calls on top (graph instantiation, the two-stream
     # pipeline's probe, the clock ramp: with the driver's W = 5 the 20-step window otherwise sits 6 % below the steady state)
-    extra = max(0, (300 if alg in ('vlsac', 'sac', 'ctrlsac') and B <= 256 else 10) - args.warmup)
+    extra = 0 if args.no_extra_warmup else max(0, (300 if alg in ('vlsac', 'sac', 'ctrlsac') and B <= 256 else 10) - args.warmup)
 
     def build_and_time(form):
         """One agent in data-parallel form `form` (None: whatever the environment says), the driver's protocol: W (+ extra) untimed calls, then

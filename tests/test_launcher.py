@@ -62,3 +62,27 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     sb = b.core.state()
     for k in sa:
         assert torch.equal(a.core.state()[k], sb[k]), k
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_sweeps_the_data_parallel_forms():
+    """`bench.py --gpus 2` as the driver runs it (here over gloo, two processes sharing the one GPU: a protocol check, not a measurement): every
+    safe data-parallel form is built and timed over the same protocol -- `fused` = every exchange inside the launches, `segments` = graph segments
+    around torch.distributed collectives -- each with a replicas_identical check; `value` is the fastest identical one and `dp_forms` lists all."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RLREP_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('RLREP_ENABLE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '24', '--warmup', '6', '--no-extra-warmup', '--no-cpu', '--quick',
+                        '--workload', 'sac_pendulum_b64'], capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['replicas_identical'] is True and d['scaling'] == 'weak'
+    forms = {f['form']: f for f in d['dp_forms']}
+    assert set(forms) == {'fused', 'segments'}
+    assert forms['fused']['ran_as'] == 'fused' and forms['fused']['replicas_identical'] and forms['fused']['fused_groups']
+    assert forms['segments']['ran_as'] == 'segments' and forms['segments']['replicas_identical']
+    chosen = [f for f in d['dp_forms'] if f['chosen']]
+    assert len(chosen) == 1 and abs(chosen[0]['value'] - d['value']) < 1e-6 and chosen[0]['value'] == max(f['value'] for f in d['dp_forms'])
