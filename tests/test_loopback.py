@@ -159,13 +159,14 @@ def _make_loopback_agents(case_name, world, enable=None, graph=False):
     return c, grp, agents, bufs
 
 
-@pytest.mark.parametrize('case', ['sac_tiny', 'vlsac_tiny', 'spedersac_tiny', 'ctrlsac_tiny'])
-def test_loopback_three_ranks_two_shot_equals_one_shot_and_the_oracle(case):
-    """Three replicas in one process, eager step programs, injected draws: two-shot forced for every slice == one-shot, bit for bit (both are the
-    rank-ordered sum), replicas bit-identical, and equal (1e-4) to the CPU oracle on the concatenated global batch."""
+@pytest.mark.parametrize('case,world', [('sac_tiny', 3), ('vlsac_tiny', 3), ('spedersac_tiny', 3), ('ctrlsac_tiny', 3), ('spedersac_tiny', 4), ('ctrlsac_tiny', 4)])
+def test_loopback_ranks_two_shot_equals_one_shot_and_the_oracle(case, world):
+    """Three / four replicas in one process (four = BASELINE config 4's rank count), eager step programs, injected draws: two-shot forced for every
+    slice == one-shot, bit for bit (both are the rank-ordered sum), replicas bit-identical, and equal (1e-4) to the CPU oracle on the concatenated
+    global batch -- spedersac's Phibar / v and ctrlsac's in-batch negatives over ALL ranks' minibatches included."""
     from fixture_io import Case, rel_l2
     from test_dp import _inputs, _oracle_global
-    world, trains, states = 3, 2, {}
+    trains, states = 2, {}
     for form, enable in (('two_shot', 'dp_two_shot_kb=0.001'), ('one_shot', 'dp_two_shot_kb=0')):
         c, grp, agents, bufs = _make_loopback_agents(case, world, enable)
         assert all(a.core.fused_groups for a in agents) and all(a.core.feature_exchange_count() == 0 for a in agents)
