@@ -261,12 +261,12 @@ int32_t rlrep_comm_allreduce(rlrep_comm* c, int64_t off, int64_t n, float* out_d
     return 0;
 }
 
-// block[off + q * n .. + n) of every rank q gathered into every rank's block (all-gather by pull; one launch, capturable; channel 6)
+// block[off + q * n .. + n) of every rank q gathered into every rank's block (all-gather by pull; one launch, capturable; channel 7)
 int32_t rlrep_comm_allgather(rlrep_comm* c, int64_t off, int64_t n, void* stream) {
     if (!c || n <= 0 || off < 0 || (off & 3) || (n & 3) || off + n * c->world > c->arena_floats + c->scratch_floats) { rl_set_error("comm_allgather: bad argument"); return RLREP_ERR_ARG; }
     if (!c->connected) { rl_set_error("comm_allgather before rlrep_comm_connect"); return RLREP_ERR_STATE; }
     DpPull d; rl_comm_fill_pull(c, &d);
-    const int rc = rl_launch_xchg_gather(&d, 6, off, n, 0, (hipStream_t)stream);
+    const int rc = rl_launch_xchg_gather(&d, 7, off, n, 0, (hipStream_t)stream);      // (channel 7, like rlrep_comm_allreduce: the same READY / DONE protocol, one epoch sequence)
     ++g_rl_launches;
     if (rc != 0) { rl_set_error("comm_allgather: launch failed (%d)", rc); return RLREP_ERR_HIP; }
     return 0;

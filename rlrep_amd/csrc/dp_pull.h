@@ -55,7 +55,7 @@
 #include <stdint.h>
 
 #define RL_DP_MAX_WORLD 16
-#define RL_DP_CHANNELS 8                /* 0-3: the optimizer groups; 4, 5: the feature step's batch-coupled exchanges; 7: rlrep_comm_allreduce (probe / tests) */
+#define RL_DP_CHANNELS 8                /* 0-3: the optimizer groups; 4, 5: the feature step's batch-coupled exchanges; 6: rlrep_comm_probe_slots; 7: rlrep_comm_allreduce / _allgather (probe / tests) */
 #define RL_DP_TICKS_PER_US 100ll        /* wall_clock64(): the 100 MHz constant clock */
 static_assert(RL_DP_MAX_WORLD <= 32, "the late-rank mask is one 32-bit word (1u << rank)");
 
