@@ -327,7 +327,7 @@ _CONCURRENT = {}
 def concurrent_streams(n, tries=48):
     """`n` torch streams of the current device that really run side by side.  HIP maps streams onto a few hardware queues and two streams
     that share one are serialised; a launch that WAITS on the device for a launch queued behind it in the same queue never ends.  Found by
-    trial, not by timing: a two-rank exchange (one rank per stream, 20 ms bound) completes only if the two streams are concurrent.  The set
+    trial, not by timing: a two-rank exchange (one rank per stream, 100 ms bound) completes only if the two streams are concurrent.  The set
     is kept for the life of the process; raises if the runtime does not have `n` concurrent queues (this image: four per process)."""
     dev = torch.cuda.current_device()
     kept = _CONCURRENT.setdefault(dev, [])
@@ -338,14 +338,20 @@ def concurrent_streams(n, tries=48):
         def together(a, b):
             for first, second in ((a, b), (b, a)):
                 with torch.cuda.stream(first):
-                    grp[0].all_reduce(0, 4, mode=1, timeout_us=20000)
+                    grp[0].all_reduce(0, 4, mode=1, timeout_us=100000)
                 with torch.cuda.stream(second):
-                    grp[1].all_reduce(0, 4, mode=1, timeout_us=20000)
+                    grp[1].all_reduce(0, 4, mode=1, timeout_us=100000)
                 torch.cuda.synchronize()
                 bad = grp[0].status(raise_on_error=False, clear=True) | grp[1].status(raise_on_error=False, clear=True)
                 if bad:
                     return False
             return True
+        # (first launches load code: run the exchange once -- one rank after the other, its one-millisecond waits running out -- before anything is judged)
+        for r in (0, 1):
+            grp[r].all_reduce(0, 4, mode=1, timeout_us=1000)
+            torch.cuda.synchronize()
+        for r in (0, 1):
+            grp[r].status(raise_on_error=False, clear=True)
         if not kept:
             kept.append(torch.cuda.Stream())
         while len(kept) < n and tries > 0:
