@@ -330,7 +330,13 @@ int32_t rlrep_comm_status(rlrep_comm* c, uint32_t* mask, int32_t clear) {
     if (!c) { rl_set_error("null comm"); return RLREP_ERR_ARG; }
     const unsigned w = __atomic_load_n(c->err_host, __ATOMIC_ACQUIRE);
     if (mask) *mask = w;
-    if (w && clear) __atomic_store_n(c->err_host, 0u, __ATOMIC_RELEASE);
+    if (w && clear) {
+        __atomic_store_n(c->err_host, 0u, __ATOMIC_RELEASE);
+        // ... and the device-side poison word that made this rank's exchange launches skip (rare path: a blocking copy is fine here)
+        const unsigned zero = 0;
+        DpFlags* f = reinterpret_cast<DpFlags*>(c->local + c->flags_off);
+        (void)hipMemcpy(&f->poison, &zero, sizeof(zero), hipMemcpyHostToDevice);
+    }
     if (w) { rl_set_error("data-parallel exchange: a peer did not arrive in time (late-rank mask 0x%x): the affected step was skipped on this rank, the replicas are no longer in step", w); return RLREP_ERR_STATE; }
     return 0;
 }

@@ -36,8 +36,9 @@
 //   * ctrlsac's two exchanges are stand-alone launches of comm.hip (push gather / pull reduce-scatter), one each per feature step, capturable.
 //
 // A wait that does not complete within `timeout` ticks of the 100 MHz wall clock (default two minutes: a watchdog, not a schedule -- a peer
-// that evaluates, checkpoints or re-captures a graph simply delays the step, as under RCCL) sets the rank's bit in the error word; an
-// optimizer launch that saw a timeout SKIPS its update (nothing is applied from a partial sum), the launch always drains, and
+// that evaluates, checkpoints or re-captures a graph simply delays the step, as under RCCL) sets the rank's bit in the error word AND the
+// rank's local `poison` word; the launch that saw it, and EVERY later exchange launch of that rank until the host has read and cleared the
+// error (rlrep_comm_status), skips its work -- nothing is ever applied from a partial or stale sum -- all launches drain, and
 // rlrep_comm_status / the agent's flush() raise.  Deadlock freedom on ONE channel: READY(e) is sent before anything is waited for; RED(e)
 // needs only the peers' READY(e); DONE(e) is sent after a rank's own reads, which need only the peers' READY(e) / RED(e).
 //
@@ -67,7 +68,9 @@ struct DpFlags {
     unsigned epoch[RL_DP_CHANNELS];                        // local: last epoch completed on this rank
     unsigned ticket[RL_DP_CHANNELS];                       // local: blocks of the running launch that have finished
     unsigned ticket2[RL_DP_CHANNELS];                      // local: phase-A blocks of the running two-shot launch that have stored their sums
-    unsigned pad_[40];
+    unsigned poison;                                       // local: a wait of THIS rank has run out since the host last cleared the error word: every later exchange
+                                                           // launch of this rank skips its work (a replica that is out of step applies nothing more until the host has seen it)
+    unsigned pad_[39];
 };
 
 struct DpPull {
@@ -134,10 +137,11 @@ __device__ __forceinline__ void dp_drain() { __builtin_amdgcn_s_waitcnt(0x0F70);
 __device__ __forceinline__ void dp_signal(unsigned* word, unsigned e) { __hip_atomic_store(word, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // the first wave of a block waits until word[q] of every peer q has reached epoch e; returns false (and reports the late ranks) on a timeout
-__device__ __forceinline__ bool dp_wait_all(const unsigned* words, int world, int rank, unsigned e, long long timeout, unsigned* err) {
+__device__ __forceinline__ bool dp_wait_all(const unsigned* words, int world, int rank, unsigned e, long long timeout, unsigned* err, unsigned* poison) {
     const int q = threadIdx.x & 63;
     const bool peer = q < world && q != rank;
     bool ok = !peer;
+    const unsigned poisoned = *poison;                 // (a plain load, issued in front of the poll: set by an EARLIER launch's timeout; costs no round trip of its own)
     const long long t0 = wall_clock64();
     while (true) {
         if (!ok) ok = dp_reached(__hip_atomic_load(words + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), e);
@@ -145,9 +149,12 @@ __device__ __forceinline__ bool dp_wait_all(const unsigned* words, int world, in
         if (wall_clock64() - t0 > timeout) break;
         __builtin_amdgcn_s_sleep(4);
     }
-    if (!ok) atomicOr(err, 1u << q);                                    // never hang the GPU: report, skip, drain
+    if (!ok) {                                                          // never hang the GPU: report, skip, drain
+        atomicOr(err, 1u << q);
+        __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("" ::: "memory");                                     // (the reads that follow are issued behind the poll that saw the word; they bypass the caches)
-    return __all(ok);
+    return __all(ok) && poisoned == 0u;
 }
 
 // Called by EVERY thread of a participating block (256 threads, or one wave: `bar` = the block has more than one wave).  `signaller`: the
@@ -161,7 +168,7 @@ __device__ __forceinline__ unsigned dp_begin(const DpPull& d, bool signaller, bo
     if (threadIdx.x < 64) {
         const int q = threadIdx.x;
         if (signaller && q < d.world && q != d.rank) dp_signal(&d.flags[q]->ready[d.channel][d.rank], e);      // (the data were written by earlier kernels)
-        const bool ok = dp_wait_all(mine->ready[d.channel], d.world, d.rank, e, d.timeout, d.err);
+        const bool ok = dp_wait_all(mine->ready[d.channel], d.world, d.rank, e, d.timeout, d.err, &mine->poison);
         if (threadIdx.x == 0) dp_good_s = ok ? 1 : 0;
         if (!bar) *good = ok;
     }
@@ -180,7 +187,7 @@ __device__ __forceinline__ void dp_end(const DpPull& d, unsigned e, bool bar) {
     const int q = threadIdx.x;
     if (!d.no_done) {
         if (q < d.world && q != d.rank) dp_signal(&d.flags[q]->done[d.channel][d.rank], e);       // (this rank's reads were consumed before its blocks took their tickets)
-        (void)dp_wait_all(mine->done[d.channel], d.world, d.rank, e, d.timeout, d.err);
+        (void)dp_wait_all(mine->done[d.channel], d.world, d.rank, e, d.timeout, d.err, &mine->poison);
     }
     if (q == 0) {
         __hip_atomic_store(&mine->ticket[d.channel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -246,7 +253,7 @@ __device__ __forceinline__ bool dp_reduce_scatter(const DpPull& d, unsigned e, i
     }
     if (threadIdx.x < 64) {
         // every rank's word, the own one included: rank -1 = "nobody is exempt"
-        const bool ok = dp_wait_all(mine->red[d.channel], d.world, -1, e, d.timeout, d.err);
+        const bool ok = dp_wait_all(mine->red[d.channel], d.world, -1, e, d.timeout, d.err, &mine->poison);
         if (threadIdx.x == 0) dp_rs_s = ok ? 1 : 0;
     }
     __syncthreads();
@@ -288,13 +295,19 @@ __device__ __forceinline__ void dp_slots_publish(const DpSlots& d, unsigned e) {
 __device__ __forceinline__ void dp_slots_sum(const DpSlots& d, float* dst) {
     DpFlags* const mine = d.flags[d.rank];
     const unsigned e = mine->epoch[d.channel];            // (written by the producer launch: an earlier kernel of this stream)
-    if (threadIdx.x < 64) (void)dp_wait_all(mine->ready[d.channel], d.world, -1, e, d.timeout, d.err);
+    __shared__ int dp_ss_s;
+    if (threadIdx.x < 64) {
+        const bool ok = dp_wait_all(mine->ready[d.channel], d.world, -1, e, d.timeout, d.err, &mine->poison);
+        if (threadIdx.x == 0) dp_ss_s = ok ? 1 : 0;
+    }
     __syncthreads();
-    const float* sl = d.slot[d.rank] + (size_t)(e & 1u) * d.world * d.n;
-    for (int f = threadIdx.x; f < d.n; f += blockDim.x) {
-        float s = dp_load1(sl + f);
-        for (int q = 1; q < d.world; ++q) s += dp_load1(sl + (size_t)q * d.n + f);
-        dst[f] = s;
+    if (dp_ss_s) {                                         // (a timed-out or poisoned rank leaves the vector as it is: the optimizer launches behind it skip too)
+        const float* sl = d.slot[d.rank] + (size_t)(e & 1u) * d.world * d.n;
+        for (int f = threadIdx.x; f < d.n; f += blockDim.x) {
+            float s = dp_load1(sl + f);
+            for (int q = 1; q < d.world; ++q) s += dp_load1(sl + (size_t)q * d.n + f);
+            dst[f] = s;
+        }
     }
     __syncthreads();
 }

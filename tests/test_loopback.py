@@ -130,10 +130,20 @@ def test_loopback_late_rank_times_out_skips_and_reports():
     torch.cuda.synchronize()
     assert time.time() - t0 < 20.0
     assert ex.status(raise_on_error=False) == 0b10
+    assert torch.all(out == -7.0), 'a launch that saw a timeout must not write a partial sum'
+    # ... and the rank stays poisoned until the host has seen the error: the next launch finds its peer "arrived" and still writes nothing
+    from rlrep_amd._lib import lib, check
+    check(lib.rlrep_comm_debug_preset(ex.h, 7, 1), 'debug_preset')
+    ex.all_reduce(0, 1024, out=out, timeout_us=300_000)
+    torch.cuda.synchronize()
+    assert torch.all(out == -7.0), 'a rank that is out of step applies nothing more until the host has cleared the error'
     with pytest.raises(RuntimeError, match='did not arrive'):
         ex.status(clear=True)
     assert ex.status() == 0
-    assert torch.all(out == -7.0), 'a launch that saw a timeout must not write a partial sum'
+    check(lib.rlrep_comm_debug_preset(ex.h, 7, 1), 'debug_preset')
+    ex.all_reduce(0, 1024, out=out, timeout_us=300_000)
+    torch.cuda.synchronize()
+    assert ex.status() == 0 and torch.all(out == 1.0), 'cleared: the exchange works again (the absent peer\'s arena holds zeros)'
     grp.close()
 
 
