@@ -251,7 +251,9 @@ class HipCore:
         """Raise if a wait of the in-launch gradient exchange has run out since the last check (a peer that never arrived: the affected
         step is invalid).  A read of mapped host memory: no device synchronisation, cheap enough for every flush()."""
         if self.exchange is not None:
-            self.exchange.status(raise_on_error=True, clear=True)
+            # NOT cleared: the error is sticky and the rank stays poisoned on the device (its exchange launches apply nothing) until the caller has
+            # re-synchronised the replicas and calls core.exchange.status(clear=True) itself -- catching this exception must not resume training
+            self.exchange.status(raise_on_error=True, clear=False)
 
     def chain_check(self):
         """Raise if a persistent chain launch (csrc/xchain.hip) failed its device-side checks since the agent was created: a wait that
