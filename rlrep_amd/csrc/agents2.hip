@@ -249,15 +249,25 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         // rhat = theta . phi + b (a [B, 1] product) is computed by the InfoNCE launch itself: beside a score matrix that routes to the LDS-tiled engine it was a
         // 16-row-engine launch of its own on the dependent chain (8 us per feature step at F = 2048); RLREP_DISABLE=fold_theta keeps it
         const bool theta_in_loss = !rl_off("fold_theta");
-        if (theta_in_loss) b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE)}, "score matrix");
+        // K12: for the small products (BASELINE config 3: F = 256, 256 columns) the score matrix is computed BY the InfoNCE launch, 16 whole rows per
+        // workgroup (replearn.hip score_infonce_kernel): one dependent launch less per feature step, S never in memory.  RLREP_DISABLE=fuse_infonce: the pair.
+        // (At most 256 columns: four column tiles per wave in static registers -- the data-parallel forms, whose matrix is [B, W B], keep the pair.)
+        // OPT-IN (RLREP_ENABLE=fuse_infonce): measured SLOWER -- 3 546 against 4 150 train()/s at config 3: the 64 waves of 16 workgroups run the 256 MFMAs
+        // per wave that 1 024 waves of the GEMM launch share, ~21 us against 11 for the pair (docs/history/r06.md).  The arithmetic K12 was declined with, confirmed.
+        const bool fuse_score = theta_in_loss && (F & 63) == 0 && F <= 512 && WB <= 256 && rl_opt("fuse_infonce") != nullptr;
+        const int nblk_loss = fuse_score ? (B + 15) / 16 : nblk_f;
+        if (fuse_score) { /* no score-matrix stage */ }
+        else if (theta_in_loss) b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE)}, "score matrix");
         else
         b.fwd_stage(p, {Builder::fwd(pf.Z, F, B, F, ZMall, F, nullptr, WB, Sx, WB, ACT_NONE),
                         Builder::fwd(pf.Z, F, B, F, Pw("theta.l.weight"), F, Pw("theta.l.bias"), 1, RH, 1, ACT_NONE)}, "score matrix + theta");
         InfoNce nc; memset(&nc, 0, sizeof(nc));
         if (theta_in_loss) { nc.Z = pf.Z; nc.ldZ = F; nc.F = F; nc.theta_w = Pw("theta.l.weight"); nc.theta_b = Pw("theta.l.bias"); }
-        nc.S = Sx; nc.ldS = WB; nc.ncols = WB; nc.diag_off = rank * B; nc.rhat = RH; nc.r = s0.R; nc.drhat = DRH; nc.partial = part_f; nc.B = B; nc.nblk = nblk_f;
+        nc.S = Sx; nc.ldS = WB; nc.ncols = WB; nc.diag_off = rank * B; nc.rhat = RH; nc.r = s0.R; nc.drhat = DRH; nc.partial = part_f; nc.B = B; nc.nblk = nblk_loss;
         nc.inv_batch = ag->inv_batch(); nc.step = ag->adam_step + 0;
-        p.stages.push_back({[=](hipStream_t st) { return rl_launch_infonce(&nc, st); }, "infonce"});
+        if (fuse_score) { nc.ZM = ZMall; nc.ldZM = F; }
+        p.stages.push_back({[=](hipStream_t st) { return rl_launch_infonce(&nc, st); }, fuse_score ? "score matrix + infonce" : "infonce"});
+        if (fuse_score) Builder::tag(p, RLREP_ENGINE_GEMM16, 2.0 * (double)B * (double)WB * (double)F, 4.0 * ((double)B * F + (double)WB * F + (double)B * WB));
         {
             GemmTask t = Builder::dx(Sx, WB, B, WB, ZMall, F, pf.GZ, F, F, ACT_NONE, nullptr, 0);
             t.r1u = DRH; t.r1v = Pw("theta.l.weight");
@@ -296,8 +306,8 @@ void build_ctrlsac(Builder& b, rlrep_agent* ag) {
         // use_feature_target=False (ctrlsac_agent.py:340-346): no Polyak into phi_target, frozen_phi_target is not written
         const bool nft = (ag->d.flags & RLREP_FLAG_NO_FEATURE_TARGET) != 0;
         b.adam(ag->feat_apply, 0, ag->h.lr_feature, nft ? nullptr : Tw("phi_target.l1.weight"), p0.off, pl.off + pl.rows - p0.off, ag->h.feature_tau,
-               {Builder::fin_sum(part_f + 0, nblk_f, 2, 1.0f / (float)B, m + M_FEAT_A),
-                Builder::fin_sum(part_f + 1, nblk_f, 2, 0.5f / (float)B, m + M_R_LOSS),
+               {Builder::fin_sum(part_f + 0, nblk_loss, 2, 1.0f / (float)B, m + M_FEAT_A),
+                Builder::fin_sum(part_f + 1, nblk_loss, 2, 0.5f / (float)B, m + M_R_LOSS),
                 Builder::fin_combine(m + M_FEAT_A, 1.f, m + M_R_LOSS, 1.f, m + M_FEAT_TOTAL)}, "adam feature + polyak phi");
         // ctrlsac_agent.py:344-346: frozen_phi, frozen_phi_target <- phi (quirk Q8)
         const long long pn = pl.off + pl.rows - p0.off;

@@ -233,6 +233,9 @@ struct InfoNce {
     // Z != nullptr: rhat_i = theta . Z_i + theta_b[0] is computed here, by the wave that owns row i (a 2048-long dot product per row), instead of
     // arriving in `rhat` from a 16-row-engine launch of its own beside the score matrix
     const float* Z; int ldZ, F; const float* theta_w; const float* theta_b;
+    // ZM != nullptr (score_infonce_kernel, K12): the score matrix S = Z ZM^T is computed HERE as well -- ZM [ncols, F] = mu(s') of every rank's
+    // minibatch -- by the workgroup that owns 16 whole rows of it; `nblk` = ceil(B / 16) then
+    const float* ZM; int ldZM;
 };
 // second set (X2 != nullptr; blockIdx.y == 1): another weighted column sum in the same launch, plus the sum of its weights (outb2) -- spedersac's
 // theta.l weight / bias gradient (sum_i drhat_i phi_i, sum_i drhat_i) rides with v = sum_k c_k mu_r,k instead of a launch of its own

@@ -51,6 +51,153 @@ __global__ __launch_bounds__(256) void infonce_kernel(InfoNce p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K12 (agent/ctrlsac/ctrlsac_agent.py:226-233): the score matrix AND its InfoNCE loss / gradient in ONE launch, for the small
+// products (BASELINE config 3: 256 x 256 scores of 256-wide features).  A workgroup owns 16 WHOLE rows of S = Z ZM^T (so the row-wise log-sum-exp
+// needs nobody else): its four waves take the 16-column tiles w, w + 4, ... (v_mfma_f32_16x16x4_f32; operand maps as gemm16_tile.h: a lane takes four
+// consecutive inner indices per 16-deep step), the row maximum and the sum of exponentials meet across the waves in LDS in fixed order, and dS =
+// (softmax(S) - I) / B goes out from the accumulators -- S itself never exists in memory.  rhat = theta . Z_i + b rides on the A fragments.
+// 16 workgroups for B = 256: fine for a 33-MFLOP product on a chain whose cost is its launch count (one dependent launch less per feature step);
+// the builder keeps the GEMM + infonce_kernel pair for F > 512 or more than 1 024 columns.
+// ------------------------------------------------------------------------------------------------
+#define SI_MAX_TILES 4                 /* column tiles per wave: ncols <= 4 * 4 * 16 = 256 */
+#define SI_DEPTH 4                     /* 16-deep steps whose operands are in flight (F % 64 == 0) */
+typedef float si_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void score_infonce_kernel(InfoNce p) {
+    __shared__ float smax[4][16], ssum[4][16], sdiag[16], srow[2][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;                      // operand row / column of the lane, its group of four inner indices
+    const int i0 = blockIdx.x * 16;
+    const int NC = p.ncols, ntiles = (NC + 15) >> 4;
+    const int nt = (ntiles - w + 3) >> 2;                          // tiles w, w + 4, ... of this wave
+    const float* __restrict__ za = p.Z + (size_t)min(i0 + li, p.B - 1) * p.ldZ + 4 * lg;
+    const float* __restrict__ th = p.theta_w + 4 * lg;
+    const float* zb[SI_MAX_TILES];
+#pragma unroll
+    for (int t = 0; t < SI_MAX_TILES; ++t) zb[t] = p.ZM + (size_t)min(16 * (w + 4 * t) + li, NC - 1) * p.ldZM + 4 * lg;
+    si_f32x4 acc[SI_MAX_TILES];
+#pragma unroll
+    for (int t = 0; t < SI_MAX_TILES; ++t) acc[t] = (si_f32x4){0.f, 0.f, 0.f, 0.f};
+    float rh = 0.f;
+    if (w == 0 && lane < 16) sdiag[lane] = 0.f;
+    // operands SI_DEPTH steps ahead in SI_DEPTH static register sets (an L2 round trip is ~1 us, the 16 MFMAs of a step 0.2 us: fetched at its own step, every
+    // step waited for its loads -- 40 us per launch where the GEMM + loss pair takes 11)
+    si_f32x4 ra[SI_DEPTH], rt[SI_DEPTH], rb[SI_DEPTH][SI_MAX_TILES];
+    const int Fm = p.F - 16;
+#define SI_LOAD(D, K)                                                                                     \
+    {                                                                                                     \
+        const int kk_ = min((K), Fm);                                                                     \
+        ra[D] = *reinterpret_cast<const si_f32x4*>(za + kk_);                                             \
+        rt[D] = *reinterpret_cast<const si_f32x4*>(th + kk_);                                             \
+        _Pragma("unroll") for (int t = 0; t < SI_MAX_TILES; ++t) rb[D][t] = *reinterpret_cast<const si_f32x4*>(zb[t] + kk_); \
+    }
+#pragma unroll
+    for (int d = 0; d < SI_DEPTH; ++d) SI_LOAD(d, 16 * d)
+    for (int k0 = 0; k0 < p.F; k0 += 16 * SI_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SI_DEPTH; ++d) {
+            const si_f32x4 a = ra[d], tv = rt[d];
+            si_f32x4 bb[SI_MAX_TILES];
+#pragma unroll
+            for (int t = 0; t < SI_MAX_TILES; ++t) bb[t] = rb[d][t];
+            SI_LOAD(d, k0 + 16 * (d + SI_DEPTH))
+            rh = fmaf(a[0], tv[0], fmaf(a[1], tv[1], fmaf(a[2], tv[2], fmaf(a[3], tv[3], rh))));          // rhat: theta . Z_i over this lane's four inner indices
+#pragma unroll
+            for (int t = 0; t < SI_MAX_TILES; ++t) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], bb[t][s4], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#undef SI_LOAD
+    // C map: acc[t][q] = S[i0 + 4 lg + q][16 (w + 4 t) + li]
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < SI_MAX_TILES; ++t) {
+        if (t < nt && 16 * (w + 4 * t) + li < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mx[q] = fmaxf(mx[q], acc[t][q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o, 64));          // over the 16 lanes that share the rows
+        if (li == 0) smax[w][4 * lg + q] = mx[q];
+    }
+    __syncthreads();
+    float se[4], sii[4] = {0.f, 0.f, 0.f, 0.f};
+    bool has[4] = {false, false, false, false};                    // this lane holds S_ii of row 4 lg + q (exactly one lane of the workgroup does)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * lg + q;
+        mx[q] = fmaxf(fmaxf(smax[0][r], smax[1][r]), fmaxf(smax[2][r], smax[3][r]));
+        se[q] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < SI_MAX_TILES; ++t) {
+        const int col = 16 * (w + 4 * t) + li;
+        if (t < nt && col < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                se[q] += expf(acc[t][q] - mx[q]);
+                if (col == p.diag_off + i0 + 4 * lg + q) { sii[q] = acc[t][q]; has[q] = true; }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se[q] += __shfl_xor(se[q], o, 64);
+        if (li == 0) ssum[w][4 * lg + q] = se[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (has[q]) sdiag[4 * lg + q] = sii[q];          // (the one lane of the workgroup that holds S_ii of the row files it)
+    float lse[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * lg + q;
+        lse[q] = mx[q] + logf(((ssum[0][r] + ssum[1][r]) + ssum[2][r]) + ssum[3][r]);
+    }
+    // dS out of the accumulators: (softmax - I) / B
+#pragma unroll
+    for (int t = 0; t < SI_MAX_TILES; ++t) {
+        const int col = 16 * (w + 4 * t) + li;
+        if (t < nt && col < NC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 4 * lg + q;
+                if (i < p.B) p.S[(size_t)i * p.ldS + col] = (expf(acc[t][q] - lse[q]) - (col == p.diag_off + i ? 1.f : 0.f)) * p.inv_batch;
+            }
+        }
+    }
+    __syncthreads();
+    // per-row terms, rows of this workgroup: wave 0 holds rhat (four inner groups to add), every lane group lg holds lse of rows 4 lg + q
+    if (w == 0) {
+        rh += __shfl_xor(rh, 16, 64);
+        rh += __shfl_xor(rh, 32, 64);                               // lanes li, li + 16, li + 32, li + 48 all hold row li's dot product now
+        if (li == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) srow[0][4 * lg + q] = lse[q] - sdiag[4 * lg + q];
+        }
+        if (lane < 16) {
+            const int i = i0 + lane;
+            const float dr = (rh + p.theta_b[0]) - p.r[min(i, p.B - 1)];
+            srow[1][lane] = i < p.B ? dr * dr : 0.f;
+            if (i < p.B) p.drhat[i] = dr * p.inv_batch;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float am = 0.f, ar = 0.f;
+        for (int r = 0; r < 16; ++r) { if (i0 + r < p.B) am += srow[0][r]; ar += srow[1][r]; }
+        p.partial[2 * blockIdx.x] = am;
+        p.partial[2 * blockIdx.x + 1] = ar;
+        if (blockIdx.x == 0 && p.step) bump_group(p.step);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weighted column sum: out[f] = sum_k w[k] * X[k, f]   (w == nullptr: plain column sum); fixed order
 // ------------------------------------------------------------------------------------------------
 // 16 columns per workgroup, 64 row groups (16 waves x 4 row sub-groups): a [1024, 512] operand is spread over 32
@@ -489,6 +636,12 @@ extern "C" int rl_launch_reg_stats(const RegStats* p, hipStream_t st) {
 static inline int rows_blocks(int B) { int g = (B + 3) / 4; return g > 128 ? 128 : g; }
 
 extern "C" int rl_launch_infonce(const InfoNce* p, hipStream_t st) {
+    if (p->ZM) {          // score matrix + loss + gradient in one launch (score_infonce_kernel): 16 whole rows per workgroup
+        if (!p->Z || (p->F & 63) || (p->ldZ & 3) || (p->ldZM & 3) || ((((uintptr_t)p->Z) | ((uintptr_t)p->ZM) | ((uintptr_t)p->theta_w)) & 15) || p->ncols > 64 * SI_MAX_TILES ||
+            p->nblk != (p->B + 15) / 16) return -7;
+        hipLaunchKernelGGL(score_infonce_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(infonce_kernel, dim3(p->nblk), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }

@@ -243,3 +243,33 @@ def test_adaptive_choice_of_the_train_form_changes_nothing(name):
     took_sequential = forms[0]
     assert not any(took_sequential[:6]) and all(took_sequential[8:12]), took_sequential          # switches after three looked-at calls ...
     assert not any(took_sequential[14:20]) and all(took_sequential[24:]), took_sequential       # ... and back after two back-to-back ones
+
+
+def test_score_matrix_inside_the_infonce_launch_matches_the_pair(monkeypatch):
+    """K12 as specified (replearn.hip score_infonce_kernel, RLREP_ENABLE=fuse_infonce; opt-in: measured slower): the score matrix computed by the
+    InfoNCE launch itself, 16 whole rows per workgroup, S never in memory -- against the default GEMM + infonce_kernel pair at BASELINE config 3's
+    dimensions: same parameters after three train() calls to fp32 rounding (different summation order of the row sums), one launch less per feature step."""
+    import numpy as np
+    import torch
+    from fixture_io import Case, rel_l2
+    from test_default_mode import _default_agent, _buffer
+    from rlrep_amd import _lib
+    c = Case('ctrlsac_hc256')
+    st, counts = [], []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv('RLREP_ENABLE', 'fuse_infonce')
+        agent, buf = _default_agent(c, graph=False), _buffer(c)
+        n0 = _lib.lib.rlrep_launch_counter()
+        for _ in range(3):
+            agent.train(buf, c.B)
+        agent.flush()
+        torch.cuda.synchronize()
+        counts.append(_lib.lib.rlrep_launch_counter() - n0)
+        st.append({k: v.numpy().copy() for k, v in agent.core.state().items()})
+        del agent
+    nf = c.kw['extra_feature_steps'] + 1
+    assert counts[1] == counts[0] - 3 * nf, counts
+    for k in st[0]:
+        if not k.endswith('noise'):
+            assert rel_l2(st[1][k], st[0][k]) < 1e-5, k

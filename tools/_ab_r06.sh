@@ -1,6 +1,7 @@
 # The alternated A/B runs docs/history/r06.md quotes (run on the GPU box: gpurun -- 'bash tools/_ab_r06.sh [part]'); one box per part.
 #   head  : vlsac headline: default / RLREP_DISABLE=dw_xcd / RLREP_ENABLE=nc_u_nt
 #   split : workloads with split-K stages: default / RLREP_ENABLE=fin_inline / RLREP_DISABLE=x3q
+#   k12   : ctrlsac config 3: default / RLREP_ENABLE=fuse_infonce (the score matrix inside the InfoNCE launch)
 #   micro : the 32 x 32 bf16x3 tile against the 64-wide tile + finisher through rlrep_gemm
 #   dp    : tools/exp/dp_loopback.py: protocol-only cost and two replicas on one chip (-> gpurun_out/r06_dp_loopback.txt)
 #   soak  : long attached runs, replicas_identical
@@ -19,6 +20,12 @@ if [ $PART = split ] || [ $PART = all ]; then
     env $arm python3 bench.py --workload $w --steps 400 --warmup 60 --no-cpu --quick --no-profile > gpurun_out/ab_tmp.log 2>&1 || exit 1
     echo "$w arm[$arm] $(line)"
   done; done; done
+fi
+if [ $PART = k12 ] || [ $PART = all ]; then
+  for rep in 1 2 3; do for arm in "" "RLREP_ENABLE=fuse_infonce"; do
+    env $arm python3 bench.py --workload ctrlsac_halfcheetah_f256_b256 --steps 2000 --warmup 300 --no-cpu --quick --no-profile > gpurun_out/ab_tmp.log 2>&1 || exit 1
+    echo "ctrlsac F=256 arm[$arm] $(line)"
+  done; done
 fi
 if [ $PART = micro ] || [ $PART = all ]; then
   python3 - <<'PY'
